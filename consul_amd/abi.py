@@ -1,0 +1,143 @@
+"""ctypes mirror of include/swimsim.h (the C-ABI of the SWIM hot-path simulator).
+
+Pure declarations: struct layouts, constants and function prototypes.  Nothing here decides
+WHICH shared library is loaded — `consul_amd.lib` loads the HIP product library, and the test
+suite binds the same prototypes onto the CPU oracle to check it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+ABI_VERSION = 1
+NONE = 0xFFFFFFFF
+
+OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE = 0, -22, -12, -19, -34, -75, -71
+ERRNAMES = {EINVAL: "SWIM_EINVAL", ENOMEM: "SWIM_ENOMEM", ENODEV: "SWIM_ENODEV",
+            ERANGE: "SWIM_ERANGE", EOVERFLOW: "SWIM_EOVERFLOW", ESTATE: "SWIM_ESTATE"}
+
+STATE_ALIVE, STATE_SUSPECT, STATE_DEAD, STATE_LEFT = 0, 1, 2, 3
+MSG_ALIVE, MSG_SUSPECT, MSG_DEAD, MSG_USER = 0, 1, 2, 3
+MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2, 3, 4
+(EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
+ EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
+PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS = 0x1, 0x2, 0x4
+F_DEFAULT = F_BUDDY_SUSPECT | F_NACK
+
+u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
+
+
+class Config(C.Structure):
+    _fields_ = [(n, u32) for n in (
+        "abi_version", "n_nodes", "n_replicas",
+        "gossip_nodes", "gossip_interval_ms", "probe_interval_ms", "probe_timeout_ms",
+        "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
+        "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size")] + [
+        ("msg_len", u32 * 4)] + [(n, u32) for n in (
+        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap",
+        "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
+        "shard_rank", "n_shards", "device")] + [("seed", u64)]
+
+
+class Derived(C.Structure):
+    _fields_ = [(n, u32) for n in (
+        "quantum_ms", "gossip_period", "probe_period", "probe_timeout_ticks", "phase_chunk",
+        "retransmit_limit", "suspicion_k", "suspicion_min_ms", "suspicion_max_ms")] + [
+        ("suspicion_timeout_ms", u32 * 8), ("node_scale_milli", u32),
+        ("push_pull_scale", u32), ("packet_budget", u32)]
+
+
+class Member(C.Structure):
+    _fields_ = [("id", u32), ("incarnation", u32), ("state_change_ms", u32),
+                ("state", u8), ("status", u8), ("n_confirm", u8), ("_pad", u8)]
+
+
+class Event(C.Structure):
+    _fields_ = [(n, u32) for n in ("time_ms", "replica", "type", "node", "ltime", "incarnation")]
+
+
+class Rumour(C.Structure):
+    _fields_ = [("subject", u32), ("incarnation", u32), ("from_", u32),
+                ("type", u8), ("transmits", u8), ("_pad", u8 * 2), ("seq", u32)]
+
+
+class NodeInfo(C.Structure):
+    _fields_ = [(n, u32) for n in (
+        "incarnation", "probe_target", "probe_deadline_tick", "probe_cursor", "probe_epoch",
+        "queue_len", "event_queue_len", "event_clock")] + [
+        ("alive", u8), ("leaving", u8), ("awareness", u8), ("partition", u8),
+        ("queue", Rumour * 32)]
+
+
+class Census(C.Structure):
+    _fields_ = [("n_observers", u32), ("by_state", u32 * 4), ("n_current", u32),
+                ("first_suspect_ms", u32), ("first_dead_ms", u32), ("all_dead_ms", u32),
+                ("all_current_ms", u32)]
+
+
+class Edge(C.Structure):
+    _fields_ = [("dst", u32), ("subject", u32), ("incarnation", u32), ("meta", u32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ticks", u64), ("gossip_rounds", u64), ("node_rounds_active", u64),
+                ("node_rounds_quiescent", u64), ("packets_sent", u64), ("packets_dropped", u64),
+                ("msgs_sent", u64 * 4), ("msgs_applied", u64 * 4), ("probes", u64),
+                ("probe_acks", u64), ("probe_indirect_acks", u64), ("probe_failures", u64),
+                ("nacks_missed", u64), ("refutes", u64), ("suspicion_timeouts", u64),
+                ("confirmations", u64), ("edges", u64), ("edges_remote", u64),
+                ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
+                ("event_drops", u64), ("user_events_delivered", u64),
+                ("user_events_deduped", u64), ("user_events_stale", u64)]
+
+
+P = C.POINTER
+SimP = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/swimsim.h declares
+PROTOTYPES = {
+    "swim_config_preset": (C.c_int, [P(Config), C.c_int]),
+    "swim_config_derive": (C.c_int, [P(Config), P(Derived)]),
+    "swim_create": (C.c_int, [P(Config), P(SimP)]),
+    "swim_destroy": (C.c_int, [SimP]),
+    "swim_backend": (C.c_char_p, []),
+    "swim_last_error": (C.c_char_p, [SimP]),
+    "swim_step": (C.c_int, [SimP, u32]),
+    "swim_sync": (C.c_int, [SimP]),
+    "swim_now": (C.c_int, [SimP, P(u32), P(u32)]),
+    "swim_tick_begin": (C.c_int, [SimP]),
+    "swim_outbound": (C.c_int, [SimP, u32, P(C.c_void_p), P(u32)]),
+    "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
+    "swim_tick_end": (C.c_int, [SimP]),
+    "swim_inject_kill": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_inject_update": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
+    "swim_set_loss": (C.c_int, [SimP, u32]),
+    "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
+    "swim_members": (C.c_int, [SimP, u32, u32, P(Member), C.c_size_t, P(C.c_size_t)]),
+    "swim_view": (C.c_int, [SimP, u32, u32, u32, P(Member)]),
+    "swim_poll_events": (C.c_int, [SimP, P(Event), C.c_size_t, P(C.c_size_t)]),
+    "swim_node_info_get": (C.c_int, [SimP, u32, u32, P(NodeInfo)]),
+    "swim_census_get": (C.c_int, [SimP, u32, u32, P(Census)]),
+    "swim_trace_read": (C.c_int, [SimP, u32, u32, u32, u32, P(u32)]),
+    "swim_stats": (C.c_int, [SimP, P(Stats)]),
+    "swim_debug_edges": (C.c_int, [SimP, P(Edge), C.c_size_t, P(C.c_size_t)]),
+    "swim_state_digest": (C.c_int, [SimP, P(u64)]),
+    "swim_transport_write_to": (C.c_int, [SimP, u32, u32, u32, P(Edge), C.c_size_t]),
+    "swim_transport_poll": (C.c_int, [SimP, u32, u32, P(Edge), C.c_size_t, P(C.c_size_t)]),
+    "swim_kat_philox4x32": (None, [P(u32), P(u32), P(u32)]),
+    "swim_kat_probe_perm": (u32, [u64, u32, u32, u32, u32]),
+    "swim_kat_remaining_suspicion_ms": (i32, [u32, u32, u32, u32, u32]),
+    "swim_kat_phase_of": (None, [P(Config), u32, P(u32), P(u32)]),
+}
+
+
+def bind(cdll: C.CDLL) -> C.CDLL:
+    """Attach restype/argtypes for every ABI symbol; raises AttributeError if one is missing."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(cdll, name)
+        fn.restype = res
+        fn.argtypes = args
+    return cdll

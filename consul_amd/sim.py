@@ -1,0 +1,223 @@
+"""Thin object wrapper over the swimsim C-ABI (include/swimsim.h).
+
+`Sim` is library-agnostic: it is handed a ctypes CDLL already bound with `abi.bind`.  The
+product entry point is `consul_amd.open_sim()` / `consul_amd.lib.load()`, which binds the HIP
+library and nothing else; tests construct `Sim(oracle_cdll, cfg)` to drive the checker.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import abi
+
+EDGE_DTYPE = np.dtype([("dst", "<u4"), ("subject", "<u4"), ("incarnation", "<u4"), ("meta", "<u4")])
+
+
+class SwimError(RuntimeError):
+    def __init__(self, fn: str, rc: int, detail: str = ""):
+        self.rc = rc
+        super().__init__(f"{fn} -> {abi.ERRNAMES.get(rc, rc)}{': ' + detail if detail else ''}")
+
+
+def preset(cdll, which: int = abi.PRESET_LAN, **overrides) -> abi.Config:
+    """memberlist.DefaultLANConfig()/DefaultWANConfig()/DefaultLocalConfig() + field overrides."""
+    cfg = abi.Config()
+    rc = cdll.swim_config_preset(C.byref(cfg), which)
+    if rc:
+        raise SwimError("swim_config_preset", rc)
+    for k, v in overrides.items():
+        if k == "msg_len":
+            for i, x in enumerate(v):
+                cfg.msg_len[i] = x
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(f"swim_config has no field {k!r}")
+            setattr(cfg, k, v)
+    return cfg
+
+
+def derive(cdll, cfg: abi.Config) -> abi.Derived:
+    d = abi.Derived()
+    rc = cdll.swim_config_derive(C.byref(cfg), C.byref(d))
+    if rc:
+        raise SwimError("swim_config_derive", rc)
+    return d
+
+
+def _ids(ids: Iterable[int]):
+    arr = np.ascontiguousarray(np.fromiter(ids, dtype=np.uint32))
+    return arr, arr.ctypes.data_as(C.POINTER(abi.u32)), arr.size
+
+
+class Sim:
+    def __init__(self, cdll, cfg: abi.Config):
+        self._l = cdll
+        self.cfg = cfg
+        self.derived = derive(cdll, cfg)
+        h = abi.SimP()
+        rc = cdll.swim_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise SwimError("swim_create", rc)
+        self._h = h
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _ck(self, fn: str, rc: int):
+        if rc:
+            err = self._l.swim_last_error(self._h)
+            raise SwimError(fn, rc, err.decode() if err else "")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.swim_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def backend(self) -> str:
+        return self._l.swim_backend().decode()
+
+    # -- time ---------------------------------------------------------------------------------
+    def step(self, n_ticks: int = 1):
+        self._ck("swim_step", self._l.swim_step(self._h, n_ticks))
+
+    def sync(self):
+        self._ck("swim_sync", self._l.swim_sync(self._h))
+
+    def now(self):
+        t, ms = abi.u32(), abi.u32()
+        self._ck("swim_now", self._l.swim_now(self._h, C.byref(t), C.byref(ms)))
+        return t.value, ms.value
+
+    def step_ms(self, ms: int):
+        q = self.derived.quantum_ms
+        if ms % q:
+            raise ValueError(f"{ms} ms is not a multiple of the {q} ms quantum")
+        self.step(ms // q)
+
+    # -- split tick (sharded population) --------------------------------------------------------
+    def tick_begin(self):
+        self._ck("swim_tick_begin", self._l.swim_tick_begin(self._h))
+
+    def outbound(self, shard: int):
+        """(raw pointer, count) of the segment addressed to `shard` (device ptr on the HIP lib)."""
+        p, n = C.c_void_p(), abi.u32()
+        self._ck("swim_outbound", self._l.swim_outbound(self._h, shard, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def inbound(self, ptr: int, count: int):
+        self._ck("swim_inbound", self._l.swim_inbound(self._h, C.c_void_p(ptr), count))
+
+    def tick_end(self):
+        self._ck("swim_tick_end", self._l.swim_tick_end(self._h))
+
+    # -- stimulus -----------------------------------------------------------------------------
+    def kill(self, replica: int, ids: Iterable[int]):
+        a, p, n = _ids(ids)
+        self._ck("swim_inject_kill", self._l.swim_inject_kill(self._h, replica, p, n))
+
+    def revive(self, replica: int, ids: Iterable[int]):
+        a, p, n = _ids(ids)
+        self._ck("swim_inject_revive", self._l.swim_inject_revive(self._h, replica, p, n))
+
+    def leave(self, replica: int, ids: Iterable[int]):
+        a, p, n = _ids(ids)
+        self._ck("swim_inject_leave", self._l.swim_inject_leave(self._h, replica, p, n))
+
+    def update(self, replica: int, ids: Iterable[int]):
+        a, p, n = _ids(ids)
+        self._ck("swim_inject_update", self._l.swim_inject_update(self._h, replica, p, n))
+
+    def partition(self, replica: int, group_of_node: Sequence[int]):
+        g = np.ascontiguousarray(group_of_node, dtype=np.uint8)
+        if g.size != self.cfg.n_nodes:
+            raise ValueError("partition mask must have n_nodes entries")
+        self._ck("swim_inject_partition",
+                 self._l.swim_inject_partition(self._h, replica, g.ctypes.data_as(C.POINTER(abi.u8))))
+
+    def set_loss(self, prob: float):
+        self._ck("swim_set_loss", self._l.swim_set_loss(self._h, min(int(prob * 2**32), 2**32 - 1)))
+
+    def user_event(self, replica: int, origin: int, event_id: int) -> int:
+        lt = abi.u32()
+        self._ck("swim_user_event",
+                 self._l.swim_user_event(self._h, replica, origin, event_id, C.byref(lt)))
+        return lt.value
+
+    # -- observation --------------------------------------------------------------------------
+    def view(self, replica: int, observer: int, subject: int) -> abi.Member:
+        m = abi.Member()
+        self._ck("swim_view", self._l.swim_view(self._h, replica, observer, subject, C.byref(m)))
+        return m
+
+    def members(self, replica: int, observer: int):
+        n = self.cfg.n_nodes
+        buf = (abi.Member * n)()
+        cnt = C.c_size_t()
+        self._ck("swim_members", self._l.swim_members(self._h, replica, observer, buf, n, C.byref(cnt)))
+        return np.frombuffer(buf, dtype=np.dtype([("id", "<u4"), ("incarnation", "<u4"),
+                                                  ("state_change_ms", "<u4"), ("state", "u1"),
+                                                  ("status", "u1"), ("n_confirm", "u1"),
+                                                  ("_pad", "u1")]))[: cnt.value].copy()
+
+    def poll_events(self, cap: int = 4096):
+        buf = (abi.Event * cap)()
+        cnt = C.c_size_t()
+        self._ck("swim_poll_events", self._l.swim_poll_events(self._h, buf, cap, C.byref(cnt)))
+        return [(e.time_ms, e.replica, e.type, e.node, e.ltime, e.incarnation) for e in buf[: cnt.value]]
+
+    def node_info(self, replica: int, node: int) -> abi.NodeInfo:
+        o = abi.NodeInfo()
+        self._ck("swim_node_info_get", self._l.swim_node_info_get(self._h, replica, node, C.byref(o)))
+        return o
+
+    def census(self, replica: int, subject: int) -> abi.Census:
+        o = abi.Census()
+        self._ck("swim_census_get", self._l.swim_census_get(self._h, replica, subject, C.byref(o)))
+        return o
+
+    def trace(self, replica: int, subject: int, first_tick: int, n: int) -> np.ndarray:
+        out = np.zeros((n, 5), dtype=np.uint32)
+        self._ck("swim_trace_read", self._l.swim_trace_read(
+            self._h, replica, subject, first_tick, n, out.ctypes.data_as(C.POINTER(abi.u32))))
+        return out
+
+    def stats(self) -> dict:
+        o = abi.Stats()
+        self._ck("swim_stats", self._l.swim_stats(self._h, C.byref(o)))
+        d = {}
+        for name, typ in abi.Stats._fields_:
+            v = getattr(o, name)
+            d[name] = list(v) if hasattr(v, "__len__") else int(v)
+        return d
+
+    def edges(self, cap: int = 1 << 22) -> np.ndarray:
+        """Last tick's rumour deliveries, canonically sorted (order of emission is not defined)."""
+        cnt = C.c_size_t()
+        self._ck("swim_debug_edges", self._l.swim_debug_edges(self._h, None, 0, C.byref(cnt)))
+        n = cnt.value
+        if n > cap:
+            raise SwimError("swim_debug_edges", abi.ERANGE, f"{n} edges > cap {cap}")
+        arr = np.zeros(n, dtype=EDGE_DTYPE)
+        if n:
+            self._ck("swim_debug_edges", self._l.swim_debug_edges(
+                self._h, arr.ctypes.data_as(C.POINTER(abi.Edge)), n, C.byref(cnt)))
+        return np.sort(arr, order=["dst", "subject", "meta", "incarnation"])
+
+    def digest(self) -> int:
+        o = abi.u64()
+        self._ck("swim_state_digest", self._l.swim_state_digest(self._h, C.byref(o)))
+        return o.value

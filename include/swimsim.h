@@ -1,0 +1,287 @@
+/*
+ * swimsim.h — C-ABI of the MI355X-native simulator of Consul's Serf/memberlist SWIM hot path.
+ *
+ * This header is the drop-in boundary.  Two shared libraries export
+ * exactly these symbols:
+ *
+ *   consul_amd/libswimsim.so      the product: hand-written HIP kernels for gfx950
+ *   oracle/_build/libswim_oracle.so  TEST INFRASTRUCTURE ONLY: the plain-C CPU restatement
+ *
+ * The reference's hot path lives in two un-vendored Go modules (reference go.mod:80
+ * github.com/hashicorp/memberlist v0.6.0, go.mod:85 github.com/hashicorp/serf v0.10.4); each
+ * entry point below names the upstream function it replaces and the Consul call/config site
+ * that reaches it (paths relative to the reference checkout).
+ *
+ * Conventions: every function returns 0 on success or a negative
+ * SWIM_E* code; the caller owns every buffer; there are no callbacks (poll model, so a cgo
+ * caller never re-enters Go from a HIP host thread); one handle = one owning thread.
+ * Integer node state produced by the two libraries for the same config+seed is bit-identical.
+ */
+#ifndef SWIMSIM_H
+#define SWIMSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWIM_ABI_VERSION 1u
+
+/* ---- status codes -------------------------------------------------------------------- */
+#define SWIM_OK          0
+#define SWIM_EINVAL    (-22)  /* bad argument / inconsistent config                         */
+#define SWIM_ENOMEM    (-12)  /* host or device allocation failed                           */
+#define SWIM_ENODEV    (-19)  /* no usable HIP device (product library only)                */
+#define SWIM_ERANGE    (-34)  /* id / replica / buffer capacity out of range                */
+#define SWIM_EOVERFLOW (-75)  /* a bounded structure overflowed; results are not trustworthy */
+#define SWIM_ESTATE    (-71)  /* call not legal in the current tick phase                   */
+
+#define SWIM_NONE 0xFFFFFFFFu
+
+/* ---- enums pinned by the reference ------------------------------------------------------ */
+/* memberlist NodeStateType (state.go) */
+enum { SWIM_STATE_ALIVE = 0, SWIM_STATE_SUSPECT = 1, SWIM_STATE_DEAD = 2, SWIM_STATE_LEFT = 3 };
+/* rumour kinds carried in gossip packets (memberlist aliveMsg/suspectMsg/deadMsg, serf
+ * messageUserEventType) */
+enum { SWIM_MSG_ALIVE = 0, SWIM_MSG_SUSPECT = 1, SWIM_MSG_DEAD = 2, SWIM_MSG_USER = 3 };
+/* serf.MemberStatus — pinned in-tree at api/agent.go:296-304 */
+enum { SWIM_MEMBER_NONE = 0, SWIM_MEMBER_ALIVE = 1, SWIM_MEMBER_LEAVING = 2,
+       SWIM_MEMBER_LEFT = 3, SWIM_MEMBER_FAILED = 4 };
+/* serf.EventType as consumed by lanEventHandler (agent/consul/server_serf.go:270-297,
+ * client_serf.go:80-110) */
+enum { SWIM_EVENT_MEMBER_JOIN = 0, SWIM_EVENT_MEMBER_LEAVE = 1, SWIM_EVENT_MEMBER_FAILED = 2,
+       SWIM_EVENT_MEMBER_UPDATE = 3, SWIM_EVENT_MEMBER_REAP = 4, SWIM_EVENT_USER = 5,
+       SWIM_EVENT_QUERY = 6 };
+/* presets = memberlist.DefaultLANConfig / DefaultWANConfig / DefaultLocalConfig
+ * (config.go upstream; the six Consul-exposed knobs are corroborated in-tree at
+ * agent/config/runtime.go:1285-1427) */
+enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
+
+/* config flags */
+#define SWIM_F_BUDDY_SUSPECT  0x1u /* probeNode: ping+suspect compound to a non-alive target  */
+#define SWIM_F_NACK           0x2u /* Lifeguard nack accounting on indirect probes            */
+#define SWIM_F_SERF_EVENTS    0x4u /* allocate the per-node Serf Lamport/event-buffer state   */
+#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK)
+
+/* ---- configuration ---------------------------------------------------------------------- */
+/* One POD mirroring memberlist.Config field names (the ones CloneSerfLANConfig copies,
+ * agent/consul/config.go:679-716, and agent/agent.go:1410-1446 sets) plus simulator bounds. */
+typedef struct swim_config {
+  uint32_t abi_version;             /* SWIM_ABI_VERSION                                     */
+  uint32_t n_nodes;                 /* N: virtual nodes per cluster replica                 */
+  uint32_t n_replicas;              /* R: independent clusters, replica r uses seed+r       */
+  /* memberlist.Config */
+  uint32_t gossip_nodes;            /* GossipNodes        agent/agent.go:1419               */
+  uint32_t gossip_interval_ms;      /* GossipInterval     agent/agent.go:1418               */
+  uint32_t probe_interval_ms;       /* ProbeInterval      agent/agent.go:1420               */
+  uint32_t probe_timeout_ms;        /* ProbeTimeout       agent/agent.go:1426               */
+  uint32_t suspicion_mult;          /* SuspicionMult      agent/agent.go:1427               */
+  uint32_t retransmit_mult;         /* RetransmitMult     agent/agent.go:1428               */
+  uint32_t indirect_checks;         /* IndirectChecks (default 3)                           */
+  uint32_t suspicion_max_timeout_mult; /* SuspicionMaxTimeoutMult (default 6)               */
+  uint32_t awareness_max_mult;      /* AwarenessMaxMultiplier (default 8)                   */
+  uint32_t gossip_to_dead_ms;       /* GossipToTheDeadTime                                  */
+  uint32_t udp_buffer_size;         /* UDPBufferSize (default 1400)                         */
+  /* modelled encoded sizes of alive/suspect/dead/user messages, bytes (queue order uses len) */
+  uint32_t msg_len[4];
+  /* simulator */
+  uint32_t quantum_ms;              /* tick length; 0 = gcd(gossip, probe, timeout)         */
+  uint32_t phase_chunk;             /* nodes per stagger chunk (power of 2); 0 = auto       */
+  uint32_t queue_cap;               /* per-node TransmitLimitedQueue slots (<= 32)          */
+  uint32_t inbox_cap;               /* per-node per-tick inbox slots                        */
+  uint32_t subject_cap;             /* per-replica subject slots (nodes with non-base views)*/
+  uint32_t event_queue_cap;         /* per-node serf user-event queue slots (<= 32)         */
+  uint32_t event_buffer;            /* serf EventBuffer ring size (default 512)             */
+  uint32_t loss_q32;                /* packet loss prob * 2^32 (0 = lossless)               */
+  uint32_t flags;                   /* SWIM_F_*                                             */
+  uint32_t watch_node;              /* observer whose serf events are recorded (SWIM_NONE=off)*/
+  uint32_t trace_ticks;             /* per-tick census history capacity (0 = off)           */
+  uint32_t shard_rank, n_shards;    /* block partition of every replica's node ids          */
+  uint32_t device;                  /* HIP device ordinal (product library)                 */
+  uint64_t seed;
+} swim_config;
+
+/* closed-form constants of memberlist util.go / suspicion.go */
+typedef struct swim_derived {
+  uint32_t quantum_ms, gossip_period, probe_period, probe_timeout_ticks;
+  uint32_t phase_chunk;
+  uint32_t retransmit_limit;        /* retransmitLimit(RetransmitMult, N)                   */
+  uint32_t suspicion_k;             /* SuspicionMult-2, or 0 when N-2 < k                   */
+  uint32_t suspicion_min_ms, suspicion_max_ms;
+  uint32_t suspicion_timeout_ms[8]; /* timeout after n = 0..k confirmations                 */
+  uint32_t node_scale_milli;        /* int(max(1,log10(max(1,N))) * 1000)                   */
+  uint32_t push_pull_scale;         /* pushPullScale multiplier                             */
+  uint32_t packet_budget;           /* UDPBufferSize - compoundHeaderOverhead               */
+} swim_derived;
+
+/* one row of an observer's member list: serf.Member / memberlist.Node reduced to integers
+ * (name, address and tags are host-side, keyed by id) — api/agent.go:291-311 */
+typedef struct swim_member {
+  uint32_t id;
+  uint32_t incarnation;
+  uint32_t state_change_ms;
+  uint8_t  state;                   /* SWIM_STATE_*                                         */
+  uint8_t  status;                  /* SWIM_MEMBER_* (serf view of the same row)            */
+  uint8_t  n_confirm;               /* suspicion confirmations seen (Suspect only)          */
+  uint8_t  _pad;
+} swim_member;
+
+/* serf.Event as delivered on EventCh (agent/consul/server.go:112-114,519-520) */
+typedef struct swim_event {
+  uint32_t time_ms;
+  uint32_t replica;
+  uint32_t type;                    /* SWIM_EVENT_*                                         */
+  uint32_t node;                    /* member id, or user-event id                          */
+  uint32_t ltime;                   /* user events: Lamport time                            */
+  uint32_t incarnation;
+} swim_event;
+
+/* one entry of a node's TransmitLimitedQueue */
+typedef struct swim_rumour {
+  uint32_t subject, incarnation, from;
+  uint8_t  type, transmits, _pad[2];
+  uint32_t seq;
+} swim_rumour;
+
+/* per-node self state (memberlist: incarnation, awareness score, probe bookkeeping) */
+typedef struct swim_node_info {
+  uint32_t incarnation;
+  uint32_t probe_target, probe_deadline_tick, probe_cursor, probe_epoch;
+  uint32_t queue_len, event_queue_len, event_clock;
+  uint8_t  alive, leaving, awareness, partition;
+  swim_rumour queue[32];
+} swim_node_info;
+
+/* how the live observers of one replica currently see one subject */
+typedef struct swim_census {
+  uint32_t n_observers;             /* live observers other than the subject                */
+  uint32_t by_state[4];             /* their view of the subject, by SWIM_STATE_*           */
+  uint32_t n_current;               /* views whose incarnation == subject's own incarnation */
+  uint32_t first_suspect_ms, first_dead_ms, all_dead_ms; /* SWIM_NONE until it happened     */
+  uint32_t all_current_ms;          /* first time every live observer held the current inc  */
+} swim_census;
+
+/* one directed rumour delivery (gossip edge): 16 bytes, the unit of the all-to-all */
+typedef struct swim_edge {
+  uint32_t dst;                     /* replica*N + node, or SWIM_NONE for a control record  */
+  uint32_t subject;
+  uint32_t incarnation;             /* user events: ltime                                   */
+  uint32_t meta;                    /* type<<30 | from                                      */
+} swim_edge;
+
+typedef struct swim_stats_t {
+  uint64_t ticks, gossip_rounds;
+  uint64_t node_rounds_active, node_rounds_quiescent; /* gossip-due live nodes w/ and w/o queue */
+  uint64_t packets_sent, packets_dropped;
+  uint64_t msgs_sent[4];
+  uint64_t msgs_applied[4];         /* handleAlive/Suspect/Dead/User that changed state     */
+  uint64_t probes, probe_acks, probe_indirect_acks, probe_failures, nacks_missed;
+  uint64_t refutes, suspicion_timeouts, confirmations;
+  uint64_t edges, edges_remote;
+  uint64_t queue_drops, inbox_overflow, subject_overflow, event_drops;
+  uint64_t user_events_delivered, user_events_deduped, user_events_stale;
+} swim_stats_t;
+
+typedef struct swim_sim swim_sim;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* memberlist.DefaultLANConfig()/DefaultWANConfig()/DefaultLocalConfig(); Consul's use:
+ * agent/consul/config.go:553-555,645 */
+int swim_config_preset(swim_config* cfg, int preset);
+/* util.go retransmitLimit/suspicionTimeout/pushPullScale + suspicion.go remainingSuspicionTime,
+ * evaluated once on the host with Go's float64 semantics (docs: agent/config/runtime.go:1326,1344) */
+int swim_config_derive(const swim_config* cfg, swim_derived* out);
+/* serf.Create -> memberlist.Create -> newMemberlist + setAlive + schedule, for all N*R virtual
+ * nodes at once (agent/consul/server_serf.go:63, client_serf.go:76).  All nodes start alive at
+ * incarnation 1 with converged views (BASELINE config #2 "all alive at t=0"). */
+int swim_create(const swim_config* cfg, swim_sim** out);
+/* serf.Shutdown (agent/consul/client.go:188, server.go:1277) */
+int swim_destroy(swim_sim* sim);
+const char* swim_backend(void);      /* "hip-gfx950" or "oracle-c" */
+const char* swim_last_error(swim_sim* sim);
+
+/* ---- time ----------------------------------------------------------------------------------- */
+/* memberlist.schedule's three tickers, advanced n_ticks quanta for every virtual node:
+ * probe()/probeNode, gossip(), suspicion timers, packet delivery, handleAlive/Suspect/Dead
+ * (SURVEY §3.2, §3.3).  Asynchronous on the product library; swim_sync waits. */
+int swim_step(swim_sim* sim, uint32_t n_ticks);
+int swim_sync(swim_sim* sim);
+int swim_now(swim_sim* sim, uint32_t* tick, uint32_t* now_ms);
+
+/* split tick for a population sharded over several devices:
+ *   begin    = timers + probe + gossip select/emit -> outbound segments bucketed by shard
+ *   outbound = device pointer + record count of the segment for `shard`
+ *   inbound  = hand over records received from another shard (device pointer on the product
+ *              library, host pointer on the oracle)
+ *   end      = subject-slot allocation, delivery, merge (aliveNode/suspectNode/deadNode)     */
+int swim_tick_begin(swim_sim* sim);
+int swim_outbound(swim_sim* sim, uint32_t shard, const swim_edge** ptr, uint32_t* count);
+int swim_inbound(swim_sim* sim, const swim_edge* ptr, uint32_t count);
+int swim_tick_end(swim_sim* sim);
+
+/* ---- stimulus (fault injection is native; the reference kills nodes with Shutdown(),
+ *      agent/consul/server_test.go:725) ----------------------------------------------------- */
+int swim_inject_kill(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);
+int swim_inject_revive(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);
+/* serf.Leave -> memberlist.Leave: dead{Node==From} => StateLeft (agent/consul/client.go:205) */
+int swim_inject_leave(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);
+/* memberlist.UpdateNode (serf.SetTags, internal/gossip/libserf/serf.go:51): bump own
+ * incarnation and broadcast alive — the "single rumour" of BASELINE config #3 */
+int swim_inject_update(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);
+/* partition mask: nodes exchange packets only within the same group id (config #4) */
+int swim_inject_partition(swim_sim* sim, uint32_t replica, const uint8_t* group_of_node);
+int swim_set_loss(swim_sim* sim, uint32_t loss_q32);
+/* serf.UserEvent(name, payload, coalesce=false) (agent/consul/server_ce.go:125-131):
+ * event_id stands for hash(name,payload); returns the Lamport time stamped on it */
+int swim_user_event(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t event_id,
+                    uint32_t* ltime_out);
+
+/* ---- observation ---------------------------------------------------------------------------- */
+/* serf.Members() as seen by `observer` (agent/consul/client.go:234, server.go:1508): writes
+ * min(cap, N) rows ordered by id; *n_out = N */
+int swim_members(swim_sim* sim, uint32_t replica, uint32_t observer, swim_member* out,
+                 size_t cap, size_t* n_out);
+/* one row of the above */
+int swim_view(swim_sim* sim, uint32_t replica, uint32_t observer, uint32_t subject,
+              swim_member* out);
+/* serf.Config.EventCh drained by lanEventHandler (server_serf.go:270): events seen by
+ * cfg.watch_node of every replica, oldest first */
+int swim_poll_events(swim_sim* sim, swim_event* out, size_t cap, size_t* n_out);
+int swim_node_info_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_node_info* out);
+int swim_census_get(swim_sim* sim, uint32_t replica, uint32_t subject, swim_census* out);
+/* per-tick census history of `subject` (infection / detection curves): rows for ticks
+ * [first_tick, first_tick+n), each {by_state[4], n_current} = 5 x u32 */
+int swim_trace_read(swim_sim* sim, uint32_t replica, uint32_t subject, uint32_t first_tick,
+                    uint32_t n, uint32_t* out_rows5);
+/* serf.Stats() / memberlist metrics (agent/consul/server.go:1749, SURVEY §5 metrics row) */
+int swim_stats(swim_sim* sim, swim_stats_t* out);
+/* the edge list of the most recent tick (after emit, before delivery), for parity tests */
+int swim_debug_edges(swim_sim* sim, swim_edge* out, size_t cap, size_t* n_out);
+/* order-independent 64-bit digest over all integer node state (self state, queues, views,
+ * suspicion timers, serf clocks) — "checksum of checksums" for full-size parity */
+int swim_state_digest(swim_sim* sim, uint64_t* out);
+
+/* ---- memberlist.Transport bridge (agent/consul/wanfed/wanfed.go:96-141)
+ * A real memberlist node attached as virtual node `attached` exchanges rumours with its
+ * virtual peers: write_to = Transport.WriteToAddress, poll = Transport.PacketCh.  Packets are
+ * swim_edge records here; the msgpack wire codec is the host shim's job. */
+int swim_transport_write_to(swim_sim* sim, uint32_t replica, uint32_t attached,
+                            uint32_t virtual_dst, const swim_edge* msgs, size_t n);
+int swim_transport_poll(swim_sim* sim, uint32_t replica, uint32_t attached, swim_edge* out,
+                        size_t cap, size_t* n_out);
+
+/* ---- known-answer hooks (pure functions; used by tests/ to pin both libraries) ------------ */
+void swim_kat_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n_nodes, uint32_t node, uint32_t epoch,
+                             uint32_t index);
+int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t elapsed_ms,
+                                        uint32_t min_ms, uint32_t max_ms);
+void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gossip_phase,
+                       uint32_t* probe_phase);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIMSIM_H */

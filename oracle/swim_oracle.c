@@ -1,0 +1,1060 @@
+/*
+ * swim_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A scalar CPU restatement, in plain C, of the algorithm on Consul's Serf/memberlist SWIM hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (consul_amd/libswimsim.so) never does.
+ *
+ * PARITY UNPINNED.  The algorithm lives in two Go modules that are NOT vendored in the
+ * reference checkout and cannot be fetched here:
+ *     github.com/hashicorp/memberlist v0.6.0   (reference go.mod:80, go.sum:441-442)
+ *     github.com/hashicorp/serf       v0.10.4  (reference go.mod:85, go.sum:456-457)
+ * and the reference's own tests hold no golden vectors for probe/suspect/gossip rounds
+ * (SURVEY.md §8(c)).  This file restates the published algorithm of those modules (state.go,
+ * suspicion.go, awareness.go, queue.go, util.go, broadcast.go; serf lamport.go, serf.go
+ * handleUserEvent, delegate.go) as recalled in SURVEY.md Appendix A, and is pinned by
+ *   - the closed-form constants the reference documents in-tree
+ *     (agent/config/runtime.go:1326,1344),
+ *   - the Random123 known-answer vectors for Philox4x32-10,
+ *   - behavioural known answers written from the upstream semantics (tests/test_oracle_kat.py).
+ * Each function cites the upstream function it follows and Consul's call/config site.
+ *
+ * Determinisation (what a lock-step simulator must add to a wall-clock, goroutine-scheduled
+ * original):
+ *   time      integer ticks of quantum_ms = gcd(GossipInterval, ProbeInterval, ProbeTimeout)
+ *   stagger   triggerFunc's random initial sleep becomes a fixed per-chunk phase:
+ *             chunk c = id / phase_chunk; gossip phase = c % G; probe phase = (c / G) % P
+ *   rand      math/rand becomes Philox4x32-10, counter (tick, node, block, 0), key (seed+replica,
+ *             stream) — so a draw depends only on who draws and when, never on execution order
+ *   shuffle   the per-node shuffled probe list becomes a keyed Feistel permutation of [0,N)
+ *   arrival   packets sent in tick t are delivered at the end of tick t; each receiver applies
+ *             its tick's messages in ascending (subject, type, incarnation, from) order
+ *   views     every observer starts with the converged base view (all alive, incarnation 1);
+ *             per-observer overrides exist only for "subjects" (nodes somebody has news about)
+ */
+#define _GNU_SOURCE
+#include "../include/swimsim.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* RNG and hashing                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4 };
+
+/* Philox4x32-10 (Salmon et al., SC'11; Random123).  Pinned by kat vectors in the tests. */
+static void philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) {
+  uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], k0 = k[0], k1 = k[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+static uint32_t fmix32(uint32_t h) { /* murmur3 finaliser */
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+static uint64_t mix64(uint64_t x) { /* splitmix64 finaliser, for the state digest */
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+
+static void stream_key(uint64_t seed_r, uint32_t stream, uint32_t key[2]) {
+  key[0] = (uint32_t)seed_r;
+  key[1] = (uint32_t)(seed_r >> 32) ^ stream;
+}
+
+/* draw #d of (stream, tick, node): word d%4 of block d/4 */
+typedef struct { uint32_t key[2], tick, node, blk, w[4]; } draws_t;
+static void draws_init(draws_t* d, uint64_t seed_r, uint32_t stream, uint32_t tick, uint32_t node) {
+  stream_key(seed_r, stream, d->key); d->tick = tick; d->node = node; d->blk = SWIM_NONE;
+}
+static uint32_t draws_get(draws_t* d, uint32_t idx) {
+  uint32_t b = idx >> 2;
+  if (b != d->blk) { uint32_t c[4] = { d->tick, d->node, b, 0 }; philox4x32(c, d->key, d->w); d->blk = b; }
+  return d->w[idx & 3];
+}
+
+/* Replaces memberlist shuffleNodes + the probeIndex walk (state.go probe/resetNodes, util.go
+ * shuffleNodes): position `index` of node's epoch-th shuffle of [0,N).  4-round balanced Feistel
+ * on 2*ceil(bits/2) bits with cycle walking, so every epoch visits each id exactly once. */
+static uint32_t probe_perm(uint64_t seed_r, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) {
+  if (n <= 1) return 0;
+  uint32_t bits = 1; while ((1u << bits) < n && bits < 32) bits++;
+  uint32_t h = (bits + 1) / 2, mask = (1u << h) - 1;
+  uint32_t key[2], c[4] = { node, epoch, 0, 0x50524D31u }, rk[4];
+  stream_key(seed_r, STREAM_PERM, key);
+  philox4x32(c, key, rk);
+  uint32_t x = index;
+  do {
+    uint32_t l = x >> h, r = x & mask;
+    for (int i = 0; i < 4; i++) { uint32_t t = l ^ (fmix32(r ^ rk[i]) & mask); l = r; r = t; }
+    x = (l << h) | r;
+  } while (x >= n);
+  return x;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Closed-form constants (memberlist util.go, suspicion.go)                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Go's math.Log2 / math.Log10 (pure-Go definitions: Log2 via Frexp, Log10 = Log2 * Ln2/Ln10), so
+ * truncation edges such as N=1e6 -> 5999 reproduce. */
+static double go_log2(double x) {
+  int e; double f = frexp(x, &e);
+  if (f == 0.5) return (double)(e - 1);
+  return log(f) * (1.0 / 0.693147180559945309417232121458176568) + (double)e;
+}
+static double go_log10(double x) { return go_log2(x) * (0.693147180559945309417232121458176568 / 2.30258509299404568401799145468436421); }
+
+static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
+
+/* suspicion.go remainingSuspicionTime, in integer milliseconds */
+static int64_t remaining_suspicion_ms(uint32_t n, uint32_t k, int64_t elapsed_ms, int64_t min_ms, int64_t max_ms) {
+  double frac = log((double)n + 1.0) / log((double)k + 1.0);
+  double max_s = (double)max_ms / 1000.0, min_s = (double)min_ms / 1000.0;
+  double raw = max_s - frac * (max_s - min_s);
+  int64_t timeout = (int64_t)floor(1000.0 * raw);
+  if (timeout < min_ms) timeout = min_ms;
+  return timeout - elapsed_ms;
+}
+
+int swim_config_preset(swim_config* c, int preset) {
+  if (!c) return SWIM_EINVAL;
+  memset(c, 0, sizeof *c);
+  c->abi_version = SWIM_ABI_VERSION;
+  c->n_nodes = 128; c->n_replicas = 1;
+  /* memberlist config.go DefaultLANConfig; WAN/Local override below (SURVEY Appendix A.2;
+   * LAN/WAN knobs corroborated at agent/config/runtime.go:1285-1427) */
+  c->indirect_checks = 3; c->retransmit_mult = 4; c->suspicion_mult = 4;
+  c->suspicion_max_timeout_mult = 6; c->probe_timeout_ms = 500; c->probe_interval_ms = 1000;
+  c->awareness_max_mult = 8; c->gossip_nodes = 3; c->gossip_interval_ms = 200;
+  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400;
+  if (preset == SWIM_PRESET_WAN) {
+    c->suspicion_mult = 6; c->probe_timeout_ms = 3000; c->probe_interval_ms = 5000;
+    c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000;
+  } else if (preset == SWIM_PRESET_LOCAL) {
+    c->indirect_checks = 1; c->retransmit_mult = 2; c->suspicion_mult = 3;
+    c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000;
+  } else if (preset != SWIM_PRESET_LAN) return SWIM_EINVAL;
+  c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
+  c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
+  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
+  c->event_queue_cap = 8; c->event_buffer = 512;
+  c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
+  return SWIM_OK;
+}
+
+static int validate(const swim_config* c) {
+  if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
+  if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 30)) return SWIM_ERANGE;
+  if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
+  if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
+  if (c->suspicion_mult < 1 || c->suspicion_mult > 6 || c->retransmit_mult < 1) return SWIM_EINVAL;
+  if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
+  if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
+  if (c->flags & SWIM_F_SERF_EVENTS)
+    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
+  if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
+  if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
+  return SWIM_OK;
+}
+
+int swim_config_derive(const swim_config* c, swim_derived* d) {
+  int rc = validate(c); if (rc) return rc;
+  if (!d) return SWIM_EINVAL;
+  memset(d, 0, sizeof *d);
+  uint32_t q = c->quantum_ms ? c->quantum_ms
+             : gcd_u32(gcd_u32(c->gossip_interval_ms, c->probe_interval_ms), c->probe_timeout_ms);
+  if (c->gossip_interval_ms % q || c->probe_interval_ms % q || c->probe_timeout_ms % q) return SWIM_EINVAL;
+  d->quantum_ms = q;
+  d->gossip_period = c->gossip_interval_ms / q;
+  d->probe_period = c->probe_interval_ms / q;
+  d->probe_timeout_ticks = c->probe_timeout_ms / q;
+  uint32_t gp = d->gossip_period * d->probe_period, ch = c->phase_chunk;
+  if (!ch) { ch = 256; while (ch > 1 && (uint64_t)ch * gp * 8 > c->n_nodes) ch >>= 1; }
+  d->phase_chunk = ch;
+  double n = (double)c->n_nodes;
+  /* util.go retransmitLimit: mult * ceil(log10(n+1))          (doc: runtime.go:1344) */
+  d->retransmit_limit = c->retransmit_mult * (uint32_t)ceil(go_log10(n + 1.0));
+  /* util.go suspicionTimeout: mult * int(max(1,log10(max(1,n)))*1000) * interval / 1000
+   * (doc: runtime.go:1326), evaluated in integer nanoseconds like time.Duration */
+  double scale = go_log10(n < 1.0 ? 1.0 : n); if (scale < 1.0) scale = 1.0;
+  int64_t scale_milli = (int64_t)(scale * 1000.0);
+  d->node_scale_milli = (uint32_t)scale_milli;
+  int64_t min_ns = (int64_t)c->suspicion_mult * scale_milli * ((int64_t)c->probe_interval_ms * 1000000) / 1000;
+  int64_t max_ns = (int64_t)c->suspicion_max_timeout_mult * min_ns;
+  int64_t min_ms = min_ns / 1000000, max_ms = max_ns / 1000000;
+  if (max_ms > 0x7FFFFFFF) return SWIM_ERANGE;
+  d->suspicion_min_ms = (uint32_t)min_ms; d->suspicion_max_ms = (uint32_t)max_ms;
+  /* state.go suspectNode: k = SuspicionMult-2; if n-2 < k then k = 0 */
+  int32_t k = (int32_t)c->suspicion_mult - 2; if (k < 0) k = 0;
+  if ((int64_t)c->n_nodes - 2 < k) k = 0;
+  d->suspicion_k = (uint32_t)k;
+  /* suspicion.go newSuspicion: timeout = max, or min when k < 1; Confirm: remainingSuspicionTime */
+  d->suspicion_timeout_ms[0] = (uint32_t)(k < 1 ? min_ms : max_ms);
+  for (int32_t i = 1; i <= k && i < 8; i++)
+    d->suspicion_timeout_ms[i] = (uint32_t)remaining_suspicion_ms((uint32_t)i, (uint32_t)k, 0, min_ms, max_ms);
+  /* util.go pushPullScale multiplier */
+  d->push_pull_scale = c->n_nodes <= 32 ? 1u : (uint32_t)(ceil(go_log2(n) - go_log2(32.0)) + 1.0);
+  /* state.go gossip(): bytesAvail = UDPBufferSize - compoundHeaderOverhead(2) - labelOverhead(0) */
+  d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
+  return SWIM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* State                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+#define QMAX 32
+#define CONF_MAX 4
+#define EV_PER_SLOT 3
+
+typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
+
+typedef struct { uint32_t key, since, conf[CONF_MAX]; uint8_t nconf; } view_t;
+#define KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
+#define KINC(k) ((k) >> 2)
+#define KST(k) ((k) & 3u)
+#define BASE_KEY KEY(1, SWIM_STATE_ALIVE)
+
+typedef struct { uint32_t ltime, ids[EV_PER_SLOT]; uint8_t n; } evslot;
+
+typedef struct {
+  uint32_t self_inc;
+  uint8_t awareness, leaving;
+  uint32_t qlen, qseq; qent q[QMAX];
+  uint32_t pr_target, pr_inc, pr_t0, pr_deadline, pr_cursor, pr_epoch; uint8_t pr_stage, pr_nack_miss;
+  /* serf */
+  uint32_t ev_clock, evqlen, evqseq; qent evq[QMAX]; evslot* ring;
+  /* per-tick inbox */
+  uint32_t in_cnt; swim_edge* inbox;
+} node_t;
+
+typedef struct {
+  uint32_t node;            /* subject id */
+  view_t* col;              /* [n_local] observer views */
+  uint8_t dirty;
+  uint32_t susp_count, min_deadline;
+  uint32_t max_inc;
+  swim_census census;       /* cached; first_* fields persistent */
+  uint32_t* trace;          /* [trace_ticks][5] */
+} slot_t;
+
+typedef struct { swim_edge* v; uint32_t n, cap; } edgevec;
+
+struct swim_sim {
+  swim_config cfg; swim_derived d;
+  uint32_t N, R, nloc, i0, tick; int in_tick;
+  uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
+  uint32_t* node_slot;           /* [R*N] replicated */
+  node_t* nodes;                 /* [R*nloc] */
+  slot_t* slots; uint32_t* n_slots; /* [R*S], [R] */
+  edgevec* out;                  /* [n_shards] */
+  edgevec in, last_edges;
+  swim_event* events; size_t n_events, cap_events;
+  swim_stats_t st;
+  uint32_t loss_q32;
+  char err[256];
+};
+
+static void ev_push(edgevec* e, swim_edge x) {
+  if (e->n == e->cap) { e->cap = e->cap ? e->cap * 2 : 1024; e->v = (swim_edge*)realloc(e->v, (size_t)e->cap * sizeof(swim_edge)); }
+  e->v[e->n++] = x;
+}
+
+static inline uint32_t now_ms(const swim_sim* s) { return s->tick * s->d.quantum_ms; }
+static inline uint64_t seed_of(const swim_sim* s, uint32_t r) { return s->cfg.seed + r; }
+static inline int is_local(const swim_sim* s, uint32_t i) { return i >= s->i0 && i < s->i0 + s->nloc; }
+static inline node_t* node_at(swim_sim* s, uint32_t r, uint32_t i) { return &s->nodes[(size_t)r * s->nloc + (i - s->i0)]; }
+static inline uint32_t shard_of(const swim_sim* s, uint32_t i) { return i / s->nloc; }
+static inline uint32_t gphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk) % s->d.gossip_period; }
+static inline uint32_t pphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk / s->d.gossip_period) % s->d.probe_period; }
+
+static void record_event(swim_sim* s, uint32_t r, uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
+  if (s->n_events == s->cap_events) {
+    s->cap_events = s->cap_events ? s->cap_events * 2 : 256;
+    s->events = (swim_event*)realloc(s->events, s->cap_events * sizeof(swim_event));
+  }
+  swim_event e = { now_ms(s), r, type, node, ltime, inc };
+  s->events[s->n_events++] = e;
+}
+
+/* observer o's view of subject x: the base view unless x has a subject slot */
+static view_t* view_ptr(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
+  if (sl == SWIM_NONE) return NULL;
+  return &s->slots[(size_t)r * s->cfg.subject_cap + sl].col[o - s->i0];
+}
+static uint32_t view_key(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, uint32_t* since) {
+  view_t* v = view_ptr(s, r, o, x);
+  if (!v) { if (since) *since = 0; return BASE_KEY; }
+  if (since) *since = v->since;
+  return v->key;
+}
+
+/* give subject x an override column, initialised to the base view for every observer */
+static int alloc_slot(swim_sim* s, uint32_t r, uint32_t x) {
+  size_t g = (size_t)r * s->N + x;
+  if (s->node_slot[g] != SWIM_NONE) return SWIM_OK;
+  if (s->n_slots[r] >= s->cfg.subject_cap) { s->st.subject_overflow++; return SWIM_EOVERFLOW; }
+  uint32_t sl = s->n_slots[r]++;
+  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+  t->node = x; t->dirty = 1; t->susp_count = 0; t->min_deadline = SWIM_NONE; t->max_inc = 1;
+  t->col = (view_t*)calloc(s->nloc, sizeof(view_t));
+  if (!t->col) return SWIM_ENOMEM;
+  for (uint32_t k = 0; k < s->nloc; k++) t->col[k].key = BASE_KEY;
+  memset(&t->census, 0, sizeof t->census);
+  t->census.first_suspect_ms = t->census.first_dead_ms = t->census.all_dead_ms = t->census.all_current_ms = SWIM_NONE;
+  if (s->cfg.trace_ticks) t->trace = (uint32_t*)calloc((size_t)s->cfg.trace_ticks * 5, sizeof(uint32_t));
+  s->node_slot[g] = sl;
+  return SWIM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TransmitLimitedQueue (memberlist queue.go; sized by Consul at internal/gossip/libserf/      */
+/* serf.go:22-27, RetransmitMult from agent/agent.go:1428)                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline uint32_t ent_len(const swim_sim* s, const qent* e) { return s->cfg.msg_len[e->type & 3]; }
+
+/* limitedBroadcast.Less: transmits asc, then msgLen desc, then id desc */
+static int ent_before(const swim_sim* s, const qent* a, const qent* b) {
+  if (a->transmits != b->transmits) return a->transmits < b->transmits;
+  uint32_t la = ent_len(s, a), lb = ent_len(s, b);
+  if (la != lb) return la > lb;
+  return a->seq > b->seq;
+}
+
+/* QueueBroadcast: a memberlistBroadcast named by its node invalidates any queued rumour about
+ * the same node (broadcast.go Invalidates); serf user events are UniqueBroadcasts.  The real
+ * queue is unbounded; ours holds `cap` entries and, like Prune(), evicts the tail of the order. */
+static void queue_push(swim_sim* s, qent* q, uint32_t* qlen, uint32_t* qseq, uint32_t cap, int named,
+                       uint32_t subject, uint8_t type, uint32_t inc, uint32_t from, uint64_t* drops) {
+  uint32_t n = *qlen;
+  if (named)
+    for (uint32_t i = 0; i < n; i++)
+      if (q[i].subject == subject) { q[i] = q[n - 1]; n--; break; }
+  qent e = { subject, inc, from, (*qseq)++ & 0x3FFFFFu, type, 0 };
+  if (n == cap) {
+    uint32_t w = SWIM_NONE; const qent* worst = &e;      /* the new entry takes part in the prune */
+    for (uint32_t i = 0; i < n; i++) if (ent_before(s, worst, &q[i])) { worst = &q[i]; w = i; }
+    (*drops)++;
+    if (w == SWIM_NONE) { *qlen = n; return; }
+    q[w] = e;
+  } else q[n++] = e;
+  *qlen = n;
+}
+
+/* GetBroadcasts(overhead, limit): walk tiers by transmit count, inside a tier largest first then
+ * newest, take what fits, bump transmits after the sweep, retire at retransmitLimit. */
+static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out) {
+  uint32_t n = *qlen, taken = 0, cnt = 0; int32_t used = 0;
+  for (;;) {
+    int32_t free_b = limit - used - (int32_t)overhead;
+    if (free_b <= 0) break;
+    uint32_t best = SWIM_NONE;
+    for (uint32_t i = 0; i < n; i++) {
+      if ((taken >> i) & 1u) continue;
+      if ((int32_t)ent_len(s, &q[i]) > free_b) continue;
+      if (best == SWIM_NONE || ent_before(s, &q[i], &q[best])) best = i;
+    }
+    if (best == SWIM_NONE) break;
+    taken |= 1u << best; used += (int32_t)(overhead + ent_len(s, &q[best])); out[cnt++] = q[best];
+  }
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if ((taken >> i) & 1u) {
+      if ((uint32_t)q[i].transmits + 1 >= s->d.retransmit_limit) continue;   /* Finished() */
+      q[i].transmits++;
+    }
+    q[m++] = q[i];
+  }
+  *qlen = m; *used_out = used;
+  return cnt;
+}
+
+/* encodeAndBroadcast (broadcast.go) */
+static void broadcast(swim_sim* s, node_t* nd, uint32_t subject, uint8_t type, uint32_t inc, uint32_t from) {
+  queue_push(s, nd->q, &nd->qlen, &nd->qseq, s->cfg.queue_cap, 1, subject, type, inc, from, &s->st.queue_drops);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* awareness.go                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static void awareness_delta(swim_sim* s, node_t* nd, int delta) {
+  int v = (int)nd->awareness + delta, mx = (int)s->cfg.awareness_max_mult - 1;
+  if (v < 0) v = 0; if (v > mx) v = mx;
+  nd->awareness = (uint8_t)v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* state.go aliveNode / suspectNode / deadNode / refute, applied at observer o                 */
+/* ------------------------------------------------------------------------------------------ */
+
+static void set_view(swim_sim* s, uint32_t r, slot_t* t, view_t* v, uint32_t inc, uint32_t st, int touch_since) {
+  uint32_t old = KST(v->key);
+  if (old == SWIM_STATE_SUSPECT && st != SWIM_STATE_SUSPECT) t->susp_count--;
+  if (old != SWIM_STATE_SUSPECT && st == SWIM_STATE_SUSPECT) t->susp_count++;
+  v->key = KEY(inc, st);
+  if (touch_since) v->since = now_ms(s);
+  if (inc > t->max_inc) t->max_inc = inc;
+  t->dirty = 1; (void)r;
+}
+
+/* refute: nextIncarnation / skipIncarnation past the accuser, awareness +1, broadcast alive */
+static void refute(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, slot_t* t, view_t* v, uint32_t accused_inc) {
+  uint32_t inc = nd->self_inc + 1;
+  if (accused_inc >= inc) inc = accused_inc + 1;
+  nd->self_inc = inc;
+  awareness_delta(s, nd, +1);
+  set_view(s, r, t, v, inc, SWIM_STATE_ALIVE, 0);
+  broadcast(s, nd, o, SWIM_MSG_ALIVE, inc, 0);
+  s->st.refutes++;
+}
+
+/* `upd` (carried in the alive record's from field) = the alive came from UpdateNode, i.e. its
+ * Meta differs from the previous incarnation's; a refutation re-sends the same Meta */
+static void alive_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t upd) {
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;
+  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
+  int local = (x == o);
+  if (local && nd->leaving) return;                       /* "if m.hasLeft() && a.Node == self" */
+  if (!local && inc <= KINC(v->key)) return;
+  if (local && inc < KINC(v->key)) return;
+  v->nconf = 0;                                           /* delete(m.nodeTimers, a.Node) */
+  uint32_t old = KST(v->key);
+  if (local) {
+    if (inc == KINC(v->key)) return;                      /* same incarnation, same meta */
+    refute(s, r, o, nd, t, v, inc);
+  } else {
+    broadcast(s, nd, x, SWIM_MSG_ALIVE, inc, upd);
+    set_view(s, r, t, v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
+    s->st.msgs_applied[SWIM_MSG_ALIVE]++;
+    if (o == s->cfg.watch_node) {
+      if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(s, r, SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
+      else if (upd) record_event(s, r, SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);   /* NotifyUpdate: meta changed */
+    }
+  }
+}
+
+static void suspect_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t from) {
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;   /* never heard of it */
+  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
+  if (inc < KINC(v->key)) return;
+  if (KST(v->key) == SWIM_STATE_SUSPECT) {                /* a timer exists: suspicion.Confirm(from) */
+    if (v->nconf >= s->d.suspicion_k) return;
+    for (uint32_t i = 0; i <= v->nconf && i < CONF_MAX; i++) if (v->conf[i] == from) return;
+    v->nconf++;
+    if (v->nconf < CONF_MAX) v->conf[v->nconf] = from;
+    uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
+    if (dl < t->min_deadline) t->min_deadline = dl;
+    t->dirty = 1; s->st.confirmations++;
+    broadcast(s, nd, x, SWIM_MSG_SUSPECT, inc, from);
+    return;
+  }
+  if (KST(v->key) != SWIM_STATE_ALIVE) return;
+  if (x == o) { refute(s, r, o, nd, t, v, inc); return; }
+  broadcast(s, nd, x, SWIM_MSG_SUSPECT, inc, from);
+  set_view(s, r, t, v, inc, SWIM_STATE_SUSPECT, 1);
+  v->nconf = 0; v->conf[0] = from;                        /* newSuspicion(from, k, min, max) */
+  uint32_t dl = v->since + s->d.suspicion_timeout_ms[0];
+  if (dl < t->min_deadline) t->min_deadline = dl;
+  s->st.msgs_applied[SWIM_MSG_SUSPECT]++;
+}
+
+static void dead_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t from) {
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;
+  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
+  if (inc < KINC(v->key)) return;
+  uint32_t old = KST(v->key);
+  if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
+  v->nconf = 0;
+  if (x == o) {
+    if (!nd->leaving) { refute(s, r, o, nd, t, v, inc); return; }
+    broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
+  } else broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
+  uint32_t st = (from == x) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+  set_view(s, r, t, v, inc, st, 1);
+  s->st.msgs_applied[SWIM_MSG_DEAD]++;
+  if (o == s->cfg.watch_node && x != o)
+    record_event(s, r, st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
+}
+
+/* serf.go handleUserEvent + lamport.go Witness (Consul fires via server_ce.go:125-131 and
+ * consumes at server_serf.go:283, client_serf.go:98) */
+static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime) {
+  if (!nd->ring) return;
+  if (ltime >= nd->ev_clock) nd->ev_clock = ltime + 1;                 /* Witness */
+  uint32_t cur = nd->ev_clock, bl = s->cfg.event_buffer;
+  if (cur > bl && ltime < cur - bl) { s->st.user_events_stale++; return; }
+  evslot* sl = &nd->ring[ltime % bl];
+  if (sl->n && sl->ltime == ltime) {
+    for (uint32_t i = 0; i < sl->n; i++) if (sl->ids[i] == id) { s->st.user_events_deduped++; return; }
+  } else { sl->ltime = ltime; sl->n = 0; }
+  if (sl->n == EV_PER_SLOT) { s->st.event_drops++; return; }
+  sl->ids[sl->n++] = id;
+  s->st.user_events_delivered++;
+  if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
+  queue_push(s, nd->evq, &nd->evqlen, &nd->evqseq, s->cfg.event_queue_cap, 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* tick phases                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+static swim_edge mk_edge(const swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+  swim_edge e = { r * s->N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu) };
+  return e;
+}
+static void emit(swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+  uint32_t sh = shard_of(s, dst);
+  ev_push(&s->out[sh], mk_edge(s, r, dst, subject, inc, type, from));
+  s->st.edges++; if (sh != s->cfg.shard_rank) s->st.edges_remote++;
+}
+static void emit_slot_request(swim_sim* s, uint32_t r, uint32_t x) {
+  swim_edge e = { SWIM_NONE, x, r, 0 };
+  for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++) ev_push(&s->out[sh], e);
+}
+
+static int lost(const swim_sim* s, uint32_t r, uint32_t node, uint32_t leg) {
+  if (!s->loss_q32) return 0;
+  uint32_t key[2], c[4] = { s->tick, node, leg, 0 }, w[4];
+  stream_key(seed_of(s, r), STREAM_LOSS, key); philox4x32(c, key, w);
+  return w[0] < s->loss_q32;
+}
+/* can a packet sent by a (alive) reach b right now */
+static int reach(const swim_sim* s, uint32_t r, uint32_t a, uint32_t b, uint32_t rng_node, uint32_t leg) {
+  size_t base = (size_t)r * s->N;
+  if (!s->gt_alive[base + b]) return 0;
+  if (s->part[base + a] != s->part[base + b]) return 0;
+  return !lost(s, r, rng_node, leg);
+}
+
+/* suspicion timers: the time.AfterFunc of suspectNode firing -> deadNode(dead{inc, node, self}) */
+static void phase_expire(swim_sim* s) {
+  uint32_t now = now_ms(s);
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
+      slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+      if (!t->susp_count || now < t->min_deadline) continue;
+      for (uint32_t k = 0; k < s->nloc; k++) {
+        view_t* v = &t->col[k]; uint32_t o = s->i0 + k;
+        if (KST(v->key) != SWIM_STATE_SUSPECT || !s->gt_alive[(size_t)r * s->N + o]) continue;
+        if (now >= v->since + s->d.suspicion_timeout_ms[v->nconf]) {
+          emit(s, r, o, t->node, KINC(v->key), SWIM_MSG_DEAD, o);
+          s->st.suspicion_timeouts++;
+        }
+      }
+    }
+}
+
+/* util.go kRandomNodes: up to 3n draws of randomOffset(n), skipping excluded and duplicates */
+typedef int (*excl_fn)(swim_sim*, uint32_t r, uint32_t o, uint32_t x, void* ctx);
+static uint32_t k_random_nodes(swim_sim* s, uint32_t r, uint32_t o, uint32_t stream, uint32_t k, excl_fn ex, void* ctx, uint32_t* out) {
+  draws_t d; draws_init(&d, seed_of(s, r), stream, s->tick, o);
+  uint32_t found = 0; uint64_t tries = 3ull * s->N;
+  for (uint64_t i = 0; i < tries && found < k; i++) {
+    uint32_t x = draws_get(&d, (uint32_t)i) % s->N;
+    if (ex(s, r, o, x, ctx)) continue;
+    int dup = 0; for (uint32_t j = 0; j < found; j++) if (out[j] == x) dup = 1;
+    if (dup) continue;
+    out[found++] = x;
+  }
+  return found;
+}
+
+/* gossip(): exclude self, Left, and Dead for longer than GossipToTheDeadTime */
+static int excl_gossip(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* ctx) {
+  (void)ctx; if (x == o) return 1;
+  uint32_t since, key = view_key(s, r, o, x, &since);
+  switch (KST(key)) {
+    case SWIM_STATE_ALIVE: case SWIM_STATE_SUSPECT: return 0;
+    case SWIM_STATE_DEAD: return now_ms(s) - since > s->cfg.gossip_to_dead_ms;
+    default: return 1;
+  }
+}
+/* probeNode indirect helpers: exclude self, the target, and anything not Alive */
+static int excl_indirect(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* ctx) {
+  uint32_t target = *(uint32_t*)ctx; if (x == o || x == target) return 1;
+  return KST(view_key(s, r, o, x, NULL)) != SWIM_STATE_ALIVE;
+}
+
+/* probeNode's failure epilogue: awareness delta then suspectNode(suspect{inc, node, self}) */
+static void probe_conclude(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
+  uint32_t x = nd->pr_target;
+  awareness_delta(s, nd, (int)nd->pr_nack_miss);
+  s->st.probe_failures++; s->st.nacks_missed += nd->pr_nack_miss;
+  if (s->node_slot[(size_t)r * s->N + x] == SWIM_NONE) emit_slot_request(s, r, x);
+  emit(s, r, o, x, nd->pr_inc, SWIM_MSG_SUSPECT, o);     /* node.Incarnation of the copy probe() took */
+  nd->pr_target = SWIM_NONE; nd->pr_stage = 0;
+}
+
+/* probe(): walk the shuffled list to the next node that is not self / dead / left */
+static void probe_start(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
+  uint32_t num_check = 0, x = SWIM_NONE, key = 0;
+  while (num_check < s->N) {
+    if (nd->pr_cursor >= s->N) { nd->pr_epoch++; nd->pr_cursor = 0; num_check++; continue; }   /* resetNodes */
+    uint32_t c = probe_perm(seed_of(s, r), s->N, o, nd->pr_epoch, nd->pr_cursor++);
+    key = view_key(s, r, o, c, NULL);
+    if (c == o || KST(key) == SWIM_STATE_DEAD || KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
+    x = c; break;
+  }
+  if (x == SWIM_NONE) return;
+  s->st.probes++;
+  /* probeNode: direct ping; a non-alive target also gets suspect{} so it can refute early */
+  int fwd = reach(s, r, o, x, o, 16);
+  if (fwd && KST(key) != SWIM_STATE_ALIVE && (s->cfg.flags & SWIM_F_BUDDY_SUSPECT))
+    emit(s, r, x, x, KINC(key), SWIM_MSG_SUSPECT, o);
+  if (fwd && !lost(s, r, o, 17)) { awareness_delta(s, nd, -1); s->st.probe_acks++; return; }
+  nd->pr_target = x; nd->pr_inc = KINC(key); nd->pr_t0 = s->tick; nd->pr_stage = 1; nd->pr_nack_miss = 1;
+  nd->pr_deadline = s->tick + s->d.probe_period * ((uint32_t)nd->awareness + 1);   /* awareness.ScaleTimeout */
+}
+
+/* ProbeTimeout after the ping: indirectPingReq to IndirectChecks random alive peers; each either
+ * relays the target's ack, or (Lifeguard) answers nack one further ProbeTimeout later */
+static void probe_indirect(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
+  uint32_t x = nd->pr_target, peers[8];
+  uint32_t np = k_random_nodes(s, r, o, STREAM_INDIRECT, s->cfg.indirect_checks, excl_indirect, &x, peers);
+  uint32_t expected = 0, nacks = 0; int acked = 0;
+  int nack_in_time = 2 * s->d.probe_timeout_ticks < nd->pr_deadline - nd->pr_t0;
+  for (uint32_t q = 0; q < np; q++) {
+    uint32_t h = peers[q];
+    if (s->cfg.flags & SWIM_F_NACK) expected++;
+    if (!reach(s, r, o, h, o, 20 + 4 * q)) continue;
+    int ok = reach(s, r, h, x, o, 21 + 4 * q) && reach(s, r, x, h, o, 22 + 4 * q);
+    int back = reach(s, r, h, o, o, 23 + 4 * q);
+    if (ok && back) acked = 1;
+    else if (!ok && back && nack_in_time) nacks++;
+  }
+  nd->pr_stage = 2;
+  if (acked) { awareness_delta(s, nd, -1); s->st.probe_indirect_acks++; nd->pr_target = SWIM_NONE; nd->pr_stage = 0; return; }
+  nd->pr_nack_miss = expected > 0 ? (uint8_t)(expected - nacks) : 1;
+}
+
+static void phase_probe(swim_sim* s) {
+  uint32_t P = s->d.probe_period, TQ = s->d.probe_timeout_ticks, t = s->tick;
+  for (uint32_t r = 0; r < s->R; r++) {
+    if (t >= TQ) {
+      uint32_t ph = (t - TQ) % P;
+      for (uint32_t k = 0; k < s->nloc; k++) {
+        uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
+        if (pphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+        if (nd->pr_stage == 1 && nd->pr_t0 + TQ == t) probe_indirect(s, r, o, nd);
+      }
+    }
+    uint32_t ph = t % P;
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
+      if (pphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (nd->pr_stage != 0) { if (t < nd->pr_deadline) continue; probe_conclude(s, r, o, nd); }
+      probe_start(s, r, o, nd);
+    }
+  }
+}
+
+/* gossip(): k random peers; per peer one getBroadcasts() = memberlist queue, then the serf
+ * delegate's user events in the bytes that remain; stop at the first empty packet */
+static void phase_gossip(swim_sim* s) {
+  uint32_t G = s->d.gossip_period, ph = s->tick % G;
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
+      if (gphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (!nd->qlen && !nd->evqlen) { s->st.node_rounds_quiescent++; continue; }
+      s->st.node_rounds_active++;
+      uint32_t peers[8], np = k_random_nodes(s, r, o, STREAM_GOSSIP, s->cfg.gossip_nodes, excl_gossip, NULL, peers);
+      for (uint32_t p = 0; p < np; p++) {
+        qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
+        uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, (int32_t)s->d.packet_budget, msgs, &used);
+        int32_t avail = (int32_t)s->d.packet_budget - used;
+        if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2);
+        if (!n) break;
+        s->st.packets_sent++;
+        for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
+        if (!reach(s, r, o, peers[p], o, p)) { s->st.packets_dropped++; continue; }
+        for (uint32_t m = 0; m < n; m++) emit(s, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+      }
+    }
+}
+
+static int edge_cmp(const void* a, const void* b) {
+  const swim_edge *x = (const swim_edge*)a, *y = (const swim_edge*)b;
+  uint32_t tx = x->meta >> 30, ty = y->meta >> 30, ux = tx == SWIM_MSG_USER, uy = ty == SWIM_MSG_USER;
+  if (ux != uy) return ux < uy ? -1 : 1;
+  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
+  if (tx != ty) return tx < ty ? -1 : 1;
+  if (x->incarnation != y->incarnation) return x->incarnation < y->incarnation ? -1 : 1;
+  if (x->meta != y->meta) return x->meta < y->meta ? -1 : 1;
+  return 0;
+}
+static int ctrl_cmp(const void* a, const void* b) {
+  const swim_edge *x = (const swim_edge*)a, *y = (const swim_edge*)b;
+  if (x->incarnation != y->incarnation) return x->incarnation < y->incarnation ? -1 : 1;
+  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
+  return 0;
+}
+
+/* packetListen -> handleCommand -> handleAlive/Suspect/Dead/User for everything that arrived */
+static void phase_deliver_resolve(swim_sim* s) {
+  /* subject-slot requests first, in (replica, id) order so every shard allocates identically */
+  uint32_t nc = 0;
+  for (uint32_t i = 0; i < s->in.n; i++) if (s->in.v[i].dst == SWIM_NONE) nc++;
+  if (nc) {
+    swim_edge* c = (swim_edge*)malloc(nc * sizeof(swim_edge)); uint32_t j = 0;
+    for (uint32_t i = 0; i < s->in.n; i++) if (s->in.v[i].dst == SWIM_NONE) c[j++] = s->in.v[i];
+    qsort(c, nc, sizeof(swim_edge), ctrl_cmp);
+    for (uint32_t i = 0; i < nc; i++) alloc_slot(s, c[i].incarnation, c[i].subject);
+    free(c);
+  }
+  /* scatter into per-node inboxes */
+  for (uint32_t i = 0; i < s->in.n; i++) {
+    swim_edge e = s->in.v[i]; if (e.dst == SWIM_NONE) continue;
+    uint32_t r = e.dst / s->N, x = e.dst % s->N;
+    if (!is_local(s, x) || !s->gt_alive[e.dst]) continue;
+    node_t* nd = node_at(s, r, x);
+    if (nd->in_cnt >= s->cfg.inbox_cap) { s->st.inbox_overflow++; continue; }
+    nd->inbox[nd->in_cnt++] = e;
+  }
+  /* merge, one observer at a time, in canonical message order, duplicates applied once */
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
+      if (!nd->in_cnt) continue;
+      qsort(nd->inbox, nd->in_cnt, sizeof(swim_edge), edge_cmp);
+      for (uint32_t i = 0; i < nd->in_cnt; i++) {
+        swim_edge e = nd->inbox[i];
+        if (i && edge_cmp(&nd->inbox[i - 1], &e) == 0) continue;
+        uint32_t type = e.meta >> 30, from = e.meta & 0x3FFFFFFFu;
+        switch (type) {
+          case SWIM_MSG_ALIVE: alive_node(s, r, o, nd, e.subject, e.incarnation, from); break;
+          case SWIM_MSG_SUSPECT: suspect_node(s, r, o, nd, e.subject, e.incarnation, from); break;
+          case SWIM_MSG_DEAD: dead_node(s, r, o, nd, e.subject, e.incarnation, from); break;
+          default: user_event(s, r, o, nd, e.subject, e.incarnation); break;
+        }
+      }
+      nd->in_cnt = 0;
+    }
+}
+
+static void census_slot(swim_sim* s, uint32_t r, slot_t* t) {
+  swim_census* c = &t->census;
+  c->n_observers = 0; memset(c->by_state, 0, sizeof c->by_state); c->n_current = 0;
+  for (uint32_t k = 0; k < s->nloc; k++) {
+    uint32_t o = s->i0 + k;
+    if (o == t->node || !s->gt_alive[(size_t)r * s->N + o]) continue;
+    c->n_observers++; c->by_state[KST(t->col[k].key)]++;
+    if (KINC(t->col[k].key) == t->max_inc) c->n_current++;
+  }
+  uint32_t now = now_ms(s);
+  if (c->first_suspect_ms == SWIM_NONE && c->by_state[SWIM_STATE_SUSPECT]) c->first_suspect_ms = now;
+  if (c->first_dead_ms == SWIM_NONE && (c->by_state[SWIM_STATE_DEAD] || c->by_state[SWIM_STATE_LEFT])) c->first_dead_ms = now;
+  if (c->all_dead_ms == SWIM_NONE && c->n_observers && c->by_state[SWIM_STATE_DEAD] + c->by_state[SWIM_STATE_LEFT] == c->n_observers) c->all_dead_ms = now;
+  if (c->all_current_ms == SWIM_NONE && c->n_observers && t->max_inc > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+  t->dirty = 0;
+}
+
+static void phase_bookkeep(swim_sim* s) {
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
+      slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+      if (t->dirty) census_slot(s, r, t);
+      if (t->trace && s->tick < s->cfg.trace_ticks) {
+        uint32_t* row = &t->trace[(size_t)s->tick * 5];
+        memcpy(row, t->census.by_state, 4 * sizeof(uint32_t)); row[4] = t->census.n_current;
+      }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* C-ABI                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+const char* swim_backend(void) { return "oracle-c"; }
+const char* swim_last_error(swim_sim* s) { return s ? s->err : "null handle"; }
+
+int swim_create(const swim_config* cfg, swim_sim** out) {
+  swim_derived d; int rc = swim_config_derive(cfg, &d); if (rc) return rc;
+  if (!out) return SWIM_EINVAL;
+  swim_sim* s = (swim_sim*)calloc(1, sizeof *s); if (!s) return SWIM_ENOMEM;
+  s->cfg = *cfg; s->d = d; s->N = cfg->n_nodes; s->R = cfg->n_replicas;
+  s->nloc = s->N / cfg->n_shards; s->i0 = cfg->shard_rank * s->nloc; s->loss_q32 = cfg->loss_q32;
+  size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
+  s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1);
+  s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
+  s->slots = (slot_t*)calloc((size_t)s->R * cfg->subject_cap, sizeof(slot_t));
+  s->n_slots = (uint32_t*)calloc(s->R, 4); s->out = (edgevec*)calloc(cfg->n_shards, sizeof(edgevec));
+  if (!s->gt_alive || !s->part || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out) { swim_destroy(s); return SWIM_ENOMEM; }
+  memset(s->gt_alive, 1, NT); memset(s->node_slot, 0xFF, NT * 4);
+  for (size_t g = 0; g < NL; g++) {
+    node_t* nd = &s->nodes[g];
+    nd->self_inc = 1; nd->pr_target = SWIM_NONE;
+    nd->inbox = (swim_edge*)malloc((size_t)cfg->inbox_cap * sizeof(swim_edge));
+    if (cfg->flags & SWIM_F_SERF_EVENTS) nd->ring = (evslot*)calloc(cfg->event_buffer, sizeof(evslot));
+    if (!nd->inbox || ((cfg->flags & SWIM_F_SERF_EVENTS) && !nd->ring)) { swim_destroy(s); return SWIM_ENOMEM; }
+  }
+  *out = s; return SWIM_OK;
+}
+
+int swim_destroy(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].inbox); free(s->nodes[g].ring); }
+  if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) { free(s->slots[i].col); free(s->slots[i].trace); }
+  if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
+  free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
+  free(s->out); free(s->in.v); free(s->last_edges.v); free(s->events); free(s);
+  return SWIM_OK;
+}
+
+int swim_tick_begin(swim_sim* s) {
+  if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
+  for (uint32_t i = 0; i < s->cfg.n_shards; i++) s->out[i].n = 0;
+  s->in.n = 0;
+  phase_expire(s); phase_probe(s); phase_gossip(s);
+  s->in_tick = 1;
+  /* the local segment never crosses the wire */
+  edgevec* loc = &s->out[s->cfg.shard_rank];
+  for (uint32_t i = 0; i < loc->n; i++) ev_push(&s->in, loc->v[i]);
+  s->last_edges.n = 0;
+  for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++)
+    for (uint32_t i = 0; i < s->out[sh].n; i++) if (s->out[sh].v[i].dst != SWIM_NONE) ev_push(&s->last_edges, s->out[sh].v[i]);
+  return SWIM_OK;
+}
+int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr, uint32_t* count) {
+  if (!s || !ptr || !count || shard >= s->cfg.n_shards) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  *ptr = s->out[shard].v; *count = s->out[shard].n; return SWIM_OK;
+}
+int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
+  if (!s || (!ptr && count)) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  for (uint32_t i = 0; i < count; i++) ev_push(&s->in, ptr[i]);
+  return SWIM_OK;
+}
+int swim_tick_end(swim_sim* s) {
+  if (!s) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  phase_deliver_resolve(s); phase_bookkeep(s);
+  s->st.ticks++; if ((s->tick + 1) % s->d.gossip_period == 0) s->st.gossip_rounds++;
+  s->tick++; s->in_tick = 0;
+  return SWIM_OK;
+}
+int swim_step(swim_sim* s, uint32_t n) {
+  if (!s) return SWIM_EINVAL; if (s->cfg.n_shards != 1) return SWIM_ESTATE;
+  for (uint32_t i = 0; i < n; i++) { int rc = swim_tick_begin(s); if (rc) return rc; rc = swim_tick_end(s); if (rc) return rc; }
+  return SWIM_OK;
+}
+int swim_sync(swim_sim* s) { return s ? SWIM_OK : SWIM_EINVAL; }
+int swim_now(swim_sim* s, uint32_t* tick, uint32_t* ms) {
+  if (!s) return SWIM_EINVAL; if (tick) *tick = s->tick; if (ms) *ms = now_ms(s); return SWIM_OK;
+}
+
+static int chk(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  if (!s || (!ids && n)) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->R) return SWIM_ERANGE;
+  for (size_t i = 0; i < n; i++) if (ids[i] >= s->N) return SWIM_ERANGE;
+  return SWIM_OK;
+}
+static void dirty_all(swim_sim* s, uint32_t r) {
+  for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) s->slots[(size_t)r * s->cfg.subject_cap + sl].dirty = 1;
+}
+int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  for (size_t i = 0; i < n; i++) s->gt_alive[(size_t)r * s->N + ids[i]] = 0;
+  dirty_all(s, r); return SWIM_OK;
+}
+int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  for (size_t i = 0; i < n; i++) {
+    s->gt_alive[(size_t)r * s->N + ids[i]] = 1;
+    if (is_local(s, ids[i])) { node_t* nd = node_at(s, r, ids[i]); nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->in_cnt = 0; }
+  }
+  dirty_all(s, r); return SWIM_OK;
+}
+/* memberlist.Leave: deadNode(dead{inc, self, self}) with hasLeft() set */
+int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t x = ids[i]; rc = alloc_slot(s, r, x); if (rc) return rc;
+    if (!is_local(s, x) || !s->gt_alive[(size_t)r * s->N + x]) continue;
+    node_t* nd = node_at(s, r, x); nd->leaving = 1;
+    dead_node(s, r, x, nd, x, nd->self_inc, x);
+  }
+  return SWIM_OK;
+}
+/* memberlist.UpdateNode: nextIncarnation(); aliveNode(alive{inc}, bootstrap=true) */
+int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t x = ids[i]; rc = alloc_slot(s, r, x); if (rc) return rc;
+    if (!is_local(s, x) || !s->gt_alive[(size_t)r * s->N + x]) continue;
+    node_t* nd = node_at(s, r, x); nd->self_inc++;
+    slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + s->node_slot[(size_t)r * s->N + x]];
+    set_view(s, r, t, &t->col[x - s->i0], nd->self_inc, SWIM_STATE_ALIVE, 0);
+    broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 1);
+  }
+  return SWIM_OK;
+}
+int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
+  if (!s || !g) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE; if (r >= s->R) return SWIM_ERANGE;
+  memcpy(s->part + (size_t)r * s->N, g, s->N); return SWIM_OK;
+}
+int swim_set_loss(swim_sim* s, uint32_t q) { if (!s) return SWIM_EINVAL; s->loss_q32 = q; return SWIM_OK; }
+
+/* serf.UserEvent: stamp eventClock.Time(), Increment(), handleUserEvent locally, queue */
+int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
+  int rc = chk(s, r, &origin, 1); if (rc) return rc;
+  if (!(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
+  if (lt) *lt = SWIM_NONE;
+  if (!is_local(s, origin) || !s->gt_alive[(size_t)r * s->N + origin]) return SWIM_OK;
+  node_t* nd = node_at(s, r, origin);
+  uint32_t ltime = nd->ev_clock; nd->ev_clock++;
+  if (lt) *lt = ltime;
+  user_event(s, r, origin, nd, id, ltime);
+  return SWIM_OK;
+}
+
+static uint8_t status_of(uint32_t st) {
+  return st == SWIM_STATE_DEAD ? SWIM_MEMBER_FAILED : st == SWIM_STATE_LEFT ? SWIM_MEMBER_LEFT : SWIM_MEMBER_ALIVE;
+}
+int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out) {
+  if (!s || !out) return SWIM_EINVAL; if (r >= s->R || o >= s->N || x >= s->N) return SWIM_ERANGE;
+  if (!is_local(s, o)) return SWIM_ERANGE;
+  view_t* v = view_ptr(s, r, o, x);
+  memset(out, 0, sizeof *out); out->id = x;
+  uint32_t key = v ? v->key : BASE_KEY;
+  out->incarnation = KINC(key); out->state = (uint8_t)KST(key); out->state_change_ms = v ? v->since : 0;
+  out->n_confirm = v && KST(key) == SWIM_STATE_SUSPECT ? v->nconf : 0;
+  out->status = status_of(KST(key));
+  if (x == o && node_at(s, r, o)->leaving && out->state == SWIM_STATE_ALIVE) out->status = SWIM_MEMBER_LEAVING;
+  return SWIM_OK;
+}
+int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap)) return SWIM_EINVAL; if (r >= s->R || o >= s->N) return SWIM_ERANGE;
+  if (!is_local(s, o)) return SWIM_ERANGE;
+  for (uint32_t x = 0; x < s->N && x < cap; x++) swim_view(s, r, o, x, &out[x]);
+  if (n_out) *n_out = s->N; return SWIM_OK;
+}
+int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
+  size_t n = s->n_events < cap ? s->n_events : cap;
+  memcpy(out, s->events, n * sizeof(swim_event));
+  memmove(s->events, s->events + n, (s->n_events - n) * sizeof(swim_event));
+  s->n_events -= n; *n_out = n; return SWIM_OK;
+}
+static int rumour_cmp(const void* a, const void* b) {
+  const swim_rumour *x = (const swim_rumour*)a, *y = (const swim_rumour*)b;
+  return x->seq < y->seq ? -1 : x->seq > y->seq;
+}
+int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out) {
+  if (!s || !out) return SWIM_EINVAL; if (r >= s->R || i >= s->N || !is_local(s, i)) return SWIM_ERANGE;
+  node_t* nd = node_at(s, r, i); memset(out, 0, sizeof *out);
+  out->incarnation = nd->self_inc; out->probe_target = nd->pr_target;
+  out->probe_deadline_tick = nd->pr_target == SWIM_NONE ? 0 : nd->pr_deadline;
+  out->probe_cursor = nd->pr_cursor; out->probe_epoch = nd->pr_epoch;
+  out->queue_len = nd->qlen; out->event_queue_len = nd->evqlen; out->event_clock = nd->ev_clock;
+  out->alive = s->gt_alive[(size_t)r * s->N + i]; out->leaving = nd->leaving; out->awareness = nd->awareness;
+  out->partition = s->part[(size_t)r * s->N + i];
+  for (uint32_t k = 0; k < nd->qlen; k++) {
+    swim_rumour q = { nd->q[k].subject, nd->q[k].inc, nd->q[k].from, nd->q[k].type, nd->q[k].transmits, {0, 0}, nd->q[k].seq };
+    out->queue[k] = q;
+  }
+  qsort(out->queue, nd->qlen, sizeof(swim_rumour), rumour_cmp);
+  return SWIM_OK;
+}
+int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {
+  if (!s || !out) return SWIM_EINVAL; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
+  if (sl == SWIM_NONE) {            /* nobody has news: everyone holds the base view */
+    memset(out, 0, sizeof *out);
+    for (uint32_t k = 0; k < s->nloc; k++) if (s->i0 + k != x && s->gt_alive[(size_t)r * s->N + s->i0 + k]) out->n_observers++;
+    out->by_state[SWIM_STATE_ALIVE] = out->n_current = out->n_observers;
+    out->first_suspect_ms = out->first_dead_ms = out->all_dead_ms = out->all_current_ms = SWIM_NONE;
+    return SWIM_OK;
+  }
+  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+  if (t->dirty) census_slot(s, r, t);
+  *out = t->census; return SWIM_OK;
+}
+int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
+  if (!s || !rows) return SWIM_EINVAL; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
+  if (sl == SWIM_NONE || !s->cfg.trace_ticks) return SWIM_ESTATE;
+  if ((uint64_t)first + n > s->cfg.trace_ticks || first + n > s->tick) return SWIM_ERANGE;
+  memcpy(rows, &s->slots[(size_t)r * s->cfg.subject_cap + sl].trace[(size_t)first * 5], (size_t)n * 5 * 4);
+  return SWIM_OK;
+}
+int swim_stats(swim_sim* s, swim_stats_t* out) { if (!s || !out) return SWIM_EINVAL; *out = s->st; return SWIM_OK; }
+int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
+  size_t n = s->last_edges.n < cap ? s->last_edges.n : cap;
+  memcpy(out, s->last_edges.v, n * sizeof(swim_edge)); *n_out = s->last_edges.n; return SWIM_OK;
+}
+
+/* order-independent digest: wrapping sum of per-item hashes, every item tagged with its global
+ * identity, so the value does not depend on slot numbering, queue order or sharding layout
+ * (shards add their digests) */
+static uint64_t h3(uint64_t tag, uint64_t a, uint64_t b) { return mix64(mix64(tag * 0x9E3779B97F4A7C15ull + a) ^ (b + 0x7F4A7C15ull)); }
+int swim_state_digest(swim_sim* s, uint64_t* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  uint64_t d = 0;
+  for (uint32_t r = 0; r < s->R; r++) {
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t i = s->i0 + k; node_t* nd = node_at(s, r, i); uint64_t g = (uint64_t)r * s->N + i;
+      d += h3(1, g, ((uint64_t)nd->self_inc << 32) | ((uint64_t)nd->awareness << 8) | nd->leaving);
+      d += h3(2, g, ((uint64_t)nd->pr_cursor << 32) | nd->pr_epoch);
+      if (nd->pr_target != SWIM_NONE)
+        d += h3(3, g, ((uint64_t)nd->pr_target << 32) | nd->pr_deadline) + h3(4, g, ((uint64_t)nd->pr_inc << 32) | ((uint64_t)nd->pr_stage << 8) | nd->pr_nack_miss);
+      for (uint32_t q = 0; q < nd->qlen; q++) {
+        const qent* e = &nd->q[q];
+        d += h3(5, g, h3(e->subject, ((uint64_t)e->inc << 32) | e->from, ((uint64_t)e->seq << 16) | ((uint64_t)e->transmits << 8) | e->type));
+      }
+      d += h3(6, g, ((uint64_t)nd->qseq << 32) | nd->ev_clock);
+      for (uint32_t q = 0; q < nd->evqlen; q++) {
+        const qent* e = &nd->evq[q];
+        d += h3(7, g, h3(e->subject, e->inc, ((uint64_t)e->seq << 16) | ((uint64_t)e->transmits << 8)));
+      }
+      if (nd->ring)
+        for (uint32_t b = 0; b < s->cfg.event_buffer; b++)
+          for (uint32_t j = 0; j < nd->ring[b].n; j++) d += h3(8, g, ((uint64_t)nd->ring[b].ltime << 32) | nd->ring[b].ids[j]);
+    }
+    for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
+      slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+      for (uint32_t k = 0; k < s->nloc; k++) {
+        view_t* v = &t->col[k]; if (v->key == BASE_KEY && v->since == 0) continue;
+        uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)t->node * 0x100000001B3ull) ^ ((uint64_t)(s->i0 + k) << 8);
+        d += h3(9, id, ((uint64_t)v->key << 32) | v->since);
+        if (KST(v->key) == SWIM_STATE_SUSPECT) {
+          d += h3(10, id, v->nconf);
+          for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX; j++) d += h3(11 + j, id, v->conf[j]);
+        }
+      }
+    }
+  }
+  *out = d; return SWIM_OK;
+}
+
+int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, const swim_edge* m, size_t n) {
+  (void)s; (void)r; (void)a; (void)dst; (void)m; (void)n; return SWIM_ESTATE;
+}
+int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edge* o, size_t cap, size_t* n) {
+  (void)s; (void)r; (void)a; (void)o; (void)cap; if (n) *n = 0; return SWIM_ESTATE;
+}
+
+/* known-answer hooks */
+void swim_kat_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out); }
+uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) { return probe_perm(seed, n, node, epoch, index); }
+int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t el, uint32_t mn, uint32_t mx) { return (int32_t)remaining_suspicion_ms(n, k, el, mn, mx); }
+void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gp, uint32_t* pp) {
+  swim_derived d; if (swim_config_derive(cfg, &d)) { if (gp) *gp = SWIM_NONE; if (pp) *pp = SWIM_NONE; return; }
+  uint32_t c = node / d.phase_chunk;
+  if (gp) *gp = c % d.gossip_period; if (pp) *pp = (c / d.gossip_period) % d.probe_period;
+}
