@@ -1,0 +1,158 @@
+// swim_device.h — device-side data layout and helpers shared by the gfx950 kernels.
+//
+// One lane = one virtual memberlist node.  All per-node state is structure-of-arrays in HBM so a
+// wave's 64 consecutive nodes read 64 consecutive 4/16-byte words.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/swimsim.h"
+
+#define SW_MAX_SHARDS 16
+#define SW_CONF_MAX 4
+#define SW_BLOCK 256
+
+// counters mirrored 1:1 into swim_stats_t by the host
+enum {
+  ST_ACTIVE = 0, ST_QUIESCENT, ST_PKT_SENT, ST_PKT_DROP,
+  ST_SENT0, ST_SENT1, ST_SENT2, ST_SENT3,
+  ST_APPL0, ST_APPL1, ST_APPL2, ST_APPL3,
+  ST_PROBES, ST_ACKS, ST_IACKS, ST_PFAIL, ST_NACKMISS,
+  ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
+  ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
+  ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE,
+  ST_COUNT
+};
+
+// sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync/swim_stats)
+#define SW_ERR_EDGE_OVF 0x1u
+#define SW_ERR_INBOX_OVF 0x2u
+#define SW_ERR_SUBJ_OVF 0x4u
+#define SW_ERR_CTRL_OVF 0x8u
+#define SW_ERR_EVENT_OVF 0x10u
+
+// per-slot census accumulators (one row per replica*subject_cap slot)
+enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
+
+struct SwDev {
+  // dimensions
+  uint32_t N, R, nloc, i0, S, Q, C, EQ, EB;
+  uint32_t G, P, TQ, CH, quantum_ms;
+  uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
+  uint32_t budget, flags, watch, trace_ticks, n_shards, rank;
+  uint32_t msg_len[4];
+  uint32_t susp_timeout[8];
+  uint32_t loss_q32;
+  uint64_t seed;
+  // global clock (device resident so a captured graph is tick independent)
+  uint32_t* tick;
+  // replicated ground truth, R*N
+  uint8_t* gt_alive;
+  uint8_t* part;
+  uint32_t* node_slot;
+  // per local lane, NL = R*nloc
+  uint4* hdr;       // {self_inc, awareness | leaving<<8 | qlen<<16 | evqlen<<24, qseq, ev_clock}
+  uint4* pr0;       // {target, inc_at_start, deadline_tick, t0}
+  uint4* pr1;       // {cursor, epoch, stage | nack_miss<<8, evqseq}
+  uint4* q;         // [Q][NL]  {subject, inc, from, type<<30 | transmits<<22 | seq}
+  uint4* evq;       // [EQ][NL] {event id, ltime, 0, meta}
+  uint4* ring;      // [EB][NL] {n<<30 | ltime, id0, id1, id2}
+  uint32_t* in_cnt; // [NL]
+  uint4* inbox;     // [C][NL] swim_edge
+  // per (replica, slot) view columns, [R*S][nloc]
+  uint32_t* v_key;
+  uint32_t* v_since;
+  uint8_t* v_nconf;
+  uint4* v_conf;
+  // slot tables
+  uint32_t* subj_node;   // [R*S]
+  uint32_t* n_slots;     // [R]
+  uint32_t* slot_dirty;  // [R*S]
+  uint32_t* slot_maxinc; // [R*S]
+  uint32_t* slot_susp;   // [R*S] suspect count at last census
+  uint32_t* slot_mindl;  // [R*S] earliest suspicion deadline at last census
+  uint32_t* cen_acc;     // [R*S][CEN_WORDS] accumulators
+  swim_census* census;   // [R*S] cached
+  uint32_t* trace;       // [R*S][trace_ticks][5]
+  // edge lists
+  uint4* out[SW_MAX_SHARDS];
+  uint32_t* out_cnt;     // [n_shards]
+  uint32_t out_cap[SW_MAX_SHARDS];
+  uint4* ctrl;           // slot requests seen this tick
+  uint32_t* ctrl_cnt;
+  uint32_t ctrl_cap;
+  // events, stats, errors
+  swim_event* events;
+  uint32_t* ev_cnt;
+  uint32_t ev_cap;
+  unsigned long long* stats;
+  uint32_t* err;
+};
+
+#define SW_KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
+#define SW_KINC(k) ((k) >> 2)
+#define SW_KST(k) ((k) & 3u)
+#define SW_BASE_KEY SW_KEY(1, SWIM_STATE_ALIVE)
+
+enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4 };
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10: counter-based, so a draw depends on (seed, stream, tick, node, index) only.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void sw_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                          uint32_t k0, uint32_t k1, uint32_t o[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__host__ __device__ inline uint32_t sw_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+__host__ __device__ inline uint64_t sw_mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return x;
+}
+__host__ __device__ inline uint64_t sw_h3(uint64_t tag, uint64_t a, uint64_t b) {
+  return sw_mix64(sw_mix64(tag * 0x9E3779B97F4A7C15ull + a) ^ (b + 0x7F4A7C15ull));
+}
+
+// sequential draws of one (stream, tick, node): word idx&3 of Philox block idx>>2
+struct SwDraws {
+  uint32_t k0, k1, tick, node, blk, w[4];
+  __host__ __device__ void init(uint64_t seed_r, uint32_t stream, uint32_t t, uint32_t n) {
+    k0 = (uint32_t)seed_r; k1 = (uint32_t)(seed_r >> 32) ^ stream; tick = t; node = n; blk = 0xFFFFFFFFu;
+  }
+  __host__ __device__ uint32_t get(uint32_t idx) {
+    uint32_t b = idx >> 2;
+    if (b != blk) { sw_philox(tick, node, b, 0, k0, k1, w); blk = b; }
+    uint32_t i = idx & 3;
+    return i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : w[3];
+  }
+};
+
+// keyed permutation of [0,n): position `index` of `node`'s epoch-th probe order
+__host__ __device__ inline uint32_t sw_probe_perm(uint64_t seed_r, uint32_t n, uint32_t node,
+                                                  uint32_t epoch, uint32_t index) {
+  if (n <= 1) return 0;
+  uint32_t bits = 1;
+  while ((1u << bits) < n && bits < 32) bits++;
+  uint32_t h = (bits + 1) / 2, mask = (1u << h) - 1, rk[4];
+  sw_philox(node, epoch, 0, 0x50524D31u, (uint32_t)seed_r, (uint32_t)(seed_r >> 32) ^ SW_STREAM_PERM, rk);
+  uint32_t x = index;
+  do {
+    uint32_t l = x >> h, r = x & mask;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { uint32_t t = l ^ (sw_fmix32(r ^ rk[i]) & mask); l = r; r = t; }
+    x = (l << h) | r;
+  } while (x >= n);
+  return x;
+}

@@ -1,0 +1,657 @@
+// swim_host.hip — C-ABI of libswimsim.so (include/swimsim.h) over the gfx950 kernels.
+//
+// Host responsibilities only: validate the memberlist.Config mirror, evaluate the closed-form
+// constants once (util.go / suspicion.go formulas with Go's float64 semantics), lay the state out
+// in HBM, and enqueue the per-tick kernel sequence on one HIP stream.  There is no CPU fallback:
+// without a HIP device swim_create returns SWIM_ENODEV.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "swim_kernels.hip"
+
+#define HIPCK(s, call)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      if (s) snprintf((s)->err, sizeof((s)->err), "%s failed: %s", #call, hipGetErrorString(e_));   \
+      return e_ == hipErrorOutOfMemory ? SWIM_ENOMEM : SWIM_ENODEV;                                 \
+    }                                                                                               \
+  } while (0)
+
+struct swim_sim {
+  swim_config cfg;
+  swim_derived d;
+  SwDev D;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  uint32_t tick = 0;
+  bool in_tick = false;
+  uint64_t ticks_run = 0, rounds_run = 0;
+  // host mirrors / staging
+  uint32_t* d_last_cnt = nullptr;      // [n_shards] edge counts of the finished tick
+  uint32_t* d_scratch = nullptr;       // small device scratch (ids upload, ltime, digest)
+  size_t scratch_bytes = 0;
+  uint4* in_buf = nullptr;             // records received from other shards
+  uint32_t in_cap = 0, in_count = 0;
+  uint32_t out_counts[SW_MAX_SHARDS];  // host copy for swim_outbound
+  bool out_counts_valid = false;
+  uint32_t probe_lanes = 0, gossip_lanes = 0;
+  std::vector<swim_event> pending_events;
+  char err[256] = { 0 };
+};
+
+// ---------------------------------------------------------------------------------------------
+// closed-form constants (memberlist util.go, suspicion.go) — independent of the oracle's copy
+// ---------------------------------------------------------------------------------------------
+namespace {
+const double kLn2 = 0.693147180559945309417232121458176568;
+const double kLn10 = 2.30258509299404568401799145468436421;
+// Go's pure-Go math.Log2 (Frexp based) and math.Log10 = Log2(x) * (Ln2/Ln10)
+double go_log2(double x) {
+  int e; double f = std::frexp(x, &e);
+  if (f == 0.5) return (double)(e - 1);
+  return std::log(f) * (1.0 / kLn2) + (double)e;
+}
+double go_log10(double x) { return go_log2(x) * (kLn2 / kLn10); }
+uint32_t gcd32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
+
+int64_t remaining_suspicion_ms(uint32_t n, uint32_t k, int64_t elapsed, int64_t min_ms, int64_t max_ms) {
+  double frac = std::log((double)n + 1.0) / std::log((double)k + 1.0);
+  double raw = (double)max_ms / 1000.0 - frac * ((double)max_ms / 1000.0 - (double)min_ms / 1000.0);
+  int64_t timeout = (int64_t)std::floor(1000.0 * raw);
+  if (timeout < min_ms) timeout = min_ms;
+  return timeout - elapsed;
+}
+
+int validate(const swim_config* c) {
+  if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
+  if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 30)) return SWIM_ERANGE;
+  if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
+  if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
+  if (c->suspicion_mult < 1 || c->suspicion_mult > 6 || c->retransmit_mult < 1) return SWIM_EINVAL;
+  if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
+  if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
+  if (c->flags & SWIM_F_SERF_EVENTS)
+    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
+  if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
+  if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
+  return SWIM_OK;
+}
+}  // namespace
+
+extern "C" int swim_config_preset(swim_config* c, int preset) {
+  if (!c) return SWIM_EINVAL;
+  memset(c, 0, sizeof *c);
+  c->abi_version = SWIM_ABI_VERSION;
+  c->n_nodes = 128; c->n_replicas = 1;
+  // memberlist.DefaultLANConfig (agent/config/runtime.go:1285-1350 documents the six Consul knobs)
+  c->indirect_checks = 3; c->retransmit_mult = 4; c->suspicion_mult = 4;
+  c->suspicion_max_timeout_mult = 6; c->probe_timeout_ms = 500; c->probe_interval_ms = 1000;
+  c->awareness_max_mult = 8; c->gossip_nodes = 3; c->gossip_interval_ms = 200;
+  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400;
+  switch (preset) {
+    case SWIM_PRESET_LAN: break;
+    case SWIM_PRESET_WAN:   // memberlist.DefaultWANConfig (runtime.go:1362-1427)
+      c->suspicion_mult = 6; c->probe_timeout_ms = 3000; c->probe_interval_ms = 5000;
+      c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000; break;
+    case SWIM_PRESET_LOCAL:
+      c->indirect_checks = 1; c->retransmit_mult = 2; c->suspicion_mult = 3;
+      c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000; break;
+    default: return SWIM_EINVAL;
+  }
+  c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
+  c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
+  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
+  c->event_queue_cap = 8; c->event_buffer = 512;
+  c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
+  return SWIM_OK;
+}
+
+extern "C" int swim_config_derive(const swim_config* c, swim_derived* d) {
+  int rc = validate(c);
+  if (rc) return rc;
+  if (!d) return SWIM_EINVAL;
+  memset(d, 0, sizeof *d);
+  uint32_t q = c->quantum_ms ? c->quantum_ms
+                             : gcd32(gcd32(c->gossip_interval_ms, c->probe_interval_ms), c->probe_timeout_ms);
+  if (c->gossip_interval_ms % q || c->probe_interval_ms % q || c->probe_timeout_ms % q) return SWIM_EINVAL;
+  d->quantum_ms = q;
+  d->gossip_period = c->gossip_interval_ms / q;
+  d->probe_period = c->probe_interval_ms / q;
+  d->probe_timeout_ticks = c->probe_timeout_ms / q;
+  uint32_t ch = c->phase_chunk;
+  if (!ch) {
+    ch = 256;
+    while (ch > 1 && (uint64_t)ch * d->gossip_period * d->probe_period * 8 > c->n_nodes) ch >>= 1;
+  }
+  d->phase_chunk = ch;
+  const double n = (double)c->n_nodes;
+  d->retransmit_limit = c->retransmit_mult * (uint32_t)std::ceil(go_log10(n + 1.0));
+  double scale = std::max(1.0, go_log10(std::max(1.0, n)));
+  int64_t scale_milli = (int64_t)(scale * 1000.0);
+  d->node_scale_milli = (uint32_t)scale_milli;
+  int64_t min_ns = (int64_t)c->suspicion_mult * scale_milli * ((int64_t)c->probe_interval_ms * 1000000) / 1000;
+  int64_t max_ns = (int64_t)c->suspicion_max_timeout_mult * min_ns;
+  int64_t min_ms = min_ns / 1000000, max_ms = max_ns / 1000000;
+  if (max_ms > 0x7FFFFFFF) return SWIM_ERANGE;
+  d->suspicion_min_ms = (uint32_t)min_ms; d->suspicion_max_ms = (uint32_t)max_ms;
+  int32_t k = std::max(0, (int32_t)c->suspicion_mult - 2);
+  if ((int64_t)c->n_nodes - 2 < k) k = 0;
+  d->suspicion_k = (uint32_t)k;
+  d->suspicion_timeout_ms[0] = (uint32_t)(k < 1 ? min_ms : max_ms);
+  for (int32_t i = 1; i <= k && i < 8; i++)
+    d->suspicion_timeout_ms[i] = (uint32_t)remaining_suspicion_ms((uint32_t)i, (uint32_t)k, 0, min_ms, max_ms);
+  d->push_pull_scale = c->n_nodes <= 32 ? 1u : (uint32_t)(std::ceil(go_log2(n) - go_log2(32.0)) + 1.0);
+  d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
+  return SWIM_OK;
+}
+
+extern "C" const char* swim_backend(void) { return "hip-gfx950"; }
+extern "C" const char* swim_last_error(swim_sim* s) { return s ? s->err : "null handle"; }
+
+// ---------------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int dalloc(swim_sim* s, T** p, size_t count) {
+  void* v = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  HIPCK(s, hipMalloc(&v, bytes));
+  s->allocs.push_back(v);
+  *p = (T*)v;
+  return SWIM_OK;
+}
+#define DALLOC(s, p, n)                      \
+  do {                                       \
+    int rc_ = dalloc((s), &(p), (n));        \
+    if (rc_) { swim_destroy(s); return rc_; } \
+  } while (0)
+
+static uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+extern "C" int swim_destroy(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) hipFree(p);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+  return SWIM_OK;
+}
+
+extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
+  swim_derived d;
+  int rc = swim_config_derive(cfg, &d);
+  if (rc) return rc;
+  if (!out) return SWIM_EINVAL;
+  if (cfg->n_shards > SW_MAX_SHARDS) return SWIM_ERANGE;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || (int)cfg->device >= ndev) return SWIM_ENODEV;
+  swim_sim* s = new (std::nothrow) swim_sim();
+  if (!s) return SWIM_ENOMEM;
+  s->cfg = *cfg; s->d = d;
+  HIPCK(s, hipSetDevice((int)cfg->device));
+  {
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return SWIM_ENODEV; }
+  }
+  SwDev& D = s->D;
+  memset(&D, 0, sizeof D);
+  const bool serf = (cfg->flags & SWIM_F_SERF_EVENTS) != 0;
+  D.N = cfg->n_nodes; D.R = cfg->n_replicas; D.nloc = D.N / cfg->n_shards; D.i0 = cfg->shard_rank * D.nloc;
+  if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
+  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap;
+  D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
+  D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
+  D.quantum_ms = d.quantum_ms; D.k_gossip = cfg->gossip_nodes; D.k_indirect = cfg->indirect_checks;
+  D.retransmit_limit = d.retransmit_limit; D.susp_k = d.suspicion_k; D.awareness_max = cfg->awareness_max_mult;
+  D.gossip_to_dead_ms = cfg->gossip_to_dead_ms; D.budget = d.packet_budget; D.flags = cfg->flags;
+  D.watch = cfg->watch_node; D.trace_ticks = cfg->trace_ticks; D.n_shards = cfg->n_shards; D.rank = cfg->shard_rank;
+  for (int i = 0; i < 4; i++) D.msg_len[i] = cfg->msg_len[i];
+  for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
+  D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
+
+  const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S;
+  DALLOC(s, D.tick, 1);
+  DALLOC(s, D.gt_alive, NT); DALLOC(s, D.part, NT); DALLOC(s, D.node_slot, NT);
+  DALLOC(s, D.hdr, NL); DALLOC(s, D.pr0, NL); DALLOC(s, D.pr1, NL);
+  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox, NL * D.C);
+  if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); }
+  DALLOC(s, D.v_key, NS * D.nloc); DALLOC(s, D.v_since, NS * D.nloc);
+  DALLOC(s, D.v_nconf, NS * D.nloc); DALLOC(s, D.v_conf, NS * D.nloc);
+  DALLOC(s, D.subj_node, NS); DALLOC(s, D.n_slots, D.R); DALLOC(s, D.slot_dirty, NS);
+  DALLOC(s, D.slot_maxinc, NS); DALLOC(s, D.slot_susp, NS); DALLOC(s, D.slot_mindl, NS);
+  DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
+  if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
+
+  // active-set upper bounds (lanes per replica) for the stagger enumeration
+  const uint32_t nchunks = cdiv(D.nloc, D.CH) + 1;
+  s->gossip_lanes = (cdiv(nchunks, D.G) + 1) * D.CH;
+  s->probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
+  // worst-case records of one tick
+  const uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
+  uint64_t e_cap = (uint64_t)s->gossip_lanes * D.R * D.k_gossip * per_pkt + 2 * NL + 4096;
+  if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
+  for (uint32_t sh = 0; sh < D.n_shards; sh++) {
+    uint64_t cap = sh == D.rank ? e_cap : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096);
+    D.out_cap[sh] = (uint32_t)cap;
+    DALLOC(s, D.out[sh], cap);
+  }
+  DALLOC(s, D.out_cnt, SW_MAX_SHARDS); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
+  D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
+  D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
+  DALLOC(s, D.stats, ST_COUNT); DALLOC(s, D.err, 1);
+  s->scratch_bytes = 1 << 20; { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
+  if (D.n_shards > 1) { s->in_cap = (uint32_t)e_cap; DALLOC(s, s->in_buf, s->in_cap); }
+
+  hipStream_t st = s->stream;
+  HIPCK(s, hipMemsetAsync(D.tick, 0, 4, st));
+  HIPCK(s, hipMemsetAsync(D.gt_alive, 1, NT, st));
+  HIPCK(s, hipMemsetAsync(D.part, 0, NT, st));
+  HIPCK(s, hipMemsetAsync(D.node_slot, 0xFF, NT * 4, st));
+  HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
+  HIPCK(s, hipMemsetAsync(D.out_cnt, 0, SW_MAX_SHARDS * 4, st));
+  HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
+  HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
+  HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
+  HIPCK(s, hipMemsetAsync(D.stats, 0, ST_COUNT * 8, st));
+  HIPCK(s, hipMemsetAsync(D.err, 0, 4, st));
+  HIPCK(s, hipMemsetAsync(D.q, 0, NL * D.Q * sizeof(uint4), st));
+  if (serf) {
+    HIPCK(s, hipMemsetAsync(D.evq, 0, NL * D.EQ * sizeof(uint4), st));
+    HIPCK(s, hipMemsetAsync(D.ring, 0, NL * D.EB * sizeof(uint4), st));
+  }
+  if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
+  hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_init_views, dim3(cdiv(NS * D.nloc, 256)), dim3(256), 0, st, D);
+  hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, D);
+  HIPCK(s, hipStreamSynchronize(st));
+  HIPCK(s, hipGetLastError());
+  *out = s;
+  return SWIM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// time
+// ---------------------------------------------------------------------------------------------
+static int launch_begin(swim_sim* s) {
+  SwDev& D = s->D; hipStream_t st = s->stream;
+  const uint32_t xb = std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64);
+  hipLaunchKernelGGL(k_expire, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D);
+  const bool same = (D.TQ % D.P) == 0;
+  const uint32_t seg_b = same ? 0 : s->probe_lanes;
+  hipLaunchKernelGGL(k_probe, dim3(cdiv(seg_b + s->probe_lanes, SW_BLOCK), D.R), dim3(SW_BLOCK), 0, st, D, seg_b);
+  const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
+  hipLaunchKernelGGL(k_gossip, dim3(cdiv(s->gossip_lanes, SW_BLOCK), D.R), dim3(SW_BLOCK), lds, st, D);
+  return SWIM_OK;
+}
+static int launch_end(swim_sim* s) {
+  SwDev& D = s->D; hipStream_t st = s->stream;
+  const size_t NL = (size_t)D.nloc * D.R;
+  const uint32_t dgrid = std::min<uint32_t>(cdiv(D.out_cap[D.rank], SW_BLOCK), 2048);
+  hipLaunchKernelGGL(k_deliver, dim3(dgrid), dim3(SW_BLOCK), 0, st, D, (const uint4*)D.out[D.rank], (const uint32_t*)&D.out_cnt[D.rank], 0u);
+  if (s->in_count)
+    hipLaunchKernelGGL(k_deliver, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK), 2048)), dim3(SW_BLOCK), 0, st, D,
+                       (const uint4*)s->in_buf, (const uint32_t*)nullptr, s->in_count);
+  hipLaunchKernelGGL(k_alloc, dim3(1), dim3(64), 0, st, D);
+  hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, D);
+  const uint32_t xb = std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64);
+  hipLaunchKernelGGL(k_census, dim3(std::max(xb, 1u), D.R * D.S), dim3(SW_BLOCK), 0, st, D);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, D, s->d_last_cnt);
+  s->in_count = 0;
+  return SWIM_OK;
+}
+
+static int check_device_errors(swim_sim* s) {
+  uint32_t e = 0;
+  HIPCK(s, hipMemcpyAsync(&e, s->D.err, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  HIPCK(s, hipGetLastError());
+  if (e) {
+    snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s",
+             e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
+             e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
+             e & SW_ERR_EVENT_OVF ? " event-ring" : "");
+    return SWIM_EOVERFLOW;
+  }
+  return SWIM_OK;
+}
+
+extern "C" int swim_tick_begin(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  launch_begin(s);
+  s->in_tick = true; s->out_counts_valid = false; s->in_count = 0;
+  return SWIM_OK;
+}
+extern "C" int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr, uint32_t* count) {
+  if (!s || !ptr || !count || shard >= s->cfg.n_shards) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  if (!s->out_counts_valid) {
+    HIPCK(s, hipMemcpyAsync(s->out_counts, s->D.out_cnt, SW_MAX_SHARDS * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(s, hipStreamSynchronize(s->stream));
+    s->out_counts_valid = true;
+  }
+  *ptr = (const swim_edge*)s->D.out[shard];
+  *count = std::min(s->out_counts[shard], s->D.out_cap[shard]);
+  return SWIM_OK;
+}
+extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
+  if (!s || (!ptr && count)) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  if (!count) return SWIM_OK;
+  if ((uint64_t)s->in_count + count > s->in_cap) { snprintf(s->err, sizeof s->err, "inbound staging full"); return SWIM_EOVERFLOW; }
+  HIPCK(s, hipMemcpyAsync(s->in_buf + s->in_count, ptr, (size_t)count * sizeof(uint4), hipMemcpyDeviceToDevice, s->stream));
+  s->in_count += count;
+  return SWIM_OK;
+}
+extern "C" int swim_tick_end(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  launch_end(s);
+  s->in_tick = false; s->tick++; s->ticks_run++;
+  if (s->tick % s->d.gossip_period == 0) s->rounds_run++;
+  return SWIM_OK;
+}
+extern "C" int swim_step(swim_sim* s, uint32_t n) {
+  if (!s) return SWIM_EINVAL;
+  if (s->cfg.n_shards != 1 || s->in_tick) return SWIM_ESTATE;
+  for (uint32_t i = 0; i < n; i++) {
+    launch_begin(s); launch_end(s);
+    s->tick++; s->ticks_run++;
+    if (s->tick % s->d.gossip_period == 0) s->rounds_run++;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "launch failed: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
+  return SWIM_OK;
+}
+extern "C" int swim_sync(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  return check_device_errors(s);
+}
+extern "C" int swim_now(swim_sim* s, uint32_t* tick, uint32_t* ms) {
+  if (!s) return SWIM_EINVAL;
+  if (tick) *tick = s->tick;
+  if (ms) *ms = s->tick * s->d.quantum_ms;
+  return SWIM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stimulus
+// ---------------------------------------------------------------------------------------------
+static int upload_ids(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+  if (!s || (!ids && n)) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->D.R) return SWIM_ERANGE;
+  for (size_t i = 0; i < n; i++) if (ids[i] >= s->D.N) return SWIM_ERANGE;
+  if (n * 4 > s->scratch_bytes) return SWIM_ERANGE;
+  if (n) HIPCK(s, hipMemcpyAsync(s->d_scratch, ids, n * 4, hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));   // ids is caller memory
+  return SWIM_OK;
+}
+static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n) {
+  int rc = upload_ids(s, r, ids, n);
+  if (rc || !n) return rc;
+  if (op == INJ_LEAVE || op == INJ_UPDATE)
+    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, s->D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
+extern "C" int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_KILL, r, ids, n); }
+extern "C" int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_REVIVE, r, ids, n); }
+extern "C" int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_LEAVE, r, ids, n); }
+extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_UPDATE, r, ids, n); }
+extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
+  if (!s || !g) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->D.R) return SWIM_ERANGE;
+  HIPCK(s, hipMemcpyAsync(s->D.part + (size_t)r * s->D.N, g, s->D.N, hipMemcpyHostToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
+extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
+  if (!s) return SWIM_EINVAL;
+  s->D.loss_q32 = q;
+  return SWIM_OK;
+}
+extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
+  if (!s) return SWIM_EINVAL;
+  if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
+  if (r >= s->D.R || origin >= s->D.N) return SWIM_ERANGE;
+  hipLaunchKernelGGL(k_user_event, dim3(1), dim3(64), 0, s->stream, s->D, r, origin, id, s->d_scratch);
+  uint32_t v = SWIM_NONE;
+  HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  if (lt) *lt = v;
+  return SWIM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// observation
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int d2h(swim_sim* s, T* dst, const T* src, size_t n) {
+  HIPCK(s, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
+static uint8_t status_of(uint32_t st) {
+  return st == SWIM_STATE_DEAD ? SWIM_MEMBER_FAILED : st == SWIM_STATE_LEFT ? SWIM_MEMBER_LEFT : SWIM_MEMBER_ALIVE;
+}
+static bool is_local(const swim_sim* s, uint32_t i) { return i >= s->D.i0 && i < s->D.i0 + s->D.nloc; }
+
+extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
+  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out); out->id = x;
+  uint32_t key = SW_BASE_KEY, since = 0; uint8_t nconf = 0;
+  if (sl != SWIM_NONE) {
+    size_t ci = ((size_t)r * D.S + sl) * D.nloc + (o - D.i0);
+    if ((rc = d2h(s, &key, D.v_key + ci, 1)) || (rc = d2h(s, &since, D.v_since + ci, 1)) || (rc = d2h(s, &nconf, D.v_nconf + ci, 1))) return rc;
+  }
+  out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
+  out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? nconf : 0;
+  out->status = status_of(SW_KST(key));
+  if (x == o && out->state == SWIM_STATE_ALIVE) {
+    uint4 h; if ((rc = d2h(s, &h, D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+    if ((h.y >> 8) & 0xFF) out->status = SWIM_MEMBER_LEAVING;
+  }
+  return SWIM_OK;
+}
+extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap)) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || o >= D.N || !is_local(s, o)) return SWIM_ERANGE;
+  uint32_t ns = 0; int rc = d2h(s, &ns, D.n_slots + r, 1);
+  if (rc) return rc;
+  std::vector<uint32_t> subj(ns ? ns : 1);
+  if (ns && (rc = d2h(s, subj.data(), D.subj_node + (size_t)r * D.S, ns))) return rc;
+  size_t n = std::min<size_t>(cap, D.N);
+  for (size_t x = 0; x < n; x++) {
+    swim_member m; memset(&m, 0, sizeof m);
+    m.id = (uint32_t)x; m.incarnation = 1; m.state = SWIM_STATE_ALIVE; m.status = SWIM_MEMBER_ALIVE;
+    out[x] = m;
+  }
+  for (uint32_t sl = 0; sl < ns; sl++)
+    if (subj[sl] < n && (rc = swim_view(s, r, o, subj[sl], &out[subj[sl]]))) return rc;
+  if (o < n && (rc = swim_view(s, r, o, o, &out[o]))) return rc;
+  if (n_out) *n_out = D.N;
+  return SWIM_OK;
+}
+extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
+  uint32_t n = 0; int rc = d2h(s, &n, s->D.ev_cnt, 1);
+  if (rc) return rc;
+  n = std::min(n, s->D.ev_cap);
+  if (n) {
+    size_t base = s->pending_events.size();
+    s->pending_events.resize(base + n);
+    if ((rc = d2h(s, s->pending_events.data() + base, s->D.events, n))) return rc;
+    HIPCK(s, hipMemsetAsync(s->D.ev_cnt, 0, 4, s->stream));
+    // one lane appends in program order; lanes of different replicas interleave arbitrarily
+    std::stable_sort(s->pending_events.begin() + base, s->pending_events.end(), [](const swim_event& a, const swim_event& b) {
+      return a.time_ms != b.time_ms ? a.time_ms < b.time_ms : a.replica < b.replica;
+    });
+  }
+  size_t k = std::min(cap, s->pending_events.size());
+  std::copy(s->pending_events.begin(), s->pending_events.begin() + k, out);
+  s->pending_events.erase(s->pending_events.begin(), s->pending_events.begin() + k);
+  *n_out = k;
+  return SWIM_OK;
+}
+extern "C" int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || i >= D.N || !is_local(s, i)) return SWIM_ERANGE;
+  size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
+  uint4 h, p0, p1; uint8_t alive, part; int rc;
+  if ((rc = d2h(s, &h, D.hdr + l, 1)) || (rc = d2h(s, &p0, D.pr0 + l, 1)) || (rc = d2h(s, &p1, D.pr1 + l, 1)) ||
+      (rc = d2h(s, &alive, D.gt_alive + (size_t)r * D.N + i, 1)) || (rc = d2h(s, &part, D.part + (size_t)r * D.N + i, 1))) return rc;
+  memset(out, 0, sizeof *out);
+  out->incarnation = h.x; out->probe_target = p0.x; out->probe_deadline_tick = p0.x == SWIM_NONE ? 0 : p0.z;
+  out->probe_cursor = p1.x; out->probe_epoch = p1.y;
+  out->queue_len = (h.y >> 16) & 0xFF; out->event_queue_len = h.y >> 24; out->event_clock = h.w;
+  out->alive = alive; out->leaving = (h.y >> 8) & 0xFF; out->awareness = h.y & 0xFF; out->partition = part;
+  for (uint32_t j = 0; j < out->queue_len && j < 32; j++) {
+    uint4 e; if ((rc = d2h(s, &e, D.q + (size_t)j * NL + l, 1))) return rc;
+    swim_rumour q = { e.x, e.y, e.z, (uint8_t)(e.w >> 30), (uint8_t)((e.w >> 22) & 0xFF), { 0, 0 }, e.w & 0x3FFFFFu };
+    out->queue[j] = q;
+  }
+  std::sort(out->queue, out->queue + std::min<uint32_t>(out->queue_len, 32), [](const swim_rumour& a, const swim_rumour& b) { return a.seq < b.seq; });
+  return SWIM_OK;
+}
+
+// census of the replica's dirty subjects outside a tick (after an injection), no trace row
+__global__ void k_census_commit(SwDev D) {
+  uint32_t t = *D.tick, now = t * D.quantum_ms;
+  for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += blockDim.x) {
+    uint32_t r = sidx / D.S, sl = sidx % D.S;
+    if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) continue;
+    swim_census* c = &D.census[sidx];
+    uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
+    c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
+    c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
+    D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
+    for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? 0xFFFFFFFFu : 0;
+    if (c->first_suspect_ms == 0xFFFFFFFFu && c->by_state[1]) c->first_suspect_ms = now;
+    if (c->first_dead_ms == 0xFFFFFFFFu && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
+    if (c->all_dead_ms == 0xFFFFFFFFu && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
+    if (c->all_current_ms == 0xFFFFFFFFu && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+    D.slot_dirty[sidx] = 0;
+  }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_count_live(SwDev D, uint32_t r, uint32_t x, uint32_t* out) {
+  uint32_t c = 0;
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK)
+    c += (D.i0 + k != x) && D.gt_alive[(size_t)r * D.N + D.i0 + k];
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+  if (sw_lane() == 0 && c) atomicAdd(out, c);
+}
+extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || x >= D.N) return SWIM_ERANGE;
+  if (s->in_tick) return SWIM_ESTATE;
+  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  if (rc) return rc;
+  if (sl == SWIM_NONE) {
+    HIPCK(s, hipMemsetAsync(s->d_scratch, 0, 4, s->stream));
+    hipLaunchKernelGGL(k_count_live, dim3(std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256)), dim3(SW_BLOCK), 0, s->stream, D, r, x, s->d_scratch);
+    uint32_t n = 0; if ((rc = d2h(s, &n, (const uint32_t*)s->d_scratch, 1))) return rc;
+    memset(out, 0, sizeof *out);
+    out->n_observers = out->by_state[SWIM_STATE_ALIVE] = out->n_current = n;
+    out->first_suspect_ms = out->first_dead_ms = out->all_dead_ms = out->all_current_ms = SWIM_NONE;
+    return SWIM_OK;
+  }
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
+  hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D);
+  hipLaunchKernelGGL(k_census_commit, dim3(1), dim3(SW_BLOCK), 0, s->stream, D);
+  return d2h(s, out, (const swim_census*)D.census + (size_t)r * D.S + sl, 1);
+}
+extern "C" int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
+  if (!s || !rows) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || x >= D.N) return SWIM_ERANGE;
+  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  if (rc) return rc;
+  if (sl == SWIM_NONE || !D.trace_ticks) return SWIM_ESTATE;
+  if ((uint64_t)first + n > D.trace_ticks || first + n > s->tick) return SWIM_ERANGE;
+  return d2h(s, rows, (const uint32_t*)D.trace + (((size_t)r * D.S + sl) * D.trace_ticks + first) * 5, (size_t)n * 5);
+}
+extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  unsigned long long v[ST_COUNT]; int rc = d2h(s, v, (const unsigned long long*)s->D.stats, ST_COUNT);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  out->ticks = s->ticks_run; out->gossip_rounds = s->rounds_run;
+  out->node_rounds_active = v[ST_ACTIVE]; out->node_rounds_quiescent = v[ST_QUIESCENT];
+  out->packets_sent = v[ST_PKT_SENT]; out->packets_dropped = v[ST_PKT_DROP];
+  for (int i = 0; i < 4; i++) { out->msgs_sent[i] = v[ST_SENT0 + i]; out->msgs_applied[i] = v[ST_APPL0 + i]; }
+  out->probes = v[ST_PROBES]; out->probe_acks = v[ST_ACKS]; out->probe_indirect_acks = v[ST_IACKS];
+  out->probe_failures = v[ST_PFAIL]; out->nacks_missed = v[ST_NACKMISS]; out->refutes = v[ST_REFUTES];
+  out->suspicion_timeouts = v[ST_TIMEOUTS]; out->confirmations = v[ST_CONFIRMS];
+  out->edges = v[ST_EDGES]; out->edges_remote = v[ST_EDGES_REMOTE]; out->queue_drops = v[ST_QDROPS];
+  out->inbox_overflow = v[ST_INBOX_OVF]; out->subject_overflow = v[ST_SUBJ_OVF]; out->event_drops = v[ST_EVDROPS];
+  out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
+  out->user_events_stale = v[ST_UEV_STALE];
+  return SWIM_OK;
+}
+extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
+  if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  uint32_t cnt[SW_MAX_SHARDS]; int rc = d2h(s, cnt, (const uint32_t*)s->d_last_cnt, SW_MAX_SHARDS);
+  if (rc) return rc;
+  size_t total = 0, w = 0;
+  std::vector<swim_edge> tmp;
+  for (uint32_t sh = 0; sh < s->D.n_shards; sh++) {
+    uint32_t n = std::min(cnt[sh], s->D.out_cap[sh]);
+    tmp.resize(n);
+    if (n && (rc = d2h(s, tmp.data(), (const swim_edge*)s->D.out[sh], n))) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+      if (tmp[i].dst == SWIM_NONE) continue;
+      if (w < cap) out[w++] = tmp[i];
+      total++;
+    }
+  }
+  *n_out = total;
+  return SWIM_OK;
+}
+extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  unsigned long long* acc = (unsigned long long*)s->d_scratch;
+  HIPCK(s, hipMemsetAsync(acc, 0, 8, s->stream));
+  const size_t NL = (size_t)D.R * D.nloc;
+  hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, D, acc);
+  hipLaunchKernelGGL(k_digest_views, dim3(std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64)), D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D, acc);
+  unsigned long long v = 0; int rc = d2h(s, &v, (const unsigned long long*)acc, 1);
+  if (rc) return rc;
+  *out = v;
+  return SWIM_OK;
+}
+
+extern "C" int swim_transport_write_to(swim_sim*, uint32_t, uint32_t, uint32_t, const swim_edge*, size_t) { return SWIM_ESTATE; }
+extern "C" int swim_transport_poll(swim_sim*, uint32_t, uint32_t, swim_edge*, size_t, size_t* n) { if (n) *n = 0; return SWIM_ESTATE; }
+
+// ---------------------------------------------------------------------------------------------
+// known-answer hooks
+// ---------------------------------------------------------------------------------------------
+extern "C" void swim_kat_philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) { sw_philox(c[0], c[1], c[2], c[3], k[0], k[1], o); }
+extern "C" uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) { return sw_probe_perm(seed, n, node, epoch, index); }
+extern "C" int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t el, uint32_t mn, uint32_t mx) { return (int32_t)remaining_suspicion_ms(n, k, el, mn, mx); }
+extern "C" void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gp, uint32_t* pp) {
+  swim_derived d;
+  if (swim_config_derive(cfg, &d)) { if (gp) *gp = SWIM_NONE; if (pp) *pp = SWIM_NONE; return; }
+  uint32_t c = node / d.phase_chunk;
+  if (gp) *gp = c % d.gossip_period;
+  if (pp) *pp = (c / d.gossip_period) % d.probe_period;
+}

@@ -1,0 +1,863 @@
+// swim_kernels.hip — hand-written gfx950 kernels for the memberlist/serf SWIM hot path.
+//
+// Pipeline of one tick.  Every kernel is integer/byte work bounded by HBM
+// bandwidth and atomic throughput; there is no dense contraction, hence no MFMA.
+//
+//   k_expire   suspicion timers that ran out           -> self-addressed dead{} records
+//   k_probe    probe()/probeNode, awareness, nacks      -> suspect{} records, slot requests
+//   k_gossip   kRandomNodes + GetBroadcasts per peer    -> outbound edge lists, bucketed by shard
+//   k_deliver  edge list -> per-node inbox (scatter)
+//   k_alloc    subject-slot requests, deterministic order
+//   k_resolve  per observer: canonical order, aliveNode/suspectNode/deadNode/handleUserEvent
+//   k_census   per dirty subject: how the live observers see it
+//   k_finish   first-suspect/first-dead/all-dead stamps, trace row, tick++
+#include "swim_device.h"
+
+#define NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t sw_lane() { return __lane_id(); }
+
+// ---- small accessors ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t h_aware(uint32_t w) { return w & 0xFFu; }
+__device__ __forceinline__ uint32_t h_leaving(uint32_t w) { return (w >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t h_qlen(uint32_t w) { return (w >> 16) & 0xFFu; }
+__device__ __forceinline__ uint32_t h_evqlen(uint32_t w) { return w >> 24; }
+__device__ __forceinline__ uint32_t h_pack(uint32_t aw, uint32_t lv, uint32_t ql, uint32_t eq) {
+  return aw | (lv << 8) | (ql << 16) | (eq << 24);
+}
+__device__ __forceinline__ uint32_t m_type(uint32_t meta) { return meta >> 30; }
+__device__ __forceinline__ uint32_t m_tr(uint32_t meta) { return (meta >> 22) & 0xFFu; }
+__device__ __forceinline__ uint32_t m_seq(uint32_t meta) { return meta & 0x3FFFFFu; }
+__device__ __forceinline__ uint32_t m_pack(uint32_t type, uint32_t tr, uint32_t seq) {
+  return (type << 30) | (tr << 22) | (seq & 0x3FFFFFu);
+}
+
+__device__ __forceinline__ uint64_t seed_of(const SwDev& D, uint32_t r) { return D.seed + r; }
+__device__ __forceinline__ uint32_t now_ms(const SwDev& D, uint32_t t) { return t * D.quantum_ms; }
+
+// observer (r, local k) looking at subject x; base view unless x owns a slot
+__device__ __forceinline__ uint32_t view_key(const SwDev& D, uint32_t r, uint32_t k, uint32_t x, uint32_t* since) {
+  uint32_t sl = D.node_slot[(size_t)r * D.N + x];
+  if (sl == NONE) { *since = 0; return SW_BASE_KEY; }
+  size_t ci = ((size_t)r * D.S + sl) * D.nloc + k;
+  *since = D.v_since[ci];
+  return D.v_key[ci];
+}
+
+__device__ __forceinline__ bool lost(const SwDev& D, uint32_t r, uint32_t t, uint32_t node, uint32_t leg) {
+  if (!D.loss_q32) return false;
+  uint32_t w[4];
+  uint64_t s = seed_of(D, r);
+  sw_philox(t, node, leg, 0, (uint32_t)s, (uint32_t)(s >> 32) ^ SW_STREAM_LOSS, w);
+  return w[0] < D.loss_q32;
+}
+__device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, uint32_t a, uint32_t b, uint32_t rng_node, uint32_t leg) {
+  size_t base = (size_t)r * D.N;
+  if (!D.gt_alive[base + b]) return false;
+  if (D.part[base + a] != D.part[base + b]) return false;
+  return !lost(D, r, t, rng_node, leg);
+}
+
+// ---- statistics: per-block LDS counters, flushed once --------------------------------------------
+struct BlockStats {
+  uint32_t* s;
+  __device__ void init(uint32_t* lds) {
+    s = lds;
+    for (uint32_t i = threadIdx.x; i < ST_COUNT; i += blockDim.x) s[i] = 0;
+    __syncthreads();
+  }
+  __device__ __forceinline__ void add(int i, uint32_t v = 1) { atomicAdd(&s[i], v); }
+  __device__ void flush(const SwDev& D) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ST_COUNT; i += blockDim.x)
+      if (s[i]) atomicAdd(&D.stats[i], (unsigned long long)s[i]);
+  }
+};
+
+// ---- wave-aggregated append of at most one record per lane ------------------------------------
+// ballot the lanes that have a record, one atomicAdd per wave, prefix rank by popcount
+__device__ __forceinline__ void wave_append(const SwDev& D, uint32_t sh, bool want, uint4 rec) {
+  uint64_t mask = __ballot(want);
+  if (!mask) return;
+  uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1, base = 0;
+  if (lane == leader) base = atomicAdd(&D.out_cnt[sh], (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (want) {
+    uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+    if (pos < D.out_cap[sh]) D.out[sh][pos] = rec;
+    else atomicOr(D.err, SW_ERR_EDGE_OVF);
+  }
+}
+// the destination shard differs per lane: one aggregated append per shard present in the wave
+__device__ __forceinline__ void wave_append_sharded(const SwDev& D, bool want, uint32_t sh, uint4 rec) {
+  if (D.n_shards == 1) { wave_append(D, 0, want, rec); return; }
+  uint64_t todo = __ballot(want);
+  while (todo) {
+    uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1;
+    uint32_t s = __shfl(sh, leader);
+    bool mine = want && sh == s;
+    wave_append(D, s, mine, rec);
+    todo &= ~__ballot(mine);
+  }
+}
+__device__ __forceinline__ uint4 mk_edge(const SwDev& D, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+  return make_uint4(r * D.N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu));
+}
+
+// ---- stagger: which nodes act in tick t --------------------------------------------------------
+// chunk c = id / CH; gossip phase = c % G; probe phase = (c / G) % P.  Enumerate the active set
+// compactly: index a -> node id i (or NONE).
+__device__ __forceinline__ uint32_t map_gossip(const SwDev& D, uint32_t ph, uint32_t a) {
+  uint32_t c0 = D.i0 / D.CH, c1 = (D.i0 + D.nloc + D.CH - 1) / D.CH;
+  uint32_t q_lo = c0 > ph ? (c0 - ph + D.G - 1) / D.G : 0;
+  uint32_t c = ph + D.G * (q_lo + a / D.CH);
+  if (c >= c1) return NONE;
+  uint32_t i = c * D.CH + a % D.CH;
+  return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
+}
+__device__ __forceinline__ uint32_t map_probe(const SwDev& D, uint32_t ph, uint32_t a) {
+  uint32_t c0 = D.i0 / D.CH, c1 = (D.i0 + D.nloc + D.CH - 1) / D.CH;
+  uint32_t u_lo = c0 / D.G;
+  uint32_t m_lo = u_lo > ph ? (u_lo - ph + D.P - 1) / D.P : 0;
+  uint32_t q = a / D.CH, m = m_lo + q / D.G, gg = q % D.G;
+  uint32_t c = (ph + D.P * m) * D.G + gg;
+  if (c < c0 || c >= c1) return NONE;
+  uint32_t i = c * D.CH + a % D.CH;
+  return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
+}
+
+// =================================================================================================
+// k_expire — suspectNode's time.AfterFunc: still Suspect when the (confirmation-shortened) timeout
+// lapses => deadNode(dead{inc, node, from: self}), delivered to self through the common inbox.
+// grid (blocks over local observers, R*S slots)
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_expire(SwDev D) {
+  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
+  if (sl >= D.n_slots[r]) return;
+  uint32_t t = *D.tick, now = now_ms(D, t);
+  if (!D.slot_susp[sidx] || now < D.slot_mindl[sidx]) return;
+  uint32_t x = D.subj_node[sidx];
+  uint32_t fired = 0;
+  for (uint32_t k0 = blockIdx.x * SW_BLOCK; k0 < D.nloc; k0 += gridDim.x * SW_BLOCK) {
+    uint32_t k = k0 + threadIdx.x;
+    bool fire = false; uint32_t key = 0;
+    if (k < D.nloc) {
+      size_t ci = (size_t)sidx * D.nloc + k;
+      key = D.v_key[ci];
+      if (SW_KST(key) == SWIM_STATE_SUSPECT && D.gt_alive[(size_t)r * D.N + D.i0 + k])
+        fire = now >= D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]];
+    }
+    uint32_t o = D.i0 + k;
+    wave_append(D, D.rank, fire, mk_edge(D, r, o, x, SW_KINC(key), SWIM_MSG_DEAD, o));
+    fired += fire;
+  }
+  // per-wave totals into the stats
+  for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
+  if (sw_lane() == 0 && fired) { atomicAdd(&D.stats[ST_TIMEOUTS], (unsigned long long)fired); atomicAdd(&D.stats[ST_EDGES], (unsigned long long)fired); }
+}
+
+// =================================================================================================
+// k_probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now,
+// plus the indirect-ping stage of probes started ProbeTimeout ago.
+// grid (blocks over [indirect set | start set], R)
+// =================================================================================================
+struct KRandomCtx { uint32_t target; int mode; };   // mode 0 gossip(), 1 indirect helpers
+
+// util.go kRandomNodes: <= 3n draws of randomOffset(n), skip excluded and already picked
+__device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
+                                   uint32_t stream, uint32_t want, KRandomCtx ctx, uint32_t* out) {
+  SwDraws d; d.init(seed_of(D, r), stream, t, o);
+  uint32_t found = 0, now = now_ms(D, t);
+  uint64_t tries = 3ull * D.N;
+  for (uint64_t i = 0; i < tries && found < want; i++) {
+    uint32_t x = d.get((uint32_t)i) % D.N;
+    if (x == o) continue;
+    uint32_t since, key = view_key(D, r, k_local, x, &since), st = SW_KST(key);
+    if (ctx.mode == 0) {
+      // gossip(): skip Left, and Dead for longer than GossipToTheDeadTime
+      if (st == SWIM_STATE_LEFT) continue;
+      if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
+    } else {
+      if (x == ctx.target || st != SWIM_STATE_ALIVE) continue;
+    }
+    bool dup = false;
+    for (uint32_t j = 0; j < found; j++) dup |= out[j] == x;
+    if (dup) continue;
+    out[found++] = x;
+  }
+  return found;
+}
+
+__device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw, int delta) {
+  int v = (int)aw + delta, mx = (int)D.awareness_max - 1;
+  return (uint32_t)(v < 0 ? 0 : v > mx ? mx : v);
+}
+
+__global__ void __launch_bounds__(SW_BLOCK) k_probe(SwDev D, uint32_t seg_b_lanes) {
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  uint32_t r = blockIdx.y, t = *D.tick;
+  uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
+  bool same = (D.TQ % D.P) == 0;                 // degenerate config: both roles fall on one node set
+  bool seg_b = a < seg_b_lanes;
+  uint32_t ph_a = t % D.P, ph_b = t >= D.TQ ? (t - D.TQ) % D.P : NONE;
+  uint32_t i = NONE;
+  if (seg_b) { if (ph_b != NONE && !same) i = map_probe(D, ph_b, a); }
+  else i = map_probe(D, ph_a, a - seg_b_lanes);
+  bool role_b = seg_b || (same && ph_b != NONE), role_a = !seg_b;
+
+  // records this lane may emit (rare): buddy suspect to the target, suspect to self, slot request
+  bool e_buddy = false, e_self = false, e_ctrl = false;
+  uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
+
+  if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
+    uint32_t k = i - D.i0; size_t l = (size_t)r * D.nloc + k;
+    uint4 h = D.hdr[l], p0 = D.pr0[l], p1 = D.pr1[l];
+    uint32_t aw = h_aware(h.y), stage = p1.z & 0xFFu, nackm = (p1.z >> 8) & 0xFFu;
+    bool dirty_h = false, dirty_p = false;
+
+    // ---- role B: ProbeTimeout after the ping, ask IndirectChecks random alive peers
+    if (role_b && stage == 1 && p0.w + D.TQ == t) {
+      uint32_t x = p0.x, peers[8];
+      KRandomCtx ctx = { x, 1 };
+      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, ctx, peers);
+      uint32_t expected = 0, nacks = 0; bool acked = false;
+      bool nack_in_time = 2 * D.TQ < p0.z - p0.w;
+      for (uint32_t q = 0; q < np; q++) {
+        uint32_t hlp = peers[q];
+        if (D.flags & SWIM_F_NACK) expected++;
+        if (!reach(D, r, t, i, hlp, i, 20 + 4 * q)) continue;
+        bool ok = reach(D, r, t, hlp, x, i, 21 + 4 * q) && reach(D, r, t, x, hlp, i, 22 + 4 * q);
+        bool back = reach(D, r, t, hlp, i, i, 23 + 4 * q);
+        if (ok && back) acked = true;
+        else if (!ok && back && nack_in_time) nacks++;
+      }
+      stage = 2; dirty_p = true;
+      if (acked) { aw = awareness_apply(D, aw, -1); dirty_h = true; S.add(ST_IACKS); p0.x = NONE; stage = 0; }
+      else nackm = expected > 0 ? expected - nacks : 1;
+    }
+
+    // ---- role A: the probe ticker
+    if (role_a) {
+      bool busy = stage != 0;
+      if (busy && t >= p0.z) {
+        // probeNode's failure epilogue: awareness, then suspectNode(suspect{inc, node, self})
+        uint32_t x = p0.x;
+        aw = awareness_apply(D, aw, (int)nackm); dirty_h = true;
+        S.add(ST_PFAIL); S.add(ST_NACKMISS, nackm);
+        if (D.node_slot[(size_t)r * D.N + x] == NONE) { e_ctrl = true; ctrl_x = x; }
+        e_self = true; rec_self = mk_edge(D, r, i, x, p0.y, SWIM_MSG_SUSPECT, i);
+        p0.x = NONE; stage = 0; dirty_p = true; busy = false;
+      }
+      if (!busy) {
+        // probe(): next entry of the shuffled list that is not self / dead / left
+        uint32_t num_check = 0, x = NONE, key = 0, cursor = p1.x, epoch = p1.y, since;
+        while (num_check < D.N) {
+          if (cursor >= D.N) { epoch++; cursor = 0; num_check++; continue; }
+          uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
+          key = view_key(D, r, k, c, &since);
+          if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
+          x = c; break;
+        }
+        p1.x = cursor; p1.y = epoch; dirty_p = true;
+        if (x != NONE) {
+          S.add(ST_PROBES);
+          bool fwd = reach(D, r, t, i, x, i, 16);
+          if (fwd && SW_KST(key) != SWIM_STATE_ALIVE && (D.flags & SWIM_F_BUDDY_SUSPECT)) {
+            e_buddy = true; rec_buddy = mk_edge(D, r, x, x, SW_KINC(key), SWIM_MSG_SUSPECT, i); buddy_sh = x / D.nloc;
+          }
+          if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); dirty_h = true; S.add(ST_ACKS); }
+          else {
+            p0.x = x; p0.y = SW_KINC(key); p0.w = t; stage = 1; nackm = 1;
+            p0.z = t + D.P * (aw + 1);                       // awareness.ScaleTimeout(ProbeInterval)
+          }
+        }
+      }
+    }
+    if (dirty_p) { p1.z = stage | (nackm << 8); D.pr0[l] = p0; D.pr1[l] = p1; }
+    if (dirty_h) { h.y = h_pack(aw, h_leaving(h.y), h_qlen(h.y), h_evqlen(h.y)); D.hdr[l] = h; }
+  }
+
+  // emission: all of this is off the common path, wave-aggregated appends suffice
+  if (__any(e_ctrl)) {
+    uint4 c = make_uint4(NONE, ctrl_x, r, 0);
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) wave_append(D, sh, e_ctrl, c);
+  }
+  if (__any(e_self)) { wave_append(D, D.rank, e_self, rec_self); }
+  if (__any(e_buddy)) { wave_append_sharded(D, e_buddy, buddy_sh, rec_buddy); }
+  uint32_t ne = (uint32_t)e_self + (uint32_t)e_buddy;
+  if (ne) { S.add(ST_EDGES, ne); if (e_buddy && buddy_sh != D.rank) S.add(ST_EDGES_REMOTE); }
+  S.flush(D);
+}
+
+// =================================================================================================
+// k_gossip — memberlist gossip() (state.go) + TransmitLimitedQueue.GetBroadcasts (queue.go) +
+// serf delegate.GetBroadcasts for user events.  The node's queues are staged in LDS, k random
+// peers come from the counter-based RNG, and the block compacts its packets into the per-shard
+// outbound edge lists with one global atomic per (block, shard).
+// grid (blocks over gossip-due nodes, R); dynamic LDS = (Q+EQ) * 256 * 16 bytes
+// =================================================================================================
+
+// limitedBroadcast.Less: transmits asc, msgLen desc, id desc
+__device__ __forceinline__ bool ent_before(const SwDev& D, uint32_t ma, uint32_t mb) {
+  uint32_t ta = m_tr(ma), tb = m_tr(mb);
+  if (ta != tb) return ta < tb;
+  uint32_t la = D.msg_len[m_type(ma)], lb = D.msg_len[m_type(mb)];
+  if (la != lb) return la > lb;
+  return m_seq(ma) > m_seq(mb);
+}
+
+// one GetBroadcasts(overhead, limit) over an LDS-staged queue.  `live` = entries still queued;
+// returns the bitmask sent; bumps transmits / retires at the retransmit limit.
+__device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
+  uint32_t taken = 0; int used = 0;
+  for (;;) {
+    int free_b = limit - used - (int)overhead;
+    if (free_b <= 0) break;
+    uint32_t best = NONE, bmeta = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      if (!((live >> j) & 1u) || ((taken >> j) & 1u)) continue;
+      uint32_t meta = sq[j * SW_BLOCK].w;
+      if ((int)D.msg_len[m_type(meta)] > free_b) continue;
+      if (best == NONE || ent_before(D, meta, bmeta)) { best = j; bmeta = meta; }
+    }
+    if (best == NONE) break;
+    taken |= 1u << best; used += (int)(overhead + D.msg_len[m_type(bmeta)]);
+  }
+  for (uint32_t j = 0; j < n; j++) {
+    if (!((taken >> j) & 1u)) continue;
+    uint32_t meta = sq[j * SW_BLOCK].w;
+    if (m_tr(meta) + 1 >= D.retransmit_limit) live &= ~(1u << j);          // Finished()
+    else sq[j * SW_BLOCK].w = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
+  }
+  used_out = used;
+  return taken;
+}
+
+__global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
+  extern __shared__ uint4 lds_q[];                 // [Q + EQ][256]
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS];
+  BlockStats S; S.init(lds_stats);
+  if (threadIdx.x < SW_MAX_SHARDS) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+
+  uint32_t r = blockIdx.y, t = *D.tick;
+  uint32_t i = map_gossip(D, t % D.G, blockIdx.x * SW_BLOCK + threadIdx.x);
+  uint4* sq = lds_q + threadIdx.x;                 // entry j at sq[j*256]
+  uint4* se = lds_q + (size_t)D.Q * SW_BLOCK + threadIdx.x;
+  bool serf = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+
+  uint32_t np = 0, peers[8], sent_m[8], sent_e[8], loc[8], psh[8];
+  uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0;
+  size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0);
+  bool active = false;
+
+  if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
+    uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
+    h = D.hdr[l]; qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
+    if (!qlen && !evqlen) S.add(ST_QUIESCENT);
+    else {
+      active = true; S.add(ST_ACTIVE);
+      size_t NL = (size_t)D.R * D.nloc;
+      for (uint32_t j = 0; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
+      for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
+      live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1;
+      live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
+      KRandomCtx ctx = { NONE, 0 };
+      uint32_t found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip, ctx, peers);
+      for (uint32_t p = 0; p < found; p++) {
+        int used = 0, used2 = 0;
+        uint32_t tm = get_broadcasts(D, sq, qlen, live_m, 2, (int)D.budget, used), te = 0;
+        int avail = (int)D.budget - used;
+        if (serf && avail > 2 + 1) te = get_broadcasts(D, se, evqlen, live_e, 3, avail, used2);
+        if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
+        S.add(ST_PKT_SENT);
+        for (uint32_t m = tm; m; m &= m - 1) S.add(ST_SENT0 + m_type(sq[(__ffs(m) - 1) * SW_BLOCK].w));
+        if (te) S.add(ST_SENT3, __popc(te));
+        bool ok = reach(D, r, t, i, peers[p], i, p);
+        if (!ok) { S.add(ST_PKT_DROP); tm = 0; te = 0; }
+        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = peers[p] / D.nloc;
+        if (tm | te) np++;
+      }
+    }
+  }
+
+  // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
+  //      atomicAdd per (block, shard)
+  for (uint32_t p = 0; p < np; p++) loc[p] = atomicAdd(&s_cnt[psh[p]], (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])));
+  __syncthreads();
+  if (threadIdx.x < D.n_shards) {
+    uint32_t c = s_cnt[threadIdx.x], b = 0;
+    if (c) {
+      b = atomicAdd(&D.out_cnt[threadIdx.x], c);
+      if (b + c > D.out_cap[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
+      atomicAdd(&D.stats[ST_EDGES], (unsigned long long)c);
+      if (threadIdx.x != D.rank) atomicAdd(&D.stats[ST_EDGES_REMOTE], (unsigned long long)c);
+    }
+    s_base[threadIdx.x] = b;
+  }
+  __syncthreads();
+  for (uint32_t p = 0; p < np; p++) {
+    uint32_t b = s_base[psh[p]];
+    if (b == NONE) continue;
+    uint4* dst = D.out[psh[p]] + b + loc[p];
+    uint32_t gdst = r * D.N + peers[p];
+    for (uint32_t m = sent_m[p]; m; m &= m - 1) {
+      uint4 e = sq[(__ffs(m) - 1) * SW_BLOCK];
+      *dst++ = make_uint4(gdst, e.x, e.y, (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu));
+    }
+    for (uint32_t m = sent_e[p]; m; m &= m - 1) {
+      uint4 e = se[(__ffs(m) - 1) * SW_BLOCK];
+      *dst++ = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
+    }
+  }
+
+  // ---- write the queues back, compacted
+  if (active) {
+    size_t NL = (size_t)D.R * D.nloc;
+    uint32_t nq = 0, ne = 0;
+    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) D.q[(size_t)(nq++) * NL + l] = sq[j * SW_BLOCK];
+    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) D.evq[(size_t)(ne++) * NL + l] = se[j * SW_BLOCK];
+    h.y = h_pack(h_aware(h.y), h_leaving(h.y), nq, ne);
+    D.hdr[l] = h;
+  }
+  S.flush(D);
+}
+
+// =================================================================================================
+// k_deliver — packetListen/ingestPacket: scatter an edge list into the per-node inboxes.
+// One returning atomic per record reserves the slot; slot requests are side-lined for k_alloc.
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D, const uint4* edges, const uint32_t* cnt_ptr, uint32_t cnt_host) {
+  uint32_t n = cnt_ptr ? *cnt_ptr : cnt_host;
+  size_t NL = (size_t)D.R * D.nloc;
+  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) {
+    uint4 rec = edges[e];
+    if (rec.x == NONE) {
+      uint32_t pos = atomicAdd(D.ctrl_cnt, 1u);
+      if (pos < D.ctrl_cap) D.ctrl[pos] = rec; else atomicOr(D.err, SW_ERR_CTRL_OVF);
+      continue;
+    }
+    uint32_t r = rec.x / D.N, x = rec.x % D.N;
+    if (x < D.i0 || x >= D.i0 + D.nloc || !D.gt_alive[rec.x]) continue;
+    size_t l = (size_t)r * D.nloc + (x - D.i0);
+    uint32_t pos = atomicAdd(&D.in_cnt[l], 1u);
+    if (pos < D.C) D.inbox[(size_t)pos * NL + l] = rec;
+  }
+}
+
+// =================================================================================================
+// k_alloc — give every requested subject a view-column slot, in (replica, id) order so that all
+// shards (and the oracle) number them identically.  Requests are rare: one thread.
+// =================================================================================================
+__device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
+  size_t g = (size_t)r * D.N + x;
+  if (D.node_slot[g] != NONE) return;
+  uint32_t sl = D.n_slots[r];
+  if (sl >= D.S) { atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(&D.stats[ST_SUBJ_OVF], 1ull); return; }
+  D.n_slots[r] = sl + 1;
+  size_t sidx = (size_t)r * D.S + sl;
+  D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
+  D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
+  D.node_slot[g] = sl;
+}
+__global__ void k_alloc(SwDev D) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t n = *D.ctrl_cnt; if (n > D.ctrl_cap) n = D.ctrl_cap;
+  // insertion sort by (replica, id); duplicates collapse because alloc_slot is idempotent
+  for (uint32_t a = 1; a < n; a++) {
+    uint4 v = D.ctrl[a]; uint32_t b = a;
+    while (b && (D.ctrl[b - 1].z > v.z || (D.ctrl[b - 1].z == v.z && D.ctrl[b - 1].y > v.y))) { D.ctrl[b] = D.ctrl[b - 1]; b--; }
+    D.ctrl[b] = v;
+  }
+  for (uint32_t a = 0; a < n; a++) alloc_slot(D, D.ctrl[a].z, D.ctrl[a].y);
+  *D.ctrl_cnt = 0;
+}
+
+// =================================================================================================
+// k_resolve — handleAlive/handleSuspect/handleDead/handleUserEvent for everything that reached a
+// node this tick, applied in ascending (user?, subject, type, incarnation, from) order with
+// duplicates applied once.  Literal aliveNode/suspectNode/deadNode/refute (state.go) and
+// suspicion.Confirm (suspicion.go) against the observer's own view column.
+// =================================================================================================
+struct NodeCtx {
+  const SwDev& D; BlockStats& S;
+  uint32_t r, o, k, t; size_t l, NL;
+  uint32_t self_inc, aw, leaving, qlen, evqlen, qseq, ev_clock, evqseq;
+  __device__ NodeCtx(const SwDev& d, BlockStats& s) : D(d), S(s) {}
+
+  __device__ void load() {
+    uint4 h = D.hdr[l];
+    self_inc = h.x; aw = h_aware(h.y); leaving = h_leaving(h.y); qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
+    qseq = h.z; ev_clock = h.w; evqseq = D.pr1[l].w;
+  }
+  __device__ void store() {
+    D.hdr[l] = make_uint4(self_inc, h_pack(aw, leaving, qlen, evqlen), qseq, ev_clock);
+    D.pr1[l].w = evqseq;
+  }
+
+  // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
+  __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t& seq, bool named,
+                             uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
+    uint32_t n = len;
+    if (named)
+      for (uint32_t j = 0; j < n; j++)
+        if (qb[(size_t)j * NL].x == subject) { qb[(size_t)j * NL] = qb[(size_t)(n - 1) * NL]; n--; break; }
+    uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq)); seq++;
+    if (n == cap) {
+      uint32_t w = NONE, wmeta = e.w;
+      for (uint32_t j = 0; j < n; j++) { uint32_t mj = qb[(size_t)j * NL].w; if (ent_before(D, wmeta, mj)) { wmeta = mj; w = j; } }
+      S.add(drop_stat);
+      if (w != NONE) qb[(size_t)w * NL] = e;
+    } else { qb[(size_t)n * NL] = e; n++; }
+    len = n;
+  }
+  __device__ void broadcast(uint32_t subject, uint32_t type, uint32_t inc, uint32_t from) {
+    queue_push(D.q + l, D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS);
+  }
+  __device__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
+    uint32_t pos = atomicAdd(D.ev_cnt, 1u);
+    if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc }; D.events[pos] = ev; }
+    else atomicOr(D.err, SW_ERR_EVENT_OVF);
+  }
+  __device__ void set_view(size_t sidx, size_t ci, uint32_t inc, uint32_t st, bool touch_since) {
+    D.v_key[ci] = SW_KEY(inc, st);
+    if (touch_since) D.v_since[ci] = now_ms(D, t);
+    if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
+    D.slot_dirty[sidx] = 1;
+  }
+  __device__ void refute(size_t sidx, size_t ci, uint32_t accused) {
+    uint32_t inc = self_inc + 1;
+    if (accused >= inc) inc = accused + 1;
+    self_inc = inc;
+    aw = awareness_apply(D, aw, +1);
+    set_view(sidx, ci, inc, SWIM_STATE_ALIVE, false);
+    broadcast(o, SWIM_MSG_ALIVE, inc, 0);
+    S.add(ST_REFUTES);
+  }
+  __device__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
+    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
+    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t key = D.v_key[ci]; bool local = x == o;
+    if (local && leaving) return;
+    if (!local && inc <= SW_KINC(key)) return;
+    if (local && inc < SW_KINC(key)) return;
+    D.v_nconf[ci] = 0;
+    uint32_t old = SW_KST(key);
+    if (local) { if (inc == SW_KINC(key)) return; refute(sidx, ci, inc); }
+    else {
+      broadcast(x, SWIM_MSG_ALIVE, inc, upd);
+      set_view(sidx, ci, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
+      S.add(ST_APPL0);
+      if (o == D.watch) {
+        if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
+        else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
+      }
+    }
+  }
+  __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
+    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
+    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t key = D.v_key[ci];
+    if (inc < SW_KINC(key)) return;
+    if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from)
+      uint32_t nc = D.v_nconf[ci];
+      if (nc >= D.susp_k) return;
+      uint4 cf = D.v_conf[ci];
+      if (cf.x == from || (nc >= 1 && cf.y == from) || (nc >= 2 && cf.z == from) || (nc >= 3 && cf.w == from)) return;
+      nc++;
+      if (nc == 1) cf.y = from; else if (nc == 2) cf.z = from; else if (nc == 3) cf.w = from;
+      D.v_conf[ci] = cf; D.v_nconf[ci] = (uint8_t)nc;
+      D.slot_dirty[sidx] = 1; S.add(ST_CONFIRMS);
+      broadcast(x, SWIM_MSG_SUSPECT, inc, from);
+      return;
+    }
+    if (SW_KST(key) != SWIM_STATE_ALIVE) return;
+    if (x == o) { refute(sidx, ci, inc); return; }
+    broadcast(x, SWIM_MSG_SUSPECT, inc, from);
+    set_view(sidx, ci, inc, SWIM_STATE_SUSPECT, true);
+    D.v_nconf[ci] = 0; D.v_conf[ci] = make_uint4(from, 0, 0, 0);
+    S.add(ST_APPL1);
+  }
+  __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
+    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
+    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t key = D.v_key[ci];
+    if (inc < SW_KINC(key)) return;
+    uint32_t old = SW_KST(key);
+    if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
+    D.v_nconf[ci] = 0;
+    if (x == o && !leaving) { refute(sidx, ci, inc); return; }
+    broadcast(x, SWIM_MSG_DEAD, inc, from);
+    uint32_t st = from == x ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+    set_view(sidx, ci, inc, st, true);
+    S.add(ST_APPL2);
+    if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
+  }
+  // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
+  __device__ void user_event(uint32_t id, uint32_t ltime) {
+    if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
+    if (ltime >= ev_clock) ev_clock = ltime + 1;
+    if (ev_clock > D.EB && ltime < ev_clock - D.EB) { S.add(ST_UEV_STALE); return; }
+    uint4* slot = D.ring + (size_t)(ltime % D.EB) * NL + l;
+    uint4 sv = *slot; uint32_t n = sv.x >> 30, lt = sv.x & 0x3FFFFFFFu;
+    if (n && lt == (ltime & 0x3FFFFFFFu)) {
+      if (sv.y == id || (n >= 2 && sv.z == id) || (n >= 3 && sv.w == id)) { S.add(ST_UEV_DEDUP); return; }
+    } else n = 0;
+    if (n == 3) { S.add(ST_EVDROPS); return; }
+    if (n == 0) sv.y = id; else if (n == 1) sv.z = id; else sv.w = id;
+    n++; sv.x = (n << 30) | (ltime & 0x3FFFFFFFu); *slot = sv;
+    S.add(ST_UEV_DELIVERED);
+    if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
+    queue_push(D.evq + l, D.EQ, evqlen, evqseq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
+  }
+};
+
+// canonical order key of an inbox record: (user?, subject, type) then (incarnation, from)
+__device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
+  uint32_t type = e.w >> 30;
+  hi = ((uint64_t)(type == SWIM_MSG_USER) << 34) | ((uint64_t)e.y << 2) | type;
+  lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
+}
+
+__global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  size_t NL = (size_t)D.R * D.nloc;
+  size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (l < NL) {
+    uint32_t cnt = D.in_cnt[l];
+    if (cnt) {
+      D.in_cnt[l] = 0;
+      if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
+      NodeCtx n(D, S);
+      n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
+      n.load();
+      bool have_last = false; uint64_t lhi = 0, llo = 0;
+      for (;;) {
+        bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
+        for (uint32_t j = 0; j < cnt; j++) {
+          uint4 e = D.inbox[(size_t)j * NL + l]; uint64_t hi, lo; edge_key(e, hi, lo);
+          if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;
+          if (!have || hi < bhi || (hi == bhi && lo < blo)) { have = true; bhi = hi; blo = lo; best = e; }
+        }
+        if (!have) break;
+        uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
+        if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
+        else if (type == SWIM_MSG_SUSPECT) n.suspect_node(best.y, best.z, from);
+        else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
+        else n.user_event(best.y, best.z);
+        have_last = true; lhi = bhi; llo = blo;
+      }
+      n.store();
+    }
+  }
+  S.flush(D);
+}
+
+// =================================================================================================
+// k_census / k_finish — observation: how the live observers of a replica see each dirty subject
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
+  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
+  if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) return;
+  __shared__ uint32_t acc[CEN_WORDS];
+  if (threadIdx.x < CEN_WORDS) acc[threadIdx.x] = threadIdx.x == CEN_MINDL ? NONE : 0;
+  __syncthreads();
+  uint32_t x = D.subj_node[sidx], maxinc = D.slot_maxinc[sidx];
+  uint32_t obs = 0, st[4] = { 0, 0, 0, 0 }, cur = 0, mindl = NONE;
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
+    uint32_t o = D.i0 + k;
+    if (o == x || !D.gt_alive[(size_t)r * D.N + o]) continue;
+    size_t ci = (size_t)sidx * D.nloc + k;
+    uint32_t key = D.v_key[ci], s = SW_KST(key);
+    obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
+    cur += SW_KINC(key) == maxinc;
+    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]]; mindl = dl < mindl ? dl : mindl; }
+  }
+  uint32_t vals[6] = { obs, st[0], st[1], st[2], st[3], cur };
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    uint32_t v = vals[j];
+    for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+    if (sw_lane() == 0 && v) atomicAdd(&acc[j], v);
+  }
+  for (int off = 32; off; off >>= 1) { uint32_t o2 = __shfl_down(mindl, off); mindl = o2 < mindl ? o2 : mindl; }
+  if (sw_lane() == 0) atomicMin(&acc[CEN_MINDL], mindl);
+  __syncthreads();
+  if (threadIdx.x < 6) { if (acc[threadIdx.x]) atomicAdd(&D.cen_acc[(size_t)sidx * CEN_WORDS + threadIdx.x], acc[threadIdx.x]); }
+  else if (threadIdx.x == CEN_MINDL) atomicMin(&D.cen_acc[(size_t)sidx * CEN_WORDS + CEN_MINDL], acc[CEN_MINDL]);
+}
+
+__global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt) {
+  uint32_t t = *D.tick, now = now_ms(D, t);
+  for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += SW_BLOCK) {
+    uint32_t r = sidx / D.S, sl = sidx % D.S;
+    if (sl >= D.n_slots[r]) continue;
+    swim_census* c = &D.census[sidx];
+    if (D.slot_dirty[sidx]) {
+      uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
+      c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
+      c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
+      D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
+      for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? NONE : 0;
+      if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
+      if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
+      if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
+      if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+      D.slot_dirty[sidx] = 0;
+    }
+    if (D.trace && t < D.trace_ticks) {
+      uint32_t* row = &D.trace[((size_t)sidx * D.trace_ticks + t) * 5];
+      row[0] = c->by_state[0]; row[1] = c->by_state[1]; row[2] = c->by_state[2]; row[3] = c->by_state[3]; row[4] = c->n_current;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *D.tick = t + 1;
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
+  }
+}
+
+// =================================================================================================
+// initialisation, stimulus, digest
+// =================================================================================================
+__global__ void k_init_nodes(SwDev D) {
+  size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= NL) return;
+  D.hdr[l] = make_uint4(1, 0, 0, 0);
+  D.pr0[l] = make_uint4(NONE, 0, 0, 0);
+  D.pr1[l] = make_uint4(0, 0, 0, 0);
+  D.in_cnt[l] = 0;
+}
+__global__ void k_init_views(SwDev D) {
+  size_t n = (size_t)D.R * D.S * D.nloc, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  D.v_key[i] = SW_BASE_KEY; D.v_since[i] = 0; D.v_nconf[i] = 0; D.v_conf[i] = make_uint4(0, 0, 0, 0);
+}
+__global__ void k_init_slots(SwDev D) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.R * D.S) return;
+  D.subj_node[i] = NONE; D.slot_dirty[i] = 0; D.slot_maxinc[i] = 1; D.slot_susp[i] = 0; D.slot_mindl[i] = NONE;
+  for (int j = 0; j < CEN_WORDS; j++) D.cen_acc[(size_t)i * CEN_WORDS + j] = j == CEN_MINDL ? NONE : 0;
+  swim_census c; memset(&c, 0, sizeof c);
+  c.first_suspect_ms = c.first_dead_ms = c.all_dead_ms = c.all_current_ms = NONE;
+  D.census[i] = c;
+}
+
+enum { INJ_KILL = 0, INJ_REVIVE = 1, INJ_LEAVE = 2, INJ_UPDATE = 3 };
+
+__global__ void k_inject_alloc(SwDev D, uint32_t r, const uint32_t* ids, uint32_t n) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (uint32_t a = 0; a < n; a++) alloc_slot(D, r, ids[a]);
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r, const uint32_t* ids, uint32_t n) {
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (a < n) {
+    uint32_t x = ids[a]; size_t g = (size_t)r * D.N + x;
+    bool local = x >= D.i0 && x < D.i0 + D.nloc;
+    size_t l = (size_t)r * D.nloc + (x - D.i0);
+    if (op == INJ_KILL) D.gt_alive[g] = 0;
+    else if (op == INJ_REVIVE) {
+      D.gt_alive[g] = 1;
+      if (local) { D.pr0[l].x = NONE; D.pr1[l].z = 0; D.in_cnt[l] = 0; }
+    } else if (local && D.gt_alive[g]) {
+      NodeCtx c(D, S);
+      c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = (size_t)D.R * D.nloc;
+      c.load();
+      uint32_t sl = D.node_slot[g];
+      if (sl != NONE) {
+        if (op == INJ_LEAVE) { c.leaving = 1; c.dead_node(x, c.self_inc, x); }   // memberlist.Leave
+        else {                                                                    // memberlist.UpdateNode
+          c.self_inc++;
+          size_t sidx = (size_t)r * D.S + sl;
+          c.set_view(sidx, sidx * D.nloc + c.k, c.self_inc, SWIM_STATE_ALIVE, false);
+          c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
+        }
+        c.store();
+      }
+    }
+  }
+  if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
+    for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
+  S.flush(D);
+}
+// serf.UserEvent at the origin: stamp, Increment, handleUserEvent locally, queue
+__global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  if (threadIdx.x == 0) {
+    *ltime_out = NONE;
+    bool local = origin >= D.i0 && origin < D.i0 + D.nloc;
+    if (local && D.gt_alive[(size_t)r * D.N + origin]) {
+      NodeCtx c(D, S);
+      c.r = r; c.o = origin; c.k = origin - D.i0; c.t = *D.tick; c.l = (size_t)r * D.nloc + c.k; c.NL = (size_t)D.R * D.nloc;
+      c.load();
+      uint32_t lt = c.ev_clock; c.ev_clock++;
+      *ltime_out = lt;
+      c.user_event(id, lt);
+      c.store();
+    }
+  }
+  S.flush(D);
+}
+
+// order-independent digest (same item hashes as the oracle; see swim_state_digest there)
+__device__ __forceinline__ void digest_commit(uint64_t d, unsigned long long* out) {
+  for (int off = 32; off; off >>= 1) d += __shfl_down(d, off);
+  if (sw_lane() == 0 && d) atomicAdd(out, (unsigned long long)d);
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(SwDev D, unsigned long long* out) {
+  size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  uint64_t d = 0;
+  if (l < NL) {
+    uint32_t r = (uint32_t)(l / D.nloc), i = D.i0 + (uint32_t)(l % D.nloc); uint64_t g = (uint64_t)r * D.N + i;
+    uint4 h = D.hdr[l], p0 = D.pr0[l], p1 = D.pr1[l];
+    d += sw_h3(1, g, ((uint64_t)h.x << 32) | ((uint64_t)h_aware(h.y) << 8) | h_leaving(h.y));
+    d += sw_h3(2, g, ((uint64_t)p1.x << 32) | p1.y);
+    if (p0.x != NONE)
+      d += sw_h3(3, g, ((uint64_t)p0.x << 32) | p0.z) + sw_h3(4, g, ((uint64_t)p0.y << 32) | ((uint64_t)(p1.z & 0xFF) << 8) | ((p1.z >> 8) & 0xFF));
+    for (uint32_t j = 0; j < h_qlen(h.y); j++) {
+      uint4 e = D.q[(size_t)j * NL + l];
+      d += sw_h3(5, g, sw_h3(e.x, ((uint64_t)e.y << 32) | e.z, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8) | m_type(e.w)));
+    }
+    d += sw_h3(6, g, ((uint64_t)h.z << 32) | h.w);
+    for (uint32_t j = 0; j < h_evqlen(h.y); j++) {
+      uint4 e = D.evq[(size_t)j * NL + l];
+      d += sw_h3(7, g, sw_h3(e.x, e.y, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8)));
+    }
+    if (D.flags & SWIM_F_SERF_EVENTS)
+      for (uint32_t b = 0; b < D.EB; b++) {
+        uint4 sv = D.ring[(size_t)b * NL + l]; uint32_t n = sv.x >> 30, lt = sv.x & 0x3FFFFFFFu;
+        if (n >= 1) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.y);
+        if (n >= 2) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.z);
+        if (n >= 3) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.w);
+      }
+  }
+  digest_commit(d, out);
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_digest_views(SwDev D, unsigned long long* out) {
+  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
+  if (sl >= D.n_slots[r]) return;
+  uint32_t x = D.subj_node[sidx];
+  uint64_t d = 0;
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
+    size_t ci = (size_t)sidx * D.nloc + k;
+    uint32_t key = D.v_key[ci], since = D.v_since[ci];
+    if (key == SW_BASE_KEY && since == 0) continue;
+    uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)x * 0x100000001B3ull) ^ ((uint64_t)(D.i0 + k) << 8);
+    d += sw_h3(9, id, ((uint64_t)key << 32) | since);
+    if (SW_KST(key) == SWIM_STATE_SUSPECT) {
+      uint32_t nc = D.v_nconf[ci]; uint4 cf = D.v_conf[ci];
+      d += sw_h3(10, id, nc);
+      d += sw_h3(11, id, cf.x);
+      if (nc >= 1) d += sw_h3(12, id, cf.y);
+      if (nc >= 2) d += sw_h3(13, id, cf.z);
+      if (nc >= 3) d += sw_h3(14, id, cf.w);
+    }
+  }
+  digest_commit(d, out);
+}

@@ -1,0 +1,34 @@
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from consul_amd import abi  # noqa: E402
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C checker (oracle/), built on demand."""
+    src = os.path.join(ROOT, "oracle", "swim_oracle.c")
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return abi.bind(C.CDLL(ORACLE_SO))
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library; loading it needs no GPU, creating a sim does."""
+    from consul_amd import lib
+    return lib.load()

@@ -1,0 +1,125 @@
+"""GPU parity: the HIP hot path against the CPU oracle on the same seeded inputs.
+
+Bit-exact bar: every integer of node state (digest over self state, queues, views, suspicion
+timers), the per-tick edge list (after canonical sort), the census and the counters.
+"""
+import numpy as np
+import pytest
+
+from consul_amd import abi
+from consul_amd.sim import Sim, preset
+
+pytestmark = pytest.mark.gpu
+
+STAT_KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent",
+             "msgs_applied", "probes", "probe_acks", "probe_indirect_acks", "probe_failures", "nacks_missed",
+             "refutes", "suspicion_timeouts", "confirmations", "edges", "queue_drops", "inbox_overflow",
+             "subject_overflow"]
+
+
+def pair(hip, oracle, which=abi.PRESET_LAN, **kw):
+    return Sim(hip, preset(hip, which, **kw)), Sim(oracle, preset(oracle, which, **kw))
+
+
+def assert_same(a, b, subjects=(), tag=""):
+    a.sync()
+    assert a.digest() == b.digest(), f"state digest differs {tag}"
+    sa, sb = a.stats(), b.stats()
+    for k in STAT_KEYS:
+        assert sa[k] == sb[k], f"stat {k}: hip {sa[k]} oracle {sb[k]} {tag}"
+    for r, x in subjects:
+        ca, cb = a.census(r, x), b.census(r, x)
+        for f, _ in abi.Census._fields_:
+            va, vb = getattr(ca, f), getattr(cb, f)
+            va, vb = (list(va), list(vb)) if hasattr(va, "__len__") else (va, vb)
+            assert va == vb, f"census[{r},{x}].{f}: hip {va} oracle {vb} {tag}"
+
+
+def test_backend_is_hip(hip):
+    assert hip.swim_backend() == b"hip-gfx950"
+
+
+def test_single_failure_lockstep_small(hip, oracle):
+    """config #1 shape: 128 nodes, LAN timers, kill node 17 at t=10s; compare every tick."""
+    a, b = pair(hip, oracle, n_nodes=128, seed=1, trace_ticks=400)
+    for s in (a, b):
+        s.step_ms(10000)
+        s.kill(0, [17])
+    for t in range(150):
+        a.step(1); b.step(1)
+        ea, eb = a.edges(), b.edges()
+        assert np.array_equal(ea, eb), f"edge list differs at tick {a.now()[0]}"
+        assert a.digest() == b.digest(), f"digest differs at tick {a.now()[0]}"
+    assert_same(a, b, [(0, 17)])
+    assert b.census(0, 17).all_dead_ms != abi.NONE
+    assert np.array_equal(a.trace(0, 17, 100, 150), b.trace(0, 17, 100, 150))
+    assert a.poll_events() == b.poll_events()
+    ma, mb = a.members(0, 3), b.members(0, 3)
+    assert np.array_equal(ma, mb)
+
+
+@pytest.mark.parametrize("n,reps,seed", [(4096, 3, 11), (65536, 2, 5)])
+def test_single_failure_replicas(hip, oracle, n, reps, seed):
+    """config #2 shape: kill one uniformly drawn node per replica at t=5s, run past detection."""
+    a, b = pair(hip, oracle, n_nodes=n, n_replicas=reps, seed=seed)
+    rng = np.random.default_rng(seed)
+    victims = [int(rng.integers(n)) for _ in range(reps)]
+    for s in (a, b):
+        s.step_ms(5000)
+        for r, v in enumerate(victims):
+            s.kill(r, [v])
+    for chunk in range(8):
+        a.step_ms(5000); b.step_ms(5000)
+        assert_same(a, b, list(enumerate(victims)), tag=f"after {5 + 5 * (chunk + 1)}s")
+    for r, v in enumerate(victims):
+        c = a.census(r, v)
+        assert c.all_dead_ms != abi.NONE and c.first_suspect_ms < c.first_dead_ms <= c.all_dead_ms
+
+
+def test_update_rumour_wan(hip, oracle):
+    """config #3 shape: WAN timers, one alive-update injected at node 0, infection curve."""
+    for k in (2, 3, 5):
+        a, b = pair(hip, oracle, abi.PRESET_WAN, n_nodes=32768, seed=3, gossip_nodes=k, trace_ticks=64)
+        for s in (a, b):
+            s.update(0, [0])
+            s.step(60)
+        assert_same(a, b, [(0, 0)], tag=f"k={k}")
+        ta, tb = a.trace(0, 0, 0, 60), b.trace(0, 0, 0, 60)
+        assert np.array_equal(ta, tb)
+        assert ta[-1, 4] == 32767 and a.census(0, 0).all_current_ms != abi.NONE
+        assert np.all(np.diff(ta[:, 4].astype(np.int64)) >= 0)      # infection is monotone
+
+
+def test_loss_refute_and_partition(hip, oracle):
+    """packet loss => false suspicions => refutes (incarnation bumps); then a partition."""
+    a, b = pair(hip, oracle, n_nodes=2048, seed=9, subject_cap=1024, queue_cap=32, inbox_cap=256,
+                loss_q32=int(0.10 * 2**32))
+    for s in (a, b):
+        s.step_ms(20000)
+    assert_same(a, b, tag="lossy")
+    st = b.stats()
+    assert st["refutes"] > 0 and st["probe_failures"] > 0 and st["queue_drops"] > 0   # Prune() path too
+    mask = np.zeros(2048, dtype=np.uint8); mask[:100] = 1
+    for s in (a, b):
+        s.set_loss(0.0)
+        s.partition(0, mask)
+        s.step_ms(15000)
+    assert_same(a, b, tag="partitioned")
+
+
+def test_leave_and_revive(hip, oracle):
+    a, b = pair(hip, oracle, n_nodes=1024, seed=2, subject_cap=16)
+    for s in (a, b):
+        s.step_ms(1000)
+        s.leave(0, [5, 900])
+        s.step_ms(3000)
+        s.kill(0, [5, 900, 33])
+        s.step_ms(40000)
+        s.revive(0, [33])
+        s.step_ms(20000)
+    assert_same(a, b, [(0, 5), (0, 900), (0, 33)])
+    assert a.view(0, 1, 5).state == abi.STATE_LEFT and a.view(0, 1, 5).status == abi.MEMBER_LEFT
+    c = a.census(0, 33)
+    assert c.by_state[abi.STATE_ALIVE] == c.n_observers       # 33 refuted its own death
+    assert a.node_info(0, 33).incarnation > 1
+    assert a.poll_events() == b.poll_events()
