@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — SWIM hot-path throughput on MI355X (BASELINE.json metric: gossip rounds/sec x nodes).
+
+Workload at N=1 = BASELINE.json configs[1]: 65 536-node clusters, memberlist DefaultLANConfig,
+fan-out k=3, single failure injection, one cluster replica per seed 1..32 batched on the GPU
+(2 097 152 virtual nodes = lanes).  Warm-up = the pre-failure phase (default 25 rounds = 5 s of
+simulated time), then one uniformly drawn node per replica is killed and the timed region runs K
+gossip rounds (default 200 = 40 s simulated: probe failure -> suspicion -> confirmations -> dead ->
+dissemination -> quiescence).  A "step" is one gossip round = GossipInterval/quantum ticks of the
+whole pipeline (timers, probe, gossip select/emit, delivery, merge) for every node.
+
+At N>1 every replica's node population is block-partitioned over the N ranks (one process per
+GPU) and cross-shard gossip records ride a per-tick all-to-all over RCCL; the replica count grows
+with N so per-GPU work is fixed (weak scaling).
+
+One JSON line on stdout (rank 0).  `roofline` is for the kernel that dominates the timed region,
+timed with HIP events on the simulator's stream in a second, instrumented pass of the same region;
+`cpu_baseline` is the plain-C oracle on one host core on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from consul_amd import abi  # noqa: E402
+from consul_amd.sim import Sim, preset  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def victims_for(seed: int, reps: int, n: int):
+    rng = np.random.default_rng(seed)
+    return [int(rng.integers(n)) for _ in range(reps)]
+
+
+def algorithmic_bytes(kernel: str, st: dict) -> float:
+    """SURVEY.md §8(d) per-unit bytes, split by the kernel that moves them.
+
+    per active node-round: emit side 16 (header) + 8m (queue slots) + k(4+4m) (edges out);
+    delivery side k(4+4m) (edges in); merge k*m*8 (view RMW) + 16+8m (header/slot write-back);
+    per quiescent node-round 16; per probe 40.  k, m are the measured packets/node and msgs/packet.
+    """
+    active, quiet = st["node_rounds_active"], st["node_rounds_quiescent"]
+    pkts, msgs = st["packets_sent"], sum(st["msgs_sent"])
+    applied = sum(st["msgs_applied"])
+    if kernel == "k_gossip":
+        return 16.0 * (active + quiet) + 8.0 * (msgs / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * msgs
+    if kernel == "k_deliver":
+        return 4.0 * pkts + 4.0 * msgs
+    if kernel == "k_resolve":
+        return 8.0 * msgs + 24.0 * applied
+    if kernel == "k_probe":
+        return 40.0 * st["probes"]
+    return 0.0
+
+
+def diff_stats(a: dict, b: dict) -> dict:
+    out = {}
+    for k, v in b.items():
+        out[k] = [x - y for x, y in zip(v, a[k])] if isinstance(v, list) else v - a[k]
+    return out
+
+
+def run_cpu_baseline(args, ticks_per_round: int) -> dict:
+    """The oracle (a scalar C port, 1 thread) on a bounded sample: `cpu_replicas` replicas."""
+    so = os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build_oracle()
+    ora = abi.bind(C.CDLL(so))
+    reps = args.cpu_replicas
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, n_nodes=args.nodes, n_replicas=reps, seed=args.seed,
+                        subject_cap=args.subject_cap, gossip_nodes=args.fanout))
+    s.step(args.warmup * ticks_per_round)
+    for r, v in enumerate(victims_for(args.seed, reps, args.nodes)):
+        s.kill(r, [v])
+    t0 = time.perf_counter()
+    s.step(args.steps * ticks_per_round)
+    dt = time.perf_counter() - t0
+    return {"value": reps * args.nodes * args.steps / dt, "unit": "node-rounds/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} of the replicas x {args.nodes} nodes x {args.steps} rounds, same scenario, "
+                      f"{dt:.1f} s on 1 host core of {os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed gossip rounds")
+    ap.add_argument("--warmup", type=int, default=25, help="untimed gossip rounds before the failure")
+    ap.add_argument("--nodes", type=int, default=65536)
+    ap.add_argument("--replicas", type=int, default=32, help="cluster replicas per GPU (seeds seed..)")
+    ap.add_argument("--fanout", type=int, default=3)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--subject-cap", type=int, default=4)
+    ap.add_argument("--cpu-replicas", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from consul_amd import lib
+    from consul_amd.dist import ShardedSim, TorchExchange
+    hip = lib.load()
+    reps = args.replicas * world                       # weak scaling: replicas grow with the ranks
+    cfg_kw = dict(n_nodes=args.nodes, n_replicas=reps, seed=args.seed, subject_cap=args.subject_cap,
+                  gossip_nodes=args.fanout, device=local_rank, shard_rank=rank, n_shards=world)
+    victims = victims_for(args.seed, reps, args.nodes)
+
+    def fresh():
+        sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
+        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank)) if world > 1 else sim
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim = fresh()
+    G = (sim.sim if world > 1 else sim).derived.gossip_period
+    sim.step(args.warmup * G)
+    for r, v in enumerate(victims):
+        sim.kill(r, [v])
+    sim.sync()
+    barrier()
+    t0 = time.perf_counter()
+    sim.step(args.steps * G)
+    sim.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    base = sim.sim if world > 1 else sim
+    census = [base.census(r, v) for r, v in enumerate(victims[: min(reps, 4)])]
+    detect = {"first_suspect_ms": [c.first_suspect_ms for c in census], "first_dead_ms": [c.first_dead_ms for c in census],
+              "all_dead_ms": [c.all_dead_ms for c in census]}
+    sim.close()
+
+    value = reps * args.nodes * args.steps / dt
+    line = {
+        "metric": "gossip rounds/sec x simulated nodes (node-rounds/s)", "value": value, "unit": "node-rounds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 65536-node memberlist clusters, DefaultLANConfig, fanout k=3, "
+                               "single failure injection per cluster, replicas batched per GPU",
+                   "nodes_per_cluster": args.nodes, "replicas": reps, "fanout": args.fanout,
+                   "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
+                   "rounds_per_sec": args.steps / dt,
+                   "parallelism": f"population sharded x{world}, all-to-all per tick" if world > 1 else "1 GPU"},
+        "detection_ms_after_t0": detect,
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # instrumented pass over the same region: HIP events around every launch on the sim's stream
+        p = fresh()
+        p.step(args.warmup * G)
+        for r, v in enumerate(victims):
+            p.kill(r, [v])
+        p.sync()
+        s0 = p.stats()
+        p.profile(True)
+        p.step(args.steps * G)
+        prof = p.profile_read()
+        st = diff_stats(s0, p.stats())
+        p.close()
+        total_ms = sum(ms for _, ms in prof.values())
+        dom = max(prof, key=lambda k: prof[k][1])
+        launches, ms = prof[dom]
+        bytes_per_launch = algorithmic_bytes(dom, st) / max(launches, 1)
+        avg_s = ms / 1000.0 / max(launches, 1)
+        achieved = bytes_per_launch / avg_s / 1e9
+        pipe_bytes = sum(algorithmic_bytes(k, st) for k in prof)
+        line["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_us": 1e6 * avg_s, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof.items()},
+            "pipeline": {"algorithmic_GBps_over_kernel_time": pipe_bytes / (total_ms / 1000.0) / 1e9,
+                         "algorithmic_GBps_over_wall": pipe_bytes / dt / 1e9,
+                         "kernel_ms_per_round": total_ms / args.steps},
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(dom)
+            if rec and rec.get("workload_nodes") == reps * args.nodes:
+                line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = run_cpu_baseline(args, G)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,10 @@ class Stats(C.Structure):
                 ("user_events_deduped", u64), ("user_events_stale", u64)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 24), ("launches", u64), ("total_ms", C.c_double)]
+
+
 P = C.POINTER
 SimP = C.c_void_p
 
@@ -125,6 +129,8 @@ PROTOTYPES = {
     "swim_stats": (C.c_int, [SimP, P(Stats)]),
     "swim_debug_edges": (C.c_int, [SimP, P(Edge), C.c_size_t, P(C.c_size_t)]),
     "swim_state_digest": (C.c_int, [SimP, P(u64)]),
+    "swim_profile": (C.c_int, [SimP, C.c_int]),
+    "swim_profile_read": (C.c_int, [SimP, P(KernelTime), C.c_size_t, P(C.c_size_t)]),
     "swim_transport_write_to": (C.c_int, [SimP, u32, u32, u32, P(Edge), C.c_size_t]),
     "swim_transport_poll": (C.c_int, [SimP, u32, u32, P(Edge), C.c_size_t, P(C.c_size_t)]),
     "swim_kat_philox4x32": (None, [P(u32), P(u32), P(u32)]),

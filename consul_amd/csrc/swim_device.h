@@ -24,6 +24,12 @@ enum {
   ST_COUNT
 };
 
+// The stats row is replicated SW_STAT_COPIES times, one 256-byte line each, and a block adds into
+// copy (block id % copies): same-address device atomics serialise at ~12 ns apiece, which at a few
+// thousand blocks per launch would cost more than the kernel itself.  The host sums the copies.
+#define SW_STAT_COPIES 256
+#define SW_STAT_STRIDE 32
+
 // sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync/swim_stats)
 #define SW_ERR_EDGE_OVF 0x1u
 #define SW_ERR_INBOX_OVF 0x2u

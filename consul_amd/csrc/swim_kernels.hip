@@ -59,6 +59,10 @@ __device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, ui
 }
 
 // ---- statistics: per-block LDS counters, flushed once --------------------------------------------
+__device__ __forceinline__ unsigned long long* stat_ptr(const SwDev& D, int i) {
+  uint32_t b = blockIdx.x + blockIdx.y * gridDim.x;
+  return &D.stats[(size_t)(b % SW_STAT_COPIES) * SW_STAT_STRIDE + i];
+}
 struct BlockStats {
   uint32_t* s;
   __device__ void init(uint32_t* lds) {
@@ -67,10 +71,15 @@ struct BlockStats {
     __syncthreads();
   }
   __device__ __forceinline__ void add(int i, uint32_t v = 1) { atomicAdd(&s[i], v); }
+  // converged call sites: one LDS atomic per wave instead of one per lane
+  __device__ __forceinline__ void count(int i, bool pred) {
+    uint64_t m = __ballot(pred);
+    if (m && sw_lane() == 0) atomicAdd(&s[i], (uint32_t)__popcll(m));
+  }
   __device__ void flush(const SwDev& D) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ST_COUNT; i += blockDim.x)
-      if (s[i]) atomicAdd(&D.stats[i], (unsigned long long)s[i]);
+      if (s[i]) atomicAdd(stat_ptr(D, i), (unsigned long long)s[i]);
   }
 };
 
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_expire(SwDev D) {
   }
   // per-wave totals into the stats
   for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-  if (sw_lane() == 0 && fired) { atomicAdd(&D.stats[ST_TIMEOUTS], (unsigned long long)fired); atomicAdd(&D.stats[ST_EDGES], (unsigned long long)fired); }
+  if (sw_lane() == 0 && fired) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
 }
 
 // =================================================================================================
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_probe(SwDev D, uint32_t seg_b_lane
   bool role_b = seg_b || (same && ph_b != NONE), role_a = !seg_b;
 
   // records this lane may emit (rare): buddy suspect to the target, suspect to self, slot request
-  bool e_buddy = false, e_self = false, e_ctrl = false;
+  bool e_buddy = false, e_self = false, e_ctrl = false, c_probe = false, c_ack = false;
   uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
 
   if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
@@ -261,12 +270,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_probe(SwDev D, uint32_t seg_b_lane
         }
         p1.x = cursor; p1.y = epoch; dirty_p = true;
         if (x != NONE) {
-          S.add(ST_PROBES);
+          c_probe = true;
           bool fwd = reach(D, r, t, i, x, i, 16);
           if (fwd && SW_KST(key) != SWIM_STATE_ALIVE && (D.flags & SWIM_F_BUDDY_SUSPECT)) {
             e_buddy = true; rec_buddy = mk_edge(D, r, x, x, SW_KINC(key), SWIM_MSG_SUSPECT, i); buddy_sh = x / D.nloc;
           }
-          if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); dirty_h = true; S.add(ST_ACKS); }
+          if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); dirty_h = true; c_ack = true; }
           else {
             p0.x = x; p0.y = SW_KINC(key); p0.w = t; stage = 1; nackm = 1;
             p0.z = t + D.P * (aw + 1);                       // awareness.ScaleTimeout(ProbeInterval)
@@ -278,6 +287,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_probe(SwDev D, uint32_t seg_b_lane
     if (dirty_h) { h.y = h_pack(aw, h_leaving(h.y), h_qlen(h.y), h_evqlen(h.y)); D.hdr[l] = h; }
   }
 
+  S.count(ST_PROBES, c_probe); S.count(ST_ACKS, c_ack);
   // emission: all of this is off the common path, wave-aggregated appends suffice
   if (__any(e_ctrl)) {
     uint4 c = make_uint4(NONE, ctrl_x, r, 0);
@@ -351,14 +361,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
   uint32_t np = 0, peers[8], sent_m[8], sent_e[8], loc[8], psh[8];
   uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0;
   size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0);
-  bool active = false;
+  bool active = false, quiet = false;
 
   if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
     uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
     h = D.hdr[l]; qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
-    if (!qlen && !evqlen) S.add(ST_QUIESCENT);
+    if (!qlen && !evqlen) quiet = true;
     else {
-      active = true; S.add(ST_ACTIVE);
+      active = true;
       size_t NL = (size_t)D.R * D.nloc;
       for (uint32_t j = 0; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
       for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
@@ -383,6 +393,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
     }
   }
 
+  S.count(ST_QUIESCENT, quiet); S.count(ST_ACTIVE, active);
+
   // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
   //      atomicAdd per (block, shard)
   for (uint32_t p = 0; p < np; p++) loc[p] = atomicAdd(&s_cnt[psh[p]], (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])));
@@ -392,8 +404,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
     if (c) {
       b = atomicAdd(&D.out_cnt[threadIdx.x], c);
       if (b + c > D.out_cap[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
-      atomicAdd(&D.stats[ST_EDGES], (unsigned long long)c);
-      if (threadIdx.x != D.rank) atomicAdd(&D.stats[ST_EDGES_REMOTE], (unsigned long long)c);
+      atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c);
+      if (threadIdx.x != D.rank) atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);
     }
     s_base[threadIdx.x] = b;
   }
@@ -455,7 +467,7 @@ __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
   if (D.node_slot[g] != NONE) return;
   uint32_t sl = D.n_slots[r];
-  if (sl >= D.S) { atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(&D.stats[ST_SUBJ_OVF], 1ull); return; }
+  if (sl >= D.S) { atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull); return; }
   D.n_slots[r] = sl + 1;
   size_t sidx = (size_t)r * D.S + sl;
   D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;

@@ -217,6 +217,16 @@ class Sim:
                 self._h, arr.ctypes.data_as(C.POINTER(abi.Edge)), n, C.byref(cnt)))
         return np.sort(arr, order=["dst", "subject", "meta", "incarnation"])
 
+    def profile(self, enable: bool = True):
+        self._ck("swim_profile", self._l.swim_profile(self._h, int(enable)))
+
+    def profile_read(self) -> dict:
+        """{kernel name: (launches, total_ms)} since the last read (HIP events on the sim's stream)."""
+        buf = (abi.KernelTime * 32)()
+        cnt = C.c_size_t()
+        self._ck("swim_profile_read", self._l.swim_profile_read(self._h, buf, 32, C.byref(cnt)))
+        return {k.name.decode(): (int(k.launches), float(k.total_ms)) for k in buf[: cnt.value]}
+
     def digest(self) -> int:
         o = abi.u64()
         self._ck("swim_state_digest", self._l.swim_state_digest(self._h, C.byref(o)))

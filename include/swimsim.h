@@ -263,6 +263,17 @@ int swim_debug_edges(swim_sim* sim, swim_edge* out, size_t cap, size_t* n_out);
  * suspicion timers, serf clocks) — "checksum of checksums" for full-size parity */
 int swim_state_digest(swim_sim* sim, uint64_t* out);
 
+/* ---- per-kernel timing (bench.py's roofline leg; memberlist's own counterpart is the
+ *      metrics.MeasureSince("memberlist","gossip"/"probeNode") timers) ---------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the simulator's stream. */
+typedef struct swim_kernel_time {
+  char     name[24];
+  uint64_t launches;
+  double   total_ms;
+} swim_kernel_time;
+int swim_profile(swim_sim* sim, int enable);
+int swim_profile_read(swim_sim* sim, swim_kernel_time* out, size_t cap, size_t* n_out);
+
 /* ---- memberlist.Transport bridge (agent/consul/wanfed/wanfed.go:96-141)
  * A real memberlist node attached as virtual node `attached` exchanges rumours with its
  * virtual peers: write_to = Transport.WriteToAddress, poll = Transport.PacketCh.  Packets are

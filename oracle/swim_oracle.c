@@ -1049,6 +1049,11 @@ int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edge* o, size_
   (void)s; (void)r; (void)a; (void)o; (void)cap; if (n) *n = 0; return SWIM_ESTATE;
 }
 
+int swim_profile(swim_sim* s, int enable) { (void)enable; return s ? SWIM_OK : SWIM_EINVAL; }
+int swim_profile_read(swim_sim* s, swim_kernel_time* out, size_t cap, size_t* n_out) {
+  (void)out; (void)cap; if (!s || !n_out) return SWIM_EINVAL; *n_out = 0; return SWIM_OK;
+}
+
 /* known-answer hooks */
 void swim_kat_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out); }
 uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) { return probe_perm(seed, n, node, epoch, index); }
