@@ -52,14 +52,13 @@ def algorithmic_bytes(kernel: str, st: dict) -> float:
     active, quiet = st["node_rounds_active"], st["node_rounds_quiescent"]
     pkts, msgs = st["packets_sent"], sum(st["msgs_sent"])
     applied = sum(st["msgs_applied"])
-    if kernel == "k_gossip":
-        return 16.0 * (active + quiet) + 8.0 * (msgs / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * msgs
+    if kernel == "k_begin":       # fused: gossip select/emit + probe (+ timers)
+        return (16.0 * (active + quiet) + 8.0 * (msgs / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * msgs
+                + 40.0 * st["probes"])
     if kernel == "k_deliver":
         return 4.0 * pkts + 4.0 * msgs
     if kernel == "k_resolve":
         return 8.0 * msgs + 24.0 * applied
-    if kernel == "k_probe":
-        return 40.0 * st["probes"]
     return 0.0
 
 
@@ -140,7 +139,10 @@ def main():
 
     sim = fresh()
     G = (sim.sim if world > 1 else sim).derived.gossip_period
-    sim.step(args.warmup * G)
+    sim.step(G); sim.sync()                            # first call builds the captured graphs
+    tq = time.perf_counter()
+    sim.step((args.warmup - 1) * G if args.warmup > 1 else 0); sim.sync()
+    quiescent_ms = 1000.0 * (time.perf_counter() - tq) / max(args.warmup - 1, 1)
     for r, v in enumerate(victims):
         sim.kill(r, [v])
     sim.sync()
@@ -169,7 +171,7 @@ def main():
                                "single failure injection per cluster, replicas batched per GPU",
                    "nodes_per_cluster": args.nodes, "replicas": reps, "fanout": args.fanout,
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
-                   "rounds_per_sec": args.steps / dt,
+                   "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
                    "parallelism": f"population sharded x{world}, all-to-all per tick" if world > 1 else "1 GPU"},
         "detection_ms_after_t0": detect,
     }

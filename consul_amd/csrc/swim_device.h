@@ -1,7 +1,7 @@
 // swim_device.h — device-side data layout and helpers shared by the gfx950 kernels.
 //
 // One lane = one virtual memberlist node.  All per-node state is structure-of-arrays in HBM so a
-// wave's 64 consecutive nodes read 64 consecutive 4/16-byte words.
+// wave's 64 consecutive nodes read 64 consecutive 4/8/16-byte words.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,7 +9,6 @@
 #include "../../include/swimsim.h"
 
 #define SW_MAX_SHARDS 16
-#define SW_CONF_MAX 4
 #define SW_BLOCK 256
 
 // counters mirrored 1:1 into swim_stats_t by the host
@@ -30,41 +29,54 @@ enum {
 #define SW_STAT_COPIES 256
 #define SW_STAT_STRIDE 32
 
-// sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync/swim_stats)
+// sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync)
 #define SW_ERR_EDGE_OVF 0x1u
 #define SW_ERR_INBOX_OVF 0x2u
 #define SW_ERR_SUBJ_OVF 0x4u
 #define SW_ERR_CTRL_OVF 0x8u
 #define SW_ERR_EVENT_OVF 0x10u
+#define SW_ERR_PEND_OVF 0x20u
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
 enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
 
+// node word nw[replica*N + id], replicated on every shard: everything a peer needs to know about
+// a node in ONE random 4-byte read
+//   bit 31     the process is not running (ground truth)
+//   bits 30-24 partition group (ground truth)
+//   bits 23-0  subject slot + 1, 0 = nobody has news about it (every observer holds the base view)
+#define NW_DEAD 0x80000000u
+#define NW_PART(w) (((w) >> 24) & 0x7Fu)
+#define NW_SLOT(w) (((w) & 0xFFFFFFu) - 1u)       /* 0xFFFFFFFF when none */
+#define NW_HAS_SLOT(w) (((w) & 0xFFFFFFu) != 0u)
+
 struct SwDev {
   // dimensions
-  uint32_t N, R, nloc, i0, S, Q, C, EQ, EB;
+  uint32_t N, R, nloc, i0, S, Q, C, CROW, EQ, EB;
   uint32_t G, P, TQ, CH, quantum_ms;
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
-  uint32_t budget, flags, watch, trace_ticks, n_shards, rank;
+  uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks;
   uint32_t msg_len[4];
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
   uint64_t seed;
   // global clock (device resident so a captured graph is tick independent)
   uint32_t* tick;
-  // replicated ground truth, R*N
-  uint8_t* gt_alive;
-  uint8_t* part;
-  uint32_t* node_slot;
+  // replicated, R*N
+  uint32_t* nw;
   // per local lane, NL = R*nloc
-  uint4* hdr;       // {self_inc, awareness | leaving<<8 | qlen<<16 | evqlen<<24, qseq, ev_clock}
-  uint4* pr0;       // {target, inc_at_start, deadline_tick, t0}
-  uint4* pr1;       // {cursor, epoch, stage | nack_miss<<8, evqseq}
+  uint4* hdr;       // {self_inc, leaving | qlen<<8 | evqlen<<16, qseq, ev_clock}
+  uint2* ph;        // probe hot: {cursor, epoch<<16 | awareness<<8 | stage<<6 | nack_miss}
+  uint4* pr0;       // probe cold (only while a probe is in flight): {target, inc_at_start, deadline_tick, t0}
+  uint32_t* evseq;  // serf event-queue id generator
   uint4* q;         // [Q][NL]  {subject, inc, from, type<<30 | transmits<<22 | seq}
   uint4* evq;       // [EQ][NL] {event id, ltime, 0, meta}
   uint4* ring;      // [EB][NL] {n<<30 | ltime, id0, id1, id2}
-  uint32_t* in_cnt; // [NL]
-  uint4* inbox;     // [C][NL] swim_edge
+  uint4* inbox;     // [NL][CROW]: row[0].x = count, row[1..C] = swim_edge; CROW*16 is a multiple of 64 B
+  // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
+  uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue
+  uint32_t* in_any;   // [NL/256] some node of the block received something this tick
+  uint32_t* alive_cnt;// [NL/256] running nodes in the block
   // per (replica, slot) view columns, [R*S][nloc]
   uint32_t* v_key;
   uint32_t* v_since;
@@ -80,6 +92,10 @@ struct SwDev {
   uint32_t* cen_acc;     // [R*S][CEN_WORDS] accumulators
   swim_census* census;   // [R*S] cached
   uint32_t* trace;       // [R*S][trace_ticks][5]
+  // probes whose direct ping failed in tick t wait in list t % (TQ+1) for their indirect stage
+  uint32_t* pend;        // [TQ+1][pend_cap] local lane ids
+  uint32_t* pend_cnt;    // [TQ+1]
+  uint32_t pend_cap;
   // edge lists
   uint4* out[SW_MAX_SHARDS];
   uint32_t* out_cnt;     // [n_shards]
@@ -93,6 +109,15 @@ struct SwDev {
   uint32_t ev_cap;
   unsigned long long* stats;
   uint32_t* err;
+};
+
+// block ranges of the fused first launch of a tick
+struct BeginPlan {
+  uint32_t nb_expire;        // blocks walking the view columns of subjects with due suspicion timers
+  uint32_t nb_pend;          // blocks walking the pending-indirect-probe list
+  uint32_t nb_probe;         // per replica: blocks over the probe-due node set
+  uint32_t nb_gossip;        // per replica: blocks over the gossip-due node set
+  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip
 };
 
 #define SW_KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))

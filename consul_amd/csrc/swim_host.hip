@@ -2,8 +2,8 @@
 //
 // Host responsibilities only: validate the memberlist.Config mirror, evaluate the closed-form
 // constants once (util.go / suspicion.go formulas with Go's float64 semantics), lay the state out
-// in HBM, and enqueue the per-tick kernel sequence on one HIP stream.  There is no CPU fallback:
-// without a HIP device swim_create returns SWIM_ENODEV.
+// in HBM, and enqueue the per-tick kernel sequence on one HIP stream (replayed from a hipGraph).
+// There is no CPU fallback: without a HIP device swim_create returns SWIM_ENODEV.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -23,28 +23,32 @@
     }                                                                                               \
   } while (0)
 
+enum { PK_BEGIN = 0, PK_DELIVER, PK_ALLOC, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
+static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_alloc", "k_resolve", "k_census", "k_finish" };
+#define SW_GRAPH_TICKS 16
+
 struct swim_sim {
   swim_config cfg;
   swim_derived d;
   SwDev D;
+  BeginPlan plan;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   uint32_t tick = 0;
   bool in_tick = false;
   uint64_t ticks_run = 0, rounds_run = 0;
-  // host mirrors / staging
   uint32_t* d_last_cnt = nullptr;      // [n_shards] edge counts of the finished tick
-  uint32_t* d_scratch = nullptr;       // small device scratch (ids upload, ltime, digest)
+  uint32_t* d_scratch = nullptr;       // small device scratch (ids upload, ltime, digest, node gather)
   size_t scratch_bytes = 0;
   uint4* in_buf = nullptr;             // records received from other shards
   uint32_t in_cap = 0, in_count = 0;
   uint32_t out_counts[SW_MAX_SHARDS];  // host copy for swim_outbound
   bool out_counts_valid = false;
-  uint32_t probe_lanes = 0, gossip_lanes = 0;
   std::vector<swim_event> pending_events;
-  // optional per-launch HIP-event timing
-  hipGraphExec_t graph_exec[2] = { nullptr, nullptr };   // captured tick sequence: 1 tick, SW_GRAPH_TICKS ticks
+  // captured tick sequence: [0] one tick, [1] SW_GRAPH_TICKS ticks
+  hipGraphExec_t graph_exec[2] = { nullptr, nullptr };
   bool use_graphs = true;
+  // optional per-launch HIP-event timing
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
   struct ProfRec { int kernel; size_t ev; };
@@ -52,9 +56,6 @@ struct swim_sim {
   size_t ev_used = 0;
   char err[256] = { 0 };
 };
-
-enum { PK_EXPIRE = 0, PK_PROBE, PK_GOSSIP, PK_DELIVER, PK_ALLOC, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
-static const char* const kKernelNames[PK_COUNT] = { "k_expire", "k_probe", "k_gossip", "k_deliver", "k_alloc", "k_resolve", "k_census", "k_finish" };
 
 // bracket one launch with two events on the simulator's stream
 struct ProfScope {
@@ -106,6 +107,7 @@ int validate(const swim_config* c) {
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
   return SWIM_OK;
 }
+uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 }  // namespace
 
 extern "C" int swim_config_preset(swim_config* c, int preset) {
@@ -184,26 +186,29 @@ extern "C" const char* swim_last_error(swim_sim* s) { return s ? s->err : "null 
 template <typename T>
 static int dalloc(swim_sim* s, T** p, size_t count) {
   void* v = nullptr;
-  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  size_t bytes = std::max<size_t>(count * sizeof(T), 64);
   HIPCK(s, hipMalloc(&v, bytes));
   s->allocs.push_back(v);
   *p = (T*)v;
   return SWIM_OK;
 }
-#define DALLOC(s, p, n)                      \
-  do {                                       \
-    int rc_ = dalloc((s), &(p), (n));        \
+#define DALLOC(s, p, n)                       \
+  do {                                        \
+    int rc_ = dalloc((s), &(p), (n));         \
     if (rc_) { swim_destroy(s); return rc_; } \
   } while (0)
 
-static uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+static void drop_graphs(swim_sim* s) {
+  for (int i = 0; i < 2; i++)
+    if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
+}
 
 extern "C" int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  drop_graphs(s);
   for (void* p : s->allocs) (void)hipFree(p);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; i++) if (s->graph_exec[i]) (void)hipGraphExecDestroy(s->graph_exec[i]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return SWIM_OK;
@@ -214,39 +219,37 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   int rc = swim_config_derive(cfg, &d);
   if (rc) return rc;
   if (!out) return SWIM_EINVAL;
-  if (cfg->n_shards > SW_MAX_SHARDS) return SWIM_ERANGE;
+  if (cfg->n_shards > SW_MAX_SHARDS || cfg->subject_cap >= (1u << 24) - 1) return SWIM_ERANGE;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || (int)cfg->device >= ndev) return SWIM_ENODEV;
   swim_sim* s = new (std::nothrow) swim_sim();
   if (!s) return SWIM_ENOMEM;
   s->cfg = *cfg; s->d = d;
-  HIPCK(s, hipSetDevice((int)cfg->device));
-  {
-    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete s; return SWIM_ENODEV; }
-  }
+  if (hipSetDevice((int)cfg->device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return SWIM_ENODEV; }
   SwDev& D = s->D;
   memset(&D, 0, sizeof D);
   const bool serf = (cfg->flags & SWIM_F_SERF_EVENTS) != 0;
   D.N = cfg->n_nodes; D.R = cfg->n_replicas; D.nloc = D.N / cfg->n_shards; D.i0 = cfg->shard_rank * D.nloc;
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
-  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap;
+  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.CROW = (1 + D.C + 3) & ~3u;
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
   D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
   D.quantum_ms = d.quantum_ms; D.k_gossip = cfg->gossip_nodes; D.k_indirect = cfg->indirect_checks;
   D.retransmit_limit = d.retransmit_limit; D.susp_k = d.suspicion_k; D.awareness_max = cfg->awareness_max_mult;
   D.gossip_to_dead_ms = cfg->gossip_to_dead_ms; D.budget = d.packet_budget; D.flags = cfg->flags;
   D.watch = cfg->watch_node; D.trace_ticks = cfg->trace_ticks; D.n_shards = cfg->n_shards; D.rank = cfg->shard_rank;
+  D.fast_blocks = (D.CH == SW_BLOCK && D.nloc % SW_BLOCK == 0) ? 1u : 0u;
   for (int i = 0; i < 4; i++) D.msg_len[i] = cfg->msg_len[i];
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
 
-  const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S;
+  const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S, NB = cdiv(NL, SW_BLOCK);
   DALLOC(s, D.tick, 1);
-  DALLOC(s, D.gt_alive, NT); DALLOC(s, D.part, NT); DALLOC(s, D.node_slot, NT);
-  DALLOC(s, D.hdr, NL); DALLOC(s, D.pr0, NL); DALLOC(s, D.pr1, NL);
-  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox, NL * D.C);
-  if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); }
+  DALLOC(s, D.nw, NT);
+  DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
+  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox, NL * D.CROW);
+  DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB);
+  if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
   DALLOC(s, D.v_key, NS * D.nloc); DALLOC(s, D.v_since, NS * D.nloc);
   DALLOC(s, D.v_nconf, NS * D.nloc); DALLOC(s, D.v_conf, NS * D.nloc);
   DALLOC(s, D.subj_node, NS); DALLOC(s, D.n_slots, D.R); DALLOC(s, D.slot_dirty, NS);
@@ -254,13 +257,21 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
   if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
 
-  // active-set upper bounds (lanes per replica) for the stagger enumeration
+  // the fused first launch: block ranges per role (upper bounds of the stagger enumeration)
   const uint32_t nchunks = cdiv(D.nloc, D.CH) + 1;
-  s->gossip_lanes = (cdiv(nchunks, D.G) + 1) * D.CH;
-  s->probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
+  const uint32_t gossip_lanes = D.fast_blocks ? cdiv(cdiv(D.nloc, D.CH), D.G) * D.CH : (cdiv(nchunks, D.G) + 1) * D.CH;
+  const uint32_t probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
+  BeginPlan& pl = s->plan;
+  pl.nb_expire = (uint32_t)NS * (NS <= 256 ? 4u : 1u);
+  pl.nb_pend = 16;
+  pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
+  pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
+  pl.roles = 0xF;
+  D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
+  DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick
   const uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
-  uint64_t e_cap = (uint64_t)s->gossip_lanes * D.R * D.k_gossip * per_pkt + 2 * NL + 4096;
+  uint64_t e_cap = (uint64_t)pl.nb_gossip * SW_BLOCK * D.R * D.k_gossip * per_pkt + 2 * NL + 4096;
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
     uint64_t cap = sh == D.rank ? e_cap : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096);
@@ -276,12 +287,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 
   hipStream_t st = s->stream;
   HIPCK(s, hipMemsetAsync(D.tick, 0, 4, st));
-  HIPCK(s, hipMemsetAsync(D.gt_alive, 1, NT, st));
-  HIPCK(s, hipMemsetAsync(D.part, 0, NT, st));
-  HIPCK(s, hipMemsetAsync(D.node_slot, 0xFF, NT * 4, st));
+  HIPCK(s, hipMemsetAsync(D.nw, 0, NT * 4, st));
   HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.out_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
+  HIPCK(s, hipMemsetAsync(D.pend_cnt, 0, (D.TQ + 1) * 4, st));
   HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
@@ -304,34 +314,43 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 // ---------------------------------------------------------------------------------------------
 // time
 // ---------------------------------------------------------------------------------------------
-static int launch_begin(swim_sim* s) {
+static void launch_begin(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
-  const uint32_t xb = std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16);
-  { ProfScope p(s, PK_EXPIRE); hipLaunchKernelGGL(k_expire, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
-  const bool same = (D.TQ % D.P) == 0;
-  const uint32_t seg_b = same ? 0 : s->probe_lanes;
-  { ProfScope p(s, PK_PROBE); hipLaunchKernelGGL(k_probe, dim3(cdiv(seg_b + s->probe_lanes, SW_BLOCK), D.R), dim3(SW_BLOCK), 0, st, D, seg_b); }
+  const BeginPlan& pl = s->plan;
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
-  { ProfScope p(s, PK_GOSSIP); hipLaunchKernelGGL(k_gossip, dim3(cdiv(s->gossip_lanes, SW_BLOCK), D.R), dim3(SW_BLOCK), lds, st, D); }
-  return SWIM_OK;
+  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip);
+  if (D.TQ % D.P == 0) {
+    // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
+    BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = 0xD;
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, a); }
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, b); }
+  } else {
+    ProfScope p(s, PK_BEGIN);
+    hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, pl);
+  }
 }
-static int launch_end(swim_sim* s) {
+static void launch_end(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  const uint32_t dgrid = std::min<uint32_t>(cdiv(D.out_cap[D.rank], SW_BLOCK), 2048);
+  const uint32_t dgrid = std::min<uint32_t>(cdiv(D.out_cap[D.rank], SW_BLOCK), 1024);
   { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(dgrid), dim3(SW_BLOCK), 0, st, D, (const uint4*)D.out[D.rank], (const uint32_t*)&D.out_cnt[D.rank], 0u); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
-    hipLaunchKernelGGL(k_deliver, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK), 2048)), dim3(SW_BLOCK), 0, st, D,
+    hipLaunchKernelGGL(k_deliver, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK), 1024)), dim3(SW_BLOCK), 0, st, D,
                        (const uint4*)s->in_buf, (const uint32_t*)nullptr, s->in_count);
   }
   { ProfScope p(s, PK_ALLOC); hipLaunchKernelGGL(k_alloc, dim3(1), dim3(64), 0, st, D); }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, D); }
-  const uint32_t xb = std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16);
-  { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(std::max(xb, 1u), D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16));
+  { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, D, s->d_last_cnt); }
   s->in_count = 0;
-  return SWIM_OK;
+}
+static void advance(swim_sim* s, uint32_t n) {
+  for (uint32_t k = 0; k < n; k++) {
+    s->tick++; s->ticks_run++;
+    if (s->tick % s->d.gossip_period == 0) s->rounds_run++;
+  }
 }
 
 static int check_device_errors(swim_sim* s) {
@@ -340,10 +359,10 @@ static int check_device_errors(swim_sim* s) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   HIPCK(s, hipGetLastError());
   if (e) {
-    snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s",
+    snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s%s",
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
              e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
-             e & SW_ERR_EVENT_OVF ? " event-ring" : "");
+             e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "");
     return SWIM_EOVERFLOW;
   }
   return SWIM_OK;
@@ -373,7 +392,9 @@ extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   if (!s->in_tick) return SWIM_ESTATE;
   if (!count) return SWIM_OK;
   if ((uint64_t)s->in_count + count > s->in_cap) { snprintf(s->err, sizeof s->err, "inbound staging full"); return SWIM_EOVERFLOW; }
+  // the source belongs to the caller (another shard's segment or a receive buffer): copy before returning
   HIPCK(s, hipMemcpyAsync(s->in_buf + s->in_count, ptr, (size_t)count * sizeof(uint4), hipMemcpyDeviceToDevice, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
   s->in_count += count;
   return SWIM_OK;
 }
@@ -381,14 +402,13 @@ extern "C" int swim_tick_end(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
   launch_end(s);
-  s->in_tick = false; s->tick++; s->ticks_run++;
-  if (s->tick % s->d.gossip_period == 0) s->rounds_run++;
+  s->in_tick = false; advance(s, 1);
   return SWIM_OK;
 }
+
 // The tick sequence is captured once into hipGraphs (1 tick and SW_GRAPH_TICKS ticks); kernels read
 // the clock from device memory, so a replay is valid for any tick.  Replaying removes the per-launch
-// host cost (~3.5 us each, 8 launches a tick) that would otherwise bound quiescent ticks.
-#define SW_GRAPH_TICKS 16
+// host cost (~3 us each) that would otherwise bound quiescent ticks.
 static int build_graph(swim_sim* s, int which, uint32_t ticks) {
   hipGraph_t g = nullptr;
   HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -399,10 +419,6 @@ static int build_graph(swim_sim* s, int which, uint32_t ticks) {
   if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
   return SWIM_OK;
 }
-static void drop_graphs(swim_sim* s) {
-  for (int i = 0; i < 2; i++) if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
-}
-
 extern "C" int swim_step(swim_sim* s, uint32_t n) {
   if (!s) return SWIM_EINVAL;
   if (s->cfg.n_shards != 1 || s->in_tick) return SWIM_ESTATE;
@@ -418,10 +434,7 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
     if (use_graph && n - i >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
     else if (use_graph) HIPCK(s, hipGraphLaunch(s->graph_exec[0], s->stream));
     else { launch_begin(s); launch_end(s); }
-    for (uint32_t k = 0; k < adv; k++) {
-      s->tick++; s->ticks_run++;
-      if (s->tick % s->d.gossip_period == 0) s->rounds_run++;
-    }
+    advance(s, adv);
     i += adv;
   }
   hipError_t e = hipGetLastError();
@@ -468,16 +481,18 @@ extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, 
 extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
   if (!s || !g) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
-  if (r >= s->D.R) return SWIM_ERANGE;
-  HIPCK(s, hipMemcpyAsync(s->D.part + (size_t)r * s->D.N, g, s->D.N, hipMemcpyHostToDevice, s->stream));
+  if (r >= s->D.R || s->D.N > s->scratch_bytes) return SWIM_ERANGE;
+  for (uint32_t i = 0; i < s->D.N; i++) if (g[i] > 127) return SWIM_ERANGE;   // 7 bits of the node word
+  HIPCK(s, hipMemcpyAsync(s->d_scratch, g, s->D.N, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, s->D, r, (const uint8_t*)s->d_scratch);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
 extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
   if (!s) return SWIM_EINVAL;
   if (s->D.loss_q32 != q) {       // kernel arguments are baked into a captured graph
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (int i = 0; i < 2; i++) if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
+    (void)hipStreamSynchronize(s->stream);
+    drop_graphs(s);
   }
   s->D.loss_q32 = q;
   return SWIM_OK;
@@ -512,20 +527,21 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
-  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)D.nw + (size_t)r * D.N + x, 1);
   if (rc) return rc;
   memset(out, 0, sizeof *out); out->id = x;
   uint32_t key = SW_BASE_KEY, since = 0; uint8_t nconf = 0;
-  if (sl != SWIM_NONE) {
-    size_t ci = ((size_t)r * D.S + sl) * D.nloc + (o - D.i0);
-    if ((rc = d2h(s, &key, D.v_key + ci, 1)) || (rc = d2h(s, &since, D.v_since + ci, 1)) || (rc = d2h(s, &nconf, D.v_nconf + ci, 1))) return rc;
+  if (NW_HAS_SLOT(w)) {
+    size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + (o - D.i0);
+    if ((rc = d2h(s, &key, (const uint32_t*)D.v_key + ci, 1)) || (rc = d2h(s, &since, (const uint32_t*)D.v_since + ci, 1)) ||
+        (rc = d2h(s, &nconf, (const uint8_t*)D.v_nconf + ci, 1))) return rc;
   }
   out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
   out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? nconf : 0;
   out->status = status_of(SW_KST(key));
   if (x == o && out->state == SWIM_STATE_ALIVE) {
-    uint4 h; if ((rc = d2h(s, &h, D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
-    if ((h.y >> 8) & 0xFF) out->status = SWIM_MEMBER_LEAVING;
+    uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+    if (h.y & 0xFF) out->status = SWIM_MEMBER_LEAVING;
   }
   return SWIM_OK;
 }
@@ -533,10 +549,10 @@ extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* ou
   if (!s || (!out && cap)) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || o >= D.N || !is_local(s, o)) return SWIM_ERANGE;
-  uint32_t ns = 0; int rc = d2h(s, &ns, D.n_slots + r, 1);
+  uint32_t ns = 0; int rc = d2h(s, &ns, (const uint32_t*)D.n_slots + r, 1);
   if (rc) return rc;
   std::vector<uint32_t> subj(ns ? ns : 1);
-  if (ns && (rc = d2h(s, subj.data(), D.subj_node + (size_t)r * D.S, ns))) return rc;
+  if (ns && (rc = d2h(s, subj.data(), (const uint32_t*)D.subj_node + (size_t)r * D.S, ns))) return rc;
   size_t n = std::min<size_t>(cap, D.N);
   for (size_t x = 0; x < n; x++) {
     swim_member m; memset(&m, 0, sizeof m);
@@ -551,13 +567,13 @@ extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* ou
 }
 extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
-  uint32_t n = 0; int rc = d2h(s, &n, s->D.ev_cnt, 1);
+  uint32_t n = 0; int rc = d2h(s, &n, (const uint32_t*)s->D.ev_cnt, 1);
   if (rc) return rc;
   n = std::min(n, s->D.ev_cap);
   if (n) {
     size_t base = s->pending_events.size();
     s->pending_events.resize(base + n);
-    if ((rc = d2h(s, s->pending_events.data() + base, s->D.events, n))) return rc;
+    if ((rc = d2h(s, s->pending_events.data() + base, (const swim_event*)s->D.events, n))) return rc;
     HIPCK(s, hipMemsetAsync(s->D.ev_cnt, 0, 4, s->stream));
     // one lane appends in program order; lanes of different replicas interleave arbitrarily
     std::stable_sort(s->pending_events.begin() + base, s->pending_events.end(), [](const swim_event& a, const swim_event& b) {
@@ -574,58 +590,31 @@ extern "C" int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || i >= D.N || !is_local(s, i)) return SWIM_ERANGE;
-  size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
-  uint4 h, p0, p1; uint8_t alive, part; int rc;
-  if ((rc = d2h(s, &h, D.hdr + l, 1)) || (rc = d2h(s, &p0, D.pr0 + l, 1)) || (rc = d2h(s, &p1, D.pr1 + l, 1)) ||
-      (rc = d2h(s, &alive, D.gt_alive + (size_t)r * D.N + i, 1)) || (rc = d2h(s, &part, D.part + (size_t)r * D.N + i, 1))) return rc;
+  hipLaunchKernelGGL(k_gather_node, dim3(1), dim3(64), 0, s->stream, D, r, i, s->d_scratch);
+  uint32_t w[16 + 4 * 32]; int rc = d2h(s, w, (const uint32_t*)s->d_scratch, 16 + 4 * 32);
+  if (rc) return rc;
   memset(out, 0, sizeof *out);
-  out->incarnation = h.x; out->probe_target = p0.x; out->probe_deadline_tick = p0.x == SWIM_NONE ? 0 : p0.z;
-  out->probe_cursor = p1.x; out->probe_epoch = p1.y;
-  out->queue_len = (h.y >> 16) & 0xFF; out->event_queue_len = h.y >> 24; out->event_clock = h.w;
-  out->alive = alive; out->leaving = (h.y >> 8) & 0xFF; out->awareness = h.y & 0xFF; out->partition = part;
-  for (uint32_t j = 0; j < out->queue_len && j < 32; j++) {
-    uint4 e; if ((rc = d2h(s, &e, D.q + (size_t)j * NL + l, 1))) return rc;
-    swim_rumour q = { e.x, e.y, e.z, (uint8_t)(e.w >> 30), (uint8_t)((e.w >> 22) & 0xFF), { 0, 0 }, e.w & 0x3FFFFFu };
+  out->incarnation = w[0]; out->probe_target = w[4]; out->probe_deadline_tick = w[4] == SWIM_NONE ? 0 : w[6];
+  out->probe_cursor = w[8]; out->probe_epoch = w[9] >> 16;
+  out->queue_len = (w[1] >> 8) & 0xFF; out->event_queue_len = (w[1] >> 16) & 0xFF; out->event_clock = w[3];
+  out->alive = !(w[10] & NW_DEAD); out->leaving = w[1] & 0xFF; out->awareness = (w[9] >> 8) & 0xFF; out->partition = NW_PART(w[10]);
+  uint32_t nq = std::min<uint32_t>(out->queue_len, 32);
+  for (uint32_t j = 0; j < nq; j++) {
+    const uint32_t* e = &w[16 + 4 * j];
+    swim_rumour q = { e[0], e[1], e[2], (uint8_t)(e[3] >> 30), (uint8_t)((e[3] >> 22) & 0xFF), { 0, 0 }, e[3] & 0x3FFFFFu };
     out->queue[j] = q;
   }
-  std::sort(out->queue, out->queue + std::min<uint32_t>(out->queue_len, 32), [](const swim_rumour& a, const swim_rumour& b) { return a.seq < b.seq; });
+  std::sort(out->queue, out->queue + nq, [](const swim_rumour& a, const swim_rumour& b) { return a.seq < b.seq; });
   return SWIM_OK;
-}
-
-// census of the replica's dirty subjects outside a tick (after an injection), no trace row
-__global__ void k_census_commit(SwDev D) {
-  uint32_t t = *D.tick, now = t * D.quantum_ms;
-  for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += blockDim.x) {
-    uint32_t r = sidx / D.S, sl = sidx % D.S;
-    if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) continue;
-    swim_census* c = &D.census[sidx];
-    uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
-    c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
-    c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
-    D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
-    for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? 0xFFFFFFFFu : 0;
-    if (c->first_suspect_ms == 0xFFFFFFFFu && c->by_state[1]) c->first_suspect_ms = now;
-    if (c->first_dead_ms == 0xFFFFFFFFu && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
-    if (c->all_dead_ms == 0xFFFFFFFFu && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
-    if (c->all_current_ms == 0xFFFFFFFFu && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
-    D.slot_dirty[sidx] = 0;
-  }
-}
-__global__ void __launch_bounds__(SW_BLOCK) k_count_live(SwDev D, uint32_t r, uint32_t x, uint32_t* out) {
-  uint32_t c = 0;
-  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK)
-    c += (D.i0 + k != x) && D.gt_alive[(size_t)r * D.N + D.i0 + k];
-  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
-  if (sw_lane() == 0 && c) atomicAdd(out, c);
 }
 extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || x >= D.N) return SWIM_ERANGE;
   if (s->in_tick) return SWIM_ESTATE;
-  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)D.nw + (size_t)r * D.N + x, 1);
   if (rc) return rc;
-  if (sl == SWIM_NONE) {
+  if (!NW_HAS_SLOT(w)) {
     HIPCK(s, hipMemsetAsync(s->d_scratch, 0, 4, s->stream));
     hipLaunchKernelGGL(k_count_live, dim3(std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256)), dim3(SW_BLOCK), 0, s->stream, D, r, x, s->d_scratch);
     uint32_t n = 0; if ((rc = d2h(s, &n, (const uint32_t*)s->d_scratch, 1))) return rc;
@@ -637,17 +626,17 @@ extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census*
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16));
   hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D);
   hipLaunchKernelGGL(k_census_commit, dim3(1), dim3(SW_BLOCK), 0, s->stream, D);
-  return d2h(s, out, (const swim_census*)D.census + (size_t)r * D.S + sl, 1);
+  return d2h(s, out, (const swim_census*)D.census + (size_t)r * D.S + NW_SLOT(w), 1);
 }
 extern "C" int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
   if (!s || !rows) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || x >= D.N) return SWIM_ERANGE;
-  uint32_t sl = SWIM_NONE; int rc = d2h(s, &sl, D.node_slot + (size_t)r * D.N + x, 1);
+  uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)D.nw + (size_t)r * D.N + x, 1);
   if (rc) return rc;
-  if (sl == SWIM_NONE || !D.trace_ticks) return SWIM_ESTATE;
+  if (!NW_HAS_SLOT(w) || !D.trace_ticks) return SWIM_ESTATE;
   if ((uint64_t)first + n > D.trace_ticks || first + n > s->tick) return SWIM_ERANGE;
-  return d2h(s, rows, (const uint32_t*)D.trace + (((size_t)r * D.S + sl) * D.trace_ticks + first) * 5, (size_t)n * 5);
+  return d2h(s, rows, (const uint32_t*)D.trace + (((size_t)r * D.S + NW_SLOT(w)) * D.trace_ticks + first) * 5, (size_t)n * 5);
 }
 extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   if (!s || !out) return SWIM_EINVAL;
@@ -694,14 +683,16 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
 extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;
-  unsigned long long* acc = (unsigned long long*)s->d_scratch;
-  HIPCK(s, hipMemsetAsync(acc, 0, 8, s->stream));
+  unsigned long long* acc = (unsigned long long*)s->d_scratch;   // 64 partials, one 64-byte line each
+  HIPCK(s, hipMemsetAsync(acc, 0, 64 * 8 * 8, s->stream));
   const size_t NL = (size_t)D.R * D.nloc;
   hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, D, acc);
   hipLaunchKernelGGL(k_digest_views, dim3(std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64)), D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D, acc);
-  unsigned long long v = 0; int rc = d2h(s, &v, (const unsigned long long*)acc, 1);
+  unsigned long long v[64 * 8]; int rc = d2h(s, v, (const unsigned long long*)acc, 64 * 8);
   if (rc) return rc;
-  *out = v;
+  uint64_t d = 0;
+  for (int i = 0; i < 64; i++) d += v[i * 8];
+  *out = d;
   return SWIM_OK;
 }
 

@@ -1,16 +1,18 @@
 // swim_kernels.hip — hand-written gfx950 kernels for the memberlist/serf SWIM hot path.
 //
-// Pipeline of one tick.  Every kernel is integer/byte work bounded by HBM
-// bandwidth and atomic throughput; there is no dense contraction, hence no MFMA.
+// One tick = six launches.  Everything is integer/byte work bounded by HBM bandwidth,
+// random-access sector traffic and atomic throughput; there is no dense contraction, hence no MFMA.
 //
-//   k_expire   suspicion timers that ran out           -> self-addressed dead{} records
-//   k_probe    probe()/probeNode, awareness, nacks      -> suspect{} records, slot requests
-//   k_gossip   kRandomNodes + GetBroadcasts per peer    -> outbound edge lists, bucketed by shard
-//   k_deliver  edge list -> per-node inbox (scatter)
+//   k_begin    fused, role by block range:
+//                expire   suspicion timers that ran out         -> self-addressed dead{} records
+//                pending  indirect-ping stage of probes whose direct ping failed ProbeTimeout ago
+//                probe    probe()/probeNode for the probe-due set -> suspect{} records, slot requests
+//                gossip   kRandomNodes + GetBroadcasts per peer   -> edge lists bucketed by shard
+//   k_deliver  edge list -> per-node inbox rows (one returning atomic + one 16 B store per record)
 //   k_alloc    subject-slot requests, deterministic order
 //   k_resolve  per observer: canonical order, aliveNode/suspectNode/deadNode/handleUserEvent
 //   k_census   per dirty subject: how the live observers see it
-//   k_finish   first-suspect/first-dead/all-dead stamps, trace row, tick++
+//   k_finish   first-suspect/first-dead/all-dead stamps, trace row, list recycling, tick++
 #include "swim_device.h"
 
 #define NONE 0xFFFFFFFFu
@@ -18,12 +20,16 @@
 __device__ __forceinline__ uint32_t sw_lane() { return __lane_id(); }
 
 // ---- small accessors ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t h_aware(uint32_t w) { return w & 0xFFu; }
-__device__ __forceinline__ uint32_t h_leaving(uint32_t w) { return (w >> 8) & 0xFFu; }
-__device__ __forceinline__ uint32_t h_qlen(uint32_t w) { return (w >> 16) & 0xFFu; }
-__device__ __forceinline__ uint32_t h_evqlen(uint32_t w) { return w >> 24; }
-__device__ __forceinline__ uint32_t h_pack(uint32_t aw, uint32_t lv, uint32_t ql, uint32_t eq) {
-  return aw | (lv << 8) | (ql << 16) | (eq << 24);
+__device__ __forceinline__ uint32_t h_leaving(uint32_t w) { return w & 0xFFu; }
+__device__ __forceinline__ uint32_t h_qlen(uint32_t w) { return (w >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t h_evqlen(uint32_t w) { return (w >> 16) & 0xFFu; }
+__device__ __forceinline__ uint32_t h_pack(uint32_t lv, uint32_t ql, uint32_t eq) { return lv | (ql << 8) | (eq << 16); }
+__device__ __forceinline__ uint32_t p_epoch(uint32_t w) { return w >> 16; }
+__device__ __forceinline__ uint32_t p_aw(uint32_t w) { return (w >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t p_stage(uint32_t w) { return (w >> 6) & 3u; }
+__device__ __forceinline__ uint32_t p_nackm(uint32_t w) { return w & 0x3Fu; }
+__device__ __forceinline__ uint32_t p_pack(uint32_t ep, uint32_t aw, uint32_t st, uint32_t nm) {
+  return (ep << 16) | (aw << 8) | (st << 6) | (nm & 0x3Fu);
 }
 __device__ __forceinline__ uint32_t m_type(uint32_t meta) { return meta >> 30; }
 __device__ __forceinline__ uint32_t m_tr(uint32_t meta) { return (meta >> 22) & 0xFFu; }
@@ -35,11 +41,10 @@ __device__ __forceinline__ uint32_t m_pack(uint32_t type, uint32_t tr, uint32_t 
 __device__ __forceinline__ uint64_t seed_of(const SwDev& D, uint32_t r) { return D.seed + r; }
 __device__ __forceinline__ uint32_t now_ms(const SwDev& D, uint32_t t) { return t * D.quantum_ms; }
 
-// observer (r, local k) looking at subject x; base view unless x owns a slot
-__device__ __forceinline__ uint32_t view_key(const SwDev& D, uint32_t r, uint32_t k, uint32_t x, uint32_t* since) {
-  uint32_t sl = D.node_slot[(size_t)r * D.N + x];
-  if (sl == NONE) { *since = 0; return SW_BASE_KEY; }
-  size_t ci = ((size_t)r * D.S + sl) * D.nloc + k;
+// observer (r, local k) looking at the node whose word is `w`; base view unless it owns a slot
+__device__ __forceinline__ uint32_t view_of(const SwDev& D, uint32_t r, uint32_t k, uint32_t w, uint32_t* since) {
+  if (!NW_HAS_SLOT(w)) { *since = 0; return SW_BASE_KEY; }
+  size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + k;
   *since = D.v_since[ci];
   return D.v_key[ci];
 }
@@ -51,17 +56,15 @@ __device__ __forceinline__ bool lost(const SwDev& D, uint32_t r, uint32_t t, uin
   sw_philox(t, node, leg, 0, (uint32_t)s, (uint32_t)(s >> 32) ^ SW_STREAM_LOSS, w);
   return w[0] < D.loss_q32;
 }
-__device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, uint32_t a, uint32_t b, uint32_t rng_node, uint32_t leg) {
-  size_t base = (size_t)r * D.N;
-  if (!D.gt_alive[base + b]) return false;
-  if (D.part[base + a] != D.part[base + b]) return false;
+// can a packet from the (running) node with word wa reach the node with word wb right now
+__device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, uint32_t wa, uint32_t wb, uint32_t rng_node, uint32_t leg) {
+  if ((wb & NW_DEAD) || NW_PART(wa) != NW_PART(wb)) return false;
   return !lost(D, r, t, rng_node, leg);
 }
 
 // ---- statistics: per-block LDS counters, flushed once --------------------------------------------
 __device__ __forceinline__ unsigned long long* stat_ptr(const SwDev& D, int i) {
-  uint32_t b = blockIdx.x + blockIdx.y * gridDim.x;
-  return &D.stats[(size_t)(b % SW_STAT_COPIES) * SW_STAT_STRIDE + i];
+  return &D.stats[(size_t)(blockIdx.x % SW_STAT_COPIES) * SW_STAT_STRIDE + i];
 }
 struct BlockStats {
   uint32_t* s;
@@ -115,86 +118,26 @@ __device__ __forceinline__ uint4 mk_edge(const SwDev& D, uint32_t r, uint32_t ds
 
 // ---- stagger: which nodes act in tick t --------------------------------------------------------
 // chunk c = id / CH; gossip phase = c % G; probe phase = (c / G) % P.  Enumerate the active set
-// compactly: index a -> node id i (or NONE).
+// compactly: index a -> node id i (or NONE).  CH is a power of two.
 __device__ __forceinline__ uint32_t map_gossip(const SwDev& D, uint32_t ph, uint32_t a) {
-  uint32_t c0 = D.i0 / D.CH, c1 = (D.i0 + D.nloc + D.CH - 1) / D.CH;
+  uint32_t sh = __ffs(D.CH) - 1;
+  uint32_t c0 = D.i0 >> sh, c1 = (D.i0 + D.nloc + D.CH - 1) >> sh;
   uint32_t q_lo = c0 > ph ? (c0 - ph + D.G - 1) / D.G : 0;
-  uint32_t c = ph + D.G * (q_lo + a / D.CH);
+  uint32_t c = ph + D.G * (q_lo + (a >> sh));
   if (c >= c1) return NONE;
-  uint32_t i = c * D.CH + a % D.CH;
+  uint32_t i = (c << sh) + (a & (D.CH - 1));
   return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
 }
 __device__ __forceinline__ uint32_t map_probe(const SwDev& D, uint32_t ph, uint32_t a) {
-  uint32_t c0 = D.i0 / D.CH, c1 = (D.i0 + D.nloc + D.CH - 1) / D.CH;
+  uint32_t sh = __ffs(D.CH) - 1;
+  uint32_t c0 = D.i0 >> sh, c1 = (D.i0 + D.nloc + D.CH - 1) >> sh;
   uint32_t u_lo = c0 / D.G;
   uint32_t m_lo = u_lo > ph ? (u_lo - ph + D.P - 1) / D.P : 0;
-  uint32_t q = a / D.CH, m = m_lo + q / D.G, gg = q % D.G;
+  uint32_t q = a >> sh, m = m_lo + q / D.G, gg = q % D.G;
   uint32_t c = (ph + D.P * m) * D.G + gg;
   if (c < c0 || c >= c1) return NONE;
-  uint32_t i = c * D.CH + a % D.CH;
+  uint32_t i = (c << sh) + (a & (D.CH - 1));
   return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
-}
-
-// =================================================================================================
-// k_expire — suspectNode's time.AfterFunc: still Suspect when the (confirmation-shortened) timeout
-// lapses => deadNode(dead{inc, node, from: self}), delivered to self through the common inbox.
-// grid (blocks over local observers, R*S slots)
-// =================================================================================================
-__global__ void __launch_bounds__(SW_BLOCK) k_expire(SwDev D) {
-  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
-  if (sl >= D.n_slots[r]) return;
-  uint32_t t = *D.tick, now = now_ms(D, t);
-  if (!D.slot_susp[sidx] || now < D.slot_mindl[sidx]) return;
-  uint32_t x = D.subj_node[sidx];
-  uint32_t fired = 0;
-  for (uint32_t k0 = blockIdx.x * SW_BLOCK; k0 < D.nloc; k0 += gridDim.x * SW_BLOCK) {
-    uint32_t k = k0 + threadIdx.x;
-    bool fire = false; uint32_t key = 0;
-    if (k < D.nloc) {
-      size_t ci = (size_t)sidx * D.nloc + k;
-      key = D.v_key[ci];
-      if (SW_KST(key) == SWIM_STATE_SUSPECT && D.gt_alive[(size_t)r * D.N + D.i0 + k])
-        fire = now >= D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]];
-    }
-    uint32_t o = D.i0 + k;
-    wave_append(D, D.rank, fire, mk_edge(D, r, o, x, SW_KINC(key), SWIM_MSG_DEAD, o));
-    fired += fire;
-  }
-  // per-wave totals into the stats
-  for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-  if (sw_lane() == 0 && fired) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
-}
-
-// =================================================================================================
-// k_probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now,
-// plus the indirect-ping stage of probes started ProbeTimeout ago.
-// grid (blocks over [indirect set | start set], R)
-// =================================================================================================
-struct KRandomCtx { uint32_t target; int mode; };   // mode 0 gossip(), 1 indirect helpers
-
-// util.go kRandomNodes: <= 3n draws of randomOffset(n), skip excluded and already picked
-__device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
-                                   uint32_t stream, uint32_t want, KRandomCtx ctx, uint32_t* out) {
-  SwDraws d; d.init(seed_of(D, r), stream, t, o);
-  uint32_t found = 0, now = now_ms(D, t);
-  uint64_t tries = 3ull * D.N;
-  for (uint64_t i = 0; i < tries && found < want; i++) {
-    uint32_t x = d.get((uint32_t)i) % D.N;
-    if (x == o) continue;
-    uint32_t since, key = view_key(D, r, k_local, x, &since), st = SW_KST(key);
-    if (ctx.mode == 0) {
-      // gossip(): skip Left, and Dead for longer than GossipToTheDeadTime
-      if (st == SWIM_STATE_LEFT) continue;
-      if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
-    } else {
-      if (x == ctx.target || st != SWIM_STATE_ALIVE) continue;
-    }
-    bool dup = false;
-    for (uint32_t j = 0; j < found; j++) dup |= out[j] == x;
-    if (dup) continue;
-    out[found++] = x;
-  }
-  return found;
 }
 
 __device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw, int delta) {
@@ -202,110 +145,191 @@ __device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw,
   return (uint32_t)(v < 0 ? 0 : v > mx ? mx : v);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK) k_probe(SwDev D, uint32_t seg_b_lanes) {
-  __shared__ uint32_t lds_stats[ST_COUNT];
+// util.go kRandomNodes: <= 3n draws of randomOffset(n), skip excluded and already picked.
+// mode 0 = gossip() (skip Left, and Dead for longer than GossipToTheDeadTime);
+// mode 1 = probeNode's indirect helpers (skip the target and anything not Alive).
+// wout[] receives the picked nodes' words so the caller needs no second lookup.
+__device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
+                                   uint32_t stream, uint32_t want, int mode, uint32_t target,
+                                   uint32_t* out, uint32_t* wout) {
+  SwDraws d; d.init(seed_of(D, r), stream, t, o);
+  uint32_t found = 0, now = now_ms(D, t);
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  uint64_t tries = 3ull * D.N;
+  for (uint64_t i = 0; i < tries && found < want; i++) {
+    uint32_t x = d.get((uint32_t)i) % D.N;
+    if (x == o) continue;
+    uint32_t w = nw[x], since, key = view_of(D, r, k_local, w, &since), st = SW_KST(key);
+    if (mode == 0) {
+      if (st == SWIM_STATE_LEFT) continue;
+      if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
+    } else {
+      if (x == target || st != SWIM_STATE_ALIVE) continue;
+    }
+    bool dup = false;
+    for (uint32_t j = 0; j < found; j++) dup |= out[j] == x;
+    if (dup) continue;
+    out[found] = x; wout[found] = w; found++;
+  }
+  return found;
+}
+
+// =================================================================================================
+// role: expire — suspectNode's time.AfterFunc.  Still Suspect when the (confirmation-shortened)
+// timeout lapses => deadNode(dead{inc, node, from: self}), delivered to self via the common inbox.
+// =================================================================================================
+__device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
+  uint32_t per = nb / (D.R * D.S);                 // blocks per slot
+  uint32_t sidx = b / per, part = b % per, r = sidx / D.S, sl = sidx % D.S;
+  if (sl >= D.n_slots[r]) return;
+  uint32_t t = *D.tick, now = now_ms(D, t);
+  if (!D.slot_susp[sidx] || now < D.slot_mindl[sidx]) return;
+  uint32_t x = D.subj_node[sidx], fired = 0;
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  for (uint32_t k0 = part * SW_BLOCK; k0 < D.nloc; k0 += per * SW_BLOCK) {
+    uint32_t k = k0 + threadIdx.x;
+    bool fire = false; uint32_t key = 0;
+    if (k < D.nloc) {
+      size_t ci = (size_t)sidx * D.nloc + k;
+      key = D.v_key[ci];
+      if (SW_KST(key) == SWIM_STATE_SUSPECT && !(nw[D.i0 + k] & NW_DEAD))
+        fire = now >= D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]];
+    }
+    uint32_t o = D.i0 + k;
+    wave_append(D, D.rank, fire, mk_edge(D, r, o, x, SW_KINC(key), SWIM_MSG_DEAD, o));
+    fired += fire;
+  }
+  for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
+  if (sw_lane() == 0 && fired) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+}
+
+// =================================================================================================
+// role: pending — ProbeTimeout after a failed direct ping: indirectPingReq to IndirectChecks random
+// alive peers; each relays the target's ack or (Lifeguard) answers nack one ProbeTimeout later.
+// =================================================================================================
+__device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   BlockStats S; S.init(lds_stats);
-  uint32_t r = blockIdx.y, t = *D.tick;
-  uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
-  bool same = (D.TQ % D.P) == 0;                 // degenerate config: both roles fall on one node set
-  bool seg_b = a < seg_b_lanes;
-  uint32_t ph_a = t % D.P, ph_b = t >= D.TQ ? (t - D.TQ) % D.P : NONE;
-  uint32_t i = NONE;
-  if (seg_b) { if (ph_b != NONE && !same) i = map_probe(D, ph_b, a); }
-  else i = map_probe(D, ph_a, a - seg_b_lanes);
-  bool role_b = seg_b || (same && ph_b != NONE), role_a = !seg_b;
-
-  // records this lane may emit (rare): buddy suspect to the target, suspect to self, slot request
-  bool e_buddy = false, e_self = false, e_ctrl = false, c_probe = false, c_ack = false;
-  uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
-
-  if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
-    uint32_t k = i - D.i0; size_t l = (size_t)r * D.nloc + k;
-    uint4 h = D.hdr[l], p0 = D.pr0[l], p1 = D.pr1[l];
-    uint32_t aw = h_aware(h.y), stage = p1.z & 0xFFu, nackm = (p1.z >> 8) & 0xFFu;
-    bool dirty_h = false, dirty_p = false;
-
-    // ---- role B: ProbeTimeout after the ping, ask IndirectChecks random alive peers
-    if (role_b && stage == 1 && p0.w + D.TQ == t) {
-      uint32_t x = p0.x, peers[8];
-      KRandomCtx ctx = { x, 1 };
-      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, ctx, peers);
+  uint32_t t = *D.tick;
+  if (t >= D.TQ) {
+    uint32_t li = (t - D.TQ) % (D.TQ + 1);
+    uint32_t n = D.pend_cnt[li]; if (n > D.pend_cap) n = D.pend_cap;
+    const uint32_t* list = D.pend + (size_t)li * D.pend_cap;
+    for (uint32_t e = b * SW_BLOCK + threadIdx.x; e < n; e += nb * SW_BLOCK) {
+      uint32_t l = list[e], r = l / D.nloc, k = l % D.nloc, i = D.i0 + k;
+      const uint32_t* nw = D.nw + (size_t)r * D.N;
+      uint32_t wi = nw[i];
+      if (wi & NW_DEAD) continue;
+      uint2 h = D.ph[l]; uint4 p0 = D.pr0[l];
+      if (p_stage(h.y) != 1 || p0.w + D.TQ != t) continue;
+      uint32_t x = p0.x, wx = nw[x], peers[8], pw[8];
+      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, 1, x, peers, pw);
       uint32_t expected = 0, nacks = 0; bool acked = false;
       bool nack_in_time = 2 * D.TQ < p0.z - p0.w;
       for (uint32_t q = 0; q < np; q++) {
-        uint32_t hlp = peers[q];
         if (D.flags & SWIM_F_NACK) expected++;
-        if (!reach(D, r, t, i, hlp, i, 20 + 4 * q)) continue;
-        bool ok = reach(D, r, t, hlp, x, i, 21 + 4 * q) && reach(D, r, t, x, hlp, i, 22 + 4 * q);
-        bool back = reach(D, r, t, hlp, i, i, 23 + 4 * q);
+        if (!reach(D, r, t, wi, pw[q], i, 20 + 4 * q)) continue;
+        bool ok = reach(D, r, t, pw[q], wx, i, 21 + 4 * q) && reach(D, r, t, wx, pw[q], i, 22 + 4 * q);
+        bool back = reach(D, r, t, pw[q], wi, i, 23 + 4 * q);
         if (ok && back) acked = true;
         else if (!ok && back && nack_in_time) nacks++;
       }
-      stage = 2; dirty_p = true;
-      if (acked) { aw = awareness_apply(D, aw, -1); dirty_h = true; S.add(ST_IACKS); p0.x = NONE; stage = 0; }
-      else nackm = expected > 0 ? expected - nacks : 1;
+      uint32_t aw = p_aw(h.y);
+      if (acked) {
+        aw = awareness_apply(D, aw, -1); S.add(ST_IACKS);
+        D.pr0[l].x = NONE; h.y = p_pack(p_epoch(h.y), aw, 0, 0);
+      } else h.y = p_pack(p_epoch(h.y), aw, 2, expected > 0 ? expected - nacks : 1);
+      D.ph[l] = h;
     }
-
-    // ---- role A: the probe ticker
-    if (role_a) {
-      bool busy = stage != 0;
-      if (busy && t >= p0.z) {
-        // probeNode's failure epilogue: awareness, then suspectNode(suspect{inc, node, self})
-        uint32_t x = p0.x;
-        aw = awareness_apply(D, aw, (int)nackm); dirty_h = true;
-        S.add(ST_PFAIL); S.add(ST_NACKMISS, nackm);
-        if (D.node_slot[(size_t)r * D.N + x] == NONE) { e_ctrl = true; ctrl_x = x; }
-        e_self = true; rec_self = mk_edge(D, r, i, x, p0.y, SWIM_MSG_SUSPECT, i);
-        p0.x = NONE; stage = 0; dirty_p = true; busy = false;
-      }
-      if (!busy) {
-        // probe(): next entry of the shuffled list that is not self / dead / left
-        uint32_t num_check = 0, x = NONE, key = 0, cursor = p1.x, epoch = p1.y, since;
-        while (num_check < D.N) {
-          if (cursor >= D.N) { epoch++; cursor = 0; num_check++; continue; }
-          uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
-          key = view_key(D, r, k, c, &since);
-          if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
-          x = c; break;
-        }
-        p1.x = cursor; p1.y = epoch; dirty_p = true;
-        if (x != NONE) {
-          c_probe = true;
-          bool fwd = reach(D, r, t, i, x, i, 16);
-          if (fwd && SW_KST(key) != SWIM_STATE_ALIVE && (D.flags & SWIM_F_BUDDY_SUSPECT)) {
-            e_buddy = true; rec_buddy = mk_edge(D, r, x, x, SW_KINC(key), SWIM_MSG_SUSPECT, i); buddy_sh = x / D.nloc;
-          }
-          if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); dirty_h = true; c_ack = true; }
-          else {
-            p0.x = x; p0.y = SW_KINC(key); p0.w = t; stage = 1; nackm = 1;
-            p0.z = t + D.P * (aw + 1);                       // awareness.ScaleTimeout(ProbeInterval)
-          }
-        }
-      }
-    }
-    if (dirty_p) { p1.z = stage | (nackm << 8); D.pr0[l] = p0; D.pr1[l] = p1; }
-    if (dirty_h) { h.y = h_pack(aw, h_leaving(h.y), h_qlen(h.y), h_evqlen(h.y)); D.hdr[l] = h; }
   }
+  S.flush(D);
+}
 
+// =================================================================================================
+// role: probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now.
+// Hot path per lane: own word, 8 B of probe state, one Feistel evaluation, the target's word.
+// =================================================================================================
+__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats) {
+  BlockStats S; S.init(lds_stats);
+  uint32_t t = *D.tick;
+  uint32_t i = map_probe(D, t % D.P, a);
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  bool e_buddy = false, e_self = false, e_ctrl = false, c_probe = false, c_ack = false, e_pend = false;
+  uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
+  size_t l = 0;
+  uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
+  if (!(wi & NW_DEAD)) {
+    uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
+    uint2 h = D.ph[l], h0 = h;
+    uint32_t aw = p_aw(h.y), stage = p_stage(h.y), nackm = p_nackm(h.y), epoch = p_epoch(h.y), cursor = h.x;
+    bool busy = stage != 0;
+    if (busy) {
+      uint4 p0 = D.pr0[l];
+      if (t >= p0.z) {
+        // probeNode's failure epilogue: awareness, then suspectNode(suspect{inc, node, self})
+        aw = awareness_apply(D, aw, (int)nackm);
+        S.add(ST_PFAIL); S.add(ST_NACKMISS, nackm);
+        if (!NW_HAS_SLOT(nw[p0.x])) { e_ctrl = true; ctrl_x = p0.x; }
+        e_self = true; rec_self = mk_edge(D, r, i, p0.x, p0.y, SWIM_MSG_SUSPECT, i);
+        D.pr0[l].x = NONE; stage = 0; nackm = 0; busy = false;
+      }
+    }
+    if (!busy) {
+      // probe(): next entry of the shuffled list that is not self / dead / left
+      uint32_t num_check = 0, x = NONE, key = 0, wx = 0, since;
+      while (num_check < D.N) {
+        if (cursor >= D.N) { epoch = (epoch + 1) & 0xFFFFu; cursor = 0; num_check++; continue; }   // resetNodes
+        uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
+        wx = nw[c]; key = view_of(D, r, k, wx, &since);
+        if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
+        x = c; break;
+      }
+      if (x != NONE) {
+        c_probe = true;
+        bool fwd = reach(D, r, t, wi, wx, i, 16);
+        if (fwd && SW_KST(key) != SWIM_STATE_ALIVE && (D.flags & SWIM_F_BUDDY_SUSPECT)) {
+          e_buddy = true; rec_buddy = mk_edge(D, r, x, x, SW_KINC(key), SWIM_MSG_SUSPECT, i); buddy_sh = x / D.nloc;
+        }
+        if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); c_ack = true; }
+        else {
+          stage = 1; nackm = 1; e_pend = true;
+          D.pr0[l] = make_uint4(x, SW_KINC(key), t + D.P * (aw + 1), t);   // awareness.ScaleTimeout(ProbeInterval)
+        }
+      }
+    }
+    h.x = cursor; h.y = p_pack(epoch, aw, stage, nackm);
+    if (h.x != h0.x || h.y != h0.y) D.ph[l] = h;
+  }
   S.count(ST_PROBES, c_probe); S.count(ST_ACKS, c_ack);
-  // emission: all of this is off the common path, wave-aggregated appends suffice
+
+  // everything below is off the common path: wave-aggregated appends suffice
+  if (__any(e_pend)) {
+    uint32_t li = t % (D.TQ + 1);
+    uint64_t mask = __ballot(e_pend);
+    uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1, base = 0;
+    if (lane == leader) base = atomicAdd(&D.pend_cnt[li], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (e_pend) {
+      uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+      if (pos < D.pend_cap) D.pend[(size_t)li * D.pend_cap + pos] = (uint32_t)l;
+      else atomicOr(D.err, SW_ERR_PEND_OVF);
+    }
+  }
   if (__any(e_ctrl)) {
     uint4 c = make_uint4(NONE, ctrl_x, r, 0);
     for (uint32_t sh = 0; sh < D.n_shards; sh++) wave_append(D, sh, e_ctrl, c);
   }
-  if (__any(e_self)) { wave_append(D, D.rank, e_self, rec_self); }
-  if (__any(e_buddy)) { wave_append_sharded(D, e_buddy, buddy_sh, rec_buddy); }
+  if (__any(e_self)) wave_append(D, D.rank, e_self, rec_self);
+  if (__any(e_buddy)) wave_append_sharded(D, e_buddy, buddy_sh, rec_buddy);
   uint32_t ne = (uint32_t)e_self + (uint32_t)e_buddy;
   if (ne) { S.add(ST_EDGES, ne); if (e_buddy && buddy_sh != D.rank) S.add(ST_EDGES_REMOTE); }
   S.flush(D);
 }
 
 // =================================================================================================
-// k_gossip — memberlist gossip() (state.go) + TransmitLimitedQueue.GetBroadcasts (queue.go) +
+// role: gossip — memberlist gossip() (state.go) + TransmitLimitedQueue.GetBroadcasts (queue.go) +
 // serf delegate.GetBroadcasts for user events.  The node's queues are staged in LDS, k random
 // peers come from the counter-based RNG, and the block compacts its packets into the per-shard
 // outbound edge lists with one global atomic per (block, shard).
-// grid (blocks over gossip-due nodes, R); dynamic LDS = (Q+EQ) * 256 * 16 bytes
 // =================================================================================================
 
 // limitedBroadcast.Less: transmits asc, msgLen desc, id desc
@@ -344,26 +368,37 @@ __device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32
   return taken;
 }
 
-__global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
-  extern __shared__ uint4 lds_q[];                 // [Q + EQ][256]
-  __shared__ uint32_t lds_stats[ST_COUNT];
-  __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS];
+__device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base) {
+  uint32_t t = *D.tick;
+  uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
+  // a block is one stagger chunk of 256 consecutive nodes: if none of them has anything queued the
+  // whole block retires after two words (the quiescent fast path of gossip(): "no broadcasts")
+  uint32_t fb = NONE;
+  if (D.fast_blocks) {
+    uint32_t i_first = map_gossip(D, t % D.G, bx * SW_BLOCK);
+    if (i_first == NONE) return;
+    fb = (uint32_t)(((size_t)r * D.nloc + (i_first - D.i0)) / SW_BLOCK);
+    if (!D.q_any[fb]) {
+      if (threadIdx.x == 0) { uint32_t c = D.alive_cnt[fb]; if (c) atomicAdd(stat_ptr(D, ST_QUIESCENT), (unsigned long long)c); }
+      return;
+    }
+  }
   BlockStats S; S.init(lds_stats);
   if (threadIdx.x < SW_MAX_SHARDS) s_cnt[threadIdx.x] = 0;
   __syncthreads();
 
-  uint32_t r = blockIdx.y, t = *D.tick;
-  uint32_t i = map_gossip(D, t % D.G, blockIdx.x * SW_BLOCK + threadIdx.x);
   uint4* sq = lds_q + threadIdx.x;                 // entry j at sq[j*256]
   uint4* se = lds_q + (size_t)D.Q * SW_BLOCK + threadIdx.x;
-  bool serf = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+  const bool serf = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
 
-  uint32_t np = 0, peers[8], sent_m[8], sent_e[8], loc[8], psh[8];
-  uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0;
+  uint32_t np = 0, peers[8], pw[8], sent_m[8], sent_e[8], loc[8], psh[8];
+  uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0, nq = 0, ne = 0;
   size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0);
   bool active = false, quiet = false;
+  uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
 
-  if (i != NONE && D.gt_alive[(size_t)r * D.N + i]) {
+  if (!(wi & NW_DEAD)) {
     uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
     h = D.hdr[l]; qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
     if (!qlen && !evqlen) quiet = true;
@@ -374,8 +409,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
       for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
       live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1;
       live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
-      KRandomCtx ctx = { NONE, 0 };
-      uint32_t found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip, ctx, peers);
+      uint32_t found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip, 0, NONE, peers, pw);
       for (uint32_t p = 0; p < found; p++) {
         int used = 0, used2 = 0;
         uint32_t tm = get_broadcasts(D, sq, qlen, live_m, 2, (int)D.budget, used), te = 0;
@@ -385,14 +419,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
         S.add(ST_PKT_SENT);
         for (uint32_t m = tm; m; m &= m - 1) S.add(ST_SENT0 + m_type(sq[(__ffs(m) - 1) * SW_BLOCK].w));
         if (te) S.add(ST_SENT3, __popc(te));
-        bool ok = reach(D, r, t, i, peers[p], i, p);
-        if (!ok) { S.add(ST_PKT_DROP); tm = 0; te = 0; }
-        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = peers[p] / D.nloc;
-        if (tm | te) np++;
+        if (!reach(D, r, t, wi, pw[p], i, p)) { S.add(ST_PKT_DROP); continue; }
+        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = peers[p] / D.nloc; np++;
       }
     }
   }
-
   S.count(ST_QUIESCENT, quiet); S.count(ST_ACTIVE, active);
 
   // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
@@ -428,22 +459,44 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip(SwDev D) {
   // ---- write the queues back, compacted
   if (active) {
     size_t NL = (size_t)D.R * D.nloc;
-    uint32_t nq = 0, ne = 0;
     for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) D.q[(size_t)(nq++) * NL + l] = sq[j * SW_BLOCK];
     for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) D.evq[(size_t)(ne++) * NL + l] = se[j * SW_BLOCK];
-    h.y = h_pack(h_aware(h.y), h_leaving(h.y), nq, ne);
+    h.y = h_pack(h_leaving(h.y), nq, ne);
     D.hdr[l] = h;
   }
+  // dead nodes keep their (frozen) queues: the hint stays up while any node of the block holds one
+  bool holds = (nq | ne) != 0;
+  if (i != NONE && (wi & NW_DEAD) && D.fast_blocks) { uint32_t hy = D.hdr[(size_t)r * D.nloc + (i - D.i0)].y; holds = (h_qlen(hy) | h_evqlen(hy)) != 0; }
+  int any = __syncthreads_or(holds);
+  if (fb != NONE && !any && threadIdx.x == 0) D.q_any[fb] = 0;
   S.flush(D);
 }
 
 // =================================================================================================
-// k_deliver — packetListen/ingestPacket: scatter an edge list into the per-node inboxes.
-// One returning atomic per record reserves the slot; slot requests are side-lined for k_alloc.
+// k_begin — the fused first launch of a tick.  grid = nb_expire + nb_pend + R*(nb_probe + nb_gossip);
+// dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
+  extern __shared__ uint4 lds_q[];
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS];
+  uint32_t b = blockIdx.x;
+  if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); return; }
+  b -= pl.nb_expire;
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending(D, b, pl.nb_pend, lds_stats); return; }
+  b -= pl.nb_pend;
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe(D, b / pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats); return; }
+  b -= D.R * pl.nb_probe;
+  if (pl.roles & 8u) role_gossip(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base);
+}
+
+// =================================================================================================
+// k_deliver — packetListen/ingestPacket: scatter an edge list into the per-node inbox rows.  One
+// returning atomic on the row's count word reserves the slot; the record lands in the same 64-byte
+// line for the first three arrivals.  Slot requests are side-lined for k_alloc.
 // =================================================================================================
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D, const uint4* edges, const uint32_t* cnt_ptr, uint32_t cnt_host) {
   uint32_t n = cnt_ptr ? *cnt_ptr : cnt_host;
-  size_t NL = (size_t)D.R * D.nloc;
   for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) {
     uint4 rec = edges[e];
     if (rec.x == NONE) {
@@ -452,10 +505,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D, const uint4* edge
       continue;
     }
     uint32_t r = rec.x / D.N, x = rec.x % D.N;
-    if (x < D.i0 || x >= D.i0 + D.nloc || !D.gt_alive[rec.x]) continue;
+    if (x < D.i0 || x >= D.i0 + D.nloc) continue;
     size_t l = (size_t)r * D.nloc + (x - D.i0);
-    uint32_t pos = atomicAdd(&D.in_cnt[l], 1u);
-    if (pos < D.C) D.inbox[(size_t)pos * NL + l] = rec;
+    uint4* row = D.inbox + l * D.CROW;
+    uint32_t pos = atomicAdd(&row[0].x, 1u);
+    if (pos < D.C) row[1 + pos] = rec;
+    if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
   }
 }
 
@@ -465,18 +520,20 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D, const uint4* edge
 // =================================================================================================
 __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
-  if (D.node_slot[g] != NONE) return;
+  uint32_t w = D.nw[g];
+  if (NW_HAS_SLOT(w)) return;
   uint32_t sl = D.n_slots[r];
   if (sl >= D.S) { atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull); return; }
   D.n_slots[r] = sl + 1;
   size_t sidx = (size_t)r * D.S + sl;
   D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
   D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
-  D.node_slot[g] = sl;
+  atomicOr(&D.nw[g], sl + 1);
 }
 __global__ void k_alloc(SwDev D) {
   if (threadIdx.x || blockIdx.x) return;
   uint32_t n = *D.ctrl_cnt; if (n > D.ctrl_cap) n = D.ctrl_cap;
+  if (!n) return;
   // insertion sort by (replica, id); duplicates collapse because alloc_slot is idempotent
   for (uint32_t a = 1; a < n; a++) {
     uint4 v = D.ctrl[a]; uint32_t b = a;
@@ -496,27 +553,23 @@ __global__ void k_alloc(SwDev D) {
 struct NodeCtx {
   const SwDev& D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
-  uint32_t self_inc, aw, leaving, qlen, evqlen, qseq, ev_clock, evqseq;
+  uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   __device__ NodeCtx(const SwDev& d, BlockStats& s) : D(d), S(s) {}
 
   __device__ void load() {
     uint4 h = D.hdr[l];
-    self_inc = h.x; aw = h_aware(h.y); leaving = h_leaving(h.y); qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
-    qseq = h.z; ev_clock = h.w; evqseq = D.pr1[l].w;
+    self_inc = h.x; leaving = h_leaving(h.y); qlen = h_qlen(h.y); evqlen = h_evqlen(h.y); qseq = h.z; ev_clock = h.w;
   }
-  __device__ void store() {
-    D.hdr[l] = make_uint4(self_inc, h_pack(aw, leaving, qlen, evqlen), qseq, ev_clock);
-    D.pr1[l].w = evqseq;
-  }
+  __device__ void store() { D.hdr[l] = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock); }
 
   // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
-  __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t& seq, bool named,
+  __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t seq, bool named,
                              uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
     uint32_t n = len;
     if (named)
       for (uint32_t j = 0; j < n; j++)
         if (qb[(size_t)j * NL].x == subject) { qb[(size_t)j * NL] = qb[(size_t)(n - 1) * NL]; n--; break; }
-    uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq)); seq++;
+    uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq));
     if (n == cap) {
       uint32_t w = NONE, wmeta = e.w;
       for (uint32_t j = 0; j < n; j++) { uint32_t mj = qb[(size_t)j * NL].w; if (ent_before(D, wmeta, mj)) { wmeta = mj; w = j; } }
@@ -524,9 +577,10 @@ struct NodeCtx {
       if (w != NONE) qb[(size_t)w * NL] = e;
     } else { qb[(size_t)n * NL] = e; n++; }
     len = n;
+    if (D.fast_blocks) D.q_any[l / SW_BLOCK] = 1;
   }
   __device__ void broadcast(uint32_t subject, uint32_t type, uint32_t inc, uint32_t from) {
-    queue_push(D.q + l, D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS);
+    queue_push(D.q + l, D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS); qseq++;
   }
   __device__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
     uint32_t pos = atomicAdd(D.ev_cnt, 1u);
@@ -543,14 +597,15 @@ struct NodeCtx {
     uint32_t inc = self_inc + 1;
     if (accused >= inc) inc = accused + 1;
     self_inc = inc;
-    aw = awareness_apply(D, aw, +1);
+    uint2 h = D.ph[l];                                     // awareness lives with the probe state
+    D.ph[l].y = p_pack(p_epoch(h.y), awareness_apply(D, p_aw(h.y), +1), p_stage(h.y), p_nackm(h.y));
     set_view(sidx, ci, inc, SWIM_STATE_ALIVE, false);
     broadcast(o, SWIM_MSG_ALIVE, inc, 0);
     S.add(ST_REFUTES);
   }
   __device__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
-    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
-    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
+    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
     uint32_t key = D.v_key[ci]; bool local = x == o;
     if (local && leaving) return;
     if (!local && inc <= SW_KINC(key)) return;
@@ -569,8 +624,8 @@ struct NodeCtx {
     }
   }
   __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
-    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
-    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
+    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
     uint32_t key = D.v_key[ci];
     if (inc < SW_KINC(key)) return;
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from)
@@ -593,8 +648,8 @@ struct NodeCtx {
     S.add(ST_APPL1);
   }
   __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
-    uint32_t sl = D.node_slot[(size_t)r * D.N + x]; if (sl == NONE) return;
-    size_t sidx = (size_t)r * D.S + sl, ci = sidx * D.nloc + k;
+    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
+    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
     uint32_t key = D.v_key[ci];
     if (inc < SW_KINC(key)) return;
     uint32_t old = SW_KST(key);
@@ -622,7 +677,8 @@ struct NodeCtx {
     n++; sv.x = (n << 30) | (ltime & 0x3FFFFFFFu); *slot = sv;
     S.add(ST_UEV_DELIVERED);
     if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
-    queue_push(D.evq + l, D.EQ, evqlen, evqseq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
+    uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
+    queue_push(D.evq + l, D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
   }
 };
 
@@ -635,13 +691,18 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
 
 __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   __shared__ uint32_t lds_stats[ST_COUNT];
+  if (D.fast_blocks) {                     // nothing reached this block of nodes: one word and out
+    if (!D.in_any[blockIdx.x]) return;
+  }
   BlockStats S; S.init(lds_stats);
+  if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
   size_t NL = (size_t)D.R * D.nloc;
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l < NL) {
-    uint32_t cnt = D.in_cnt[l];
+    uint4* row = D.inbox + l * D.CROW;
+    uint32_t cnt = row[0].x;
     if (cnt) {
-      D.in_cnt[l] = 0;
+      row[0].x = 0;
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
       NodeCtx n(D, S);
       n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
@@ -650,7 +711,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
       for (;;) {
         bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
         for (uint32_t j = 0; j < cnt; j++) {
-          uint4 e = D.inbox[(size_t)j * NL + l]; uint64_t hi, lo; edge_key(e, hi, lo);
+          uint4 e = row[1 + j]; uint64_t hi, lo; edge_key(e, hi, lo);
           if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;
           if (!have || hi < bhi || (hi == bhi && lo < blo)) { have = true; bhi = hi; blo = lo; best = e; }
         }
@@ -679,9 +740,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
   __syncthreads();
   uint32_t x = D.subj_node[sidx], maxinc = D.slot_maxinc[sidx];
   uint32_t obs = 0, st[4] = { 0, 0, 0, 0 }, cur = 0, mindl = NONE;
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     uint32_t o = D.i0 + k;
-    if (o == x || !D.gt_alive[(size_t)r * D.N + o]) continue;
+    if (o == x || (nw[o] & NW_DEAD)) continue;
     size_t ci = (size_t)sidx * D.nloc + k;
     uint32_t key = D.v_key[ci], s = SW_KST(key);
     obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
@@ -702,25 +764,29 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
   else if (threadIdx.x == CEN_MINDL) atomicMin(&D.cen_acc[(size_t)sidx * CEN_WORDS + CEN_MINDL], acc[CEN_MINDL]);
 }
 
+// fold the accumulators of a dirty slot into its cached census and stamp the first-times
+__device__ void census_commit(const SwDev& D, uint32_t sidx, uint32_t now) {
+  swim_census* c = &D.census[sidx];
+  uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
+  c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
+  c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
+  D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
+  for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? NONE : 0;
+  if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
+  if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
+  if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
+  if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+  D.slot_dirty[sidx] = 0;
+}
+
 __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt) {
   uint32_t t = *D.tick, now = now_ms(D, t);
   for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += SW_BLOCK) {
     uint32_t r = sidx / D.S, sl = sidx % D.S;
     if (sl >= D.n_slots[r]) continue;
-    swim_census* c = &D.census[sidx];
-    if (D.slot_dirty[sidx]) {
-      uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
-      c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
-      c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
-      D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
-      for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? NONE : 0;
-      if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
-      if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
-      if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
-      if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
-      D.slot_dirty[sidx] = 0;
-    }
+    if (D.slot_dirty[sidx]) census_commit(D, sidx, now);
     if (D.trace && t < D.trace_ticks) {
+      const swim_census* c = &D.census[sidx];
       uint32_t* row = &D.trace[((size_t)sidx * D.trace_ticks + t) * 5];
       row[0] = c->by_state[0]; row[1] = c->by_state[1]; row[2] = c->by_state[2]; row[3] = c->by_state[3]; row[4] = c->n_current;
     }
@@ -729,7 +795,23 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt
   if (threadIdx.x == 0) {
     *D.tick = t + 1;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
+    D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
   }
+}
+__global__ void k_census_commit(SwDev D) {
+  uint32_t now = now_ms(D, *D.tick);
+  for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += blockDim.x) {
+    uint32_t r = sidx / D.S, sl = sidx % D.S;
+    if (sl < D.n_slots[r] && D.slot_dirty[sidx]) census_commit(D, sidx, now);
+  }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_count_live(SwDev D, uint32_t r, uint32_t x, uint32_t* out) {
+  uint32_t c = 0;
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK)
+    c += (D.i0 + k != x) && !(nw[D.i0 + k] & NW_DEAD);
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+  if (sw_lane() == 0 && c) atomicAdd(out, c);
 }
 
 // =================================================================================================
@@ -739,9 +821,14 @@ __global__ void k_init_nodes(SwDev D) {
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= NL) return;
   D.hdr[l] = make_uint4(1, 0, 0, 0);
+  D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.pr1[l] = make_uint4(0, 0, 0, 0);
-  D.in_cnt[l] = 0;
+  D.inbox[l * D.CROW].x = 0;
+  if (D.evseq) D.evseq[l] = 0;
+  if (l % SW_BLOCK == 0) {
+    size_t rem = NL - l;
+    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK;
+  }
 }
 __global__ void k_init_views(SwDev D) {
   size_t n = (size_t)D.R * D.S * D.nloc, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -772,20 +859,26 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
     uint32_t x = ids[a]; size_t g = (size_t)r * D.N + x;
     bool local = x >= D.i0 && x < D.i0 + D.nloc;
     size_t l = (size_t)r * D.nloc + (x - D.i0);
-    if (op == INJ_KILL) D.gt_alive[g] = 0;
-    else if (op == INJ_REVIVE) {
-      D.gt_alive[g] = 1;
-      if (local) { D.pr0[l].x = NONE; D.pr1[l].z = 0; D.in_cnt[l] = 0; }
-    } else if (local && D.gt_alive[g]) {
+    if (op == INJ_KILL) {
+      uint32_t old = atomicOr(&D.nw[g], NW_DEAD);
+      if (local && !(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);
+    } else if (op == INJ_REVIVE) {
+      uint32_t old = atomicAnd(&D.nw[g], ~NW_DEAD);
+      if (local) {
+        if (old & NW_DEAD) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
+        uint2 h = D.ph[l];
+        D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.inbox[l * D.CROW].x = 0;
+      }
+    } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
       c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = (size_t)D.R * D.nloc;
       c.load();
-      uint32_t sl = D.node_slot[g];
-      if (sl != NONE) {
+      uint32_t w = D.nw[g];
+      if (NW_HAS_SLOT(w)) {
         if (op == INJ_LEAVE) { c.leaving = 1; c.dead_node(x, c.self_inc, x); }   // memberlist.Leave
         else {                                                                    // memberlist.UpdateNode
           c.self_inc++;
-          size_t sidx = (size_t)r * D.S + sl;
+          size_t sidx = (size_t)r * D.S + NW_SLOT(w);
           c.set_view(sidx, sidx * D.nloc + c.k, c.self_inc, SWIM_STATE_ALIVE, false);
           c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
         }
@@ -797,6 +890,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
 }
+__global__ void k_set_partition(SwDev D, uint32_t r, const uint8_t* group) {
+  uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= D.N) return;
+  size_t g = (size_t)r * D.N + x;
+  D.nw[g] = (D.nw[g] & ~0x7F000000u) | (((uint32_t)group[x] & 0x7Fu) << 24);
+}
 // serf.UserEvent at the origin: stamp, Increment, handleUserEvent locally, queue
 __global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
   __shared__ uint32_t lds_stats[ST_COUNT];
@@ -804,7 +903,7 @@ __global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, 
   if (threadIdx.x == 0) {
     *ltime_out = NONE;
     bool local = origin >= D.i0 && origin < D.i0 + D.nloc;
-    if (local && D.gt_alive[(size_t)r * D.N + origin]) {
+    if (local && !(D.nw[(size_t)r * D.N + origin] & NW_DEAD)) {
       NodeCtx c(D, S);
       c.r = r; c.o = origin; c.k = origin - D.i0; c.t = *D.tick; c.l = (size_t)r * D.nloc + c.k; c.NL = (size_t)D.R * D.nloc;
       c.load();
@@ -816,22 +915,31 @@ __global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, 
   }
   S.flush(D);
 }
+// one node's self state, gathered for swim_node_info_get
+__global__ void k_gather_node(SwDev D, uint32_t r, uint32_t i, uint32_t* out) {
+  if (threadIdx.x || blockIdx.x) return;
+  size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
+  uint4 h = D.hdr[l], p0 = D.pr0[l]; uint2 p = D.ph[l]; uint32_t w = D.nw[(size_t)r * D.N + i];
+  out[0] = h.x; out[1] = h.y; out[2] = h.z; out[3] = h.w;
+  out[4] = p0.x; out[5] = p0.y; out[6] = p0.z; out[7] = p0.w; out[8] = p.x; out[9] = p.y; out[10] = w;
+  for (uint32_t j = 0; j < h_qlen(h.y) && j < 32; j++) { uint4 e = D.q[(size_t)j * NL + l]; out[16 + 4 * j] = e.x; out[17 + 4 * j] = e.y; out[18 + 4 * j] = e.z; out[19 + 4 * j] = e.w; }
+}
 
 // order-independent digest (same item hashes as the oracle; see swim_state_digest there)
 __device__ __forceinline__ void digest_commit(uint64_t d, unsigned long long* out) {
   for (int off = 32; off; off >>= 1) d += __shfl_down(d, off);
-  if (sw_lane() == 0 && d) atomicAdd(out, (unsigned long long)d);
+  if (sw_lane() == 0 && d) atomicAdd(out + (blockIdx.x % 64) * 8, (unsigned long long)d);
 }
 __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(SwDev D, unsigned long long* out) {
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   uint64_t d = 0;
   if (l < NL) {
     uint32_t r = (uint32_t)(l / D.nloc), i = D.i0 + (uint32_t)(l % D.nloc); uint64_t g = (uint64_t)r * D.N + i;
-    uint4 h = D.hdr[l], p0 = D.pr0[l], p1 = D.pr1[l];
-    d += sw_h3(1, g, ((uint64_t)h.x << 32) | ((uint64_t)h_aware(h.y) << 8) | h_leaving(h.y));
-    d += sw_h3(2, g, ((uint64_t)p1.x << 32) | p1.y);
+    uint4 h = D.hdr[l], p0 = D.pr0[l]; uint2 p = D.ph[l];
+    d += sw_h3(1, g, ((uint64_t)h.x << 32) | ((uint64_t)p_aw(p.y) << 8) | h_leaving(h.y));
+    d += sw_h3(2, g, ((uint64_t)p.x << 32) | p_epoch(p.y));
     if (p0.x != NONE)
-      d += sw_h3(3, g, ((uint64_t)p0.x << 32) | p0.z) + sw_h3(4, g, ((uint64_t)p0.y << 32) | ((uint64_t)(p1.z & 0xFF) << 8) | ((p1.z >> 8) & 0xFF));
+      d += sw_h3(3, g, ((uint64_t)p0.x << 32) | p0.z) + sw_h3(4, g, ((uint64_t)p0.y << 32) | ((uint64_t)p_stage(p.y) << 8) | p_nackm(p.y));
     for (uint32_t j = 0; j < h_qlen(h.y); j++) {
       uint4 e = D.q[(size_t)j * NL + l];
       d += sw_h3(5, g, sw_h3(e.x, ((uint64_t)e.y << 32) | e.z, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8) | m_type(e.w)));
