@@ -124,8 +124,12 @@ def main():
     from consul_amd.dist import ShardedSim, TorchExchange
     hip = lib.load()
     reps = args.replicas * world                       # weak scaling: replicas grow with the ranks
+    # one failure per cluster => at most a couple of rumours queued per node: 4 queue slots (LDS per
+    # gossip block scales with queue_cap) and 24 inbox slots (in-degree is Poisson(k)) are ample, and
+    # an overflow would raise SWIM_EOVERFLOW instead of passing silently
     cfg_kw = dict(n_nodes=args.nodes, n_replicas=reps, seed=args.seed, subject_cap=args.subject_cap,
-                  gossip_nodes=args.fanout, device=local_rank, shard_rank=rank, n_shards=world)
+                  gossip_nodes=args.fanout, queue_cap=4, inbox_cap=24,
+                  device=local_rank, shard_rank=rank, n_shards=world)
     victims = victims_for(args.seed, reps, args.nodes)
 
     def fresh():

@@ -9,6 +9,7 @@
 #include "../../include/swimsim.h"
 
 #define SW_MAX_SHARDS 16
+#define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
 
 // counters mirrored 1:1 into swim_stats_t by the host
@@ -52,7 +53,7 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 
 struct SwDev {
   // dimensions
-  uint32_t N, R, nloc, i0, S, Q, C, CROW, EQ, EB;
+  uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB;
   uint32_t G, P, TQ, CH, quantum_ms;
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
   uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks;
@@ -72,7 +73,10 @@ struct SwDev {
   uint4* q;         // [Q][NL]  {subject, inc, from, type<<30 | transmits<<22 | seq}
   uint4* evq;       // [EQ][NL] {event id, ltime, 0, meta}
   uint4* ring;      // [EB][NL] {n<<30 | ltime, id0, id1, id2}
-  uint4* inbox;     // [NL][CROW]: row[0].x = count, row[1..C] = swim_edge; CROW*16 is a multiple of 64 B
+  // per-node inbox: one 64-byte line {count, 5 x 12-byte messages} that stays cache resident, plus an
+  // overflow row for arrivals 6..C (a message = {subject, incarnation, type<<30|from})
+  uint32_t* inbox1; // [NL][16]
+  uint32_t* inbox2; // [NL][C2][3]
   // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
   uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue
   uint32_t* in_any;   // [NL/256] some node of the block received something this tick
@@ -96,7 +100,13 @@ struct SwDev {
   uint32_t* pend;        // [TQ+1][pend_cap] local lane ids
   uint32_t* pend_cnt;    // [TQ+1]
   uint32_t pend_cap;
-  // edge lists
+  // edge lists.  Records for nodes of this shard produced by gossip block b go to the block's
+  // private segment seg[b*seg_cap ..] (no global atomic); everything else (timers, probes, slot
+  // requests, other shards) is appended to out[shard] with wave-aggregated atomics.
+  uint4* seg;
+  uint32_t* seg_cnt;     // [n_seg] consumed and zeroed by k_deliver
+  uint32_t* seg_last;    // [n_seg] what k_deliver consumed in the most recent tick (swim_debug_edges)
+  uint32_t seg_cap, n_seg, nb_gossip;
   uint4* out[SW_MAX_SHARDS];
   uint32_t* out_cnt;     // [n_shards]
   uint32_t out_cap[SW_MAX_SHARDS];

@@ -231,7 +231,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const bool serf = (cfg->flags & SWIM_F_SERF_EVENTS) != 0;
   D.N = cfg->n_nodes; D.R = cfg->n_replicas; D.nloc = D.N / cfg->n_shards; D.i0 = cfg->shard_rank * D.nloc;
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
-  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.CROW = (1 + D.C + 3) & ~3u;
+  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C - SW_INBOX_FAST : 0;
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
   D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
   D.quantum_ms = d.quantum_ms; D.k_gossip = cfg->gossip_nodes; D.k_indirect = cfg->indirect_checks;
@@ -247,7 +247,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.tick, 1);
   DALLOC(s, D.nw, NT);
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
-  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox, NL * D.CROW);
+  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
   DALLOC(s, D.v_key, NS * D.nloc); DALLOC(s, D.v_since, NS * D.nloc);
@@ -269,12 +269,15 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.roles = 0xF;
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
-  // worst-case records of one tick
+  // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
   const uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
-  uint64_t e_cap = (uint64_t)pl.nb_gossip * SW_BLOCK * D.R * D.k_gossip * per_pkt + 2 * NL + 4096;
+  D.nb_gossip = pl.nb_gossip; D.n_seg = D.R * pl.nb_gossip; D.seg_cap = SW_BLOCK * D.k_gossip * per_pkt;
+  uint64_t e_cap = (uint64_t)D.n_seg * D.seg_cap;
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
+  DALLOC(s, D.seg, e_cap); DALLOC(s, D.seg_cnt, D.n_seg); DALLOC(s, D.seg_last, D.n_seg);
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
-    uint64_t cap = sh == D.rank ? e_cap : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096);
+    // own shard: only timers/probes/slot requests; other shards: their share of the gossip records
+    uint64_t cap = sh == D.rank ? 2 * NL + 4096 : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards;
     D.out_cap[sh] = (uint32_t)cap;
     DALLOC(s, D.out[sh], cap);
   }
@@ -290,6 +293,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.nw, 0, NT * 4, st));
   HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.out_cnt, 0, SW_MAX_SHARDS * 4, st));
+  HIPCK(s, hipMemsetAsync(D.seg_cnt, 0, (size_t)D.n_seg * 4, st));
+  HIPCK(s, hipMemsetAsync(D.seg_last, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(D.pend_cnt, 0, (D.TQ + 1) * 4, st));
   HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
@@ -332,16 +337,15 @@ static void launch_begin(swim_sim* s) {
 static void launch_end(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  const uint32_t dgrid = std::min<uint32_t>(cdiv(D.out_cap[D.rank], SW_BLOCK), 1024);
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(dgrid), dim3(SW_BLOCK), 0, st, D, (const uint4*)D.out[D.rank], (const uint32_t*)&D.out_cnt[D.rank], 0u); }
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, D); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
-    hipLaunchKernelGGL(k_deliver, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK), 1024)), dim3(SW_BLOCK), 0, st, D,
-                       (const uint4*)s->in_buf, (const uint32_t*)nullptr, s->in_count);
+    hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, D,
+                       (const uint4*)s->in_buf, s->in_count);
   }
   { ProfScope p(s, PK_ALLOC); hipLaunchKernelGGL(k_alloc, dim3(1), dim3(64), 0, st, D); }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, D); }
-  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16));
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
   { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, D, s->d_last_cnt); }
   s->in_count = 0;
@@ -384,7 +388,8 @@ extern "C" int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr,
     s->out_counts_valid = true;
   }
   *ptr = (const swim_edge*)s->D.out[shard];
-  *count = std::min(s->out_counts[shard], s->D.out_cap[shard]);
+  // the shard's own records never cross the wire (they sit in the gossip segments and its misc list)
+  *count = shard == s->D.rank ? 0 : std::min(s->out_counts[shard], s->D.out_cap[shard]);
   return SWIM_OK;
 }
 extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
@@ -667,6 +672,15 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
   if (rc) return rc;
   size_t total = 0, w = 0;
   std::vector<swim_edge> tmp;
+  std::vector<uint32_t> segn(s->D.n_seg);
+  if ((rc = d2h(s, segn.data(), (const uint32_t*)s->D.seg_last, s->D.n_seg))) return rc;
+  for (uint32_t b = 0; b < s->D.n_seg; b++) {
+    uint32_t n = std::min(segn[b], s->D.seg_cap);
+    if (!n) continue;
+    tmp.resize(n);
+    if ((rc = d2h(s, tmp.data(), (const swim_edge*)s->D.seg + (size_t)b * s->D.seg_cap, n))) return rc;
+    for (uint32_t i = 0; i < n; i++) { if (w < cap) out[w++] = tmp[i]; total++; }
+  }
   for (uint32_t sh = 0; sh < s->D.n_shards; sh++) {
     uint32_t n = std::min(cnt[sh], s->D.out_cap[sh]);
     tmp.resize(n);

@@ -156,10 +156,19 @@ __device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint3
   uint32_t found = 0, now = now_ms(D, t);
   const uint32_t* nw = D.nw + (size_t)r * D.N;
   uint64_t tries = 3ull * D.N;
+  // the first Philox block yields four candidates: fetch their node words together (four
+  // independent random reads in flight) instead of one dependent read per loop trip
+  uint32_t x4[4], w4[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) x4[j] = d.get(j) % D.N;
+#pragma unroll
+  for (int j = 0; j < 4; j++) w4[j] = nw[x4[j]];
   for (uint64_t i = 0; i < tries && found < want; i++) {
-    uint32_t x = d.get((uint32_t)i) % D.N;
+    uint32_t x, w;
+    if (i < 4) { x = i == 0 ? x4[0] : i == 1 ? x4[1] : i == 2 ? x4[2] : x4[3]; w = i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]; }
+    else { x = d.get((uint32_t)i) % D.N; w = nw[x]; }
     if (x == o) continue;
-    uint32_t w = nw[x], since, key = view_of(D, r, k_local, w, &since), st = SW_KST(key);
+    uint32_t since, key = view_of(D, r, k_local, w, &since), st = SW_KST(key);
     if (mode == 0) {
       if (st == SWIM_STATE_LEFT) continue;
       if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
@@ -428,23 +437,40 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
 
   // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
   //      atomicAdd per (block, shard)
-  for (uint32_t p = 0; p < np; p++) loc[p] = atomicAdd(&s_cnt[psh[p]], (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])));
-  __syncthreads();
-  if (threadIdx.x < D.n_shards) {
-    uint32_t c = s_cnt[threadIdx.x], b = 0;
-    if (c) {
-      b = atomicAdd(&D.out_cnt[threadIdx.x], c);
-      if (b + c > D.out_cap[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
-      atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c);
-      if (threadIdx.x != D.rank) atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);
-    }
-    s_base[threadIdx.x] = b;
+  // (a) records for nodes of this shard: wavefront prefix sum of the per-lane counts, one LDS atomic per
+  //     wave, block-private segment -> no global atomic and no barrier on the way out
+  const uint32_t segb = r * D.nb_gossip + bx;
+  uint32_t n_loc = 0;
+  for (uint32_t p = 0; p < np; p++) if (psh[p] == D.rank) n_loc += (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p]));
+  uint32_t incl = n_loc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
+  uint32_t wave_total = __shfl(incl, 63), wbase = 0;
+  if (wave_total) {
+    if (sw_lane() == 63) wbase = atomicAdd(&s_cnt[D.rank], wave_total);
+    wbase = __shfl(wbase, 63);
   }
-  __syncthreads();
+  uint32_t my_off = wbase + incl - n_loc;
+  // (b) records for other shards: LDS offsets, then one global atomicAdd per (block, shard)
+  if (D.n_shards > 1) {
+    for (uint32_t p = 0; p < np; p++) if (psh[p] != D.rank) loc[p] = atomicAdd(&s_cnt[psh[p]], (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])));
+    __syncthreads();
+    if (threadIdx.x < D.n_shards && threadIdx.x != D.rank) {
+      uint32_t c = s_cnt[threadIdx.x], b = 0;
+      if (c) {
+        b = atomicAdd(&D.out_cnt[threadIdx.x], c);
+        if (b + c > D.out_cap[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
+        atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c);
+        atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);
+      }
+      s_base[threadIdx.x] = b;
+    }
+    __syncthreads();
+  }
   for (uint32_t p = 0; p < np; p++) {
-    uint32_t b = s_base[psh[p]];
-    if (b == NONE) continue;
-    uint4* dst = D.out[psh[p]] + b + loc[p];
+    uint4* dst;
+    if (psh[p] == D.rank) { dst = D.seg + (size_t)segb * D.seg_cap + my_off; my_off += (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])); }
+    else { uint32_t b = s_base[psh[p]]; if (b == NONE) continue; dst = D.out[psh[p]] + b + loc[p]; }
     uint32_t gdst = r * D.N + peers[p];
     for (uint32_t m = sent_m[p]; m; m &= m - 1) {
       uint4 e = sq[(__ffs(m) - 1) * SW_BLOCK];
@@ -468,7 +494,11 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   bool holds = (nq | ne) != 0;
   if (i != NONE && (wi & NW_DEAD) && D.fast_blocks) { uint32_t hy = D.hdr[(size_t)r * D.nloc + (i - D.i0)].y; holds = (h_qlen(hy) | h_evqlen(hy)) != 0; }
   int any = __syncthreads_or(holds);
-  if (fb != NONE && !any && threadIdx.x == 0) D.q_any[fb] = 0;
+  if (threadIdx.x == 0) {
+    if (fb != NONE && !any) D.q_any[fb] = 0;
+    uint32_t c = s_cnt[D.rank];                    // every wave has added its total (barrier above)
+    if (c) { D.seg_cnt[segb] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); }
+  }
   S.flush(D);
 }
 
@@ -495,23 +525,58 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
 // returning atomic on the row's count word reserves the slot; the record lands in the same 64-byte
 // line for the first three arrivals.  Slot requests are side-lined for k_alloc.
 // =================================================================================================
-__global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D, const uint4* edges, const uint32_t* cnt_ptr, uint32_t cnt_host) {
-  uint32_t n = cnt_ptr ? *cnt_ptr : cnt_host;
-  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) {
-    uint4 rec = edges[e];
-    if (rec.x == NONE) {
-      uint32_t pos = atomicAdd(D.ctrl_cnt, 1u);
-      if (pos < D.ctrl_cap) D.ctrl[pos] = rec; else atomicOr(D.err, SW_ERR_CTRL_OVF);
-      continue;
-    }
-    uint32_t r = rec.x / D.N, x = rec.x % D.N;
-    if (x < D.i0 || x >= D.i0 + D.nloc) continue;
-    size_t l = (size_t)r * D.nloc + (x - D.i0);
-    uint4* row = D.inbox + l * D.CROW;
-    uint32_t pos = atomicAdd(&row[0].x, 1u);
-    if (pos < D.C) row[1 + pos] = rec;
-    if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
+// reserve: one returning atomic on the count word of the node's 64-byte inbox line
+__device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, size_t& l) {
+  if (rec.x == NONE) {
+    uint32_t pos = atomicAdd(D.ctrl_cnt, 1u);
+    if (pos < D.ctrl_cap) D.ctrl[pos] = rec; else atomicOr(D.err, SW_ERR_CTRL_OVF);
+    return NONE;
   }
+  uint32_t r = rec.x / D.N, x = rec.x % D.N;
+  if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
+  l = (size_t)r * D.nloc + (x - D.i0);
+  return atomicAdd(&D.inbox1[l * 16], 1u);
+}
+// place: the message lands in the same line for the first SW_INBOX_FAST arrivals, else in the overflow row
+__device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l, uint32_t pos) {
+  if (pos == NONE) return;
+  uint32_t* m = nullptr;
+  if (pos < SW_INBOX_FAST) m = D.inbox1 + l * 16 + 1 + 3 * pos;
+  else if (pos < D.C) m = D.inbox2 + (l * D.C2 + (pos - SW_INBOX_FAST)) * 3;
+  if (m) { m[0] = rec.y; m[1] = rec.z; m[2] = rec.w; }
+  if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
+}
+// four records per thread per trip: all four atomics are in flight before the first store
+__device__ __forceinline__ void deliver_span(const SwDev& D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride) {
+  for (uint32_t e = first; e < n; e += 4 * stride) {
+    uint4 rec[4]; size_t l[4]; uint32_t pos[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (e + j * stride < n) rec[j] = edges[e + j * stride];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pos[j] = e + j * stride < n ? inbox_reserve(D, rec[j], l[j]) : NONE;
+#pragma unroll
+    for (int j = 0; j < 4; j++) inbox_place(D, rec[j], l[j], pos[j]);
+  }
+}
+// grid = n_seg blocks (block b drains gossip segment b) + extra blocks over the shard's misc list
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
+  uint32_t b = blockIdx.x;
+  if (b < D.n_seg) {
+    uint32_t n = D.seg_cnt[b], last = D.seg_last[b];
+    __syncthreads();                               // everybody has read the count before lane 0 clears it
+    if (threadIdx.x == 0 && last != n) D.seg_last[b] = n;
+    if (!n) return;
+    deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK);
+    if (threadIdx.x == 0) D.seg_cnt[b] = 0;
+    return;
+  }
+  uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
+  if (n > D.out_cap[D.rank]) n = D.out_cap[D.rank];
+  deliver_span(D, D.out[D.rank], n, (b - D.n_seg) * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
+}
+// records handed over by other shards (swim_inbound)
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(SwDev D, const uint4* edges, uint32_t n) {
+  deliver_span(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 
 // =================================================================================================
@@ -554,13 +619,18 @@ struct NodeCtx {
   const SwDev& D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
+  uint4 h0;
   __device__ NodeCtx(const SwDev& d, BlockStats& s) : D(d), S(s) {}
 
   __device__ void load() {
-    uint4 h = D.hdr[l];
-    self_inc = h.x; leaving = h_leaving(h.y); qlen = h_qlen(h.y); evqlen = h_evqlen(h.y); qseq = h.z; ev_clock = h.w;
+    h0 = D.hdr[l];
+    self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
-  __device__ void store() { D.hdr[l] = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock); }
+  // most deliveries in a saturated cluster are old news: only write the header back when it changed
+  __device__ void store() {
+    uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
+    if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
+  }
 
   // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
   __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t seq, bool named,
@@ -699,11 +769,15 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   size_t NL = (size_t)D.R * D.nloc;
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l < NL) {
-    uint4* row = D.inbox + l * D.CROW;
-    uint32_t cnt = row[0].x;
+    // the whole 64-byte line (count + first five messages) in one go, kept in registers
+    const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
+    uint4 ra = row4[0];
+    uint32_t cnt = ra.x;
     if (cnt) {
-      row[0].x = 0;
+      uint4 rb = row4[1], rc = row4[2], rd = row4[3];
+      D.inbox1[l * 16] = 0;
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
+      const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
       NodeCtx n(D, S);
       n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
       n.load();
@@ -711,7 +785,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
       for (;;) {
         bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
         for (uint32_t j = 0; j < cnt; j++) {
-          uint4 e = row[1 + j]; uint64_t hi, lo; edge_key(e, hi, lo);
+          uint4 e;                                   // {-, subject, inc, meta}
+          if (j == 0) e = make_uint4(0, ra.y, ra.z, ra.w);
+          else if (j == 1) e = make_uint4(0, rb.x, rb.y, rb.z);
+          else if (j == 2) e = make_uint4(0, rb.w, rc.x, rc.y);
+          else if (j == 3) e = make_uint4(0, rc.z, rc.w, rd.x);
+          else if (j == 4) e = make_uint4(0, rd.y, rd.z, rd.w);
+          else { const uint32_t* m = row2 + (j - SW_INBOX_FAST) * 3; e = make_uint4(0, m[0], m[1], m[2]); }
+          uint64_t hi, lo; edge_key(e, hi, lo);
           if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;
           if (!have || hi < bhi || (hi == bhi && lo < blo)) { have = true; bhi = hi; blo = lo; best = e; }
         }
@@ -823,7 +904,7 @@ __global__ void k_init_nodes(SwDev D) {
   D.hdr[l] = make_uint4(1, 0, 0, 0);
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.inbox[l * D.CROW].x = 0;
+  D.inbox1[l * 16] = 0;
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
@@ -867,7 +948,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
       if (local) {
         if (old & NW_DEAD) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
         uint2 h = D.ph[l];
-        D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.inbox[l * D.CROW].x = 0;
+        D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.inbox1[l * 16] = 0;
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
