@@ -74,14 +74,16 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 namespace {
 const double kLn2 = 0.693147180559945309417232121458176568;
-const double kLn10 = 2.30258509299404568401799145468436421;
 // Go's pure-Go math.Log2 (Frexp based) and math.Log10 = Log2(x) * (Ln2/Ln10)
 double go_log2(double x) {
   int e; double f = std::frexp(x, &e);
   if (f == 0.5) return (double)(e - 1);
   return std::log(f) * (1.0 / kLn2) + (double)e;
 }
-double go_log10(double x) { return go_log2(x) * (kLn2 / kLn10); }
+// Go evaluates the constant Ln2/Ln10 exactly and rounds once: 0x1.34413509f79ffp-2 (kLn2 / kLn10 in
+// double arithmetic is one ulp lower and would make log10(100) < 2).
+const double kLn2OverLn10 = 0x1.34413509f79ffp-2;
+double go_log10(double x) { return go_log2(x) * kLn2OverLn10; }
 uint32_t gcd32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
 
 int64_t remaining_suspicion_ms(uint32_t n, uint32_t k, int64_t elapsed, int64_t min_ms, int64_t max_ms) {

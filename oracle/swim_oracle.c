@@ -109,13 +109,16 @@ static uint32_t probe_perm(uint64_t seed_r, uint32_t n, uint32_t node, uint32_t 
 /* ------------------------------------------------------------------------------------------ */
 
 /* Go's math.Log2 / math.Log10 (pure-Go definitions: Log2 via Frexp, Log10 = Log2 * Ln2/Ln10), so
- * truncation edges such as N=1e6 -> 5999 reproduce. */
+ * truncation edges reproduce (pinned by upstream's util_test.go table in tests/test_oracle_kat.py). */
 static double go_log2(double x) {
   int e; double f = frexp(x, &e);
   if (f == 0.5) return (double)(e - 1);
   return log(f) * (1.0 / 0.693147180559945309417232121458176568) + (double)e;
 }
-static double go_log10(double x) { return go_log2(x) * (0.693147180559945309417232121458176568 / 2.30258509299404568401799145468436421); }
+/* Go folds the constant expression Ln2/Ln10 exactly and rounds ONCE (0x1.34413509f79ffp-2); dividing
+ * the two rounded doubles gives ...79fep-2 and turns log10(100) into 1.9999999999999998, which would
+ * contradict upstream's own util_test.go table (suspicionTimeout(3, 100, 1s)/3 == 2000 ms). */
+static double go_log10(double x) { return go_log2(x) * 0x1.34413509f79ffp-2; }
 
 static uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
 

@@ -1,0 +1,59 @@
+"""The N>1 path on CPU: every replica's population block-partitioned over shards.
+
+ * in-process: 2 and 4 shards of the oracle, records handed over by pointer (LocalExchange);
+ * two real processes over torch.distributed/gloo: counts + uneven all_to_all_single
+   (TorchExchange — the code path bench.py uses with the nccl backend on GPUs).
+Both must reproduce the unsharded oracle bit for bit (digests add up; counters add up)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from consul_amd import abi
+from consul_amd.dist import LocalExchange, ShardedSim
+from consul_amd.sim import Sim, preset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_in_process_shards_match_unsharded(oracle, n_shards):
+    kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, queue_cap=16, inbox_cap=128,
+              loss_q32=int(0.05 * 2**32))
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw))
+                     for i in range(n_shards)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.step_ms(3000)
+        s.kill(0, [100, 1500]); s.kill(1, [7]); s.update(1, [1024])
+        s.step_ms(20000)
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("edges", "refutes", "probe_failures", "msgs_applied", "packets_sent", "confirmations"):
+        assert a[k] == b[k], k
+    assert a["edges_remote"] > 0 and b["edges_remote"] == 0
+
+
+def test_split_tick_rejects_out_of_phase_calls(oracle):
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=256, n_shards=2, shard_rank=0))
+    with pytest.raises(Exception):
+        s.step(1)                                   # swim_step is single-shard only
+    with pytest.raises(Exception):
+        s.tick_end()                                # no tick open
+    s.tick_begin()
+    with pytest.raises(Exception):
+        s.tick_begin()
+    with pytest.raises(Exception):
+        s.kill(0, [1])                              # stimulus only between ticks
+    s.tick_end()
+
+
+def test_two_processes_over_gloo_match_unsharded(oracle):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and "ok=True" in line[0], (line, out.stderr[-1000:])

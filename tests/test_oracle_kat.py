@@ -1,0 +1,307 @@
+"""Known-answer tests that pin the CPU oracle (and the host-side arithmetic of the HIP library).
+
+The reference's hot path lives in un-vendored Go modules and its own tests hold no golden vectors
+for it, so these KATs are written from
+  * the closed-form constants the reference documents in-tree (agent/config/runtime.go:1326,1344) as
+    tabulated in BASELINE.md §2 / SURVEY.md Appendix B (whose N=1e6 row is corrected here: Go folds
+    Ln2/Ln10 with a single rounding, so log10(1e6) is exactly 6, as upstream's own util_test table demands),
+  * the Random123 published vectors for Philox4x32-10,
+  * the upstream semantics restated in SURVEY.md Appendix A (queue order, state precedence, Lifeguard).
+Both libraries are checked wherever the function is pure host code (no GPU needed).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from consul_amd import abi
+from consul_amd.sim import Sim, derive, preset
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(params=["oracle", "hip"])
+def anylib(request, oracle, hip):
+    return oracle if request.param == "oracle" else hip
+
+
+# ---- Philox4x32-10 (Random123 kat_vectors) ------------------------------------------------------
+PHILOX_KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+    ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+    ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+     (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KAT)
+def test_philox_known_answers(anylib, ctr, key, want):
+    c, k, o = (abi.u32 * 4)(*ctr), (abi.u32 * 2)(*key), (abi.u32 * 4)()
+    anylib.swim_kat_philox4x32(c, k, o)
+    assert tuple(o) == want
+
+
+# ---- closed-form constants: SURVEY Appendix B / BASELINE.md §2 -----------------------------------
+# N: (retransmit limit, int(nodeScale*1000), LAN min, LAN max, WAN min, WAN max, push-pull multiplier)
+CONSTANTS = {
+    128: (12, 2107, 8428, 50568, 63210, 379260, 3),
+    65536: (20, 4816, 19264, 115584, 144480, 866880, 12),
+    1000000: (28, 6000, 24000, 144000, 180000, 1080000, 16),   # NOT 5999: see test_upstream_util_tables
+    1048576: (28, 6020, 24080, 144480, 180600, 1083600, 16),
+    4194304: (28, 6622, 26488, 158928, 198660, 1191960, 18),
+}
+
+
+@pytest.mark.parametrize("n", sorted(CONSTANTS))
+def test_scaling_constants(anylib, n):
+    rl, scale, lmin, lmax, wmin, wmax, pp = CONSTANTS[n]
+    d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=n))
+    assert (d.retransmit_limit, d.node_scale_milli, d.suspicion_min_ms, d.suspicion_max_ms, d.push_pull_scale) == \
+        (rl, scale, lmin, lmax, pp)
+    assert d.suspicion_k == 2 and d.suspicion_timeout_ms[0] == lmax and d.suspicion_timeout_ms[2] == lmin
+    assert (d.quantum_ms, d.gossip_period, d.probe_period, d.probe_timeout_ticks) == (100, 2, 10, 5)
+    w = derive(anylib, preset(anylib, abi.PRESET_WAN, n_nodes=n))
+    assert (w.suspicion_min_ms, w.suspicion_max_ms, w.suspicion_k) == (wmin, wmax, 4)
+    assert (w.quantum_ms, w.gossip_period, w.probe_period, w.probe_timeout_ticks) == (500, 1, 10, 6)
+
+
+def test_presets_match_documented_defaults(anylib):
+    """agent/config/runtime.go:1285-1427 (LAN / WAN) and SURVEY Appendix A.2 (Local)."""
+    lan, wan, loc = (preset(anylib, p) for p in (abi.PRESET_LAN, abi.PRESET_WAN, abi.PRESET_LOCAL))
+    assert (lan.gossip_interval_ms, lan.gossip_nodes, lan.probe_interval_ms, lan.probe_timeout_ms,
+            lan.suspicion_mult, lan.retransmit_mult) == (200, 3, 1000, 500, 4, 4)
+    assert (wan.gossip_interval_ms, wan.gossip_nodes, wan.probe_interval_ms, wan.probe_timeout_ms,
+            wan.suspicion_mult, wan.retransmit_mult) == (500, 4, 5000, 3000, 6, 4)
+    assert (loc.gossip_interval_ms, loc.indirect_checks, loc.retransmit_mult, loc.suspicion_mult,
+            loc.probe_timeout_ms) == (100, 1, 2, 3, 200)
+    for c in (lan, wan, loc):
+        assert (c.indirect_checks if c is not loc else 3, c.suspicion_max_timeout_mult, c.awareness_max_mult,
+                c.udp_buffer_size) == (3, 6, 8, 1400)
+    assert (lan.gossip_to_dead_ms, wan.gossip_to_dead_ms, loc.gossip_to_dead_ms) == (30000, 60000, 15000)
+
+
+def test_small_cluster_expects_no_confirmations(anylib):
+    """suspectNode: k = SuspicionMult-2, but 0 when n-2 < k; newSuspicion then starts at min."""
+    d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=3))
+    assert d.suspicion_k == 0 and d.suspicion_timeout_ms[0] == d.suspicion_min_ms
+    d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=4))
+    assert d.suspicion_k == 2 and d.suspicion_timeout_ms[0] == d.suspicion_max_ms
+
+
+# ---- suspicion.go remainingSuspicionTime (upstream suspicion_test.go shape: k=3, min 2s, max 30s) ----
+@pytest.mark.parametrize("n,elapsed,want", [
+    (0, 0, 30000), (1, 2000, 14000), (2, 3000, 4810), (3, 4000, -2000), (4, 5000, -3000), (5, 10000, -8000)])
+def test_remaining_suspicion_time(anylib, n, elapsed, want):
+    assert anylib.swim_kat_remaining_suspicion_ms(n, 3, elapsed, 2000, 30000) == want
+
+
+def test_suspicion_table_lan_fraction(anylib):
+    """LAN k=2: n=1 -> max - log(2)/log(3) * (max - min), floor to ms."""
+    d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=65536))
+    import math
+    assert d.suspicion_timeout_ms[1] == math.floor(1000 * (115.584 - math.log(2) / math.log(3) * (115.584 - 19.264)))
+
+
+# ---- the shuffled probe order is a permutation per (node, epoch) ------------------------------------
+@pytest.mark.parametrize("n", [2, 7, 128, 1000, 4096])
+def test_probe_order_is_a_permutation(anylib, n):
+    for node, epoch in ((0, 0), (n - 1, 3)):
+        seen = sorted(anylib.swim_kat_probe_perm(11, n, node, epoch, i) for i in range(n))
+        assert seen == list(range(n))
+    a = [anylib.swim_kat_probe_perm(11, n, 0, 0, i) for i in range(min(n, 64))]
+    b = [anylib.swim_kat_probe_perm(11, n, 0, 1, i) for i in range(min(n, 64))]
+    assert n < 7 or a != b                                   # reshuffled on wrap
+
+
+def test_probe_order_agrees_between_libraries(oracle, hip):
+    for args in ((1, 65536, 17, 0, 5), (99, 1000, 3, 7, 999), (2**40 + 3, 4194304, 4194303, 2, 123456)):
+        assert oracle.swim_kat_probe_perm(*args) == hip.swim_kat_probe_perm(*args)
+
+
+def test_stagger_phases_cover_all_combinations(anylib):
+    cfg = preset(anylib, abi.PRESET_LAN, n_nodes=65536)
+    g, p = abi.u32(), abi.u32()
+    combos = set()
+    for node in range(0, 65536, 256):
+        anylib.swim_kat_phase_of(C.byref(cfg), node, C.byref(g), C.byref(p))
+        combos.add((g.value, p.value))
+    assert combos == {(a, b) for a in range(2) for b in range(10)}
+
+
+# ---- config validation -----------------------------------------------------------------------------
+@pytest.mark.parametrize("field,value", [("n_nodes", 1), ("gossip_nodes", 0), ("gossip_nodes", 9), ("suspicion_mult", 7),
+                                         ("queue_cap", 33), ("quantum_ms", 300), ("phase_chunk", 48),
+                                         ("n_shards", 3), ("abi_version", 99)])
+def test_bad_config_is_rejected(anylib, field, value):
+    cfg = preset(anylib, abi.PRESET_LAN, n_nodes=128)
+    setattr(cfg, field, value)
+    d = abi.Derived()
+    assert anylib.swim_config_derive(C.byref(cfg), C.byref(d)) in (abi.EINVAL, abi.ERANGE)
+    h = abi.SimP()
+    assert anylib.swim_create(C.byref(cfg), C.byref(h)) != abi.OK
+
+
+# ---- behavioural known answers on the oracle ---------------------------------------
+def small(oracle, **kw):
+    base = dict(n_nodes=8, seed=3, subject_cap=8, watch_node=0)
+    base.update(kw)
+    return Sim(oracle, preset(oracle, abi.PRESET_LAN, **base))
+
+
+def test_queue_transmit_limit_and_retire(oracle):
+    """A rumour is handed to GetBroadcasts once per peer and retires after retransmitLimit sends."""
+    s = small(oracle, n_nodes=8)
+    limit = s.derived.retransmit_limit                      # 4 * ceil(log10(9)) = 4
+    assert limit == 4
+    s.update(0, [5])
+    q = s.node_info(0, 5)
+    assert q.queue_len == 1 and q.queue[0].type == abi.MSG_ALIVE and q.queue[0].transmits == 0 and q.incarnation == 2
+    # node 5 gossips every other tick to 3 peers: transmits climb 3 at a time, gone after `limit` sends
+    before = s.stats()["msgs_sent"][abi.MSG_ALIVE]
+    s.step(2)
+    assert s.stats()["msgs_sent"][abi.MSG_ALIVE] - before >= 3
+    for _ in range(20):
+        s.step(1)
+    assert s.node_info(0, 5).queue_len == 0
+    per_origin = [s.view(0, o, 5).incarnation for o in range(8)]
+    assert per_origin == [2] * 8                           # everybody adopted the higher incarnation
+
+
+def test_named_broadcast_invalidates_older_rumour_about_same_node(oracle):
+    s = small(oracle)
+    s.update(0, [2])
+    s.update(0, [2])                                        # second UpdateNode replaces the first rumour
+    q = s.node_info(0, 2)
+    assert q.queue_len == 1 and q.queue[0].incarnation == 3 and q.queue[0].seq == 1
+
+
+def test_queue_order_prefers_fewer_transmits_then_newer(oracle):
+    """limitedBroadcast.Less (transmits asc, len desc, id desc) with a byte budget of ONE message per
+    packet: a node holding two equally-transmitted rumours sends newest, oldest, newest to its three
+    peers, so the newer entry gains 2 transmits and the older 1 (one GetBroadcasts call per peer)."""
+    s = small(oracle, n_nodes=64, udp_buffer_size=2 + 2 + 128, queue_cap=8)   # budget 130 = one alive msg
+    assert s.derived.packet_budget == 130 and s.derived.retransmit_limit == 8
+    s.update(0, [1]); s.update(0, [2])
+    checked = 0
+    for _ in range(12):
+        before = {i: s.node_info(0, i) for i in range(64)}
+        s.step(1)
+        for i, b in before.items():
+            a = s.node_info(0, i)
+            if b.queue_len != 2 or a.queue_len != 2:
+                continue
+            qb, qa = [b.queue[0], b.queue[1]], [a.queue[0], a.queue[1]]          # sorted by seq (age)
+            if [q.seq for q in qb] != [q.seq for q in qa] or qb[0].transmits != qb[1].transmits:
+                continue
+            gained = [qa[j].transmits - qb[j].transmits for j in range(2)]
+            if sum(gained) == 3:                                                 # it gossiped this tick
+                assert gained == [1, 2], gained
+                checked += 1
+    assert checked > 0
+    st = s.stats()
+    assert sum(st["msgs_sent"]) == st["packets_sent"]          # one message per packet under this budget
+
+
+def test_upstream_util_tables(anylib):
+    """The tables of memberlist's own util_test.go (TestSuspicionTimeout, TestRetransmitLimit,
+    TestPushPullScale), recalled from upstream v0.5.x — not present in the reference checkout."""
+    for n, want in {5: 1000, 10: 1000, 50: 1698, 100: 2000, 500: 2698, 1000: 3000}.items():
+        d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=n, suspicion_mult=3, probe_interval_ms=1000))
+        assert d.suspicion_min_ms // 3 == want, n
+    for n, want in {2: 3, 99: 6, 9: 3, 10: 6, 999: 9}.items():        # retransmitLimit(3, n)
+        assert derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=n, retransmit_mult=3)).retransmit_limit == want
+    for n in range(2, 129):                                              # pushPullScale
+        want = 1 if n <= 32 else 2 if n <= 64 else 3
+        assert derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=n)).push_pull_scale == want, n
+
+
+def test_state_precedence_matrix(oracle):
+    """aliveNode needs a strictly higher incarnation; suspect/dead accept an equal one; dead>suspect>alive."""
+    s = small(oracle, n_nodes=32)
+    s.kill(0, [4])
+    s.step_ms(60000)                                        # probe failure -> suspect -> dead, everywhere
+    v = s.view(0, 1, 4)
+    assert v.state == abi.STATE_DEAD and v.incarnation == 1 and v.status == abi.MEMBER_FAILED
+    c = s.census(0, 4)
+    assert c.by_state[abi.STATE_DEAD] == c.n_observers == 31
+    assert c.first_suspect_ms < c.first_dead_ms <= c.all_dead_ms
+    ev = s.poll_events()
+    assert [e[2] for e in ev] == [abi.EVENT_MEMBER_FAILED] and ev[0][3] == 4
+
+
+def test_refute_bumps_incarnation_and_awareness(oracle):
+    """A live node that hears it is suspected re-asserts itself with incarnation+1 (refute)."""
+    s = small(oracle, n_nodes=64, loss_q32=int(0.35 * 2**32), subject_cap=64, queue_cap=16, inbox_cap=64)
+    assert s.derived.suspicion_min_ms > 6000                # no suspicion can run out during the lossy phase
+    s.step_ms(6000)
+    st = s.stats()
+    assert st["refutes"] > 0 and st["probe_failures"] > 0
+    bumped = [i for i in range(64) if s.node_info(0, i).incarnation > 1]
+    assert bumped
+    s.set_loss(0.0)
+    s.step_ms(60000)
+    # Once the network heals the refutations win almost everywhere; gossip alone (no push-pull
+    # anti-entropy in this model) gives no hard guarantee, so the bar is "nearly all, never ahead".
+    for i in bumped:
+        inc = s.node_info(0, i).incarnation
+        views = [s.view(0, o, i) for o in range(64)]
+        assert all(v.incarnation <= inc for v in views)
+        assert sum(v.state == abi.STATE_ALIVE and v.incarnation == inc for v in views) >= 58
+
+
+def test_lifeguard_nacks_miss_at_lan_timing(oracle):
+    """LAN timers: the nack leaves the helper ProbeTimeout after the indirect ping, i.e. at the
+    prober's deadline, so at health score 0 it is missed: awareness += expectedNacks."""
+    s = small(oracle, n_nodes=64)
+    s.kill(0, [20])
+    s.step_ms(5000)
+    st = s.stats()
+    assert st["probe_failures"] >= 1 and st["nacks_missed"] >= 3 * 1
+    worst = max(s.node_info(0, i).awareness for i in range(64) if i != 20)
+    assert worst >= 2
+
+
+def test_leave_is_left_not_failed(oracle):
+    s = small(oracle, n_nodes=64)
+    s.leave(0, [10])
+    assert s.view(0, 10, 10).status == abi.MEMBER_LEFT
+    s.step_ms(5000)
+    assert all(s.view(0, o, 10).state == abi.STATE_LEFT for o in range(64))
+    assert [e[2] for e in s.poll_events()] == [abi.EVENT_MEMBER_LEAVE]
+
+
+def test_push_gossip_infection_follows_the_analytic_recurrence(oracle):
+    """single rumour, synchronous rounds: I' = I + (N-I)(1-(1-1/N)^(k I))."""
+    n, k = 16384, 3
+    s = Sim(oracle, preset(oracle, abi.PRESET_WAN, n_nodes=n, gossip_nodes=k, seed=5, trace_ticks=40))
+    s.update(0, [0])
+    s.step(30)
+    got = s.trace(0, 0, 0, 30)[:, 4].astype(float) + 1      # + the origin itself
+    i, model = 1.0, []
+    for _ in range(30):
+        i = i + (n - i) * (1 - (1 - 1 / n) ** (k * i))
+        model.append(i)
+    model = np.array(model)
+    # WAN: G=1 so a tick is a round; the simulated curve reaches 50% / 99% within one round of the model
+    for frac in (0.5, 0.99):
+        assert abs(int(np.argmax(got >= frac * n)) - int(np.argmax(model >= frac * n))) <= 1
+    assert got[-1] == n
+
+
+def test_golden_fixture_config1(oracle):
+    """tests/golden/config1_kill17.json was generated by tools/make_golden.py from this oracle at the
+    commit that introduced it; it guards the restatement against silent drift."""
+    path = os.path.join(HERE, "golden", "config1_kill17.json")
+    g = json.load(open(path))
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, **g["config"]))
+    s.step_ms(g["kill_at_ms"])
+    s.kill(0, [g["victim"]])
+    s.step_ms(g["run_ms"])
+    c = s.census(0, g["victim"])
+    assert [c.first_suspect_ms, c.first_dead_ms, c.all_dead_ms] == g["detect_ms"]
+    assert f"{s.digest():#018x}" == g["digest"]
+    st = s.stats()
+    for k, v in g["stats"].items():
+        assert st[k] == v, k

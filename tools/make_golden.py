@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the CPU oracle (run by hand; the output is committed).
+
+The reference itself cannot be run here (Go modules absent, no Go toolchain), so these fixtures do
+not pin the oracle to the reference — the KATs in tests/test_oracle_kat.py do that as far as it is
+possible.  They freeze the oracle's behaviour so that a later edit cannot drift silently.
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from consul_amd import abi  # noqa: E402
+from consul_amd.sim import Sim, preset  # noqa: E402
+
+ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
+KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "msgs_sent", "msgs_applied", "probes",
+        "probe_acks", "probe_failures", "nacks_missed", "suspicion_timeouts", "confirmations", "edges"]
+
+
+def config1():
+    """BASELINE config #1: 128 nodes, DefaultLANConfig, seed 1, kill node 17 at t=10 s."""
+    cfg = dict(n_nodes=128, seed=1)
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **cfg))
+    s.step_ms(10000); s.kill(0, [17]); s.step_ms(30000)
+    c = s.census(0, 17); st = s.stats()
+    return {"config": cfg, "kill_at_ms": 10000, "victim": 17, "run_ms": 30000,
+            "detect_ms": [c.first_suspect_ms, c.first_dead_ms, c.all_dead_ms],
+            "digest": f"{s.digest():#018x}", "stats": {k: st[k] for k in KEYS}}
+
+
+def config3_small():
+    """BASELINE config #3 shape at 32768 nodes: WAN timers, single update rumour, k in {2,3,5}."""
+    out = {}
+    for k in (2, 3, 5):
+        s = Sim(ora, preset(ora, abi.PRESET_WAN, n_nodes=32768, seed=3, gossip_nodes=k, trace_ticks=64))
+        s.update(0, [0]); s.step(60)
+        out[str(k)] = {"infected": [int(x) for x in s.trace(0, 0, 0, 60)[:, 4]], "digest": f"{s.digest():#018x}"}
+    return {"config": dict(n_nodes=32768, seed=3), "curves": out}
+
+
+if __name__ == "__main__":
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small)):
+        with open(os.path.join(ROOT, "tests", "golden", name + ".json"), "w") as f:
+            json.dump(fn(), f, indent=1)
+        print("wrote", name)
