@@ -1,0 +1,379 @@
+// swimsim_serf.hpp — host side above the C-ABI, in the reference's shape.
+//
+// Consul's seam to its gossip layer is a dozen methods on *serf.Serf plus one event channel
+// (SURVEY.md §8(b)).  This header mirrors that surface — same names, argument meaning and error
+// behaviour — over include/swimsim.h, so code (and tests) written against hashicorp/serf read the
+// same here.  The reference is Go; this image has no Go toolchain, so the compiled host side is C++
+// (header only, links against whichever library exports the C-ABI).  INTEGRATION.md holds the cgo
+// shim a Consul maintainer would add instead.
+//
+//   memberlist::Config / DefaultLANConfig() ...   memberlist config.go; Consul sets the six gossip knobs at
+//                                                 agent/agent.go:1410-1446 and clones them at agent/consul/config.go:679-716
+//   memberlist::Transport / Delegate / ...        the plugin interfaces (wanfed.Transport implements the first:
+//                                                 agent/consul/wanfed/wanfed.go:36-141)
+//   serf::Config / DefaultConfig()                serf config.go; Consul's flavour: internal/gossip/libserf/serf.go:19-36
+//   serf::Member / MemberStatus / Event           api/agent.go:291-311; events consumed at agent/consul/server_serf.go:270-297
+//   serf::Cluster                                 NEW: the simulated gossip pool all virtual members live in
+//   serf::Serf                                    serf.Create/Join/Leave/Shutdown/Members/LocalMember/UserEvent/
+//                                                 SetTags/RemoveFailedNode/Stats/NumNodes as called from
+//                                                 agent/consul/{client,server,server_serf,server_ce,leader}.go
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "swimsim.h"
+
+namespace swimsim {
+
+using Duration = std::chrono::milliseconds;
+
+struct Error : std::runtime_error {
+  int code;
+  Error(const std::string& what, int rc) : std::runtime_error(what + " (swim rc " + std::to_string(rc) + ")"), code(rc) {}
+};
+inline void check(int rc, const char* what) { if (rc) throw Error(what, rc); }
+
+// =================================================================================================
+namespace memberlist {
+
+// memberlist.Config: the fields Consul touches (agent/consul/config.go:679-716) + the fixed defaults
+struct Config {
+  std::string Name;
+  int GossipNodes = 3, IndirectChecks = 3, RetransmitMult = 4, SuspicionMult = 4;
+  int SuspicionMaxTimeoutMult = 6, AwarenessMaxMultiplier = 8, UDPBufferSize = 1400;
+  Duration GossipInterval{200}, ProbeInterval{1000}, ProbeTimeout{500};
+  Duration GossipToTheDeadTime{30000}, PushPullInterval{30000}, TCPTimeout{10000};
+  Duration DeadNodeReclaimTime{0};
+  bool DisableTcpPings = false;
+};
+inline Config DefaultLANConfig() { return Config{}; }
+inline Config DefaultWANConfig() {
+  Config c; c.TCPTimeout = Duration(30000); c.SuspicionMult = 6; c.PushPullInterval = Duration(60000);
+  c.ProbeTimeout = Duration(3000); c.ProbeInterval = Duration(5000); c.GossipNodes = 4;
+  c.GossipInterval = Duration(500); c.GossipToTheDeadTime = Duration(60000);
+  return c;
+}
+inline Config DefaultLocalConfig() {
+  Config c; c.TCPTimeout = Duration(1000); c.IndirectChecks = 1; c.RetransmitMult = 2; c.SuspicionMult = 3;
+  c.PushPullInterval = Duration(15000); c.ProbeTimeout = Duration(200); c.GossipInterval = Duration(100);
+  c.GossipToTheDeadTime = Duration(15000);
+  return c;
+}
+
+struct Address { std::string Addr, Name; };
+struct Packet { std::vector<uint8_t> Buf; std::string From; Duration Timestamp{0}; };
+
+// memberlist.Transport / NodeAwareTransport (poll model instead of channels: no callbacks cross the ABI)
+struct Transport {
+  virtual ~Transport() = default;
+  virtual std::pair<std::string, int> FinalAdvertiseAddr(const std::string& ip, int port) = 0;
+  virtual Duration WriteTo(const std::vector<uint8_t>& b, const std::string& addr) = 0;
+  virtual bool PollPacket(Packet* out) = 0;                    // PacketCh()
+  virtual void Shutdown() = 0;
+};
+struct NodeAwareTransport : Transport {
+  virtual Duration WriteToAddress(const std::vector<uint8_t>& b, const Address& addr) = 0;
+};
+// memberlist.Delegate / EventDelegate
+struct Delegate {
+  virtual ~Delegate() = default;
+  virtual std::vector<uint8_t> NodeMeta(int limit) = 0;
+  virtual void NotifyMsg(const std::vector<uint8_t>& msg) = 0;
+  virtual std::vector<std::vector<uint8_t>> GetBroadcasts(int overhead, int limit) = 0;
+  virtual std::vector<uint8_t> LocalState(bool join) = 0;
+  virtual void MergeRemoteState(const std::vector<uint8_t>& buf, bool join) = 0;
+};
+struct Node { std::string Name, Addr; uint16_t Port = 0; uint32_t Incarnation = 0; int State = 0; };
+struct EventDelegate {
+  virtual ~EventDelegate() = default;
+  virtual void NotifyJoin(const Node&) = 0;
+  virtual void NotifyLeave(const Node&) = 0;
+  virtual void NotifyUpdate(const Node&) = 0;
+};
+}  // namespace memberlist
+
+// =================================================================================================
+namespace serf {
+
+enum MemberStatus { StatusNone = 0, StatusAlive = 1, StatusLeaving = 2, StatusLeft = 3, StatusFailed = 4 };
+enum EventType { EventMemberJoin = 0, EventMemberLeave, EventMemberFailed, EventMemberUpdate, EventMemberReap, EventUser, EventQuery };
+enum SerfState { SerfAlive = 0, SerfLeaving, SerfLeft, SerfShutdown };
+
+inline const char* StatusString(MemberStatus s) {
+  static const char* n[] = { "none", "alive", "leaving", "left", "failed" };
+  return n[s];
+}
+
+struct Member {
+  std::string Name, Addr;
+  uint16_t Port = 0;
+  std::map<std::string, std::string> Tags;
+  MemberStatus Status = StatusNone;
+  uint8_t ProtocolMin = 1, ProtocolMax = 5, ProtocolCur = 2, DelegateMin = 2, DelegateMax = 5, DelegateCur = 4;
+  uint32_t id = 0, Incarnation = 0;       // simulator-side identity
+};
+
+// serf.Event: MemberEvent{Type, Members} or UserEvent{LTime, Name, Payload, Coalesce}
+struct Event {
+  EventType Type = EventMemberJoin;
+  std::vector<Member> Members;
+  uint64_t LTime = 0;
+  std::string Name;
+  std::vector<uint8_t> Payload;
+  bool Coalesce = false;
+  Duration At{0};
+};
+
+// serf.Config: what Consul sets (agent/consul/server_serf.go:71-252, config.go:553-555,640-653)
+struct Config {
+  std::string NodeName;
+  std::map<std::string, std::string> Tags;
+  size_t EventChCap = 256;                 // Consul: 2048 servers / 256 clients (server.go:112-114, client.go:51-59)
+  memberlist::Config MemberlistConfig;
+  Duration ReapInterval{15000}, ReconnectTimeout{24 * 3600 * 1000}, TombstoneTimeout{24 * 3600 * 1000};
+  Duration LeavePropagateDelay{1000};
+  int EventBuffer = 512, UserEventSizeLimit = 512, MaxQueueDepth = 4096, MinQueueDepth = 0;
+  uint8_t ProtocolVersion = 4;
+};
+inline Config DefaultConfig() { return Config{}; }
+// internal/gossip/libserf/serf.go:19-36 + agent/consul/config.go:640-641
+inline Config ConsulDefaultConfig() {
+  Config c; c.MinQueueDepth = 4096; c.LeavePropagateDelay = Duration(3000);
+  c.ReconnectTimeout = Duration(3LL * 24 * 3600 * 1000);
+  return c;
+}
+
+// The virtual gossip pool.  Every member of the pool is a lane on the device; stimulus (kill, partition,
+// loss) is applied to the pool; a serf::Serf is one member's handle into it.
+class Cluster {
+ public:
+  struct Options {
+    uint32_t Nodes = 128, Replicas = 1, QueueCap = 8, InboxCap = 32, SubjectCap = 16, WatchNode = 0;
+    uint64_t Seed = 1;
+    uint32_t Device = 0;
+    int EventBuffer = 512;
+  };
+  Cluster(const memberlist::Config& mc, const Options& o) : opts_(o) {
+    check(swim_config_preset(&cfg_, SWIM_PRESET_LAN), "swim_config_preset");
+    cfg_.n_nodes = o.Nodes; cfg_.n_replicas = o.Replicas; cfg_.seed = o.Seed; cfg_.device = o.Device;
+    cfg_.gossip_nodes = (uint32_t)mc.GossipNodes; cfg_.gossip_interval_ms = (uint32_t)mc.GossipInterval.count();
+    cfg_.probe_interval_ms = (uint32_t)mc.ProbeInterval.count(); cfg_.probe_timeout_ms = (uint32_t)mc.ProbeTimeout.count();
+    cfg_.suspicion_mult = (uint32_t)mc.SuspicionMult; cfg_.retransmit_mult = (uint32_t)mc.RetransmitMult;
+    cfg_.indirect_checks = (uint32_t)mc.IndirectChecks; cfg_.suspicion_max_timeout_mult = (uint32_t)mc.SuspicionMaxTimeoutMult;
+    cfg_.awareness_max_mult = (uint32_t)mc.AwarenessMaxMultiplier; cfg_.gossip_to_dead_ms = (uint32_t)mc.GossipToTheDeadTime.count();
+    cfg_.udp_buffer_size = (uint32_t)mc.UDPBufferSize;
+    cfg_.queue_cap = o.QueueCap; cfg_.inbox_cap = o.InboxCap; cfg_.subject_cap = o.SubjectCap; cfg_.watch_node = o.WatchNode;
+    cfg_.event_buffer = (uint32_t)o.EventBuffer; cfg_.flags |= SWIM_F_SERF_EVENTS;
+    check(swim_config_derive(&cfg_, &derived_), "swim_config_derive");
+    check(swim_create(&cfg_, &sim_), "swim_create");
+  }
+  ~Cluster() { if (sim_) swim_destroy(sim_); }
+  Cluster(const Cluster&) = delete;
+  Cluster& operator=(const Cluster&) = delete;
+
+  // advance simulated time for every member (memberlist's tickers)
+  void Advance(Duration d) {
+    if (d.count() % derived_.quantum_ms) throw Error("Advance: not a multiple of the tick", SWIM_EINVAL);
+    check(swim_step(sim_, (uint32_t)(d.count() / derived_.quantum_ms)), "swim_step");
+    check(swim_sync(sim_), "swim_sync");
+  }
+  Duration Now() const { uint32_t t = 0, ms = 0; swim_now(sim_, &t, &ms); return Duration(ms); }
+  // fault injection (the reference's tests call Shutdown() on a member: agent/consul/server_test.go:725)
+  void Kill(const std::vector<uint32_t>& ids, uint32_t replica = 0) { check(swim_inject_kill(sim_, replica, ids.data(), ids.size()), "swim_inject_kill"); }
+  void Revive(const std::vector<uint32_t>& ids, uint32_t replica = 0) { check(swim_inject_revive(sim_, replica, ids.data(), ids.size()), "swim_inject_revive"); }
+  void Partition(const std::vector<uint8_t>& group, uint32_t replica = 0) {
+    if (group.size() != cfg_.n_nodes) throw Error("Partition: one group id per node", SWIM_EINVAL);
+    check(swim_inject_partition(sim_, replica, group.data()), "swim_inject_partition");
+  }
+  void SetPacketLoss(double p) { check(swim_set_loss(sim_, (uint32_t)std::min(4294967295.0, p * 4294967296.0)), "swim_set_loss"); }
+
+  swim_sim* handle() const { return sim_; }
+  const swim_config& config() const { return cfg_; }
+  const swim_derived& derived() const { return derived_; }
+  static std::string NodeName(uint32_t id) { return "node-" + std::to_string(id); }
+  static std::string NodeAddr(uint32_t id) {
+    return "10." + std::to_string((id >> 16) & 255) + "." + std::to_string((id >> 8) & 255) + "." + std::to_string(id & 255);
+  }
+
+ private:
+  Options opts_;
+  swim_config cfg_{};
+  swim_derived derived_{};
+  swim_sim* sim_ = nullptr;
+};
+
+// One member's *serf.Serf.
+class Serf {
+ public:
+  // serf.Create(conf): conf.NodeName must name a member of the pool ("node-<id>")
+  static std::unique_ptr<Serf> Create(const Config& conf, std::shared_ptr<Cluster> pool, uint32_t id, uint32_t replica = 0) {
+    if (!pool || id >= pool->config().n_nodes) throw Error("serf.Create: unknown member", SWIM_ERANGE);
+    if (conf.UserEventSizeLimit > 9 * 1024) throw Error("serf.Create: user event size limit exceeds limit of 9216 bytes", SWIM_EINVAL);
+    return std::unique_ptr<Serf>(new Serf(conf, std::move(pool), id, replica));
+  }
+
+  // Members(): every member this node knows, with its serf status; failed/left members disappear once
+  // reaped (ReconnectTimeout / TombstoneTimeout, checked at ReapInterval granularity) — handleReap
+  std::vector<Member> Members() {
+    requireNotShutdown("Members");
+    std::vector<swim_member> raw(pool_->config().n_nodes);
+    size_t n = 0;
+    check(swim_members(pool_->handle(), replica_, id_, raw.data(), raw.size(), &n), "swim_members");
+    const int64_t now = pool_->Now().count();
+    const int64_t reap_q = std::max<int64_t>(1, conf_.ReapInterval.count());
+    std::vector<Member> out;
+    for (size_t i = 0; i < n; i++) {
+      const swim_member& r = raw[i];
+      MemberStatus st = (MemberStatus)r.status;
+      if (removed_.count(r.id) && st != StatusAlive) continue;       // RemoveFailedNodePrune
+      if (forced_left_.count(r.id) && st == StatusFailed) st = StatusLeft;
+      if (st == StatusFailed || st == StatusLeft) {
+        int64_t limit = st == StatusFailed ? conf_.ReconnectTimeout.count() : conf_.TombstoneTimeout.count();
+        int64_t checked = now / reap_q * reap_q;                     // the reaper only looks every ReapInterval
+        if (checked - (int64_t)r.state_change_ms > limit) continue;
+      }
+      out.push_back(makeMember(r.id, st, r.incarnation));
+    }
+    return out;
+  }
+  Member LocalMember() {
+    swim_member r;
+    check(swim_view(pool_->handle(), replica_, id_, id_, &r), "swim_view");
+    Member m = makeMember(id_, (MemberStatus)r.status, r.incarnation);
+    m.Tags = conf_.Tags;
+    if (state_ == SerfLeaving) m.Status = StatusLeaving;
+    if (state_ == SerfLeft) m.Status = StatusLeft;
+    return m;
+  }
+  int NumNodes() { return (int)Members().size(); }
+  SerfState State() const { return state_; }
+
+  // Join: the pool starts converged, so every address is "contacted"; errors mirror serf.Join
+  int Join(const std::vector<std::string>& existing, bool /*ignoreOld*/) {
+    if (state_ == SerfShutdown) throw Error("Join: Serf can't Join after Shutdown", SWIM_ESTATE);
+    if (state_ != SerfAlive) throw Error("Join: Serf can't Join after Leave or Shutdown", SWIM_ESTATE);
+    return (int)existing.size();
+  }
+  // Leave: broadcast the intent (memberlist dead{Node==From} => StatusLeft at every peer)
+  void Leave() {
+    if (state_ == SerfLeft) return;
+    if (state_ == SerfLeaving) throw Error("Leave: Leave already in progress", SWIM_ESTATE);
+    if (state_ == SerfShutdown) throw Error("Leave: Leave called after Shutdown", SWIM_ESTATE);
+    state_ = SerfLeaving;
+    check(swim_inject_leave(pool_->handle(), replica_, &id_, 1), "swim_inject_leave");
+    pool_->Advance(roundUp(conf_.LeavePropagateDelay));
+    state_ = SerfLeft;
+  }
+  void Shutdown() {
+    if (state_ == SerfShutdown) return;
+    check(swim_inject_kill(pool_->handle(), replica_, &id_, 1), "swim_inject_kill");
+    state_ = SerfShutdown;
+  }
+  // UserEvent(name, payload, coalesce): size check first, as serf does
+  void UserEvent(const std::string& name, const std::vector<uint8_t>& payload, bool coalesce) {
+    requireNotShutdown("UserEvent");
+    if ((int)(name.size() + payload.size()) > conf_.UserEventSizeLimit)
+      throw Error("user event exceeds configured limit of " + std::to_string(conf_.UserEventSizeLimit) + " bytes before encoding", SWIM_EINVAL);
+    uint32_t id = eventId(name, payload), lt = 0;
+    catalog()[id] = { name, payload, coalesce };
+    check(swim_user_event(pool_->handle(), replica_, id_, id, &lt), "swim_user_event");
+  }
+  void SetTags(const std::map<std::string, std::string>& tags) {
+    requireNotShutdown("SetTags");
+    conf_.Tags = tags;
+    check(swim_inject_update(pool_->handle(), replica_, &id_, 1), "swim_inject_update");   // memberlist.UpdateNode
+  }
+  void RemoveFailedNode(const std::string& node) { forced_left_.insert({ idOf(node), true }); }
+  void RemoveFailedNodePrune(const std::string& node) { removed_.insert({ idOf(node), true }); }
+  std::map<std::string, std::string> Stats() {
+    swim_stats_t st; check(swim_stats(pool_->handle(), &st), "swim_stats");
+    auto ms = Members();
+    size_t failed = 0, left = 0;
+    for (auto& m : ms) { failed += m.Status == StatusFailed; left += m.Status == StatusLeft; }
+    swim_node_info ni; check(swim_node_info_get(pool_->handle(), replica_, id_, &ni), "swim_node_info_get");
+    return { { "members", std::to_string(ms.size()) }, { "failed", std::to_string(failed) }, { "left", std::to_string(left) },
+             { "health_score", std::to_string(ni.awareness) }, { "event_time", std::to_string(ni.event_clock) },
+             { "event_queue", std::to_string(ni.event_queue_len) }, { "intent_queue", std::to_string(ni.queue_len) },
+             { "encrypted", "false" } };
+  }
+
+  // Config.EventCh: bounded; drained by the caller.  Returns false when empty.  A full channel blocks Serf
+  // in the reference (agent/consul/server.go:112-113); here the backlog is reported by EventBacklog().
+  bool PollEvent(Event* out) {
+    pump();
+    if (ch_.empty()) return false;
+    *out = ch_.front(); ch_.pop_front();
+    return true;
+  }
+  size_t EventBacklog() { pump(); return ch_.size(); }
+  bool EventChFull() { pump(); return ch_.size() >= conf_.EventChCap; }
+
+ private:
+  struct Fired { std::string name; std::vector<uint8_t> payload; bool coalesce; };
+  Serf(const Config& c, std::shared_ptr<Cluster> p, uint32_t id, uint32_t r) : conf_(c), pool_(std::move(p)), id_(id), replica_(r) {
+    if (conf_.NodeName.empty()) conf_.NodeName = Cluster::NodeName(id);
+  }
+  void requireNotShutdown(const char* what) const {
+    if (state_ == SerfShutdown) throw Error(std::string(what) + ": Serf is shut down", SWIM_ESTATE);
+  }
+  Duration roundUp(Duration d) const {
+    int64_t q = pool_->derived().quantum_ms;
+    return Duration((d.count() + q - 1) / q * q);
+  }
+  Member makeMember(uint32_t id, MemberStatus st, uint32_t inc) const {
+    Member m; m.id = id; m.Name = Cluster::NodeName(id); m.Addr = Cluster::NodeAddr(id); m.Port = 8301; m.Status = st; m.Incarnation = inc;
+    return m;
+  }
+  static uint32_t idOf(const std::string& name) {
+    if (name.rfind("node-", 0) != 0) throw Error("unknown member " + name, SWIM_ERANGE);
+    return (uint32_t)std::stoul(name.substr(5));
+  }
+  static uint32_t eventId(const std::string& name, const std::vector<uint8_t>& payload) {   // FNV-1a
+    uint32_t h = 2166136261u;
+    for (unsigned char c : name) { h ^= c; h *= 16777619u; }
+    h ^= 0xFF; h *= 16777619u;
+    for (unsigned char c : payload) { h ^= c; h *= 16777619u; }
+    return h;
+  }
+  static std::map<uint32_t, Fired>& catalog() { static std::map<uint32_t, Fired> c; return c; }
+  // swim_poll_events -> EventCh (only the pool's watch node has its events recorded)
+  void pump() {
+    if (id_ != pool_->config().watch_node) return;
+    swim_event buf[256]; size_t n = 0;
+    do {
+      check(swim_poll_events(pool_->handle(), buf, 256, &n), "swim_poll_events");
+      for (size_t i = 0; i < n; i++) {
+        if (buf[i].replica != replica_) continue;
+        Event e; e.Type = (EventType)buf[i].type; e.At = Duration(buf[i].time_ms);
+        if (e.Type == EventUser) {
+          auto it = catalog().find(buf[i].node);
+          e.LTime = buf[i].ltime;
+          if (it != catalog().end()) { e.Name = it->second.name; e.Payload = it->second.payload; e.Coalesce = it->second.coalesce; }
+        } else {
+          MemberStatus st = e.Type == EventMemberFailed ? StatusFailed : e.Type == EventMemberLeave ? StatusLeft : StatusAlive;
+          e.Members.push_back(makeMember(buf[i].node, st, buf[i].incarnation));
+        }
+        ch_.push_back(std::move(e));
+      }
+    } while (n == 256);
+  }
+
+  Config conf_;
+  std::shared_ptr<Cluster> pool_;
+  uint32_t id_, replica_;
+  SerfState state_ = SerfAlive;
+  std::deque<Event> ch_;
+  std::map<uint32_t, bool> removed_, forced_left_;
+};
+
+}  // namespace serf
+}  // namespace swimsim

@@ -1,0 +1,121 @@
+// Acceptance tests of the host-side serf facade, shaped after the reference's own eventual-outcome
+// tests of this seam:
+//   TestServer_LANReap            agent/consul/server_test.go:666-733   (shutdown => failed => reaped)
+//   TestAgent_ForceLeave[Prune]   agent/agent_endpoint_test.go:2524-2677 (failed => left / erased)
+//   TestLeader_LeftMember         agent/consul/leader_registrator_v1_test.go:162-208 (graceful leave)
+//   TestClientServer_UserEvent    agent/consul/client_test.go:756-830   (event "foo" arrives once)
+// with the reference's shrunk test timers (server_test.go:221-237).
+// Links against any library exporting include/swimsim.h; the library under test is named on argv.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/swimsim_serf.hpp"
+
+using namespace swimsim;
+static int failures = 0;
+#define EXPECT(c)                                                                    \
+  do { if (!(c)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
+
+static memberlist::Config testTimers() {
+  memberlist::Config c = memberlist::DefaultLANConfig();
+  c.SuspicionMult = 2; c.ProbeTimeout = Duration(50); c.ProbeInterval = Duration(100); c.GossipInterval = Duration(100);
+  return c;
+}
+static serf::MemberStatus statusOf(const std::vector<serf::Member>& ms, const std::string& name) {
+  for (auto& m : ms) if (m.Name == name) return m.Status;
+  return serf::StatusNone;
+}
+
+static void testLANReap() {
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 3, 1, 8, 32, 8, 0, 1, 0, 512 });
+  serf::Config c = serf::ConsulDefaultConfig();
+  c.ReconnectTimeout = Duration(250); c.TombstoneTimeout = Duration(250); c.ReapInterval = Duration(300);
+  auto s1 = serf::Serf::Create(c, pool, 0), s3 = serf::Serf::Create(c, pool, 2);
+  EXPECT(s1->Join({ "10.0.0.1:8301", "10.0.0.2:8301" }, true) == 2);
+  pool->Advance(Duration(500));
+  EXPECT(s1->Members().size() == 3);
+  s3->Shutdown();                                   // "s3.Shutdown()" — server_test.go:725
+  bool sawFailed = false, reaped = false;
+  for (int i = 0; i < 200 && !reaped; i++) {
+    pool->Advance(Duration(50));
+    auto ms = s1->Members();
+    if (statusOf(ms, "node-2") == serf::StatusFailed) sawFailed = true;
+    if (ms.size() == 2 && statusOf(ms, "node-2") == serf::StatusNone) reaped = true;
+  }
+  EXPECT(sawFailed);
+  EXPECT(reaped);
+  serf::Event e; bool gotFailed = false;
+  while (s1->PollEvent(&e)) if (e.Type == serf::EventMemberFailed && e.Members[0].Name == "node-2") gotFailed = true;
+  EXPECT(gotFailed);
+  bool threw = false;
+  try { s3->Join({ "x" }, false); } catch (const Error&) { threw = true; }
+  EXPECT(threw);                                    // "Serf can't Join after Shutdown"
+  std::printf("ok LANReap\n");
+}
+
+static void testForceLeaveAndPrune() {
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 16, 1, 8, 32, 8, 0, 2, 0, 512 });
+  auto a1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0), a2 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 7);
+  a2->Shutdown();
+  for (int i = 0; i < 200 && statusOf(a1->Members(), "node-7") != serf::StatusFailed; i++) pool->Advance(Duration(50));
+  EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusFailed);   // agent_endpoint_test.go:2550
+  a1->RemoveFailedNode("node-7");
+  EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusLeft);     // :2559-2565
+  a1->RemoveFailedNodePrune("node-7");
+  EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusNone);     // :2668-2676 member erased
+  EXPECT(a1->Members().size() == 15);
+  std::printf("ok ForceLeave/Prune\n");
+}
+
+static void testGracefulLeave() {
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 32, 1, 8, 32, 8, 0, 3, 0, 512 });
+  auto s1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0), c1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 9);
+  c1->Leave();                                      // returns after LeavePropagateDelay (3 s for Consul)
+  EXPECT(c1->State() == serf::SerfLeft);
+  EXPECT(c1->LocalMember().Status == serf::StatusLeft);
+  EXPECT(statusOf(s1->Members(), "node-9") == serf::StatusLeft);
+  serf::Event e; int leaves = 0, failed = 0;
+  while (s1->PollEvent(&e)) { leaves += e.Type == serf::EventMemberLeave; failed += e.Type == serf::EventMemberFailed; }
+  EXPECT(leaves == 1 && failed == 0);               // a leave is not a failure (leader_registrator_v1_test.go:162)
+  c1->Shutdown(); c1->Shutdown();                   // idempotent
+  bool threw = false;
+  try { c1->Leave(); } catch (const Error&) { threw = true; }
+  EXPECT(threw);                                    // "Leave called after Shutdown"
+  std::printf("ok GracefulLeave\n");
+}
+
+static void testUserEvent() {
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 64, 1, 8, 32, 8, 0, 4, 0, 512 });
+  auto s1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0), c1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 33);
+  c1->UserEvent("consul:event:foo", { 'b', 'a', 'r' }, false);      // client_test.go:808, name prefix server_serf.go:36
+  pool->Advance(Duration(2000));
+  serf::Event e; int seen = 0;
+  while (s1->PollEvent(&e))
+    if (e.Type == serf::EventUser) { seen++; EXPECT(e.Name == "consul:event:foo"); EXPECT(e.Payload.size() == 3 && e.Payload[0] == 'b'); EXPECT(!e.Coalesce); }
+  EXPECT(seen == 1);                                // exactly once
+  bool threw = false;
+  try { c1->UserEvent("big", std::vector<uint8_t>(600, 'x'), false); } catch (const Error&) { threw = true; }
+  EXPECT(threw);                                    // UserEventSizeLimit 512
+  auto st = s1->Stats();
+  EXPECT(st["members"] == "64" && st["failed"] == "0");
+  std::printf("ok UserEvent\n");
+}
+
+static void testConfigPresets() {
+  auto lan = memberlist::DefaultLANConfig(), wan = memberlist::DefaultWANConfig(), loc = memberlist::DefaultLocalConfig();
+  EXPECT(lan.GossipInterval == Duration(200) && lan.GossipNodes == 3 && lan.ProbeInterval == Duration(1000) && lan.SuspicionMult == 4);
+  EXPECT(wan.GossipInterval == Duration(500) && wan.GossipNodes == 4 && wan.ProbeTimeout == Duration(3000) && wan.SuspicionMult == 6);
+  EXPECT(loc.GossipInterval == Duration(100) && loc.IndirectChecks == 1 && loc.RetransmitMult == 2);
+  auto c = serf::ConsulDefaultConfig();
+  EXPECT(c.MinQueueDepth == 4096 && c.LeavePropagateDelay == Duration(3000) && c.ReconnectTimeout == Duration(259200000));
+  std::printf("ok ConfigPresets\n");
+}
+
+int main() {
+  try {
+    std::printf("backend %s\n", swim_backend());
+    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testGracefulLeave(); testUserEvent();
+  } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
+  std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
+  return failures ? 1 : 0;
+}
