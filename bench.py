@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--cpu-replicas", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
     args = ap.parse_args()
 
     import torch
@@ -116,8 +118,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_exchange
+    if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from consul_amd import lib
@@ -134,7 +139,7 @@ def main():
 
     def fresh():
         sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
-        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank)) if world > 1 else sim
+        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank)) if sharded else sim
 
     def barrier():
         if world > 1:
@@ -142,7 +147,7 @@ def main():
         torch.cuda.synchronize()
 
     sim = fresh()
-    G = (sim.sim if world > 1 else sim).derived.gossip_period
+    G = (sim.sim if sharded else sim).derived.gossip_period
     sim.step(G); sim.sync()                            # first call builds the captured graphs
     tq = time.perf_counter()
     sim.step((args.warmup - 1) * G if args.warmup > 1 else 0); sim.sync()
@@ -160,7 +165,7 @@ def main():
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    base = sim.sim if world > 1 else sim
+    base = sim.sim if sharded else sim
     census = [base.census(r, v) for r, v in enumerate(victims[: min(reps, 4)])]
     detect = {"first_suspect_ms": [c.first_suspect_ms for c in census], "first_dead_ms": [c.first_dead_ms for c in census],
               "all_dead_ms": [c.all_dead_ms for c in census]}
@@ -176,11 +181,11 @@ def main():
                    "nodes_per_cluster": args.nodes, "replicas": reps, "fanout": args.fanout,
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
                    "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
-                   "parallelism": f"population sharded x{world}, all-to-all per tick" if world > 1 else "1 GPU"},
+                   "parallelism": f"population sharded x{world}, all-to-all per tick" if sharded else "1 GPU"},
         "detection_ms_after_t0": detect,
     }
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not sharded and not args.no_roofline:
         # instrumented pass over the same region: HIP events around every launch on the sim's stream
         p = fresh()
         p.step(args.warmup * G)
@@ -214,11 +219,11 @@ def main():
             rec = json.load(open(pmc)).get(dom)
             if rec and rec.get("workload_nodes") == reps * args.nodes:
                 line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         line["cpu_baseline"] = run_cpu_baseline(args, G)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
