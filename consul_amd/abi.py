@@ -21,8 +21,8 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
 (EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
-F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS = 0x1, 0x2, 0x4
-F_DEFAULT = F_BUDDY_SUSPECT | F_NACK
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP = 0x1, 0x2, 0x4, 0x8
+F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP
 
 u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
 
@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("confirmations", u64), ("edges", u64), ("edges_remote", u64),
                 ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
                 ("event_drops", u64), ("user_events_delivered", u64),
-                ("user_events_deduped", u64), ("user_events_stale", u64)]
+                ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64)]
 
 
 class KernelTime(C.Structure):

@@ -20,7 +20,7 @@ enum {
   ST_PROBES, ST_ACKS, ST_IACKS, ST_PFAIL, ST_NACKMISS,
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
-  ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE,
+  ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED,
   ST_COUNT
 };
 

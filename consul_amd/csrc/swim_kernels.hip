@@ -75,6 +75,12 @@ struct BlockStats {
   }
   __device__ __forceinline__ void add(int i, uint32_t v = 1) { atomicAdd(&s[i], v); }
   // converged call sites: one LDS atomic per wave instead of one per lane
+  // converged call sites: wave-reduce a per-lane tally, one LDS atomic per wave
+  __device__ __forceinline__ void wave_add(int i, uint32_t v) {
+    if (!__any(v != 0)) return;
+    for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+    if (sw_lane() == 0) atomicAdd(&s[i], v);
+  }
   __device__ __forceinline__ void count(int i, bool pred) {
     uint64_t m = __ballot(pred);
     if (m && sw_lane() == 0) atomicAdd(&s[i], (uint32_t)__popcll(m));
@@ -350,6 +356,29 @@ __device__ __forceinline__ bool ent_before(const SwDev& D, uint32_t ma, uint32_t
   return m_seq(ma) > m_seq(mb);
 }
 
+// SWIM_F_FILTER_NOOP: would aliveNode/suspectNode/deadNode at `dst` return without doing anything —
+// judged only by conditions that stay true whatever else reaches dst this tick (view incarnations never
+// decrease): an older incarnation, or the same incarnation in a state the message cannot move.  One
+// random 4-byte read of the receiver's view replaces an edge write, an inbox atomic and a merge.
+__device__ __forceinline__ bool noop_at_receiver(const SwDev& D, uint32_t r, const uint32_t* nw, uint32_t dst, uint4 e) {
+  uint32_t type = m_type(e.w);
+  if (e.x == dst) return false;                                  // about the receiver itself: it must refute
+  uint32_t w = nw[e.x];
+  if (!NW_HAS_SLOT(w)) return false;
+  size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + (dst - D.i0);
+  uint32_t key = D.v_key[ci], vinc = SW_KINC(key), st = SW_KST(key);
+  if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
+  if (e.y != vinc) return e.y < vinc;
+  if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
+  if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
+    uint32_t nc = D.v_nconf[ci];
+    if (nc >= D.susp_k) return true;
+    uint4 cf = D.v_conf[ci];
+    return cf.x == e.z || (nc >= 1 && cf.y == e.z) || (nc >= 2 && cf.z == e.z) || (nc >= 3 && cf.w == e.z);
+  }
+  return false;
+}
+
 // one GetBroadcasts(overhead, limit) over an LDS-staged queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
 __device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
@@ -405,6 +434,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0, nq = 0, ne = 0;
   size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0);
   bool active = false, quiet = false;
+  uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0;   // per-lane tallies
   uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
 
   if (!(wi & NW_DEAD)) {
@@ -425,15 +455,27 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
         int avail = (int)D.budget - used;
         if (serf && avail > 2 + 1) te = get_broadcasts(D, se, evqlen, live_e, 3, avail, used2);
         if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
-        S.add(ST_PKT_SENT);
-        for (uint32_t m = tm; m; m &= m - 1) S.add(ST_SENT0 + m_type(sq[(__ffs(m) - 1) * SW_BLOCK].w));
-        if (te) S.add(ST_SENT3, __popc(te));
-        if (!reach(D, r, t, wi, pw[p], i, p)) { S.add(ST_PKT_DROP); continue; }
-        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = peers[p] / D.nloc; np++;
+        c_pkt++;
+        for (uint32_t m = tm; m; m &= m - 1) {
+          uint32_t ty = m_type(sq[(__ffs(m) - 1) * SW_BLOCK].w);
+          c_s0 += ty == SWIM_MSG_ALIVE; c_s1 += ty == SWIM_MSG_SUSPECT; c_s2 += ty == SWIM_MSG_DEAD;
+        }
+        c_s3 += (uint32_t)__popc(te);
+        if (!reach(D, r, t, wi, pw[p], i, p)) { c_drop++; continue; }
+        uint32_t sh = peers[p] / D.nloc;
+        if ((D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank)
+          for (uint32_t m = tm; m; m &= m - 1) {
+            uint32_t j = __ffs(m) - 1;
+            if (noop_at_receiver(D, r, nw, peers[p], sq[j * SW_BLOCK])) { tm &= ~(1u << j); c_filt++; }
+          }
+        if (!(tm | te)) continue;
+        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = sh; np++;
       }
     }
   }
   S.count(ST_QUIESCENT, quiet); S.count(ST_ACTIVE, active);
+  S.wave_add(ST_PKT_SENT, c_pkt); S.wave_add(ST_PKT_DROP, c_drop); S.wave_add(ST_FILTERED, c_filt);
+  S.wave_add(ST_SENT0, c_s0); S.wave_add(ST_SENT1, c_s1); S.wave_add(ST_SENT2, c_s2); S.wave_add(ST_SENT3, c_s3);
 
   // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
   //      atomicAdd per (block, shard)

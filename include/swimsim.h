@@ -63,7 +63,11 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
 #define SWIM_F_BUDDY_SUSPECT  0x1u /* probeNode: ping+suspect compound to a non-alive target  */
 #define SWIM_F_NACK           0x2u /* Lifeguard nack accounting on indirect probes            */
 #define SWIM_F_SERF_EVENTS    0x4u /* allocate the per-node Serf Lamport/event-buffer state   */
-#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK)
+/* Drop, at the sender, a rumour that provably cannot change its receiver (same shard only): the
+ * receiver already holds a newer incarnation, or the same incarnation in a state the message cannot
+ * move.  Node state is identical with the flag on or off; only `edges` differ. */
+#define SWIM_F_FILTER_NOOP    0x8u
+#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP)
 
 /* ---- configuration ---------------------------------------------------------------------- */
 /* One POD mirroring memberlist.Config field names (the ones CloneSerfLANConfig copies,
@@ -182,6 +186,7 @@ typedef struct swim_stats_t {
   uint64_t edges, edges_remote;
   uint64_t queue_drops, inbox_overflow, subject_overflow, event_drops;
   uint64_t user_events_delivered, user_events_deduped, user_events_stale;
+  uint64_t msgs_filtered;           /* rumours dropped at the sender by SWIM_F_FILTER_NOOP       */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;

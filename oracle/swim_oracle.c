@@ -667,6 +667,26 @@ static void phase_probe(swim_sim* s) {
   }
 }
 
+/* SWIM_F_FILTER_NOOP: would aliveNode/suspectNode/deadNode at `dst` return without doing anything?
+ * Only conditions that stay true whatever else reaches dst in the same tick (view incarnations never
+ * decrease): an older incarnation; or the same incarnation in a state the message cannot move.  A
+ * message with a HIGHER incarnation than the view is always delivered (an alive of that incarnation
+ * arriving in the same tick could make it applicable), and so is anything about dst itself (refute). */
+static int noop_at_receiver(swim_sim* s, uint32_t r, uint32_t dst, const qent* m) {
+  if (m->type == SWIM_MSG_USER || m->subject == dst || !is_local(s, dst)) return 0;
+  view_t* v = view_ptr(s, r, dst, m->subject);
+  if (!v) return 0;
+  uint32_t vinc = KINC(v->key), st = KST(v->key);
+  if (m->type == SWIM_MSG_ALIVE) return m->inc <= vinc;
+  if (m->inc != vinc) return m->inc < vinc;
+  if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return 1;
+  if (m->type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
+    if (v->nconf >= s->d.suspicion_k) return 1;
+    for (uint32_t i = 0; i <= v->nconf && i < CONF_MAX; i++) if (v->conf[i] == m->from) return 1;
+  }
+  return 0;
+}
+
 /* gossip(): k random peers; per peer one getBroadcasts() = memberlist queue, then the serf
  * delegate's user events in the bytes that remain; stop at the first empty packet */
 static void phase_gossip(swim_sim* s) {
@@ -687,7 +707,10 @@ static void phase_gossip(swim_sim* s) {
         s->st.packets_sent++;
         for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
         if (!reach(s, r, o, peers[p], o, p)) { s->st.packets_dropped++; continue; }
-        for (uint32_t m = 0; m < n; m++) emit(s, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+        for (uint32_t m = 0; m < n; m++) {
+          if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, peers[p], &msgs[m])) { s->st.msgs_filtered++; continue; }
+          emit(s, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+        }
       }
     }
 }

@@ -29,7 +29,7 @@ def main():
     parts = [torch.zeros_like(d) for _ in range(world)]
     dist.all_gather(parts, d)
     st = sh.stats()
-    cnt = torch.tensor([st["edges"], st["edges_remote"], st["refutes"], st["probe_failures"]], dtype=torch.int64)
+    cnt = torch.tensor([st["packets_sent"], st["edges_remote"], st["refutes"], st["probe_failures"]], dtype=torch.int64)
     dist.all_reduce(cnt)
     if rank == 0:
         total = sum(int(p[0]) | (int(p[1]) << 31) | (int(p[2]) << 62) for p in parts) & 0xFFFFFFFFFFFFFFFF
@@ -38,7 +38,7 @@ def main():
         ref.kill(0, [100, 1500]); ref.kill(1, [7]); ref.update(1, [1024])
         ref.step_ms(25000)
         rs = ref.stats()
-        ok = total == ref.digest() and int(cnt[0]) == rs["edges"] and int(cnt[2]) == rs["refutes"] and int(cnt[1]) > 0
+        ok = total == ref.digest() and int(cnt[0]) == rs["packets_sent"] and int(cnt[2]) == rs["refutes"] and int(cnt[1]) > 0
         print(f"RESULT ok={ok} digest={total:#x} ref={ref.digest():#x} edges={int(cnt[0])}/{rs['edges']} remote={int(cnt[1])}")
     dist.destroy_process_group()
 

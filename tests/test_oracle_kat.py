@@ -290,6 +290,30 @@ def test_push_gossip_infection_follows_the_analytic_recurrence(oracle):
     assert got[-1] == n
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_nodes=4096, n_replicas=2, seed=5),
+    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=256, loss_q32=int(0.1 * 2**32)),
+    dict(n_nodes=512, seed=2, suspicion_mult=6, subject_cap=64),              # k = 4 confirmations
+])
+def test_noop_filter_never_changes_node_state(oracle, kw):
+    """SWIM_F_FILTER_NOOP drops at the sender what the receiver would ignore anyway: every integer of
+    node state (digest), every applied-message counter and every event must be identical on or off."""
+    out = []
+    for flags in (abi.F_DEFAULT, abi.F_DEFAULT & ~abi.F_FILTER_NOOP):
+        s = Sim(oracle, preset(oracle, abi.PRESET_LAN, flags=flags, **kw))
+        s.step_ms(3000)
+        s.kill(0, [100, 300]); s.update(0, [55]); s.leave(0, [77])
+        s.step_ms(30000)
+        s.revive(0, [300])
+        s.step_ms(20000)
+        st = s.stats()
+        out.append((s.digest(), st["msgs_applied"], st["refutes"], st["confirmations"], st["suspicion_timeouts"],
+                    s.poll_events(), st["edges"], st["msgs_filtered"]))
+    assert out[0][:6] == out[1][:6]
+    assert out[0][7] > 0 and out[1][7] == 0 and out[0][6] < out[1][6]
+    assert out[0][6] + out[0][7] == out[1][6]                 # every record is either sent or filtered
+
+
 def test_golden_fixture_config1(oracle):
     """tests/golden/config1_kill17.json was generated by tools/make_golden.py from this oracle at the
     commit that introduced it; it guards the restatement against silent drift."""
