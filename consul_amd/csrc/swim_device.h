@@ -9,6 +9,7 @@
 #include "../../include/swimsim.h"
 
 #define SW_MAX_SHARDS 16
+#define SW_EXC_MAX 16               /* per-replica list of nodes whose node word is non-zero */
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
 
@@ -60,11 +61,19 @@ struct SwDev {
   uint32_t msg_len[4];
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
+  uint32_t ablate;   // SWIMSIM_ABLATE env: timing experiments only (results invalid); 0 in normal use
   uint64_t seed;
   // global clock (device resident so a captured graph is tick independent)
   uint32_t* tick;
   // replicated, R*N
   uint32_t* nw;
+  // In steady state almost every node word is 0 (running, group 0, no subject slot).  exc_list[r] holds
+  // the ids of replica r whose word is NOT 0 when there are at most SW_EXC_MAX of them (exc_cnt[r] =
+  // how many; larger = list unusable, read nw).  Blocks stage it in LDS, so looking at a random peer
+  // costs no memory access at all.  Rebuilt by k_finish / after injections when exc_dirty[r] is set.
+  uint32_t* exc_list;    // [R][SW_EXC_MAX]
+  uint32_t* exc_cnt;     // [R]
+  uint32_t* exc_dirty;   // [R]
   // per local lane, NL = R*nloc
   uint4* hdr;       // {self_inc, leaving | qlen<<8 | evqlen<<16, qseq, ev_clock}
   uint2* ph;        // probe hot: {cursor, epoch<<16 | awareness<<8 | stage<<6 | nack_miss}
@@ -82,10 +91,11 @@ struct SwDev {
   uint32_t* in_any;   // [NL/256] some node of the block received something this tick
   uint32_t* alive_cnt;// [NL/256] running nodes in the block
   // per (replica, slot) view columns, [R*S][nloc]
-  uint32_t* v_key;
-  uint32_t* v_since;
-  uint8_t* v_nconf;
-  uint4* v_conf;
+  //   va = {inc<<2|state, state-change ms, confirmations seen, first accuser}: one 16-byte sector answers
+  //        "what does this observer think of the subject" for peer selection, probing and the no-op filter
+  //   vb = {2nd, 3rd, 4th confirmer}: only read when a suspicion is being confirmed
+  uint4* va;
+  uint4* vb;
   // slot tables
   uint32_t* subj_node;   // [R*S]
   uint32_t* n_slots;     // [R]

@@ -32,6 +32,7 @@ struct swim_sim {
   swim_derived d;
   SwDev D;
   BeginPlan plan;
+  BeginKernel begin_kernel = nullptr;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   uint32_t tick = 0;
@@ -244,16 +245,17 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   for (int i = 0; i < 4; i++) D.msg_len[i] = cfg->msg_len[i];
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
+  if (const char* ab = getenv("SWIMSIM_ABLATE")) D.ablate = (uint32_t)strtoul(ab, nullptr, 0);
 
   const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S, NB = cdiv(NL, SW_BLOCK);
   DALLOC(s, D.tick, 1);
   DALLOC(s, D.nw, NT);
+  DALLOC(s, D.exc_list, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
-  DALLOC(s, D.v_key, NS * D.nloc); DALLOC(s, D.v_since, NS * D.nloc);
-  DALLOC(s, D.v_nconf, NS * D.nloc); DALLOC(s, D.v_conf, NS * D.nloc);
+  DALLOC(s, D.va, NS * D.nloc); DALLOC(s, D.vb, NS * D.nloc);
   DALLOC(s, D.subj_node, NS); DALLOC(s, D.n_slots, D.R); DALLOC(s, D.slot_dirty, NS);
   DALLOC(s, D.slot_maxinc, NS); DALLOC(s, D.slot_susp, NS); DALLOC(s, D.slot_mindl, NS);
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
@@ -264,11 +266,16 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const uint32_t gossip_lanes = D.fast_blocks ? cdiv(cdiv(D.nloc, D.CH), D.G) * D.CH : (cdiv(nchunks, D.G) + 1) * D.CH;
   const uint32_t probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
   BeginPlan& pl = s->plan;
-  pl.nb_expire = (uint32_t)NS * (NS <= 256 ? 4u : 1u);
+  {   // expire: enough blocks per subject slot that a due slot is scanned in a few trips
+    uint32_t per = std::max(1u, std::min(8u, cdiv(D.nloc, 4 * SW_BLOCK)));
+    while (per > 1 && (uint64_t)NS * per > 16384) per >>= 1;
+    pl.nb_expire = (uint32_t)NS * per;
+  }
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
   pl.roles = 0xF;
+  s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
@@ -293,6 +300,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   hipStream_t st = s->stream;
   HIPCK(s, hipMemsetAsync(D.tick, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.nw, 0, NT * 4, st));
+  HIPCK(s, hipMemsetAsync(D.exc_cnt, 0, D.R * 4, st)); HIPCK(s, hipMemsetAsync(D.exc_dirty, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.out_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(D.seg_cnt, 0, (size_t)D.n_seg * 4, st));
@@ -329,11 +337,11 @@ static void launch_begin(swim_sim* s) {
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = 0xD;
-    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, a); }
-    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, b); }
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, a); }
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, b); }
   } else {
     ProfScope p(s, PK_BEGIN);
-    hipLaunchKernelGGL(k_begin, dim3(grid), dim3(SW_BLOCK), lds, st, D, pl);
+    hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, pl);
   }
 }
 static void launch_end(swim_sim* s) {
@@ -478,6 +486,7 @@ static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n
   if (op == INJ_LEAVE || op == INJ_UPDATE)
     hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
   hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, s->D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);   // node words changed
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
@@ -492,6 +501,7 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
   for (uint32_t i = 0; i < s->D.N; i++) if (g[i] > 127) return SWIM_ERANGE;   // 7 bits of the node word
   HIPCK(s, hipMemcpyAsync(s->d_scratch, g, s->D.N, hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, s->D, r, (const uint8_t*)s->d_scratch);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
@@ -540,8 +550,8 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   uint32_t key = SW_BASE_KEY, since = 0; uint8_t nconf = 0;
   if (NW_HAS_SLOT(w)) {
     size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + (o - D.i0);
-    if ((rc = d2h(s, &key, (const uint32_t*)D.v_key + ci, 1)) || (rc = d2h(s, &since, (const uint32_t*)D.v_since + ci, 1)) ||
-        (rc = d2h(s, &nconf, (const uint8_t*)D.v_nconf + ci, 1))) return rc;
+    uint4 a; if ((rc = d2h(s, &a, (const uint4*)D.va + ci, 1))) return rc;
+    key = a.x; since = a.y; nconf = (uint8_t)a.z;
   }
   out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
   out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? nconf : 0;

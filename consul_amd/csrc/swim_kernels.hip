@@ -45,8 +45,9 @@ __device__ __forceinline__ uint32_t now_ms(const SwDev& D, uint32_t t) { return 
 __device__ __forceinline__ uint32_t view_of(const SwDev& D, uint32_t r, uint32_t k, uint32_t w, uint32_t* since) {
   if (!NW_HAS_SLOT(w)) { *since = 0; return SW_BASE_KEY; }
   size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + k;
-  *since = D.v_since[ci];
-  return D.v_key[ci];
+  uint4 a = D.va[ci];
+  *since = a.y;
+  return a.x;
 }
 
 __device__ __forceinline__ bool lost(const SwDev& D, uint32_t r, uint32_t t, uint32_t node, uint32_t leg) {
@@ -61,6 +62,26 @@ __device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, ui
   if ((wb & NW_DEAD) || NW_PART(wa) != NW_PART(wb)) return false;
   return !lost(D, r, t, rng_node, leg);
 }
+
+// ---- the replica's exception list, staged in LDS by the first SW_EXC_MAX lanes of a block ----------
+struct ExcList {
+  uint32_t* id; uint32_t* w; uint32_t n;           // n > SW_EXC_MAX: unusable, fall back to nw
+  __device__ void stage(const SwDev& D, uint32_t r, uint32_t* lds) {   // caller provides the barrier
+    id = lds; w = lds + SW_EXC_MAX;
+    n = D.exc_cnt[r];
+    if (threadIdx.x < SW_EXC_MAX && threadIdx.x < n && n <= SW_EXC_MAX) {
+      uint32_t x = D.exc_list[(size_t)r * SW_EXC_MAX + threadIdx.x];
+      id[threadIdx.x] = x; w[threadIdx.x] = D.nw[(size_t)r * D.N + x];
+    }
+  }
+  __device__ __forceinline__ bool usable() const { return n <= SW_EXC_MAX; }
+  // node word of x when the list is usable: 0 unless listed
+  __device__ __forceinline__ uint32_t word(uint32_t x) const {
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < n; j++) v = id[j] == x ? w[j] : v;
+    return v;
+  }
+};
 
 // ---- statistics: per-block LDS counters, flushed once --------------------------------------------
 __device__ __forceinline__ unsigned long long* stat_ptr(const SwDev& D, int i) {
@@ -157,7 +178,7 @@ __device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw,
 // wout[] receives the picked nodes' words so the caller needs no second lookup.
 __device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
                                    uint32_t stream, uint32_t want, int mode, uint32_t target,
-                                   uint32_t* out, uint32_t* wout) {
+                                   uint32_t* out, uint32_t* wout, const ExcList& X) {
   SwDraws d; d.init(seed_of(D, r), stream, t, o);
   uint32_t found = 0, now = now_ms(D, t);
   const uint32_t* nw = D.nw + (size_t)r * D.N;
@@ -167,12 +188,17 @@ __device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint3
   uint32_t x4[4], w4[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) x4[j] = d.get(j) % D.N;
+  if (X.usable()) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) w4[j] = nw[x4[j]];
+    for (int j = 0; j < 4; j++) w4[j] = X.word(x4[j]);                 // no memory access
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) w4[j] = nw[x4[j]];
+  }
   for (uint64_t i = 0; i < tries && found < want; i++) {
     uint32_t x, w;
     if (i < 4) { x = i == 0 ? x4[0] : i == 1 ? x4[1] : i == 2 ? x4[2] : x4[3]; w = i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]; }
-    else { x = d.get((uint32_t)i) % D.N; w = nw[x]; }
+    else { x = d.get((uint32_t)i) % D.N; w = X.usable() ? X.word(x) : nw[x]; }
     if (x == o) continue;
     uint32_t since, key = view_of(D, r, k_local, w, &since), st = SW_KST(key);
     if (mode == 0) {
@@ -201,27 +227,33 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
   if (!D.slot_susp[sidx] || now < D.slot_mindl[sidx]) return;
   uint32_t x = D.subj_node[sidx], fired = 0;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
-  for (uint32_t k0 = part * SW_BLOCK; k0 < D.nloc; k0 += per * SW_BLOCK) {
-    uint32_t k = k0 + threadIdx.x;
-    bool fire = false; uint32_t key = 0;
-    if (k < D.nloc) {
-      size_t ci = (size_t)sidx * D.nloc + k;
-      key = D.v_key[ci];
-      if (SW_KST(key) == SWIM_STATE_SUSPECT && !(nw[D.i0 + k] & NW_DEAD))
-        fire = now >= D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]];
+  // the scan is latency bound: four independent rows in flight per trip
+  for (uint32_t k0 = part * SW_BLOCK; k0 < D.nloc; k0 += 4 * per * SW_BLOCK) {
+    uint32_t kk[4]; uint4 v[4]; bool f[4]; bool any_f = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { kk[j] = k0 + j * per * SW_BLOCK + threadIdx.x; v[j] = kk[j] < D.nloc ? D.va[(size_t)sidx * D.nloc + kk[j]] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { f[j] = kk[j] < D.nloc && SW_KST(v[j].x) == SWIM_STATE_SUSPECT && now >= v[j].y + D.susp_timeout[v[j].z & 7u]; any_f |= f[j]; }
+    if (__any(any_f)) {                             // rare: only now look at liveness and append
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        f[j] = f[j] && !(nw[D.i0 + kk[j]] & NW_DEAD);
+        wave_append(D, D.rank, f[j], mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]));
+        fired += (uint32_t)f[j];
+      }
     }
-    uint32_t o = D.i0 + k;
-    wave_append(D, D.rank, fire, mk_edge(D, r, o, x, SW_KINC(key), SWIM_MSG_DEAD, o));
-    fired += fire;
   }
-  for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-  if (sw_lane() == 0 && fired) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+  if (__any(fired != 0)) {
+    for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
+    if (sw_lane() == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+  }
 }
 
 // =================================================================================================
 // role: pending — ProbeTimeout after a failed direct ping: indirectPingReq to IndirectChecks random
 // alive peers; each relays the target's ack or (Lifeguard) answers nack one ProbeTimeout later.
 // =================================================================================================
+template <int KMAX>
 __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
@@ -236,8 +268,9 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
       if (wi & NW_DEAD) continue;
       uint2 h = D.ph[l]; uint4 p0 = D.pr0[l];
       if (p_stage(h.y) != 1 || p0.w + D.TQ != t) continue;
-      uint32_t x = p0.x, wx = nw[x], peers[8], pw[8];
-      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, 1, x, peers, pw);
+      uint32_t x = p0.x, wx = nw[x], peers[KMAX], pw[KMAX];
+      ExcList none; none.id = nullptr; none.w = nullptr; none.n = SW_EXC_MAX + 1;   // entries span replicas: read nw
+      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, 1, x, peers, pw, none);
       uint32_t expected = 0, nacks = 0; bool acked = false;
       bool nack_in_time = 2 * D.TQ < p0.z - p0.w;
       for (uint32_t q = 0; q < np; q++) {
@@ -263,7 +296,8 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 // role: probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now.
 // Hot path per lane: own word, 8 B of probe state, one Feistel evaluation, the target's word.
 // =================================================================================================
-__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats) {
+__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
+  ExcList X; X.stage(D, r, lds_exc);
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
   uint32_t i = map_probe(D, t % D.P, a);
@@ -283,7 +317,7 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds
         // probeNode's failure epilogue: awareness, then suspectNode(suspect{inc, node, self})
         aw = awareness_apply(D, aw, (int)nackm);
         S.add(ST_PFAIL); S.add(ST_NACKMISS, nackm);
-        if (!NW_HAS_SLOT(nw[p0.x])) { e_ctrl = true; ctrl_x = p0.x; }
+        if (!NW_HAS_SLOT(X.usable() ? X.word(p0.x) : nw[p0.x])) { e_ctrl = true; ctrl_x = p0.x; }
         e_self = true; rec_self = mk_edge(D, r, i, p0.x, p0.y, SWIM_MSG_SUSPECT, i);
         D.pr0[l].x = NONE; stage = 0; nackm = 0; busy = false;
       }
@@ -294,7 +328,7 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds
       while (num_check < D.N) {
         if (cursor >= D.N) { epoch = (epoch + 1) & 0xFFFFu; cursor = 0; num_check++; continue; }   // resetNodes
         uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
-        wx = nw[c]; key = view_of(D, r, k, wx, &since);
+        wx = X.usable() ? X.word(c) : nw[c]; key = view_of(D, r, k, wx, &since);
         if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
         x = c; break;
       }
@@ -356,25 +390,22 @@ __device__ __forceinline__ bool ent_before(const SwDev& D, uint32_t ma, uint32_t
   return m_seq(ma) > m_seq(mb);
 }
 
-// SWIM_F_FILTER_NOOP: would aliveNode/suspectNode/deadNode at `dst` return without doing anything —
-// judged only by conditions that stay true whatever else reaches dst this tick (view incarnations never
+// SWIM_F_FILTER_NOOP: would aliveNode/suspectNode/deadNode at the receiver return without doing anything —
+// judged only by conditions that stay true whatever else reaches it this tick (view incarnations never
 // decrease): an older incarnation, or the same incarnation in a state the message cannot move.  One
-// random 4-byte read of the receiver's view replaces an edge write, an inbox atomic and a merge.
-__device__ __forceinline__ bool noop_at_receiver(const SwDev& D, uint32_t r, const uint32_t* nw, uint32_t dst, uint4 e) {
-  uint32_t type = m_type(e.w);
-  if (e.x == dst) return false;                                  // about the receiver itself: it must refute
-  uint32_t w = nw[e.x];
-  if (!NW_HAS_SLOT(w)) return false;
-  size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + (dst - D.i0);
-  uint32_t key = D.v_key[ci], vinc = SW_KINC(key), st = SW_KST(key);
+// random 16-byte read of the receiver's view replaces an edge write, an inbox atomic and a merge.
+// `a` = the receiver's va record of the subject, `e` = the queue entry {subject, inc, from, meta}.
+__device__ __forceinline__ bool noop_given_view(const SwDev& D, uint4 a, size_t ci, uint4 e) {
+  uint32_t type = m_type(e.w), key = a.x, vinc = SW_KINC(key), st = SW_KST(key);
   if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
   if (e.y != vinc) return e.y < vinc;
   if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
   if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
-    uint32_t nc = D.v_nconf[ci];
-    if (nc >= D.susp_k) return true;
-    uint4 cf = D.v_conf[ci];
-    return cf.x == e.z || (nc >= 1 && cf.y == e.z) || (nc >= 2 && cf.z == e.z) || (nc >= 3 && cf.w == e.z);
+    uint32_t nc = a.z;
+    if (nc >= D.susp_k || a.w == e.z) return true;
+    if (nc == 0) return false;
+    uint4 b = D.vb[ci];
+    return b.x == e.z || (nc >= 2 && b.y == e.z) || (nc >= 3 && b.z == e.z);
   }
   return false;
 }
@@ -406,7 +437,15 @@ __device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32
   return taken;
 }
 
-__device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base) {
+// Compile-time variants keep the register footprint of the common case small (the kernel is latency
+// bound, so waves per SIMD matter): KMAX = fan-out array size (4 or 8), SERF = user-event queue
+// present, MULTI = records may leave this shard.
+//
+// A lane's work is a chain of dependent memory round trips, so independent loads are issued together:
+//   trip 1  own node word + header            trip 3  subject node words (slot of each queued rumour)
+//   trip 2  queue entries + 4 candidate peers  trip 4  the receivers' view records for the no-op filter
+template <int KMAX, bool SERF, bool MULTI>
+__device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base, uint32_t* lds_exc) {
   uint32_t t = *D.tick;
   uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
   // a block is one stagger chunk of 256 consecutive nodes: if none of them has anything queued the
@@ -421,37 +460,55 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
       return;
     }
   }
+  ExcList X; X.stage(D, r, lds_exc);
   BlockStats S; S.init(lds_stats);
   if (threadIdx.x < SW_MAX_SHARDS) s_cnt[threadIdx.x] = 0;
   __syncthreads();
 
   uint4* sq = lds_q + threadIdx.x;                 // entry j at sq[j*256]
   uint4* se = lds_q + (size_t)D.Q * SW_BLOCK + threadIdx.x;
-  const bool serf = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+  constexpr bool serf = SERF;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
+  const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
 
-  uint32_t np = 0, peers[8], pw[8], sent_m[8], sent_e[8], loc[8], psh[8];
+  uint32_t np = 0, peers[KMAX], pw[KMAX], sent_m[KMAX], sent_e[SERF ? KMAX : 1], loc[MULTI ? KMAX : 1], psh[MULTI ? KMAX : 1];
   uint32_t qlen = 0, evqlen = 0, live_m = 0, live_e = 0, nq = 0, ne = 0;
   size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0);
   bool active = false, quiet = false;
   uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0;   // per-lane tallies
-  uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
+  uint32_t wi = NW_DEAD;
+  if (i != NONE) {                                  // trip 1: node word and header together
+    l = (size_t)r * D.nloc + (i - D.i0);
+    wi = nw[i]; h = D.hdr[l];
+  }
 
   if (!(wi & NW_DEAD)) {
-    uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
-    h = D.hdr[l]; qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
+    uint32_t k = i - D.i0;
+    qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
     if (!qlen && !evqlen) quiet = true;
     else {
       active = true;
       size_t NL = (size_t)D.R * D.nloc;
-      for (uint32_t j = 0; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
-      for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
+      // trip 2: the queue entries and the first four peer candidates' node words, all independent
+      uint4 e0 = qlen > 0 ? D.q[l] : make_uint4(0, 0, 0, 0), e1 = qlen > 1 ? D.q[NL + l] : make_uint4(0, 0, 0, 0);
+      uint32_t found;
+      if (D.ablate & 1u) { found = D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX; for (uint32_t p = 0; p < found; p++) { peers[p] = (i + 1 + p * 977u) % D.N; pw[p] = 0; } }
+      else found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
+      if (D.ablate & 32u) found = 0;
+      if (qlen > 0) sq[0] = e0;
+      if (qlen > 1) sq[SW_BLOCK] = e1;
+      for (uint32_t j = 2; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
+      if (serf) for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
+      // trip 3: where the subjects of the first two rumours keep their view columns
+      uint32_t ws0 = (filter && qlen > 0) ? (X.usable() ? X.word(e0.x) : nw[e0.x]) : 0, ws1 = (filter && qlen > 1) ? (X.usable() ? X.word(e1.x) : nw[e1.x]) : 0;
       live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1;
       live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
-      uint32_t found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip, 0, NONE, peers, pw);
+      // per peer one GetBroadcasts() (LDS only)
+      uint32_t npk = 0;
+      bool ok[KMAX];
       for (uint32_t p = 0; p < found; p++) {
         int used = 0, used2 = 0;
-        uint32_t tm = get_broadcasts(D, sq, qlen, live_m, 2, (int)D.budget, used), te = 0;
+        uint32_t tm = (D.ablate & 2u) ? (live_m & 1u) : get_broadcasts(D, sq, qlen, live_m, 2, (int)D.budget, used), te = 0;
         int avail = (int)D.budget - used;
         if (serf && avail > 2 + 1) te = get_broadcasts(D, se, evqlen, live_e, 3, avail, used2);
         if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
@@ -461,41 +518,74 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
           c_s0 += ty == SWIM_MSG_ALIVE; c_s1 += ty == SWIM_MSG_SUSPECT; c_s2 += ty == SWIM_MSG_DEAD;
         }
         c_s3 += (uint32_t)__popc(te);
-        if (!reach(D, r, t, wi, pw[p], i, p)) { c_drop++; continue; }
-        uint32_t sh = peers[p] / D.nloc;
-        if ((D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank)
-          for (uint32_t m = tm; m; m &= m - 1) {
-            uint32_t j = __ffs(m) - 1;
-            if (noop_at_receiver(D, r, nw, peers[p], sq[j * SW_BLOCK])) { tm &= ~(1u << j); c_filt++; }
+        ok[p] = reach(D, r, t, wi, pw[p], i, p);
+        if (!ok[p]) c_drop++;
+        sent_m[p] = tm; if (SERF) sent_e[p] = te;
+        npk = p + 1;
+      }
+      // trip 4: the no-op filter.  The view records of every (peer, rumour 0) pair are fetched together;
+      // rumours beyond the first take the one-at-a-time path.
+      if (filter && !(D.ablate & 4u)) {
+        uint4 va0[KMAX];
+#pragma unroll
+        for (int p = 0; p < KMAX; p++) {
+          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && NW_HAS_SLOT(ws0);
+          va0[p] = need ? D.va[((size_t)r * D.S + NW_SLOT(ws0)) * D.nloc + (peers[p] - D.i0)] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < KMAX; p++) {
+          if ((uint32_t)p >= npk || !ok[p] || (MULTI && peers[p] / D.nloc != D.rank)) continue;
+          uint32_t tm = sent_m[p];
+          if ((tm & 1u) && e0.x != peers[p] && NW_HAS_SLOT(ws0)) {
+            size_t ci = ((size_t)r * D.S + NW_SLOT(ws0)) * D.nloc + (peers[p] - D.i0);
+            if (noop_given_view(D, va0[p], ci, e0)) { tm &= ~1u; c_filt++; }
           }
-        if (!(tm | te)) continue;
-        sent_m[np] = tm; sent_e[np] = te; peers[np] = peers[p]; psh[np] = sh; np++;
+          for (uint32_t m = tm & ~1u; m; m &= m - 1) {
+            uint32_t j = __ffs(m) - 1; uint4 e = sq[j * SW_BLOCK];
+            if (e.x == peers[p]) continue;
+            uint32_t ws = j == 1 ? ws1 : (X.usable() ? X.word(e.x) : nw[e.x]);
+            if (!NW_HAS_SLOT(ws)) continue;
+            size_t ci = ((size_t)r * D.S + NW_SLOT(ws)) * D.nloc + (peers[p] - D.i0);
+            if (noop_given_view(D, D.va[ci], ci, e)) { tm &= ~(1u << j); c_filt++; }
+          }
+          sent_m[p] = tm;
+        }
+      }
+      // keep the packets that still carry something
+      for (uint32_t p = 0; p < npk; p++) {
+        uint32_t tm = sent_m[p], te = SERF ? sent_e[p] : 0;
+        if (!ok[p] || !(tm | te)) continue;
+        sent_m[np] = tm; peers[np] = peers[p];
+        if (SERF) sent_e[np] = te;
+        if (MULTI) psh[np] = peers[p] / D.nloc;
+        np++;
       }
     }
   }
   S.count(ST_QUIESCENT, quiet); S.count(ST_ACTIVE, active);
-  S.wave_add(ST_PKT_SENT, c_pkt); S.wave_add(ST_PKT_DROP, c_drop); S.wave_add(ST_FILTERED, c_filt);
+  if (!(D.ablate & 16u)) S.wave_add(ST_PKT_SENT, c_pkt); S.wave_add(ST_PKT_DROP, c_drop); S.wave_add(ST_FILTERED, c_filt);
   S.wave_add(ST_SENT0, c_s0); S.wave_add(ST_SENT1, c_s1); S.wave_add(ST_SENT2, c_s2); S.wave_add(ST_SENT3, c_s3);
 
-  // ---- compaction of the block's packets into the outbound lists: LDS offsets, then one global
-  //      atomicAdd per (block, shard)
+  // ---- compaction of the block's packets into the outbound lists
   // (a) records for nodes of this shard: wavefront prefix sum of the per-lane counts, one LDS atomic per
   //     wave, block-private segment -> no global atomic and no barrier on the way out
   const uint32_t segb = r * D.nb_gossip + bx;
   uint32_t n_loc = 0;
-  for (uint32_t p = 0; p < np; p++) if (psh[p] == D.rank) n_loc += (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p]));
-  uint32_t incl = n_loc;
+#define PKT_SH(p) (MULTI ? psh[p] : D.rank)
+#define PKT_N(p) ((uint32_t)(__popc(sent_m[p]) + (SERF ? __popc(sent_e[p]) : 0)))
+  for (uint32_t p = 0; p < np; p++) if (PKT_SH(p) == D.rank) n_loc += PKT_N(p);
+  uint32_t incl = n_loc, my_off = 0;
+  if (__any(n_loc != 0)) {
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
-  uint32_t wave_total = __shfl(incl, 63), wbase = 0;
-  if (wave_total) {
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
+    uint32_t wave_total = __shfl(incl, 63), wbase = 0;
     if (sw_lane() == 63) wbase = atomicAdd(&s_cnt[D.rank], wave_total);
     wbase = __shfl(wbase, 63);
+    my_off = wbase + incl - n_loc;
   }
-  uint32_t my_off = wbase + incl - n_loc;
   // (b) records for other shards: LDS offsets, then one global atomicAdd per (block, shard)
-  if (D.n_shards > 1) {
-    for (uint32_t p = 0; p < np; p++) if (psh[p] != D.rank) loc[p] = atomicAdd(&s_cnt[psh[p]], (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])));
+  if (MULTI) {
+    for (uint32_t p = 0; p < np; p++) if (PKT_SH(p) != D.rank) loc[MULTI ? p : 0] = atomicAdd(&s_cnt[PKT_SH(p)], PKT_N(p));
     __syncthreads();
     if (threadIdx.x < D.n_shards && threadIdx.x != D.rank) {
       uint32_t c = s_cnt[threadIdx.x], b = 0;
@@ -511,30 +601,33 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   }
   for (uint32_t p = 0; p < np; p++) {
     uint4* dst;
-    if (psh[p] == D.rank) { dst = D.seg + (size_t)segb * D.seg_cap + my_off; my_off += (uint32_t)(__popc(sent_m[p]) + __popc(sent_e[p])); }
-    else { uint32_t b = s_base[psh[p]]; if (b == NONE) continue; dst = D.out[psh[p]] + b + loc[p]; }
+    if (PKT_SH(p) == D.rank) { dst = D.seg + (size_t)segb * D.seg_cap + my_off; my_off += PKT_N(p); }
+    else { uint32_t b = s_base[PKT_SH(p)]; if (b == NONE) continue; dst = D.out[PKT_SH(p)] + b + loc[MULTI ? p : 0]; }
     uint32_t gdst = r * D.N + peers[p];
     for (uint32_t m = sent_m[p]; m; m &= m - 1) {
       uint4 e = sq[(__ffs(m) - 1) * SW_BLOCK];
       *dst++ = make_uint4(gdst, e.x, e.y, (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu));
     }
-    for (uint32_t m = sent_e[p]; m; m &= m - 1) {
-      uint4 e = se[(__ffs(m) - 1) * SW_BLOCK];
-      *dst++ = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
-    }
+    if (SERF)
+      for (uint32_t m = sent_e[p]; m; m &= m - 1) {
+        uint4 e = se[(__ffs(m) - 1) * SW_BLOCK];
+        *dst++ = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
+      }
   }
+#undef PKT_SH
+#undef PKT_N
 
-  // ---- write the queues back, compacted
-  if (active) {
+  // ---- write the queues back, compacted; untouched entries are not rewritten
+  if (active && !(D.ablate & 8u)) {
     size_t NL = (size_t)D.R * D.nloc;
-    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) D.q[(size_t)(nq++) * NL + l] = sq[j * SW_BLOCK];
-    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) D.evq[(size_t)(ne++) * NL + l] = se[j * SW_BLOCK];
-    h.y = h_pack(h_leaving(h.y), nq, ne);
-    D.hdr[l] = h;
+    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { D.q[(size_t)nq * NL + l] = sq[j * SW_BLOCK]; nq++; }
+    if (SERF) for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) { D.evq[(size_t)ne * NL + l] = se[j * SW_BLOCK]; ne++; }
+    uint32_t hy = h_pack(h_leaving(h.y), nq, ne);
+    if (hy != h.y) { h.y = hy; D.hdr[l] = h; }
   }
   // dead nodes keep their (frozen) queues: the hint stays up while any node of the block holds one
   bool holds = (nq | ne) != 0;
-  if (i != NONE && (wi & NW_DEAD) && D.fast_blocks) { uint32_t hy = D.hdr[(size_t)r * D.nloc + (i - D.i0)].y; holds = (h_qlen(hy) | h_evqlen(hy)) != 0; }
+  if (i != NONE && (wi & NW_DEAD) && D.fast_blocks) holds = (h_qlen(h.y) | h_evqlen(h.y)) != 0;
   int any = __syncthreads_or(holds);
   if (threadIdx.x == 0) {
     if (fb != NONE && !any) D.q_any[fb] = 0;
@@ -548,18 +641,26 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
 // k_begin — the fused first launch of a tick.  grid = nb_expire + nb_pend + R*(nb_probe + nb_gossip);
 // dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
 // =================================================================================================
+template <int KMAX, bool SERF, bool MULTI>
 __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
   extern __shared__ uint4 lds_q[];
   __shared__ uint32_t lds_stats[ST_COUNT];
-  __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS];
+  __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS], lds_exc[2 * SW_EXC_MAX];
   uint32_t b = blockIdx.x;
   if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); return; }
   b -= pl.nb_expire;
-  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending(D, b, pl.nb_pend, lds_stats); return; }
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats); return; }
   b -= pl.nb_pend;
-  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe(D, b / pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats); return; }
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe(D, b / pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc); return; }
   b -= D.R * pl.nb_probe;
-  if (pl.roles & 8u) role_gossip(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base);
+  if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc);
+}
+typedef void (*BeginKernel)(SwDev, BeginPlan);
+// pick the leanest instantiation the configuration allows
+static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
+  const bool k8 = fanout > 4;
+  if (k8) return serf ? (multi ? k_begin<8, true, true> : k_begin<8, true, false>) : (multi ? k_begin<8, false, true> : k_begin<8, false, false>);
+  return serf ? (multi ? k_begin<4, true, true> : k_begin<4, true, false>) : (multi ? k_begin<4, false, true> : k_begin<4, false, false>);
 }
 
 // =================================================================================================
@@ -636,6 +737,13 @@ __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
   D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
   D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
   atomicOr(&D.nw[g], sl + 1);
+  // keep the replica's exception list exact without a rescan (single-threaded here)
+  uint32_t n = D.exc_cnt[r];
+  if (n <= SW_EXC_MAX) {
+    bool listed = false;
+    for (uint32_t j = 0; j < n; j++) listed |= D.exc_list[(size_t)r * SW_EXC_MAX + j] == x;
+    if (!listed) { if (n < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + n] = x; D.exc_cnt[r] = n + 1; }
+  }
 }
 __global__ void k_alloc(SwDev D) {
   if (threadIdx.x || blockIdx.x) return;
@@ -699,78 +807,87 @@ struct NodeCtx {
     if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc }; D.events[pos] = ev; }
     else atomicOr(D.err, SW_ERR_EVENT_OVF);
   }
-  __device__ void set_view(size_t sidx, size_t ci, uint32_t inc, uint32_t st, bool touch_since) {
-    D.v_key[ci] = SW_KEY(inc, st);
-    if (touch_since) D.v_since[ci] = now_ms(D, t);
+  // the observer's record of a subject is edited in registers (a = {key, since, nconf, conf0}) and
+  // written back once by the caller
+  __device__ void set_view(size_t sidx, uint4& a, uint32_t inc, uint32_t st, bool touch_since) {
+    a.x = SW_KEY(inc, st);
+    if (touch_since) a.y = now_ms(D, t);
     if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
     D.slot_dirty[sidx] = 1;
   }
-  __device__ void refute(size_t sidx, size_t ci, uint32_t accused) {
+  __device__ void refute(size_t sidx, uint4& a, uint32_t accused) {
     uint32_t inc = self_inc + 1;
     if (accused >= inc) inc = accused + 1;
     self_inc = inc;
     uint2 h = D.ph[l];                                     // awareness lives with the probe state
     D.ph[l].y = p_pack(p_epoch(h.y), awareness_apply(D, p_aw(h.y), +1), p_stage(h.y), p_nackm(h.y));
-    set_view(sidx, ci, inc, SWIM_STATE_ALIVE, false);
+    set_view(sidx, a, inc, SWIM_STATE_ALIVE, false);
     broadcast(o, SWIM_MSG_ALIVE, inc, 0);
     S.add(ST_REFUTES);
   }
   __device__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
     uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
     size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint32_t key = D.v_key[ci]; bool local = x == o;
+    uint4 a = D.va[ci];
+    uint32_t key = a.x; bool local = x == o;
     if (local && leaving) return;
     if (!local && inc <= SW_KINC(key)) return;
     if (local && inc < SW_KINC(key)) return;
-    D.v_nconf[ci] = 0;
+    a.z = 0;                                               // delete(m.nodeTimers, a.Node)
     uint32_t old = SW_KST(key);
-    if (local) { if (inc == SW_KINC(key)) return; refute(sidx, ci, inc); }
+    if (local) { if (inc == SW_KINC(key)) { D.va[ci] = a; return; } refute(sidx, a, inc); }
     else {
       broadcast(x, SWIM_MSG_ALIVE, inc, upd);
-      set_view(sidx, ci, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
+      set_view(sidx, a, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
       S.add(ST_APPL0);
       if (o == D.watch) {
         if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
         else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
       }
     }
+    D.va[ci] = a;
   }
   __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
     uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
     size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint32_t key = D.v_key[ci];
+    uint4 a = D.va[ci];
+    uint32_t key = a.x;
     if (inc < SW_KINC(key)) return;
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from)
-      uint32_t nc = D.v_nconf[ci];
-      if (nc >= D.susp_k) return;
-      uint4 cf = D.v_conf[ci];
-      if (cf.x == from || (nc >= 1 && cf.y == from) || (nc >= 2 && cf.z == from) || (nc >= 3 && cf.w == from)) return;
+      uint32_t nc = a.z;
+      if (nc >= D.susp_k || a.w == from) return;
+      uint4 b = nc ? D.vb[ci] : make_uint4(0, 0, 0, 0);
+      if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
-      if (nc == 1) cf.y = from; else if (nc == 2) cf.z = from; else if (nc == 3) cf.w = from;
-      D.v_conf[ci] = cf; D.v_nconf[ci] = (uint8_t)nc;
+      if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
+      if (nc <= 3) D.vb[ci] = b;
+      a.z = nc; D.va[ci] = a;
       D.slot_dirty[sidx] = 1; S.add(ST_CONFIRMS);
       broadcast(x, SWIM_MSG_SUSPECT, inc, from);
       return;
     }
     if (SW_KST(key) != SWIM_STATE_ALIVE) return;
-    if (x == o) { refute(sidx, ci, inc); return; }
+    if (x == o) { refute(sidx, a, inc); D.va[ci] = a; return; }
     broadcast(x, SWIM_MSG_SUSPECT, inc, from);
-    set_view(sidx, ci, inc, SWIM_STATE_SUSPECT, true);
-    D.v_nconf[ci] = 0; D.v_conf[ci] = make_uint4(from, 0, 0, 0);
+    set_view(sidx, a, inc, SWIM_STATE_SUSPECT, true);
+    a.z = 0; a.w = from;                                   // newSuspicion(from, k, min, max)
+    D.va[ci] = a;
     S.add(ST_APPL1);
   }
   __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
     uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
     size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint32_t key = D.v_key[ci];
+    uint4 a = D.va[ci];
+    uint32_t key = a.x;
     if (inc < SW_KINC(key)) return;
     uint32_t old = SW_KST(key);
     if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
-    D.v_nconf[ci] = 0;
-    if (x == o && !leaving) { refute(sidx, ci, inc); return; }
+    a.z = 0;
+    if (x == o && !leaving) { refute(sidx, a, inc); D.va[ci] = a; return; }
     broadcast(x, SWIM_MSG_DEAD, inc, from);
     uint32_t st = from == x ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
-    set_view(sidx, ci, inc, st, true);
+    set_view(sidx, a, inc, st, true);
+    D.va[ci] = a;
     S.add(ST_APPL2);
     if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
   }
@@ -868,10 +985,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
     uint32_t o = D.i0 + k;
     if (o == x || (nw[o] & NW_DEAD)) continue;
     size_t ci = (size_t)sidx * D.nloc + k;
-    uint32_t key = D.v_key[ci], s = SW_KST(key);
+    uint4 a = D.va[ci];
+    uint32_t key = a.x, s = SW_KST(key);
     obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
     cur += SW_KINC(key) == maxinc;
-    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = D.v_since[ci] + D.susp_timeout[D.v_nconf[ci]]; mindl = dl < mindl ? dl : mindl; }
+    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = a.y + D.susp_timeout[a.z & 7u]; mindl = dl < mindl ? dl : mindl; }
   }
   uint32_t vals[6] = { obs, st[0], st[1], st[2], st[3], cur };
 #pragma unroll
@@ -900,6 +1018,22 @@ __device__ void census_commit(const SwDev& D, uint32_t sidx, uint32_t now) {
   if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
   if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
   D.slot_dirty[sidx] = 0;
+}
+
+// collect the ids of replica r whose node word is non-zero (whole block cooperates)
+__device__ void rebuild_exceptions(const SwDev& D, uint32_t r, uint32_t* s_n) {
+  if (threadIdx.x == 0) *s_n = 0;
+  __syncthreads();
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  for (uint32_t x = threadIdx.x; x < D.N; x += blockDim.x)
+    if (nw[x]) { uint32_t pos = atomicAdd(s_n, 1u); if (pos < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + pos] = x; }
+  __syncthreads();
+  if (threadIdx.x == 0) { D.exc_cnt[r] = *s_n; D.exc_dirty[r] = 0; }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild(SwDev D, uint32_t r) {
+  __shared__ uint32_t s_n;
+  rebuild_exceptions(D, r, &s_n);
 }
 
 __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt) {
@@ -956,7 +1090,7 @@ __global__ void k_init_nodes(SwDev D) {
 __global__ void k_init_views(SwDev D) {
   size_t n = (size_t)D.R * D.S * D.nloc, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  D.v_key[i] = SW_BASE_KEY; D.v_since[i] = 0; D.v_nconf[i] = 0; D.v_conf[i] = make_uint4(0, 0, 0, 0);
+  D.va[i] = make_uint4(SW_BASE_KEY, 0, 0, 0); D.vb[i] = make_uint4(0, 0, 0, 0);
 }
 __global__ void k_init_slots(SwDev D) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1002,7 +1136,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
         else {                                                                    // memberlist.UpdateNode
           c.self_inc++;
           size_t sidx = (size_t)r * D.S + NW_SLOT(w);
-          c.set_view(sidx, sidx * D.nloc + c.k, c.self_inc, SWIM_STATE_ALIVE, false);
+          uint4 a = D.va[sidx * D.nloc + c.k];
+          c.set_view(sidx, a, c.self_inc, SWIM_STATE_ALIVE, false);
+          D.va[sidx * D.nloc + c.k] = a;
           c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
         }
         c.store();
@@ -1089,17 +1225,18 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(SwDev D, unsigned lon
   uint64_t d = 0;
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     size_t ci = (size_t)sidx * D.nloc + k;
-    uint32_t key = D.v_key[ci], since = D.v_since[ci];
+    uint4 a = D.va[ci];
+    uint32_t key = a.x, since = a.y;
     if (key == SW_BASE_KEY && since == 0) continue;
     uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)x * 0x100000001B3ull) ^ ((uint64_t)(D.i0 + k) << 8);
     d += sw_h3(9, id, ((uint64_t)key << 32) | since);
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {
-      uint32_t nc = D.v_nconf[ci]; uint4 cf = D.v_conf[ci];
+      uint32_t nc = a.z; uint4 cf = D.vb[ci];
       d += sw_h3(10, id, nc);
-      d += sw_h3(11, id, cf.x);
-      if (nc >= 1) d += sw_h3(12, id, cf.y);
-      if (nc >= 2) d += sw_h3(13, id, cf.z);
-      if (nc >= 3) d += sw_h3(14, id, cf.w);
+      d += sw_h3(11, id, a.w);
+      if (nc >= 1) d += sw_h3(12, id, cf.x);
+      if (nc >= 2) d += sw_h3(13, id, cf.y);
+      if (nc >= 3) d += sw_h3(14, id, cf.z);
     }
   }
   digest_commit(d, out);

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Per-tick kernel breakdown from a rocprofv3 --kernel-trace CSV."""
-import csv, glob, sys
+import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 ticks, cur = [], None
 for r in rows:
-    n = r['Kernel_Name'].split('(')[0]
-    if not n.startswith('k_') or 'init' in n or 'inject' in n or 'commit' in n: continue
+    m = re.search(r'\b(k_[a-z_]+)', r['Kernel_Name'])
+    if not m: continue
+    n = m.group(1)
+    if 'init' in n or 'inject' in n or 'commit' in n or n == 'k_deliver_list': continue
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if n == 'k_begin' and (cur is None or 'k_deliver' in cur): cur = {'start': int(r['Start_Timestamp'])}
     if cur is None: continue
