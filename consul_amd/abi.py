@@ -111,6 +111,9 @@ PROTOTYPES = {
     "swim_now": (C.c_int, [SimP, P(u32), P(u32)]),
     "swim_tick_begin": (C.c_int, [SimP]),
     "swim_outbound": (C.c_int, [SimP, u32, P(C.c_void_p), P(u32)]),
+    "swim_outbound_capacity": (u32, [SimP, u32]),
+    "swim_stream": (C.c_int, [SimP, P(C.c_void_p)]),
+    "swim_outbound_raw": (C.c_int, [SimP, u32, P(C.c_void_p), P(C.c_void_p)]),
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_tick_end": (C.c_int, [SimP]),
     "swim_inject_kill": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),

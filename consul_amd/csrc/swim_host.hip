@@ -402,14 +402,27 @@ extern "C" int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr,
   *count = shard == s->D.rank ? 0 : std::min(s->out_counts[shard], s->D.out_cap[shard]);
   return SWIM_OK;
 }
+extern "C" int swim_stream(swim_sim* s, void** st) {
+  if (!s || !st) return SWIM_EINVAL;
+  *st = (void*)s->stream;
+  return SWIM_OK;
+}
+extern "C" int swim_outbound_raw(swim_sim* s, uint32_t shard, const swim_edge** seg, const uint32_t** cnt) {
+  if (!s || shard >= s->cfg.n_shards) return SWIM_EINVAL;
+  if (seg) *seg = (const swim_edge*)s->D.out[shard];
+  if (cnt) *cnt = s->D.out_cnt;
+  return SWIM_OK;
+}
+extern "C" uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) {
+  return (s && shard < s->cfg.n_shards) ? s->D.out_cap[shard] : 0;
+}
 extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   if (!s || (!ptr && count)) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
   if (!count) return SWIM_OK;
   if ((uint64_t)s->in_count + count > s->in_cap) { snprintf(s->err, sizeof s->err, "inbound staging full"); return SWIM_EOVERFLOW; }
-  // the source belongs to the caller (another shard's segment or a receive buffer): copy before returning
+  // asynchronous on the simulator's stream; the caller keeps the source alive (see swimsim.h)
   HIPCK(s, hipMemcpyAsync(s->in_buf + s->in_count, ptr, (size_t)count * sizeof(uint4), hipMemcpyDeviceToDevice, s->stream));
-  HIPCK(s, hipStreamSynchronize(s->stream));
   s->in_count += count;
   return SWIM_OK;
 }

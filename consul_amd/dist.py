@@ -34,6 +34,20 @@ class _DevMem:
 
 
 class TorchExchange:
+    """All-to-all of the per-destination record segments over torch.distributed.
+
+    GPU (backend nccl = RCCL over xGMI), device driven: the collectives are issued on the simulator's
+    own HIP stream (torch.cuda.ExternalStream), so kernels and exchange are ordered without host
+    synchronisation.  Per tick: all-gather the device-resident record counters (no D2H/H2D bounce),
+    read the gathered matrix once (the only host sync), and — only if some rank has remote records —
+    a list-form all_to_all (grouped ncclSend/ncclRecv) from slices of the aliased outbound buffers
+    straight into a persistent receive buffer.
+    CPU (backend gloo, used by the tests): host counts + uneven all_to_all_single of the concatenated
+    segments (gloo has no list form).
+    """
+
+    MAX_SHARDS = 16
+
     def __init__(self, group, device_index: int | None):
         import torch
         import torch.distributed as dist
@@ -42,40 +56,84 @@ class TorchExchange:
         self.rank = dist.get_rank(group)
         self.on_gpu = device_index is not None
         self.device = torch.device("cuda", device_index) if self.on_gpu else torch.device("cpu")
-        self._keep = None
+        self._bound = None          # simulator the GPU aliases belong to
+        self._recv = None
+        self._empty = torch.empty((0, 4), dtype=torch.int32, device=self.device)
+        self.skipped = 0            # ticks in which no rank had anything to send
 
-    def _segment(self, ptr: int, count: int):
+    # ---- GPU path -------------------------------------------------------------------------------
+    def _bind(self, sim: Sim):
         torch = self.torch
-        if count == 0:
-            return torch.empty((0, 4), dtype=torch.int32, device=self.device)
-        if self.on_gpu:
-            return torch.as_tensor(_DevMem(ptr, count * 4), device=self.device).view(count, 4)
-        buf = (C.c_int32 * (count * 4)).from_address(ptr)
-        return torch.from_numpy(np.frombuffer(buf, dtype=np.int32).reshape(count, 4))
+        self._stream = torch.cuda.ExternalStream(sim.stream_ptr(), device=self.device)
+        self._segs = []
+        cnt_ptr = 0
+        for sh in range(self.world):
+            seg, cnt_ptr = sim.outbound_raw(sh)
+            cap = sim.outbound_capacity(sh)
+            self._segs.append(torch.as_tensor(_DevMem(seg, cap * 4), device=self.device).view(cap, 4))
+        self._counts = torch.as_tensor(_DevMem(cnt_ptr, self.MAX_SHARDS), device=self.device)
+        self._gathered = torch.empty((self.world, self.MAX_SHARDS), dtype=torch.int32, device=self.device)
+        self._caps = [sim.outbound_capacity(sh) for sh in range(self.world)]
+        self._bound = sim
 
-    def run(self, sims: Sequence[Sim]):
-        (sim,) = sims
+    def _run_gpu(self, sim: Sim):
+        torch, dist = self.torch, self.dist
+        if self._bound is not sim:
+            self._bind(sim)
+        with torch.cuda.stream(self._stream):
+            dist.all_gather_into_tensor(self._gathered, self._counts, group=self.group)
+            m = self._gathered.cpu()                       # the tick's only host synchronisation
+            # every rank derives the same (clamped) sizes from the same matrix; a clamped segment has
+            # already raised the sender's sticky overflow flag
+            rcap = self._caps[(self.rank + 1) % self.world]
+            send = [0 if sh == self.rank else min(int(m[self.rank, sh]), rcap) for sh in range(self.world)]
+            recv_n = [0 if src == self.rank else min(int(m[src, self.rank]), rcap) for src in range(self.world)]
+            remote_total = int(m[:, : self.world].sum()) - int(sum(m[i, i] for i in range(self.world)))
+            if remote_total == 0:
+                self.skipped += 1
+                return
+            total = sum(recv_n)
+            if self._recv is None or self._recv.shape[0] < total:
+                self._recv = torch.empty((max(total, 1) * 2, 4), dtype=torch.int32, device=self.device)
+            outs, off = [], 0
+            for n in recv_n:
+                outs.append(self._recv[off:off + n]); off += n
+            ins = [self._segs[sh][: send[sh]] for sh in range(self.world)]
+            dist.all_to_all(outs, ins, group=self.group)
+            if total:
+                sim.inbound(self._recv.data_ptr(), total)  # asynchronous copy on the same stream
+
+    # ---- CPU path -------------------------------------------------------------------------------
+    def _run_cpu(self, sim: Sim):
         torch, dist = self.torch, self.dist
         segs, counts = [], []
         for sh in range(self.world):
-            ptr, n = sim.outbound(sh)            # syncs the simulator's stream: the records are complete
+            ptr, n = sim.outbound(sh)
             if sh == self.rank:
                 n = 0                            # the local segment never crosses the wire
-            segs.append(self._segment(ptr, n)); counts.append(n)
-        send_counts = torch.tensor(counts, dtype=torch.int64, device=self.device)
+            if n:
+                buf = (C.c_int32 * (n * 4)).from_address(ptr)
+                segs.append(torch.from_numpy(np.frombuffer(buf, dtype=np.int32).reshape(n, 4)))
+            else:
+                segs.append(self._empty)
+            counts.append(n)
+        send_counts = torch.tensor(counts, dtype=torch.int64)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         rc = [int(x) for x in recv_counts.tolist()]
-        send = torch.cat(segs, dim=0) if sum(counts) else torch.empty((0, 4), dtype=torch.int32, device=self.device)
-        recv = torch.empty((sum(rc), 4), dtype=torch.int32, device=self.device)
+        total = sum(rc)
+        recv = torch.empty((total, 4), dtype=torch.int32)
+        send = torch.cat(segs, dim=0) if sum(counts) else self._empty
         dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=counts, group=self.group)
+        if total:
+            sim.inbound(recv.data_ptr(), total)  # the oracle copies synchronously
+
+    def run(self, sims: Sequence[Sim]):
+        (sim,) = sims
         if self.on_gpu:
-            torch.cuda.current_stream(self.device).synchronize()   # hand-over to the simulator's stream
-        if recv.shape[0]:
-            sim.inbound(recv.data_ptr(), recv.shape[0])
-            if self.on_gpu:
-                sim.sync()                                         # recv may be recycled after this
-        self._keep = recv
+            self._run_gpu(sim)
+        else:
+            self._run_cpu(sim)
 
 
 class LocalExchange:
@@ -88,6 +146,8 @@ class LocalExchange:
             for j in range(n):
                 if i != j and segs[i][j][1]:
                     sims[j].inbound(*segs[i][j])
+        for s in sims:                       # the copies read other shards' buffers: finish them before anyone moves on
+            s.sync()
 
 
 class ShardedSim:

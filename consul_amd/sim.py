@@ -118,6 +118,21 @@ class Sim:
         self._ck("swim_outbound", self._l.swim_outbound(self._h, shard, C.byref(p), C.byref(n)))
         return p.value or 0, n.value
 
+    def outbound_capacity(self, shard: int) -> int:
+        """Upper bound on records ever returned for `shard` (size of the buffer behind outbound())."""
+        return int(self._l.swim_outbound_capacity(self._h, shard))
+
+    def stream_ptr(self) -> int:
+        p = C.c_void_p()
+        self._ck("swim_stream", self._l.swim_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def outbound_raw(self, shard: int):
+        """(segment pointer, counters pointer) on the device, no synchronisation."""
+        seg, cnt = C.c_void_p(), C.c_void_p()
+        self._ck("swim_outbound_raw", self._l.swim_outbound_raw(self._h, shard, C.byref(seg), C.byref(cnt)))
+        return seg.value or 0, cnt.value or 0
+
     def inbound(self, ptr: int, count: int):
         self._ck("swim_inbound", self._l.swim_inbound(self._h, C.c_void_p(ptr), count))
 

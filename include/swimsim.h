@@ -219,10 +219,18 @@ int swim_now(swim_sim* sim, uint32_t* tick, uint32_t* now_ms);
  *   begin    = timers + probe + gossip select/emit -> outbound segments bucketed by shard
  *   outbound = device pointer + record count of the segment for `shard`
  *   inbound  = hand over records received from another shard (device pointer on the product
- *              library, host pointer on the oracle)
+ *              library, host pointer on the oracle).  The product library copies asynchronously on
+ *              its stream: the buffer must stay untouched until swim_tick_end has been called and the
+ *              next swim_outbound / swim_sync returned
  *   end      = subject-slot allocation, delivery, merge (aliveNode/suspectNode/deadNode)     */
 int swim_tick_begin(swim_sim* sim);
 int swim_outbound(swim_sim* sim, uint32_t shard, const swim_edge** ptr, uint32_t* count);
+uint32_t swim_outbound_capacity(swim_sim* sim, uint32_t shard);   /* records the segment can ever hold */
+/* For a device-driven exchange (no host round trip for the counts): the stream every kernel of this
+ * simulator runs on, the address of the n_shards record counters (uint32 each, valid after
+ * swim_tick_begin in stream order) and of a shard's segment.  NULL/0 on the oracle. */
+int swim_stream(swim_sim* sim, void** hip_stream);
+int swim_outbound_raw(swim_sim* sim, uint32_t shard, const swim_edge** segment, const uint32_t** counters);
 int swim_inbound(swim_sim* sim, const swim_edge* ptr, uint32_t count);
 int swim_tick_end(swim_sim* sim);
 

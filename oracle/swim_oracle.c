@@ -861,6 +861,12 @@ int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr, uint32_t* 
   if (!s || !ptr || !count || shard >= s->cfg.n_shards) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
   *ptr = s->out[shard].v; *count = s->out[shard].n; return SWIM_OK;
 }
+int swim_stream(swim_sim* s, void** st) { if (!s || !st) return SWIM_EINVAL; *st = NULL; return SWIM_OK; }
+int swim_outbound_raw(swim_sim* s, uint32_t shard, const swim_edge** seg, const uint32_t** cnt) {
+  if (!s || shard >= s->cfg.n_shards) return SWIM_EINVAL;
+  if (seg) *seg = NULL; if (cnt) *cnt = NULL; return SWIM_ESTATE;     /* host buffers move: use swim_outbound */
+}
+uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) { return (s && shard < s->cfg.n_shards) ? 0x7FFFFFFFu : 0; }
 int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   if (!s || (!ptr && count)) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
   for (uint32_t i = 0; i < count; i++) ev_push(&s->in, ptr[i]);
