@@ -107,6 +107,11 @@ def main():
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
     args = ap.parse_args()
 
+    # Libraries (RCCL prints a version banner) must not reach stdout: the contract is ONE JSON line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -221,8 +226,11 @@ def main():
                 line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         line["cpu_baseline"] = run_cpu_baseline(args, G)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
     if sharded:
         dist.destroy_process_group()
 

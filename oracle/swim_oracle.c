@@ -237,10 +237,10 @@ typedef struct { uint32_t ltime, ids[EV_PER_SLOT]; uint8_t n; } evslot;
 typedef struct {
   uint32_t self_inc;
   uint8_t awareness, leaving;
-  uint32_t qlen, qseq; qent q[QMAX];
+  uint32_t qlen, qseq; qent* q;                 /* [queue_cap] in one slab for all nodes */
   uint32_t pr_target, pr_inc, pr_t0, pr_deadline, pr_cursor, pr_epoch; uint8_t pr_stage, pr_nack_miss;
   /* serf */
-  uint32_t ev_clock, evqlen, evqseq; qent evq[QMAX]; evslot* ring;
+  uint32_t ev_clock, evqlen, evqseq; qent* evq; evslot* ring;
   /* per-tick inbox */
   uint32_t in_cnt; swim_edge* inbox;
 } node_t;
@@ -263,6 +263,8 @@ struct swim_sim {
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
   uint32_t* node_slot;           /* [R*N] replicated */
   node_t* nodes;                 /* [R*nloc] */
+  qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous */
+  swim_edge* inbox_slab;
   slot_t* slots; uint32_t* n_slots; /* [R*S], [R] */
   edgevec* out;                  /* [n_shards] */
   edgevec in, last_edges;
@@ -823,21 +825,29 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   s->n_slots = (uint32_t*)calloc(s->R, 4); s->out = (edgevec*)calloc(cfg->n_shards, sizeof(edgevec));
   if (!s->gt_alive || !s->part || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out) { swim_destroy(s); return SWIM_ENOMEM; }
   memset(s->gt_alive, 1, NT); memset(s->node_slot, 0xFF, NT * 4);
+  s->q_slab = (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
+  s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
+  s->inbox_slab = (swim_edge*)malloc(NL * cfg->inbox_cap * sizeof(swim_edge));
+  if (!s->q_slab || !s->inbox_slab || ((cfg->flags & SWIM_F_SERF_EVENTS) && !s->evq_slab)) { swim_destroy(s); return SWIM_ENOMEM; }
   for (size_t g = 0; g < NL; g++) {
     node_t* nd = &s->nodes[g];
+    nd->q = s->q_slab + g * cfg->queue_cap;
+    nd->evq = s->evq_slab ? s->evq_slab + g * cfg->event_queue_cap : NULL;
     nd->self_inc = 1; nd->pr_target = SWIM_NONE;
-    nd->inbox = (swim_edge*)malloc((size_t)cfg->inbox_cap * sizeof(swim_edge));
+    nd->inbox = s->inbox_slab + g * cfg->inbox_cap;
     if (cfg->flags & SWIM_F_SERF_EVENTS) nd->ring = (evslot*)calloc(cfg->event_buffer, sizeof(evslot));
-    if (!nd->inbox || ((cfg->flags & SWIM_F_SERF_EVENTS) && !nd->ring)) { swim_destroy(s); return SWIM_ENOMEM; }
+    if ((cfg->flags & SWIM_F_SERF_EVENTS) && !nd->ring) { swim_destroy(s); return SWIM_ENOMEM; }
   }
   *out = s; return SWIM_OK;
 }
 
 int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
-  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].inbox); free(s->nodes[g].ring); }
+  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) free(s->nodes[g].ring);
+  free(s->inbox_slab);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) { free(s->slots[i].col); free(s->slots[i].trace); }
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
+  free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->events); free(s);
   return SWIM_OK;

@@ -147,3 +147,67 @@ def test_sharded_population_matches_unsharded(hip, oracle, n_shards):
             assert a[k] == b[k], k
     assert a["edges_remote"] > 0
     sh.close()
+
+
+# ---- BASELINE's full sizes: golden fixtures + size-independent properties -----------------------------
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("k", [2, 3, 5])
+def test_config3_full_size_matches_golden_curve(hip, k):
+    """config #3: N = 1 048 576, DefaultWANConfig timers, fan-out sweep, one update rumour at node 0.
+    The fixture was produced by the oracle in the build container (tools/make_golden.py)."""
+    g = json.load(open(os.path.join(GOLDEN, "config3_infection_1m.json")))
+    want = g["curves"][str(k)]
+    s = Sim(hip, preset(hip, abi.PRESET_WAN, gossip_nodes=k, trace_ticks=64, **g["config"]))
+    s.update(0, [0])
+    s.step(45)
+    s.sync()
+    got = [int(x) for x in s.trace(0, 0, 0, 45)[:, 4]]
+    assert got == want["infected"]
+    assert got.index(1048575) + 1 == want["rounds_to_full"]
+    assert s.census(0, 0).all_current_ms == want["all_current_ms"]
+    assert f"{s.digest():#018x}" == want["digest"]
+    assert all(b >= a for a, b in zip(got, got[1:]))               # infection is monotone
+    st = s.stats()
+    assert st["msgs_applied"][abi.MSG_ALIVE] == 1048575             # everybody adopted it exactly once
+    assert st["edges"] + st["msgs_filtered"] == st["msgs_sent"][abi.MSG_ALIVE] - 0 * st["packets_dropped"]
+
+
+def test_full_size_sharded_equals_unsharded(hip):
+    """1 048 576 nodes split over 2 and 4 simulators on this device: digests add up to the same value."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=1048576, seed=4, gossip_nodes=3, subject_cap=4)
+    ref = Sim(hip, preset(hip, abi.PRESET_WAN, **kw))
+    ref.update(0, [123456]); ref.kill(0, [777]); ref.step(30); ref.sync()
+    want = ref.digest(); ref.close()
+    for n_shards in (2, 4):
+        sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_WAN, shard_rank=i, n_shards=n_shards, **kw))
+                         for i in range(n_shards)], LocalExchange())
+        sh.update(0, [123456]); sh.kill(0, [777]); sh.step(30); sh.sync()
+        assert sh.digest() == want
+        sh.close()
+
+
+def test_runs_are_deterministic_and_seeds_differ(hip):
+    kw = dict(n_nodes=65536, n_replicas=4, subject_cap=4)
+    out = []
+    for seed in (1, 1, 2):
+        s = Sim(hip, preset(hip, abi.PRESET_LAN, seed=seed, **kw))
+        s.step_ms(2000); s.kill(0, [4242]); s.kill(3, [99]); s.step_ms(28000); s.sync()
+        out.append((s.digest(), s.census(0, 4242).all_dead_ms))
+        s.close()
+    assert out[0] == out[1] and out[0][0] != out[2][0]
+
+
+def test_finer_quantum_parity(hip, oracle):
+    """quantum_ms = 50 instead of the gcd (100): twice the ticks per round, finer stagger; still bit-exact."""
+    a, b = pair(hip, oracle, n_nodes=8192, seed=6, quantum_ms=50)
+    assert a.derived.gossip_period == 4 and a.derived.probe_period == 20
+    for s in (a, b):
+        s.step_ms(1500); s.kill(0, [5000]); s.step_ms(30000)
+    assert_same(a, b, [(0, 5000)])
+    assert a.census(0, 5000).all_dead_ms != abi.NONE

@@ -41,9 +41,25 @@ def config3_small():
     return {"config": dict(n_nodes=32768, seed=3), "curves": out}
 
 
+def config3_full():
+    """BASELINE config #3 at full size: N = 1 048 576, DefaultWANConfig timers, fan-out k in {2,3,5}, one
+    update rumour injected at node 0, tick 0.  Infected count per round until everyone has it."""
+    out = {}
+    for k in (2, 3, 5):
+        s = Sim(ora, preset(ora, abi.PRESET_WAN, n_nodes=1048576, seed=1, gossip_nodes=k, trace_ticks=64, subject_cap=2))
+        s.update(0, [0]); s.step(45)
+        tr = [int(x) for x in s.trace(0, 0, 0, 45)[:, 4]]
+        c = s.census(0, 0)
+        out[str(k)] = {"infected": tr, "rounds_to_full": tr.index(1048575) + 1, "all_current_ms": c.all_current_ms,
+                       "digest": f"{s.digest():#018x}"}
+        s.close()
+    return {"config": dict(n_nodes=1048576, seed=1, subject_cap=2), "curves": out}
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small)):
+    for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small),
+                     ("config3_infection_1m", config3_full)):
         with open(os.path.join(ROOT, "tests", "golden", name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name)
