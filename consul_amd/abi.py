@@ -32,7 +32,7 @@ class Config(C.Structure):
         "abi_version", "n_nodes", "n_replicas",
         "gossip_nodes", "gossip_interval_ms", "probe_interval_ms", "probe_timeout_ms",
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
-        "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size")] + [
+        "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4)] + [(n, u32) for n in (
         "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
@@ -44,7 +44,7 @@ class Derived(C.Structure):
         "quantum_ms", "gossip_period", "probe_period", "probe_timeout_ticks", "phase_chunk",
         "retransmit_limit", "suspicion_k", "suspicion_min_ms", "suspicion_max_ms")] + [
         ("suspicion_timeout_ms", u32 * 8), ("node_scale_milli", u32),
-        ("push_pull_scale", u32), ("packet_budget", u32)]
+        ("push_pull_scale", u32), ("push_pull_period_ticks", u32), ("packet_budget", u32)]
 
 
 class Member(C.Structure):
@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("confirmations", u64), ("edges", u64), ("edges_remote", u64),
                 ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
                 ("event_drops", u64), ("user_events_delivered", u64),
-                ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64)]
+                ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64)]
 
 
 class KernelTime(C.Structure):

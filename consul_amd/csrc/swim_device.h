@@ -21,7 +21,7 @@ enum {
   ST_PROBES, ST_ACKS, ST_IACKS, ST_PFAIL, ST_NACKMISS,
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
-  ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED,
+  ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
   ST_COUNT
 };
 
@@ -57,7 +57,7 @@ struct SwDev {
   uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB;
   uint32_t G, P, TQ, CH, quantum_ms;
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
-  uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks;
+  uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks, pp_period;
   uint32_t msg_len[4];
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
@@ -110,6 +110,10 @@ struct SwDev {
   uint32_t* pend;        // [TQ+1][pend_cap] local lane ids
   uint32_t* pend_cnt;    // [TQ+1]
   uint32_t pend_cap;
+  // push-pull: requests seen by k_resolve in tick t are answered by k_begin in tick t+1
+  uint2* pp_list;        // [2][pp_cap] {replier lane, requester id}
+  uint32_t* pp_cnt;      // [2]
+  uint32_t pp_cap;
   // edge lists.  Records for nodes of this shard produced by gossip block b go to the block's
   // private segment seg[b*seg_cap ..] (no global atomic); everything else (timers, probes, slot
   // requests, other shards) is appended to out[shard] with wave-aggregated atomics.
@@ -137,7 +141,9 @@ struct BeginPlan {
   uint32_t nb_pend;          // blocks walking the pending-indirect-probe list
   uint32_t nb_probe;         // per replica: blocks over the probe-due node set
   uint32_t nb_gossip;        // per replica: blocks over the gossip-due node set
-  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip
+  uint32_t nb_pp;            // per replica: blocks over the push-pull-due node set (0 = push-pull off)
+  uint32_t nb_ppreply;       // blocks answering the previous tick's pull requests
+  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull
 };
 
 #define SW_KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
@@ -145,7 +151,7 @@ struct BeginPlan {
 #define SW_KST(k) ((k) & 3u)
 #define SW_BASE_KEY SW_KEY(1, SWIM_STATE_ALIVE)
 
-enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4 };
+enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4, SW_STREAM_PUSHPULL = 5 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10: counter-based, so a draw depends on (seed, stream, tick, node, index) only.

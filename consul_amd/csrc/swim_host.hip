@@ -122,15 +122,15 @@ extern "C" int swim_config_preset(swim_config* c, int preset) {
   c->indirect_checks = 3; c->retransmit_mult = 4; c->suspicion_mult = 4;
   c->suspicion_max_timeout_mult = 6; c->probe_timeout_ms = 500; c->probe_interval_ms = 1000;
   c->awareness_max_mult = 8; c->gossip_nodes = 3; c->gossip_interval_ms = 200;
-  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400;
+  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400; c->push_pull_interval_ms = 30000;
   switch (preset) {
     case SWIM_PRESET_LAN: break;
     case SWIM_PRESET_WAN:   // memberlist.DefaultWANConfig (runtime.go:1362-1427)
       c->suspicion_mult = 6; c->probe_timeout_ms = 3000; c->probe_interval_ms = 5000;
-      c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000; break;
+      c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000; c->push_pull_interval_ms = 60000; break;
     case SWIM_PRESET_LOCAL:
       c->indirect_checks = 1; c->retransmit_mult = 2; c->suspicion_mult = 3;
-      c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000; break;
+      c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000; c->push_pull_interval_ms = 15000; break;
     default: return SWIM_EINVAL;
   }
   c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
@@ -176,6 +176,11 @@ extern "C" int swim_config_derive(const swim_config* c, swim_derived* d) {
   for (int32_t i = 1; i <= k && i < 8; i++)
     d->suspicion_timeout_ms[i] = (uint32_t)remaining_suspicion_ms((uint32_t)i, (uint32_t)k, 0, min_ms, max_ms);
   d->push_pull_scale = c->n_nodes <= 32 ? 1u : (uint32_t)(std::ceil(go_log2(n) - go_log2(32.0)) + 1.0);
+  {   // pushPullTrigger: every pushPullScale(PushPullInterval, n)
+    uint64_t per = (uint64_t)c->push_pull_interval_ms * d->push_pull_scale / q;
+    if (per > 0x7FFFFFFFull) return SWIM_ERANGE;
+    d->push_pull_period_ticks = (uint32_t)per;
+  }
   d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
   return SWIM_OK;
 }
@@ -242,6 +247,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.gossip_to_dead_ms = cfg->gossip_to_dead_ms; D.budget = d.packet_budget; D.flags = cfg->flags;
   D.watch = cfg->watch_node; D.trace_ticks = cfg->trace_ticks; D.n_shards = cfg->n_shards; D.rank = cfg->shard_rank;
   D.fast_blocks = (D.CH == SW_BLOCK && D.nloc % SW_BLOCK == 0) ? 1u : 0u;
+  D.pp_period = d.push_pull_period_ticks;
   for (int i = 0; i < 4; i++) D.msg_len[i] = cfg->msg_len[i];
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
@@ -274,7 +280,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
-  pl.roles = 0xF;
+  pl.nb_pp = D.pp_period ? cdiv(cdiv(D.N, D.pp_period), SW_BLOCK) : 0;
+  pl.nb_ppreply = D.pp_period ? 4 : 0;
+  pl.roles = D.pp_period ? 0x1F : 0xF;
+  D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) : 0);
+  DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2);
   s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
@@ -307,6 +317,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.seg_last, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(D.pend_cnt, 0, (D.TQ + 1) * 4, st));
+  HIPCK(s, hipMemsetAsync(D.pp_cnt, 0, 8, st));
   HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
@@ -333,10 +344,10 @@ static void launch_begin(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const BeginPlan& pl = s->plan;
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
-  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip);
+  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + D.R * pl.nb_pp;
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
-    BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = 0xD;
+    BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
     { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, a); }
     { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, b); }
   } else {
@@ -687,7 +698,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->edges = v[ST_EDGES]; out->edges_remote = v[ST_EDGES_REMOTE]; out->queue_drops = v[ST_QDROPS];
   out->inbox_overflow = v[ST_INBOX_OVF]; out->subject_overflow = v[ST_SUBJ_OVF]; out->event_drops = v[ST_EVDROPS];
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
-  out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED];
+  out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

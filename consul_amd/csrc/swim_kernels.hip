@@ -638,6 +638,70 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
 }
 
 // =================================================================================================
+// roles: push-pull — memberlist pushPull/pushPullNode/mergeState (state.go), message based so it works
+// across shards: the initiator sends, for every subject, the rumour mergeState would derive from its
+// own view (Alive -> alive, Left -> dead{From: node}, Dead|Suspect -> suspect{From: receiver}; a
+// remote Dead is never trusted directly) plus a pull request; the peer answers the same way next tick.
+// =================================================================================================
+__device__ void append_one(const SwDev& D, uint32_t sh, uint4 rec, BlockStats& S) {
+  uint32_t pos = atomicAdd(&D.out_cnt[sh], 1u);
+  if (pos < D.out_cap[sh]) D.out[sh][pos] = rec; else atomicOr(D.err, SW_ERR_EDGE_OVF);
+  S.add(ST_EDGES); if (sh != D.rank) S.add(ST_EDGES_REMOTE);
+}
+__device__ void send_state(const SwDev& D, uint32_t r, uint32_t owner, uint32_t dst, BlockStats& S) {
+  const uint32_t sh = dst / D.nloc;
+  const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
+  for (uint32_t sl = 0; sl < D.n_slots[r]; sl++) {
+    size_t sidx = (size_t)r * D.S + sl;
+    uint4 a = D.va[sidx * D.nloc + (owner - D.i0)];
+    if (a.x == SW_BASE_KEY) continue;                       // the base row merges to nothing
+    uint32_t x = D.subj_node[sidx], st = SW_KST(a.x), type, from = 0;
+    if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
+    else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
+    else { type = SWIM_MSG_SUSPECT; from = dst; }
+    if (filter && x != dst) {
+      size_t ci = sidx * D.nloc + (dst - D.i0);
+      if (noop_given_view(D, D.va[ci], ci, make_uint4(x, SW_KINC(a.x), from, type << 30))) { S.add(ST_FILTERED); continue; }
+    }
+    append_one(D, sh, mk_edge(D, r, dst, x, SW_KINC(a.x), type, from), S);
+  }
+}
+__device__ void role_pushpull(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
+  ExcList X; X.stage(D, r, lds_exc);
+  BlockStats S; S.init(lds_stats);
+  uint32_t t = *D.tick;
+  uint64_t i64 = (uint64_t)(t % D.pp_period) + (uint64_t)a * D.pp_period;
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  if (i64 < D.N) {
+    uint32_t o = (uint32_t)i64;
+    if (o >= D.i0 && o < D.i0 + D.nloc) {
+      uint32_t wo = nw[o];
+      if (!(wo & NW_DEAD)) {
+        uint32_t p, wp;
+        if (k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X) &&
+            !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp)) {          // else the TCP dial fails
+          S.add(ST_PUSHPULLS);
+          send_state(D, r, o, p, S);
+          append_one(D, p / D.nloc, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0), S);
+        }
+      }
+    }
+  }
+  S.flush(D);
+}
+__device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+  BlockStats S; S.init(lds_stats);
+  uint32_t t = *D.tick, li = t & 1u;
+  uint32_t n = D.pp_cnt[li]; if (n > D.pp_cap) n = D.pp_cap;
+  for (uint32_t e = b * SW_BLOCK + threadIdx.x; e < n; e += nb * SW_BLOCK) {
+    uint2 rq = D.pp_list[(size_t)li * D.pp_cap + e];
+    uint32_t r = rq.x / D.nloc, p = D.i0 + rq.x % D.nloc;
+    if (!(D.nw[(size_t)r * D.N + p] & NW_DEAD)) send_state(D, r, p, rq.y, S);
+  }
+  S.flush(D);
+}
+
+// =================================================================================================
 // k_begin — the fused first launch of a tick.  grid = nb_expire + nb_pend + R*(nb_probe + nb_gossip);
 // dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
 // =================================================================================================
@@ -653,7 +717,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
   b -= pl.nb_pend;
   if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe(D, b / pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc); return; }
   b -= D.R * pl.nb_probe;
-  if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc);
+  if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); return; }
+  b -= D.R * pl.nb_gossip;
+  if (b < pl.nb_ppreply) { if (pl.roles & 16u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); return; }
+  b -= pl.nb_ppreply;
+  if (pl.roles & 16u) role_pushpull(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
 }
 typedef void (*BeginKernel)(SwDev, BeginPlan);
 // pick the leanest instantiation the configuration allows
@@ -957,7 +1025,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         }
         if (!have) break;
         uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
-        if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
+        if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
+          uint32_t pos = atomicAdd(&D.pp_cnt[(n.t + 1) & 1u], 1u);
+          if (pos < D.pp_cap) D.pp_list[(size_t)((n.t + 1) & 1u) * D.pp_cap + pos] = make_uint2((uint32_t)l, best.z);
+          else atomicOr(D.err, SW_ERR_PEND_OVF);
+        }
+        else if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
         else if (type == SWIM_MSG_SUSPECT) n.suspect_node(best.y, best.z, from);
         else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
         else n.user_event(best.y, best.z);
@@ -1053,6 +1126,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt
     *D.tick = t + 1;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
+    D.pp_cnt[t & 1u] = 0;                      // this tick's pull requests have been answered
   }
 }
 __global__ void k_census_commit(SwDev D) {

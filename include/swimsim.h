@@ -39,6 +39,7 @@ extern "C" {
 #define SWIM_ESTATE    (-71)  /* call not legal in the current tick phase                   */
 
 #define SWIM_NONE 0xFFFFFFFFu
+#define SWIM_SUBJECT_PULL 0xFFFFFFFEu  /* edge.subject of a push-pull request; edge.incarnation = requester */
 
 /* ---- enums pinned by the reference ------------------------------------------------------ */
 /* memberlist NodeStateType (state.go) */
@@ -88,6 +89,8 @@ typedef struct swim_config {
   uint32_t awareness_max_mult;      /* AwarenessMaxMultiplier (default 8)                   */
   uint32_t gossip_to_dead_ms;       /* GossipToTheDeadTime                                  */
   uint32_t udp_buffer_size;         /* UDPBufferSize (default 1400)                         */
+  uint32_t push_pull_interval_ms;   /* PushPullInterval (LAN 30 s, WAN 60 s; 0 = off); scaled by
+                                       pushPullScale(N) like memberlist                      */
   /* modelled encoded sizes of alive/suspect/dead/user messages, bytes (queue order uses len) */
   uint32_t msg_len[4];
   /* simulator */
@@ -117,6 +120,7 @@ typedef struct swim_derived {
   uint32_t suspicion_timeout_ms[8]; /* timeout after n = 0..k confirmations                 */
   uint32_t node_scale_milli;        /* int(max(1,log10(max(1,N))) * 1000)                   */
   uint32_t push_pull_scale;         /* pushPullScale multiplier                             */
+  uint32_t push_pull_period_ticks;  /* PushPullInterval * scale / quantum (0 = off)         */
   uint32_t packet_budget;           /* UDPBufferSize - compoundHeaderOverhead               */
 } swim_derived;
 
@@ -187,6 +191,7 @@ typedef struct swim_stats_t {
   uint64_t queue_drops, inbox_overflow, subject_overflow, event_drops;
   uint64_t user_events_delivered, user_events_deduped, user_events_stale;
   uint64_t msgs_filtered;           /* rumours dropped at the sender by SWIM_F_FILTER_NOOP       */
+  uint64_t push_pulls;              /* pushPullNode exchanges initiated                          */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;

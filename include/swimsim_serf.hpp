@@ -170,7 +170,7 @@ class Cluster {
     cfg_.suspicion_mult = (uint32_t)mc.SuspicionMult; cfg_.retransmit_mult = (uint32_t)mc.RetransmitMult;
     cfg_.indirect_checks = (uint32_t)mc.IndirectChecks; cfg_.suspicion_max_timeout_mult = (uint32_t)mc.SuspicionMaxTimeoutMult;
     cfg_.awareness_max_mult = (uint32_t)mc.AwarenessMaxMultiplier; cfg_.gossip_to_dead_ms = (uint32_t)mc.GossipToTheDeadTime.count();
-    cfg_.udp_buffer_size = (uint32_t)mc.UDPBufferSize;
+    cfg_.udp_buffer_size = (uint32_t)mc.UDPBufferSize; cfg_.push_pull_interval_ms = (uint32_t)mc.PushPullInterval.count();
     cfg_.queue_cap = o.QueueCap; cfg_.inbox_cap = o.InboxCap; cfg_.subject_cap = o.SubjectCap; cfg_.watch_node = o.WatchNode;
     cfg_.event_buffer = (uint32_t)o.EventBuffer; cfg_.flags |= SWIM_F_SERF_EVENTS;
     check(swim_config_derive(&cfg_, &derived_), "swim_config_derive");

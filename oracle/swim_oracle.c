@@ -44,7 +44,7 @@
 /* RNG and hashing                                                                             */
 /* ------------------------------------------------------------------------------------------ */
 
-enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4 };
+enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4, STREAM_PUSHPULL = 5 };
 
 /* Philox4x32-10 (Salmon et al., SC'11; Random123).  Pinned by kat vectors in the tests. */
 static void philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) {
@@ -142,13 +142,13 @@ int swim_config_preset(swim_config* c, int preset) {
   c->indirect_checks = 3; c->retransmit_mult = 4; c->suspicion_mult = 4;
   c->suspicion_max_timeout_mult = 6; c->probe_timeout_ms = 500; c->probe_interval_ms = 1000;
   c->awareness_max_mult = 8; c->gossip_nodes = 3; c->gossip_interval_ms = 200;
-  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400;
+  c->gossip_to_dead_ms = 30000; c->udp_buffer_size = 1400; c->push_pull_interval_ms = 30000;
   if (preset == SWIM_PRESET_WAN) {
     c->suspicion_mult = 6; c->probe_timeout_ms = 3000; c->probe_interval_ms = 5000;
-    c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000;
+    c->gossip_nodes = 4; c->gossip_interval_ms = 500; c->gossip_to_dead_ms = 60000; c->push_pull_interval_ms = 60000;
   } else if (preset == SWIM_PRESET_LOCAL) {
     c->indirect_checks = 1; c->retransmit_mult = 2; c->suspicion_mult = 3;
-    c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000;
+    c->probe_timeout_ms = 200; c->gossip_interval_ms = 100; c->gossip_to_dead_ms = 15000; c->push_pull_interval_ms = 15000;
   } else if (preset != SWIM_PRESET_LAN) return SWIM_EINVAL;
   c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
   c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
@@ -211,6 +211,10 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
     d->suspicion_timeout_ms[i] = (uint32_t)remaining_suspicion_ms((uint32_t)i, (uint32_t)k, 0, min_ms, max_ms);
   /* util.go pushPullScale multiplier */
   d->push_pull_scale = c->n_nodes <= 32 ? 1u : (uint32_t)(ceil(go_log2(n) - go_log2(32.0)) + 1.0);
+  /* state.go pushPullTrigger: every pushPullScale(PushPullInterval, n), after a random stagger */
+  { uint64_t per = (uint64_t)c->push_pull_interval_ms * d->push_pull_scale / q;
+    if (per > 0x7FFFFFFFull) return SWIM_ERANGE;
+    d->push_pull_period_ticks = (uint32_t)per; }
   /* state.go gossip(): bytesAvail = UDPBufferSize - compoundHeaderOverhead(2) - labelOverhead(0) */
   d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
   return SWIM_OK;
@@ -268,6 +272,7 @@ struct swim_sim {
   slot_t* slots; uint32_t* n_slots; /* [R*S], [R] */
   edgevec* out;                  /* [n_shards] */
   edgevec in, last_edges;
+  edgevec pp_reply[2];           /* push-pull requests seen in tick t are answered in tick t+1: {dst=replier, subject=requester, incarnation=replica} */
   swim_event* events; size_t n_events, cap_events;
   swim_stats_t st;
   uint32_t loss_q32;
@@ -689,6 +694,52 @@ static int noop_at_receiver(swim_sim* s, uint32_t r, uint32_t dst, const qent* m
   return 0;
 }
 
+/* state.go pushPull / pushPullNode / mergeState, made message-based so it works across
+ * shards: the initiator sends, for every subject, the rumour mergeState would derive from its own view
+ * (Alive -> alive, Left -> dead{From: node}, Dead|Suspect -> suspect{From: receiver} — a remote Dead is
+ * never trusted directly) plus a pull request; the peer answers the same way one tick later. */
+static int excl_pushpull(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* ctx) {
+  (void)ctx; if (x == o) return 1;
+  return KST(view_key(s, r, o, x, NULL)) != SWIM_STATE_ALIVE;
+}
+static void send_state(swim_sim* s, uint32_t r, uint32_t owner, uint32_t dst) {
+  for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
+    slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
+    view_t* v = &t->col[owner - s->i0];
+    if (v->key == BASE_KEY) continue;                      /* the base row merges to nothing */
+    qent m = { t->node, KINC(v->key), 0, 0, 0, 0 };
+    switch (KST(v->key)) {
+      case SWIM_STATE_ALIVE: m.type = SWIM_MSG_ALIVE; break;
+      case SWIM_STATE_LEFT: m.type = SWIM_MSG_DEAD; m.from = t->node; break;
+      default: m.type = SWIM_MSG_SUSPECT; m.from = dst; break;
+    }
+    if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, dst, &m)) { s->st.msgs_filtered++; continue; }
+    emit(s, r, dst, m.subject, m.inc, m.type, m.from);
+  }
+}
+static void phase_pushpull(swim_sim* s) {
+  /* answers to the requests of the previous tick */
+  edgevec* rq = &s->pp_reply[s->tick & 1];
+  for (uint32_t i = 0; i < rq->n; i++) {
+    uint32_t r = rq->v[i].incarnation, p = rq->v[i].dst, o = rq->v[i].subject;
+    if (s->gt_alive[(size_t)r * s->N + p]) send_state(s, r, p, o);
+  }
+  rq->n = 0;
+  uint32_t per = s->d.push_pull_period_ticks;
+  if (!per) return;
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint64_t i64 = s->tick % per; i64 < s->N; i64 += per) {
+      uint32_t o = (uint32_t)i64, p;
+      if (!is_local(s, o) || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (!k_random_nodes(s, r, o, STREAM_PUSHPULL, 1, excl_pushpull, NULL, &p)) continue;
+      size_t base = (size_t)r * s->N;
+      if (!s->gt_alive[base + p] || s->part[base + o] != s->part[base + p]) continue;   /* TCP dial fails */
+      s->st.push_pulls++;
+      send_state(s, r, o, p);
+      emit(s, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0);
+    }
+}
+
 /* gossip(): k random peers; per peer one getBroadcasts() = memberlist queue, then the serf
  * delegate's user events in the bytes that remain; stop at the first empty packet */
 static void phase_gossip(swim_sim* s) {
@@ -765,6 +816,11 @@ static void phase_deliver_resolve(swim_sim* s) {
         swim_edge e = nd->inbox[i];
         if (i && edge_cmp(&nd->inbox[i - 1], &e) == 0) continue;
         uint32_t type = e.meta >> 30, from = e.meta & 0x3FFFFFFFu;
+        if (e.subject == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {      /* answer next tick */
+          swim_edge rq = { o, e.incarnation, r, 0 };
+          ev_push(&s->pp_reply[(s->tick + 1) & 1], rq);
+          continue;
+        }
         switch (type) {
           case SWIM_MSG_ALIVE: alive_node(s, r, o, nd, e.subject, e.incarnation, from); break;
           case SWIM_MSG_SUSPECT: suspect_node(s, r, o, nd, e.subject, e.incarnation, from); break;
@@ -849,7 +905,7 @@ int swim_destroy(swim_sim* s) {
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
   free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
-  free(s->out); free(s->in.v); free(s->last_edges.v); free(s->events); free(s);
+  free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->events); free(s);
   return SWIM_OK;
 }
 
@@ -857,7 +913,7 @@ int swim_tick_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
   for (uint32_t i = 0; i < s->cfg.n_shards; i++) s->out[i].n = 0;
   s->in.n = 0;
-  phase_expire(s); phase_probe(s); phase_gossip(s);
+  phase_expire(s); phase_probe(s); phase_pushpull(s); phase_gossip(s);
   s->in_tick = 1;
   /* the local segment never crosses the wire */
   edgevec* loc = &s->out[s->cfg.shard_rank];

@@ -292,7 +292,8 @@ def test_push_gossip_infection_follows_the_analytic_recurrence(oracle):
 
 @pytest.mark.parametrize("kw", [
     dict(n_nodes=4096, n_replicas=2, seed=5),
-    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=256, loss_q32=int(0.1 * 2**32)),
+    # inbox large enough that the UNfiltered run does not overflow it (a push-pull delivers every subject at once)
+    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=4096, loss_q32=int(0.1 * 2**32)),
     dict(n_nodes=512, seed=2, suspicion_mult=6, subject_cap=64),              # k = 4 confirmations
 ])
 def test_noop_filter_never_changes_node_state(oracle, kw):
@@ -329,3 +330,30 @@ def test_golden_fixture_config1(oracle):
     st = s.stats()
     for k, v in g["stats"].items():
         assert st[k] == v, k
+
+
+def test_push_pull_heals_what_gossip_cannot(oracle):
+    """pushPull/mergeState: a node that every peer holds Dead is neither probed nor (after
+    GossipToTheDeadTime) gossiped to; only the periodic full-state exchange tells it, and it refutes."""
+    out = {}
+    for ppi in (30000, 0):
+        s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=1024, seed=2, subject_cap=16, push_pull_interval_ms=ppi))
+        assert s.derived.push_pull_period_ticks == (1800 if ppi else 0)       # 30 s * pushPullScale(1024)=6 / 100 ms
+        s.step_ms(1000); s.kill(0, [33]); s.step_ms(40000)
+        assert s.census(0, 33).by_state[abi.STATE_DEAD] == 1023
+        s.revive(0, [33]); s.step_ms(400000)
+        c = s.census(0, 33)
+        out[ppi] = (list(c.by_state), s.node_info(0, 33).incarnation, s.stats()["push_pulls"])
+    assert out[0] == ([0, 0, 1023, 0], 1, 0)                 # without anti-entropy it stays dead for ever
+    assert out[30000][0] == [1023, 0, 0, 0] and out[30000][1] == 2 and out[30000][2] > 1024
+
+
+def test_push_pull_never_trusts_a_remote_dead(oracle):
+    """mergeState turns a remote Dead into suspectNode{From: self}: the receiver starts its own suspicion
+    timer instead of adopting the death."""
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=64, seed=1, subject_cap=8, gossip_nodes=1, retransmit_mult=1))
+    assert s.derived.push_pull_period_ticks == 600
+    s.kill(0, [9])
+    s.step_ms(200000)
+    st = s.stats()
+    assert st["push_pulls"] > 0 and s.census(0, 9).by_state[abi.STATE_DEAD] == 63

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 STAT_KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent",
              "msgs_applied", "probes", "probe_acks", "probe_indirect_acks", "probe_failures", "nacks_missed",
-             "refutes", "suspicion_timeouts", "confirmations", "edges", "msgs_filtered", "queue_drops", "inbox_overflow",
+             "refutes", "suspicion_timeouts", "confirmations", "edges", "msgs_filtered", "push_pulls", "queue_drops",
+             "inbox_overflow",
              "subject_overflow"]
 
 
@@ -211,3 +212,22 @@ def test_finer_quantum_parity(hip, oracle):
         s.step_ms(1500); s.kill(0, [5000]); s.step_ms(30000)
     assert_same(a, b, [(0, 5000)])
     assert a.census(0, 5000).all_dead_ms != abi.NONE
+
+
+def test_push_pull_parity_and_heal(hip, oracle):
+    """a14: push-pull on a short period so it dominates: kill, let everyone declare it dead, revive,
+    and let the state exchange heal the views — bit-exact against the oracle, sharded too."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=4096, n_replicas=2, seed=8, subject_cap=16, push_pull_interval_ms=1000)
+    a, b = pair(hip, oracle, **kw)
+    sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    for s in (a, b, sh):
+        s.step_ms(1000); s.kill(0, [33]); s.kill(1, [5]); s.update(1, [77]); s.step_ms(40000)
+        s.revive(0, [33]); s.step_ms(30000)
+    assert_same(a, b, [(0, 33), (1, 5), (1, 77)])
+    sh.sync()
+    assert sh.digest() == b.digest()
+    c = a.census(0, 33)
+    assert c.by_state[abi.STATE_ALIVE] == c.n_observers and a.node_info(0, 33).incarnation == 2
+    assert a.stats()["push_pulls"] == b.stats()["push_pulls"] > 0
+    sh.close()
