@@ -280,11 +280,12 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
-  pl.nb_pp = D.pp_period ? cdiv(cdiv(D.N, D.pp_period), SW_BLOCK) : 0;
+  pl.nb_pp = D.pp_period ? cdiv((uint64_t)cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period), SW_BLOCK) : 0;
   pl.nb_ppreply = D.pp_period ? 4 : 0;
   pl.roles = D.pp_period ? 0x1F : 0xF;
-  D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) : 0);
-  DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2);
+  D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0);
+  D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
+  DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
   s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
@@ -317,7 +318,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.seg_last, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(D.pend_cnt, 0, (D.TQ + 1) * 4, st));
-  HIPCK(s, hipMemsetAsync(D.pp_cnt, 0, 8, st));
+  HIPCK(s, hipMemsetAsync(D.pp_cnt, 0, 2 * SW_PP_LISTS * 16 * 4, st));
   HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));

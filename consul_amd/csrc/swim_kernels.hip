@@ -643,61 +643,82 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
 // own view (Alive -> alive, Left -> dead{From: node}, Dead|Suspect -> suspect{From: receiver}; a
 // remote Dead is never trusted directly) plus a pull request; the peer answers the same way next tick.
 // =================================================================================================
-__device__ void append_one(const SwDev& D, uint32_t sh, uint4 rec, BlockStats& S) {
-  uint32_t pos = atomicAdd(&D.out_cnt[sh], 1u);
-  if (pos < D.out_cap[sh]) D.out[sh][pos] = rec; else atomicOr(D.err, SW_ERR_EDGE_OVF);
-  S.add(ST_EDGES); if (sh != D.rank) S.add(ST_EDGES_REMOTE);
-}
-__device__ void send_state(const SwDev& D, uint32_t r, uint32_t owner, uint32_t dst, BlockStats& S) {
-  const uint32_t sh = dst / D.nloc;
+// Every lane of the wave calls this together (`on` = the lane takes part); the records of a wave are
+// appended with one atomic per destination shard, never one per record.
+__device__ void send_state(const SwDev& D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
+  uint32_t ns = on ? D.n_slots[r] : 0, ns_max = ns;
+  for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(ns_max, off); ns_max = v > ns_max ? v : ns_max; }
+  const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
-  for (uint32_t sl = 0; sl < D.n_slots[r]; sl++) {
-    size_t sidx = (size_t)r * D.S + sl;
-    uint4 a = D.va[sidx * D.nloc + (owner - D.i0)];
-    if (a.x == SW_BASE_KEY) continue;                       // the base row merges to nothing
-    uint32_t x = D.subj_node[sidx], st = SW_KST(a.x), type, from = 0;
-    if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
-    else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
-    else { type = SWIM_MSG_SUSPECT; from = dst; }
-    if (filter && x != dst) {
-      size_t ci = sidx * D.nloc + (dst - D.i0);
-      if (noop_given_view(D, D.va[ci], ci, make_uint4(x, SW_KINC(a.x), from, type << 30))) { S.add(ST_FILTERED); continue; }
+  for (uint32_t sl = 0; sl < ns_max; sl++) {
+    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
+    if (sl < ns) {
+      size_t sidx = (size_t)r * D.S + sl;
+      uint4 a = D.va[sidx * D.nloc + (owner - D.i0)];
+      if (a.x != SW_BASE_KEY) {                            // the base row merges to nothing
+        uint32_t x = D.subj_node[sidx], st = SW_KST(a.x), type, from = 0;
+        if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
+        else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
+        else { type = SWIM_MSG_SUSPECT; from = dst; }
+        want = true;
+        if (filter && x != dst) {
+          size_t ci = sidx * D.nloc + (dst - D.i0);
+          if (noop_given_view(D, D.va[ci], ci, make_uint4(x, SW_KINC(a.x), from, type << 30))) { want = false; c_filt++; }
+        }
+        rec = mk_edge(D, r, dst, x, SW_KINC(a.x), type, from);
+      }
     }
-    append_one(D, sh, mk_edge(D, r, dst, x, SW_KINC(a.x), type, from), S);
+    wave_append_sharded(D, want, sh, rec);
+    c_edges += want; c_remote += want && sh != D.rank;
   }
 }
 __device__ void role_pushpull(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
+  uint32_t t = *D.tick;
+  if (t % D.P) return;                              // exchanges start on probe-interval boundaries only
   ExcList X; X.stage(D, r, lds_exc);
   BlockStats S; S.init(lds_stats);
-  uint32_t t = *D.tick;
-  uint64_t i64 = (uint64_t)(t % D.pp_period) + (uint64_t)a * D.pp_period;
+  // lane a -> (window offset, j-th node due in that tick); everything due within the next P ticks goes now
+  uint32_t grp = D.P < D.pp_period ? D.P : D.pp_period, off = a % grp;
+  uint64_t i64 = (uint64_t)((t + off) % D.pp_period) + (uint64_t)(a / grp) * D.pp_period;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
+  bool go = false; uint32_t o = 0, p = 0;
   if (i64 < D.N) {
-    uint32_t o = (uint32_t)i64;
+    o = (uint32_t)i64;
     if (o >= D.i0 && o < D.i0 + D.nloc) {
-      uint32_t wo = nw[o];
-      if (!(wo & NW_DEAD)) {
-        uint32_t p, wp;
-        if (k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X) &&
-            !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp)) {          // else the TCP dial fails
-          S.add(ST_PUSHPULLS);
-          send_state(D, r, o, p, S);
-          append_one(D, p / D.nloc, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0), S);
-        }
-      }
+      uint32_t wo = nw[o], wp;
+      if (!(wo & NW_DEAD) && k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X))
+        go = !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp);          // else the TCP dial fails
     }
   }
+  uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
+  send_state(D, go, r, o, p, c_edges, c_remote, c_filt);
+  uint32_t sh = go ? p / D.nloc : 0;
+  wave_append_sharded(D, go, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
+  c_edges += go; c_remote += go && sh != D.rank;
+  S.count(ST_PUSHPULLS, go);
+  S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
   S.flush(D);
 }
+// pull requests are filed in 64 sub-lists (k_resolve picks one by block) so that no counter is hot
+#define SW_PP_LISTS 64
 __device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
-  BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick, li = t & 1u;
-  uint32_t n = D.pp_cnt[li]; if (n > D.pp_cap) n = D.pp_cap;
-  for (uint32_t e = b * SW_BLOCK + threadIdx.x; e < n; e += nb * SW_BLOCK) {
-    uint2 rq = D.pp_list[(size_t)li * D.pp_cap + e];
-    uint32_t r = rq.x / D.nloc, p = D.i0 + rq.x % D.nloc;
-    if (!(D.nw[(size_t)r * D.N + p] & NW_DEAD)) send_state(D, r, p, rq.y, S);
+  if (t == 0 || (t - 1) % D.P) return;              // requests only exist the tick after a boundary
+  BlockStats S; S.init(lds_stats);
+  uint32_t sub_cap = D.pp_cap / SW_PP_LISTS, c_edges = 0, c_remote = 0, c_filt = 0;
+  for (uint32_t sub = b; sub < SW_PP_LISTS; sub += nb) {
+    uint32_t n = D.pp_cnt[(li * SW_PP_LISTS + sub) * 16]; if (n > sub_cap) n = sub_cap;
+    for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
+      uint32_t e = e0 + threadIdx.x; bool on = e < n; uint32_t r = 0, p = 0, o = 0;
+      if (on) {
+        uint2 rq = D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + e];
+        r = rq.x / D.nloc; p = D.i0 + rq.x % D.nloc; o = rq.y;
+        on = !(D.nw[(size_t)r * D.N + p] & NW_DEAD);
+      }
+      send_state(D, on, r, p, o, c_edges, c_remote, c_filt);
+    }
   }
+  S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
   S.flush(D);
 }
 
@@ -1026,8 +1047,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         if (!have) break;
         uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
         if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
-          uint32_t pos = atomicAdd(&D.pp_cnt[(n.t + 1) & 1u], 1u);
-          if (pos < D.pp_cap) D.pp_list[(size_t)((n.t + 1) & 1u) * D.pp_cap + pos] = make_uint2((uint32_t)l, best.z);
+          uint32_t li = (n.t + 1) & 1u, sub = blockIdx.x % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
+          uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
+          if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
           else atomicOr(D.err, SW_ERR_PEND_OVF);
         }
         else if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
@@ -1126,7 +1148,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt
     *D.tick = t + 1;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
-    D.pp_cnt[t & 1u] = 0;                      // this tick's pull requests have been answered
+    for (uint32_t j = 0; j < SW_PP_LISTS; j++) D.pp_cnt[((t & 1u) * SW_PP_LISTS + j) * 16] = 0;   // answered
   }
 }
 __global__ void k_census_commit(SwDev D) {

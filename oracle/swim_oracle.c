@@ -725,10 +725,14 @@ static void phase_pushpull(swim_sim* s) {
     if (s->gt_alive[(size_t)r * s->N + p]) send_state(s, r, p, o);
   }
   rq->n = 0;
-  uint32_t per = s->d.push_pull_period_ticks;
-  if (!per) return;
+  /* stagger: node i is due in tick (i mod period), but exchanges start only on probe-interval boundaries
+   * (everything due within the next ProbeInterval goes now) — memberlist's own stagger is a random point
+   * of the whole interval, so second-granularity loses nothing and keeps most ticks free of this path */
+  uint32_t per = s->d.push_pull_period_ticks, grp = s->d.probe_period;
+  if (!per || s->tick % grp) return;
   for (uint32_t r = 0; r < s->R; r++)
-    for (uint64_t i64 = s->tick % per; i64 < s->N; i64 += per) {
+   for (uint32_t off = 0; off < grp && off < per; off++)
+    for (uint64_t i64 = (s->tick + off) % per; i64 < s->N; i64 += per) {
       uint32_t o = (uint32_t)i64, p;
       if (!is_local(s, o) || !s->gt_alive[(size_t)r * s->N + o]) continue;
       if (!k_random_nodes(s, r, o, STREAM_PUSHPULL, 1, excl_pushpull, NULL, &p)) continue;
