@@ -23,8 +23,8 @@
     }                                                                                               \
   } while (0)
 
-enum { PK_BEGIN = 0, PK_DELIVER, PK_ALLOC, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
-static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_alloc", "k_resolve", "k_census", "k_finish" };
+enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
+static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" };
 #define SW_GRAPH_TICKS 16
 
 struct swim_sim {
@@ -365,7 +365,6 @@ static void launch_end(swim_sim* s) {
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, D,
                        (const uint4*)s->in_buf, s->in_count);
   }
-  { ProfScope p(s, PK_ALLOC); hipLaunchKernelGGL(k_alloc, dim3(1), dim3(64), 0, st, D); }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, D); }
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
   { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }

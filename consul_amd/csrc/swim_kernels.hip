@@ -1,6 +1,6 @@
 // swim_kernels.hip — hand-written gfx950 kernels for the memberlist/serf SWIM hot path.
 //
-// One tick = six launches.  Everything is integer/byte work bounded by HBM bandwidth,
+// One tick = five launches.  Everything is integer/byte work bounded by HBM bandwidth,
 // random-access sector traffic and atomic throughput; there is no dense contraction, hence no MFMA.
 //
 //   k_begin    fused, role by block range:
@@ -9,7 +9,6 @@
 //                probe    probe()/probeNode for the probe-due set -> suspect{} records, slot requests
 //                gossip   kRandomNodes + GetBroadcasts per peer   -> edge lists bucketed by shard
 //   k_deliver  edge list -> per-node inbox rows (one returning atomic + one 16 B store per record)
-//   k_alloc    subject-slot requests, deterministic order
 //   k_resolve  per observer: canonical order, aliveNode/suspectNode/deadNode/handleUserEvent
 //   k_census   per dirty subject: how the live observers see it
 //   k_finish   first-suspect/first-dead/all-dead stamps, trace row, list recycling, tick++
@@ -757,13 +756,34 @@ static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
 // returning atomic on the row's count word reserves the slot; the record lands in the same 64-byte
 // line for the first three arrivals.  Slot requests are side-lined for k_alloc.
 // =================================================================================================
+// Give subject x of replica r a view-column slot.  Runs inside k_deliver (nobody reads slot bits there):
+// the first request to flip the node word's slot field to the "being granted" pattern wins, later
+// duplicates (other probers, other shards) see a non-zero field and leave.  Which index a subject gets is
+// not observable: everything the ABI reports is keyed by node id.
+__device__ void grant_slot(const SwDev& D, uint32_t r, uint32_t x) {
+  size_t g = (size_t)r * D.N + x;
+  uint32_t w = D.nw[g];
+  if (NW_HAS_SLOT(w)) return;
+  if (atomicCAS(&D.nw[g], w, w | 0xFFFFFFu) != w) return;
+  uint32_t sl = atomicAdd(&D.n_slots[r], 1u);
+  if (sl >= D.S) {
+    atomicSub(&D.n_slots[r], 1u); D.nw[g] = w;
+    atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull);
+    return;
+  }
+  size_t sidx = (size_t)r * D.S + sl;
+  D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
+  D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
+  D.nw[g] = w | (sl + 1);
+  // the replica's exception list: x may already be on it (a dead node has a non-zero word)
+  uint32_t n = D.exc_cnt[r]; bool listed = false;
+  for (uint32_t j = 0; j < n && j < SW_EXC_MAX; j++) listed |= D.exc_list[(size_t)r * SW_EXC_MAX + j] == x;
+  if (!listed) { uint32_t pos = atomicAdd(&D.exc_cnt[r], 1u); if (pos < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + pos] = x; }
+}
+
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
 __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, size_t& l) {
-  if (rec.x == NONE) {
-    uint32_t pos = atomicAdd(D.ctrl_cnt, 1u);
-    if (pos < D.ctrl_cap) D.ctrl[pos] = rec; else atomicOr(D.err, SW_ERR_CTRL_OVF);
-    return NONE;
-  }
+  if (rec.x == NONE) { grant_slot(D, rec.z, rec.y); return NONE; }     // subject-slot request
   uint32_t r = rec.x / D.N, x = rec.x % D.N;
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
   l = (size_t)r * D.nloc + (x - D.i0);
@@ -811,10 +831,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(SwDev D, const uint4*
   deliver_span(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 
-// =================================================================================================
-// k_alloc — give every requested subject a view-column slot, in (replica, id) order so that all
-// shards (and the oracle) number them identically.  Requests are rare: one thread.
-// =================================================================================================
+// host-side stimulus (leave/update) needs a slot before the tick: single-threaded variant
 __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
   uint32_t w = D.nw[g];
@@ -834,20 +851,6 @@ __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
     if (!listed) { if (n < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + n] = x; D.exc_cnt[r] = n + 1; }
   }
 }
-__global__ void k_alloc(SwDev D) {
-  if (threadIdx.x || blockIdx.x) return;
-  uint32_t n = *D.ctrl_cnt; if (n > D.ctrl_cap) n = D.ctrl_cap;
-  if (!n) return;
-  // insertion sort by (replica, id); duplicates collapse because alloc_slot is idempotent
-  for (uint32_t a = 1; a < n; a++) {
-    uint4 v = D.ctrl[a]; uint32_t b = a;
-    while (b && (D.ctrl[b - 1].z > v.z || (D.ctrl[b - 1].z == v.z && D.ctrl[b - 1].y > v.y))) { D.ctrl[b] = D.ctrl[b - 1]; b--; }
-    D.ctrl[b] = v;
-  }
-  for (uint32_t a = 0; a < n; a++) alloc_slot(D, D.ctrl[a].z, D.ctrl[a].y);
-  *D.ctrl_cnt = 0;
-}
-
 // =================================================================================================
 // k_resolve — handleAlive/handleSuspect/handleDead/handleUserEvent for everything that reached a
 // node this tick, applied in ascending (user?, subject, type, incarnation, from) order with
