@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--cpu-replicas", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
     args = ap.parse_args()
@@ -224,6 +225,25 @@ def main():
             rec = json.load(open(pmc)).get(dom)
             if rec and rec.get("workload_nodes") == reps * args.nodes:
                 line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+    if rank == 0 and not sharded and not args.no_convergence:
+        # second half of the metric: rounds to full convergence at N ~ 1e6 (BASELINE configs[2]:
+        # 1 048 576 nodes, DefaultWANConfig timers, one update rumour at node 0, fan-out sweep)
+        conv = {}
+        for k in (2, 3, 5):
+            c3 = Sim(hip, preset(hip, abi.PRESET_WAN, n_nodes=1 << 20, seed=args.seed, gossip_nodes=k,
+                                 trace_ticks=64, subject_cap=2, queue_cap=4, inbox_cap=32, device=local_rank))
+            c3.update(0, [0])
+            tc = time.perf_counter()
+            c3.step(45); c3.sync()
+            dtc = time.perf_counter() - tc
+            curve = [int(x) for x in c3.trace(0, 0, 0, 45)[:, 4]]
+            full = (1 << 20) - 1
+            conv[str(k)] = {"rounds_to_full_convergence": curve.index(full) + 1 if full in curve else None,
+                            "rounds_to_half": next(i + 1 for i, v in enumerate(curve) if v >= full // 2),
+                            "rounds_per_sec": 45 / dtc}
+            c3.close()
+        line["convergence"] = {"workload": "BASELINE configs[2]: 1048576 nodes, DefaultWANConfig, single rumour, k in {2,3,5}",
+                               "n_nodes": 1 << 20, "by_fanout": conv}
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         line["cpu_baseline"] = run_cpu_baseline(args, G)
     sys.stdout.flush()

@@ -46,11 +46,16 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 // a node in ONE random 4-byte read
 //   bit 31     the process is not running (ground truth)
 //   bits 30-24 partition group (ground truth)
-//   bits 23-0  subject slot + 1, 0 = nobody has news about it (every observer holds the base view)
+//   bit 23     attached: driven from outside through the transport bridge (peers see it alive, the
+//              simulator does not act for it, rumours sent to it are captured)
+//   bits 22-0  subject slot + 1, 0 = nobody has news about it (every observer holds the base view)
 #define NW_DEAD 0x80000000u
+#define NW_ATTACHED 0x00800000u
+#define NW_INERT (NW_DEAD | NW_ATTACHED)           /* the simulator takes no action on behalf of this node */
+#define NW_SLOT_MASK 0x7FFFFFu
 #define NW_PART(w) (((w) >> 24) & 0x7Fu)
-#define NW_SLOT(w) (((w) & 0xFFFFFFu) - 1u)       /* 0xFFFFFFFF when none */
-#define NW_HAS_SLOT(w) (((w) & 0xFFFFFFu) != 0u)
+#define NW_SLOT(w) (((w) & NW_SLOT_MASK) - 1u)     /* 0xFFFFFFFF when none */
+#define NW_HAS_SLOT(w) (((w) & NW_SLOT_MASK) != 0u)
 
 struct SwDev {
   // dimensions
@@ -127,6 +132,8 @@ struct SwDev {
   uint4* ctrl;           // slot requests seen this tick
   uint32_t* ctrl_cnt;
   uint32_t ctrl_cap;
+  // rumours sent to attached nodes (memberlist.Transport bridge): {sender, subject, incarnation, meta} + target
+  uint4* cap; uint32_t* cap_dst; uint32_t* cap_cnt; uint32_t cap_cap;
   // events, stats, errors
   swim_event* events;
   uint32_t* ev_cnt;

@@ -46,6 +46,9 @@ struct swim_sim {
   uint32_t out_counts[SW_MAX_SHARDS];  // host copy for swim_outbound
   bool out_counts_valid = false;
   std::vector<swim_event> pending_events;
+  std::vector<uint64_t> attached;                      // (replica << 32 | node) driven through the transport bridge
+  struct Captured { uint32_t gdst; swim_edge rec; };   // rec.dst = sender
+  std::vector<Captured> captured;
   // captured tick sequence: [0] one tick, [1] SW_GRAPH_TICKS ticks
   hipGraphExec_t graph_exec[2] = { nullptr, nullptr };
   bool use_graphs = true;
@@ -227,7 +230,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   int rc = swim_config_derive(cfg, &d);
   if (rc) return rc;
   if (!out) return SWIM_EINVAL;
-  if (cfg->n_shards > SW_MAX_SHARDS || cfg->subject_cap >= (1u << 24) - 1) return SWIM_ERANGE;
+  if (cfg->n_shards > SW_MAX_SHARDS || cfg->subject_cap >= NW_SLOT_MASK) return SWIM_ERANGE;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || (int)cfg->device >= ndev) return SWIM_ENODEV;
   swim_sim* s = new (std::nothrow) swim_sim();
@@ -304,6 +307,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.out_cnt, SW_MAX_SHARDS); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
   D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
+  D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
   s->scratch_bytes = 1 << 20; { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
   if (D.n_shards > 1) { s->in_cap = (uint32_t)e_cap; DALLOC(s, s->in_buf, s->in_cap); }
@@ -321,6 +325,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.pp_cnt, 0, 2 * SW_PP_LISTS * 16 * 4, st));
   HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
+  HIPCK(s, hipMemsetAsync(D.cap_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
   HIPCK(s, hipMemsetAsync(D.err, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.q, 0, NL * D.Q * sizeof(uint4), st));
@@ -771,8 +776,68 @@ extern "C" int swim_profile_read(swim_sim* s, swim_kernel_time* out, size_t cap,
   return SWIM_OK;
 }
 
-extern "C" int swim_transport_write_to(swim_sim*, uint32_t, uint32_t, uint32_t, const swim_edge*, size_t) { return SWIM_ESTATE; }
-extern "C" int swim_transport_poll(swim_sim*, uint32_t, uint32_t, swim_edge*, size_t, size_t* n) { if (n) *n = 0; return SWIM_ESTATE; }
+// memberlist.Transport bridge at rumour granularity (the msgpack codec is the host shim's job).  The first
+// call naming `a` attaches it: the simulator stops acting for it, peers keep seeing it alive.
+static int attach(swim_sim* s, uint32_t r, uint32_t a) {
+  if (!s) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->D.R || a >= s->D.N) return SWIM_ERANGE;
+  uint64_t key = ((uint64_t)r << 32) | a;
+  if (std::find(s->attached.begin(), s->attached.end(), key) != s->attached.end()) return SWIM_OK;
+  hipLaunchKernelGGL(k_attach, dim3(1), dim3(64), 0, s->stream, s->D, r, a);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  s->attached.push_back(key);
+  return SWIM_OK;
+}
+// Transport.WriteToAddress: a packet of n rumours from the attached node to a virtual peer; it is in the
+// peer's inbox at once and merged at the end of the next tick
+extern "C" int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, const swim_edge* m, size_t n) {
+  int rc = attach(s, r, a);
+  if (rc) return rc;
+  if (dst >= s->D.N || (!m && n) || n * sizeof(swim_edge) + n * 4 > s->scratch_bytes) return SWIM_EINVAL;
+  if (!n) return SWIM_OK;
+  std::vector<swim_edge> recs(m, m + n); std::vector<uint32_t> subj;
+  for (auto& e : recs) {
+    if ((e.meta >> 30) != SWIM_MSG_USER) { if (e.subject >= s->D.N) return SWIM_ERANGE; subj.push_back(e.subject); }
+    e.dst = r * s->D.N + dst;
+  }
+  uint8_t* scratch = (uint8_t*)s->d_scratch;
+  if (!subj.empty()) {            // a rumour about somebody new needs a view column first
+    HIPCK(s, hipMemcpyAsync(scratch, subj.data(), subj.size() * 4, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)scratch, (uint32_t)subj.size());
+  }
+  uint8_t* drec = scratch + ((subj.size() * 4 + 15) & ~(size_t)15);
+  HIPCK(s, hipMemcpyAsync(drec, recs.data(), n * sizeof(swim_edge), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_deliver_list, dim3(cdiv(n, SW_BLOCK * 4)), dim3(SW_BLOCK), 0, s->stream, s->D, (const uint4*)drec, (uint32_t)n);
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
+// Transport.PacketCh: rumours virtual peers sent to the attached node since the last poll; out[i].dst
+// carries the SENDER (Packet.From), SWIM_NONE when it is not a gossip packet
+extern "C" int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edge* o, size_t cap, size_t* n) {
+  int rc = attach(s, r, a);
+  if (rc) return rc;
+  if (!n || (!o && cap)) return SWIM_EINVAL;
+  uint32_t cnt = 0;
+  if ((rc = d2h(s, &cnt, (const uint32_t*)s->D.cap_cnt, 1))) return rc;
+  cnt = std::min(cnt, s->D.cap_cap);
+  if (cnt) {
+    std::vector<uint4> recs(cnt); std::vector<uint32_t> dsts(cnt);
+    if ((rc = d2h(s, recs.data(), (const uint4*)s->D.cap, cnt)) || (rc = d2h(s, dsts.data(), (const uint32_t*)s->D.cap_dst, cnt))) return rc;
+    HIPCK(s, hipMemsetAsync(s->D.cap_cnt, 0, 4, s->stream));
+    for (uint32_t i = 0; i < cnt; i++) s->captured.push_back({ dsts[i], { recs[i].x, recs[i].y, recs[i].z, recs[i].w } });
+  }
+  size_t w = 0; const uint32_t g = r * s->D.N + a;
+  std::vector<swim_sim::Captured> keep;
+  for (auto& c : s->captured) {
+    if (c.gdst == g && w < cap) o[w++] = c.rec;
+    else keep.push_back(c);
+  }
+  s->captured.swap(keep);
+  *n = w;
+  return SWIM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // known-answer hooks

@@ -142,6 +142,13 @@ __device__ __forceinline__ uint4 mk_edge(const SwDev& D, uint32_t r, uint32_t ds
   return make_uint4(r * D.N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu));
 }
 
+// memberlist.Transport bridge: a rumour for an attached node is handed to the host instead of an inbox
+__device__ __forceinline__ void capture(const SwDev& D, uint32_t src, uint32_t gdst, uint32_t subject, uint32_t inc, uint32_t meta) {
+  uint32_t pos = atomicAdd(D.cap_cnt, 1u);
+  if (pos < D.cap_cap) { D.cap[pos] = make_uint4(src, subject, inc, meta); D.cap_dst[pos] = gdst; }
+  else atomicOr(D.err, SW_ERR_EVENT_OVF);
+}
+
 // ---- stagger: which nodes act in tick t --------------------------------------------------------
 // chunk c = id / CH; gossip phase = c % G; probe phase = (c / G) % P.  Enumerate the active set
 // compactly: index a -> node id i (or NONE).  CH is a power of two.
@@ -236,7 +243,7 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
     if (__any(any_f)) {                             // rare: only now look at liveness and append
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        f[j] = f[j] && !(nw[D.i0 + kk[j]] & NW_DEAD);
+        f[j] = f[j] && !(nw[D.i0 + kk[j]] & NW_INERT);
         wave_append(D, D.rank, f[j], mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]));
         fired += (uint32_t)f[j];
       }
@@ -264,7 +271,7 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
       uint32_t l = list[e], r = l / D.nloc, k = l % D.nloc, i = D.i0 + k;
       const uint32_t* nw = D.nw + (size_t)r * D.N;
       uint32_t wi = nw[i];
-      if (wi & NW_DEAD) continue;
+      if (wi & NW_INERT) continue;
       uint2 h = D.ph[l]; uint4 p0 = D.pr0[l];
       if (p_stage(h.y) != 1 || p0.w + D.TQ != t) continue;
       uint32_t x = p0.x, wx = nw[x], peers[KMAX], pw[KMAX];
@@ -305,7 +312,7 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds
   uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
   size_t l = 0;
   uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
-  if (!(wi & NW_DEAD)) {
+  if (!(wi & NW_INERT)) {
     uint32_t k = i - D.i0; l = (size_t)r * D.nloc + k;
     uint2 h = D.ph[l], h0 = h;
     uint32_t aw = p_aw(h.y), stage = p_stage(h.y), nackm = p_nackm(h.y), epoch = p_epoch(h.y), cursor = h.x;
@@ -481,7 +488,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
     wi = nw[i]; h = D.hdr[l];
   }
 
-  if (!(wi & NW_DEAD)) {
+  if (!(wi & NW_INERT)) {
     uint32_t k = i - D.i0;
     qlen = h_qlen(h.y); evqlen = h_evqlen(h.y);
     if (!qlen && !evqlen) quiet = true;
@@ -554,6 +561,11 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
       for (uint32_t p = 0; p < npk; p++) {
         uint32_t tm = sent_m[p], te = SERF ? sent_e[p] : 0;
         if (!ok[p] || !(tm | te)) continue;
+        if (pw[p] & NW_ATTACHED) {                   // Transport.WriteTo towards the real node
+          for (uint32_t m = tm; m; m &= m - 1) { uint4 e = sq[(__ffs(m) - 1) * SW_BLOCK]; capture(D, i, r * D.N + peers[p], e.x, e.y, (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu)); }
+          if (SERF) for (uint32_t m = te; m; m &= m - 1) { uint4 e = se[(__ffs(m) - 1) * SW_BLOCK]; capture(D, i, r * D.N + peers[p], e.x, e.y, (uint32_t)SWIM_MSG_USER << 30); }
+          continue;
+        }
         sent_m[np] = tm; peers[np] = peers[p];
         if (SERF) sent_e[np] = te;
         if (MULTI) psh[np] = peers[p] / D.nloc;
@@ -626,7 +638,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   }
   // dead nodes keep their (frozen) queues: the hint stays up while any node of the block holds one
   bool holds = (nq | ne) != 0;
-  if (i != NONE && (wi & NW_DEAD) && D.fast_blocks) holds = (h_qlen(h.y) | h_evqlen(h.y)) != 0;
+  if (i != NONE && (wi & NW_INERT) && D.fast_blocks) holds = (h_qlen(h.y) | h_evqlen(h.y)) != 0;
   int any = __syncthreads_or(holds);
   if (threadIdx.x == 0) {
     if (fb != NONE && !any) D.q_any[fb] = 0;
@@ -685,7 +697,7 @@ __device__ void role_pushpull(const SwDev& D, uint32_t r, uint32_t a, uint32_t* 
     o = (uint32_t)i64;
     if (o >= D.i0 && o < D.i0 + D.nloc) {
       uint32_t wo = nw[o], wp;
-      if (!(wo & NW_DEAD) && k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X))
+      if (!(wo & NW_INERT) && k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X))
         go = !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp);          // else the TCP dial fails
     }
   }
@@ -712,7 +724,7 @@ __device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
       if (on) {
         uint2 rq = D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + e];
         r = rq.x / D.nloc; p = D.i0 + rq.x % D.nloc; o = rq.y;
-        on = !(D.nw[(size_t)r * D.N + p] & NW_DEAD);
+        on = !(D.nw[(size_t)r * D.N + p] & NW_INERT);
       }
       send_state(D, on, r, p, o, c_edges, c_remote, c_filt);
     }
@@ -764,7 +776,7 @@ __device__ void grant_slot(const SwDev& D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
   uint32_t w = D.nw[g];
   if (NW_HAS_SLOT(w)) return;
-  if (atomicCAS(&D.nw[g], w, w | 0xFFFFFFu) != w) return;
+  if (atomicCAS(&D.nw[g], w, w | NW_SLOT_MASK) != w) return;
   uint32_t sl = atomicAdd(&D.n_slots[r], 1u);
   if (sl >= D.S) {
     atomicSub(&D.n_slots[r], 1u); D.nw[g] = w;
@@ -786,6 +798,9 @@ __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, siz
   if (rec.x == NONE) { grant_slot(D, rec.z, rec.y); return NONE; }     // subject-slot request
   uint32_t r = rec.x / D.N, x = rec.x % D.N;
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
+  uint32_t w = D.nw[rec.x];
+  if (w & NW_DEAD) return NONE;                    // e.g. a push-pull reply to a requester that died meanwhile
+  if (w & NW_ATTACHED) { capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
   l = (size_t)r * D.nloc + (x - D.i0);
   return atomicAdd(&D.inbox1[l * 16], 1u);
 }
@@ -1247,6 +1262,16 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
+}
+__global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
+  if (threadIdx.x || blockIdx.x) return;
+  size_t g = (size_t)r * D.N + x;
+  uint32_t old = atomicOr(&D.nw[g], NW_ATTACHED);
+  bool local = x >= D.i0 && x < D.i0 + D.nloc;
+  if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
+    size_t l = (size_t)r * D.nloc + (x - D.i0);
+    uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.inbox1[l * 16] = 0;
+  }
 }
 __global__ void k_set_partition(SwDev D, uint32_t r, const uint8_t* group) {
   uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;

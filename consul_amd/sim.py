@@ -232,6 +232,23 @@ class Sim:
                 self._h, arr.ctypes.data_as(C.POINTER(abi.Edge)), n, C.byref(cnt)))
         return np.sort(arr, order=["dst", "subject", "meta", "incarnation"])
 
+    # -- memberlist.Transport bridge (rumour granularity) ------------------------------------------
+    def transport_write_to(self, replica: int, attached: int, dst: int, msgs):
+        """Transport.WriteToAddress: `msgs` = iterable of (subject, incarnation, type, from)."""
+        msgs = list(msgs)
+        buf = (abi.Edge * max(len(msgs), 1))()
+        for i, (subject, inc, typ, frm) in enumerate(msgs):
+            buf[i] = abi.Edge(0, subject, inc, (typ << 30) | (frm & 0x3FFFFFFF))
+        self._ck("swim_transport_write_to",
+                 self._l.swim_transport_write_to(self._h, replica, attached, dst, buf, len(msgs)))
+
+    def transport_poll(self, replica: int, attached: int, cap: int = 4096):
+        """Transport.PacketCh: sorted list of (sender, subject, incarnation, type, from)."""
+        buf = (abi.Edge * cap)()
+        n = C.c_size_t()
+        self._ck("swim_transport_poll", self._l.swim_transport_poll(self._h, replica, attached, buf, cap, C.byref(n)))
+        return sorted((e.dst, e.subject, e.incarnation, e.meta >> 30, e.meta & 0x3FFFFFFF) for e in buf[: n.value])
+
     def profile(self, enable: bool = True):
         self._ck("swim_profile", self._l.swim_profile(self._h, int(enable)))
 

@@ -265,6 +265,9 @@ struct swim_sim {
   swim_config cfg; swim_derived d;
   uint32_t N, R, nloc, i0, tick; int in_tick;
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
+  uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
+  edgevec captured;              /* rumours sent to attached nodes: {dst = replica*N+attached, ..}, src kept in cap_src */
+  uint32_t* cap_src; uint32_t cap_src_cap;
   uint32_t* node_slot;           /* [R*N] replicated */
   node_t* nodes;                 /* [R*nloc] */
   qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous */
@@ -289,6 +292,8 @@ static inline uint64_t seed_of(const swim_sim* s, uint32_t r) { return s->cfg.se
 static inline int is_local(const swim_sim* s, uint32_t i) { return i >= s->i0 && i < s->i0 + s->nloc; }
 static inline node_t* node_at(swim_sim* s, uint32_t r, uint32_t i) { return &s->nodes[(size_t)r * s->nloc + (i - s->i0)]; }
 static inline uint32_t shard_of(const swim_sim* s, uint32_t i) { return i / s->nloc; }
+/* does the simulator act for this node (running and not driven from outside) */
+static inline int acts(const swim_sim* s, uint32_t r, uint32_t i) { size_t g = (size_t)r * s->N + i; return s->gt_alive[g] && !s->attached[g]; }
 static inline uint32_t gphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk) % s->d.gossip_period; }
 static inline uint32_t pphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk / s->d.gossip_period) % s->d.probe_period; }
 
@@ -528,10 +533,19 @@ static swim_edge mk_edge(const swim_sim* s, uint32_t r, uint32_t dst, uint32_t s
   swim_edge e = { r * s->N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu) };
   return e;
 }
-static void emit(swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+static void emit_from(swim_sim* s, uint32_t src, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+  if (s->attached[(size_t)r * s->N + dst]) {            /* memberlist.Transport: hand the packet to the real node */
+    if (s->captured.n == s->cap_src_cap) { s->cap_src_cap = s->cap_src_cap ? s->cap_src_cap * 2 : 1024; s->cap_src = (uint32_t*)realloc(s->cap_src, (size_t)s->cap_src_cap * 4); }
+    s->cap_src[s->captured.n] = src;
+    ev_push(&s->captured, mk_edge(s, r, dst, subject, inc, type, from));
+    return;
+  }
   uint32_t sh = shard_of(s, dst);
   ev_push(&s->out[sh], mk_edge(s, r, dst, subject, inc, type, from));
   s->st.edges++; if (sh != s->cfg.shard_rank) s->st.edges_remote++;
+}
+static void emit(swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+  emit_from(s, SWIM_NONE, r, dst, subject, inc, type, from);
 }
 static void emit_slot_request(swim_sim* s, uint32_t r, uint32_t x) {
   swim_edge e = { SWIM_NONE, x, r, 0 };
@@ -561,7 +575,7 @@ static void phase_expire(swim_sim* s) {
       if (!t->susp_count || now < t->min_deadline) continue;
       for (uint32_t k = 0; k < s->nloc; k++) {
         view_t* v = &t->col[k]; uint32_t o = s->i0 + k;
-        if (KST(v->key) != SWIM_STATE_SUSPECT || !s->gt_alive[(size_t)r * s->N + o]) continue;
+        if (KST(v->key) != SWIM_STATE_SUSPECT || !acts(s, r, o)) continue;
         if (now >= v->since + s->d.suspicion_timeout_ms[v->nconf]) {
           emit(s, r, o, t->node, KINC(v->key), SWIM_MSG_DEAD, o);
           s->st.suspicion_timeouts++;
@@ -660,14 +674,14 @@ static void phase_probe(swim_sim* s) {
       uint32_t ph = (t - TQ) % P;
       for (uint32_t k = 0; k < s->nloc; k++) {
         uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
-        if (pphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+        if (pphase_of(s, o) != ph || !acts(s, r, o)) continue;
         if (nd->pr_stage == 1 && nd->pr_t0 + TQ == t) probe_indirect(s, r, o, nd);
       }
     }
     uint32_t ph = t % P;
     for (uint32_t k = 0; k < s->nloc; k++) {
       uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
-      if (pphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (pphase_of(s, o) != ph || !acts(s, r, o)) continue;
       if (nd->pr_stage != 0) { if (t < nd->pr_deadline) continue; probe_conclude(s, r, o, nd); }
       probe_start(s, r, o, nd);
     }
@@ -722,7 +736,7 @@ static void phase_pushpull(swim_sim* s) {
   edgevec* rq = &s->pp_reply[s->tick & 1];
   for (uint32_t i = 0; i < rq->n; i++) {
     uint32_t r = rq->v[i].incarnation, p = rq->v[i].dst, o = rq->v[i].subject;
-    if (s->gt_alive[(size_t)r * s->N + p]) send_state(s, r, p, o);
+    if (acts(s, r, p)) send_state(s, r, p, o);
   }
   rq->n = 0;
   /* stagger: node i is due in tick (i mod period), but exchanges start only on probe-interval boundaries
@@ -734,7 +748,7 @@ static void phase_pushpull(swim_sim* s) {
    for (uint32_t off = 0; off < grp && off < per; off++)
     for (uint64_t i64 = (s->tick + off) % per; i64 < s->N; i64 += per) {
       uint32_t o = (uint32_t)i64, p;
-      if (!is_local(s, o) || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (!is_local(s, o) || !acts(s, r, o)) continue;
       if (!k_random_nodes(s, r, o, STREAM_PUSHPULL, 1, excl_pushpull, NULL, &p)) continue;
       size_t base = (size_t)r * s->N;
       if (!s->gt_alive[base + p] || s->part[base + o] != s->part[base + p]) continue;   /* TCP dial fails */
@@ -751,7 +765,7 @@ static void phase_gossip(swim_sim* s) {
   for (uint32_t r = 0; r < s->R; r++)
     for (uint32_t k = 0; k < s->nloc; k++) {
       uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
-      if (gphase_of(s, o) != ph || !s->gt_alive[(size_t)r * s->N + o]) continue;
+      if (gphase_of(s, o) != ph || !acts(s, r, o)) continue;
       if (!nd->qlen && !nd->evqlen) { s->st.node_rounds_quiescent++; continue; }
       s->st.node_rounds_active++;
       uint32_t peers[8], np = k_random_nodes(s, r, o, STREAM_GOSSIP, s->cfg.gossip_nodes, excl_gossip, NULL, peers);
@@ -766,7 +780,7 @@ static void phase_gossip(swim_sim* s) {
         if (!reach(s, r, o, peers[p], o, p)) { s->st.packets_dropped++; continue; }
         for (uint32_t m = 0; m < n; m++) {
           if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, peers[p], &msgs[m])) { s->st.msgs_filtered++; continue; }
-          emit(s, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+          emit_from(s, o, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
         }
       }
     }
@@ -806,6 +820,7 @@ static void phase_deliver_resolve(swim_sim* s) {
     swim_edge e = s->in.v[i]; if (e.dst == SWIM_NONE) continue;
     uint32_t r = e.dst / s->N, x = e.dst % s->N;
     if (!is_local(s, x) || !s->gt_alive[e.dst]) continue;
+    if (s->attached[e.dst]) { emit_from(s, SWIM_NONE, r, x, e.subject, e.incarnation, e.meta >> 30, e.meta & 0x3FFFFFFFu); continue; }
     node_t* nd = node_at(s, r, x);
     if (nd->in_cnt >= s->cfg.inbox_cap) { s->st.inbox_overflow++; continue; }
     nd->inbox[nd->in_cnt++] = e;
@@ -879,11 +894,11 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   s->cfg = *cfg; s->d = d; s->N = cfg->n_nodes; s->R = cfg->n_replicas;
   s->nloc = s->N / cfg->n_shards; s->i0 = cfg->shard_rank * s->nloc; s->loss_q32 = cfg->loss_q32;
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
-  s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1);
+  s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1);
   s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
   s->slots = (slot_t*)calloc((size_t)s->R * cfg->subject_cap, sizeof(slot_t));
   s->n_slots = (uint32_t*)calloc(s->R, 4); s->out = (edgevec*)calloc(cfg->n_shards, sizeof(edgevec));
-  if (!s->gt_alive || !s->part || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out) { swim_destroy(s); return SWIM_ENOMEM; }
+  if (!s->gt_alive || !s->part || !s->attached || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out) { swim_destroy(s); return SWIM_ENOMEM; }
   memset(s->gt_alive, 1, NT); memset(s->node_slot, 0xFF, NT * 4);
   s->q_slab = (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
   s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
@@ -907,6 +922,7 @@ int swim_destroy(swim_sim* s) {
   free(s->inbox_slab);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) { free(s->slots[i].col); free(s->slots[i].trace); }
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
+  free(s->attached); free(s->captured.v); free(s->cap_src);
   free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->events); free(s);
@@ -1144,11 +1160,42 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
   *out = d; return SWIM_OK;
 }
 
-int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, const swim_edge* m, size_t n) {
-  (void)s; (void)r; (void)a; (void)dst; (void)m; (void)n; return SWIM_ESTATE;
+/* memberlist.Transport bridge at rumour granularity (the msgpack codec is the host shim's job).
+ * The first call naming `a` attaches it: the simulator stops acting for it, peers keep seeing it alive. */
+static int attach(swim_sim* s, uint32_t r, uint32_t a) {
+  if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->R || a >= s->N) return SWIM_ERANGE;
+  s->attached[(size_t)r * s->N + a] = 1;
+  return SWIM_OK;
 }
+/* Transport.WriteToAddress: a packet of n rumours from the attached node to a virtual peer; it is in the
+ * peer's inbox at once and merged at the end of the next tick */
+int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, const swim_edge* m, size_t n) {
+  int rc = attach(s, r, a); if (rc) return rc;
+  if (dst >= s->N || (!m && n)) return SWIM_EINVAL;
+  for (size_t i = 0; i < n; i++)                       /* a rumour about somebody new needs a view column first */
+    if ((m[i].meta >> 30) != SWIM_MSG_USER) { if (m[i].subject >= s->N) return SWIM_ERANGE; alloc_slot(s, r, m[i].subject); }
+  if (!is_local(s, dst) || !s->gt_alive[(size_t)r * s->N + dst] || s->attached[(size_t)r * s->N + dst]) return SWIM_OK;
+  node_t* nd = node_at(s, r, dst);
+  for (size_t i = 0; i < n; i++) {
+    if (nd->in_cnt >= s->cfg.inbox_cap) { s->st.inbox_overflow++; continue; }
+    swim_edge e = { r * s->N + dst, m[i].subject, m[i].incarnation, m[i].meta };
+    nd->inbox[nd->in_cnt++] = e;
+  }
+  return SWIM_OK;
+}
+/* Transport.PacketCh: rumours virtual peers sent to the attached node since the last poll; out[i].dst
+ * carries the SENDER (Packet.From), SWIM_NONE when it is not a gossip packet */
 int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edge* o, size_t cap, size_t* n) {
-  (void)s; (void)r; (void)a; (void)o; (void)cap; if (n) *n = 0; return SWIM_ESTATE;
+  int rc = attach(s, r, a); if (rc) return rc;
+  if (!n || (!o && cap)) return SWIM_EINVAL;
+  size_t w = 0, keep = 0; uint32_t g = r * s->N + a;
+  for (uint32_t i = 0; i < s->captured.n; i++) {
+    if (s->captured.v[i].dst == g && w < cap) { o[w] = s->captured.v[i]; o[w].dst = s->cap_src[i]; w++; }
+    else { s->captured.v[keep] = s->captured.v[i]; s->cap_src[keep] = s->cap_src[i]; keep++; }
+  }
+  s->captured.n = (uint32_t)keep; *n = w;
+  return SWIM_OK;
 }
 
 int swim_profile(swim_sim* s, int enable) { (void)enable; return s ? SWIM_OK : SWIM_EINVAL; }
