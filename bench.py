@@ -15,7 +15,8 @@ with N so per-GPU work is fixed (weak scaling).
 
 One JSON line on stdout (rank 0).  `roofline` is for the kernel that dominates the timed region,
 timed with HIP events on the simulator's stream in a second, instrumented pass of the same region;
-`cpu_baseline` is the plain-C oracle on one host core on a bounded sample of the same workload.
+`cpu_baseline` is the plain-C oracle on the host cores (one replica per thread) on a bounded sample of
+the same workload.
 """
 from __future__ import annotations
 
@@ -70,24 +71,41 @@ def diff_stats(a: dict, b: dict) -> dict:
 
 
 def run_cpu_baseline(args, ticks_per_round: int) -> dict:
-    """The oracle (a scalar C port, 1 thread) on a bounded sample: `cpu_replicas` replicas."""
+    """The oracle (a scalar C port) on a bounded sample: `cpu_replicas` replicas, one per host thread.
+
+    Replica r of seed s is by construction replica 0 of seed s+r, so each thread owns an independent
+    one-replica handle (ctypes drops the GIL during swim_step) and the sample is the same scenario as
+    the first `cpu_replicas` replicas of the GPU run.
+    """
+    from concurrent.futures import ThreadPoolExecutor
     so = os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")
     if not os.path.exists(so):
         import __graft_entry__
         __graft_entry__.build_oracle()
     ora = abi.bind(C.CDLL(so))
     reps = args.cpu_replicas
-    s = Sim(ora, preset(ora, abi.PRESET_LAN, n_nodes=args.nodes, n_replicas=reps, seed=args.seed,
-                        subject_cap=args.subject_cap, gossip_nodes=args.fanout))
-    s.step(args.warmup * ticks_per_round)
-    for r, v in enumerate(victims_for(args.seed, reps, args.nodes)):
-        s.kill(r, [v])
-    t0 = time.perf_counter()
-    s.step(args.steps * ticks_per_round)
-    dt = time.perf_counter() - t0
-    return {"value": reps * args.nodes * args.steps / dt, "unit": "node-rounds/s", "cores": 1, "kind": "port",
+    cores = max(1, min(reps, os.cpu_count() or 1, args.cpu_threads or (os.cpu_count() or 1)))
+    victims = victims_for(args.seed, reps, args.nodes)
+    sims = [Sim(ora, preset(ora, abi.PRESET_LAN, n_nodes=args.nodes, n_replicas=1, seed=args.seed + r,
+                            subject_cap=args.subject_cap, gossip_nodes=args.fanout)) for r in range(reps)]
+
+    def prep(r):
+        sims[r].step(args.warmup * ticks_per_round)
+        sims[r].kill(0, [victims[r]])
+
+    def timed(r):
+        sims[r].step(args.steps * ticks_per_round)
+
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(prep, range(reps)))
+        t0 = time.perf_counter()
+        list(ex.map(timed, range(reps)))
+        dt = time.perf_counter() - t0
+    for s in sims:
+        s.close()
+    return {"value": reps * args.nodes * args.steps / dt, "unit": "node-rounds/s", "cores": cores, "kind": "port",
             "sample": f"{reps} of the replicas x {args.nodes} nodes x {args.steps} rounds, same scenario, "
-                      f"{dt:.1f} s on 1 host core of {os.cpu_count()}"}
+                      f"{dt:.1f} s wall on {cores} host threads of {os.cpu_count()}"}
 
 
 def main():
@@ -100,7 +118,8 @@ def main():
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--subject-cap", type=int, default=4)
-    ap.add_argument("--cpu-replicas", type=int, default=8)
+    ap.add_argument("--cpu-replicas", type=int, default=32, help="replicas the CPU baseline runs (32 = the whole workload)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true")
