@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NONE = 0xFFFFFFFF
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE = 0, -22, -12, -19, -34, -75, -71
@@ -21,8 +21,9 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
 (EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
-F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP = 0x1, 0x2, 0x4, 0x8
-F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK = 0x1, 0x2, 0x4, 0x8, 0x10
+F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK
+SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
 
 u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
 
@@ -33,7 +34,7 @@ class Config(C.Structure):
         "gossip_nodes", "gossip_interval_ms", "probe_interval_ms", "probe_timeout_ms",
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
-        ("msg_len", u32 * 4)] + [(n, u32) for n in (
+        ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
         "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device")] + [("seed", u64)]
@@ -88,7 +89,8 @@ class Stats(C.Structure):
                 ("confirmations", u64), ("edges", u64), ("edges_remote", u64),
                 ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
                 ("event_drops", u64), ("user_events_delivered", u64),
-                ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64)]
+                ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
+                ("piggybacks", u64), ("msgs_piggybacked", u64)]
 
 
 class KernelTime(C.Structure):
@@ -112,6 +114,8 @@ PROTOTYPES = {
     "swim_tick_begin": (C.c_int, [SimP]),
     "swim_outbound": (C.c_int, [SimP, u32, P(C.c_void_p), P(u32)]),
     "swim_outbound_capacity": (u32, [SimP, u32]),
+    "swim_peer_activity": (C.c_int, [SimP, C.c_int]),
+    "swim_activity": (C.c_int, [SimP, C.POINTER(C.c_int)]),
     "swim_stream": (C.c_int, [SimP, P(C.c_void_p)]),
     "swim_outbound_raw": (C.c_int, [SimP, u32, P(C.c_void_p), P(C.c_void_p)]),
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),

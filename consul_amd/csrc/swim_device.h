@@ -22,14 +22,15 @@ enum {
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
+  ST_PIGGY, ST_PIGGY_MSGS,
   ST_COUNT
 };
 
-// The stats row is replicated SW_STAT_COPIES times, one 256-byte line each, and a block adds into
+// The stats row is replicated SW_STAT_COPIES times, 384 bytes each, and a block adds into
 // copy (block id % copies): same-address device atomics serialise at ~12 ns apiece, which at a few
 // thousand blocks per launch would cost more than the kernel itself.  The host sums the copies.
 #define SW_STAT_COPIES 256
-#define SW_STAT_STRIDE 32
+#define SW_STAT_STRIDE 48
 
 // sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync)
 #define SW_ERR_EDGE_OVF 0x1u
@@ -38,6 +39,7 @@ enum {
 #define SW_ERR_CTRL_OVF 0x8u
 #define SW_ERR_EVENT_OVF 0x10u
 #define SW_ERR_PEND_OVF 0x20u
+#define SW_ERR_CARRY_OVF 0x40u
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
 enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
@@ -64,6 +66,7 @@ struct SwDev {
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
   uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks, pp_period;
   uint32_t msg_len[4];
+  uint32_t ctl_len[4];
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
   uint32_t ablate;   // SWIMSIM_ABLATE env: timing experiments only (results invalid); 0 in normal use
@@ -125,7 +128,14 @@ struct SwDev {
   uint4* seg;
   uint32_t* seg_cnt;     // [n_seg] consumed and zeroed by k_deliver
   uint32_t* seg_last;    // [n_seg] what k_deliver consumed in the most recent tick (swim_debug_edges)
-  uint32_t seg_cap, n_seg, nb_gossip;
+  uint32_t seg_cap, n_seg, nb_gossip, nb_probe;   // segments: R*nb_gossip gossip blocks, then R*nb_probe probe blocks
+  // SWIM_F_PIGGYBACK: broadcasts a node piggy-backs on its pings/acks are picked by k_resolve in tick t into
+  // the private area of its block, carry[(t+1)&1][block][carry_cap], and delivered by k_deliver of tick t+1
+  uint4* carry;
+  uint32_t* carry_cnt;   // [2][NB] consumed and zeroed by k_deliver
+  uint32_t* carry_last;  // [NB] what k_deliver consumed in the most recent tick (swim_debug_edges)
+  uint32_t carry_cap, NB, nb_carry;
+  uint32_t* act;         // [1] sharded runs: this shard may hold a non-empty broadcast queue / emitted something
   uint4* out[SW_MAX_SHARDS];
   uint32_t* out_cnt;     // [n_shards]
   uint32_t out_cap[SW_MAX_SHARDS];
@@ -150,8 +160,11 @@ struct BeginPlan {
   uint32_t nb_gossip;        // per replica: blocks over the gossip-due node set
   uint32_t nb_pp;            // per replica: blocks over the push-pull-due node set (0 = push-pull off)
   uint32_t nb_ppreply;       // blocks answering the previous tick's pull requests
-  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull
+  uint32_t nb_carry;         // sharded runs: blocks moving carried broadcasts for other shards into their lists
+  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry
+  uint32_t peer_active;      // 0 = the caller vouches that no node of any OTHER shard has anything queued
 };
+#define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard */
 
 #define SW_KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
 #define SW_KINC(k) ((k) >> 2)

@@ -43,7 +43,8 @@ struct swim_sim {
   size_t scratch_bytes = 0;
   uint4* in_buf = nullptr;             // records received from other shards
   uint32_t in_cap = 0, in_count = 0;
-  uint32_t out_counts[SW_MAX_SHARDS];  // host copy for swim_outbound
+  uint32_t out_counts[SW_MAX_SHARDS + 1];  // host copy for swim_outbound / swim_activity (counts, then the activity word)
+  bool force_active = false;           // a host-side stimulus since the last tick: ignore the peer-activity hint once
   bool out_counts_valid = false;
   std::vector<swim_event> pending_events;
   std::vector<uint64_t> attached;                      // (replica << 32 | node) driven through the transport bridge
@@ -138,6 +139,8 @@ extern "C" int swim_config_preset(swim_config* c, int preset) {
   }
   c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
   c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
+  // ping / indirectPingReq / ackResp (serf puts a coordinate in Payload) / nackResp, msgpack with field names
+  c->ctl_len[SWIM_CTL_PING] = 86; c->ctl_len[SWIM_CTL_INDIRECT] = 122; c->ctl_len[SWIM_CTL_ACK] = 108; c->ctl_len[SWIM_CTL_NACK] = 13;
   c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
@@ -251,7 +254,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.watch = cfg->watch_node; D.trace_ticks = cfg->trace_ticks; D.n_shards = cfg->n_shards; D.rank = cfg->shard_rank;
   D.fast_blocks = (D.CH == SW_BLOCK && D.nloc % SW_BLOCK == 0) ? 1u : 0u;
   D.pp_period = d.push_pull_period_ticks;
-  for (int i = 0; i < 4; i++) D.msg_len[i] = cfg->msg_len[i];
+  for (int i = 0; i < 4; i++) { D.msg_len[i] = cfg->msg_len[i]; D.ctl_len[i] = cfg->ctl_len[i]; }
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
   if (const char* ab = getenv("SWIMSIM_ABLATE")) D.ablate = (uint32_t)strtoul(ab, nullptr, 0);
@@ -286,6 +289,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_pp = D.pp_period ? cdiv((uint64_t)cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period), SW_BLOCK) : 0;
   pl.nb_ppreply = D.pp_period ? 4 : 0;
   pl.roles = D.pp_period ? 0x1F : 0xF;
+  const bool piggy = (cfg->flags & SWIM_F_PIGGYBACK) != 0;
+  pl.nb_carry = D.n_shards > 1 ? 64 : 0;
+  if (piggy && D.n_shards > 1) pl.roles |= 0x20;
+  pl.peer_active = 1;
   D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0);
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
@@ -294,7 +301,17 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
   const uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
-  D.nb_gossip = pl.nb_gossip; D.n_seg = D.R * pl.nb_gossip; D.seg_cap = SW_BLOCK * D.k_gossip * per_pkt;
+  D.nb_gossip = pl.nb_gossip; D.nb_probe = pl.nb_probe; D.n_seg = D.R * (pl.nb_gossip + pl.nb_probe);
+  D.seg_cap = std::max<uint32_t>(SW_BLOCK * D.k_gossip * per_pkt, 2 * SW_BLOCK);   // a probe block files <= 2 orders per lane
+  {   // carry areas: one per k_resolve block; a probe-due chunk is exactly one block, so all 256 nodes may answer
+      // their own ping's order in the same tick, plus the acks and indirect legs they serve
+    uint32_t min_len = std::min(std::min(cfg->msg_len[0], cfg->msg_len[1]), cfg->msg_len[2]) + 2;
+    if (serf) min_len = std::min(min_len, cfg->msg_len[3] + 3);
+    const uint32_t fit = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / std::max(1u, min_len)));
+    D.NB = (uint32_t)NB; D.carry_cap = piggy ? 2 * SW_BLOCK * fit : 1;
+    D.nb_carry = piggy ? std::max<uint32_t>(std::min<uint32_t>(D.NB, 512), cdiv(D.NB, SW_BLOCK)) : 0;
+    DALLOC(s, D.carry, piggy ? (size_t)2 * NB * D.carry_cap : 1); DALLOC(s, D.carry_cnt, 2 * NB); DALLOC(s, D.carry_last, NB);
+  }
   uint64_t e_cap = (uint64_t)D.n_seg * D.seg_cap;
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
   DALLOC(s, D.seg, e_cap); DALLOC(s, D.seg_cnt, D.n_seg); DALLOC(s, D.seg_last, D.n_seg);
@@ -304,7 +321,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     D.out_cap[sh] = (uint32_t)cap;
     DALLOC(s, D.out[sh], cap);
   }
-  DALLOC(s, D.out_cnt, SW_MAX_SHARDS); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
+  DALLOC(s, D.out_cnt, SW_MAX_SHARDS + 1); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
+  D.act = D.out_cnt + D.n_shards;                  // rides behind the counts so one gather fetches both
   D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
@@ -317,7 +335,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.nw, 0, NT * 4, st));
   HIPCK(s, hipMemsetAsync(D.exc_cnt, 0, D.R * 4, st)); HIPCK(s, hipMemsetAsync(D.exc_dirty, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
-  HIPCK(s, hipMemsetAsync(D.out_cnt, 0, SW_MAX_SHARDS * 4, st));
+  HIPCK(s, hipMemsetAsync(D.out_cnt, 0, (SW_MAX_SHARDS + 1) * 4, st));
+  HIPCK(s, hipMemsetAsync(D.carry_cnt, 0, 2 * NB * 4, st)); HIPCK(s, hipMemsetAsync(D.carry_last, 0, NB * 4, st));
   HIPCK(s, hipMemsetAsync(D.seg_cnt, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(D.seg_last, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
@@ -348,9 +367,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 // ---------------------------------------------------------------------------------------------
 static void launch_begin(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
-  const BeginPlan& pl = s->plan;
+  BeginPlan pl = s->plan;
+  if (s->force_active) { pl.peer_active = 1; s->force_active = false; }
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
-  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + D.R * pl.nb_pp;
+  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + D.R * pl.nb_pp;
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
@@ -364,7 +384,7 @@ static void launch_begin(swim_sim* s) {
 static void launch_end(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, D); }
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + D.nb_carry + 32), dim3(SW_BLOCK), 0, st, D); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, D,
@@ -389,10 +409,10 @@ static int check_device_errors(swim_sim* s) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   HIPCK(s, hipGetLastError());
   if (e) {
-    snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s%s",
+    snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s%s%s",
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
              e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
-             e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "");
+             e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "", e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : "");
     return SWIM_EOVERFLOW;
   }
   return SWIM_OK;
@@ -409,7 +429,7 @@ extern "C" int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr,
   if (!s || !ptr || !count || shard >= s->cfg.n_shards) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
   if (!s->out_counts_valid) {
-    HIPCK(s, hipMemcpyAsync(s->out_counts, s->D.out_cnt, SW_MAX_SHARDS * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCK(s, hipMemcpyAsync(s->out_counts, s->D.out_cnt, (SW_MAX_SHARDS + 1) * 4, hipMemcpyDeviceToHost, s->stream));
     HIPCK(s, hipStreamSynchronize(s->stream));
     s->out_counts_valid = true;
   }
@@ -428,6 +448,28 @@ extern "C" int swim_outbound_raw(swim_sim* s, uint32_t shard, const swim_edge** 
   if (seg) *seg = (const swim_edge*)s->D.out[shard];
   if (cnt) *cnt = s->D.out_cnt;
   return SWIM_OK;
+}
+extern "C" int swim_peer_activity(swim_sim* s, int active) {
+  if (!s) return SWIM_EINVAL;
+  s->plan.peer_active = active ? 1u : 0u;          // read by the next swim_tick_begin
+  return SWIM_OK;
+}
+extern "C" int swim_activity(swim_sim* s, int* active) {
+  if (!s || !active) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  const swim_edge* p; uint32_t c;
+  int rc = swim_outbound(s, 0, &p, &c);             // (re)uses the tick's one copy of the counters
+  if (rc) return rc;
+  uint32_t any = s->out_counts[s->D.n_shards];
+  for (uint32_t sh = 0; sh < s->D.n_shards; sh++) any |= s->out_counts[sh];
+  *active = any != 0;
+  return SWIM_OK;
+}
+// a host-side stimulus may fill queues behind the back of the activity word: raise it, and ignore the
+// caller's hint for the next tick (stimulus is replicated on every shard, so every shard does)
+static void touched(swim_sim* s) {
+  s->force_active = true;
+  if (s->D.n_shards > 1) (void)hipMemsetD32Async((hipDeviceptr_t)s->D.act, 1, 1, s->stream);
 }
 extern "C" uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) {
   return (s && shard < s->cfg.n_shards) ? s->D.out_cap[shard] : 0;
@@ -512,6 +554,7 @@ static int upload_ids(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
 static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n) {
   int rc = upload_ids(s, r, ids, n);
   if (rc || !n) return rc;
+  touched(s);
   if (op == INJ_LEAVE || op == INJ_UPDATE)
     hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
   hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, s->D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
@@ -528,6 +571,7 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
   if (s->in_tick) return SWIM_ESTATE;
   if (r >= s->D.R || s->D.N > s->scratch_bytes) return SWIM_ERANGE;
   for (uint32_t i = 0; i < s->D.N; i++) if (g[i] > 127) return SWIM_ERANGE;   // 7 bits of the node word
+  touched(s);
   HIPCK(s, hipMemcpyAsync(s->d_scratch, g, s->D.N, hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, s->D, r, (const uint8_t*)s->d_scratch);
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);
@@ -547,6 +591,7 @@ extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_
   if (!s) return SWIM_EINVAL;
   if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
   if (r >= s->D.R || origin >= s->D.N) return SWIM_ERANGE;
+  touched(s);
   hipLaunchKernelGGL(k_user_event, dim3(1), dim3(64), 0, s->stream, s->D, r, origin, id, s->d_scratch);
   uint32_t v = SWIM_NONE;
   HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
@@ -704,6 +749,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->inbox_overflow = v[ST_INBOX_OVF]; out->subject_overflow = v[ST_SUBJ_OVF]; out->event_drops = v[ST_EVDROPS];
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
+  out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
@@ -720,14 +766,26 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
     if (!n) continue;
     tmp.resize(n);
     if ((rc = d2h(s, tmp.data(), (const swim_edge*)s->D.seg + (size_t)b * s->D.seg_cap, n))) return rc;
-    for (uint32_t i = 0; i < n; i++) { if (w < cap) out[w++] = tmp[i]; total++; }
+    for (uint32_t i = 0; i < n; i++) { if (tmp[i].subject == SWIM_SUBJECT_PIGGY) continue; if (w < cap) out[w++] = tmp[i]; total++; }
+  }
+  if (s->D.flags & SWIM_F_PIGGYBACK) {               // the broadcasts carried into the finished tick, before the filter
+    std::vector<uint32_t> cn(s->D.NB);
+    if ((rc = d2h(s, cn.data(), (const uint32_t*)s->D.carry_last, s->D.NB))) return rc;
+    const uint32_t par = (s->tick - 1) & 1u;
+    for (uint32_t a = 0; s->tick && a < s->D.NB; a++) {
+      uint32_t n = std::min(cn[a], s->D.carry_cap);
+      if (!n) continue;
+      tmp.resize(n);
+      if ((rc = d2h(s, tmp.data(), (const swim_edge*)s->D.carry + ((size_t)par * s->D.NB + a) * s->D.carry_cap, n))) return rc;
+      for (uint32_t i = 0; i < n; i++) { if (tmp[i].dst == SW_DST_VOID) continue; if (w < cap) out[w++] = tmp[i]; total++; }
+    }
   }
   for (uint32_t sh = 0; sh < s->D.n_shards; sh++) {
     uint32_t n = std::min(cnt[sh], s->D.out_cap[sh]);
     tmp.resize(n);
     if (n && (rc = d2h(s, tmp.data(), (const swim_edge*)s->D.out[sh], n))) return rc;
     for (uint32_t i = 0; i < n; i++) {
-      if (tmp[i].dst == SWIM_NONE) continue;
+      if (tmp[i].dst == SWIM_NONE || tmp[i].subject == SWIM_SUBJECT_PIGGY) continue;
       if (w < cap) out[w++] = tmp[i];
       total++;
     }
@@ -797,6 +855,7 @@ extern "C" int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint
   if (rc) return rc;
   if (dst >= s->D.N || (!m && n) || n * sizeof(swim_edge) + n * 4 > s->scratch_bytes) return SWIM_EINVAL;
   if (!n) return SWIM_OK;
+  touched(s);
   std::vector<swim_edge> recs(m, m + n); std::vector<uint32_t> subj;
   for (auto& e : recs) {
     if ((e.meta >> 30) != SWIM_MSG_USER) { if (e.subject >= s->D.N) return SWIM_ERANGE; subj.push_back(e.subject); }

@@ -6,7 +6,8 @@
 //   k_begin    fused, role by block range:
 //                expire   suspicion timers that ran out         -> self-addressed dead{} records
 //                pending  indirect-ping stage of probes whose direct ping failed ProbeTimeout ago
-//                probe    probe()/probeNode for the probe-due set -> suspect{} records, slot requests
+//                probe    probe()/probeNode for the probe-due set -> suspect{} records, slot requests,
+//                         piggy-back orders for the ping and the ack (sendMsg)
 //                gossip   kRandomNodes + GetBroadcasts per peer   -> edge lists bucketed by shard
 //   k_deliver  edge list -> per-node inbox rows (one returning atomic + one 16 B store per record)
 //   k_resolve  per observer: canonical order, aliveNode/suspectNode/deadNode/handleUserEvent
@@ -149,6 +150,21 @@ __device__ __forceinline__ void capture(const SwDev& D, uint32_t src, uint32_t g
   else atomicOr(D.err, SW_ERR_EVENT_OVF);
 }
 
+// ---- SWIM_F_PIGGYBACK: sendMsg (net.go) lets every ping / indirect ping / ack / nack carry its sender's
+// getBroadcasts().  The probing lane files an *order* addressed to the sender S (an edge record with subject
+// SWIM_SUBJECT_PIGGY, incarnation = the packet's receiver or NONE when the packet is lost, type = carrier
+// kind, from = the prober); S picks the broadcasts in k_resolve.  An order for a node with nothing queued is a
+// no-op, so it is only filed when the block hint says S's block may hold something (k_deliver re-checks S's
+// header exactly, which makes the racy hint read harmless).
+__device__ __forceinline__ bool piggy_hint(const SwDev& D, uint32_t r, uint32_t sender, uint32_t peer_active) {
+  if (!(D.flags & SWIM_F_PIGGYBACK)) return false;
+  if (sender < D.i0 || sender >= D.i0 + D.nloc) return peer_active != 0;
+  return !D.fast_blocks || D.q_any[((size_t)r * D.nloc + (sender - D.i0)) / SW_BLOCK] != 0;
+}
+__device__ __forceinline__ uint4 piggy_rec(const SwDev& D, uint32_t r, uint32_t sender, uint32_t receiver, uint32_t kind, uint32_t prober) {
+  return make_uint4(r * D.N + sender, SWIM_SUBJECT_PIGGY, receiver, (kind << 30) | (prober & 0x3FFFFFFFu));
+}
+
 // ---- stagger: which nodes act in tick t --------------------------------------------------------
 // chunk c = id / CH; gossip phase = c % G; probe phase = (c / G) % P.  Enumerate the active set
 // compactly: index a -> node id i (or NONE).  CH is a power of two.
@@ -260,7 +276,7 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
 // alive peers; each relays the target's ack or (Lifeguard) answers nack one ProbeTimeout later.
 // =================================================================================================
 template <int KMAX>
-__device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+__device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats, uint32_t peer_active) {
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
   if (t >= D.TQ) {
@@ -281,9 +297,19 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
       bool nack_in_time = 2 * D.TQ < p0.z - p0.w;
       for (uint32_t q = 0; q < np; q++) {
         if (D.flags & SWIM_F_NACK) expected++;
-        if (!reach(D, r, t, wi, pw[q], i, 20 + 4 * q)) continue;
-        bool ok = reach(D, r, t, pw[q], wx, i, 21 + 4 * q) && reach(D, r, t, wx, pw[q], i, 22 + 4 * q);
+        const uint32_t hq = peers[q];
+        bool there = reach(D, r, t, wi, pw[q], i, 20 + 4 * q);
+        // rare path (a direct ping just failed): plain per-lane appends are fine
+        if (piggy_hint(D, r, i, peer_active)) wave_append_sharded(D, true, i / D.nloc, piggy_rec(D, r, i, there ? hq : NONE, SWIM_CTL_INDIRECT, i));
+        if (!there) continue;
+        bool hx = reach(D, r, t, pw[q], wx, i, 21 + 4 * q), xh = hx && reach(D, r, t, wx, pw[q], i, 22 + 4 * q), ok = hx && xh;
         bool back = reach(D, r, t, pw[q], wi, i, 23 + 4 * q);
+        if (piggy_hint(D, r, hq, peer_active)) {
+          wave_append_sharded(D, true, hq / D.nloc, piggy_rec(D, r, hq, hx ? x : NONE, SWIM_CTL_PING, i));
+          if (ok) wave_append_sharded(D, true, hq / D.nloc, piggy_rec(D, r, hq, back ? i : NONE, SWIM_CTL_ACK, i));
+          else if ((D.flags & SWIM_F_NACK) && nack_in_time) wave_append_sharded(D, true, hq / D.nloc, piggy_rec(D, r, hq, back ? i : NONE, SWIM_CTL_NACK, i));
+        }
+        if (hx && piggy_hint(D, r, x, peer_active)) wave_append_sharded(D, true, x / D.nloc, piggy_rec(D, r, x, xh ? hq : NONE, SWIM_CTL_ACK, i));
         if (ok && back) acked = true;
         else if (!ok && back && nack_in_time) nacks++;
       }
@@ -302,13 +328,17 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 // role: probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now.
 // Hot path per lane: own word, 8 B of probe state, one Feistel evaluation, the target's word.
 // =================================================================================================
-__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
+template <bool MULTI>
+__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t pb, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc, uint32_t* s_cnt, uint32_t peer_active) {
   ExcList X; X.stage(D, r, lds_exc);
+  if (threadIdx.x == 0) s_cnt[0] = 0;
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
   uint32_t i = map_probe(D, t % D.P, a);
   const uint32_t* nw = D.nw + (size_t)r * D.N;
   bool e_buddy = false, e_self = false, e_ctrl = false, c_probe = false, c_ack = false, e_pend = false;
+  bool o_ping = false, o_ack = false;                // piggy-back orders: for my ping, for the target's ack
+  uint32_t o_ping_rcv = NONE, o_ack_rcv = NONE, o_x = 0;
   uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
   size_t l = 0;
   uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
@@ -344,7 +374,14 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds
         if (fwd && SW_KST(key) != SWIM_STATE_ALIVE && (D.flags & SWIM_F_BUDDY_SUSPECT)) {
           e_buddy = true; rec_buddy = mk_edge(D, r, x, x, SW_KINC(key), SWIM_MSG_SUSPECT, i); buddy_sh = x / D.nloc;
         }
-        if (fwd && !lost(D, r, t, i, 17)) { aw = awareness_apply(D, aw, -1); c_ack = true; }
+        bool ack = fwd && !lost(D, r, t, i, 17);
+        if (D.flags & SWIM_F_PIGGYBACK) {
+          o_x = x;
+          // a non-alive target gets the ping+suspect compound, which is sent raw (no piggy-back)
+          if (SW_KST(key) == SWIM_STATE_ALIVE && piggy_hint(D, r, i, peer_active)) { o_ping = true; o_ping_rcv = fwd ? x : NONE; }
+          if (fwd && piggy_hint(D, r, x, peer_active)) { o_ack = true; o_ack_rcv = ack ? i : NONE; }
+        }
+        if (ack) { aw = awareness_apply(D, aw, -1); c_ack = true; }
         else {
           stage = 1; nackm = 1; e_pend = true;
           D.pr0[l] = make_uint4(x, SW_KINC(key), t + D.P * (aw + 1), t);   // awareness.ScaleTimeout(ProbeInterval)
@@ -377,6 +414,27 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds
   if (__any(e_buddy)) wave_append_sharded(D, e_buddy, buddy_sh, rec_buddy);
   uint32_t ne = (uint32_t)e_self + (uint32_t)e_buddy;
   if (ne) { S.add(ST_EDGES, ne); if (e_buddy && buddy_sh != D.rank) S.add(ST_EDGES_REMOTE); }
+  // piggy-back orders: during dissemination every probing lane files one or two, so the ones that stay on
+  // this shard go to the block's private segment (wave prefix sum, one LDS atomic per wave, no global atomic)
+  if (D.flags & SWIM_F_PIGGYBACK) {
+    bool ack_local = o_ack && (!MULTI || o_x / D.nloc == D.rank);
+    uint32_t n_loc = (uint32_t)o_ping + (uint32_t)ack_local, incl = n_loc, my_off = 0;
+    if (__any(n_loc != 0)) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
+      uint32_t wave_total = __shfl(incl, 63), wbase = 0;
+      if (sw_lane() == 63) wbase = atomicAdd(&s_cnt[0], wave_total);
+      wbase = __shfl(wbase, 63);
+      my_off = wbase + incl - n_loc;
+      const uint32_t segb = D.R * D.nb_gossip + r * D.nb_probe + pb;
+      uint4* dst = D.seg + (size_t)segb * D.seg_cap + my_off;
+      if (o_ping) *dst++ = piggy_rec(D, r, i, o_ping_rcv, SWIM_CTL_PING, i);
+      if (ack_local) *dst = piggy_rec(D, r, o_x, o_ack_rcv, SWIM_CTL_ACK, i);
+    }
+    if (MULTI) { bool rem = o_ack && !ack_local; if (__any(rem)) wave_append_sharded(D, rem, o_x / D.nloc, piggy_rec(D, r, o_x, o_ack_rcv, SWIM_CTL_ACK, i)); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt[0]) { D.seg_cnt[D.R * D.nb_gossip + r * D.nb_probe + pb] = s_cnt[0]; if (MULTI) *D.act = 1; }
+  }
   S.flush(D);
 }
 
@@ -416,9 +474,15 @@ __device__ __forceinline__ bool noop_given_view(const SwDev& D, uint4 a, size_t 
   return false;
 }
 
-// one GetBroadcasts(overhead, limit) over an LDS-staged queue.  `live` = entries still queued;
+// where a node's queue lives: staged in LDS (gossip role: entry j of this lane at sq[j*256]) or in HBM
+// (k_resolve: entry j of lane l at q[j*NL + l])
+struct LdsQ { uint4* p; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[j * SW_BLOCK]; } };
+struct HbmQ { uint4* p; size_t NL; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[(size_t)j * NL]; } };
+
+// one GetBroadcasts(overhead, limit) over a queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
-__device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
+template <typename QV>
+__device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
   uint32_t taken = 0; int used = 0;
   for (;;) {
     int free_b = limit - used - (int)overhead;
@@ -426,7 +490,7 @@ __device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32
     uint32_t best = NONE, bmeta = 0;
     for (uint32_t j = 0; j < n; j++) {
       if (!((live >> j) & 1u) || ((taken >> j) & 1u)) continue;
-      uint32_t meta = sq[j * SW_BLOCK].w;
+      uint32_t meta = sq.at(j).w;
       if ((int)D.msg_len[m_type(meta)] > free_b) continue;
       if (best == NONE || ent_before(D, meta, bmeta)) { best = j; bmeta = meta; }
     }
@@ -435,9 +499,9 @@ __device__ uint32_t get_broadcasts(const SwDev& D, uint4* sq, uint32_t n, uint32
   }
   for (uint32_t j = 0; j < n; j++) {
     if (!((taken >> j) & 1u)) continue;
-    uint32_t meta = sq[j * SW_BLOCK].w;
+    uint32_t meta = sq.at(j).w;
     if (m_tr(meta) + 1 >= D.retransmit_limit) live &= ~(1u << j);          // Finished()
-    else sq[j * SW_BLOCK].w = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
+    else sq.at(j).w = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
   }
   used_out = used;
   return taken;
@@ -514,9 +578,9 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
       bool ok[KMAX];
       for (uint32_t p = 0; p < found; p++) {
         int used = 0, used2 = 0;
-        uint32_t tm = (D.ablate & 2u) ? (live_m & 1u) : get_broadcasts(D, sq, qlen, live_m, 2, (int)D.budget, used), te = 0;
+        uint32_t tm = (D.ablate & 2u) ? (live_m & 1u) : get_broadcasts(D, LdsQ{sq}, qlen, live_m, 2, (int)D.budget, used), te = 0;
         int avail = (int)D.budget - used;
-        if (serf && avail > 2 + 1) te = get_broadcasts(D, se, evqlen, live_e, 3, avail, used2);
+        if (serf && avail > 2 + 1) te = get_broadcasts(D, LdsQ{se}, evqlen, live_e, 3, avail, used2);
         if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
         c_pkt++;
         for (uint32_t m = tm; m; m &= m - 1) {
@@ -643,7 +707,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   if (threadIdx.x == 0) {
     if (fb != NONE && !any) D.q_any[fb] = 0;
     uint32_t c = s_cnt[D.rank];                    // every wave has added its total (barrier above)
-    if (c) { D.seg_cnt[segb] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); }
+    if (c) { D.seg_cnt[segb] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); if (MULTI) *D.act = 1; }
   }
   S.flush(D);
 }
@@ -734,6 +798,29 @@ __device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 }
 
 // =================================================================================================
+// role: carry (sharded runs only) — the broadcasts k_resolve piggy-backed last tick sit in the blocks'
+// private areas; the ones addressed to other shards move to those shards' lists and are voided in place,
+// the rest is delivered (and filtered) by k_deliver like in an unsharded run.
+// =================================================================================================
+__device__ void role_carry(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+  BlockStats S; S.init(lds_stats);
+  const uint32_t par = *D.tick & 1u;
+  uint32_t c_rem = 0;
+  for (uint32_t a = b; a < D.NB; a += nb) {
+    uint32_t n = D.carry_cnt[(size_t)par * D.NB + a]; if (n > D.carry_cap) n = D.carry_cap;
+    uint4* area = D.carry + ((size_t)par * D.NB + a) * D.carry_cap;
+    for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
+      uint32_t e = e0 + threadIdx.x; bool rem = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t sh = 0;
+      if (e < n) { rec = area[e]; sh = (rec.x % D.N) / D.nloc; rem = sh != D.rank; }
+      wave_append_sharded(D, rem, sh, rec);
+      if (rem) { area[e].x = SW_DST_VOID; c_rem++; }
+    }
+  }
+  S.wave_add(ST_EDGES, c_rem); S.wave_add(ST_EDGES_REMOTE, c_rem);
+  S.flush(D);
+}
+
+// =================================================================================================
 // k_begin — the fused first launch of a tick.  grid = nb_expire + nb_pend + R*(nb_probe + nb_gossip);
 // dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
 // =================================================================================================
@@ -745,14 +832,18 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
   uint32_t b = blockIdx.x;
   if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); return; }
   b -= pl.nb_expire;
-  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats); return; }
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, pl.peer_active); return; }
   b -= pl.nb_pend;
-  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe(D, b / pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc); return; }
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, pl.peer_active); return; }
   b -= D.R * pl.nb_probe;
   if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); return; }
   b -= D.R * pl.nb_gossip;
   if (b < pl.nb_ppreply) { if (pl.roles & 16u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); return; }
   b -= pl.nb_ppreply;
+  if (MULTI) {
+    if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); return; }
+    b -= pl.nb_carry;
+  }
   if (pl.roles & 16u) role_pushpull(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
 }
 typedef void (*BeginKernel)(SwDev, BeginPlan);
@@ -800,8 +891,12 @@ __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, siz
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
   uint32_t w = D.nw[rec.x];
   if (w & NW_DEAD) return NONE;                    // e.g. a push-pull reply to a requester that died meanwhile
-  if (w & NW_ATTACHED) { capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
+  if (w & NW_ATTACHED) { if (rec.y != SWIM_SUBJECT_PIGGY) capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
   l = (size_t)r * D.nloc + (x - D.i0);
+  if (rec.y == SWIM_SUBJECT_PIGGY) {               // a piggy-back order for a node with nothing queued is a no-op
+    uint32_t hy = D.hdr[l].y;                      // (headers do not change between k_begin and k_resolve)
+    if (!(h_qlen(hy) | h_evqlen(hy))) return NONE;
+  }
   return atomicAdd(&D.inbox1[l * 16], 1u);
 }
 // place: the message lands in the same line for the first SW_INBOX_FAST arrivals, else in the overflow row
@@ -825,7 +920,29 @@ __device__ __forceinline__ void deliver_span(const SwDev& D, const uint4* edges,
     for (int j = 0; j < 4; j++) inbox_place(D, rec[j], l[j], pos[j]);
   }
 }
-// grid = n_seg blocks (block b drains gossip segment b) + extra blocks over the shard's misc list
+// The broadcasts piggy-backed on last tick's pings and acks (picked by k_resolve, one private area per block)
+// arrive with this tick's packets.  Same no-op filter as the gossip role applies at the sender: here the
+// receiver's view is read before the inbox is touched.
+__device__ void deliver_carried(const SwDev& D, const uint4* area, uint32_t n, uint32_t& c_edges, uint32_t& c_filt) {
+  const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
+  for (uint32_t e = threadIdx.x; e < n; e += SW_BLOCK) {
+    uint4 rec = area[e];
+    if (rec.x == SW_DST_VOID) continue;              // left for another shard in k_begin
+    uint32_t r = rec.x / D.N, x = rec.x % D.N, type = rec.w >> 30;
+    if (filter && type != SWIM_MSG_USER && rec.y != x) {
+      uint32_t ws = D.nw[(size_t)r * D.N + rec.y];
+      if (NW_HAS_SLOT(ws)) {
+        size_t ci = ((size_t)r * D.S + NW_SLOT(ws)) * D.nloc + (x - D.i0);
+        if (noop_given_view(D, D.va[ci], ci, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30))) { c_filt++; continue; }
+      }
+    }
+    c_edges++;
+    size_t l; uint32_t pos = inbox_reserve(D, rec, l);
+    inbox_place(D, rec, l, pos);
+  }
+}
+// grid = n_seg blocks (block b drains segment b) + nb_carry blocks over the carry areas + extra blocks over
+// the shard's misc list
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
   uint32_t b = blockIdx.x;
   if (b < D.n_seg) {
@@ -837,9 +954,37 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
     if (threadIdx.x == 0) D.seg_cnt[b] = 0;
     return;
   }
-  uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
+  b -= D.n_seg;
+  if (b < D.nb_carry) {
+    // block b owns the areas [b*per, (b+1)*per): their counts are fetched together, most ticks all are zero
+    __shared__ uint32_t s_n[SW_BLOCK];
+    const uint32_t par = *D.tick & 1u, per = (D.NB + D.nb_carry - 1) / D.nb_carry, a = b * per + threadIdx.x;
+    uint32_t n = 0, last = 0;
+    if (threadIdx.x < per && a < D.NB) { n = D.carry_cnt[(size_t)par * D.NB + a]; last = D.carry_last[a]; }
+    if (!__syncthreads_or((n | last) != 0)) return;
+    if (threadIdx.x < per && a < D.NB) {
+      if (n > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); n = D.carry_cap; }
+      if (last != n) D.carry_last[a] = n;
+      if (n) D.carry_cnt[(size_t)par * D.NB + a] = 0;
+    }
+    if (threadIdx.x < per) s_n[threadIdx.x] = n;
+    __syncthreads();
+    uint32_t c_edges = 0, c_filt = 0;
+    for (uint32_t j = 0; j < per && b * per + j < D.NB; j++)
+      if (s_n[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b * per + j) * D.carry_cap, s_n[j], c_edges, c_filt);
+    if (__any((c_edges | c_filt) != 0)) {
+      for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_filt += __shfl_down(c_filt, off); }
+      if (sw_lane() == 0) {
+        if (c_edges) atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c_edges);
+        if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
+      }
+    }
+    return;
+  }
+  b -= D.nb_carry;
+  uint32_t nb = gridDim.x - D.n_seg - D.nb_carry, n = D.out_cnt[D.rank];
   if (n > D.out_cap[D.rank]) n = D.out_cap[D.rank];
-  deliver_span(D, D.out[D.rank], n, (b - D.n_seg) * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
+  deliver_span(D, D.out[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
 }
 // records handed over by other shards (swim_inbound)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(SwDev D, const uint4* edges, uint32_t n) {
@@ -998,6 +1143,43 @@ struct NodeCtx {
     S.add(ST_APPL2);
     if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
   }
+  // sendMsg (net.go): extra := getBroadcasts(compoundOverhead, UDPBufferSize - len(msg) - compoundHeaderOverhead),
+  // i.e. the memberlist queue and then the serf delegate's user events, for a ping/ack/... this node sent this
+  // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
+  // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
+  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area) {
+    const int limit = (int)D.budget - (int)D.ctl_len[kind & 3u];
+    uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
+    int used = 0, used2 = 0;
+    HbmQ qm{D.q + l, NL}, qe{D.evq + l, NL};
+    uint32_t tm = get_broadcasts(D, qm, qlen, live_m, 2, limit, used), te = 0;
+    int avail = limit - used;
+    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, qe, evqlen, live_e, 3, avail, used2);
+    if (!(tm | te)) return;
+    const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
+    S.add(ST_PIGGY); S.add(ST_PIGGY_MSGS, cnt);
+    for (uint32_t m = tm; m; m &= m - 1) S.add(ST_SENT0 + (int)m_type(qm.at(__ffs(m) - 1).w));
+    if (te) S.add(ST_SENT3, (uint32_t)__popc(te));
+    if (receiver != NONE) {
+      const uint32_t gdst = r * D.N + receiver;
+      const bool att = (D.nw[gdst] & NW_ATTACHED) != 0;           // Transport.WriteTo towards the real node
+      uint32_t pos = att ? 0 : atomicAdd(s_carry, cnt);
+      if (!att && pos + cnt > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); pos = NONE; }
+      for (uint32_t m = tm; m && pos != NONE; m &= m - 1) {
+        uint4 e = qm.at(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
+        if (att) capture(D, o, gdst, e.x, e.y, meta); else area[pos++] = make_uint4(gdst, e.x, e.y, meta);
+      }
+      for (uint32_t m = te; m && pos != NONE; m &= m - 1) {
+        uint4 e = qe.at(__ffs(m) - 1);
+        if (att) capture(D, o, gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30); else area[pos++] = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
+      }
+    }
+    // retire what reached the retransmit limit (stable compaction, like the gossip role's write-back)
+    uint32_t nq = 0, ne = 0;
+    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { if (nq != j) qm.at(nq) = qm.at(j); nq++; }
+    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) { if (ne != j) qe.at(ne) = qe.at(j); ne++; }
+    qlen = nq; evqlen = ne;
+  }
   // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
   __device__ void user_event(uint32_t id, uint32_t ltime) {
     if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
@@ -1020,16 +1202,18 @@ struct NodeCtx {
 
 // canonical order key of an inbox record: (user?, subject, type) then (incarnation, from)
 __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
-  uint32_t type = e.w >> 30;
-  hi = ((uint64_t)(type == SWIM_MSG_USER) << 34) | ((uint64_t)e.y << 2) | type;
+  uint32_t type = e.w >> 30; bool order = e.y == SWIM_SUBJECT_PIGGY;     // orders act on the queue as k_begin left it
+  hi = ((uint64_t)!order << 35) | ((uint64_t)(!order && type == SWIM_MSG_USER) << 34) | ((uint64_t)e.y << 2) | type;
   lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
 }
 
 __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   __shared__ uint32_t lds_stats[ST_COUNT];
+  __shared__ uint32_t s_carry;
   if (D.fast_blocks) {                     // nothing reached this block of nodes: one word and out
     if (!D.in_any[blockIdx.x]) return;
   }
+  if (threadIdx.x == 0) s_carry = 0;
   BlockStats S; S.init(lds_stats);
   if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
   size_t NL = (size_t)D.R * D.nloc;
@@ -1064,7 +1248,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         }
         if (!have) break;
         uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
-        if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
+        if (best.y == SWIM_SUBJECT_PIGGY)
+          n.piggyback(best.z, type, &s_carry, D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + blockIdx.x) * D.carry_cap);
+        else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
           uint32_t li = (n.t + 1) & 1u, sub = blockIdx.x % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
           uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
           if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
@@ -1079,7 +1265,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
       n.store();
     }
   }
-  S.flush(D);
+  S.flush(D);                                      // (barrier inside: every lane's carry reservations are in)
+  if (threadIdx.x == 0 && s_carry) D.carry_cnt[(size_t)((*D.tick + 1) & 1u) * D.NB + blockIdx.x] = s_carry;
 }
 
 // =================================================================================================
@@ -1160,6 +1347,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt
       uint32_t* row = &D.trace[((size_t)sidx * D.trace_ticks + t) * 5];
       row[0] = c->by_state[0]; row[1] = c->by_state[1]; row[2] = c->by_state[2]; row[3] = c->by_state[3]; row[4] = c->n_current;
     }
+  }
+  // sharded runs: tell the other shards (through the count exchange) whether any queue here may be non-empty;
+  // while nobody has anything, probes need not file piggy-back orders for nodes of other shards
+  if (D.n_shards > 1 && (D.flags & SWIM_F_PIGGYBACK)) {
+    uint32_t any = 0;
+    if (D.fast_blocks) { for (uint32_t bb = threadIdx.x; bb < D.NB; bb += SW_BLOCK) any |= D.q_any[bb]; } else any = 1;
+    any = __syncthreads_or(any != 0);
+    if (threadIdx.x == 0) *D.act = any ? 1u : 0u;
   }
   __syncthreads();
   if (threadIdx.x == 0) {

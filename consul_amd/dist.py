@@ -71,8 +71,9 @@ class TorchExchange:
             seg, cnt_ptr = sim.outbound_raw(sh)
             cap = sim.outbound_capacity(sh)
             self._segs.append(torch.as_tensor(_DevMem(seg, cap * 4), device=self.device).view(cap, 4))
-        self._counts = torch.as_tensor(_DevMem(cnt_ptr, self.MAX_SHARDS), device=self.device)
-        self._gathered = torch.empty((self.world, self.MAX_SHARDS), dtype=torch.int32, device=self.device)
+        # the n_shards counters, then the shard's activity word (swim_peer_activity)
+        self._counts = torch.as_tensor(_DevMem(cnt_ptr, self.world + 1), device=self.device)
+        self._gathered = torch.empty((self.world, self.world + 1), dtype=torch.int32, device=self.device)
         self._caps = [sim.outbound_capacity(sh) for sh in range(self.world)]
         self._bound = sim
 
@@ -83,6 +84,9 @@ class TorchExchange:
         with torch.cuda.stream(self._stream):
             dist.all_gather_into_tensor(self._gathered, self._counts, group=self.group)
             m = self._gathered.cpu()                       # the tick's only host synchronisation
+            # nobody emitted anything and nobody can hold a queued broadcast: next tick's probes need not file
+            # piggy-back orders for nodes of other shards, and the quiescent tick stays off the wire
+            sim.peer_activity(bool(m.any()))
             # every rank derives the same (clamped) sizes from the same matrix; a clamped segment has
             # already raised the sender's sticky overflow flag
             rcap = self._caps[(self.rank + 1) % self.world]
@@ -141,6 +145,9 @@ class LocalExchange:
 
     def run(self, sims: Sequence[Sim]):
         n = len(sims)
+        active = any([s.activity() for s in sims])
+        for s in sims:
+            s.peer_activity(active)
         segs = [[s.outbound(j) for j in range(n)] for s in sims]
         for i in range(n):
             for j in range(n):

@@ -29,9 +29,9 @@ def preset(cdll, which: int = abi.PRESET_LAN, **overrides) -> abi.Config:
     if rc:
         raise SwimError("swim_config_preset", rc)
     for k, v in overrides.items():
-        if k == "msg_len":
+        if k in ("msg_len", "ctl_len"):
             for i, x in enumerate(v):
-                cfg.msg_len[i] = x
+                getattr(cfg, k)[i] = x
         else:
             if not hasattr(cfg, k):
                 raise AttributeError(f"swim_config has no field {k!r}")
@@ -135,6 +135,14 @@ class Sim:
 
     def inbound(self, ptr: int, count: int):
         self._ck("swim_inbound", self._l.swim_inbound(self._h, C.c_void_p(ptr), count))
+
+    def peer_activity(self, active: bool):
+        self._ck("swim_peer_activity", self._l.swim_peer_activity(self._h, 1 if active else 0))
+
+    def activity(self) -> bool:
+        a = C.c_int(1)
+        self._ck("swim_activity", self._l.swim_activity(self._h, C.byref(a)))
+        return bool(a.value)
 
     def tick_end(self):
         self._ck("swim_tick_end", self._l.swim_tick_end(self._h))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 1u
+#define SWIM_ABI_VERSION 2u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -40,6 +40,13 @@ extern "C" {
 
 #define SWIM_NONE 0xFFFFFFFFu
 #define SWIM_SUBJECT_PULL 0xFFFFFFFEu  /* edge.subject of a push-pull request; edge.incarnation = requester */
+#define SWIM_SUBJECT_PIGGY 0xFFFFFFFDu /* edge.subject of a piggy-back order (SWIM_F_PIGGYBACK): dst = the node whose
+                                          ping/ack/indirect-ping/nack carries broadcasts, edge.incarnation = the
+                                          packet's receiver (SWIM_NONE: the packet is lost), meta = carrier<<30 | prober */
+#define SWIM_CTL_PING 0u
+#define SWIM_CTL_INDIRECT 1u
+#define SWIM_CTL_ACK 2u
+#define SWIM_CTL_NACK 3u
 
 /* ---- enums pinned by the reference ------------------------------------------------------ */
 /* memberlist NodeStateType (state.go) */
@@ -68,7 +75,11 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
  * receiver already holds a newer incarnation, or the same incarnation in a state the message cannot
  * move.  Node state is identical with the flag on or off; only `edges` differ. */
 #define SWIM_F_FILTER_NOOP    0x8u
-#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP)
+/* memberlist sendMsg (net.go): every ping / indirect ping / ack / nack also carries getBroadcasts() of its
+ * sender in the bytes the packet has left.  The sender picks the broadcasts at the end of the
+ * tick the carrier goes out (before it merges that tick's arrivals); they arrive one tick later. */
+#define SWIM_F_PIGGYBACK      0x10u
+#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK)
 
 /* ---- configuration ---------------------------------------------------------------------- */
 /* One POD mirroring memberlist.Config field names (the ones CloneSerfLANConfig copies,
@@ -93,6 +104,8 @@ typedef struct swim_config {
                                        pushPullScale(N) like memberlist                      */
   /* modelled encoded sizes of alive/suspect/dead/user messages, bytes (queue order uses len) */
   uint32_t msg_len[4];
+  /* modelled encoded sizes of the ping / indirect ping / ack / nack that carry piggy-backed broadcasts */
+  uint32_t ctl_len[4];
   /* simulator */
   uint32_t quantum_ms;              /* tick length; 0 = gcd(gossip, probe, timeout)         */
   uint32_t phase_chunk;             /* nodes per stagger chunk (power of 2); 0 = auto       */
@@ -192,6 +205,8 @@ typedef struct swim_stats_t {
   uint64_t user_events_delivered, user_events_deduped, user_events_stale;
   uint64_t msgs_filtered;           /* rumours dropped at the sender by SWIM_F_FILTER_NOOP       */
   uint64_t push_pulls;              /* pushPullNode exchanges initiated                          */
+  uint64_t piggybacks;              /* pings/acks/... that carried at least one broadcast        */
+  uint64_t msgs_piggybacked;        /* broadcasts carried that way (also counted in msgs_sent)   */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;
@@ -238,6 +253,16 @@ int swim_stream(swim_sim* sim, void** hip_stream);
 int swim_outbound_raw(swim_sim* sim, uint32_t shard, const swim_edge** segment, const uint32_t** counters);
 int swim_inbound(swim_sim* sim, const swim_edge* ptr, uint32_t count);
 int swim_tick_end(swim_sim* sim);
+/* SWIM_F_PIGGYBACK across shards: a probe files a piggy-back order for its target's ack, and the target may live
+ * on another shard.  While no node anywhere has anything queued such orders are no-ops; `active` = 0 tells the
+ * next swim_tick_begin that the caller knows this to be so for every OTHER shard, and the orders stay unfiled
+ * (the quiescent tick then crosses no wire).  How to know: the word behind the n_shards counters of
+ * swim_outbound_raw is non-zero when this shard may hold a non-empty queue or emitted anything this tick; if that
+ * word and all counters of all shards are zero in tick t, `active` may be 0 for tick t+1.  Default 1 (always
+ * correct).  Results never depend on the hint.  swim_activity is the host-side read of the same condition for
+ * this shard (between swim_tick_begin and swim_tick_end; the oracle always answers 1). */
+int swim_peer_activity(swim_sim* sim, int active);
+int swim_activity(swim_sim* sim, int* active);
 
 /* ---- stimulus (fault injection is native; the reference kills nodes with Shutdown(),
  *      agent/consul/server_test.go:725) ----------------------------------------------------- */

@@ -152,6 +152,9 @@ int swim_config_preset(swim_config* c, int preset) {
   } else if (preset != SWIM_PRESET_LAN) return SWIM_EINVAL;
   c->msg_len[SWIM_MSG_ALIVE] = 128; c->msg_len[SWIM_MSG_SUSPECT] = 48;
   c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
+  /* ping{SeqNo,Node,SourceAddr,SourcePort,SourceNode}, indirectPingReq{+Target,Port,Nack}, ackResp{SeqNo,Payload}
+   * (serf's ping delegate puts a coordinate in Payload), nackResp{SeqNo} — msgpack with field names */
+  c->ctl_len[SWIM_CTL_PING] = 86; c->ctl_len[SWIM_CTL_INDIRECT] = 122; c->ctl_len[SWIM_CTL_ACK] = 108; c->ctl_len[SWIM_CTL_NACK] = 13;
   c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
@@ -275,6 +278,7 @@ struct swim_sim {
   slot_t* slots; uint32_t* n_slots; /* [R*S], [R] */
   edgevec* out;                  /* [n_shards] */
   edgevec in, last_edges;
+  edgevec carry[2];              /* piggy-backed broadcasts picked in tick t travel with tick t+1's packets */
   edgevec pp_reply[2];           /* push-pull requests seen in tick t are answered in tick t+1: {dst=replier, subject=requester, incarnation=replica} */
   swim_event* events; size_t n_events, cap_events;
   swim_stats_t st;
@@ -552,6 +556,14 @@ static void emit_slot_request(swim_sim* s, uint32_t r, uint32_t x) {
   for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++) ev_push(&s->out[sh], e);
 }
 
+/* sendMsg (net.go): a ping / indirect ping / ack / nack from `sender` also carries sender's getBroadcasts().
+ * The order reaches `sender` like a packet of this tick; `receiver` = SWIM_NONE when the carrier is lost on
+ * the way (the broadcasts still count as transmitted).  Orders are not rumours: no edge statistics. */
+static void piggy_order(swim_sim* s, uint32_t r, uint32_t sender, uint32_t receiver, uint32_t kind, uint32_t prober) {
+  if (!(s->cfg.flags & SWIM_F_PIGGYBACK)) return;
+  ev_push(&s->out[shard_of(s, sender)], mk_edge(s, r, sender, SWIM_SUBJECT_PIGGY, receiver, kind, prober));
+}
+
 static int lost(const swim_sim* s, uint32_t r, uint32_t node, uint32_t leg) {
   if (!s->loss_q32) return 0;
   uint32_t key[2], c[4] = { s->tick, node, leg, 0 }, w[4];
@@ -641,7 +653,10 @@ static void probe_start(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   int fwd = reach(s, r, o, x, o, 16);
   if (fwd && KST(key) != SWIM_STATE_ALIVE && (s->cfg.flags & SWIM_F_BUDDY_SUSPECT))
     emit(s, r, x, x, KINC(key), SWIM_MSG_SUSPECT, o);
-  if (fwd && !lost(s, r, o, 17)) { awareness_delta(s, nd, -1); s->st.probe_acks++; return; }
+  int ack = fwd && !lost(s, r, o, 17);
+  if (KST(key) == SWIM_STATE_ALIVE) piggy_order(s, r, o, fwd ? x : SWIM_NONE, SWIM_CTL_PING, o);   /* else: ping+suspect compound, sent raw */
+  if (fwd) piggy_order(s, r, x, ack ? o : SWIM_NONE, SWIM_CTL_ACK, o);
+  if (ack) { awareness_delta(s, nd, -1); s->st.probe_acks++; return; }
   nd->pr_target = x; nd->pr_inc = KINC(key); nd->pr_t0 = s->tick; nd->pr_stage = 1; nd->pr_nack_miss = 1;
   nd->pr_deadline = s->tick + s->d.probe_period * ((uint32_t)nd->awareness + 1);   /* awareness.ScaleTimeout */
 }
@@ -656,9 +671,15 @@ static void probe_indirect(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   for (uint32_t q = 0; q < np; q++) {
     uint32_t h = peers[q];
     if (s->cfg.flags & SWIM_F_NACK) expected++;
-    if (!reach(s, r, o, h, o, 20 + 4 * q)) continue;
-    int ok = reach(s, r, h, x, o, 21 + 4 * q) && reach(s, r, x, h, o, 22 + 4 * q);
+    int there = reach(s, r, o, h, o, 20 + 4 * q);
+    piggy_order(s, r, o, there ? h : SWIM_NONE, SWIM_CTL_INDIRECT, o);
+    if (!there) continue;
+    int hx = reach(s, r, h, x, o, 21 + 4 * q), xh = hx && reach(s, r, x, h, o, 22 + 4 * q), ok = hx && xh;
     int back = reach(s, r, h, o, o, 23 + 4 * q);
+    piggy_order(s, r, h, hx ? x : SWIM_NONE, SWIM_CTL_PING, o);
+    if (hx) piggy_order(s, r, x, xh ? h : SWIM_NONE, SWIM_CTL_ACK, o);
+    if (ok) piggy_order(s, r, h, back ? o : SWIM_NONE, SWIM_CTL_ACK, o);
+    else if ((s->cfg.flags & SWIM_F_NACK) && nack_in_time) piggy_order(s, r, h, back ? o : SWIM_NONE, SWIM_CTL_NACK, o);
     if (ok && back) acked = 1;
     else if (!ok && back && nack_in_time) nacks++;
   }
@@ -788,7 +809,9 @@ static void phase_gossip(swim_sim* s) {
 
 static int edge_cmp(const void* a, const void* b) {
   const swim_edge *x = (const swim_edge*)a, *y = (const swim_edge*)b;
-  uint32_t tx = x->meta >> 30, ty = y->meta >> 30, ux = tx == SWIM_MSG_USER, uy = ty == SWIM_MSG_USER;
+  uint32_t px = x->subject != SWIM_SUBJECT_PIGGY, py = y->subject != SWIM_SUBJECT_PIGGY;
+  if (px != py) return px < py ? -1 : 1;          /* piggy-back orders act on the queue as the begin phase left it */
+  uint32_t tx = x->meta >> 30, ty = y->meta >> 30, ux = px && tx == SWIM_MSG_USER, uy = py && ty == SWIM_MSG_USER;
   if (ux != uy) return ux < uy ? -1 : 1;
   if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
   if (tx != ty) return tx < ty ? -1 : 1;
@@ -801,6 +824,24 @@ static int ctrl_cmp(const void* a, const void* b) {
   if (x->incarnation != y->incarnation) return x->incarnation < y->incarnation ? -1 : 1;
   if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
   return 0;
+}
+
+/* sendMsg: extra := getBroadcasts(compoundOverhead, UDPBufferSize - len(msg) - compoundHeaderOverhead) — the
+ * memberlist queue, then the serf delegate's user events; what is picked travels with the next tick */
+static void piggyback(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t receiver, uint32_t kind) {
+  qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
+  int32_t limit = (int32_t)s->d.packet_budget - (int32_t)s->cfg.ctl_len[kind & 3];
+  uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, limit, msgs, &used);
+  int32_t avail = limit - used;
+  if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2);
+  if (!n) return;
+  s->st.piggybacks++; s->st.msgs_piggybacked += n;
+  for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
+  if (receiver == SWIM_NONE) return;
+  for (uint32_t m = 0; m < n; m++) {
+    if (s->attached[(size_t)r * s->N + receiver]) emit_from(s, o, r, receiver, msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+    else ev_push(&s->carry[(s->tick + 1) & 1], mk_edge(s, r, receiver, msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from));
+  }
 }
 
 /* packetListen -> handleCommand -> handleAlive/Suspect/Dead/User for everything that arrived */
@@ -820,8 +861,9 @@ static void phase_deliver_resolve(swim_sim* s) {
     swim_edge e = s->in.v[i]; if (e.dst == SWIM_NONE) continue;
     uint32_t r = e.dst / s->N, x = e.dst % s->N;
     if (!is_local(s, x) || !s->gt_alive[e.dst]) continue;
-    if (s->attached[e.dst]) { emit_from(s, SWIM_NONE, r, x, e.subject, e.incarnation, e.meta >> 30, e.meta & 0x3FFFFFFFu); continue; }
+    if (s->attached[e.dst]) { if (e.subject == SWIM_SUBJECT_PIGGY) continue; emit_from(s, SWIM_NONE, r, x, e.subject, e.incarnation, e.meta >> 30, e.meta & 0x3FFFFFFFu); continue; }
     node_t* nd = node_at(s, r, x);
+    if (e.subject == SWIM_SUBJECT_PIGGY && !nd->qlen && !nd->evqlen) continue;   /* nothing to carry */
     if (nd->in_cnt >= s->cfg.inbox_cap) { s->st.inbox_overflow++; continue; }
     nd->inbox[nd->in_cnt++] = e;
   }
@@ -835,6 +877,7 @@ static void phase_deliver_resolve(swim_sim* s) {
         swim_edge e = nd->inbox[i];
         if (i && edge_cmp(&nd->inbox[i - 1], &e) == 0) continue;
         uint32_t type = e.meta >> 30, from = e.meta & 0x3FFFFFFFu;
+        if (e.subject == SWIM_SUBJECT_PIGGY) { piggyback(s, r, o, nd, e.incarnation, type); continue; }
         if (e.subject == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {      /* answer next tick */
           swim_edge rq = { o, e.incarnation, r, 0 };
           ev_push(&s->pp_reply[(s->tick + 1) & 1], rq);
@@ -925,8 +968,25 @@ int swim_destroy(swim_sim* s) {
   free(s->attached); free(s->captured.v); free(s->cap_src);
   free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
-  free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->events); free(s);
+  free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->carry[0].v); free(s->carry[1].v); free(s->events); free(s);
   return SWIM_OK;
+}
+
+/* the broadcasts piggy-backed on last tick's pings and acks arrive with this tick's packets; the no-op
+ * filter sees them like any other rumour of the tick */
+static void phase_carry(swim_sim* s) {
+  edgevec* c = &s->carry[s->tick & 1];
+  for (uint32_t i = 0; i < c->n; i++) {
+    swim_edge e = c->v[i];
+    ev_push(&s->last_edges, e);
+    uint32_t r = e.dst / s->N, x = e.dst % s->N;
+    qent m = { e.subject, e.incarnation, e.meta & 0x3FFFFFFFu, 0, (uint8_t)(e.meta >> 30), 0 };
+    if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, x, &m)) { s->st.msgs_filtered++; continue; }
+    uint32_t sh = shard_of(s, x);
+    ev_push(&s->out[sh], e);
+    s->st.edges++; if (sh != s->cfg.shard_rank) s->st.edges_remote++;
+  }
+  c->n = 0;
 }
 
 int swim_tick_begin(swim_sim* s) {
@@ -934,13 +994,16 @@ int swim_tick_begin(swim_sim* s) {
   for (uint32_t i = 0; i < s->cfg.n_shards; i++) s->out[i].n = 0;
   s->in.n = 0;
   phase_expire(s); phase_probe(s); phase_pushpull(s); phase_gossip(s);
+  /* swim_debug_edges: what the roles emitted (orders excluded), then the carried broadcasts before the filter */
+  s->last_edges.n = 0;
+  for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++)
+    for (uint32_t i = 0; i < s->out[sh].n; i++)
+      if (s->out[sh].v[i].dst != SWIM_NONE && s->out[sh].v[i].subject != SWIM_SUBJECT_PIGGY) ev_push(&s->last_edges, s->out[sh].v[i]);
+  phase_carry(s);
   s->in_tick = 1;
   /* the local segment never crosses the wire */
   edgevec* loc = &s->out[s->cfg.shard_rank];
   for (uint32_t i = 0; i < loc->n; i++) ev_push(&s->in, loc->v[i]);
-  s->last_edges.n = 0;
-  for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++)
-    for (uint32_t i = 0; i < s->out[sh].n; i++) if (s->out[sh].v[i].dst != SWIM_NONE) ev_push(&s->last_edges, s->out[sh].v[i]);
   return SWIM_OK;
 }
 int swim_outbound(swim_sim* s, uint32_t shard, const swim_edge** ptr, uint32_t* count) {
@@ -952,6 +1015,8 @@ int swim_outbound_raw(swim_sim* s, uint32_t shard, const swim_edge** seg, const 
   if (!s || shard >= s->cfg.n_shards) return SWIM_EINVAL;
   if (seg) *seg = NULL; if (cnt) *cnt = NULL; return SWIM_ESTATE;     /* host buffers move: use swim_outbound */
 }
+int swim_peer_activity(swim_sim* s, int active) { (void)active; return s ? SWIM_OK : SWIM_EINVAL; }   /* a hint: the oracle files every order */
+int swim_activity(swim_sim* s, int* active) { if (!s || !active) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE; *active = 1; return SWIM_OK; }
 uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) { return (s && shard < s->cfg.n_shards) ? 0x7FFFFFFFu : 0; }
 int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   if (!s || (!ptr && count)) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;

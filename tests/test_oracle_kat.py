@@ -275,7 +275,8 @@ def test_leave_is_left_not_failed(oracle):
 def test_push_gossip_infection_follows_the_analytic_recurrence(oracle):
     """single rumour, synchronous rounds: I' = I + (N-I)(1-(1-1/N)^(k I))."""
     n, k = 16384, 3
-    s = Sim(oracle, preset(oracle, abi.PRESET_WAN, n_nodes=n, gossip_nodes=k, seed=5, trace_ticks=40))
+    s = Sim(oracle, preset(oracle, abi.PRESET_WAN, n_nodes=n, gossip_nodes=k, seed=5, trace_ticks=40,
+                           flags=abi.F_DEFAULT & ~abi.F_PIGGYBACK))       # the recurrence models gossip() alone
     s.update(0, [0])
     s.step(30)
     got = s.trace(0, 0, 0, 30)[:, 4].astype(float) + 1      # + the origin itself
@@ -288,6 +289,77 @@ def test_push_gossip_infection_follows_the_analytic_recurrence(oracle):
     for frac in (0.5, 0.99):
         assert abs(int(np.argmax(got >= frac * n)) - int(np.argmax(model >= frac * n))) <= 1
     assert got[-1] == n
+
+
+# ---- a12: sendMsg piggy-back (pings, acks, indirect pings and nacks carry getBroadcasts()) ----------------
+def test_piggyback_rides_on_ping_and_ack(oracle):
+    """Two nodes, both probe-due and gossip-due in tick 0.  Node 0 holds one rumour: it goes out once by
+    gossip(), once on node 0's ping to node 1 and once on node 0's ack of node 1's ping = 3 transmits (1 without
+    piggy-back).  The two carried copies arrive one tick later and are no-ops by then (the gossip copy landed)."""
+    for flags, want_tx, want_pb in ((abi.F_DEFAULT, 3, 2), (abi.F_DEFAULT & ~abi.F_PIGGYBACK, 1, 0)):
+        s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=2, seed=1, flags=flags, push_pull_interval_ms=0))
+        assert s.derived.retransmit_limit == 4
+        s.update(0, [0])
+        s.step(1)
+        q, st = s.node_info(0, 0), s.stats()
+        assert q.queue_len == 1 and q.queue[0].transmits == want_tx
+        assert (st["piggybacks"], st["msgs_piggybacked"]) == (want_pb, want_pb)
+        assert st["msgs_sent"][abi.MSG_ALIVE] == want_tx and st["packets_sent"] == 1
+        assert s.view(0, 1, 0).incarnation == 2                  # the gossip packet itself arrived in tick 0
+        f0, e0 = st["msgs_filtered"], st["edges"]
+        s.step(1)                  # tick 1: the carried copies land (no-ops); node 1 (chunk 1) gossips the rumour back to its subject
+        st = s.stats()
+        assert st["msgs_filtered"] - f0 == want_pb and st["edges"] - e0 == 1
+        s.close()
+
+
+def test_piggyback_on_a_lost_carrier_still_counts_as_transmitted(oracle):
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=2, seed=1, push_pull_interval_ms=0))
+    s.kill(0, [1]); s.update(0, [0])
+    s.step(1)                                                    # gossip packet and ping both go to the dead node
+    q, st = s.node_info(0, 0), s.stats()
+    assert q.queue[0].transmits == 2 and st["piggybacks"] == 1 and st["packets_dropped"] == 1
+    e0 = st["edges"]
+    s.step(1)
+    assert s.stats()["edges"] == e0                              # nothing was carried anywhere
+
+
+def test_piggyback_respects_the_bytes_the_carrier_leaves(oracle):
+    """extra := getBroadcasts(compoundOverhead, bytesAvail - len(msg)): a carrier that fills the packet carries nothing."""
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=256, seed=3, ctl_len=[1400] * 4))
+    s.step(20); s.kill(0, [9]); s.step(300)
+    st = s.stats()
+    assert st["piggybacks"] == 0 and st["probe_failures"] > 0 and sum(st["msgs_sent"]) > 0
+    # room for exactly one suspect/dead (48+2) on an ack but not for an alive (128+2)
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=256, seed=3, ctl_len=[1400, 1400, 1398 - 60, 1400]))
+    s.step(20); s.kill(0, [9]); s.update(0, [3]); s.step(300)
+    st = s.stats()
+    assert st["piggybacks"] > 0 and st["msgs_piggybacked"] == st["piggybacks"]
+
+
+def test_piggyback_speeds_up_dissemination(oracle):
+    curves = {}
+    for flags in (abi.F_DEFAULT, abi.F_DEFAULT & ~abi.F_PIGGYBACK):
+        s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=8192, seed=4, gossip_nodes=2, flags=flags, trace_ticks=80,
+                               push_pull_interval_ms=0))
+        s.update(0, [0]); s.step(80)
+        curves[flags] = s.trace(0, 0, 0, 80)[:, 4].astype(int)
+        s.close()
+    on, off = curves[abi.F_DEFAULT], curves[abi.F_DEFAULT & ~abi.F_PIGGYBACK]
+    assert on[-1] == off[-1] == 8191
+    assert int(np.argmax(on == 8191)) <= int(np.argmax(off == 8191)) and on.sum() > off.sum()
+
+
+def test_golden_infection_curves_32k(oracle):
+    """tests/golden/config3_infection_32k.json (tools/make_golden.py): BASELINE config #3's shape at 32 768 nodes."""
+    with open(os.path.join(HERE, "golden", "config3_infection_32k.json")) as f:
+        g = json.load(f)
+    for k, want in g["curves"].items():
+        s = Sim(oracle, preset(oracle, abi.PRESET_WAN, gossip_nodes=int(k), trace_ticks=64, **g["config"]))
+        s.update(0, [0]); s.step(60)
+        assert [int(x) for x in s.trace(0, 0, 0, 60)[:, 4]] == want["infected"]
+        assert f"{s.digest():#018x}" == want["digest"]
+        s.close()
 
 
 @pytest.mark.parametrize("kw", [

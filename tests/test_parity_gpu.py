@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 STAT_KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent",
              "msgs_applied", "probes", "probe_acks", "probe_indirect_acks", "probe_failures", "nacks_missed",
              "refutes", "suspicion_timeouts", "confirmations", "edges", "msgs_filtered", "push_pulls", "queue_drops",
-             "inbox_overflow",
+             "inbox_overflow", "piggybacks", "msgs_piggybacked",
              "subject_overflow"]
 
 
@@ -147,6 +147,33 @@ def test_sharded_population_matches_unsharded(hip, oracle, n_shards):
         if k not in ("subject_overflow", "edges", "msgs_filtered"):   # a shard cannot filter what goes to another shard
             assert a[k] == b[k], k
     assert a["edges_remote"] > 0
+    sh.close()
+
+
+def test_sharded_quiet_cluster_stays_off_the_wire_and_wakes_up(hip, oracle):
+    """Piggy-back orders for nodes of other shards are only filed while somebody may have something queued
+    (swim_peer_activity): a quiescent sharded cluster exchanges nothing, and every way of waking it up (failure,
+    update, user-visible leave) still reproduces the unsharded oracle bit for bit."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=4096, seed=8, subject_cap=64, queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+    sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.step_ms(3000)
+    assert sh.stats()["edges_remote"] == 0 and sh.digest() == ref.digest()
+    for s in (sh, ref):
+        s.update(0, [5]); s.step(1); s.update(0, [4000]); s.step_ms(2000)
+    assert sh.digest() == ref.digest()
+    for s in (sh, ref):
+        s.step_ms(20000)                                     # everything retires: quiet again
+        s.kill(0, [2500]); s.step_ms(40000)
+        s.leave(0, [77]); s.step_ms(10000)
+    sh.sync()
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("piggybacks", "msgs_piggybacked", "msgs_sent", "msgs_applied", "probe_failures", "suspicion_timeouts"):
+        assert a[k] == b[k], k
+    assert a["piggybacks"] > 0
     sh.close()
 
 
