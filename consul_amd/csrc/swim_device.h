@@ -132,8 +132,10 @@ struct SwDev {
   // SWIM_F_PIGGYBACK: broadcasts a node piggy-backs on its pings/acks are picked by k_resolve in tick t into
   // the private area of its block, carry[(t+1)&1][block][carry_cap], and delivered by k_deliver of tick t+1
   uint4* carry;
-  uint32_t* carry_cnt;   // [2][NB] consumed and zeroed by k_deliver
-  uint32_t* carry_last;  // [NB] what k_deliver consumed in the most recent tick (swim_debug_edges)
+  uint2* carry_cl;       // [NB] {records waiting (zeroed by k_deliver), records k_deliver consumed in the most recent tick}
+  uint32_t* att_any;     // [1] some node is attached to the transport bridge
+  uint32_t* carry_stamp; // [0] the tick the most recent piggy-back picks travel in (k_resolve of tick t writes t+1);
+                         // [1] the last tick in which k_deliver drained carry areas
   uint32_t carry_cap, NB, nb_carry;
   uint32_t* act;         // [1] sharded runs: this shard may hold a non-empty broadcast queue / emitted something
   uint4* out[SW_MAX_SHARDS];

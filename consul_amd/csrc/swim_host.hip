@@ -309,8 +309,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     if (serf) min_len = std::min(min_len, cfg->msg_len[3] + 3);
     const uint32_t fit = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / std::max(1u, min_len)));
     D.NB = (uint32_t)NB; D.carry_cap = piggy ? 2 * SW_BLOCK * fit : 1;
-    D.nb_carry = piggy ? std::max<uint32_t>(std::min<uint32_t>(D.NB, 512), cdiv(D.NB, SW_BLOCK)) : 0;
-    DALLOC(s, D.carry, piggy ? (size_t)2 * NB * D.carry_cap : 1); DALLOC(s, D.carry_cnt, 2 * NB); DALLOC(s, D.carry_last, NB);
+    D.nb_carry = piggy ? 1 : 0;                      // (flag) k_deliver's segment blocks drain the carry areas too
+    DALLOC(s, D.carry, piggy ? (size_t)2 * NB * D.carry_cap : 1); DALLOC(s, D.carry_cl, NB); DALLOC(s, D.att_any, 1); DALLOC(s, D.carry_stamp, 2);
   }
   uint64_t e_cap = (uint64_t)D.n_seg * D.seg_cap;
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
@@ -336,7 +336,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.exc_cnt, 0, D.R * 4, st)); HIPCK(s, hipMemsetAsync(D.exc_dirty, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.n_slots, 0, D.R * 4, st));
   HIPCK(s, hipMemsetAsync(D.out_cnt, 0, (SW_MAX_SHARDS + 1) * 4, st));
-  HIPCK(s, hipMemsetAsync(D.carry_cnt, 0, 2 * NB * 4, st)); HIPCK(s, hipMemsetAsync(D.carry_last, 0, NB * 4, st));
+  HIPCK(s, hipMemsetAsync(D.carry_cl, 0, NB * 8, st)); HIPCK(s, hipMemsetAsync(D.att_any, 0, 4, st)); HIPCK(s, hipMemsetAsync(D.carry_stamp, 0xFF, 8, st));
   HIPCK(s, hipMemsetAsync(D.seg_cnt, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(D.seg_last, 0, (size_t)D.n_seg * 4, st));
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
@@ -384,13 +384,13 @@ static void launch_begin(swim_sim* s) {
 static void launch_end(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + D.nb_carry + 32), dim3(SW_BLOCK), 0, st, D); }
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, D); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, D,
                        (const uint4*)s->in_buf, s->in_count);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), ((D.flags & SWIM_F_PIGGYBACK) && !(D.ablate & 64u)) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, D); }
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
   { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, D, s->d_last_cnt); }
@@ -769,11 +769,13 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
     for (uint32_t i = 0; i < n; i++) { if (tmp[i].subject == SWIM_SUBJECT_PIGGY) continue; if (w < cap) out[w++] = tmp[i]; total++; }
   }
   if (s->D.flags & SWIM_F_PIGGYBACK) {               // the broadcasts carried into the finished tick, before the filter
-    std::vector<uint32_t> cn(s->D.NB);
-    if ((rc = d2h(s, cn.data(), (const uint32_t*)s->D.carry_last, s->D.NB))) return rc;
+    std::vector<uint2> cl(s->D.NB);
+    if ((rc = d2h(s, cl.data(), (const uint2*)s->D.carry_cl, s->D.NB))) return rc;
     const uint32_t par = (s->tick - 1) & 1u;
-    for (uint32_t a = 0; s->tick && a < s->D.NB; a++) {
-      uint32_t n = std::min(cn[a], s->D.carry_cap);
+    uint32_t seen[2] = { SWIM_NONE, SWIM_NONE };
+    if ((rc = d2h(s, seen, (const uint32_t*)s->D.carry_stamp, 2))) return rc;
+    for (uint32_t a = 0; s->tick && seen[1] == s->tick - 1 && a < s->D.NB; a++) {
+      uint32_t n = std::min(cl[a].y, s->D.carry_cap);
       if (!n) continue;
       tmp.resize(n);
       if ((rc = d2h(s, tmp.data(), (const swim_edge*)s->D.carry + ((size_t)par * s->D.NB + a) * s->D.carry_cap, n))) return rc;

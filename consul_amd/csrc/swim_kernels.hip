@@ -476,8 +476,10 @@ __device__ __forceinline__ bool noop_given_view(const SwDev& D, uint4 a, size_t 
 
 // where a node's queue lives: staged in LDS (gossip role: entry j of this lane at sq[j*256]) or in HBM
 // (k_resolve: entry j of lane l at q[j*NL + l])
-struct LdsQ { uint4* p; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[j * SW_BLOCK]; } };
+struct LdsQ { uint4* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK].w; } };
 struct HbmQ { uint4* p; size_t NL; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[(size_t)j * NL]; } };
+// k_resolve: only the meta words (type | transmits | seq) of the lane's queue, staged in LDS
+struct MetaQ { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK]; } };
 
 // one GetBroadcasts(overhead, limit) over a queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
@@ -490,7 +492,7 @@ __device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& 
     uint32_t best = NONE, bmeta = 0;
     for (uint32_t j = 0; j < n; j++) {
       if (!((live >> j) & 1u) || ((taken >> j) & 1u)) continue;
-      uint32_t meta = sq.at(j).w;
+      uint32_t meta = sq.meta(j);
       if ((int)D.msg_len[m_type(meta)] > free_b) continue;
       if (best == NONE || ent_before(D, meta, bmeta)) { best = j; bmeta = meta; }
     }
@@ -499,9 +501,9 @@ __device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& 
   }
   for (uint32_t j = 0; j < n; j++) {
     if (!((taken >> j) & 1u)) continue;
-    uint32_t meta = sq.at(j).w;
+    uint32_t meta = sq.meta(j);
     if (m_tr(meta) + 1 >= D.retransmit_limit) live &= ~(1u << j);          // Finished()
-    else sq.at(j).w = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
+    else sq.meta(j) = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
   }
   used_out = used;
   return taken;
@@ -803,11 +805,12 @@ __device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 // the rest is delivered (and filtered) by k_deliver like in an unsharded run.
 // =================================================================================================
 __device__ void role_carry(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+  if (*D.carry_stamp != *D.tick) return;            // nothing was piggy-backed last tick
   BlockStats S; S.init(lds_stats);
   const uint32_t par = *D.tick & 1u;
   uint32_t c_rem = 0;
   for (uint32_t a = b; a < D.NB; a += nb) {
-    uint32_t n = D.carry_cnt[(size_t)par * D.NB + a]; if (n > D.carry_cap) n = D.carry_cap;
+    uint32_t n = D.carry_cl[a].x; if (n > D.carry_cap) n = D.carry_cap;
     uint4* area = D.carry + ((size_t)par * D.NB + a) * D.carry_cap;
     for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
       uint32_t e = e0 + threadIdx.x; bool rem = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t sh = 0;
@@ -941,37 +944,46 @@ __device__ void deliver_carried(const SwDev& D, const uint4* area, uint32_t n, u
     inbox_place(D, rec, l, pos);
   }
 }
-// grid = n_seg blocks (block b drains segment b) + nb_carry blocks over the carry areas + extra blocks over
-// the shard's misc list
+// grid = n_seg blocks + extra blocks over the shard's misc list.  Block b drains segment b and the carry areas
+// b, b + n_seg, ... (their counts are fetched together with the segment's: no extra trip in a quiet tick)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
   uint32_t b = blockIdx.x;
   if (b < D.n_seg) {
     uint32_t n = D.seg_cnt[b], last = D.seg_last[b];
-    __syncthreads();                               // everybody has read the count before lane 0 clears it
-    if (threadIdx.x == 0 && last != n) D.seg_last[b] = n;
-    if (!n) return;
-    deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK);
-    if (threadIdx.x == 0) D.seg_cnt[b] = 0;
-    return;
-  }
-  b -= D.n_seg;
-  if (b < D.nb_carry) {
-    // block b owns the areas [b*per, (b+1)*per): their counts are fetched together, most ticks all are zero
-    __shared__ uint32_t s_n[SW_BLOCK];
-    const uint32_t par = *D.tick & 1u, per = (D.NB + D.nb_carry - 1) / D.nb_carry, a = b * per + threadIdx.x;
-    uint32_t n = 0, last = 0;
-    if (threadIdx.x < per && a < D.NB) { n = D.carry_cnt[(size_t)par * D.NB + a]; last = D.carry_last[a]; }
-    if (!__syncthreads_or((n | last) != 0)) return;
-    if (threadIdx.x < per && a < D.NB) {
-      if (n > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); n = D.carry_cap; }
-      if (last != n) D.carry_last[a] = n;
-      if (n) D.carry_cnt[(size_t)par * D.NB + a] = 0;
+    uint32_t cn[4] = { 0, 0, 0, 0 }, cl[4] = { 0, 0, 0, 0 };
+    // anything carried into this tick?  (uniform words: k_resolve stamps carry_stamp with the tick its picks
+    // travel in, so a tick without piggy-backed broadcasts costs this block nothing more)
+    uint32_t par = 0;
+    const bool piggy = D.nb_carry != 0 && *D.carry_stamp == *D.tick;
+    if (piggy) {                                     // {count, count of the previous tick} in one 8-byte load per area
+      par = *D.tick & 1u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { uint32_t a = b + j * D.n_seg; if (a < D.NB) { uint2 c = D.carry_cl[a]; cn[j] = c.x; cl[j] = c.y; } }
     }
-    if (threadIdx.x < per) s_n[threadIdx.x] = n;
-    __syncthreads();
+    __syncthreads();                               // everybody has read the counts before lane 0 clears them
+    if (threadIdx.x == 0) {
+      if (last != n) D.seg_last[b] = n;
+      if (piggy && b == 0) D.carry_stamp[1] = *D.tick;            // swim_debug_edges: the areas' `last` words are of this tick
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t a = b + j * D.n_seg;
+        if (cn[j] > D.carry_cap) atomicOr(D.err, SW_ERR_CARRY_OVF);
+        if (cl[j] | cn[j]) D.carry_cl[a] = make_uint2(0, cn[j]);
+      }
+    }
+    if (n) deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK);
+    if (threadIdx.x == 0 && n) D.seg_cnt[b] = 0;
+    if (!piggy) return;
     uint32_t c_edges = 0, c_filt = 0;
-    for (uint32_t j = 0; j < per && b * per + j < D.NB; j++)
-      if (s_n[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b * per + j) * D.carry_cap, s_n[j], c_edges, c_filt);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (cn[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
+    for (uint32_t a = b + 4 * D.n_seg; a < D.NB; a += D.n_seg) {      // only with very fine quanta (G > 4)
+      uint2 cc = D.carry_cl[a]; uint32_t c = cc.x;
+      __syncthreads();
+      if (threadIdx.x == 0 && (cc.x | cc.y)) D.carry_cl[a] = make_uint2(0, c);
+      if (c) deliver_carried(D, D.carry + ((size_t)par * D.NB + a) * D.carry_cap, c < D.carry_cap ? c : D.carry_cap, c_edges, c_filt);
+    }
     if (__any((c_edges | c_filt) != 0)) {
       for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_filt += __shfl_down(c_filt, off); }
       if (sw_lane() == 0) {
@@ -981,8 +993,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
     }
     return;
   }
-  b -= D.nb_carry;
-  uint32_t nb = gridDim.x - D.n_seg - D.nb_carry, n = D.out_cnt[D.rank];
+  b -= D.n_seg;
+  uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
   if (n > D.out_cap[D.rank]) n = D.out_cap[D.rank];
   deliver_span(D, D.out[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
 }
@@ -1021,6 +1033,7 @@ struct NodeCtx {
   const SwDev& D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
+  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
   uint4 h0;
   __device__ NodeCtx(const SwDev& d, BlockStats& s) : D(d), S(s) {}
 
@@ -1147,22 +1160,26 @@ struct NodeCtx {
   // i.e. the memberlist queue and then the serf delegate's user events, for a ping/ack/... this node sent this
   // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
   // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
-  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area) {
+  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_meta) {
     const int limit = (int)D.budget - (int)D.ctl_len[kind & 3u];
     uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
     int used = 0, used2 = 0;
     HbmQ qm{D.q + l, NL}, qe{D.evq + l, NL};
-    uint32_t tm = get_broadcasts(D, qm, qlen, live_m, 2, limit, used), te = 0;
+    // the pick walks the queue several times: fetch the meta words once (independent loads), pick in LDS
+    MetaQ mm{lds_meta + threadIdx.x}, me{lds_meta + (size_t)D.Q * SW_BLOCK + threadIdx.x};
+    for (uint32_t j = 0; j < qlen; j++) mm.meta(j) = qm.at(j).w;
+    for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
+    uint32_t tm = get_broadcasts(D, mm, qlen, live_m, 2, limit, used), te = 0;
     int avail = limit - used;
-    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, qe, evqlen, live_e, 3, avail, used2);
+    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2);
     if (!(tm | te)) return;
     const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
-    S.add(ST_PIGGY); S.add(ST_PIGGY_MSGS, cnt);
-    for (uint32_t m = tm; m; m &= m - 1) S.add(ST_SENT0 + (int)m_type(qm.at(__ffs(m) - 1).w));
-    if (te) S.add(ST_SENT3, (uint32_t)__popc(te));
+    c_pig++;
+    for (uint32_t m = tm; m; m &= m - 1) { uint32_t ty = m_type(mm.meta(__ffs(m) - 1)); if (ty < 2) c_sent01 += 1u << (16 * ty); else c_sent23 += 1u << (16 * (ty - 2)); }
+    c_sent23 += (uint32_t)__popc(te) << 16;
     if (receiver != NONE) {
       const uint32_t gdst = r * D.N + receiver;
-      const bool att = (D.nw[gdst] & NW_ATTACHED) != 0;           // Transport.WriteTo towards the real node
+      const bool att = *D.att_any && (D.nw[gdst] & NW_ATTACHED);   // Transport.WriteTo towards the real node
       uint32_t pos = att ? 0 : atomicAdd(s_carry, cnt);
       if (!att && pos + cnt > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); pos = NONE; }
       for (uint32_t m = tm; m && pos != NONE; m &= m - 1) {
@@ -1174,10 +1191,17 @@ struct NodeCtx {
         if (att) capture(D, o, gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30); else area[pos++] = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
       }
     }
-    // retire what reached the retransmit limit (stable compaction, like the gossip role's write-back)
+    // write the bumped transmit counts back; retire what reached the retransmit limit (stable compaction,
+    // like the gossip role's write-back)
     uint32_t nq = 0, ne = 0;
-    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { if (nq != j) qm.at(nq) = qm.at(j); nq++; }
-    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) { if (ne != j) qe.at(ne) = qe.at(j); ne++; }
+    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) {
+      if (nq != j) { uint4 e = qm.at(j); e.w = mm.meta(j); qm.at(nq) = e; } else if ((tm >> j) & 1u) qm.at(j).w = mm.meta(j);
+      nq++;
+    }
+    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) {
+      if (ne != j) { uint4 e = qe.at(j); e.w = me.meta(j); qe.at(ne) = e; } else if ((te >> j) & 1u) qe.at(j).w = me.meta(j);
+      ne++;
+    }
     qlen = nq; evqlen = ne;
   }
   // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
@@ -1208,6 +1232,7 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
 }
 
 __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
+  extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry;
   if (D.fast_blocks) {                     // nothing reached this block of nodes: one word and out
@@ -1215,6 +1240,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   }
   if (threadIdx.x == 0) s_carry = 0;
   BlockStats S; S.init(lds_stats);
+  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
   if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
   size_t NL = (size_t)D.R * D.nloc;
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
@@ -1249,7 +1275,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         if (!have) break;
         uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
         if (best.y == SWIM_SUBJECT_PIGGY)
-          n.piggyback(best.z, type, &s_carry, D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + blockIdx.x) * D.carry_cap);
+          n.piggyback(best.z, type, &s_carry, D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + blockIdx.x) * D.carry_cap, lds_meta);
         else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
           uint32_t li = (n.t + 1) & 1u, sub = blockIdx.x % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
           uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
@@ -1263,10 +1289,16 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         have_last = true; lhi = bhi; llo = blo;
       }
       n.store();
+      c_pig = n.c_pig; c_sent01 = n.c_sent01; c_sent23 = n.c_sent23;
     }
   }
+  if (D.flags & SWIM_F_PIGGYBACK) {
+    uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
+    S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
+    S.wave_add(ST_SENT0, s0); S.wave_add(ST_SENT1, s1); S.wave_add(ST_SENT2, s2); S.wave_add(ST_SENT3, s3);
+  }
   S.flush(D);                                      // (barrier inside: every lane's carry reservations are in)
-  if (threadIdx.x == 0 && s_carry) D.carry_cnt[(size_t)((*D.tick + 1) & 1u) * D.NB + blockIdx.x] = s_carry;
+  if (threadIdx.x == 0 && s_carry) { D.carry_cl[blockIdx.x].x = s_carry; *D.carry_stamp = *D.tick + 1; }
 }
 
 // =================================================================================================
@@ -1462,6 +1494,7 @@ __global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
   if (threadIdx.x || blockIdx.x) return;
   size_t g = (size_t)r * D.N + x;
   uint32_t old = atomicOr(&D.nw[g], NW_ATTACHED);
+  *D.att_any = 1;
   bool local = x >= D.i0 && x < D.i0 + D.nloc;
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
