@@ -156,10 +156,30 @@ __device__ __forceinline__ void capture(const SwDev& D, uint32_t src, uint32_t g
 // kind, from = the prober); S picks the broadcasts in k_resolve.  An order for a node with nothing queued is a
 // no-op, so it is only filed when the block hint says S's block may hold something (k_deliver re-checks S's
 // header exactly, which makes the racy hint read harmless).
+// qbits: one bit per local lane, set exactly while the node has something queued (broadcasts or user events).
+// Set by whoever pushes (k_resolve, stimulus), cleared by whoever drains (gossip role, k_resolve's piggy-back pick).
+__device__ __forceinline__ bool q_bit(const SwDev& D, size_t l) { return (D.qbits[l >> 5] >> (l & 31)) & 1u; }
+// a whole wave of 64 consecutive, 64-aligned lanes publishes its transitions with at most two atomics per word
+__device__ __forceinline__ void q_bits_wave(const SwDev& D, size_t l, bool set, bool clr) {
+  uint64_t ms = __ballot(set), mc = __ballot(clr);
+  if (!(ms | mc)) return;
+  uint32_t lane = sw_lane();
+  if (lane == 0 || lane == 32) {
+    uint32_t s32 = (uint32_t)(ms >> lane), c32 = (uint32_t)(mc >> lane);
+    if (s32) atomicOr(&D.qbits[l >> 5], s32);
+    if (c32) atomicAnd(&D.qbits[l >> 5], ~c32);
+  }
+}
+__device__ __forceinline__ void q_bit_lane(const SwDev& D, size_t l, bool set, bool clr) {
+  if (set) atomicOr(&D.qbits[l >> 5], 1u << (l & 31));
+  if (clr) atomicAnd(&D.qbits[l >> 5], ~(1u << (l & 31)));
+}
+// The prober reads the bit while gossip blocks of the same launch may be clearing it: a stale 1 files an order
+// that k_deliver (which sees the settled bit) drops; a 0 is final, since only k_resolve sets bits.
 __device__ __forceinline__ bool piggy_hint(const SwDev& D, uint32_t r, uint32_t sender, uint32_t peer_active) {
   if (!(D.flags & SWIM_F_PIGGYBACK)) return false;
   if (sender < D.i0 || sender >= D.i0 + D.nloc) return peer_active != 0;
-  return !D.fast_blocks || D.q_any[((size_t)r * D.nloc + (sender - D.i0)) / SW_BLOCK] != 0;
+  return q_bit(D, (size_t)r * D.nloc + (sender - D.i0));
 }
 __device__ __forceinline__ uint4 piggy_rec(const SwDev& D, uint32_t r, uint32_t sender, uint32_t receiver, uint32_t kind, uint32_t prober) {
   return make_uint4(r * D.N + sender, SWIM_SUBJECT_PIGGY, receiver, (kind << 30) | (prober & 0x3FFFFFFFu));
@@ -702,6 +722,10 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
     uint32_t hy = h_pack(h_leaving(h.y), nq, ne);
     if (hy != h.y) { h.y = hy; D.hdr[l] = h; }
   }
+  {
+    const bool drained = active && !(nq | ne);
+    if (D.fast_blocks) q_bits_wave(D, l, false, drained); else q_bit_lane(D, l, false, drained);
+  }
   // dead nodes keep their (frozen) queues: the hint stays up while any node of the block holds one
   bool holds = (nq | ne) != 0;
   if (i != NONE && (wi & NW_INERT) && D.fast_blocks) holds = (h_qlen(h.y) | h_evqlen(h.y)) != 0;
@@ -897,8 +921,7 @@ __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, siz
   if (w & NW_ATTACHED) { if (rec.y != SWIM_SUBJECT_PIGGY) capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
   l = (size_t)r * D.nloc + (x - D.i0);
   if (rec.y == SWIM_SUBJECT_PIGGY) {               // a piggy-back order for a node with nothing queued is a no-op
-    uint32_t hy = D.hdr[l].y;                      // (headers do not change between k_begin and k_resolve)
-    if (!(h_qlen(hy) | h_evqlen(hy))) return NONE;
+    if (!q_bit(D, l) || (D.ablate & 256u)) return NONE;   // (queues do not change between k_begin and k_resolve)
   }
   return atomicAdd(&D.inbox1[l * 16], 1u);
 }
@@ -977,7 +1000,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
     uint32_t c_edges = 0, c_filt = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (cn[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
+      if (cn[j] && !(D.ablate & 128u)) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
     for (uint32_t a = b + 4 * D.n_seg; a < D.NB; a += D.n_seg) {      // only with very fine quanta (G > 4)
       uint2 cc = D.carry_cl[a]; uint32_t c = cc.x;
       __syncthreads();
@@ -1042,6 +1065,9 @@ struct NodeCtx {
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
+  // did the node go from "nothing queued" to "something queued" (or back) since load()?
+  __device__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
+  __device__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
   __device__ void store() {
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
@@ -1241,6 +1267,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   if (threadIdx.x == 0) s_carry = 0;
   BlockStats S; S.init(lds_stats);
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
+  bool q_set = false, q_clr = false;
   if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
   size_t NL = (size_t)D.R * D.nloc;
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
@@ -1290,8 +1317,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
       }
       n.store();
       c_pig = n.c_pig; c_sent01 = n.c_sent01; c_sent23 = n.c_sent23;
+      q_set = n.q_became_set(); q_clr = n.q_became_clr();
     }
   }
+  q_bits_wave(D, l, q_set, q_clr);
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
@@ -1483,6 +1512,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
           c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
         }
         c.store();
+        q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
       }
     }
   }
@@ -1499,6 +1529,7 @@ __global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
     uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.inbox1[l * 16] = 0;
+    q_bit_lane(D, l, false, true);
   }
 }
 __global__ void k_set_partition(SwDev D, uint32_t r, const uint8_t* group) {
@@ -1522,6 +1553,7 @@ __global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, 
       *ltime_out = lt;
       c.user_event(id, lt);
       c.store();
+      q_bit_lane(D, c.l, c.q_became_set(), c.q_became_clr());
     }
   }
   S.flush(D);
