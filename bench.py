@@ -52,14 +52,16 @@ def algorithmic_bytes(kernel: str, st: dict) -> float:
     """
     active, quiet = st["node_rounds_active"], st["node_rounds_quiescent"]
     pkts, msgs = st["packets_sent"], sum(st["msgs_sent"])
+    pb, pbm = st.get("piggybacks", 0), st.get("msgs_piggybacked", 0)   # carriers with a load / broadcasts they carried
     applied = sum(st["msgs_applied"])
-    if kernel == "k_begin":       # fused: gossip select/emit + probe (+ timers)
-        return (16.0 * (active + quiet) + 8.0 * (msgs / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * msgs
+    gm = msgs - pbm                                                     # broadcasts sent by gossip() itself
+    if kernel == "k_begin":       # fused: gossip select/emit + probe (+ timers); a piggy-back order is 8 B of the probe's 40
+        return (16.0 * (active + quiet) + 8.0 * (gm / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * gm
                 + 40.0 * st["probes"])
-    if kernel == "k_deliver":
-        return 4.0 * pkts + 4.0 * msgs
-    if kernel == "k_resolve":
-        return 8.0 * msgs + 24.0 * applied
+    if kernel == "k_deliver":     # gossip packets + the carried broadcasts (and their carriers' orders)
+        return 4.0 * (pkts + pb) + 4.0 * msgs
+    if kernel == "k_resolve":     # merges + the piggy-back pick (8 B queue slot per carried broadcast, read and written)
+        return 8.0 * msgs + 24.0 * applied + 16.0 * pbm
     return 0.0
 
 
