@@ -1257,10 +1257,11 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
   lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
+__global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(SwDev D) {
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry;
+  __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
   if (D.fast_blocks) {                     // nothing reached this block of nodes: one word and out
     if (!D.in_any[blockIdx.x]) return;
   }
@@ -1272,13 +1273,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
   size_t NL = (size_t)D.R * D.nloc;
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l < NL) {
-    // the whole 64-byte line (count + first five messages) in one go, kept in registers
+    // the whole 64-byte line (count + first five messages) in one go, parked in the lane's LDS column
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
     uint4 ra = row4[0];
     uint32_t cnt = ra.x;
     if (cnt) {
-      uint4 rb = row4[1], rc = row4[2], rd = row4[3];
+      s_in[0][threadIdx.x] = ra; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
       D.inbox1[l * 16] = 0;
+#define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
       const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
       NodeCtx n(D, S);
@@ -1289,11 +1291,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(SwDev D) {
         bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
         for (uint32_t j = 0; j < cnt; j++) {
           uint4 e;                                   // {-, subject, inc, meta}
-          if (j == 0) e = make_uint4(0, ra.y, ra.z, ra.w);
-          else if (j == 1) e = make_uint4(0, rb.x, rb.y, rb.z);
-          else if (j == 2) e = make_uint4(0, rb.w, rc.x, rc.y);
-          else if (j == 3) e = make_uint4(0, rc.z, rc.w, rd.x);
-          else if (j == 4) e = make_uint4(0, rd.y, rd.z, rd.w);
+          if (j < SW_INBOX_FAST) { uint32_t w = 1 + 3 * j; e = make_uint4(0, IN_WORD(w), IN_WORD(w + 1), IN_WORD(w + 2)); }
           else { const uint32_t* m = row2 + (j - SW_INBOX_FAST) * 3; e = make_uint4(0, m[0], m[1], m[2]); }
           uint64_t hi, lo; edge_key(e, hi, lo);
           if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;

@@ -11,7 +11,8 @@ for p in sorted(glob.glob(f"{root}/pass*/*/*_counter_collection.csv")):
     seq = collections.Counter()
     seen = {}
     for r in rows:
-        k = r["Kernel_Name"].split("(")[0]
+        import re as _re
+        _m = _re.search(r"\b(k_[a-z_]+)", r["Kernel_Name"]); k = _m.group(1) if _m else r["Kernel_Name"]
         did = r["Dispatch_Id"]
         if did not in seen:
             seen[did] = seq[k]; seq[k] += 1
