@@ -70,6 +70,8 @@ struct SwDev {
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
   uint32_t ablate;   // SWIMSIM_ABLATE env: timing experiments only (results invalid); 0 in normal use
+  // SWIMSIM_ROLECLK=<file>: per tick and k_begin role, earliest block start / latest block end (100 MHz clock)
+  unsigned long long* role_clk; uint32_t role_clk_ticks;
   uint64_t seed;
   // global clock (device resident so a captured graph is tick independent)
   uint32_t* tick;

@@ -220,6 +220,23 @@ static void drop_graphs(swim_sim* s) {
 extern "C" int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->D.role_clk && getenv("SWIMSIM_ROLECLK")) {          // diagnostics: per tick, per role: start/end of the role's blocks
+    std::vector<unsigned long long> raw((size_t)s->D.role_clk_ticks * 16 * 64), c((size_t)s->D.role_clk_ticks * 16);
+    if (hipMemcpy(raw.data(), s->D.role_clk, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (size_t i = 0; i < c.size() / 2; i++) { c[2 * i] = ~0ull; c[2 * i + 1] = 0; for (int k = 0; k < 64; k++) { c[2 * i] = std::min(c[2 * i], raw[(i * 64 + k) * 2]); c[2 * i + 1] = std::max(c[2 * i + 1], raw[(i * 64 + k) * 2 + 1]); } }
+      if (FILE* f = fopen(getenv("SWIMSIM_ROLECLK"), "a")) {
+        static const char* const names[8] = { "expire", "pending", "probe", "gossip", "ppreply", "carry", "pushpull", "-" };
+        for (uint32_t t = 0; t < s->D.role_clk_ticks && t < s->tick; t++) {
+          unsigned long long t0 = ~0ull;
+          for (int r = 0; r < 7; r++) if (c[(t * 8 + r) * 2 + 1]) t0 = std::min(t0, c[(t * 8 + r) * 2]);
+          fprintf(f, "tick %u", t);
+          for (int r = 0; r < 7; r++) if (c[(t * 8 + r) * 2 + 1]) fprintf(f, " %s %.1f-%.1f", names[r], (c[(t * 8 + r) * 2] - t0) / 100.0, (c[(t * 8 + r) * 2 + 1] - t0) / 100.0);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    }
+  }
   drop_graphs(s);
   for (void* p : s->allocs) (void)hipFree(p);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -258,9 +275,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
   if (const char* ab = getenv("SWIMSIM_ABLATE")) D.ablate = (uint32_t)strtoul(ab, nullptr, 0);
+  const bool want_role_clk = getenv("SWIMSIM_ROLECLK") != nullptr;
 
   const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S, NB = cdiv(NL, SW_BLOCK);
   DALLOC(s, D.tick, 1);
+  if (want_role_clk) { D.role_clk_ticks = 1024; DALLOC(s, D.role_clk, (size_t)D.role_clk_ticks * 16 * 64); }
   DALLOC(s, D.nw, NT);
   DALLOC(s, D.exc_list, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
@@ -287,7 +306,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
   pl.nb_pp = D.pp_period ? cdiv((uint64_t)cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period), SW_BLOCK) : 0;
-  pl.nb_ppreply = D.pp_period ? 4 : 0;
+  pl.nb_ppreply = D.pp_period ? SW_PP_LISTS : 0;   // one block per request sub-list (4 blocks were a 40 us long pole every ProbeInterval)
   pl.roles = D.pp_period ? 0x1F : 0xF;
   const bool piggy = (cfg->flags & SWIM_F_PIGGYBACK) != 0;
   pl.nb_carry = D.n_shards > 1 ? 64 : 0;
@@ -332,6 +351,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 
   hipStream_t st = s->stream;
   HIPCK(s, hipMemsetAsync(D.tick, 0, 4, st));
+  if (D.role_clk) { std::vector<unsigned long long> init((size_t)D.role_clk_ticks * 16 * 64); for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; } HIPCK(s, hipMemcpy(D.role_clk, init.data(), init.size() * 8, hipMemcpyHostToDevice)); }
   HIPCK(s, hipMemsetAsync(D.nw, 0, NT * 4, st));
   HIPCK(s, hipMemsetAsync(D.qbits, 0, (cdiv(NL, 32) + 2) * 4, st));
   HIPCK(s, hipMemsetAsync(D.exc_cnt, 0, D.R * 4, st)); HIPCK(s, hipMemsetAsync(D.exc_dirty, 0, D.R * 4, st));

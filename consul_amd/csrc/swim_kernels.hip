@@ -261,6 +261,7 @@ __device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint3
 // role: expire — suspectNode's time.AfterFunc.  Still Suspect when the (confirmation-shortened)
 // timeout lapses => deadNode(dead{inc, node, from: self}), delivered to self via the common inbox.
 // =================================================================================================
+__device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l, uint32_t pos);
 __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
   uint32_t per = nb / (D.R * D.S);                 // blocks per slot
   uint32_t sidx = b / per, part = b % per, r = sidx / D.S, sl = sidx % D.S;
@@ -280,7 +281,13 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         f[j] = f[j] && !(nw[D.i0 + kk[j]] & NW_INERT);
-        wave_append(D, D.rank, f[j], mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]));
+        // a timer is not a packet: the verdict goes straight into the node's own inbox line.  (When a whole
+        // cluster's suspicion of one node runs out within a few ticks, appending these to a shared list cost
+        // thousands of same-address atomics — the launch's long pole, profiles/r01_role_clock.txt.)
+        if (f[j]) {
+          size_t l = (size_t)r * D.nloc + kk[j];
+          inbox_place(D, mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]), l, atomicAdd(&D.inbox1[l * 16], 1u));
+        }
         fired += (uint32_t)f[j];
       }
     }
@@ -857,21 +864,27 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS], lds_exc[2 * SW_EXC_MAX];
   uint32_t b = blockIdx.x;
-  if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); return; }
+  // diagnostics (SWIMSIM_ROLECLK): when did the first block of a role start, when did its last block end
+  const unsigned long long t_in = D.role_clk ? wall_clock64() : 0;
+#define ROLE_DONE(id) do { if (D.role_clk && threadIdx.x == 0) { uint32_t tk = *D.tick; if (tk < D.role_clk_ticks) { \
+    unsigned long long* c = D.role_clk + (((size_t)tk * 8 + (id)) * 64 + (blockIdx.x & 63u)) * 2; atomicMin(c, t_in); atomicMax(c + 1, (unsigned long long)wall_clock64()); } } } while (0)
+  if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); ROLE_DONE(0); return; }
   b -= pl.nb_expire;
-  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, pl.peer_active); return; }
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, pl.peer_active); ROLE_DONE(1); return; }
   b -= pl.nb_pend;
-  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, pl.peer_active); return; }
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, pl.peer_active); ROLE_DONE(2); return; }
   b -= D.R * pl.nb_probe;
-  if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); return; }
+  if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
   b -= D.R * pl.nb_gossip;
-  if (b < pl.nb_ppreply) { if (pl.roles & 16u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); return; }
+  if (b < pl.nb_ppreply) { if (pl.roles & 16u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); ROLE_DONE(4); return; }
   b -= pl.nb_ppreply;
   if (MULTI) {
-    if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); return; }
+    if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); ROLE_DONE(5); return; }
     b -= pl.nb_carry;
   }
   if (pl.roles & 16u) role_pushpull(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
+  ROLE_DONE(6);
+#undef ROLE_DONE
 }
 typedef void (*BeginKernel)(SwDev, BeginPlan);
 // pick the leanest instantiation the configuration allows

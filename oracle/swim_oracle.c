@@ -589,8 +589,9 @@ static void phase_expire(swim_sim* s) {
         view_t* v = &t->col[k]; uint32_t o = s->i0 + k;
         if (KST(v->key) != SWIM_STATE_SUSPECT || !acts(s, r, o)) continue;
         if (now >= v->since + s->d.suspicion_timeout_ms[v->nconf]) {
-          emit(s, r, o, t->node, KINC(v->key), SWIM_MSG_DEAD, o);
-          s->st.suspicion_timeouts++;
+          /* a timer is not a packet: straight into the node's own inbox (not part of swim_debug_edges) */
+          ev_push(&s->in, mk_edge(s, r, o, t->node, KINC(v->key), SWIM_MSG_DEAD, o));
+          s->st.edges++; s->st.suspicion_timeouts++;
         }
       }
     }
