@@ -94,7 +94,8 @@ struct SwDev {
   uint4* ring;      // [EB][NL] {n<<30 | ltime, id0, id1, id2}
   // per-node inbox: one 64-byte line {count, 5 x 12-byte messages} that stays cache resident, plus an
   // overflow row for arrivals 6..C (a message = {subject, incarnation, type<<30|from})
-  uint32_t* inbox1; // [NL][16]
+  uint32_t* in_cnt; // [NL] arrivals this tick (dense: what the scatter's atomics work on)
+  uint32_t* inbox1; // [NL][16] word 0 unused, then 5 x 12-byte messages
   uint32_t* inbox2; // [NL][C2][3]
   // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
   uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue

@@ -286,7 +286,7 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
         // thousands of same-address atomics — the launch's long pole, profiles/r01_role_clock.txt.)
         if (f[j]) {
           size_t l = (size_t)r * D.nloc + kk[j];
-          inbox_place(D, mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]), l, atomicAdd(&D.inbox1[l * 16], 1u));
+          inbox_place(D, mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]), l, atomicAdd(&D.in_cnt[l], 1u));
         }
         fired += (uint32_t)f[j];
       }
@@ -936,7 +936,7 @@ __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, siz
   if (rec.y == SWIM_SUBJECT_PIGGY) {               // a piggy-back order for a node with nothing queued is a no-op
     if (!q_bit(D, l) || (D.ablate & 256u)) return NONE;   // (queues do not change between k_begin and k_resolve)
   }
-  return atomicAdd(&D.inbox1[l * 16], 1u);
+  return atomicAdd(&D.in_cnt[l], 1u);
 }
 // place: the message lands in the same line for the first SW_INBOX_FAST arrivals, else in the overflow row
 __device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l, uint32_t pos) {
@@ -1287,12 +1287,13 @@ __global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(SwDev D) {
   size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l < NL) {
     // the whole 64-byte line (count + first five messages) in one go, parked in the lane's LDS column
+    // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
+    // stay cache resident instead of pulling in the node's 64-byte message line)
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
-    uint4 ra = row4[0];
-    uint32_t cnt = ra.x;
+    uint32_t cnt = D.in_cnt[l];
     if (cnt) {
-      s_in[0][threadIdx.x] = ra; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-      D.inbox1[l * 16] = 0;
+      s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
+      D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
       const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
@@ -1461,7 +1462,7 @@ __global__ void k_init_nodes(SwDev D) {
   D.hdr[l] = make_uint4(1, 0, 0, 0);
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.inbox1[l * 16] = 0;
+  D.in_cnt[l] = 0;
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
@@ -1505,7 +1506,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
       if (local) {
         if (old & NW_DEAD) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
         uint2 h = D.ph[l];
-        D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.inbox1[l * 16] = 0;
+        D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.in_cnt[l] = 0;
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
@@ -1539,7 +1540,7 @@ __global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
   bool local = x >= D.i0 && x < D.i0 + D.nloc;
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
-    uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.inbox1[l * 16] = 0;
+    uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.in_cnt[l] = 0;
     q_bit_lane(D, l, false, true);
   }
 }
