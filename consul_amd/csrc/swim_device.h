@@ -142,7 +142,8 @@ struct SwDev {
                          // [1] the last tick in which k_deliver drained carry areas
   uint32_t carry_cap, NB, nb_carry;
   uint32_t* act;         // [1] sharded runs: this shard may hold a non-empty broadcast queue / emitted something
-  uint4* out[SW_MAX_SHARDS];
+  uint4* out[SW_MAX_SHARDS];       // host side only; device code goes through out_tab / out_cap_tab (global memory)
+  uint4** out_tab; uint32_t* out_cap_tab;
   uint32_t* out_cnt;     // [n_shards]
   uint32_t out_cap[SW_MAX_SHARDS];
   uint4* ctrl;           // slot requests seen this tick
@@ -157,6 +158,13 @@ struct SwDev {
   unsigned long long* stats;
   uint32_t* err;
 };
+
+// Kernels receive a POINTER to the (read-only) descriptor and read it through the constant address space: fields
+// are fetched with scalar loads where they are used.  Passing the ~1 KB struct by value made the compiler copy it
+// to scratch memory whenever a helper taking `const SwDev&` was not inlined (fan-out > 4 and sharded variants of
+// k_begin: ~1 KB of scratch per lane and 300+ scratch loads per kernel).
+typedef const __attribute__((address_space(4))) SwDev& DevRef;
+#define SW_DEV_BIND DevRef D = *(const __attribute__((address_space(4))) SwDev*)Dp;
 
 // block ranges of the fused first launch of a tick
 struct BeginPlan {

@@ -38,6 +38,7 @@ struct swim_sim {
   uint32_t tick = 0;
   bool in_tick = false;
   uint64_t ticks_run = 0, rounds_run = 0;
+  SwDev* d_D = nullptr;                // the descriptor the kernels read (device copy of D)
   uint32_t* d_last_cnt = nullptr;      // [n_shards] edge counts of the finished tick
   uint32_t* d_scratch = nullptr;       // small device scratch (ids upload, ltime, digest, node gather)
   size_t scratch_bytes = 0;
@@ -340,6 +341,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     D.out_cap[sh] = (uint32_t)cap;
     DALLOC(s, D.out[sh], cap);
   }
+  DALLOC(s, D.out_tab, SW_MAX_SHARDS); DALLOC(s, D.out_cap_tab, SW_MAX_SHARDS);
+  HIPCK(s, hipMemcpy(D.out_tab, D.out, sizeof D.out, hipMemcpyHostToDevice)); HIPCK(s, hipMemcpy(D.out_cap_tab, D.out_cap, sizeof D.out_cap, hipMemcpyHostToDevice));
   DALLOC(s, D.out_cnt, SW_MAX_SHARDS + 1); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
   D.act = D.out_cnt + D.n_shards;                  // rides behind the counts so one gather fetches both
   D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
@@ -374,9 +377,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     HIPCK(s, hipMemsetAsync(D.ring, 0, NL * D.EB * sizeof(uint4), st));
   }
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
-  hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_init_views, dim3(cdiv(NS * D.nloc, 256)), dim3(256), 0, st, D);
-  hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, D);
+  DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
+  HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_init_views, dim3(cdiv(NS * D.nloc, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
   *out = s;
@@ -395,28 +400,28 @@ static void launch_begin(swim_sim* s) {
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
-    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, a); }
-    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, b); }
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, a); }
+    { ProfScope p(s, PK_BEGIN); hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, b); }
   } else {
     ProfScope p(s, PK_BEGIN);
-    hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, D, pl);
+    hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
   }
 }
 static void launch_end(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, D); }
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
-    hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, D,
+    hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D,
                        (const uint4*)s->in_buf, s->in_count);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), ((D.flags & SWIM_F_PIGGYBACK) && !(D.ablate & 64u)) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), ((D.flags & SWIM_F_PIGGYBACK) && !(D.ablate & 64u)) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
   // blocks per subject slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
-  { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, D); }
-  { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, D, s->d_last_cnt); }
+  { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
   s->in_count = 0;
 }
 static void advance(swim_sim* s, uint32_t n) {
@@ -579,9 +584,9 @@ static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n
   if (rc || !n) return rc;
   touched(s);
   if (op == INJ_LEAVE || op == INJ_UPDATE)
-    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
-  hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, s->D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
-  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);   // node words changed
+    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);   // node words changed
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
@@ -596,18 +601,18 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
   for (uint32_t i = 0; i < s->D.N; i++) if (g[i] > 127) return SWIM_ERANGE;   // 7 bits of the node word
   touched(s);
   HIPCK(s, hipMemcpyAsync(s->d_scratch, g, s->D.N, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, s->D, r, (const uint8_t*)s->d_scratch);
-  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);
+  hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, (const SwDev*)s->d_D, r, (const uint8_t*)s->d_scratch);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
 extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
   if (!s) return SWIM_EINVAL;
-  if (s->D.loss_q32 != q) {       // kernel arguments are baked into a captured graph
+  if (s->D.loss_q32 != q) {       // the kernels read the descriptor from device memory: update it in place
     (void)hipStreamSynchronize(s->stream);
-    drop_graphs(s);
+    s->D.loss_q32 = q;
+    HIPCK(s, hipMemcpy(s->d_D, &s->D, sizeof s->D, hipMemcpyHostToDevice));
   }
-  s->D.loss_q32 = q;
   return SWIM_OK;
 }
 extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
@@ -615,7 +620,7 @@ extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_
   if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
   if (r >= s->D.R || origin >= s->D.N) return SWIM_ERANGE;
   touched(s);
-  hipLaunchKernelGGL(k_user_event, dim3(1), dim3(64), 0, s->stream, s->D, r, origin, id, s->d_scratch);
+  hipLaunchKernelGGL(k_user_event, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, origin, id, s->d_scratch);
   uint32_t v = SWIM_NONE;
   HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
@@ -704,7 +709,7 @@ extern "C" int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || i >= D.N || !is_local(s, i)) return SWIM_ERANGE;
-  hipLaunchKernelGGL(k_gather_node, dim3(1), dim3(64), 0, s->stream, D, r, i, s->d_scratch);
+  hipLaunchKernelGGL(k_gather_node, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, i, s->d_scratch);
   uint32_t w[16 + 4 * 32]; int rc = d2h(s, w, (const uint32_t*)s->d_scratch, 16 + 4 * 32);
   if (rc) return rc;
   memset(out, 0, sizeof *out);
@@ -730,7 +735,7 @@ extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census*
   if (rc) return rc;
   if (!NW_HAS_SLOT(w)) {
     HIPCK(s, hipMemsetAsync(s->d_scratch, 0, 4, s->stream));
-    hipLaunchKernelGGL(k_count_live, dim3(std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256)), dim3(SW_BLOCK), 0, s->stream, D, r, x, s->d_scratch);
+    hipLaunchKernelGGL(k_count_live, dim3(std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, x, s->d_scratch);
     uint32_t n = 0; if ((rc = d2h(s, &n, (const uint32_t*)s->d_scratch, 1))) return rc;
     memset(out, 0, sizeof *out);
     out->n_observers = out->by_state[SWIM_STATE_ALIVE] = out->n_current = n;
@@ -738,8 +743,8 @@ extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census*
     return SWIM_OK;
   }
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 8), 16));
-  hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D);
-  hipLaunchKernelGGL(k_census_commit, dim3(1), dim3(SW_BLOCK), 0, s->stream, D);
+  hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_census_commit, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D);
   return d2h(s, out, (const swim_census*)D.census + (size_t)r * D.S + NW_SLOT(w), 1);
 }
 extern "C" int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
@@ -824,8 +829,8 @@ extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
   unsigned long long* acc = (unsigned long long*)s->d_scratch;   // 64 partials, one 64-byte line each
   HIPCK(s, hipMemsetAsync(acc, 0, 64 * 8 * 8, s->stream));
   const size_t NL = (size_t)D.R * D.nloc;
-  hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, D, acc);
-  hipLaunchKernelGGL(k_digest_views, dim3(std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64)), D.R * D.S), dim3(SW_BLOCK), 0, s->stream, D, acc);
+  hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
+  hipLaunchKernelGGL(k_digest_views, dim3(std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64)), D.R * D.S), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
   unsigned long long v[64 * 8]; int rc = d2h(s, v, (const unsigned long long*)acc, 64 * 8);
   if (rc) return rc;
   uint64_t d = 0;
@@ -867,8 +872,8 @@ static int attach(swim_sim* s, uint32_t r, uint32_t a) {
   if (r >= s->D.R || a >= s->D.N) return SWIM_ERANGE;
   uint64_t key = ((uint64_t)r << 32) | a;
   if (std::find(s->attached.begin(), s->attached.end(), key) != s->attached.end()) return SWIM_OK;
-  hipLaunchKernelGGL(k_attach, dim3(1), dim3(64), 0, s->stream, s->D, r, a);
-  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, s->D, r);
+  hipLaunchKernelGGL(k_attach, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, a);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));
   s->attached.push_back(key);
   return SWIM_OK;
@@ -889,11 +894,11 @@ extern "C" int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint
   uint8_t* scratch = (uint8_t*)s->d_scratch;
   if (!subj.empty()) {            // a rumour about somebody new needs a view column first
     HIPCK(s, hipMemcpyAsync(scratch, subj.data(), subj.size() * 4, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, s->D, r, (const uint32_t*)scratch, (uint32_t)subj.size());
+    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)scratch, (uint32_t)subj.size());
   }
   uint8_t* drec = scratch + ((subj.size() * 4 + 15) & ~(size_t)15);
   HIPCK(s, hipMemcpyAsync(drec, recs.data(), n * sizeof(swim_edge), hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_deliver_list, dim3(cdiv(n, SW_BLOCK * 4)), dim3(SW_BLOCK), 0, s->stream, s->D, (const uint4*)drec, (uint32_t)n);
+  hipLaunchKernelGGL(k_deliver_list, dim3(cdiv(n, SW_BLOCK * 4)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (const uint4*)drec, (uint32_t)n);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }

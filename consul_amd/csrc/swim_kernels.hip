@@ -38,11 +38,21 @@ __device__ __forceinline__ uint32_t m_pack(uint32_t type, uint32_t tr, uint32_t 
   return (type << 30) | (tr << 22) | (seq & 0x3FFFFFu);
 }
 
-__device__ __forceinline__ uint64_t seed_of(const SwDev& D, uint32_t r) { return D.seed + r; }
-__device__ __forceinline__ uint32_t now_ms(const SwDev& D, uint32_t t) { return t * D.quantum_ms; }
+// The kernel argument struct lives in SGPRs / the constant cache.  Indexing one of its member arrays with a per-lane
+// value makes the compiler copy the WHOLE struct to scratch memory and read every field from there (seen in the
+// fan-out > 4 and sharded variants: ~1 KB of scratch per lane, 300+ scratch loads) — so: select chains for the small
+// tables, and tables in global memory (out_tab, out_cap_tab) for the per-shard lists.
+// (by value: binding a reference to a member array would itself force the struct into memory)
+__device__ __forceinline__ uint32_t sel4v(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t i) {
+  return (i & 2u) ? ((i & 1u) ? a3 : a2) : ((i & 1u) ? a1 : a0);
+}
+#define sel4(a, i) sel4v((a)[0], (a)[1], (a)[2], (a)[3], (i))
+#define sel8(a, i) ((((i) & 4u) ? sel4v((a)[4], (a)[5], (a)[6], (a)[7], (i)) : sel4v((a)[0], (a)[1], (a)[2], (a)[3], (i))))
+__device__ __forceinline__ uint64_t seed_of(DevRef D, uint32_t r) { return D.seed + r; }
+__device__ __forceinline__ uint32_t now_ms(DevRef D, uint32_t t) { return t * D.quantum_ms; }
 
 // observer (r, local k) looking at the node whose word is `w`; base view unless it owns a slot
-__device__ __forceinline__ uint32_t view_of(const SwDev& D, uint32_t r, uint32_t k, uint32_t w, uint32_t* since) {
+__device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t w, uint32_t* since) {
   if (!NW_HAS_SLOT(w)) { *since = 0; return SW_BASE_KEY; }
   size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + k;
   uint4 a = D.va[ci];
@@ -50,7 +60,7 @@ __device__ __forceinline__ uint32_t view_of(const SwDev& D, uint32_t r, uint32_t
   return a.x;
 }
 
-__device__ __forceinline__ bool lost(const SwDev& D, uint32_t r, uint32_t t, uint32_t node, uint32_t leg) {
+__device__ __forceinline__ bool lost(DevRef D, uint32_t r, uint32_t t, uint32_t node, uint32_t leg) {
   if (!D.loss_q32) return false;
   uint32_t w[4];
   uint64_t s = seed_of(D, r);
@@ -58,7 +68,7 @@ __device__ __forceinline__ bool lost(const SwDev& D, uint32_t r, uint32_t t, uin
   return w[0] < D.loss_q32;
 }
 // can a packet from the (running) node with word wa reach the node with word wb right now
-__device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, uint32_t wa, uint32_t wb, uint32_t rng_node, uint32_t leg) {
+__device__ __forceinline__ bool reach(DevRef D, uint32_t r, uint32_t t, uint32_t wa, uint32_t wb, uint32_t rng_node, uint32_t leg) {
   if ((wb & NW_DEAD) || NW_PART(wa) != NW_PART(wb)) return false;
   return !lost(D, r, t, rng_node, leg);
 }
@@ -66,7 +76,7 @@ __device__ __forceinline__ bool reach(const SwDev& D, uint32_t r, uint32_t t, ui
 // ---- the replica's exception list, staged in LDS by the first SW_EXC_MAX lanes of a block ----------
 struct ExcList {
   uint32_t* id; uint32_t* w; uint32_t n;           // n > SW_EXC_MAX: unusable, fall back to nw
-  __device__ void stage(const SwDev& D, uint32_t r, uint32_t* lds) {   // caller provides the barrier
+  __device__ void stage(DevRef D, uint32_t r, uint32_t* lds) {   // caller provides the barrier
     id = lds; w = lds + SW_EXC_MAX;
     n = D.exc_cnt[r];
     if (threadIdx.x < SW_EXC_MAX && threadIdx.x < n && n <= SW_EXC_MAX) {
@@ -84,7 +94,7 @@ struct ExcList {
 };
 
 // ---- statistics: per-block LDS counters, flushed once --------------------------------------------
-__device__ __forceinline__ unsigned long long* stat_ptr(const SwDev& D, int i) {
+__device__ __forceinline__ unsigned long long* stat_ptr(DevRef D, int i) {
   return &D.stats[(size_t)(blockIdx.x % SW_STAT_COPIES) * SW_STAT_STRIDE + i];
 }
 struct BlockStats {
@@ -106,7 +116,7 @@ struct BlockStats {
     uint64_t m = __ballot(pred);
     if (m && sw_lane() == 0) atomicAdd(&s[i], (uint32_t)__popcll(m));
   }
-  __device__ void flush(const SwDev& D) {
+  __device__ void flush(DevRef D) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ST_COUNT; i += blockDim.x)
       if (s[i]) atomicAdd(stat_ptr(D, i), (unsigned long long)s[i]);
@@ -115,7 +125,7 @@ struct BlockStats {
 
 // ---- wave-aggregated append of at most one record per lane ------------------------------------
 // ballot the lanes that have a record, one atomicAdd per wave, prefix rank by popcount
-__device__ __forceinline__ void wave_append(const SwDev& D, uint32_t sh, bool want, uint4 rec) {
+__device__ __forceinline__ void wave_append(DevRef D, uint32_t sh, bool want, uint4 rec) {
   uint64_t mask = __ballot(want);
   if (!mask) return;
   uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1, base = 0;
@@ -123,12 +133,12 @@ __device__ __forceinline__ void wave_append(const SwDev& D, uint32_t sh, bool wa
   base = __shfl(base, leader);
   if (want) {
     uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-    if (pos < D.out_cap[sh]) D.out[sh][pos] = rec;
+    if (pos < D.out_cap_tab[sh]) D.out_tab[sh][pos] = rec;
     else atomicOr(D.err, SW_ERR_EDGE_OVF);
   }
 }
 // the destination shard differs per lane: one aggregated append per shard present in the wave
-__device__ __forceinline__ void wave_append_sharded(const SwDev& D, bool want, uint32_t sh, uint4 rec) {
+__device__ __forceinline__ void wave_append_sharded(DevRef D, bool want, uint32_t sh, uint4 rec) {
   if (D.n_shards == 1) { wave_append(D, 0, want, rec); return; }
   uint64_t todo = __ballot(want);
   while (todo) {
@@ -139,12 +149,12 @@ __device__ __forceinline__ void wave_append_sharded(const SwDev& D, bool want, u
     todo &= ~__ballot(mine);
   }
 }
-__device__ __forceinline__ uint4 mk_edge(const SwDev& D, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
+__device__ __forceinline__ uint4 mk_edge(DevRef D, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
   return make_uint4(r * D.N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu));
 }
 
 // memberlist.Transport bridge: a rumour for an attached node is handed to the host instead of an inbox
-__device__ __forceinline__ void capture(const SwDev& D, uint32_t src, uint32_t gdst, uint32_t subject, uint32_t inc, uint32_t meta) {
+__device__ __forceinline__ void capture(DevRef D, uint32_t src, uint32_t gdst, uint32_t subject, uint32_t inc, uint32_t meta) {
   uint32_t pos = atomicAdd(D.cap_cnt, 1u);
   if (pos < D.cap_cap) { D.cap[pos] = make_uint4(src, subject, inc, meta); D.cap_dst[pos] = gdst; }
   else atomicOr(D.err, SW_ERR_EVENT_OVF);
@@ -158,9 +168,9 @@ __device__ __forceinline__ void capture(const SwDev& D, uint32_t src, uint32_t g
 // header exactly, which makes the racy hint read harmless).
 // qbits: one bit per local lane, set exactly while the node has something queued (broadcasts or user events).
 // Set by whoever pushes (k_resolve, stimulus), cleared by whoever drains (gossip role, k_resolve's piggy-back pick).
-__device__ __forceinline__ bool q_bit(const SwDev& D, size_t l) { return (D.qbits[l >> 5] >> (l & 31)) & 1u; }
+__device__ __forceinline__ bool q_bit(DevRef D, size_t l) { return (D.qbits[l >> 5] >> (l & 31)) & 1u; }
 // a whole wave of 64 consecutive, 64-aligned lanes publishes its transitions with at most two atomics per word
-__device__ __forceinline__ void q_bits_wave(const SwDev& D, size_t l, bool set, bool clr) {
+__device__ __forceinline__ void q_bits_wave(DevRef D, size_t l, bool set, bool clr) {
   uint64_t ms = __ballot(set), mc = __ballot(clr);
   if (!(ms | mc)) return;
   uint32_t lane = sw_lane();
@@ -170,25 +180,25 @@ __device__ __forceinline__ void q_bits_wave(const SwDev& D, size_t l, bool set, 
     if (c32) atomicAnd(&D.qbits[l >> 5], ~c32);
   }
 }
-__device__ __forceinline__ void q_bit_lane(const SwDev& D, size_t l, bool set, bool clr) {
+__device__ __forceinline__ void q_bit_lane(DevRef D, size_t l, bool set, bool clr) {
   if (set) atomicOr(&D.qbits[l >> 5], 1u << (l & 31));
   if (clr) atomicAnd(&D.qbits[l >> 5], ~(1u << (l & 31)));
 }
 // The prober reads the bit while gossip blocks of the same launch may be clearing it: a stale 1 files an order
 // that k_deliver (which sees the settled bit) drops; a 0 is final, since only k_resolve sets bits.
-__device__ __forceinline__ bool piggy_hint(const SwDev& D, uint32_t r, uint32_t sender, uint32_t peer_active) {
+__device__ __forceinline__ bool piggy_hint(DevRef D, uint32_t r, uint32_t sender, uint32_t peer_active) {
   if (!(D.flags & SWIM_F_PIGGYBACK)) return false;
   if (sender < D.i0 || sender >= D.i0 + D.nloc) return peer_active != 0;
   return q_bit(D, (size_t)r * D.nloc + (sender - D.i0));
 }
-__device__ __forceinline__ uint4 piggy_rec(const SwDev& D, uint32_t r, uint32_t sender, uint32_t receiver, uint32_t kind, uint32_t prober) {
+__device__ __forceinline__ uint4 piggy_rec(DevRef D, uint32_t r, uint32_t sender, uint32_t receiver, uint32_t kind, uint32_t prober) {
   return make_uint4(r * D.N + sender, SWIM_SUBJECT_PIGGY, receiver, (kind << 30) | (prober & 0x3FFFFFFFu));
 }
 
 // ---- stagger: which nodes act in tick t --------------------------------------------------------
 // chunk c = id / CH; gossip phase = c % G; probe phase = (c / G) % P.  Enumerate the active set
 // compactly: index a -> node id i (or NONE).  CH is a power of two.
-__device__ __forceinline__ uint32_t map_gossip(const SwDev& D, uint32_t ph, uint32_t a) {
+__device__ __forceinline__ uint32_t map_gossip(DevRef D, uint32_t ph, uint32_t a) {
   uint32_t sh = __ffs(D.CH) - 1;
   uint32_t c0 = D.i0 >> sh, c1 = (D.i0 + D.nloc + D.CH - 1) >> sh;
   uint32_t q_lo = c0 > ph ? (c0 - ph + D.G - 1) / D.G : 0;
@@ -197,7 +207,7 @@ __device__ __forceinline__ uint32_t map_gossip(const SwDev& D, uint32_t ph, uint
   uint32_t i = (c << sh) + (a & (D.CH - 1));
   return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
 }
-__device__ __forceinline__ uint32_t map_probe(const SwDev& D, uint32_t ph, uint32_t a) {
+__device__ __forceinline__ uint32_t map_probe(DevRef D, uint32_t ph, uint32_t a) {
   uint32_t sh = __ffs(D.CH) - 1;
   uint32_t c0 = D.i0 >> sh, c1 = (D.i0 + D.nloc + D.CH - 1) >> sh;
   uint32_t u_lo = c0 / D.G;
@@ -209,7 +219,7 @@ __device__ __forceinline__ uint32_t map_probe(const SwDev& D, uint32_t ph, uint3
   return (i < D.i0 + D.nloc && i >= D.i0) ? i : NONE;
 }
 
-__device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw, int delta) {
+__device__ __forceinline__ uint32_t awareness_apply(DevRef D, uint32_t aw, int delta) {
   int v = (int)aw + delta, mx = (int)D.awareness_max - 1;
   return (uint32_t)(v < 0 ? 0 : v > mx ? mx : v);
 }
@@ -218,7 +228,7 @@ __device__ __forceinline__ uint32_t awareness_apply(const SwDev& D, uint32_t aw,
 // mode 0 = gossip() (skip Left, and Dead for longer than GossipToTheDeadTime);
 // mode 1 = probeNode's indirect helpers (skip the target and anything not Alive).
 // wout[] receives the picked nodes' words so the caller needs no second lookup.
-__device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
+__device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
                                    uint32_t stream, uint32_t want, int mode, uint32_t target,
                                    uint32_t* out, uint32_t* wout, const ExcList& X) {
   SwDraws d; d.init(seed_of(D, r), stream, t, o);
@@ -261,8 +271,8 @@ __device__ uint32_t k_random_nodes(const SwDev& D, uint32_t r, uint32_t o, uint3
 // role: expire — suspectNode's time.AfterFunc.  Still Suspect when the (confirmation-shortened)
 // timeout lapses => deadNode(dead{inc, node, from: self}), delivered to self via the common inbox.
 // =================================================================================================
-__device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l, uint32_t pos);
-__device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
+__device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos);
+__device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
   uint32_t per = nb / (D.R * D.S);                 // blocks per slot
   uint32_t sidx = b / per, part = b % per, r = sidx / D.S, sl = sidx % D.S;
   if (sl >= D.n_slots[r]) return;
@@ -276,7 +286,7 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { kk[j] = k0 + j * per * SW_BLOCK + threadIdx.x; v[j] = kk[j] < D.nloc ? D.va[(size_t)sidx * D.nloc + kk[j]] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
-    for (int j = 0; j < 4; j++) { f[j] = kk[j] < D.nloc && SW_KST(v[j].x) == SWIM_STATE_SUSPECT && now >= v[j].y + D.susp_timeout[v[j].z & 7u]; any_f |= f[j]; }
+    for (int j = 0; j < 4; j++) { f[j] = kk[j] < D.nloc && SW_KST(v[j].x) == SWIM_STATE_SUSPECT && now >= v[j].y + sel8(D.susp_timeout, v[j].z & 7u); any_f |= f[j]; }
     if (__any(any_f)) {                             // rare: only now look at liveness and append
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -303,7 +313,7 @@ __device__ void role_expire(const SwDev& D, uint32_t b, uint32_t nb) {
 // alive peers; each relays the target's ack or (Lifeguard) answers nack one ProbeTimeout later.
 // =================================================================================================
 template <int KMAX>
-__device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats, uint32_t peer_active) {
+__device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats, uint32_t peer_active) {
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
   if (t >= D.TQ) {
@@ -356,7 +366,7 @@ __device__ void role_pending(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 // Hot path per lane: own word, 8 B of probe state, one Feistel evaluation, the target's word.
 // =================================================================================================
 template <bool MULTI>
-__device__ void role_probe(const SwDev& D, uint32_t r, uint32_t pb, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc, uint32_t* s_cnt, uint32_t peer_active) {
+__device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc, uint32_t* s_cnt, uint32_t peer_active) {
   ExcList X; X.stage(D, r, lds_exc);
   if (threadIdx.x == 0) s_cnt[0] = 0;
   BlockStats S; S.init(lds_stats);
@@ -473,10 +483,10 @@ __device__ void role_probe(const SwDev& D, uint32_t r, uint32_t pb, uint32_t a, 
 // =================================================================================================
 
 // limitedBroadcast.Less: transmits asc, msgLen desc, id desc
-__device__ __forceinline__ bool ent_before(const SwDev& D, uint32_t ma, uint32_t mb) {
+__device__ __forceinline__ bool ent_before(DevRef D, uint32_t ma, uint32_t mb) {
   uint32_t ta = m_tr(ma), tb = m_tr(mb);
   if (ta != tb) return ta < tb;
-  uint32_t la = D.msg_len[m_type(ma)], lb = D.msg_len[m_type(mb)];
+  uint32_t la = sel4(D.msg_len, m_type(ma)), lb = sel4(D.msg_len, m_type(mb));
   if (la != lb) return la > lb;
   return m_seq(ma) > m_seq(mb);
 }
@@ -486,7 +496,7 @@ __device__ __forceinline__ bool ent_before(const SwDev& D, uint32_t ma, uint32_t
 // decrease): an older incarnation, or the same incarnation in a state the message cannot move.  One
 // random 16-byte read of the receiver's view replaces an edge write, an inbox atomic and a merge.
 // `a` = the receiver's va record of the subject, `e` = the queue entry {subject, inc, from, meta}.
-__device__ __forceinline__ bool noop_given_view(const SwDev& D, uint4 a, size_t ci, uint4 e) {
+__device__ __forceinline__ bool noop_given_view(DevRef D, uint4 a, size_t ci, uint4 e) {
   uint32_t type = m_type(e.w), key = a.x, vinc = SW_KINC(key), st = SW_KST(key);
   if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
   if (e.y != vinc) return e.y < vinc;
@@ -511,7 +521,7 @@ struct MetaQ { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j
 // one GetBroadcasts(overhead, limit) over a queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
 template <typename QV>
-__device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
+__device__ uint32_t get_broadcasts(DevRef D, QV sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
   uint32_t taken = 0; int used = 0;
   for (;;) {
     int free_b = limit - used - (int)overhead;
@@ -520,11 +530,11 @@ __device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& 
     for (uint32_t j = 0; j < n; j++) {
       if (!((live >> j) & 1u) || ((taken >> j) & 1u)) continue;
       uint32_t meta = sq.meta(j);
-      if ((int)D.msg_len[m_type(meta)] > free_b) continue;
+      if ((int)sel4(D.msg_len, m_type(meta)) > free_b) continue;
       if (best == NONE || ent_before(D, meta, bmeta)) { best = j; bmeta = meta; }
     }
     if (best == NONE) break;
-    taken |= 1u << best; used += (int)(overhead + D.msg_len[m_type(bmeta)]);
+    taken |= 1u << best; used += (int)(overhead + sel4(D.msg_len, m_type(bmeta)));
   }
   for (uint32_t j = 0; j < n; j++) {
     if (!((taken >> j) & 1u)) continue;
@@ -544,7 +554,7 @@ __device__ uint32_t get_broadcasts(const SwDev& D, QV sq, uint32_t n, uint32_t& 
 //   trip 1  own node word + header            trip 3  subject node words (slot of each queued rumour)
 //   trip 2  queue entries + 4 candidate peers  trip 4  the receivers' view records for the no-op filter
 template <int KMAX, bool SERF, bool MULTI>
-__device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base, uint32_t* lds_exc) {
+__device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base, uint32_t* lds_exc) {
   uint32_t t = *D.tick;
   uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
   // a block is one stagger chunk of 256 consecutive nodes: if none of them has anything queued the
@@ -695,7 +705,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
       uint32_t c = s_cnt[threadIdx.x], b = 0;
       if (c) {
         b = atomicAdd(&D.out_cnt[threadIdx.x], c);
-        if (b + c > D.out_cap[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
+        if (b + c > D.out_cap_tab[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
         atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c);
         atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);
       }
@@ -706,7 +716,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
   for (uint32_t p = 0; p < np; p++) {
     uint4* dst;
     if (PKT_SH(p) == D.rank) { dst = D.seg + (size_t)segb * D.seg_cap + my_off; my_off += PKT_N(p); }
-    else { uint32_t b = s_base[PKT_SH(p)]; if (b == NONE) continue; dst = D.out[PKT_SH(p)] + b + loc[MULTI ? p : 0]; }
+    else { uint32_t b = s_base[PKT_SH(p)]; if (b == NONE) continue; dst = D.out_tab[PKT_SH(p)] + b + loc[MULTI ? p : 0]; }
     uint32_t gdst = r * D.N + peers[p];
     for (uint32_t m = sent_m[p]; m; m &= m - 1) {
       uint4 e = sq[(__ffs(m) - 1) * SW_BLOCK];
@@ -753,7 +763,7 @@ __device__ void role_gossip(const SwDev& D, uint32_t r, uint32_t bx, uint4* lds_
 // =================================================================================================
 // Every lane of the wave calls this together (`on` = the lane takes part); the records of a wave are
 // appended with one atomic per destination shard, never one per record.
-__device__ void send_state(const SwDev& D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
+__device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
   uint32_t ns = on ? D.n_slots[r] : 0, ns_max = ns;
   for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(ns_max, off); ns_max = v > ns_max ? v : ns_max; }
   const uint32_t sh = on ? dst / D.nloc : 0;
@@ -780,7 +790,7 @@ __device__ void send_state(const SwDev& D, bool on, uint32_t r, uint32_t owner, 
     c_edges += want; c_remote += want && sh != D.rank;
   }
 }
-__device__ void role_pushpull(const SwDev& D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
+__device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
   uint32_t t = *D.tick;
   if (t % D.P) return;                              // exchanges start on probe-interval boundaries only
   ExcList X; X.stage(D, r, lds_exc);
@@ -809,7 +819,7 @@ __device__ void role_pushpull(const SwDev& D, uint32_t r, uint32_t a, uint32_t* 
 }
 // pull requests are filed in 64 sub-lists (k_resolve picks one by block) so that no counter is hot
 #define SW_PP_LISTS 64
-__device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+__device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   uint32_t t = *D.tick, li = t & 1u;
   if (t == 0 || (t - 1) % D.P) return;              // requests only exist the tick after a boundary
   BlockStats S; S.init(lds_stats);
@@ -835,7 +845,7 @@ __device__ void role_ppreply(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* 
 // private areas; the ones addressed to other shards move to those shards' lists and are voided in place,
 // the rest is delivered (and filtered) by k_deliver like in an unsharded run.
 // =================================================================================================
-__device__ void role_carry(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
+__device__ __forceinline__ void role_carry(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   if (*D.carry_stamp != *D.tick) return;            // nothing was piggy-backed last tick
   BlockStats S; S.init(lds_stats);
   const uint32_t par = *D.tick & 1u;
@@ -859,7 +869,8 @@ __device__ void role_carry(const SwDev& D, uint32_t b, uint32_t nb, uint32_t* ld
 // dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
 // =================================================================================================
 template <int KMAX, bool SERF, bool MULTI>
-__global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
+__global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp, BeginPlan pl) {
+  SW_DEV_BIND
   extern __shared__ uint4 lds_q[];
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS], lds_exc[2 * SW_EXC_MAX];
@@ -886,7 +897,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(SwDev D, BeginPlan pl) {
   ROLE_DONE(6);
 #undef ROLE_DONE
 }
-typedef void (*BeginKernel)(SwDev, BeginPlan);
+typedef void (*BeginKernel)(const SwDev*, BeginPlan);
 // pick the leanest instantiation the configuration allows
 static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
   const bool k8 = fanout > 4;
@@ -903,7 +914,7 @@ static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
 // the first request to flip the node word's slot field to the "being granted" pattern wins, later
 // duplicates (other probers, other shards) see a non-zero field and leave.  Which index a subject gets is
 // not observable: everything the ABI reports is keyed by node id.
-__device__ void grant_slot(const SwDev& D, uint32_t r, uint32_t x) {
+__device__ void grant_slot(DevRef D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
   uint32_t w = D.nw[g];
   if (NW_HAS_SLOT(w)) return;
@@ -925,7 +936,7 @@ __device__ void grant_slot(const SwDev& D, uint32_t r, uint32_t x) {
 }
 
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
-__device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, size_t& l) {
+__device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l) {
   if (rec.x == NONE) { grant_slot(D, rec.z, rec.y); return NONE; }     // subject-slot request
   uint32_t r = rec.x / D.N, x = rec.x % D.N;
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
@@ -939,7 +950,7 @@ __device__ __forceinline__ uint32_t inbox_reserve(const SwDev& D, uint4 rec, siz
   return atomicAdd(&D.in_cnt[l], 1u);
 }
 // place: the message lands in the same line for the first SW_INBOX_FAST arrivals, else in the overflow row
-__device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l, uint32_t pos) {
+__device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos) {
   if (pos == NONE) return;
   uint32_t* m = nullptr;
   if (pos < SW_INBOX_FAST) m = D.inbox1 + l * 16 + 1 + 3 * pos;
@@ -948,7 +959,7 @@ __device__ __forceinline__ void inbox_place(const SwDev& D, uint4 rec, size_t l,
   if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
 }
 // four records per thread per trip: all four atomics are in flight before the first store
-__device__ __forceinline__ void deliver_span(const SwDev& D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride) {
+__device__ __forceinline__ void deliver_span(DevRef D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride) {
   for (uint32_t e = first; e < n; e += 4 * stride) {
     uint4 rec[4]; size_t l[4]; uint32_t pos[4];
 #pragma unroll
@@ -962,7 +973,7 @@ __device__ __forceinline__ void deliver_span(const SwDev& D, const uint4* edges,
 // The broadcasts piggy-backed on last tick's pings and acks (picked by k_resolve, one private area per block)
 // arrive with this tick's packets.  Same no-op filter as the gossip role applies at the sender: here the
 // receiver's view is read before the inbox is touched.
-__device__ void deliver_carried(const SwDev& D, const uint4* area, uint32_t n, uint32_t& c_edges, uint32_t& c_filt) {
+__device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_t& c_edges, uint32_t& c_filt) {
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
   for (uint32_t e = threadIdx.x; e < n; e += SW_BLOCK) {
     uint4 rec = area[e];
@@ -982,7 +993,8 @@ __device__ void deliver_carried(const SwDev& D, const uint4* area, uint32_t n, u
 }
 // grid = n_seg blocks + extra blocks over the shard's misc list.  Block b drains segment b and the carry areas
 // b, b + n_seg, ... (their counts are fetched together with the segment's: no extra trip in a quiet tick)
-__global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   uint32_t b = blockIdx.x;
   if (b < D.n_seg) {
     uint32_t n = D.seg_cnt[b], last = D.seg_last[b];
@@ -1031,16 +1043,17 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(SwDev D) {
   }
   b -= D.n_seg;
   uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
-  if (n > D.out_cap[D.rank]) n = D.out_cap[D.rank];
-  deliver_span(D, D.out[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
+  if (n > D.out_cap_tab[D.rank]) n = D.out_cap_tab[D.rank];
+  deliver_span(D, D.out_tab[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
 }
 // records handed over by other shards (swim_inbound)
-__global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(SwDev D, const uint4* edges, uint32_t n) {
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restrict__ Dp, const uint4* edges, uint32_t n) {
+  SW_DEV_BIND
   deliver_span(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 
 // host-side stimulus (leave/update) needs a slot before the tick: single-threaded variant
-__device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
+__device__ void alloc_slot(DevRef D, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * D.N + x;
   uint32_t w = D.nw[g];
   if (NW_HAS_SLOT(w)) return;
@@ -1066,12 +1079,12 @@ __device__ void alloc_slot(const SwDev& D, uint32_t r, uint32_t x) {
 // suspicion.Confirm (suspicion.go) against the observer's own view column.
 // =================================================================================================
 struct NodeCtx {
-  const SwDev& D; BlockStats& S;
+  DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
   uint4 h0;
-  __device__ NodeCtx(const SwDev& d, BlockStats& s) : D(d), S(s) {}
+  __device__ NodeCtx(DevRef d, BlockStats& s) : D(d), S(s) {}
 
   __device__ void load() {
     h0 = D.hdr[l];
@@ -1200,7 +1213,7 @@ struct NodeCtx {
   // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
   // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
   __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_meta) {
-    const int limit = (int)D.budget - (int)D.ctl_len[kind & 3u];
+    const int limit = (int)D.budget - (int)sel4(D.ctl_len, kind & 3u);
     uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
     int used = 0, used2 = 0;
     HbmQ qm{D.q + l, NL}, qe{D.evq + l, NL};
@@ -1270,7 +1283,8 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
   lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(SwDev D) {
+__global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry;
@@ -1345,7 +1359,8 @@ __global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(SwDev D) {
 // =================================================================================================
 // k_census / k_finish — observation: how the live observers of a replica see each dirty subject
 // =================================================================================================
-__global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
+__global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
   if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) return;
   __shared__ uint32_t acc[CEN_WORDS];
@@ -1362,7 +1377,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
     uint32_t key = a.x, s = SW_KST(key);
     obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
     cur += SW_KINC(key) == maxinc;
-    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = a.y + D.susp_timeout[a.z & 7u]; mindl = dl < mindl ? dl : mindl; }
+    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = a.y + sel8(D.susp_timeout, a.z & 7u); mindl = dl < mindl ? dl : mindl; }
   }
   uint32_t vals[6] = { obs, st[0], st[1], st[2], st[3], cur };
 #pragma unroll
@@ -1379,7 +1394,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(SwDev D) {
 }
 
 // fold the accumulators of a dirty slot into its cached census and stamp the first-times
-__device__ void census_commit(const SwDev& D, uint32_t sidx, uint32_t now) {
+__device__ void census_commit(DevRef D, uint32_t sidx, uint32_t now) {
   swim_census* c = &D.census[sidx];
   uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
   c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
@@ -1394,7 +1409,7 @@ __device__ void census_commit(const SwDev& D, uint32_t sidx, uint32_t now) {
 }
 
 // collect the ids of replica r whose node word is non-zero (whole block cooperates)
-__device__ void rebuild_exceptions(const SwDev& D, uint32_t r, uint32_t* s_n) {
+__device__ void rebuild_exceptions(DevRef D, uint32_t r, uint32_t* s_n) {
   if (threadIdx.x == 0) *s_n = 0;
   __syncthreads();
   const uint32_t* nw = D.nw + (size_t)r * D.N;
@@ -1404,12 +1419,14 @@ __device__ void rebuild_exceptions(const SwDev& D, uint32_t r, uint32_t* s_n) {
   if (threadIdx.x == 0) { D.exc_cnt[r] = *s_n; D.exc_dirty[r] = 0; }
   __syncthreads();
 }
-__global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild(SwDev D, uint32_t r) {
+__global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild(const SwDev* __restrict__ Dp, uint32_t r) {
+  SW_DEV_BIND
   __shared__ uint32_t s_n;
   rebuild_exceptions(D, r, &s_n);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt) {
+__global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ Dp, uint32_t* last_cnt) {
+  SW_DEV_BIND
   uint32_t t = *D.tick, now = now_ms(D, t);
   for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += SW_BLOCK) {
     uint32_t r = sidx / D.S, sl = sidx % D.S;
@@ -1437,14 +1454,16 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(SwDev D, uint32_t* last_cnt
     for (uint32_t j = 0; j < SW_PP_LISTS; j++) D.pp_cnt[((t & 1u) * SW_PP_LISTS + j) * 16] = 0;   // answered
   }
 }
-__global__ void k_census_commit(SwDev D) {
+__global__ void k_census_commit(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   uint32_t now = now_ms(D, *D.tick);
   for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += blockDim.x) {
     uint32_t r = sidx / D.S, sl = sidx % D.S;
     if (sl < D.n_slots[r] && D.slot_dirty[sidx]) census_commit(D, sidx, now);
   }
 }
-__global__ void __launch_bounds__(SW_BLOCK) k_count_live(SwDev D, uint32_t r, uint32_t x, uint32_t* out) {
+__global__ void __launch_bounds__(SW_BLOCK) k_count_live(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x, uint32_t* out) {
+  SW_DEV_BIND
   uint32_t c = 0;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK)
@@ -1456,7 +1475,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_count_live(SwDev D, uint32_t r, ui
 // =================================================================================================
 // initialisation, stimulus, digest
 // =================================================================================================
-__global__ void k_init_nodes(SwDev D) {
+__global__ void k_init_nodes(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= NL) return;
   D.hdr[l] = make_uint4(1, 0, 0, 0);
@@ -1469,12 +1489,14 @@ __global__ void k_init_nodes(SwDev D) {
     D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK;
   }
 }
-__global__ void k_init_views(SwDev D) {
+__global__ void k_init_views(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   size_t n = (size_t)D.R * D.S * D.nloc, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   D.va[i] = make_uint4(SW_BASE_KEY, 0, 0, 0); D.vb[i] = make_uint4(0, 0, 0, 0);
 }
-__global__ void k_init_slots(SwDev D) {
+__global__ void k_init_slots(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.R * D.S) return;
   D.subj_node[i] = NONE; D.slot_dirty[i] = 0; D.slot_maxinc[i] = 1; D.slot_susp[i] = 0; D.slot_mindl[i] = NONE;
@@ -1486,11 +1508,13 @@ __global__ void k_init_slots(SwDev D) {
 
 enum { INJ_KILL = 0, INJ_REVIVE = 1, INJ_LEAVE = 2, INJ_UPDATE = 3 };
 
-__global__ void k_inject_alloc(SwDev D, uint32_t r, const uint32_t* ids, uint32_t n) {
+__global__ void k_inject_alloc(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n) {
+  SW_DEV_BIND
   if (threadIdx.x || blockIdx.x) return;
   for (uint32_t a = 0; a < n; a++) alloc_slot(D, r, ids[a]);
 }
-__global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r, const uint32_t* ids, uint32_t n) {
+__global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ Dp, int op, uint32_t r, const uint32_t* ids, uint32_t n) {
+  SW_DEV_BIND
   __shared__ uint32_t lds_stats[ST_COUNT];
   BlockStats S; S.init(lds_stats);
   uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
@@ -1532,7 +1556,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(SwDev D, int op, uint32_t r
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
 }
-__global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
+__global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
+  SW_DEV_BIND
   if (threadIdx.x || blockIdx.x) return;
   size_t g = (size_t)r * D.N + x;
   uint32_t old = atomicOr(&D.nw[g], NW_ATTACHED);
@@ -1544,14 +1569,16 @@ __global__ void k_attach(SwDev D, uint32_t r, uint32_t x) {
     q_bit_lane(D, l, false, true);
   }
 }
-__global__ void k_set_partition(SwDev D, uint32_t r, const uint8_t* group) {
+__global__ void k_set_partition(const SwDev* __restrict__ Dp, uint32_t r, const uint8_t* group) {
+  SW_DEV_BIND
   uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= D.N) return;
   size_t g = (size_t)r * D.N + x;
   D.nw[g] = (D.nw[g] & ~0x7F000000u) | (((uint32_t)group[x] & 0x7Fu) << 24);
 }
 // serf.UserEvent at the origin: stamp, Increment, handleUserEvent locally, queue
-__global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
+__global__ void k_user_event(const SwDev* __restrict__ Dp, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
+  SW_DEV_BIND
   __shared__ uint32_t lds_stats[ST_COUNT];
   BlockStats S; S.init(lds_stats);
   if (threadIdx.x == 0) {
@@ -1571,7 +1598,8 @@ __global__ void k_user_event(SwDev D, uint32_t r, uint32_t origin, uint32_t id, 
   S.flush(D);
 }
 // one node's self state, gathered for swim_node_info_get
-__global__ void k_gather_node(SwDev D, uint32_t r, uint32_t i, uint32_t* out) {
+__global__ void k_gather_node(const SwDev* __restrict__ Dp, uint32_t r, uint32_t i, uint32_t* out) {
+  SW_DEV_BIND
   if (threadIdx.x || blockIdx.x) return;
   size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
   uint4 h = D.hdr[l], p0 = D.pr0[l]; uint2 p = D.ph[l]; uint32_t w = D.nw[(size_t)r * D.N + i];
@@ -1585,7 +1613,8 @@ __device__ __forceinline__ void digest_commit(uint64_t d, unsigned long long* ou
   for (int off = 32; off; off >>= 1) d += __shfl_down(d, off);
   if (sw_lane() == 0 && d) atomicAdd(out + (blockIdx.x % 64) * 8, (unsigned long long)d);
 }
-__global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(SwDev D, unsigned long long* out) {
+__global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restrict__ Dp, unsigned long long* out) {
+  SW_DEV_BIND
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   uint64_t d = 0;
   if (l < NL) {
@@ -1614,7 +1643,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(SwDev D, unsigned lon
   }
   digest_commit(d, out);
 }
-__global__ void __launch_bounds__(SW_BLOCK) k_digest_views(SwDev D, unsigned long long* out) {
+__global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restrict__ Dp, unsigned long long* out) {
+  SW_DEV_BIND
   uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
   if (sl >= D.n_slots[r]) return;
   uint32_t x = D.subj_node[sidx];
