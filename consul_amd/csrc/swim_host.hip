@@ -252,6 +252,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (rc) return rc;
   if (!out) return SWIM_EINVAL;
   if (cfg->n_shards > SW_MAX_SHARDS || cfg->subject_cap >= NW_SLOT_MASK) return SWIM_ERANGE;
+  {   // the gossip role stages both queues of its 256 lanes in LDS: 16 B x 256 x (queue_cap + event_queue_cap) of the CU's 160 KB
+    const uint32_t slots = cfg->queue_cap + ((cfg->flags & SWIM_F_SERF_EVENTS) ? cfg->event_queue_cap : 0);
+    if ((size_t)slots * SW_BLOCK * sizeof(uint4) + 8192 > 160 * 1024) return SWIM_ERANGE;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || (int)cfg->device >= ndev) return SWIM_ENODEV;
   swim_sim* s = new (std::nothrow) swim_sim();

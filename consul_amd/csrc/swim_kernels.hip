@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
   lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK, 5) k_resolve(const SwDev* __restrict__ Dp) {
+__global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];

@@ -257,3 +257,66 @@ def test_push_pull_parity_and_heal(hip, oracle):
     assert c.by_state[abi.STATE_ALIVE] == c.n_observers and a.node_info(0, 33).incarnation == 2
     assert a.stats()["push_pulls"] == b.stats()["push_pulls"] > 0
     sh.close()
+
+
+# ---- BASELINE config #5's shape at test size: churn + Serf user-event flood + Lifeguard -------------------------
+def _churn_and_flood(sims, n, seconds, rng_seed, events_per_s=3, churn=0.03):
+    """Every simulated second: a uniformly drawn `churn` share of the nodes flips alive <-> dead (kill / revive) and
+    `events_per_s` user events start at uniformly drawn live origins.  The same stimulus goes to every simulator."""
+    rng = np.random.default_rng(rng_seed)
+    dead = np.zeros(n, dtype=bool)
+    eid = 1
+    for sec in range(seconds):
+        flip = rng.choice(n, size=int(n * churn), replace=False)
+        kill, revive = [int(x) for x in flip if not dead[x]], [int(x) for x in flip if dead[x]]
+        dead[flip] = ~dead[flip]
+        origins = [int(x) for x in rng.choice(np.flatnonzero(~dead), size=events_per_s)]
+        for s in sims:
+            if kill: s.kill(0, kill)
+            if revive: s.revive(0, revive)
+            for j, o in enumerate(origins):
+                s.user_event(0, o, eid + j)
+        eid += events_per_s
+        for s in sims:
+            s.step_ms(1000)
+
+
+@pytest.mark.parametrize("fanout", [3, 5])
+def test_churn_and_event_flood(hip, oracle, fanout):
+    """Config #5's shape (Lifeguard on, churn, user-event flood) at 2 048 nodes, compared every two seconds.
+    fan-out 5 runs the wide-array kernel variant with the Serf queue."""
+    kw = dict(n_nodes=2048, seed=21, gossip_nodes=fanout, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048,
+              queue_cap=16, event_queue_cap=16, inbox_cap=512, push_pull_interval_ms=0)
+    a, b = pair(hip, oracle, **kw)
+    for step in range(8):
+        _churn_and_flood((a, b), 2048, 2, rng_seed=100 + step)
+        a.sync()
+        assert a.digest() == b.digest(), f"after {2 * (step + 1)} s"
+    sa, sb = a.stats(), b.stats()
+    for k in STAT_KEYS + ["user_events_delivered", "user_events_deduped", "user_events_stale", "event_drops"]:
+        assert sa[k] == sb[k], k
+    assert sb["user_events_delivered"] > 0 and sb["refutes"] > 0 and sb["suspicion_timeouts"] > 0 and sb["piggybacks"] > 0
+
+
+def test_churn_and_event_flood_sharded(hip, oracle):
+    """The same on two HIP shards (sharded kernel variant with the Serf queue) against the unsharded oracle."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=2048, seed=22, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048, queue_cap=16,
+              event_queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+    sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    _churn_and_flood((sh, ref), 2048, 12, rng_seed=7)
+    sh.sync()
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("user_events_delivered", "user_events_deduped", "msgs_applied", "piggybacks", "probe_failures", "refutes"):
+        assert a[k] == b[k], k
+    sh.close()
+
+
+def test_queues_that_do_not_fit_the_lds_are_refused(hip):
+    """The gossip role stages 16 B x 256 lanes x (queue_cap + event_queue_cap) in LDS: 64 slots would need 256 KB."""
+    cfg = preset(hip, abi.PRESET_LAN, n_nodes=1024, queue_cap=32, event_queue_cap=32, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS)
+    with pytest.raises(Exception) as e:
+        Sim(hip, cfg)
+    assert "ERANGE" in str(e.value) or "-34" in str(e.value)
