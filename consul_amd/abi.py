@@ -120,6 +120,7 @@ PROTOTYPES = {
     "swim_outbound_raw": (C.c_int, [SimP, u32, P(C.c_void_p), P(C.c_void_p)]),
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_tick_end": (C.c_int, [SimP]),
+    "swim_tick_end_begin": (C.c_int, [SimP]),
     "swim_inject_kill": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),

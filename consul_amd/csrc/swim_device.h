@@ -141,6 +141,8 @@ struct SwDev {
   uint32_t* carry_stamp; // [0] the tick the most recent piggy-back picks travel in (k_resolve of tick t writes t+1);
                          // [1] the last tick in which k_deliver drained carry areas
   uint32_t carry_cap, NB, nb_carry;
+  uint32_t* peer_act;    // [1] swim_peer_activity: 0 = the caller vouches that no node of any OTHER shard has anything queued
+                         //     (device resident, so a captured launch sequence picks up the current value)
   uint32_t* act;         // [1] sharded runs: this shard may hold a non-empty broadcast queue / emitted something
   uint4* out[SW_MAX_SHARDS];       // host side only; device code goes through out_tab / out_cap_tab (global memory)
   uint4** out_tab; uint32_t* out_cap_tab;
@@ -176,7 +178,6 @@ struct BeginPlan {
   uint32_t nb_ppreply;       // blocks answering the previous tick's pull requests
   uint32_t nb_carry;         // sharded runs: blocks moving carried broadcasts for other shards into their lists
   uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry
-  uint32_t peer_active;      // 0 = the caller vouches that no node of any OTHER shard has anything queued
 };
 #define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard */
 

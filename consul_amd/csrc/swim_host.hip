@@ -45,7 +45,8 @@ struct swim_sim {
   uint4* in_buf = nullptr;             // records received from other shards
   uint32_t in_cap = 0, in_count = 0;
   uint32_t out_counts[SW_MAX_SHARDS + 1];  // host copy for swim_outbound / swim_activity (counts, then the activity word)
-  bool force_active = false;           // a host-side stimulus since the last tick: ignore the peer-activity hint once
+  uint32_t peer_act_host = 1;          // what the device word D.peer_act currently holds
+  hipGraphExec_t graph_end_begin = nullptr;   // sharded runs: [end of tick t, begin of tick t+1] when nothing came in
   bool out_counts_valid = false;
   std::vector<swim_event> pending_events;
   std::vector<uint64_t> attached;                      // (replica << 32 | node) driven through the transport bridge
@@ -216,6 +217,7 @@ static int dalloc(swim_sim* s, T** p, size_t count) {
 static void drop_graphs(swim_sim* s) {
   for (int i = 0; i < 2; i++)
     if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
+  if (s->graph_end_begin) { (void)hipGraphExecDestroy(s->graph_end_begin); s->graph_end_begin = nullptr; }
 }
 
 extern "C" int swim_destroy(swim_sim* s) {
@@ -316,7 +318,6 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const bool piggy = (cfg->flags & SWIM_F_PIGGYBACK) != 0;
   pl.nb_carry = D.n_shards > 1 ? 64 : 0;
   if (piggy && D.n_shards > 1) pl.roles |= 0x20;
-  pl.peer_active = 1;
   D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0);
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
@@ -349,6 +350,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemcpy(D.out_tab, D.out, sizeof D.out, hipMemcpyHostToDevice)); HIPCK(s, hipMemcpy(D.out_cap_tab, D.out_cap, sizeof D.out_cap, hipMemcpyHostToDevice));
   DALLOC(s, D.out_cnt, SW_MAX_SHARDS + 1); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
   D.act = D.out_cnt + D.n_shards;                  // rides behind the counts so one gather fetches both
+  DALLOC(s, D.peer_act, 1); HIPCK(s, hipMemsetD32Async((hipDeviceptr_t)D.peer_act, 1, 1, s->stream));
   D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
@@ -398,7 +400,6 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 static void launch_begin(swim_sim* s) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   BeginPlan pl = s->plan;
-  if (s->force_active) { pl.peer_active = 1; s->force_active = false; }
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
   const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + D.R * pl.nb_pp;
   if (D.TQ % D.P == 0) {
@@ -483,7 +484,8 @@ extern "C" int swim_outbound_raw(swim_sim* s, uint32_t shard, const swim_edge** 
 }
 extern "C" int swim_peer_activity(swim_sim* s, int active) {
   if (!s) return SWIM_EINVAL;
-  s->plan.peer_active = active ? 1u : 0u;          // read by the next swim_tick_begin
+  const uint32_t v = active ? 1u : 0u;             // read by the next k_begin, in stream order
+  if (v != s->peer_act_host) { HIPCK(s, hipMemsetD32Async((hipDeviceptr_t)s->D.peer_act, (int)v, 1, s->stream)); s->peer_act_host = v; }
   return SWIM_OK;
 }
 extern "C" int swim_activity(swim_sim* s, int* active) {
@@ -500,8 +502,8 @@ extern "C" int swim_activity(swim_sim* s, int* active) {
 // a host-side stimulus may fill queues behind the back of the activity word: raise it, and ignore the
 // caller's hint for the next tick (stimulus is replicated on every shard, so every shard does)
 static void touched(swim_sim* s) {
-  s->force_active = true;
   if (s->D.n_shards > 1) (void)hipMemsetD32Async((hipDeviceptr_t)s->D.act, 1, 1, s->stream);
+  if (s->peer_act_host != 1) { (void)hipMemsetD32Async((hipDeviceptr_t)s->D.peer_act, 1, 1, s->stream); s->peer_act_host = 1; }
 }
 extern "C" uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) {
   return (s && shard < s->cfg.n_shards) ? s->D.out_cap[shard] : 0;
@@ -514,6 +516,28 @@ extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   // asynchronous on the simulator's stream; the caller keeps the source alive (see swimsim.h)
   HIPCK(s, hipMemcpyAsync(s->in_buf + s->in_count, ptr, (size_t)count * sizeof(uint4), hipMemcpyDeviceToDevice, s->stream));
   s->in_count += count;
+  return SWIM_OK;
+}
+// sharded runs: end tick t and begin tick t+1 in one go.  When nothing came in from other shards (every quiet
+// tick) the six launches are replayed from one captured graph instead of being issued one by one — the host
+// sits on the critical path of a sharded tick (it must read the exchanged counts), so its launch time shows.
+extern "C" int swim_tick_end_begin(swim_sim* s) {
+  if (!s) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  if (s->in_count == 0 && s->use_graphs && !s->profiling) {
+    if (!s->graph_end_begin) {
+      hipGraph_t g = nullptr;
+      HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+      launch_end(s); launch_begin(s);
+      HIPCK(s, hipStreamEndCapture(s->stream, &g));
+      hipError_t e = hipGraphInstantiate(&s->graph_end_begin, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
+    }
+    HIPCK(s, hipGraphLaunch(s->graph_end_begin, s->stream));
+  } else { launch_end(s); launch_begin(s); }
+  advance(s, 1);
+  s->out_counts_valid = false; s->in_count = 0;
   return SWIM_OK;
 }
 extern "C" int swim_tick_end(swim_sim* s) {

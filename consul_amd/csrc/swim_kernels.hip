@@ -881,9 +881,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp
     unsigned long long* c = D.role_clk + (((size_t)tk * 8 + (id)) * 64 + (blockIdx.x & 63u)) * 2; atomicMin(c, t_in); atomicMax(c + 1, (unsigned long long)wall_clock64()); } } } while (0)
   if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); ROLE_DONE(0); return; }
   b -= pl.nb_expire;
-  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, pl.peer_active); ROLE_DONE(1); return; }
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, MULTI ? *D.peer_act : 1u); ROLE_DONE(1); return; }
   b -= pl.nb_pend;
-  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, pl.peer_active); ROLE_DONE(2); return; }
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, MULTI ? *D.peer_act : 1u); ROLE_DONE(2); return; }
   b -= D.R * pl.nb_probe;
   if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
   b -= D.R * pl.nb_gossip;

@@ -147,6 +147,9 @@ class Sim:
     def tick_end(self):
         self._ck("swim_tick_end", self._l.swim_tick_end(self._h))
 
+    def tick_end_begin(self):
+        self._ck("swim_tick_end_begin", self._l.swim_tick_end_begin(self._h))
+
     # -- stimulus -----------------------------------------------------------------------------
     def kill(self, replica: int, ids: Iterable[int]):
         a, p, n = _ids(ids)

@@ -253,6 +253,9 @@ int swim_stream(swim_sim* sim, void** hip_stream);
 int swim_outbound_raw(swim_sim* sim, uint32_t shard, const swim_edge** segment, const uint32_t** counters);
 int swim_inbound(swim_sim* sim, const swim_edge* ptr, uint32_t count);
 int swim_tick_end(swim_sim* sim);
+/* swim_tick_end immediately followed by the next swim_tick_begin, as one call (the product library replays the
+ * whole launch sequence from a captured graph when nothing was handed in with swim_inbound) */
+int swim_tick_end_begin(swim_sim* sim);
 /* SWIM_F_PIGGYBACK across shards: a probe files a piggy-back order for its target's ack, and the target may live
  * on another shard.  While no node anywhere has anything queued such orders are no-ops; `active` = 0 tells the
  * next swim_tick_begin that the caller knows this to be so for every OTHER shard, and the orders stay unfiled

@@ -1031,6 +1031,7 @@ int swim_tick_end(swim_sim* s) {
   s->tick++; s->in_tick = 0;
   return SWIM_OK;
 }
+int swim_tick_end_begin(swim_sim* s) { int rc = swim_tick_end(s); return rc ? rc : swim_tick_begin(s); }
 int swim_step(swim_sim* s, uint32_t n) {
   if (!s) return SWIM_EINVAL; if (s->cfg.n_shards != 1) return SWIM_ESTATE;
   for (uint32_t i = 0; i < n; i++) { int rc = swim_tick_begin(s); if (rc) return rc; rc = swim_tick_end(s); if (rc) return rc; }
