@@ -1,0 +1,442 @@
+// swimsim_wire.hpp — memberlist's packet format for the transport bridge.
+//
+// swim_transport_poll / swim_transport_write_to exchange rumour records (swim_edge).  A *real* memberlist node
+// speaks bytes: a message-type byte followed by a go-msgpack map of the message struct's fields, several messages
+// folded into a compound packet, optionally behind a label header and a CRC32 header.  This header turns one into
+// the other, so that the Go shim of INTEGRATION.md can hand Transport.WriteTo's buffer straight through and feed
+// PacketCh with what comes back.
+//
+// The format lives in github.com/hashicorp/memberlist v0.6.0 (go.mod:80: net.go messageType / encode /
+// makeCompoundMessage / decodeCompoundMessage, util.go, label.go) and github.com/hashicorp/serf v0.10.4
+// (go.mod:85: messages.go) with github.com/hashicorp/go-msgpack/v2 v2.1.5 (go.mod:225) underneath — none of them
+// vendored under /root/reference.  It is restated here from the published sources; PARITY UNPINNED against the real
+// encoder (no Go toolchain), pinned only by hand-derived byte vectors in tests/host/test_wire.cpp.  In-tree
+// corroboration: the u32/u16 big-endian framing style of agent/consul/wanfed/wanfed.go:112-121, UDPBufferSize 1400
+// (agent/consul/config_test.go:51), the status values of api/agent.go:296-304.
+//
+// go-msgpack specifics that matter (codec.MsgpackHandle{} as memberlist's encode() constructs it: RawToString and
+// WriteExt off): a struct is a map keyed by the Go field names in declaration order; strings AND byte slices use the
+// old "raw" family (fixraw 0xa0|n, raw16 0xda, raw32 0xdb — no str8 / bin8); unsigned integers take the smallest of
+// positive-fixint / 0xcc / 0xcd / 0xce / 0xcf; a nil slice is 0xc0; bools are 0xc2 / 0xc3; `omitempty` fields vanish.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "swimsim.h"
+
+namespace swimsim {
+namespace wire {
+
+using Bytes = std::vector<uint8_t>;
+
+// memberlist net.go messageType
+enum MessageType : uint8_t {
+  kPing = 0, kIndirectPing = 1, kAckResp = 2, kSuspect = 3, kAlive = 4, kDead = 5, kPushPull = 6, kCompound = 7,
+  kUser = 8, kCompress = 9, kEncrypt = 10, kNackResp = 11, kHasCrc = 12, kErr = 13, kHasLabel = 244,
+};
+// serf messages.go messageType (the first byte of a memberlist user message)
+enum SerfMessageType : uint8_t { kSerfLeave = 0, kSerfJoin = 1, kSerfPushPull = 2, kSerfUserEvent = 3, kSerfQuery = 4 };
+
+struct DecodeError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// msgpack, the subset memberlist uses
+// ---------------------------------------------------------------------------------------------------------------
+struct Writer {
+  Bytes& b;
+  void u8(uint8_t v) { b.push_back(v); }
+  void be16(uint16_t v) { u8(uint8_t(v >> 8)); u8(uint8_t(v)); }
+  void be32(uint32_t v) { be16(uint16_t(v >> 16)); be16(uint16_t(v)); }
+  void be64(uint64_t v) { be32(uint32_t(v >> 32)); be32(uint32_t(v)); }
+  void map(size_t n) { if (n < 16) u8(uint8_t(0x80 | n)); else { u8(0xde); be16(uint16_t(n)); } }
+  void uint(uint64_t v) {
+    if (v < 128) u8(uint8_t(v));
+    else if (v <= 0xFF) { u8(0xcc); u8(uint8_t(v)); }
+    else if (v <= 0xFFFF) { u8(0xcd); be16(uint16_t(v)); }
+    else if (v <= 0xFFFFFFFFull) { u8(0xce); be32(uint32_t(v)); }
+    else { u8(0xcf); be64(v); }
+  }
+  void boolean(bool v) { u8(v ? 0xc3 : 0xc2); }
+  void nil() { u8(0xc0); }
+  void raw(const void* p, size_t n) {               // strings and []byte alike (old-spec "raw")
+    if (n < 32) u8(uint8_t(0xa0 | n)); else if (n <= 0xFFFF) { u8(0xda); be16(uint16_t(n)); } else { u8(0xdb); be32(uint32_t(n)); }
+    const uint8_t* q = static_cast<const uint8_t*>(p); b.insert(b.end(), q, q + n);
+  }
+  void str(const std::string& s) { raw(s.data(), s.size()); }
+  void bytes(const Bytes& v, bool nil_when_empty) { if (v.empty() && nil_when_empty) nil(); else raw(v.data(), v.size()); }
+};
+
+struct Reader {
+  const uint8_t* p; const uint8_t* end;
+  Reader(const uint8_t* b, size_t n) : p(b), end(b + n) {}
+  size_t left() const { return size_t(end - p); }
+  uint8_t u8() { if (p >= end) throw DecodeError("truncated"); return *p++; }
+  uint16_t be16() { uint16_t a = u8(); return uint16_t(a << 8 | u8()); }
+  uint32_t be32() { uint32_t a = be16(); return a << 16 | be16(); }
+  uint64_t be64() { uint64_t a = be32(); return a << 32 | be32(); }
+  size_t map() {
+    uint8_t t = u8();
+    if ((t & 0xF0) == 0x80) return t & 0x0F;
+    if (t == 0xde) return be16();
+    if (t == 0xdf) return be32();
+    throw DecodeError("expected a map");
+  }
+  uint64_t uint() {
+    uint8_t t = u8();
+    if (t < 0x80) return t;
+    switch (t) {
+      case 0xcc: return u8(); case 0xcd: return be16(); case 0xce: return be32(); case 0xcf: return be64();
+      case 0xd0: return uint64_t(int8_t(u8())); case 0xd1: return uint64_t(int16_t(be16()));
+      case 0xd2: return uint64_t(int32_t(be32())); case 0xd3: return be64();
+    }
+    throw DecodeError("expected an integer");
+  }
+  bool boolean() { uint8_t t = u8(); if (t == 0xc2) return false; if (t == 0xc3) return true; throw DecodeError("expected a bool"); }
+  // raw / str / bin in either msgpack dialect, or nil
+  Bytes raw() {
+    uint8_t t = u8(); size_t n;
+    if (t == 0xc0) return {};
+    if ((t & 0xE0) == 0xa0) n = t & 0x1F;
+    else if (t == 0xd9 || t == 0xc4) n = u8();
+    else if (t == 0xda || t == 0xc5) n = be16();
+    else if (t == 0xdb || t == 0xc6) n = be32();
+    else throw DecodeError("expected raw bytes");
+    if (n > left()) throw DecodeError("truncated");
+    Bytes v(p, p + n); p += n; return v;
+  }
+  std::string str() { Bytes v = raw(); return std::string(v.begin(), v.end()); }
+  void skip() {                                     // any value
+    uint8_t t = *p;
+    if (t < 0x80 || t >= 0xe0 || t == 0xc0 || t == 0xc2 || t == 0xc3) { u8(); return; }
+    if ((t & 0xE0) == 0xa0 || t == 0xd9 || t == 0xda || t == 0xdb || t == 0xc4 || t == 0xc5 || t == 0xc6) { raw(); return; }
+    if ((t & 0xF0) == 0x80 || t == 0xde || t == 0xdf) { size_t n = map(); for (size_t i = 0; i < 2 * n; i++) skip(); return; }
+    if ((t & 0xF0) == 0x90) { u8(); for (size_t i = 0; i < size_t(t & 0x0F); i++) skip(); return; }
+    if (t == 0xdc) { u8(); size_t n = be16(); for (size_t i = 0; i < n; i++) skip(); return; }
+    if (t >= 0xcc && t <= 0xd3) { uint(); return; }
+    if (t == 0xca) { u8(); be32(); return; }
+    if (t == 0xcb) { u8(); be64(); return; }
+    throw DecodeError("unsupported msgpack type");
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// memberlist message structs (net.go), fields in declaration order
+// ---------------------------------------------------------------------------------------------------------------
+struct Alive { uint32_t incarnation = 0; std::string node; Bytes addr; uint16_t port = 0; Bytes meta; Bytes vsn; };
+struct Suspect { uint32_t incarnation = 0; std::string node, from; };
+using Dead = Suspect;                                // dead{Incarnation, Node, From}: Node == From means "left"
+struct Ping { uint32_t seq_no = 0; std::string node; Bytes source_addr; uint16_t source_port = 0; std::string source_node; };
+struct IndirectPing { uint32_t seq_no = 0; Bytes target; uint16_t port = 0; std::string node; bool nack = false;
+                      Bytes source_addr; uint16_t source_port = 0; std::string source_node; };
+struct AckResp { uint32_t seq_no = 0; Bytes payload; };
+struct NackResp { uint32_t seq_no = 0; };
+// serf messages.go messageUserEvent
+struct UserEvent { uint64_t ltime = 0; std::string name; Bytes payload; bool cc = false; };
+
+inline Bytes encode(const Alive& m) {
+  Bytes b{kAlive}; Writer w{b};
+  w.map(6);
+  w.str("Incarnation"); w.uint(m.incarnation); w.str("Node"); w.str(m.node); w.str("Addr"); w.bytes(m.addr, true);
+  w.str("Port"); w.uint(m.port); w.str("Meta"); w.bytes(m.meta, true); w.str("Vsn"); w.bytes(m.vsn, true);
+  return b;
+}
+inline Bytes encode_suspect_like(uint8_t type, const Suspect& m) {
+  Bytes b{type}; Writer w{b};
+  w.map(3); w.str("Incarnation"); w.uint(m.incarnation); w.str("Node"); w.str(m.node); w.str("From"); w.str(m.from);
+  return b;
+}
+inline Bytes encode_suspect(const Suspect& m) { return encode_suspect_like(kSuspect, m); }
+inline Bytes encode_dead(const Dead& m) { return encode_suspect_like(kDead, m); }
+inline Bytes encode(const Ping& m) {
+  Bytes b{kPing}; Writer w{b};
+  size_t n = 2 + !m.source_addr.empty() + (m.source_port != 0) + !m.source_node.empty();   // `codec:",omitempty"` on the Source* fields
+  w.map(n); w.str("SeqNo"); w.uint(m.seq_no); w.str("Node"); w.str(m.node);
+  if (!m.source_addr.empty()) { w.str("SourceAddr"); w.bytes(m.source_addr, false); }
+  if (m.source_port) { w.str("SourcePort"); w.uint(m.source_port); }
+  if (!m.source_node.empty()) { w.str("SourceNode"); w.str(m.source_node); }
+  return b;
+}
+inline Bytes encode(const IndirectPing& m) {
+  Bytes b{kIndirectPing}; Writer w{b};
+  size_t n = 5 + !m.source_addr.empty() + (m.source_port != 0) + !m.source_node.empty();
+  w.map(n); w.str("SeqNo"); w.uint(m.seq_no); w.str("Target"); w.bytes(m.target, true); w.str("Port"); w.uint(m.port);
+  w.str("Node"); w.str(m.node); w.str("Nack"); w.boolean(m.nack);
+  if (!m.source_addr.empty()) { w.str("SourceAddr"); w.bytes(m.source_addr, false); }
+  if (m.source_port) { w.str("SourcePort"); w.uint(m.source_port); }
+  if (!m.source_node.empty()) { w.str("SourceNode"); w.str(m.source_node); }
+  return b;
+}
+inline Bytes encode(const AckResp& m) {
+  Bytes b{kAckResp}; Writer w{b};
+  w.map(2); w.str("SeqNo"); w.uint(m.seq_no); w.str("Payload"); w.bytes(m.payload, true);
+  return b;
+}
+inline Bytes encode(const NackResp& m) { Bytes b{kNackResp}; Writer w{b}; w.map(1); w.str("SeqNo"); w.uint(m.seq_no); return b; }
+// a serf user event as memberlist carries it: userMsg, then serf's own type byte, then the msgpack struct
+inline Bytes encode(const UserEvent& m) {
+  Bytes b{kUser, kSerfUserEvent}; Writer w{b};
+  w.map(4); w.str("LTime"); w.uint(m.ltime); w.str("Name"); w.str(m.name); w.str("Payload"); w.bytes(m.payload, true);
+  w.str("CC"); w.boolean(m.cc);
+  return b;
+}
+
+// decoders take the bytes AFTER the message-type byte(s); unknown keys are skipped like go-msgpack does
+template <typename F> inline void decode_map(const uint8_t* p, size_t n, F&& field) {
+  Reader r(p, n);
+  size_t k = r.map();
+  for (size_t i = 0; i < k; i++) { std::string key = r.str(); if (!field(key, r)) r.skip(); }
+}
+inline Alive decode_alive(const uint8_t* p, size_t n) {
+  Alive m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "Incarnation") m.incarnation = uint32_t(r.uint()); else if (k == "Node") m.node = r.str();
+    else if (k == "Addr") m.addr = r.raw(); else if (k == "Port") m.port = uint16_t(r.uint());
+    else if (k == "Meta") m.meta = r.raw(); else if (k == "Vsn") m.vsn = r.raw(); else return false;
+    return true;
+  });
+  return m;
+}
+inline Suspect decode_suspect(const uint8_t* p, size_t n) {
+  Suspect m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "Incarnation") m.incarnation = uint32_t(r.uint()); else if (k == "Node") m.node = r.str();
+    else if (k == "From") m.from = r.str(); else return false;
+    return true;
+  });
+  return m;
+}
+inline Ping decode_ping(const uint8_t* p, size_t n) {
+  Ping m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "SeqNo") m.seq_no = uint32_t(r.uint()); else if (k == "Node") m.node = r.str();
+    else if (k == "SourceAddr") m.source_addr = r.raw(); else if (k == "SourcePort") m.source_port = uint16_t(r.uint());
+    else if (k == "SourceNode") m.source_node = r.str(); else return false;
+    return true;
+  });
+  return m;
+}
+inline AckResp decode_ack(const uint8_t* p, size_t n) {
+  AckResp m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "SeqNo") m.seq_no = uint32_t(r.uint()); else if (k == "Payload") m.payload = r.raw(); else return false;
+    return true;
+  });
+  return m;
+}
+inline UserEvent decode_user_event(const uint8_t* p, size_t n) {
+  UserEvent m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "LTime") m.ltime = r.uint(); else if (k == "Name") m.name = r.str(); else if (k == "Payload") m.payload = r.raw();
+    else if (k == "CC") m.cc = r.boolean(); else return false;
+    return true;
+  });
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// framing: compound packets (util.go makeCompoundMessage / decodeCompoundMessage), label (label.go), CRC (net.go)
+// ---------------------------------------------------------------------------------------------------------------
+// [compoundMsg][n u8][n x len u16 BE][payloads]; more than 255 messages span several packets
+inline std::vector<Bytes> make_compound(const std::vector<Bytes>& msgs) {
+  std::vector<Bytes> out;
+  for (size_t i = 0; i < msgs.size(); i += 255) {
+    size_t n = std::min<size_t>(255, msgs.size() - i);
+    Bytes b{kCompound, uint8_t(n)}; Writer w{b};
+    for (size_t j = 0; j < n; j++) { if (msgs[i + j].size() > 0xFFFF) throw std::length_error("message too long for a compound"); w.be16(uint16_t(msgs[i + j].size())); }
+    for (size_t j = 0; j < n; j++) b.insert(b.end(), msgs[i + j].begin(), msgs[i + j].end());
+    out.push_back(std::move(b));
+  }
+  return out;
+}
+// bytes after the compoundMsg type byte -> the parts; `truncated` counts parts cut off by a short buffer (memberlist
+// keeps what it got and reports the number it lost)
+inline std::vector<Bytes> decode_compound(const uint8_t* p, size_t n, size_t* truncated = nullptr) {
+  if (n < 1) throw DecodeError("missing compound length byte");
+  size_t parts = p[0]; p++; n--;
+  if (n < 2 * parts) throw DecodeError("truncated len slice");
+  std::vector<uint16_t> lens(parts);
+  for (size_t i = 0; i < parts; i++) lens[i] = uint16_t(p[2 * i] << 8 | p[2 * i + 1]);
+  p += 2 * parts; n -= 2 * parts;
+  std::vector<Bytes> out; size_t lost = 0;
+  for (size_t i = 0; i < parts; i++) {
+    if (n < lens[i]) { lost = parts - i; break; }
+    out.emplace_back(p, p + lens[i]); p += lens[i]; n -= lens[i];
+  }
+  if (truncated) *truncated = lost;
+  return out;
+}
+// memberlist fills a gossip packet with getBroadcasts(compoundOverhead = 2, limit): the same arithmetic for a caller
+// that packs encoded messages itself.  Returns how many of `msgs` (in order) fit a packet of `udp_buffer_size`.
+inline size_t fit_compound(const std::vector<Bytes>& msgs, size_t udp_buffer_size = 1400, size_t label_len = 0) {
+  const size_t compound_header_overhead = 2, compound_overhead = 2;
+  size_t label_overhead = label_len ? 2 + label_len : 0;
+  if (udp_buffer_size < compound_header_overhead + label_overhead) return 0;
+  size_t avail = udp_buffer_size - compound_header_overhead - label_overhead, used = 0, k = 0;
+  for (; k < msgs.size() && k < 255; k++) { size_t need = compound_overhead + msgs[k].size(); if (used + need > avail) break; used += need; }
+  return k;
+}
+// label.go: [hasLabelMsg][len u8][label] in front of the packet
+inline Bytes add_label(const Bytes& packet, const std::string& label) {
+  if (label.empty()) return packet;
+  if (label.size() > 255) throw std::length_error("label too long");
+  Bytes b{kHasLabel, uint8_t(label.size())}; b.insert(b.end(), label.begin(), label.end()); b.insert(b.end(), packet.begin(), packet.end());
+  return b;
+}
+inline Bytes strip_label(const Bytes& packet, std::string* label) {
+  if (packet.empty() || packet[0] != kHasLabel) { if (label) label->clear(); return packet; }
+  if (packet.size() < 2 || packet.size() < 2u + packet[1] || packet[1] == 0) throw DecodeError("bad label header");
+  if (label) label->assign(packet.begin() + 2, packet.begin() + 2 + packet[1]);
+  return Bytes(packet.begin() + 2 + packet[1], packet.end());
+}
+// net.go: protocol version >= 5 prefixes [hasCrcMsg][crc32 IEEE u32 BE] over the rest of the packet
+inline uint32_t crc32_ieee(const uint8_t* p, size_t n) {
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) { c ^= p[i]; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); }
+  return ~c;
+}
+inline Bytes add_crc(const Bytes& packet) {
+  Bytes b{kHasCrc}; Writer w{b}; w.be32(crc32_ieee(packet.data(), packet.size())); b.insert(b.end(), packet.begin(), packet.end());
+  return b;
+}
+inline Bytes strip_crc(const Bytes& packet) {
+  if (packet.empty() || packet[0] != kHasCrc) return packet;
+  if (packet.size() < 5) throw DecodeError("truncated crc header");
+  uint32_t want = uint32_t(packet[1]) << 24 | uint32_t(packet[2]) << 16 | uint32_t(packet[3]) << 8 | packet[4];
+  if (crc32_ieee(packet.data() + 5, packet.size() - 5) != want) throw DecodeError("crc mismatch");
+  return Bytes(packet.begin() + 5, packet.end());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the bridge: rumour records <-> packets
+// ---------------------------------------------------------------------------------------------------------------
+// How virtual node ids appear to a real memberlist node.  The defaults match the cgo shim of INTEGRATION.md
+// (name "node-<id>", address 10.x.y.z, serf port 8301, protocol/delegate versions {1,5,2,2,5,4}).
+struct Naming {
+  std::string prefix = "node-";
+  uint16_t port = 8301;
+  Bytes vsn = { 1, 5, 2, 2, 5, 4 };
+  std::string event_name = "swimsim";               // user events travel as {Name: event_name, Payload: id u32 BE}
+  std::string name_of(uint32_t id) const { return prefix + std::to_string(id); }
+  bool id_of(const std::string& name, uint32_t* id) const {
+    if (name.compare(0, prefix.size(), prefix) != 0 || name.size() == prefix.size()) return false;
+    uint64_t v = 0;
+    for (size_t i = prefix.size(); i < name.size(); i++) { if (name[i] < '0' || name[i] > '9') return false; v = v * 10 + uint64_t(name[i] - '0'); if (v > 0xFFFFFFFFull) return false; }
+    *id = uint32_t(v); return true;
+  }
+  Bytes addr_of(uint32_t id) const { return Bytes{ 10, uint8_t(id >> 16), uint8_t(id >> 8), uint8_t(id) }; }
+};
+
+// one rumour record (as swim_transport_poll returns it) -> one encoded memberlist message
+inline Bytes to_wire(const swim_edge& e, const Naming& nm = Naming()) {
+  const uint32_t type = e.meta >> 30, from = e.meta & 0x3FFFFFFFu;
+  switch (type) {
+    case SWIM_MSG_ALIVE: { Alive a; a.incarnation = e.incarnation; a.node = nm.name_of(e.subject); a.addr = nm.addr_of(e.subject); a.port = nm.port; a.vsn = nm.vsn; return encode(a); }
+    case SWIM_MSG_SUSPECT: return encode_suspect(Suspect{ e.incarnation, nm.name_of(e.subject), nm.name_of(from) });
+    case SWIM_MSG_DEAD: return encode_dead(Dead{ e.incarnation, nm.name_of(e.subject), nm.name_of(from) });
+    default: { UserEvent u; u.ltime = e.incarnation; u.name = nm.event_name;
+               u.payload = Bytes{ uint8_t(e.subject >> 24), uint8_t(e.subject >> 16), uint8_t(e.subject >> 8), uint8_t(e.subject) }; return encode(u); }
+  }
+}
+// every rumour of a polled batch that went to the same receiver from the same sender in one packet: the gossip packet
+// the real node would have received (compound when more than one message)
+inline Bytes to_packet(const std::vector<swim_edge>& rumours, const Naming& nm = Naming()) {
+  std::vector<Bytes> msgs; msgs.reserve(rumours.size());
+  for (const swim_edge& e : rumours) msgs.push_back(to_wire(e, nm));
+  if (msgs.size() == 1) return msgs[0];
+  std::vector<Bytes> c = make_compound(msgs);
+  if (c.size() != 1) throw std::length_error("more than 255 messages for one packet");
+  return c[0];
+}
+// a packet written by the real node -> the rumour records to hand to swim_transport_write_to (edge.dst is left 0: the
+// call names the receiver).  Pings, acks and the other control messages carry no rumour and are counted in `control`;
+// names that are not "<prefix><id>" are counted in `foreign`.
+inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm = Naming(), size_t* control = nullptr, size_t* foreign = nullptr) {
+  std::vector<swim_edge> out; size_t n_control = 0, n_foreign = 0;
+  std::vector<Bytes> todo{ strip_crc(strip_label(packet, nullptr)) };
+  while (!todo.empty()) {
+    Bytes m = std::move(todo.back()); todo.pop_back();
+    if (m.empty()) continue;
+    const uint8_t* body = m.data() + 1; size_t n = m.size() - 1;
+    switch (m[0]) {
+      case kCompound: { std::vector<Bytes> parts = decode_compound(body, n); for (size_t i = parts.size(); i-- > 0;) todo.push_back(std::move(parts[i])); break; }
+      case kAlive: {
+        Alive a = decode_alive(body, n); uint32_t id;
+        if (!nm.id_of(a.node, &id)) { n_foreign++; break; }
+        out.push_back(swim_edge{ 0, id, a.incarnation, uint32_t(SWIM_MSG_ALIVE) << 30 }); break;
+      }
+      case kSuspect: case kDead: {
+        Suspect s = decode_suspect(body, n); uint32_t id, from;
+        if (!nm.id_of(s.node, &id) || !nm.id_of(s.from, &from)) { n_foreign++; break; }
+        out.push_back(swim_edge{ 0, id, s.incarnation, uint32_t(m[0] == kSuspect ? SWIM_MSG_SUSPECT : SWIM_MSG_DEAD) << 30 | (from & 0x3FFFFFFFu) }); break;
+      }
+      case kUser: {
+        if (n < 1 || body[0] != kSerfUserEvent) { n_control++; break; }       // serf joins/leaves/queries: not modelled
+        UserEvent u = decode_user_event(body + 1, n - 1);
+        uint32_t id = 0; for (size_t i = 0; i < u.payload.size() && i < 4; i++) id = id << 8 | u.payload[i];
+        out.push_back(swim_edge{ 0, id, uint32_t(u.ltime), uint32_t(SWIM_MSG_USER) << 30 }); break;
+      }
+      default: n_control++; break;                   // ping / indirect ping / ack / nack / push-pull / err
+    }
+  }
+  if (control) *control = n_control;
+  if (foreign) *foreign = n_foreign;
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// memberlist.Transport over the bridge, at the byte level: what a NodeAwareTransport like wanfed.Transport
+// (agent/consul/wanfed/wanfed.go:96-141) does with real sockets, done with the simulator's attached-node calls.
+// ---------------------------------------------------------------------------------------------------------------
+class BridgeTransport {
+ public:
+  struct Packet { Bytes buf; std::string from; uint32_t from_id; };   // memberlist.Packet{Buf, From}; from_id SWIM_NONE: not a gossip packet
+
+  BridgeTransport(swim_sim* sim, uint32_t replica, uint32_t self_id, Naming naming = Naming(), std::string label = std::string(), bool crc = true)
+      : sim_(sim), replica_(replica), self_(self_id), nm_(std::move(naming)), label_(std::move(label)), crc_(crc) {}
+
+  // Transport.WriteToAddress(b, Address{Addr, Name}): `to` is the receiver's node name ("node-7") or its "10.a.b.c[:port]"
+  // address.  Returns 0, a SWIM_E* code, or SWIM_EINVAL for an address outside the virtual cluster.
+  int WriteTo(const Bytes& packet, const std::string& to) {
+    uint32_t dst;
+    if (!resolve(to, &dst)) return SWIM_EINVAL;
+    std::vector<swim_edge> recs = from_packet(packet, nm_, &control_seen_, &foreign_seen_);
+    if (recs.empty()) return SWIM_OK;                 // pings and acks: the simulator answers probes for the attached node
+    return swim_transport_write_to(sim_, replica_, self_, dst, recs.data(), recs.size());
+  }
+  // Transport.PacketCh(): everything virtual peers sent to this node since the last call, one packet per sender and
+  // tick batch, framed as the real node expects it (compound, CRC, label)
+  std::vector<Packet> Poll(size_t cap = 65536) {
+    std::vector<swim_edge> got(cap); size_t n = 0;
+    std::vector<Packet> out;
+    if (swim_transport_poll(sim_, replica_, self_, got.data(), got.size(), &n) != SWIM_OK) return out;
+    for (size_t i = 0; i < n;) {
+      size_t j = i; std::vector<swim_edge> batch;
+      while (j < n && got[j].dst == got[i].dst && batch.size() < 255) { swim_edge e = got[j]; e.dst = 0; batch.push_back(e); j++; }
+      Bytes pkt = to_packet(batch, nm_);
+      if (crc_) pkt = add_crc(pkt);
+      pkt = add_label(pkt, label_);
+      out.push_back(Packet{ std::move(pkt), got[i].dst == SWIM_NONE ? std::string() : nm_.name_of(got[i].dst), got[i].dst });
+      i = j;
+    }
+    return out;
+  }
+  size_t control_messages_seen() const { return control_seen_; }
+  size_t foreign_names_seen() const { return foreign_seen_; }
+
+ private:
+  bool resolve(const std::string& to, uint32_t* id) const {
+    if (nm_.id_of(to, id)) return true;
+    unsigned a, b, c, d;
+    if (sscanf(to.c_str(), "%u.%u.%u.%u", &a, &b, &c, &d) == 4 && a == 10 && b < 256 && c < 256 && d < 256) { *id = b << 16 | c << 8 | d; return true; }
+    return false;
+  }
+  swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_;
+  size_t control_seen_ = 0, foreign_seen_ = 0;
+};
+
+}  // namespace wire
+}  // namespace swimsim
