@@ -148,9 +148,6 @@ struct SwDev {
   uint4** out_tab; uint32_t* out_cap_tab;
   uint32_t* out_cnt;     // [n_shards]
   uint32_t out_cap[SW_MAX_SHARDS];
-  uint4* ctrl;           // slot requests seen this tick
-  uint32_t* ctrl_cnt;
-  uint32_t ctrl_cap;
   // rumours sent to attached nodes (memberlist.Transport bridge): {sender, subject, incarnation, meta} + target
   uint4* cap; uint32_t* cap_dst; uint32_t* cap_cnt; uint32_t cap_cap;
   // events, stats, errors

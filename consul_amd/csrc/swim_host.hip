@@ -351,7 +351,6 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.out_cnt, SW_MAX_SHARDS + 1); DALLOC(s, s->d_last_cnt, SW_MAX_SHARDS);
   D.act = D.out_cnt + D.n_shards;                  // rides behind the counts so one gather fetches both
   DALLOC(s, D.peer_act, 1); HIPCK(s, hipMemsetD32Async((hipDeviceptr_t)D.peer_act, 1, 1, s->stream));
-  D.ctrl_cap = 4096; DALLOC(s, D.ctrl, D.ctrl_cap); DALLOC(s, D.ctrl_cnt, 1);
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
@@ -372,7 +371,6 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(s->d_last_cnt, 0, SW_MAX_SHARDS * 4, st));
   HIPCK(s, hipMemsetAsync(D.pend_cnt, 0, (D.TQ + 1) * 4, st));
   HIPCK(s, hipMemsetAsync(D.pp_cnt, 0, 2 * SW_PP_LISTS * 16 * 4, st));
-  HIPCK(s, hipMemsetAsync(D.ctrl_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.ev_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.cap_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));

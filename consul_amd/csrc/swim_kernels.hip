@@ -908,7 +908,7 @@ static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
 // =================================================================================================
 // k_deliver — packetListen/ingestPacket: scatter an edge list into the per-node inbox rows.  One
 // returning atomic on the row's count word reserves the slot; the record lands in the same 64-byte
-// line for the first three arrivals.  Slot requests are side-lined for k_alloc.
+// line for the first five arrivals.  Slot requests are granted on the spot (grant_slot).
 // =================================================================================================
 // Give subject x of replica r a view-column slot.  Runs inside k_deliver (nobody reads slot bits there):
 // the first request to flip the node word's slot field to the "being granted" pattern wins, later
