@@ -77,11 +77,11 @@ struct SwDev {
   uint32_t* tick;
   // replicated, R*N
   uint32_t* nw;
-  // In steady state almost every node word is 0 (running, group 0, no subject slot).  exc_list[r] holds
+  // In steady state almost every node word is 0 (running, group 0, no subject slot).  exc_ent[r] holds
   // the ids of replica r whose word is NOT 0 when there are at most SW_EXC_MAX of them (exc_cnt[r] =
   // how many; larger = list unusable, read nw).  Blocks stage it in LDS, so looking at a random peer
   // costs no memory access at all.  Rebuilt by k_finish / after injections when exc_dirty[r] is set.
-  uint32_t* exc_list;    // [R][SW_EXC_MAX]
+  uint2* exc_ent;        // [R][SW_EXC_MAX] {id, node word}: kept equal to nw by everybody who changes a listed node's word
   uint32_t* exc_cnt;     // [R]
   uint32_t* exc_dirty;   // [R]
   // per local lane, NL = R*nloc

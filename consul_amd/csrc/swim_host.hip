@@ -288,7 +288,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.tick, 1);
   if (want_role_clk) { D.role_clk_ticks = 1024; DALLOC(s, D.role_clk, (size_t)D.role_clk_ticks * 16 * 64); }
   DALLOC(s, D.nw, NT);
-  DALLOC(s, D.exc_list, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
+  DALLOC(s, D.exc_ent, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);

@@ -79,9 +79,9 @@ struct ExcList {
   __device__ void stage(DevRef D, uint32_t r, uint32_t* lds) {   // caller provides the barrier
     id = lds; w = lds + SW_EXC_MAX;
     n = D.exc_cnt[r];
-    if (threadIdx.x < SW_EXC_MAX && threadIdx.x < n && n <= SW_EXC_MAX) {
-      uint32_t x = D.exc_list[(size_t)r * SW_EXC_MAX + threadIdx.x];
-      id[threadIdx.x] = x; w[threadIdx.x] = D.nw[(size_t)r * D.N + x];
+    if (threadIdx.x < SW_EXC_MAX) {                  // {id, node word} pairs next to the count: one trip, no dependent lookup
+      uint2 e = D.exc_ent[(size_t)r * SW_EXC_MAX + threadIdx.x];
+      id[threadIdx.x] = e.x; w[threadIdx.x] = e.y;
     }
   }
   __device__ __forceinline__ bool usable() const { return n <= SW_EXC_MAX; }
@@ -931,8 +931,9 @@ __device__ void grant_slot(DevRef D, uint32_t r, uint32_t x) {
   D.nw[g] = w | (sl + 1);
   // the replica's exception list: x may already be on it (a dead node has a non-zero word)
   uint32_t n = D.exc_cnt[r]; bool listed = false;
-  for (uint32_t j = 0; j < n && j < SW_EXC_MAX; j++) listed |= D.exc_list[(size_t)r * SW_EXC_MAX + j] == x;
-  if (!listed) { uint32_t pos = atomicAdd(&D.exc_cnt[r], 1u); if (pos < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + pos] = x; }
+  for (uint32_t j = 0; j < n && j < SW_EXC_MAX; j++)
+    if (D.exc_ent[(size_t)r * SW_EXC_MAX + j].x == x) { listed = true; D.exc_ent[(size_t)r * SW_EXC_MAX + j].y = w | (sl + 1); }
+  if (!listed) { uint32_t pos = atomicAdd(&D.exc_cnt[r], 1u); if (pos < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + pos] = make_uint2(x, w | (sl + 1)); }
 }
 
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
@@ -1067,9 +1068,9 @@ __device__ void alloc_slot(DevRef D, uint32_t r, uint32_t x) {
   // keep the replica's exception list exact without a rescan (single-threaded here)
   uint32_t n = D.exc_cnt[r];
   if (n <= SW_EXC_MAX) {
-    bool listed = false;
-    for (uint32_t j = 0; j < n; j++) listed |= D.exc_list[(size_t)r * SW_EXC_MAX + j] == x;
-    if (!listed) { if (n < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + n] = x; D.exc_cnt[r] = n + 1; }
+    bool listed = false; const uint32_t wn = w | (sl + 1);
+    for (uint32_t j = 0; j < n; j++) if (D.exc_ent[(size_t)r * SW_EXC_MAX + j].x == x) { listed = true; D.exc_ent[(size_t)r * SW_EXC_MAX + j].y = wn; }
+    if (!listed) { if (n < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + n] = make_uint2(x, wn); D.exc_cnt[r] = n + 1; }
   }
 }
 // =================================================================================================
@@ -1414,7 +1415,7 @@ __device__ void rebuild_exceptions(DevRef D, uint32_t r, uint32_t* s_n) {
   __syncthreads();
   const uint32_t* nw = D.nw + (size_t)r * D.N;
   for (uint32_t x = threadIdx.x; x < D.N; x += blockDim.x)
-    if (nw[x]) { uint32_t pos = atomicAdd(s_n, 1u); if (pos < SW_EXC_MAX) D.exc_list[(size_t)r * SW_EXC_MAX + pos] = x; }
+    if (nw[x]) { uint32_t pos = atomicAdd(s_n, 1u); if (pos < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + pos] = make_uint2(x, nw[x]); }
   __syncthreads();
   if (threadIdx.x == 0) { D.exc_cnt[r] = *s_n; D.exc_dirty[r] = 0; }
   __syncthreads();
