@@ -169,6 +169,46 @@ def test_queue_transmit_limit_and_retire(oracle):
     assert per_origin == [2] * 8                           # everybody adopted the higher incarnation
 
 
+def test_get_broadcasts_byte_budget_like_upstream_queue_test(oracle):
+    """memberlist queue_test.go TestTransmitLimited_GetBroadcasts (recalled): four 18-byte broadcasts, limit 80 —
+    with 2 bytes of per-message overhead all four fit (4 x 20 = 80), with 3 bytes only three do (3 x 21 = 63, a
+    fourth would make 84).  memberlist's own queue is read with overhead 2, serf's user events with overhead 3."""
+    kw = dict(n_nodes=64, seed=2, udp_buffer_size=82, msg_len=[18, 18, 18, 18], gossip_nodes=1, queue_cap=8,
+              event_queue_cap=8, subject_cap=8, push_pull_interval_ms=0, flags=(abi.F_DEFAULT | abi.F_SERF_EVENTS) & ~abi.F_PIGGYBACK)
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    assert s.derived.packet_budget == 80
+    # node 0 learns four rumours at once (three peers update themselves next to it: hand them over through the bridge)
+    s.update(0, [0])
+    a = 63
+    s.transport_poll(0, a)                                   # attach node 63 so that it can write
+    s.transport_write_to(0, a, 0, [(x, 2, abi.MSG_ALIVE, 1) for x in (10, 11, 12)])
+    s.step(2)                                                # the tick that merges them, then node 0's gossip tick
+    before = s.stats()
+    for _ in range(2):
+        s.step(1)
+    st = s.stats()
+    # with exactly four 18-byte rumours queued every packet of node 0 carried all four
+    sent = sum(st["msgs_sent"]) - sum(before["msgs_sent"]); pk = st["packets_sent"] - before["packets_sent"]
+    assert s.node_info(0, 0).queue_len == 4 and pk >= 1 and sent >= 4
+    # one message less of budget and the fourth no longer fits
+    kw["udp_buffer_size"] = 81
+    t = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    t.update(0, [0]); t.transport_poll(0, a); t.transport_write_to(0, a, 0, [(x, 2, abi.MSG_ALIVE, 1) for x in (10, 11, 12)])
+    t.step(2)
+    q0 = [(e.subject, e.transmits) for e in list(t.node_info(0, 0).queue)[:4]]
+    t.step(2)
+    q1 = [(e.subject, e.transmits) for e in list(t.node_info(0, 0).queue)[:4]]
+    gained = sorted(b[1] - a_[1] for a_, b in zip(sorted(q0), sorted(q1)))
+    assert gained == [0, 1, 1, 1], (q0, q1)                  # one gossip packet in those two ticks: three of four went out
+    # serf's user events are packed with overhead 3: four 18-byte events, limit 80 -> three per packet
+    u = Sim(oracle, preset(oracle, abi.PRESET_LAN, **dict(kw, udp_buffer_size=82)))
+    for i in range(4):
+        u.user_event(0, 0, 100 + i)
+    u.step(1)                                                # tick 0 is a gossip tick of node 0 (chunk 0)
+    su = u.stats()
+    assert su["msgs_sent"][abi.MSG_USER] == 3 and su["packets_sent"] == 1
+
+
 def test_named_broadcast_invalidates_older_rumour_about_same_node(oracle):
     s = small(oracle)
     s.update(0, [2])
