@@ -21,8 +21,8 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
 (EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
-F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK = 0x1, 0x2, 0x4, 0x8, 0x10
-F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK | F_TCP_FALLBACK
 SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
 
 u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
@@ -90,7 +90,7 @@ class Stats(C.Structure):
                 ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
-                ("piggybacks", u64), ("msgs_piggybacked", u64)]
+                ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64)]
 
 
 class KernelTime(C.Structure):

@@ -803,7 +803,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->inbox_overflow = v[ST_INBOX_OVF]; out->subject_overflow = v[ST_SUBJ_OVF]; out->event_drops = v[ST_EVDROPS];
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
-  out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS];
+  out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

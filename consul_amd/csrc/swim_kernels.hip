@@ -351,8 +351,11 @@ __device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, 
         else if (!ok && back && nack_in_time) nacks++;
       }
       uint32_t aw = p_aw(h.y);
-      if (acked) {
-        aw = awareness_apply(D, aw, -1); S.add(ST_IACKS);
+      // probeNode's TCP fallback ping next to the indirect probes: TCP rides out packet loss, so it reaches every
+      // running node of the same partition
+      const bool tcp = !acked && (D.flags & SWIM_F_TCP_FALLBACK) && !(wx & NW_DEAD) && NW_PART(wi) == NW_PART(wx);
+      if (acked || tcp) {
+        aw = awareness_apply(D, aw, -1); S.add(acked ? ST_IACKS : ST_TCPACKS);
         D.pr0[l].x = NONE; h.y = p_pack(p_epoch(h.y), aw, 0, 0);
       } else h.y = p_pack(p_epoch(h.y), aw, 2, expected > 0 ? expected - nacks : 1);
       D.ph[l] = h;

@@ -79,7 +79,12 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
  * sender in the bytes the packet has left.  The sender picks the broadcasts at the end of the
  * tick the carrier goes out (before it merges that tick's arrivals); they arrive one tick later. */
 #define SWIM_F_PIGGYBACK      0x10u
-#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK)
+/* probeNode's TCP fallback (memberlist Config.DisableTcpPings = false, the default; Consul switches it off per node only
+ * for WAN federation over mesh gateways, agent/consul/server_serf.go:222-231): when the direct UDP ping got no ack,
+ * a TCP ping goes out next to the indirect probes.  TCP rides out packet loss, so it reaches every running node of
+ * the same partition; contact counts as a successful probe. */
+#define SWIM_F_TCP_FALLBACK   0x20u
+#define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK | SWIM_F_TCP_FALLBACK)
 
 /* ---- configuration ---------------------------------------------------------------------- */
 /* One POD mirroring memberlist.Config field names (the ones CloneSerfLANConfig copies,
@@ -207,6 +212,7 @@ typedef struct swim_stats_t {
   uint64_t push_pulls;              /* pushPullNode exchanges initiated                          */
   uint64_t piggybacks;              /* pings/acks/... that carried at least one broadcast        */
   uint64_t msgs_piggybacked;        /* broadcasts carried that way (also counted in msgs_sent)   */
+  uint64_t probe_tcp_acks;          /* probes saved by the TCP fallback ping (SWIM_F_TCP_FALLBACK)*/
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;

@@ -685,7 +685,18 @@ static void probe_indirect(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
     else if (!ok && back && nack_in_time) nacks++;
   }
   nd->pr_stage = 2;
-  if (acked) { awareness_delta(s, nd, -1); s->st.probe_indirect_acks++; nd->pr_target = SWIM_NONE; nd->pr_stage = 0; return; }
+  /* probeNode's TCP fallback ping next to the indirect probes: TCP rides out packet loss, so it reaches every running
+   * node of the same partition ("Was able to connect to %s over TCP but UDP probes failed") */
+  int tcp = 0;
+  if (!acked && (s->cfg.flags & SWIM_F_TCP_FALLBACK)) {
+    size_t base = (size_t)r * s->N;
+    tcp = s->gt_alive[base + x] && s->part[base + o] == s->part[base + x];
+  }
+  if (acked || tcp) {
+    awareness_delta(s, nd, -1);
+    if (acked) s->st.probe_indirect_acks++; else s->st.probe_tcp_acks++;
+    nd->pr_target = SWIM_NONE; nd->pr_stage = 0; return;
+  }
   nd->pr_nack_miss = expected > 0 ? (uint8_t)(expected - nacks) : 1;
 }
 

@@ -273,7 +273,8 @@ def test_state_precedence_matrix(oracle):
 
 def test_refute_bumps_incarnation_and_awareness(oracle):
     """A live node that hears it is suspected re-asserts itself with incarnation+1 (refute)."""
-    s = small(oracle, n_nodes=64, loss_q32=int(0.35 * 2**32), subject_cap=64, queue_cap=16, inbox_cap=64)
+    s = small(oracle, n_nodes=64, loss_q32=int(0.35 * 2**32), subject_cap=64, queue_cap=16, inbox_cap=64,
+              flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)        # UDP-only probing: loss alone must be able to raise suspicions
     assert s.derived.suspicion_min_ms > 6000                # no suspicion can run out during the lossy phase
     s.step_ms(6000)
     st = s.stats()
@@ -405,14 +406,16 @@ def test_golden_infection_curves_32k(oracle):
 @pytest.mark.parametrize("kw", [
     dict(n_nodes=4096, n_replicas=2, seed=5),
     # inbox large enough that the UNfiltered run does not overflow it (a push-pull delivers every subject at once)
-    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=4096, loss_q32=int(0.1 * 2**32)),
+    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=4096, loss_q32=int(0.1 * 2**32),
+         base_flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK),
     dict(n_nodes=512, seed=2, suspicion_mult=6, subject_cap=64),              # k = 4 confirmations
 ])
 def test_noop_filter_never_changes_node_state(oracle, kw):
     """SWIM_F_FILTER_NOOP drops at the sender what the receiver would ignore anyway: every integer of
     node state (digest), every applied-message counter and every event must be identical on or off."""
     out = []
-    for flags in (abi.F_DEFAULT, abi.F_DEFAULT & ~abi.F_FILTER_NOOP):
+    kw = dict(kw); base = kw.pop("base_flags", abi.F_DEFAULT)
+    for flags in (base, base & ~abi.F_FILTER_NOOP):
         s = Sim(oracle, preset(oracle, abi.PRESET_LAN, flags=flags, **kw))
         s.step_ms(3000)
         s.kill(0, [100, 300]); s.update(0, [55]); s.leave(0, [77])
@@ -425,6 +428,29 @@ def test_noop_filter_never_changes_node_state(oracle, kw):
     assert out[0][:6] == out[1][:6]
     assert out[0][7] > 0 and out[1][7] == 0 and out[0][6] < out[1][6]
     assert out[0][6] + out[0][7] == out[1][6]                 # every record is either sent or filtered
+
+
+def test_tcp_fallback_ping_rides_out_packet_loss(oracle):
+    """probeNode's TCP fallback (on by default, as in memberlist): with 30 % UDP loss and nobody dead, direct and
+    indirect probes fail now and then but the TCP ping always connects — no suspicion is ever raised; a node that
+    really died is still detected at the usual pace.  Without the fallback the same loss produces false suspicions."""
+    kw = dict(n_nodes=512, seed=6, loss_q32=int(0.30 * 2**32), subject_cap=128, queue_cap=16, inbox_cap=128)
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    s.step_ms(20000)
+    st = s.stats()
+    assert st["probe_tcp_acks"] > 0 and st["probe_failures"] == 0 and st["refutes"] == 0 and sum(st["msgs_sent"]) == 0
+    s.kill(0, [77]); s.step_ms(60000)
+    c = s.census(0, 77)
+    assert c.all_dead_ms != abi.NONE and s.stats()["probe_failures"] > 0
+    t = Sim(oracle, preset(oracle, abi.PRESET_LAN, flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK, **kw))
+    t.step_ms(20000)
+    st = t.stats()
+    assert st["probe_tcp_acks"] == 0 and st["probe_failures"] > 0 and st["msgs_sent"][abi.MSG_SUSPECT] > 0
+    # a partition is not packet loss: TCP cannot cross it either
+    u = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=64, seed=1, subject_cap=64, queue_cap=32, inbox_cap=256))
+    u.partition(0, [1 if i < 8 else 0 for i in range(64)])
+    u.step_ms(15000)
+    assert u.stats()["probe_failures"] > 0 and u.stats()["probe_tcp_acks"] == 0
 
 
 def test_golden_fixture_config1(oracle):

@@ -94,7 +94,7 @@ def test_update_rumour_wan(hip, oracle):
 def test_loss_refute_and_partition(hip, oracle):
     """packet loss => false suspicions => refutes (incarnation bumps); then a partition."""
     a, b = pair(hip, oracle, n_nodes=2048, seed=9, subject_cap=1024, queue_cap=32, inbox_cap=256,
-                loss_q32=int(0.10 * 2**32))
+                loss_q32=int(0.10 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     for s in (a, b):
         s.step_ms(20000)
     assert_same(a, b, tag="lossy")
@@ -132,7 +132,7 @@ def test_sharded_population_matches_unsharded(hip, oracle, n_shards):
     device, records handed over in-process) must reproduce the unsharded oracle bit for bit."""
     from consul_amd.dist import LocalExchange, ShardedSim
     kw = dict(n_nodes=4096, n_replicas=2, seed=5, subject_cap=256, queue_cap=16, inbox_cap=1024,
-              loss_q32=int(0.05 * 2**32))
+              loss_q32=int(0.05 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw))
                      for i in range(n_shards)], LocalExchange())
     ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
@@ -320,3 +320,19 @@ def test_queues_that_do_not_fit_the_lds_are_refused(hip):
     with pytest.raises(Exception) as e:
         Sim(hip, cfg)
     assert "ERANGE" in str(e.value) or "-34" in str(e.value)
+
+
+def test_tcp_fallback_under_loss_parity(hip, oracle):
+    """Default flags (TCP fallback ping on) with 20 % packet loss, a real failure and a partition: the lossy probes are
+    saved by TCP on both libraries alike, the dead node and the partitioned ones are still found out."""
+    a, b = pair(hip, oracle, n_nodes=2048, seed=13, subject_cap=256, queue_cap=16, inbox_cap=256, loss_q32=int(0.20 * 2**32))
+    mask = np.zeros(2048, dtype=np.uint8); mask[1000:1040] = 1
+    for s in (a, b):
+        s.step_ms(8000)
+        s.kill(0, [321])
+        s.step_ms(12000)
+        s.partition(0, mask)
+        s.step_ms(20000)
+    assert_same(a, b, [(0, 321)])
+    st = b.stats()
+    assert st["probe_tcp_acks"] > 0 and a.stats()["probe_tcp_acks"] == st["probe_tcp_acks"] and st["probe_failures"] > 0
