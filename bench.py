@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true")
+    ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the unsharded 32-clusters-per-GPU comparison")
     ap.add_argument("--no-piggyback", action="store_true", help="ablation: SWIM_F_PIGGYBACK off (not memberlist's behaviour)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
@@ -213,6 +214,25 @@ def main():
                    "parallelism": f"population sharded x{world}, all-to-all per tick" if sharded else "1 GPU"},
         "detection_ms_after_t0": detect,
     }
+
+    if world > 1 and not args.no_replica_leg:
+        # The clusters of this workload are independent of each other, so the box can also simply run 32 whole clusters
+        # per GPU with nothing on the wire (same scenario, captured-graph replay as at N=1): reported next to the
+        # sharded figure so that the cost of the per-tick exchange is visible.  Every rank measures, MAX over ranks.
+        kw = dict(cfg_kw, n_replicas=args.replicas, seed=args.seed + rank * args.replicas, shard_rank=0, n_shards=1)
+        solo = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+        solo.step(args.warmup * G); solo.sync()
+        for r, v in enumerate(victims_for(args.seed + rank, args.replicas, args.nodes)):
+            solo.kill(r, [v])
+        solo.sync(); barrier()
+        ts = time.perf_counter()
+        solo.step(args.steps * G); solo.sync(); barrier()
+        dts = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        solo.close()
+        line["replica_parallel"] = {"value": world * args.replicas * args.nodes * args.steps / float(dts.item()),
+                                    "unit": "node-rounds/s", "ms_per_step": 1000.0 * float(dts.item()) / args.steps,
+                                    "parallelism": f"{args.replicas} whole clusters per GPU x {world} GPUs, no data-path collective"}
 
     if rank == 0 and not sharded and not args.no_roofline:
         # instrumented pass over the same region: HIP events around every launch on the sim's stream

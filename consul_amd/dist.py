@@ -143,6 +143,13 @@ class TorchExchange:
         else:
             self._run_cpu(sim)
 
+    def close(self):
+        """Give torch its default stream back (the simulator's stream is about to be destroyed)."""
+        if self.on_gpu and self._bound is not None:
+            self.torch.cuda.current_stream(self.device).synchronize()
+            self.torch.cuda.set_stream(self.torch.cuda.default_stream(self.device))
+        self._bound = None
+
 
 class LocalExchange:
     """All shards live in this process; outbound segment j of shard i is handed to shard j."""
@@ -214,5 +221,7 @@ class ShardedSim:
         return tot
 
     def close(self):
+        if hasattr(self.exchange, "close"):
+            self.exchange.close()
         for s in self.sims:
             s.close()
