@@ -215,7 +215,7 @@ def main():
         "detection_ms_after_t0": detect,
     }
 
-    if world > 1 and not args.no_replica_leg:
+    if sharded and not args.no_replica_leg:
         # The clusters of this workload are independent of each other, so the box can also simply run 32 whole clusters
         # per GPU with nothing on the wire (same scenario, captured-graph replay as at N=1): reported next to the
         # sharded figure so that the cost of the per-tick exchange is visible.  Every rank measures, MAX over ranks.
