@@ -196,9 +196,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     base = sim.sim if sharded else sim
-    census = [base.census(r, v) for r, v in enumerate(victims[: min(reps, 4)])]
-    detect = {"first_suspect_ms": [c.first_suspect_ms for c in census], "first_dead_ms": [c.first_dead_ms for c in census],
-              "all_dead_ms": [c.all_dead_ms for c in census]}
+    census = [base.census(r, v) for r, v in enumerate(victims)]
+    detect = {"first_suspect_ms": [c.first_suspect_ms for c in census[:4]], "first_dead_ms": [c.first_dead_ms for c in census[:4]],
+              "all_dead_ms": [c.all_dead_ms for c in census[:4]]}
+    # BASELINE configs[1] asks for the time-to-detect distribution: over all replicas, in ms after the failure
+    t_kill = args.warmup * G * base.derived.quantum_ms
+
+    def spread(vals):
+        v = sorted(int(x) - t_kill for x in vals if x != abi.NONE)
+        return {"n": len(v), "min": v[0], "median": v[len(v) // 2], "max": v[-1]} if v else {"n": 0}
+    detect_after_kill = {"first_suspect": spread(c.first_suspect_ms for c in census),
+                         "first_dead": spread(c.first_dead_ms for c in census),
+                         "all_know_dead": spread(c.all_dead_ms for c in census)}
     sim.close()
 
     value = reps * args.nodes * args.steps / dt
@@ -212,7 +221,7 @@ def main():
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
                    "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
                    "parallelism": f"population sharded x{world}, all-to-all per tick" if sharded else "1 GPU"},
-        "detection_ms_after_t0": detect,
+        "detection_ms_after_t0": detect, "detection_ms_after_failure": detect_after_kill,
     }
 
     if sharded and not args.no_replica_leg:
