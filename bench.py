@@ -162,7 +162,10 @@ def main():
     # gossip block scales with queue_cap) and 24 inbox slots (in-degree is Poisson(k)) are ample, and
     # an overflow would raise SWIM_EOVERFLOW instead of passing silently
     cfg_kw = dict(n_nodes=args.nodes, n_replicas=reps, seed=args.seed, subject_cap=args.subject_cap,
-                  gossip_nodes=args.fanout, queue_cap=4, inbox_cap=24,
+                  gossip_nodes=args.fanout, queue_cap=4,
+                  # records from other shards arrive unfiltered (a shard cannot see a remote receiver's view), so a
+                  # sharded node's in-degree is the raw Poisson(k) of packets times the rumours in each: more room
+                  inbox_cap=24 if world == 1 else 96,
                   device=local_rank, shard_rank=rank, n_shards=world,
                   flags=abi.F_DEFAULT & ~abi.F_PIGGYBACK if args.no_piggyback else abi.F_DEFAULT)
     victims = victims_for(args.seed, reps, args.nodes)
