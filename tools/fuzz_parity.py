@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Randomised lock-step parity: random configurations and stimulus schedules, product library (optionally sharded over
+several in-process shards) against the unsharded oracle; state digest and counters compared every few ticks.
+
+usage: tools/fuzz_parity.py [--cases N] [--seed S] [--backend hip|oracle]   (oracle = sharded oracle vs unsharded oracle: a CPU
+self-check of the harness and of the oracle's own sharding)
+"""
+import argparse, ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+from consul_amd import abi
+from consul_amd.sim import Sim, SwimError, preset
+from consul_amd.dist import LocalExchange, ShardedSim
+
+KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent", "msgs_applied", "probes",
+        "probe_acks", "probe_indirect_acks", "probe_tcp_acks", "probe_failures", "nacks_missed", "refutes", "suspicion_timeouts",
+        "confirmations", "queue_drops", "event_drops", "user_events_delivered", "user_events_deduped", "user_events_stale",
+        "piggybacks", "msgs_piggybacked", "push_pulls"]
+
+
+def draw_case(rng):
+    which = int(rng.choice([abi.PRESET_LAN, abi.PRESET_LAN, abi.PRESET_WAN, abi.PRESET_LOCAL]))
+    shards = int(rng.choice([1, 1, 2, 3, 4]))
+    chunk = int(rng.choice([0, 0, 64, 256]))
+    per = int(rng.integers(1, 9)) * (chunk or 256) if rng.random() < 0.7 else int(rng.integers(40, 1500))
+    n = per * shards
+    if chunk and n % (chunk * shards):
+        chunk = 0
+    flags = abi.F_DEFAULT
+    for f in (abi.F_BUDDY_SUSPECT, abi.F_NACK, abi.F_FILTER_NOOP, abi.F_PIGGYBACK, abi.F_TCP_FALLBACK):
+        if rng.random() < 0.25:
+            flags &= ~f
+    if rng.random() < 0.5:
+        flags |= abi.F_SERF_EVENTS
+    kw = dict(n_nodes=n, n_replicas=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)), flags=flags,
+              gossip_nodes=int(rng.integers(1, 6)), indirect_checks=int(rng.integers(0, 5)), subject_cap=min(n, 1024),
+              queue_cap=int(rng.choice([2, 4, 8, 16])), event_queue_cap=int(rng.choice([2, 4, 8])), inbox_cap=4096,
+              loss_q32=int(float(rng.choice([0, 0, 0.05, 0.25])) * 2**32), phase_chunk=chunk,
+              suspicion_mult=int(rng.integers(3, 8)), retransmit_mult=int(rng.integers(1, 5)),
+              push_pull_interval_ms=int(rng.choice([0, 3000, 30000])), watch_node=int(rng.integers(0, n)))
+    return which, shards, kw
+
+
+def stimulate(rng, sims, n, reps, dead, serf):
+    r = int(rng.integers(reps)); op = rng.random()
+    ids = [int(x) for x in rng.choice(n, size=int(rng.integers(1, 4)), replace=False)]
+    if op < 0.30:
+        ids = [i for i in ids if not dead[r][i]]
+        for i in ids: dead[r][i] = True
+        if ids: [s.kill(r, ids) for s in sims]
+    elif op < 0.45:
+        ids = [i for i in range(n) if dead[r][i]][:3]
+        for i in ids: dead[r][i] = False
+        if ids: [s.revive(r, ids) for s in sims]
+    elif op < 0.55:
+        [s.leave(r, ids) for s in sims]
+    elif op < 0.70:
+        [s.update(r, ids) for s in sims]
+    elif op < 0.78:
+        g = (rng.random(n) < 0.02).astype(np.uint8) if rng.random() < 0.6 else np.zeros(n, dtype=np.uint8)
+        [s.partition(r, g) for s in sims]
+    elif op < 0.84:
+        p = float(rng.choice([0.0, 0.1]))
+        [s.set_loss(p) for s in sims]
+    elif serf:
+        live = [i for i in range(n) if not dead[r][i]]
+        if live:
+            o = int(rng.choice(live)); eid = int(rng.integers(1, 1 << 20))
+            [s.user_event(r, o, eid) for s in sims]
+
+
+def run_case(k, lib, ora, rng, verbose):
+    which, shards, kw = draw_case(rng)
+    n, reps = kw["n_nodes"], kw["n_replicas"]
+    try:
+        if shards > 1:
+            a = ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw)) for i in range(shards)], LocalExchange())
+        else:
+            a = Sim(lib, preset(lib, which, **kw))
+        b = Sim(ora, preset(ora, which, **kw))
+    except SwimError as e:
+        if verbose: print(f"case {k}: config refused ({e})")
+        return "refused"
+    dead = [[False] * n for _ in range(reps)]
+    serf = bool(kw["flags"] & abi.F_SERF_EVENTS)
+    ticks = 0
+    try:
+        for block in range(int(rng.integers(6, 16))):
+            for _ in range(int(rng.integers(0, 3))):
+                stimulate(rng, (a, b), n, reps, dead, serf)
+            step = int(rng.integers(1, 40))
+            a.step(step); b.step(step); ticks += step
+            a.sync()
+            da, db = a.digest(), b.digest()
+            sa, sb = a.stats(), b.stats()
+            bad = [key for key in KEYS if sa[key] != sb[key]]
+            if da != db or bad:
+                print(f"case {k}: MISMATCH after {ticks} ticks: digest {'differs' if da != db else 'ok'}, stats {bad}\n   preset {which} shards {shards} {kw}")
+                return "mismatch"
+    except SwimError as e:
+        # a bounded structure overflowed: legal, but both sides must agree that it did
+        print(f"case {k}: {e} after ~{ticks} ticks (preset {which} shards {shards} n {n})")
+        return "overflow"
+    finally:
+        a.close(); b.close()
+    if verbose: print(f"case {k}: ok ({ticks} ticks, preset {which}, {shards} shard(s), n {n} x {reps})")
+    return "ok"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20); ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--backend", default="hip"); ap.add_argument("-v", action="store_true")
+    args = ap.parse_args()
+    ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
+    if args.backend == "hip":
+        from consul_amd import lib as L
+        lib = L.load()
+    else:
+        lib = ora
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time(); tally = {}
+    for k in range(args.cases):
+        res = run_case(k, lib, ora, rng, args.v)
+        tally[res] = tally.get(res, 0) + 1
+    print(f"{args.cases} cases in {time.time() - t0:.1f} s: {tally}")
+    sys.exit(1 if tally.get("mismatch") else 0)
+
+
+if __name__ == "__main__":
+    main()
