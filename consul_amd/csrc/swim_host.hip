@@ -341,8 +341,13 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
   DALLOC(s, D.seg, e_cap); DALLOC(s, D.seg_cnt, D.n_seg); DALLOC(s, D.seg_last, D.n_seg);
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
-    // own shard: only timers/probes/slot requests; other shards: their share of the gossip records
-    uint64_t cap = sh == D.rank ? 2 * NL + 4096 : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards;
+    // own shard: probe verdicts, slot requests, push-pull; other shards: their share of the gossip records, the acks'
+    // piggy-back orders, carried broadcasts, and push-pull — whose every exchange sends one record per subject in use,
+    // all of a boundary tick's exchanges possibly to the same shard
+    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * (D.S + 1);
+    uint64_t cap = sh == D.rank ? 2 * NL + 4096 + pp_burst
+                                : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards + NL + pp_burst;
+    if (cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
     D.out_cap[sh] = (uint32_t)cap;
     DALLOC(s, D.out[sh], cap);
   }
@@ -355,7 +360,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
   s->scratch_bytes = 1 << 20; { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
-  if (D.n_shards > 1) { s->in_cap = (uint32_t)e_cap; DALLOC(s, s->in_buf, s->in_cap); }
+  if (D.n_shards > 1) {   // what all the other shards together may address to this one in a tick (their lists are sized like ours)
+    uint64_t in_cap = 0;
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) if (sh != D.rank) in_cap += D.out_cap[sh];
+    s->in_cap = (uint32_t)std::min<uint64_t>(in_cap, 0x7FFFFFFFull); DALLOC(s, s->in_buf, s->in_cap);
+  }
 
   hipStream_t st = s->stream;
   HIPCK(s, hipMemsetAsync(D.tick, 0, 4, st));

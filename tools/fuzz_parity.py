@@ -26,6 +26,8 @@ def draw_case(rng):
     n = per * shards
     if chunk and n % (chunk * shards):
         chunk = 0
+    if shards > 1 and (n // shards) % (chunk or min(256, 1 << max(0, (n // shards).bit_length() - 1))):
+        per = 256 * int(rng.integers(1, 9)); n = per * shards; chunk = 0     # a shard must hold whole stagger chunks
     flags = abi.F_DEFAULT
     for f in (abi.F_BUDDY_SUSPECT, abi.F_NACK, abi.F_FILTER_NOOP, abi.F_PIGGYBACK, abi.F_TCP_FALLBACK):
         if rng.random() < 0.25:
