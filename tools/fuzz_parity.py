@@ -71,7 +71,68 @@ def stimulate(rng, sims, n, reps, dead, serf):
             [s.user_event(r, o, eid) for s in sims]
 
 
-def run_case(k, lib, ora, rng, verbose):
+def node_fields(ni):
+    q = [(e.subject, e.incarnation, e.from_, e.type, e.transmits, e.seq) for e in list(ni.queue)[: ni.queue_len]]
+    return dict(inc=ni.incarnation, target=ni.probe_target, deadline=ni.probe_deadline_tick, cursor=ni.probe_cursor, epoch=ni.probe_epoch,
+                qlen=ni.queue_len, evqlen=ni.event_queue_len, evclock=ni.event_clock, alive=ni.alive, leaving=ni.leaving,
+                awareness=ni.awareness, queue=sorted(q))
+
+
+def diagnose(k, lib, ora, seed):
+    """Replay case k one tick at a time and describe the first divergence."""
+    rng = np.random.default_rng([seed, k])
+    which, shards, kw = draw_case(rng)
+    n, reps = kw["n_nodes"], kw["n_replicas"]
+    a = (ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw)) for i in range(shards)], LocalExchange())
+         if shards > 1 else Sim(lib, preset(lib, which, **kw)))
+    b = Sim(ora, preset(ora, which, **kw))
+    dead = [[False] * n for _ in range(reps)]
+    serf = bool(kw["flags"] & abi.F_SERF_EVENTS)
+    tick = 0
+    for block in range(int(rng.integers(6, 16))):
+        for _ in range(int(rng.integers(0, 3))):
+            stimulate(rng, (a, b), n, reps, dead, serf)
+        for _ in range(int(rng.integers(1, 40))):
+            a.step(1); b.step(1); tick += 1; a.sync()
+            sa, sb = a.stats(), b.stats()
+            bad = {key: (sa[key], sb[key]) for key in KEYS if sa[key] != sb[key]}
+            if a.digest() == b.digest() and not bad:
+                continue
+            print(f"  case {k}: first divergence in tick {tick - 1}; stats (hip, oracle): {bad}")
+            if shards == 1:
+                ea, eb = a.edges(), b.edges()
+                sa_, sb_ = set(map(tuple, ea.tolist())), set(map(tuple, eb.tolist()))
+                print(f"  edges: hip {len(ea)} oracle {len(eb)}; only hip {sorted(sa_ - sb_)[:6]}; only oracle {sorted(sb_ - sa_)[:6]}")
+            shown = 0
+            sims_a = a.sims if shards > 1 else [a]
+            for r in range(reps):
+                for i in range(n):
+                    owner = sims_a[i // (n // shards)] if shards > 1 else a
+                    fa, fb = node_fields(owner.node_info(r, i)), node_fields(b.node_info(r, i))
+                    if fa != fb:
+                        print(f"  node ({r},{i}): " + "; ".join(f"{key}: hip {fa[key]} oracle {fb[key]}" for key in fa if fa[key] != fb[key]))
+                        shown += 1
+                        if shown >= 4: break
+                if shown >= 4: break
+            if not shown:
+                print("  node self-state equal everywhere: the difference is in the views")
+                for r in range(reps):
+                    for o in range(0, n, max(1, n // 64)):
+                        owner = sims_a[o // (n // shards)] if shards > 1 else a
+                        ma, mb = owner.members(r, o), b.members(r, o)
+                        if not np.array_equal(ma, mb):
+                            d = [(x.tolist(), y.tolist()) for x, y in zip(ma, mb) if x.tolist() != y.tolist()][:3]
+                            print(f"  observer ({r},{o}) rows differ (hip, oracle): {d}"); shown += 1
+                            break
+                    if shown: break
+            a.close(); b.close()
+            return
+    print(f"  case {k}: no divergence on replay (non-deterministic?)")
+    a.close(); b.close()
+
+
+def run_case(k, lib, ora, seed, verbose):
+    rng = np.random.default_rng([seed, k])
     which, shards, kw = draw_case(rng)
     n, reps = kw["n_nodes"], kw["n_replicas"]
     try:
@@ -113,6 +174,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=20); ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--backend", default="hip"); ap.add_argument("-v", action="store_true")
+    ap.add_argument("--diagnose", type=int, default=3, help="replay this many mismatching cases tick by tick")
+    ap.add_argument("--only", default="", help="comma separated case numbers")
     args = ap.parse_args()
     ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
     if args.backend == "hip":
@@ -120,11 +183,13 @@ def main():
         lib = L.load()
     else:
         lib = ora
-    rng = np.random.default_rng(args.seed)
-    t0 = time.time(); tally = {}
-    for k in range(args.cases):
-        res = run_case(k, lib, ora, rng, args.v)
+    t0 = time.time(); tally = {}; diagnosed = 0
+    only = [int(x) for x in args.only.split(",")] if args.only else range(args.cases)
+    for k in only:
+        res = run_case(k, lib, ora, args.seed, args.v)
         tally[res] = tally.get(res, 0) + 1
+        if res == "mismatch" and diagnosed < args.diagnose:
+            diagnose(k, lib, ora, args.seed); diagnosed += 1
     print(f"{args.cases} cases in {time.time() - t0:.1f} s: {tally}")
     sys.exit(1 if tally.get("mismatch") else 0)
 
