@@ -1557,7 +1557,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
     }
   }
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
-    for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
+    for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) {
+      D.slot_dirty[(size_t)r * D.S + sl] = 1;
+      // The expire role's gate (suspect count and earliest deadline of the last census) only covers observers that were
+      // running then.  A node that comes back resumes its old views, whose suspicion timers may be long overdue: open
+      // the gate so that the next tick scans the column; the census at the end of that tick closes it again.
+      if (op == INJ_REVIVE) { D.slot_susp[(size_t)r * D.S + sl] = 1; D.slot_mindl[(size_t)r * D.S + sl] = 0; }
+    }
   S.flush(D);
 }
 __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {

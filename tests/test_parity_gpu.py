@@ -336,3 +336,22 @@ def test_tcp_fallback_under_loss_parity(hip, oracle):
     assert_same(a, b, [(0, 321)])
     st = b.stats()
     assert st["probe_tcp_acks"] > 0 and a.stats()["probe_tcp_acks"] == st["probe_tcp_acks"] and st["probe_failures"] > 0
+
+
+def test_revived_node_fires_overdue_suspicion_timers(hip, oracle):
+    """A node that went down while it suspected somebody resumes its old views when it comes back, and the suspicion
+    timer that ran out meanwhile fires in its first tick (found by tools/fuzz_parity.py: the expire role's gate only
+    knew the observers that were running at the last census)."""
+    a, b = pair(hip, oracle, n_nodes=64, seed=4, subject_cap=16)
+    for s in (a, b):
+        s.step_ms(2000); s.kill(0, [9]); s.step_ms(3000)
+    holder = next(o for o in range(64) if o != 9 and b.view(0, o, 9).state == abi.STATE_SUSPECT)
+    for s in (a, b):
+        s.kill(0, [holder]); s.step_ms(60000)          # everybody else has long declared 9 dead; holder's timer is overdue
+        s.revive(0, [holder])
+    t0 = b.stats()["suspicion_timeouts"]
+    for t in range(30):
+        a.step(1); b.step(1); a.sync()
+        assert a.digest() == b.digest(), f"tick {t} after the revive"
+        assert a.stats()["suspicion_timeouts"] == b.stats()["suspicion_timeouts"]
+    assert b.stats()["suspicion_timeouts"] > t0 and b.view(0, holder, 9).state == abi.STATE_DEAD
