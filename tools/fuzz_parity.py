@@ -43,9 +43,34 @@ def draw_case(rng):
     return which, shards, kw
 
 
-def stimulate(rng, sims, n, reps, dead, serf):
+BRIDGE = {}      # per case: replica -> the node a "real" member is attached as (unsharded cases only)
+
+
+def bridge_poll_equal(sims):
+    """Transport.PacketCh of every attached node: both libraries must have captured the same rumours."""
+    for r, att in BRIDGE.items():
+        got = [s.transport_poll(r, att) for s in sims]
+        if got[0] != got[1]:
+            return False, (r, att, got[0][:4], got[1][:4])
+    return True, None
+
+
+def stimulate(rng, sims, n, reps, dead, serf, bridge=False):
     r = int(rng.integers(reps)); op = rng.random()
     ids = [int(x) for x in rng.choice(n, size=int(rng.integers(1, 4)), replace=False)]
+    if r in BRIDGE:
+        ids = [i for i in ids if i != BRIDGE[r]] or [(BRIDGE[r] + 1) % n]      # the attached node is driven from outside only
+    if bridge and op >= 0.90:
+        if r not in BRIDGE:
+            live = [i for i in range(n) if not dead[r][i]]
+            if not live: return
+            BRIDGE[r] = int(rng.choice(live))
+            [s.transport_poll(r, BRIDGE[r]) for s in sims]                      # the first call attaches
+        msgs = [(int(rng.integers(n)), int(rng.integers(1, 4)), int(rng.integers(0, 3)), int(rng.integers(n))) for _ in range(int(rng.integers(1, 4)))]
+        dst = int(rng.integers(n))
+        if dst != BRIDGE[r]:
+            [s.transport_write_to(r, BRIDGE[r], dst, msgs) for s in sims]
+        return
     if op < 0.30:
         ids = [i for i in ids if not dead[r][i]]
         for i in ids: dead[r][i] = True
@@ -89,9 +114,10 @@ def diagnose(k, lib, ora, seed):
     dead = [[False] * n for _ in range(reps)]
     serf = bool(kw["flags"] & abi.F_SERF_EVENTS)
     tick = 0
+    BRIDGE.clear()
     for block in range(int(rng.integers(6, 16))):
         for _ in range(int(rng.integers(0, 3))):
-            stimulate(rng, (a, b), n, reps, dead, serf)
+            stimulate(rng, (a, b), n, reps, dead, serf, bridge=shards == 1)
         for _ in range(int(rng.integers(1, 40))):
             a.step(1); b.step(1); tick += 1; a.sync()
             sa, sb = a.stats(), b.stats()
@@ -147,16 +173,20 @@ def run_case(k, lib, ora, seed, verbose):
     dead = [[False] * n for _ in range(reps)]
     serf = bool(kw["flags"] & abi.F_SERF_EVENTS)
     ticks = 0
+    BRIDGE.clear()
     try:
         for block in range(int(rng.integers(6, 16))):
             for _ in range(int(rng.integers(0, 3))):
-                stimulate(rng, (a, b), n, reps, dead, serf)
+                stimulate(rng, (a, b), n, reps, dead, serf, bridge=shards == 1)
             step = int(rng.integers(1, 40))
             a.step(step); b.step(step); ticks += step
             a.sync()
             da, db = a.digest(), b.digest()
             sa, sb = a.stats(), b.stats()
             bad = [key for key in KEYS if sa[key] != sb[key]]
+            same, what = bridge_poll_equal((a, b)) if shards == 1 else (True, None)
+            if not same:
+                bad.append(f"transport_poll {what}")
             if da != db or bad:
                 print(f"case {k}: MISMATCH after {ticks} ticks: digest {'differs' if da != db else 'ok'}, stats {bad}\n   preset {which} shards {shards} {kw}")
                 return "mismatch"
