@@ -100,7 +100,7 @@ struct SwDev {
   // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
   uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue
   uint32_t* in_any;   // [NL/256] some node of the block received something this tick
-  uint32_t* alive_cnt;// [NL/256] running nodes in the block
+  uint32_t* alive_cnt;// [NL/256] nodes of the block the simulator acts for (running, not attached)
   uint32_t* qbits;    // [NL/32] bit per lane: the node has something queued (exact; piggy-back orders are gated on it)
   // per (replica, slot) view columns, [R*S][nloc]
   //   va = {inc<<2|state, state-change ms, confirmations seen, first accuser}: one 16-byte sector answers

@@ -1528,11 +1528,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
     size_t l = (size_t)r * D.nloc + (x - D.i0);
     if (op == INJ_KILL) {
       uint32_t old = atomicOr(&D.nw[g], NW_DEAD);
-      if (local && !(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);
+      if (local && !(old & NW_INERT)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);     // it was being acted for
     } else if (op == INJ_REVIVE) {
       uint32_t old = atomicAnd(&D.nw[g], ~NW_DEAD);
       if (local) {
-        if (old & NW_DEAD) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
+        if ((old & NW_DEAD) && !(old & NW_ATTACHED)) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
         uint2 h = D.ph[l];
         D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.in_cnt[l] = 0;
       }
@@ -1576,6 +1576,7 @@ __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
     uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.in_cnt[l] = 0;
+    if (!(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);          // no longer one of the nodes the simulator acts for
     q_bit_lane(D, l, false, true);
   }
 }

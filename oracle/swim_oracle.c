@@ -1243,7 +1243,12 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
 static int attach(swim_sim* s, uint32_t r, uint32_t a) {
   if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
   if (r >= s->R || a >= s->N) return SWIM_ERANGE;
-  s->attached[(size_t)r * s->N + a] = 1;
+  size_t g = (size_t)r * s->N + a;
+  if (!s->attached[g] && is_local(s, a)) {   /* from now on the node is driven from outside: what it had queued or received is void */
+    node_t* nd = node_at(s, r, a);
+    nd->qlen = 0; nd->evqlen = 0; nd->in_cnt = 0;
+  }
+  s->attached[g] = 1;
   return SWIM_OK;
 }
 /* Transport.WriteToAddress: a packet of n rumours from the attached node to a virtual peer; it is in the
