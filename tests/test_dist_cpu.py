@@ -57,3 +57,16 @@ def test_two_processes_over_gloo_match_unsharded(oracle):
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
     assert line and "ok=True" in line[0], (line, out.stderr[-1000:])
+
+
+def test_randomised_sharding_cases(oracle):
+    """tools/fuzz_parity.py with the oracle on both sides: random configurations and stimulus, 1-4 in-process shards against
+    the unsharded run (also exercises swim_tick_end_begin, the activity hint and the transport bridge of the oracle)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    tally = {}
+    for k in range(10):
+        res = fz.run_case(k, oracle, oracle, 7, False)
+        tally[res] = tally.get(res, 0) + 1
+    assert not tally.get("mismatch") and tally.get("ok", 0) >= 5, tally

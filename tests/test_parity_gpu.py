@@ -355,3 +355,18 @@ def test_revived_node_fires_overdue_suspicion_timers(hip, oracle):
         assert a.digest() == b.digest(), f"tick {t} after the revive"
         assert a.stats()["suspicion_timeouts"] == b.stats()["suspicion_timeouts"]
     assert b.stats()["suspicion_timeouts"] > t0 and b.view(0, holder, 9).state == abi.STATE_DEAD
+
+
+def test_randomised_parity_cases(hip, oracle):
+    """A fixed slice of tools/fuzz_parity.py (random configurations, shards, stimulus and transport-bridge operations):
+    none of the cases that run to the end may differ from the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    tally = {}
+    for k in range(30):
+        res = fz.run_case(k, hip, oracle, 131, False)
+        tally[res] = tally.get(res, 0) + 1
+    assert not tally.get("mismatch") and tally.get("ok", 0) >= 15, tally
