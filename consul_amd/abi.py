@@ -145,6 +145,8 @@ PROTOTYPES = {
     "swim_kat_probe_perm": (u32, [u64, u32, u32, u32, u32]),
     "swim_kat_remaining_suspicion_ms": (i32, [u32, u32, u32, u32, u32]),
     "swim_kat_phase_of": (None, [P(Config), u32, P(u32), P(u32)]),
+    "swim_kat_awareness_apply": (u32, [u32, u32, C.c_int32]),
+    "swim_kat_awareness_scale_ms": (u32, [u32, u32]),
 }
 
 

@@ -969,6 +969,13 @@ extern "C" int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edg
 extern "C" void swim_kat_philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) { sw_philox(c[0], c[1], c[2], c[3], k[0], k[1], o); }
 extern "C" uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) { return sw_probe_perm(seed, n, node, epoch, index); }
 extern "C" int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t el, uint32_t mn, uint32_t mx) { return (int32_t)remaining_suspicion_ms(n, k, el, mn, mx); }
+// awareness.go ApplyDelta / ScaleTimeout: the same expressions as awareness_apply() in swim_kernels.hip and the probe
+// deadline `t + P * (awareness + 1)` of the probe role
+extern "C" uint32_t swim_kat_awareness_apply(uint32_t max_mult, uint32_t score, int32_t delta) {
+  int v = (int)score + delta, mx = (int)max_mult - 1;
+  return (uint32_t)(v < 0 ? 0 : v > mx ? mx : v);
+}
+extern "C" uint32_t swim_kat_awareness_scale_ms(uint32_t score, uint32_t timeout_ms) { return timeout_ms * (score + 1); }
 extern "C" void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gp, uint32_t* pp) {
   swim_derived d;
   if (swim_config_derive(cfg, &d)) { if (gp) *gp = SWIM_NONE; if (pp) *pp = SWIM_NONE; return; }

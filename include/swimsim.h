@@ -343,6 +343,9 @@ int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t elapsed
                                         uint32_t min_ms, uint32_t max_ms);
 void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gossip_phase,
                        uint32_t* probe_phase);
+/* awareness.go ApplyDelta (clamped to [0, max-1]) and ScaleTimeout (timeout * (score+1)) */
+uint32_t swim_kat_awareness_apply(uint32_t awareness_max_mult, uint32_t score, int32_t delta);
+uint32_t swim_kat_awareness_scale_ms(uint32_t score, uint32_t timeout_ms);
 
 #ifdef __cplusplus
 }

@@ -412,10 +412,13 @@ static void broadcast(swim_sim* s, node_t* nd, uint32_t subject, uint8_t type, u
 /* ------------------------------------------------------------------------------------------ */
 /* awareness.go                                                                                */
 /* ------------------------------------------------------------------------------------------ */
-static void awareness_delta(swim_sim* s, node_t* nd, int delta) {
-  int v = (int)nd->awareness + delta, mx = (int)s->cfg.awareness_max_mult - 1;
+static int awareness_next(int max_mult, int score, int delta) {       /* awareness.ApplyDelta */
+  int v = score + delta, mx = max_mult - 1;
   if (v < 0) v = 0; if (v > mx) v = mx;
-  nd->awareness = (uint8_t)v;
+  return v;
+}
+static void awareness_delta(swim_sim* s, node_t* nd, int delta) {
+  nd->awareness = (uint8_t)awareness_next((int)s->cfg.awareness_max_mult, (int)nd->awareness, delta);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1290,6 +1293,8 @@ int swim_profile_read(swim_sim* s, swim_kernel_time* out, size_t cap, size_t* n_
 void swim_kat_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out); }
 uint32_t swim_kat_probe_perm(uint64_t seed, uint32_t n, uint32_t node, uint32_t epoch, uint32_t index) { return probe_perm(seed, n, node, epoch, index); }
 int32_t swim_kat_remaining_suspicion_ms(uint32_t n, uint32_t k, uint32_t el, uint32_t mn, uint32_t mx) { return (int32_t)remaining_suspicion_ms(n, k, el, mn, mx); }
+uint32_t swim_kat_awareness_apply(uint32_t max_mult, uint32_t score, int32_t delta) { return (uint32_t)awareness_next((int)max_mult, (int)score, (int)delta); }
+uint32_t swim_kat_awareness_scale_ms(uint32_t score, uint32_t timeout_ms) { return timeout_ms * (score + 1); }   /* awareness.ScaleTimeout */
 void swim_kat_phase_of(const swim_config* cfg, uint32_t node, uint32_t* gp, uint32_t* pp) {
   swim_derived d; if (swim_config_derive(cfg, &d)) { if (gp) *gp = SWIM_NONE; if (pp) *pp = SWIM_NONE; return; }
   uint32_t c = node / d.phase_chunk;

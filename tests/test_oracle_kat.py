@@ -105,6 +105,17 @@ def test_suspicion_table_lan_fraction(anylib):
 
 
 # ---- the shuffled probe order is a permutation per (node, epoch) ------------------------------------
+def test_awareness_table_like_upstream(anylib):
+    """memberlist awareness_test.go TestAwareness (recalled): max 8, deltas applied in sequence, health score and
+    ScaleTimeout(1 s) after each."""
+    cases = [(0, 0, 1000), (-1, 0, 1000), (-10, 0, 1000), (1, 1, 2000), (-1, 0, 1000), (10, 7, 8000), (-1, 6, 7000),
+             (-1, 5, 6000), (-1, 4, 5000), (-1, 3, 4000), (-1, 2, 3000), (-1, 1, 2000), (-1, 0, 1000), (-1, 0, 1000)]
+    score = 0
+    for delta, want, timeout in cases:
+        score = anylib.swim_kat_awareness_apply(8, score, delta)
+        assert score == want and anylib.swim_kat_awareness_scale_ms(score, 1000) == timeout
+
+
 @pytest.mark.parametrize("n", [2, 7, 128, 1000, 4096])
 def test_probe_order_is_a_permutation(anylib, n):
     for node, epoch in ((0, 0), (n - 1, 3)):
