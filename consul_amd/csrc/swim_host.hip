@@ -903,7 +903,7 @@ extern "C" int swim_profile_read(swim_sim* s, swim_kernel_time* out, size_t cap,
 // call naming `a` attaches it: the simulator stops acting for it, peers keep seeing it alive.
 static int attach(swim_sim* s, uint32_t r, uint32_t a) {
   if (!s) return SWIM_EINVAL;
-  if (s->in_tick) return SWIM_ESTATE;
+  if (s->in_tick || s->cfg.n_shards != 1) return SWIM_ESTATE;      // the bridge is defined for an unsharded population
   if (r >= s->D.R || a >= s->D.N) return SWIM_ERANGE;
   uint64_t key = ((uint64_t)r << 32) | a;
   if (std::find(s->attached.begin(), s->attached.end(), key) != s->attached.end()) return SWIM_OK;

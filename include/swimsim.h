@@ -329,7 +329,9 @@ int swim_profile_read(swim_sim* sim, swim_kernel_time* out, size_t cap, size_t* 
 /* ---- memberlist.Transport bridge (agent/consul/wanfed/wanfed.go:96-141)
  * A real memberlist node attached as virtual node `attached` exchanges rumours with its
  * virtual peers: write_to = Transport.WriteToAddress, poll = Transport.PacketCh.  Packets are
- * swim_edge records here; the msgpack wire codec is the host shim's job. */
+ * swim_edge records here; include/swimsim_wire.hpp converts them to and from memberlist's packet bytes.
+ * Defined for an unsharded population (n_shards == 1; SWIM_ESTATE otherwise).  The first call naming a node
+ * attaches it: what it had queued is dropped and the simulator stops acting for it. */
 int swim_transport_write_to(swim_sim* sim, uint32_t replica, uint32_t attached,
                             uint32_t virtual_dst, const swim_edge* msgs, size_t n);
 int swim_transport_poll(swim_sim* sim, uint32_t replica, uint32_t attached, swim_edge* out,

@@ -1244,7 +1244,7 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
 /* memberlist.Transport bridge at rumour granularity (the msgpack codec is the host shim's job).
  * The first call naming `a` attaches it: the simulator stops acting for it, peers keep seeing it alive. */
 static int attach(swim_sim* s, uint32_t r, uint32_t a) {
-  if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
+  if (!s) return SWIM_EINVAL; if (s->in_tick || s->cfg.n_shards != 1) return SWIM_ESTATE;   /* unsharded populations only */
   if (r >= s->R || a >= s->N) return SWIM_ERANGE;
   size_t g = (size_t)r * s->N + a;
   if (!s->attached[g] && is_local(s, a)) {   /* from now on the node is driven from outside: what it had queued or received is void */
