@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NONE = 0xFFFFFFFF
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE = 0, -22, -12, -19, -34, -75, -71
@@ -35,7 +35,7 @@ class Config(C.Structure):
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
-        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap",
+        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "fold_interval_ms",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device")] + [("seed", u64)]
 
@@ -45,7 +45,8 @@ class Derived(C.Structure):
         "quantum_ms", "gossip_period", "probe_period", "probe_timeout_ticks", "phase_chunk",
         "retransmit_limit", "suspicion_k", "suspicion_min_ms", "suspicion_max_ms")] + [
         ("suspicion_timeout_ms", u32 * 8), ("node_scale_milli", u32),
-        ("push_pull_scale", u32), ("push_pull_period_ticks", u32), ("packet_budget", u32)]
+        ("push_pull_scale", u32), ("push_pull_period_ticks", u32), ("packet_budget", u32),
+        ("view_cap", u32), ("fold_period_ticks", u32)]
 
 
 class Member(C.Structure):
@@ -90,7 +91,8 @@ class Stats(C.Structure):
                 ("queue_drops", u64), ("inbox_overflow", u64), ("subject_overflow", u64),
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
-                ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64)]
+                ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
+                ("view_drops", u64), ("folds", u64), ("fold_freed", u64)]
 
 
 class KernelTime(C.Structure):
@@ -128,6 +130,7 @@ PROTOTYPES = {
     "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
     "swim_set_loss": (C.c_int, [SimP, u32]),
     "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
+    "swim_watch": (C.c_int, [SimP, u32, u32]),
     "swim_members": (C.c_int, [SimP, u32, u32, P(Member), C.c_size_t, P(C.c_size_t)]),
     "swim_view": (C.c_int, [SimP, u32, u32, u32, P(Member)]),
     "swim_poll_events": (C.c_int, [SimP, P(Event), C.c_size_t, P(C.c_size_t)]),

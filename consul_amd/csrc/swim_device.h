@@ -22,7 +22,7 @@ enum {
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
-  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS,
+  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_FOLDS, ST_FOLD_FREED,
   ST_COUNT
 };
 
@@ -40,6 +40,7 @@ enum {
 #define SW_ERR_EVENT_OVF 0x10u
 #define SW_ERR_PEND_OVF 0x20u
 #define SW_ERR_CARRY_OVF 0x40u
+#define SW_ERR_VIEW_CORRUPT 0x80u   /* an observer's view table lost its free slot: cannot happen (load <= (view_cap+1)/VT <= 1/2) */
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
 enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
@@ -50,14 +51,29 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 //   bits 30-24 partition group (ground truth)
 //   bit 23     attached: driven from outside through the transport bridge (peers see it alive, the
 //              simulator does not act for it, rumours sent to it are captured)
-//   bits 22-0  subject slot + 1, 0 = nobody has news about it (every observer holds the base view)
+//   bit 22     subject: some observer OF THIS SHARD may hold an explicit view of it (set by the first
+//              observer that creates one, cleared when the subject is folded into the base row); clear =
+//              every local observer holds the base row's view, no table needs to be looked at
+//   bit 21     the base row's view of it is not alive@1 (read bk[])
+//   bits 20-0  watch slot + 1 (census / trace), 0 = not watched
 #define NW_DEAD 0x80000000u
 #define NW_ATTACHED 0x00800000u
+#define NW_SUBJECT 0x00400000u
+#define NW_BASEMOD 0x00200000u
 #define NW_INERT (NW_DEAD | NW_ATTACHED)           /* the simulator takes no action on behalf of this node */
-#define NW_SLOT_MASK 0x7FFFFFu
+#define NW_SLOT_MASK 0x1FFFFFu
 #define NW_PART(w) (((w) >> 24) & 0x7Fu)
 #define NW_SLOT(w) (((w) & NW_SLOT_MASK) - 1u)     /* 0xFFFFFFFF when none */
 #define NW_HAS_SLOT(w) (((w) & NW_SLOT_MASK) != 0u)
+
+// an observer's explicit views: open addressing, VT slots per lane (power of two, >= 2*(view_cap+1)), slot-major
+// (slot s of lane l at [s*NL + l]) so that lanes looking up the SAME subject — the hot case: one failure per
+// cluster — read consecutive 16-byte words.  Home slot by Fibonacci hashing, linear probing, backward-shift
+// deletion.  Only the owning lane writes its table (k_resolve, stimulus kernels, fold); everybody else reads.
+//   vt = {subject (VT_EMPTY = free), inc<<2|state, state-change ms, first accuser<<3 | confirmations}
+//   vc = {2nd, 3rd, 4th confirmer, -}: only touched while a suspicion is being confirmed
+#define VT_EMPTY 0xFFFFFFFFu
+#define FOLD_POISON 0xFFFFFFFFu
 
 struct SwDev {
   // dimensions
@@ -69,8 +85,7 @@ struct SwDev {
   uint32_t ctl_len[4];
   uint32_t susp_timeout[8];
   uint32_t loss_q32;
-  uint32_t ablate;   // SWIMSIM_ABLATE env: timing experiments only (results invalid); 0 in normal use
-  // SWIMSIM_ROLECLK=<file>: per tick and k_begin role, earliest block start / latest block end (100 MHz clock)
+  // -DSWIMSIM_DIAG builds only, SWIMSIM_ROLECLK=<file>: per tick and k_begin role, earliest block start / latest block end
   unsigned long long* role_clk; uint32_t role_clk_ticks;
   uint64_t seed;
   // global clock (device resident so a captured graph is tick independent)
@@ -102,19 +117,23 @@ struct SwDev {
   uint32_t* in_any;   // [NL/256] some node of the block received something this tick
   uint32_t* alive_cnt;// [NL/256] nodes of the block the simulator acts for (running, not attached)
   uint32_t* qbits;    // [NL/32] bit per lane: the node has something queued (exact; piggy-back orders are gated on it)
-  // per (replica, slot) view columns, [R*S][nloc]
-  //   va = {inc<<2|state, state-change ms, confirmations seen, first accuser}: one 16-byte sector answers
-  //        "what does this observer think of the subject" for peer selection, probing and the no-op filter
-  //   vb = {2nd, 3rd, 4th confirmer}: only read when a suspicion is being confirmed
-  uint4* va;
-  uint4* vb;
-  // slot tables
+  // explicit views (see above) and what bounds them
+  uint32_t VT, vt_shift, view_cap, fold_period;
+  uint4* vt;             // [VT][NL]
+  uint4* vc;             // [VT][NL]
+  uint32_t* vnum;        // [NL] explicit views held
+  uint32_t* vdl;         // [NL] earliest suspicion deadline among them (lower bound; NONE = none)
+  uint32_t* dl_blk;      // [NL/256] lower bound of the block's vdl over the lanes the simulator acts for
+  uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
+  uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)
+  // fold census: what this shard's acting observers hold (fl_*), what all shards reported (fg_*), per replica*N + id
+  uint32_t *fl_cnt, *fl_kmin, *fl_kmax, *fl_bad, *fg_cnt, *fg_kmin, *fg_kmax;
+  uint32_t* fold_any;    // [1] something was folded this tick (exception lists need a rebuild)
+  // watch slots (census / first-* stamps / trace of chosen subjects; observation only)
   uint32_t* subj_node;   // [R*S]
   uint32_t* n_slots;     // [R]
   uint32_t* slot_dirty;  // [R*S]
   uint32_t* slot_maxinc; // [R*S]
-  uint32_t* slot_susp;   // [R*S] suspect count at last census
-  uint32_t* slot_mindl;  // [R*S] earliest suspicion deadline at last census
   uint32_t* cen_acc;     // [R*S][CEN_WORDS] accumulators
   swim_census* census;   // [R*S] cached
   uint32_t* trace;       // [R*S][trace_ticks][5]
@@ -167,7 +186,7 @@ typedef const __attribute__((address_space(4))) SwDev& DevRef;
 
 // block ranges of the fused first launch of a tick
 struct BeginPlan {
-  uint32_t nb_expire;        // blocks walking the view columns of subjects with due suspicion timers
+  uint32_t nb_expire;        // blocks checking the node blocks' earliest suspicion deadlines (one wave per 64 node blocks)
   uint32_t nb_pend;          // blocks walking the pending-indirect-probe list
   uint32_t nb_probe;         // per replica: blocks over the probe-due node set
   uint32_t nb_gossip;        // per replica: blocks over the gossip-due node set

@@ -40,8 +40,10 @@ struct swim_sim {
   uint64_t ticks_run = 0, rounds_run = 0;
   SwDev* d_D = nullptr;                // the descriptor the kernels read (device copy of D)
   uint32_t* d_last_cnt = nullptr;      // [n_shards] edge counts of the finished tick
-  uint32_t* d_scratch = nullptr;       // small device scratch (ids upload, ltime, digest, node gather)
+  uint32_t* d_scratch = nullptr;       // device scratch (ids / partition mask upload in chunks, ltime, digest, gathers)
   size_t scratch_bytes = 0;
+  uint32_t* d_fresh = nullptr;         // [1024] watch slots allocated by the last stimulus call (count, then slot indices)
+  void *fold_zero = nullptr, *fold_ones = nullptr; size_t fold_zero_bytes = 0, fold_ones_bytes = 0;   // fold accumulators, by initial value
   uint4* in_buf = nullptr;             // records received from other shards
   uint32_t in_cap = 0, in_count = 0;
   uint32_t out_counts[SW_MAX_SHARDS + 1];  // host copy for swim_outbound / swim_activity (counts, then the activity word)
@@ -104,7 +106,8 @@ int64_t remaining_suspicion_ms(uint32_t n, uint32_t k, int64_t elapsed, int64_t 
 int validate(const swim_config* c) {
   if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
   if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
-  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 30)) return SWIM_ERANGE;
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 29)) return SWIM_ERANGE;   // first accuser<<3 | confirmations
+  if (c->view_cap > (1u << 20)) return SWIM_ERANGE;
   if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
   if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
   if (c->suspicion_mult < 1 || c->suspicion_mult > 6 || c->retransmit_mult < 1) return SWIM_EINVAL;
@@ -143,7 +146,7 @@ extern "C" int swim_config_preset(swim_config* c, int preset) {
   c->msg_len[SWIM_MSG_DEAD] = 48; c->msg_len[SWIM_MSG_USER] = 64;
   // ping / indirectPingReq / ackResp (serf puts a coordinate in Payload) / nackResp, msgpack with field names
   c->ctl_len[SWIM_CTL_PING] = 86; c->ctl_len[SWIM_CTL_INDIRECT] = 122; c->ctl_len[SWIM_CTL_ACK] = 108; c->ctl_len[SWIM_CTL_NACK] = 13;
-  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
+  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8; c->view_cap = 0; c->fold_interval_ms = 0;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
   return SWIM_OK;
@@ -190,6 +193,9 @@ extern "C" int swim_config_derive(const swim_config* c, swim_derived* d) {
     d->push_pull_period_ticks = (uint32_t)per;
   }
   d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
+  if (d->retransmit_limit > 255) return SWIM_ERANGE;     // transmits is an 8-bit field of the queue entry's meta word
+  d->view_cap = c->view_cap ? c->view_cap : std::min<uint32_t>(c->n_nodes, 32);
+  d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -223,6 +229,7 @@ static void drop_graphs(swim_sim* s) {
 extern "C" int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+#ifdef SWIMSIM_DIAG
   if (s->D.role_clk && getenv("SWIMSIM_ROLECLK")) {          // diagnostics: per tick, per role: start/end of the role's blocks
     std::vector<unsigned long long> raw((size_t)s->D.role_clk_ticks * 16 * 64), c((size_t)s->D.role_clk_ticks * 16);
     if (hipMemcpy(raw.data(), s->D.role_clk, raw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -240,6 +247,7 @@ extern "C" int swim_destroy(swim_sim* s) {
       }
     }
   }
+#endif
   drop_graphs(s);
   for (void* p : s->allocs) (void)hipFree(p);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -254,6 +262,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (rc) return rc;
   if (!out) return SWIM_EINVAL;
   if (cfg->n_shards > SW_MAX_SHARDS || cfg->subject_cap >= NW_SLOT_MASK) return SWIM_ERANGE;
+  if ((uint64_t)cfg->n_replicas * cfg->subject_cap > (1u << 24)) return SWIM_ERANGE;   // watch slots are observation only: keep them few
   {   // the gossip role stages both queues of its 256 lanes in LDS: 16 B x 256 x (queue_cap + event_queue_cap) of the CU's 160 KB
     const uint32_t slots = cfg->queue_cap + ((cfg->flags & SWIM_F_SERF_EVENTS) ? cfg->event_queue_cap : 0);
     if ((size_t)slots * SW_BLOCK * sizeof(uint4) + 8192 > 160 * 1024) return SWIM_ERANGE;
@@ -281,8 +290,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   for (int i = 0; i < 4; i++) { D.msg_len[i] = cfg->msg_len[i]; D.ctl_len[i] = cfg->ctl_len[i]; }
   for (int i = 0; i < 8; i++) D.susp_timeout[i] = d.suspicion_timeout_ms[i];
   D.loss_q32 = cfg->loss_q32; D.seed = cfg->seed;
-  if (const char* ab = getenv("SWIMSIM_ABLATE")) D.ablate = (uint32_t)strtoul(ab, nullptr, 0);
+#ifdef SWIMSIM_DIAG
   const bool want_role_clk = getenv("SWIMSIM_ROLECLK") != nullptr;
+#else
+  const bool want_role_clk = false;
+#endif
 
   const size_t NT = (size_t)D.N * D.R, NL = (size_t)D.nloc * D.R, NS = (size_t)D.R * D.S, NB = cdiv(NL, SW_BLOCK);
   DALLOC(s, D.tick, 1);
@@ -293,9 +305,20 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
-  DALLOC(s, D.va, NS * D.nloc); DALLOC(s, D.vb, NS * D.nloc);
+  // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
+  D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
+  { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
+  DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
+  DALLOC(s, D.vnum, NL); DALLOC(s, D.vdl, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+  {   // fold accumulators, grouped by the value a fold tick resets them to
+    const size_t n = D.fold_period ? NT : 1;
+    uint32_t* z; DALLOC(s, z, 5 * n + 16); s->fold_zero = z; s->fold_zero_bytes = (5 * n + 16) * 4;
+    D.fl_cnt = z; D.fl_kmax = z + n; D.fl_bad = z + 2 * n; D.fg_cnt = z + 3 * n; D.fg_kmax = z + 4 * n; D.fold_any = z + 5 * n;
+    uint32_t* f; DALLOC(s, f, 2 * n); s->fold_ones = f; s->fold_ones_bytes = 2 * n * 4;
+    D.fl_kmin = f; D.fg_kmin = f + n;
+  }
   DALLOC(s, D.subj_node, NS); DALLOC(s, D.n_slots, D.R); DALLOC(s, D.slot_dirty, NS);
-  DALLOC(s, D.slot_maxinc, NS); DALLOC(s, D.slot_susp, NS); DALLOC(s, D.slot_mindl, NS);
+  DALLOC(s, D.slot_maxinc, NS);
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
   if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
 
@@ -304,11 +327,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const uint32_t gossip_lanes = D.fast_blocks ? cdiv(cdiv(D.nloc, D.CH), D.G) * D.CH : (cdiv(nchunks, D.G) + 1) * D.CH;
   const uint32_t probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
   BeginPlan& pl = s->plan;
-  {   // expire: enough blocks per subject slot that a due slot is scanned in a few trips
-    uint32_t per = std::max(1u, std::min(8u, cdiv(D.nloc, 4 * SW_BLOCK)));
-    while (per > 1 && (uint64_t)NS * per > 16384) per >>= 1;
-    pl.nb_expire = (uint32_t)NS * per;
-  }
+  pl.nb_expire = cdiv(NB, 64 * (SW_BLOCK / 64));    // expire: one wave looks after 64 node blocks' deadline bounds
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
@@ -359,7 +378,9 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
-  s->scratch_bytes = 1 << 20; { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
+  s->scratch_bytes = std::max<size_t>(1 << 20, std::min<size_t>((size_t)D.VT * 32 + 64, (size_t)1 << 26));   // an observer's views fit (swim_members)
+  { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
+  DALLOC(s, s->d_fresh, 1024);
   if (D.n_shards > 1) {   // what all the other shards together may address to this one in a tick (their lists are sized like ours)
     uint64_t in_cap = 0;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) if (sh != D.rank) in_cap += D.out_cap[sh];
@@ -385,6 +406,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
   HIPCK(s, hipMemsetAsync(D.err, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.q, 0, NL * D.Q * sizeof(uint4), st));
+  HIPCK(s, hipMemsetAsync(D.vt, 0xFF, NL * D.VT * sizeof(uint4), st));      // every slot free (subject = VT_EMPTY)
+  HIPCK(s, hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st)); HIPCK(s, hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st));
   if (serf) {
     HIPCK(s, hipMemsetAsync(D.evq, 0, NL * D.EQ * sizeof(uint4), st));
     HIPCK(s, hipMemsetAsync(D.ring, 0, NL * D.EB * sizeof(uint4), st));
@@ -393,7 +416,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
   HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
-  hipLaunchKernelGGL(k_init_views, dim3(cdiv(NS * D.nloc, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_init_base, dim3(cdiv(NT, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
@@ -404,11 +427,20 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 // ---------------------------------------------------------------------------------------------
 // time
 // ---------------------------------------------------------------------------------------------
-static void launch_begin(swim_sim* s) {
+// a fold tick carries four extra launches (scan + emit before k_begin, apply + count between k_deliver and k_resolve);
+// the captured tick graphs never contain one (swim_step / swim_tick_end_begin launch fold ticks eagerly)
+static bool fold_tick(const swim_sim* s, uint32_t tick) { return s->D.fold_period && tick && tick % s->D.fold_period == 0; }
+static void launch_begin(swim_sim* s, bool fold) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   BeginPlan pl = s->plan;
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
   const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + D.R * pl.nb_pp;
+  if (fold) {
+    const size_t NL = (size_t)D.nloc * D.R, NT = (size_t)D.N * D.R;
+    (void)hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st); (void)hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st);
+    hipLaunchKernelGGL(k_fold_scan, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
@@ -419,7 +451,7 @@ static void launch_begin(swim_sim* s) {
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
   }
 }
-static void launch_end(swim_sim* s) {
+static void launch_end(swim_sim* s, bool fold) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
   { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
@@ -428,12 +460,17 @@ static void launch_end(swim_sim* s) {
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D,
                        (const uint4*)s->in_buf, s->in_count);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), ((D.flags & SWIM_F_PIGGYBACK) && !(D.ablate & 64u)) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
-  // blocks per subject slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
+  if (fold) {
+    hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    hipLaunchKernelGGL(k_fold_count, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (D.flags & SWIM_F_PIGGYBACK) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
+  // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
   { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
+  if (fold) hipLaunchKernelGGL(k_exc_rebuild_folded, dim3(D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   s->in_count = 0;
 }
 static void advance(swim_sim* s, uint32_t n) {
@@ -452,7 +489,8 @@ static int check_device_errors(swim_sim* s) {
     snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s%s%s",
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
              e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
-             e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "", e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : "");
+             e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "",
+             e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : (e & SW_ERR_VIEW_CORRUPT ? " view-table(corrupt)" : ""));
     return SWIM_EOVERFLOW;
   }
   return SWIM_OK;
@@ -461,7 +499,7 @@ static int check_device_errors(swim_sim* s) {
 extern "C" int swim_tick_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
-  launch_begin(s);
+  launch_begin(s, fold_tick(s, s->tick));
   s->in_tick = true; s->out_counts_valid = false; s->in_count = 0;
   return SWIM_OK;
 }
@@ -531,18 +569,19 @@ extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
 extern "C" int swim_tick_end_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
-  if (s->in_count == 0 && s->use_graphs && !s->profiling) {
+  const bool f0 = fold_tick(s, s->tick), f1 = fold_tick(s, s->tick + 1);
+  if (s->in_count == 0 && s->use_graphs && !s->profiling && !f0 && !f1) {
     if (!s->graph_end_begin) {
       hipGraph_t g = nullptr;
       HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-      launch_end(s); launch_begin(s);
+      launch_end(s, false); launch_begin(s, false);
       HIPCK(s, hipStreamEndCapture(s->stream, &g));
       hipError_t e = hipGraphInstantiate(&s->graph_end_begin, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
     }
     HIPCK(s, hipGraphLaunch(s->graph_end_begin, s->stream));
-  } else { launch_end(s); launch_begin(s); }
+  } else { launch_end(s, f0); launch_begin(s, f1); }
   advance(s, 1);
   s->out_counts_valid = false; s->in_count = 0;
   return SWIM_OK;
@@ -550,7 +589,7 @@ extern "C" int swim_tick_end_begin(swim_sim* s) {
 extern "C" int swim_tick_end(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
-  launch_end(s);
+  launch_end(s, fold_tick(s, s->tick));
   s->in_tick = false; advance(s, 1);
   return SWIM_OK;
 }
@@ -561,7 +600,7 @@ extern "C" int swim_tick_end(swim_sim* s) {
 static int build_graph(swim_sim* s, int which, uint32_t ticks) {
   hipGraph_t g = nullptr;
   HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-  for (uint32_t i = 0; i < ticks; i++) { launch_begin(s); launch_end(s); }
+  for (uint32_t i = 0; i < ticks; i++) { launch_begin(s, false); launch_end(s, false); }
   HIPCK(s, hipStreamEndCapture(s->stream, &g));
   hipError_t e = hipGraphInstantiate(&s->graph_exec[which], g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
@@ -580,9 +619,12 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
   uint32_t i = 0;
   while (i < n) {
     uint32_t adv = 1;
-    if (use_graph && n - i >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
+    // ticks until the next fold tick (a fold tick itself is launched eagerly, with its extra kernels)
+    const uint32_t fp = s->D.fold_period, to_fold = !fp ? 0xFFFFFFFFu : fold_tick(s, s->tick) ? 0u : fp - s->tick % fp;
+    if (to_fold == 0) { launch_begin(s, true); launch_end(s, true); }
+    else if (use_graph && n - i >= SW_GRAPH_TICKS && to_fold >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
     else if (use_graph) HIPCK(s, hipGraphLaunch(s->graph_exec[0], s->stream));
-    else { launch_begin(s); launch_end(s); }
+    else { launch_begin(s, false); launch_end(s, false); }
     advance(s, adv);
     i += adv;
   }
@@ -604,23 +646,33 @@ extern "C" int swim_now(swim_sim* s, uint32_t* tick, uint32_t* ms) {
 // ---------------------------------------------------------------------------------------------
 // stimulus
 // ---------------------------------------------------------------------------------------------
-static int upload_ids(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
+static int check_ids(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
   if (!s || (!ids && n)) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
   if (r >= s->D.R) return SWIM_ERANGE;
   for (size_t i = 0; i < n; i++) if (ids[i] >= s->D.N) return SWIM_ERANGE;
-  if (n * 4 > s->scratch_bytes) return SWIM_ERANGE;
-  if (n) HIPCK(s, hipMemcpyAsync(s->d_scratch, ids, n * 4, hipMemcpyHostToDevice, s->stream));
-  HIPCK(s, hipStreamSynchronize(s->stream));   // ids is caller memory
+  return SWIM_OK;
+}
+// watch slots for the named nodes (while slots remain), then their highest-incarnation seeds
+static int watch_ids(swim_sim* s, uint32_t r, const uint32_t* d_ids, uint32_t n) {
+  const SwDev& D = s->D;
+  hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, d_ids, n, s->d_fresh);
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
+  hipLaunchKernelGGL(k_watch_seed, dim3(xb, std::min<uint32_t>(n, 1023)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (const uint32_t*)s->d_fresh);
   return SWIM_OK;
 }
 static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n) {
-  int rc = upload_ids(s, r, ids, n);
+  int rc = check_ids(s, r, ids, n);
   if (rc || !n) return rc;
   touched(s);
-  if (op == INJ_LEAVE || op == INJ_UPDATE)
-    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
-  hipLaunchKernelGGL(k_inject, dim3(cdiv(n, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, op, r, (const uint32_t*)s->d_scratch, (uint32_t)n);
+  const size_t chunk = s->scratch_bytes / 4;          // ids travel through the scratch buffer, a chunk at a time
+  for (size_t off = 0; off < n; off += chunk) {
+    const uint32_t c = (uint32_t)std::min(chunk, n - off);
+    HIPCK(s, hipMemcpyAsync(s->d_scratch, ids + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
+    watch_ids(s, r, s->d_scratch, c);
+    hipLaunchKernelGGL(k_inject, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, op, r, (const uint32_t*)s->d_scratch, c);
+    HIPCK(s, hipStreamSynchronize(s->stream));          // ids is caller memory; the scratch buffer is reused
+  }
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);   // node words changed
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
@@ -629,14 +681,30 @@ extern "C" int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, si
 extern "C" int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_REVIVE, r, ids, n); }
 extern "C" int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_LEAVE, r, ids, n); }
 extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_UPDATE, r, ids, n); }
+extern "C" int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
+  if (!s) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  if (r >= s->D.R || x >= s->D.N) return SWIM_ERANGE;
+  HIPCK(s, hipMemcpyAsync(s->d_scratch, &x, 4, hipMemcpyHostToDevice, s->stream));
+  watch_ids(s, r, s->d_scratch, 1);
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
+  uint32_t w = 0;
+  HIPCK(s, hipMemcpyAsync(&w, s->D.nw + (size_t)r * s->D.N + x, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return NW_HAS_SLOT(w) ? SWIM_OK : SWIM_EOVERFLOW;
+}
 extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
   if (!s || !g) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
-  if (r >= s->D.R || s->D.N > s->scratch_bytes) return SWIM_ERANGE;
+  if (r >= s->D.R) return SWIM_ERANGE;
   for (uint32_t i = 0; i < s->D.N; i++) if (g[i] > 127) return SWIM_ERANGE;   // 7 bits of the node word
   touched(s);
-  HIPCK(s, hipMemcpyAsync(s->d_scratch, g, s->D.N, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_set_partition, dim3(cdiv(s->D.N, 256)), dim3(256), 0, s->stream, (const SwDev*)s->d_D, r, (const uint8_t*)s->d_scratch);
+  for (size_t off = 0; off < s->D.N; off += s->scratch_bytes) {                // the mask travels in chunks
+    const uint32_t c = (uint32_t)std::min<size_t>(s->scratch_bytes, s->D.N - off);
+    HIPCK(s, hipMemcpyAsync(s->d_scratch, g + off, c, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_set_partition, dim3(cdiv(c, 256)), dim3(256), 0, s->stream, (const SwDev*)s->d_D, r, (const uint8_t*)s->d_scratch, (uint32_t)off, c);
+    HIPCK(s, hipStreamSynchronize(s->stream));
+  }
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
@@ -677,46 +745,55 @@ static uint8_t status_of(uint32_t st) {
 }
 static bool is_local(const swim_sim* s, uint32_t i) { return i >= s->D.i0 && i < s->D.i0 + s->D.nloc; }
 
-extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out) {
-  if (!s || !out) return SWIM_EINVAL;
+// one observer's explicit views, keyed by subject: {key, since, first accuser<<3|confirmations}
+struct HostView { uint32_t key, since, w; };
+static int gather_views(swim_sim* s, uint32_t r, uint32_t o, std::vector<std::pair<uint32_t, HostView>>& out) {
   const SwDev& D = s->D;
-  if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
-  uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)D.nw + (size_t)r * D.N + x, 1);
+  const uint32_t cap = (uint32_t)std::min<size_t>(D.VT, (s->scratch_bytes - 16) / 32);
+  hipLaunchKernelGGL(k_gather_views, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, o, s->d_scratch, cap);
+  std::vector<uint32_t> w(4 + (size_t)cap * 8);
+  int rc = d2h(s, w.data(), (const uint32_t*)s->d_scratch, w.size());
   if (rc) return rc;
-  memset(out, 0, sizeof *out); out->id = x;
-  uint32_t key = SW_BASE_KEY, since = 0; uint8_t nconf = 0;
-  if (NW_HAS_SLOT(w)) {
-    size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + (o - D.i0);
-    uint4 a; if ((rc = d2h(s, &a, (const uint4*)D.va + ci, 1))) return rc;
-    key = a.x; since = a.y; nconf = (uint8_t)a.z;
-  }
-  out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
-  out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? nconf : 0;
-  out->status = status_of(SW_KST(key));
-  if (x == o && out->state == SWIM_STATE_ALIVE) {
-    uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
-    if (h.y & 0xFF) out->status = SWIM_MEMBER_LEAVING;
-  }
+  const uint32_t n = std::min(w[0], cap);
+  out.clear();
+  for (uint32_t i = 0; i < n; i++) out.push_back({ w[4 + i * 8], HostView{ w[5 + i * 8], w[6 + i * 8], w[7 + i * 8] } });
   return SWIM_OK;
+}
+static void fill_member(swim_member* out, uint32_t x, uint32_t key, uint32_t since, uint32_t wpack) {
+  memset(out, 0, sizeof *out); out->id = x;
+  out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
+  out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? (uint8_t)(wpack & 7u) : 0;
+  out->status = status_of(SW_KST(key));
 }
 extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap)) return SWIM_EINVAL;
   const SwDev& D = s->D;
   if (r >= D.R || o >= D.N || !is_local(s, o)) return SWIM_ERANGE;
-  uint32_t ns = 0; int rc = d2h(s, &ns, (const uint32_t*)D.n_slots + r, 1);
-  if (rc) return rc;
-  std::vector<uint32_t> subj(ns ? ns : 1);
-  if (ns && (rc = d2h(s, subj.data(), (const uint32_t*)D.subj_node + (size_t)r * D.S, ns))) return rc;
   size_t n = std::min<size_t>(cap, D.N);
-  for (size_t x = 0; x < n; x++) {
-    swim_member m; memset(&m, 0, sizeof m);
-    m.id = (uint32_t)x; m.incarnation = 1; m.state = SWIM_STATE_ALIVE; m.status = SWIM_MEMBER_ALIVE;
-    out[x] = m;
-  }
-  for (uint32_t sl = 0; sl < ns; sl++)
-    if (subj[sl] < n && (rc = swim_view(s, r, o, subj[sl], &out[subj[sl]]))) return rc;
-  if (o < n && (rc = swim_view(s, r, o, o, &out[o]))) return rc;
+  std::vector<uint32_t> bk(n ? n : 1);
+  int rc = n ? d2h(s, bk.data(), (const uint32_t*)D.bk + (size_t)r * D.N, n) : SWIM_OK;
+  if (rc) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+  for (size_t x = 0; x < n; x++) fill_member(&out[x], (uint32_t)x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk[x], 0, 0);   // implicit views
+  std::vector<std::pair<uint32_t, HostView>> ex;
+  if ((rc = gather_views(s, r, o, ex))) return rc;
+  for (auto& e : ex) if (e.first < n) fill_member(&out[e.first], e.first, e.second.key, e.second.since, e.second.w);
+  if (o < n && out[o].state == SWIM_STATE_ALIVE && (h.y & 0xFF)) out[o].status = SWIM_MEMBER_LEAVING;
   if (n_out) *n_out = D.N;
+  return SWIM_OK;
+}
+extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
+  uint32_t bk = 0; int rc = d2h(s, &bk, (const uint32_t*)D.bk + (size_t)r * D.N + x, 1);
+  if (rc) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+  fill_member(out, x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk, 0, 0);
+  std::vector<std::pair<uint32_t, HostView>> ex;
+  if ((rc = gather_views(s, r, o, ex))) return rc;
+  for (auto& e : ex) if (e.first == x) fill_member(out, x, e.second.key, e.second.since, e.second.w);
+  if (x == o && out->state == SWIM_STATE_ALIVE && (h.y & 0xFF)) out->status = SWIM_MEMBER_LEAVING;
   return SWIM_OK;
 }
 extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
@@ -768,12 +845,14 @@ extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census*
   if (s->in_tick) return SWIM_ESTATE;
   uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)D.nw + (size_t)r * D.N + x, 1);
   if (rc) return rc;
-  if (!NW_HAS_SLOT(w)) {
-    HIPCK(s, hipMemsetAsync(s->d_scratch, 0, 4, s->stream));
-    hipLaunchKernelGGL(k_count_live, dim3(std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, x, s->d_scratch);
-    uint32_t n = 0; if ((rc = d2h(s, &n, (const uint32_t*)s->d_scratch, 1))) return rc;
+  if (!NW_HAS_SLOT(w)) {            // not watched: counted on demand, no history
+    HIPCK(s, hipMemsetAsync(s->d_scratch, 0, 32, s->stream));
+    const uint32_t nb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 256));
+    hipLaunchKernelGGL(k_census_adhoc, dim3(nb), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, x, 0, s->d_scratch);
+    hipLaunchKernelGGL(k_census_adhoc, dim3(nb), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, x, 1, s->d_scratch);
+    uint32_t a[8]; if ((rc = d2h(s, a, (const uint32_t*)s->d_scratch, 8))) return rc;
     memset(out, 0, sizeof *out);
-    out->n_observers = out->by_state[SWIM_STATE_ALIVE] = out->n_current = n;
+    out->n_observers = a[0]; for (int i = 0; i < 4; i++) out->by_state[i] = a[1 + i]; out->n_current = a[5];
     out->first_suspect_ms = out->first_dead_ms = out->all_dead_ms = out->all_current_ms = SWIM_NONE;
     return SWIM_OK;
   }
@@ -813,6 +892,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
+  out->view_drops = v[ST_VIEW_DROPS]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
@@ -865,7 +945,7 @@ extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
   HIPCK(s, hipMemsetAsync(acc, 0, 64 * 8 * 8, s->stream));
   const size_t NL = (size_t)D.R * D.nloc;
   hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
-  hipLaunchKernelGGL(k_digest_views, dim3(std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK), 64)), D.R * D.S), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
+  hipLaunchKernelGGL(k_digest_views, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
   unsigned long long v[64 * 8]; int rc = d2h(s, v, (const unsigned long long*)acc, 64 * 8);
   if (rc) return rc;
   uint64_t d = 0;
@@ -921,17 +1001,12 @@ extern "C" int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint
   if (dst >= s->D.N || (!m && n) || n * sizeof(swim_edge) + n * 4 > s->scratch_bytes) return SWIM_EINVAL;
   if (!n) return SWIM_OK;
   touched(s);
-  std::vector<swim_edge> recs(m, m + n); std::vector<uint32_t> subj;
+  std::vector<swim_edge> recs(m, m + n);
   for (auto& e : recs) {
-    if ((e.meta >> 30) != SWIM_MSG_USER) { if (e.subject >= s->D.N) return SWIM_ERANGE; subj.push_back(e.subject); }
+    if ((e.meta >> 30) != SWIM_MSG_USER && e.subject >= s->D.N) return SWIM_ERANGE;
     e.dst = r * s->D.N + dst;
   }
-  uint8_t* scratch = (uint8_t*)s->d_scratch;
-  if (!subj.empty()) {            // a rumour about somebody new needs a view column first
-    HIPCK(s, hipMemcpyAsync(scratch, subj.data(), subj.size() * 4, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_inject_alloc, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)scratch, (uint32_t)subj.size());
-  }
-  uint8_t* drec = scratch + ((subj.size() * 4 + 15) & ~(size_t)15);
+  uint8_t* drec = (uint8_t*)s->d_scratch;
   HIPCK(s, hipMemcpyAsync(drec, recs.data(), n * sizeof(swim_edge), hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_deliver_list, dim3(cdiv(n, SW_BLOCK * 4)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (const uint4*)drec, (uint32_t)n);
   HIPCK(s, hipStreamSynchronize(s->stream));

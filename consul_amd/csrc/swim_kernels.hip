@@ -4,7 +4,7 @@
 // random-access sector traffic and atomic throughput; there is no dense contraction, hence no MFMA.
 //
 //   k_begin    fused, role by block range:
-//                expire   suspicion timers that ran out         -> self-addressed dead{} records
+//                expire   suspicion timers that ran out         -> dead{} verdicts in the node's own inbox
 //                pending  indirect-ping stage of probes whose direct ping failed ProbeTimeout ago
 //                probe    probe()/probeNode for the probe-due set -> suspect{} records, slot requests,
 //                         piggy-back orders for the ping and the ack (sendMsg)
@@ -51,13 +51,42 @@ __device__ __forceinline__ uint32_t sel4v(uint32_t a0, uint32_t a1, uint32_t a2,
 __device__ __forceinline__ uint64_t seed_of(DevRef D, uint32_t r) { return D.seed + r; }
 __device__ __forceinline__ uint32_t now_ms(DevRef D, uint32_t t) { return t * D.quantum_ms; }
 
-// observer (r, local k) looking at the node whose word is `w`; base view unless it owns a slot
-__device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t w, uint32_t* since) {
-  if (!NW_HAS_SLOT(w)) { *since = 0; return SW_BASE_KEY; }
-  size_t ci = ((size_t)r * D.S + NW_SLOT(w)) * D.nloc + k;
-  uint4 a = D.va[ci];
-  *since = a.y;
-  return a.x;
+// ---- an observer's explicit views (layout: swim_device.h) ------------------------------------------
+__device__ __forceinline__ uint32_t vt_home(DevRef D, uint32_t x) { return (x * 0x9E3779B1u) >> D.vt_shift; }
+__device__ __forceinline__ uint32_t vw_nconf(uint32_t w) { return w & 7u; }
+__device__ __forceinline__ uint32_t vw_conf0(uint32_t w) { return w >> 3; }
+__device__ __forceinline__ uint32_t vw_pack(uint32_t conf0, uint32_t nconf) { return (conf0 << 3) | nconf; }
+// lane l's explicit view of subject x: its slot (entry in `e`), or NONE with `free_slot` = where it would go.
+// `first` = the home slot's entry when the caller fetched it already (together with other loads).
+__device__ __forceinline__ uint32_t vt_probe(DevRef D, size_t l, uint32_t x, uint4 first, uint4& e, uint32_t& free_slot) {
+  const size_t NL = (size_t)D.R * D.nloc; const uint32_t m = D.VT - 1;
+  uint32_t s = vt_home(D, x);
+  e = first;
+  for (uint32_t i = 0; i < D.VT; i++) {
+    if (e.x == x) return s;
+    if (e.x == VT_EMPTY) { free_slot = s; return NONE; }
+    s = (s + 1) & m;
+    e = D.vt[(size_t)s * NL + l];
+  }
+  atomicOr(D.err, SW_ERR_VIEW_CORRUPT); free_slot = NONE;
+  return NONE;
+}
+__device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint4& e, uint32_t& free_slot) {
+  return vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * ((size_t)D.R * D.nloc) + l], e, free_slot);
+}
+// what the base row says about the node whose word is w
+__device__ __forceinline__ uint32_t base_key_of(DevRef D, uint32_t r, uint32_t x, uint32_t w) {
+  return (w & NW_BASEMOD) ? D.bk[(size_t)r * D.N + x] : SW_BASE_KEY;
+}
+// observer (r, local k) looking at node x whose word is `w`: the base row unless somebody here has news about x
+// AND this observer holds an explicit view
+__device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t x, uint32_t w, uint32_t* since) {
+  *since = 0;
+  if (w & NW_SUBJECT) {
+    uint4 e; uint32_t fs;
+    if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) { *since = e.z; return e.y; }
+  }
+  return base_key_of(D, r, x, w);
 }
 
 __device__ __forceinline__ bool lost(DevRef D, uint32_t r, uint32_t t, uint32_t node, uint32_t leg) {
@@ -252,7 +281,7 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
     if (i < 4) { x = i == 0 ? x4[0] : i == 1 ? x4[1] : i == 2 ? x4[2] : x4[3]; w = i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]; }
     else { x = d.get((uint32_t)i) % D.N; w = X.usable() ? X.word(x) : nw[x]; }
     if (x == o) continue;
-    uint32_t since, key = view_of(D, r, k_local, w, &since), st = SW_KST(key);
+    uint32_t since, key = view_of(D, r, k_local, x, w, &since), st = SW_KST(key);
     if (mode == 0) {
       if (st == SWIM_STATE_LEFT) continue;
       if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
@@ -272,39 +301,53 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
 // timeout lapses => deadNode(dead{inc, node, from: self}), delivered to self via the common inbox.
 // =================================================================================================
 __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos);
+// Gate: dl_blk[node block] is a lower bound of the earliest deadline among the block's acting lanes, vdl[lane] of
+// the lane's own timers.  One wave looks after 64 node blocks (one coalesced read); only a block whose bound has
+// passed has its 256 lanes looked at, and only a lane whose own bound has passed walks its view table.
 __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
-  uint32_t per = nb / (D.R * D.S);                 // blocks per slot
-  uint32_t sidx = b / per, part = b % per, r = sidx / D.S, sl = sidx % D.S;
-  if (sl >= D.n_slots[r]) return;
-  uint32_t t = *D.tick, now = now_ms(D, t);
-  if (!D.slot_susp[sidx] || now < D.slot_mindl[sidx]) return;
-  uint32_t x = D.subj_node[sidx], fired = 0;
-  const uint32_t* nw = D.nw + (size_t)r * D.N;
-  // the scan is latency bound: four independent rows in flight per trip
-  for (uint32_t k0 = part * SW_BLOCK; k0 < D.nloc; k0 += 4 * per * SW_BLOCK) {
-    uint32_t kk[4]; uint4 v[4]; bool f[4]; bool any_f = false;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { kk[j] = k0 + j * per * SW_BLOCK + threadIdx.x; v[j] = kk[j] < D.nloc ? D.va[(size_t)sidx * D.nloc + kk[j]] : make_uint4(0, 0, 0, 0); }
-#pragma unroll
-    for (int j = 0; j < 4; j++) { f[j] = kk[j] < D.nloc && SW_KST(v[j].x) == SWIM_STATE_SUSPECT && now >= v[j].y + sel8(D.susp_timeout, v[j].z & 7u); any_f |= f[j]; }
-    if (__any(any_f)) {                             // rare: only now look at liveness and append
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        f[j] = f[j] && !(nw[D.i0 + kk[j]] & NW_INERT);
-        // a timer is not a packet: the verdict goes straight into the node's own inbox line.  (When a whole
-        // cluster's suspicion of one node runs out within a few ticks, appending these to a shared list cost
-        // thousands of same-address atomics — the launch's long pole, profiles/r01_role_clock.txt.)
-        if (f[j]) {
-          size_t l = (size_t)r * D.nloc + kk[j];
-          inbox_place(D, mk_edge(D, r, D.i0 + kk[j], x, SW_KINC(v[j].x), SWIM_MSG_DEAD, D.i0 + kk[j]), l, atomicAdd(&D.in_cnt[l], 1u));
+  (void)nb;
+  const uint32_t t = *D.tick, now = now_ms(D, t), lane = sw_lane();
+  const size_t NL = (size_t)D.R * D.nloc;
+  const uint32_t first_nb = (b * (SW_BLOCK / 64) + threadIdx.x / 64) * 64;
+  const uint32_t mine = first_nb + lane < D.NB ? D.dl_blk[first_nb + lane] : NONE;
+  uint64_t due = __ballot(now >= mine);
+  uint32_t fired = 0;
+  while (due) {
+    const uint32_t j = (uint32_t)__ffsll((long long)due) - 1; due &= due - 1;
+    const uint32_t nbk = first_nb + j;
+    uint32_t newmin = NONE;
+    for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
+      const size_t l = (size_t)nbk * SW_BLOCK + part * 64 + lane;
+      if (l >= NL) continue;
+      uint32_t d = D.vdl[l];
+      if (d == NONE) continue;
+      const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
+      if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;           // its timers rest; a revive lowers dl_blk again
+      if (now >= d) {
+        uint32_t next = NONE, left = D.vnum[l];
+        for (uint32_t sl = 0; sl < D.VT && left; sl++) {
+          const uint4 e = D.vt[(size_t)sl * NL + l];
+          if (e.x == VT_EMPTY) continue;
+          left--;
+          if (SW_KST(e.y) != SWIM_STATE_SUSPECT) continue;
+          const uint32_t dl = e.z + sel8(D.susp_timeout, vw_nconf(e.w));
+          if (now >= dl) {
+            // a timer is not a packet: the verdict goes straight into the node's own inbox line
+            inbox_place(D, mk_edge(D, r, o, e.x, SW_KINC(e.y), SWIM_MSG_DEAD, o), l, atomicAdd(&D.in_cnt[l], 1u));
+            fired++;
+          }
+          next = dl < next ? dl : next;   // a fired timer keeps the bound low until its verdict is merged
         }
-        fired += (uint32_t)f[j];
+        d = next; D.vdl[l] = d;
       }
+      newmin = d < newmin ? d : newmin;
     }
+    for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(newmin, off); newmin = v < newmin ? v : newmin; }
+    if (lane == 0) D.dl_blk[nbk] = newmin;
   }
   if (__any(fired != 0)) {
     for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-    if (sw_lane() == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+    if (lane == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
   }
 }
 
@@ -376,10 +419,10 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
   uint32_t t = *D.tick;
   uint32_t i = map_probe(D, t % D.P, a);
   const uint32_t* nw = D.nw + (size_t)r * D.N;
-  bool e_buddy = false, e_self = false, e_ctrl = false, c_probe = false, c_ack = false, e_pend = false;
+  bool e_buddy = false, e_self = false, c_probe = false, c_ack = false, e_pend = false;
   bool o_ping = false, o_ack = false;                // piggy-back orders: for my ping, for the target's ack
   uint32_t o_ping_rcv = NONE, o_ack_rcv = NONE, o_x = 0;
-  uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t ctrl_x = 0, buddy_sh = 0;
+  uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t buddy_sh = 0;
   size_t l = 0;
   uint32_t wi = i != NONE ? nw[i] : NW_DEAD;
   if (!(wi & NW_INERT)) {
@@ -393,7 +436,6 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
         // probeNode's failure epilogue: awareness, then suspectNode(suspect{inc, node, self})
         aw = awareness_apply(D, aw, (int)nackm);
         S.add(ST_PFAIL); S.add(ST_NACKMISS, nackm);
-        if (!NW_HAS_SLOT(X.usable() ? X.word(p0.x) : nw[p0.x])) { e_ctrl = true; ctrl_x = p0.x; }
         e_self = true; rec_self = mk_edge(D, r, i, p0.x, p0.y, SWIM_MSG_SUSPECT, i);
         D.pr0[l].x = NONE; stage = 0; nackm = 0; busy = false;
       }
@@ -404,7 +446,7 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
       while (num_check < D.N) {
         if (cursor >= D.N) { epoch = (epoch + 1) & 0xFFFFu; cursor = 0; num_check++; continue; }   // resetNodes
         uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
-        wx = X.usable() ? X.word(c) : nw[c]; key = view_of(D, r, k, wx, &since);
+        wx = X.usable() ? X.word(c) : nw[c]; key = view_of(D, r, k, c, wx, &since);
         if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
         x = c; break;
       }
@@ -445,10 +487,6 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
       if (pos < D.pend_cap) D.pend[(size_t)li * D.pend_cap + pos] = (uint32_t)l;
       else atomicOr(D.err, SW_ERR_PEND_OVF);
     }
-  }
-  if (__any(e_ctrl)) {
-    uint4 c = make_uint4(NONE, ctrl_x, r, 0);
-    for (uint32_t sh = 0; sh < D.n_shards; sh++) wave_append(D, sh, e_ctrl, c);
   }
   if (__any(e_self)) wave_append(D, D.rank, e_self, rec_self);
   if (__any(e_buddy)) wave_append_sharded(D, e_buddy, buddy_sh, rec_buddy);
@@ -498,20 +536,34 @@ __device__ __forceinline__ bool ent_before(DevRef D, uint32_t ma, uint32_t mb) {
 // judged only by conditions that stay true whatever else reaches it this tick (view incarnations never
 // decrease): an older incarnation, or the same incarnation in a state the message cannot move.  One
 // random 16-byte read of the receiver's view replaces an edge write, an inbox atomic and a merge.
-// `a` = the receiver's va record of the subject, `e` = the queue entry {subject, inc, from, meta}.
-__device__ __forceinline__ bool noop_given_view(DevRef D, uint4 a, size_t ci, uint4 e) {
-  uint32_t type = m_type(e.w), key = a.x, vinc = SW_KINC(key), st = SW_KST(key);
+// (key, wpack) = the receiver's view of the subject (wpack = first accuser<<3 | confirmations; 0 for a base-row
+// view, which is never Suspect), vci = index of its confirmer record in vc, `e` = the queue entry
+// {subject, inc, from, meta}.
+__device__ __forceinline__ bool noop_given_view(DevRef D, uint32_t key, uint32_t wpack, size_t vci, uint4 e) {
+  uint32_t type = m_type(e.w), vinc = SW_KINC(key), st = SW_KST(key);
   if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
   if (e.y != vinc) return e.y < vinc;
   if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
   if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
-    uint32_t nc = a.z;
-    if (nc >= D.susp_k || a.w == e.z) return true;
+    uint32_t nc = vw_nconf(wpack);
+    if (nc >= D.susp_k || vw_conf0(wpack) == e.z) return true;
     if (nc == 0) return false;
-    uint4 b = D.vb[ci];
+    uint4 b = D.vc[vci];
     return b.x == e.z || (nc >= 2 && b.y == e.z) || (nc >= 3 && b.z == e.z);
   }
   return false;
+}
+// the same question for receiver lane lr and a subject whose node word is ws; `first` = the home slot of the
+// subject in the receiver's table when the caller fetched it already (have_first)
+__device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr, uint32_t ws, uint4 e, bool have_first, uint4 first) {
+  const size_t NL = (size_t)D.R * D.nloc;
+  if (ws & NW_SUBJECT) {
+    uint4 v; uint32_t fs;
+    if (!have_first) first = D.vt[(size_t)vt_home(D, e.x) * NL + lr];
+    uint32_t sl = vt_probe(D, lr, e.x, first, v, fs);
+    if (sl != NONE) return noop_given_view(D, v.y, v.w, (size_t)sl * NL + lr, e);
+  }
+  return noop_given_view(D, base_key_of(D, r, e.x, ws), 0, 0, e);
 }
 
 // where a node's queue lives: staged in LDS (gossip role: entry j of this lane at sq[j*256]) or in HBM
@@ -604,9 +656,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       // trip 2: the queue entries and the first four peer candidates' node words, all independent
       uint4 e0 = qlen > 0 ? D.q[l] : make_uint4(0, 0, 0, 0), e1 = qlen > 1 ? D.q[NL + l] : make_uint4(0, 0, 0, 0);
       uint32_t found;
-      if (D.ablate & 1u) { found = D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX; for (uint32_t p = 0; p < found; p++) { peers[p] = (i + 1 + p * 977u) % D.N; pw[p] = 0; } }
-      else found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
-      if (D.ablate & 32u) found = 0;
+      found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
       if (qlen > 0) sq[0] = e0;
       if (qlen > 1) sq[SW_BLOCK] = e1;
       for (uint32_t j = 2; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
@@ -620,7 +670,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       bool ok[KMAX];
       for (uint32_t p = 0; p < found; p++) {
         int used = 0, used2 = 0;
-        uint32_t tm = (D.ablate & 2u) ? (live_m & 1u) : get_broadcasts(D, LdsQ{sq}, qlen, live_m, 2, (int)D.budget, used), te = 0;
+        uint32_t tm = get_broadcasts(D, LdsQ{sq}, qlen, live_m, 2, (int)D.budget, used), te = 0;
         int avail = (int)D.budget - used;
         if (serf && avail > 2 + 1) te = get_broadcasts(D, LdsQ{se}, evqlen, live_e, 3, avail, used2);
         if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
@@ -635,30 +685,27 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
         sent_m[p] = tm; if (SERF) sent_e[p] = te;
         npk = p + 1;
       }
-      // trip 4: the no-op filter.  The view records of every (peer, rumour 0) pair are fetched together;
-      // rumours beyond the first take the one-at-a-time path.
-      if (filter && !(D.ablate & 4u)) {
-        uint4 va0[KMAX];
+      // trip 4: the no-op filter.  The receivers' home-slot entries for rumour 0 are fetched together (in the hot
+      // case — every lane gossips about the same subject — that is the entry itself); rumours beyond the first take
+      // the one-at-a-time path.
+      if (filter) {
+        uint4 va0[KMAX]; const uint32_t h0 = (ws0 & NW_SUBJECT) ? vt_home(D, e0.x) : 0;
 #pragma unroll
         for (int p = 0; p < KMAX; p++) {
-          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && NW_HAS_SLOT(ws0);
-          va0[p] = need ? D.va[((size_t)r * D.S + NW_SLOT(ws0)) * D.nloc + (peers[p] - D.i0)] : make_uint4(0, 0, 0, 0);
+          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && (ws0 & NW_SUBJECT);
+          va0[p] = need ? D.vt[(size_t)h0 * NL + (size_t)r * D.nloc + (peers[p] - D.i0)] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < KMAX; p++) {
           if ((uint32_t)p >= npk || !ok[p] || (MULTI && peers[p] / D.nloc != D.rank)) continue;
           uint32_t tm = sent_m[p];
-          if ((tm & 1u) && e0.x != peers[p] && NW_HAS_SLOT(ws0)) {
-            size_t ci = ((size_t)r * D.S + NW_SLOT(ws0)) * D.nloc + (peers[p] - D.i0);
-            if (noop_given_view(D, va0[p], ci, e0)) { tm &= ~1u; c_filt++; }
-          }
+          const size_t lr = (size_t)r * D.nloc + (peers[p] - D.i0);
+          if ((tm & 1u) && e0.x != peers[p] && noop_at_receiver(D, r, lr, ws0, e0, true, va0[p])) { tm &= ~1u; c_filt++; }
           for (uint32_t m = tm & ~1u; m; m &= m - 1) {
             uint32_t j = __ffs(m) - 1; uint4 e = sq[j * SW_BLOCK];
             if (e.x == peers[p]) continue;
             uint32_t ws = j == 1 ? ws1 : (X.usable() ? X.word(e.x) : nw[e.x]);
-            if (!NW_HAS_SLOT(ws)) continue;
-            size_t ci = ((size_t)r * D.S + NW_SLOT(ws)) * D.nloc + (peers[p] - D.i0);
-            if (noop_given_view(D, D.va[ci], ci, e)) { tm &= ~(1u << j); c_filt++; }
+            if (noop_at_receiver(D, r, lr, ws, e, false, e)) { tm &= ~(1u << j); c_filt++; }
           }
           sent_m[p] = tm;
         }
@@ -680,7 +727,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
     }
   }
   S.count(ST_QUIESCENT, quiet); S.count(ST_ACTIVE, active);
-  if (!(D.ablate & 16u)) S.wave_add(ST_PKT_SENT, c_pkt); S.wave_add(ST_PKT_DROP, c_drop); S.wave_add(ST_FILTERED, c_filt);
+  S.wave_add(ST_PKT_SENT, c_pkt); S.wave_add(ST_PKT_DROP, c_drop); S.wave_add(ST_FILTERED, c_filt);
   S.wave_add(ST_SENT0, c_s0); S.wave_add(ST_SENT1, c_s1); S.wave_add(ST_SENT2, c_s2); S.wave_add(ST_SENT3, c_s3);
 
   // ---- compaction of the block's packets into the outbound lists
@@ -735,7 +782,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
 #undef PKT_N
 
   // ---- write the queues back, compacted; untouched entries are not rewritten
-  if (active && !(D.ablate & 8u)) {
+  if (active) {
     size_t NL = (size_t)D.R * D.nloc;
     for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { D.q[(size_t)nq * NL + l] = sq[j * SW_BLOCK]; nq++; }
     if (SERF) for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) { D.evq[(size_t)ne * NL + l] = se[j * SW_BLOCK]; ne++; }
@@ -767,26 +814,28 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
 // Every lane of the wave calls this together (`on` = the lane takes part); the records of a wave are
 // appended with one atomic per destination shard, never one per record.
 __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
-  uint32_t ns = on ? D.n_slots[r] : 0, ns_max = ns;
-  for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(ns_max, off); ns_max = v > ns_max ? v : ns_max; }
+  // what the base row says merges to nothing: only the owner's explicit views travel.  The lanes of the wave walk
+  // their tables slot by slot together (wave_append_* is a wave-wide operation).
+  const size_t NL = (size_t)D.R * D.nloc, lo = (size_t)r * D.nloc + (owner - D.i0);
+  uint32_t left = on ? D.vnum[lo] : 0;
   const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
-  for (uint32_t sl = 0; sl < ns_max; sl++) {
+  for (uint32_t sl = 0; sl < D.VT; sl++) {
+    if (!__any(left != 0)) break;
     bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
-    if (sl < ns) {
-      size_t sidx = (size_t)r * D.S + sl;
-      uint4 a = D.va[sidx * D.nloc + (owner - D.i0)];
-      if (a.x != SW_BASE_KEY) {                            // the base row merges to nothing
-        uint32_t x = D.subj_node[sidx], st = SW_KST(a.x), type, from = 0;
+    if (left) {
+      uint4 a = D.vt[(size_t)sl * NL + lo];
+      if (a.x != VT_EMPTY) {
+        left--;
+        uint32_t x = a.x, st = SW_KST(a.y), type, from = 0;
         if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
         else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
         else { type = SWIM_MSG_SUSPECT; from = dst; }
         want = true;
         if (filter && x != dst) {
-          size_t ci = sidx * D.nloc + (dst - D.i0);
-          if (noop_given_view(D, D.va[ci], ci, make_uint4(x, SW_KINC(a.x), from, type << 30))) { want = false; c_filt++; }
+          if (noop_at_receiver(D, r, (size_t)r * D.nloc + (dst - D.i0), D.nw[(size_t)r * D.N + x], make_uint4(x, SW_KINC(a.y), from, type << 30), false, a)) { want = false; c_filt++; }
         }
-        rec = mk_edge(D, r, dst, x, SW_KINC(a.x), type, from);
+        rec = mk_edge(D, r, dst, x, SW_KINC(a.y), type, from);
       }
     }
     wave_append_sharded(D, want, sh, rec);
@@ -878,10 +927,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS], lds_exc[2 * SW_EXC_MAX];
   uint32_t b = blockIdx.x;
+#ifdef SWIMSIM_DIAG
   // diagnostics (SWIMSIM_ROLECLK): when did the first block of a role start, when did its last block end
   const unsigned long long t_in = D.role_clk ? wall_clock64() : 0;
 #define ROLE_DONE(id) do { if (D.role_clk && threadIdx.x == 0) { uint32_t tk = *D.tick; if (tk < D.role_clk_ticks) { \
     unsigned long long* c = D.role_clk + (((size_t)tk * 8 + (id)) * 64 + (blockIdx.x & 63u)) * 2; atomicMin(c, t_in); atomicMax(c + 1, (unsigned long long)wall_clock64()); } } } while (0)
+#else
+#define ROLE_DONE(id) do { } while (0)
+#endif
   if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); ROLE_DONE(0); return; }
   b -= pl.nb_expire;
   if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, MULTI ? *D.peer_act : 1u); ROLE_DONE(1); return; }
@@ -911,37 +964,19 @@ static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
 // =================================================================================================
 // k_deliver — packetListen/ingestPacket: scatter an edge list into the per-node inbox rows.  One
 // returning atomic on the row's count word reserves the slot; the record lands in the same 64-byte
-// line for the first five arrivals.  Slot requests are granted on the spot (grant_slot).
+// line for the first five arrivals.  Fold census records (dst = NONE) are accumulated on the spot.
 // =================================================================================================
-// Give subject x of replica r a view-column slot.  Runs inside k_deliver (nobody reads slot bits there):
-// the first request to flip the node word's slot field to the "being granted" pattern wins, later
-// duplicates (other probers, other shards) see a non-zero field and leave.  Which index a subject gets is
-// not observable: everything the ABI reports is keyed by node id.
-__device__ void grant_slot(DevRef D, uint32_t r, uint32_t x) {
-  size_t g = (size_t)r * D.N + x;
-  uint32_t w = D.nw[g];
-  if (NW_HAS_SLOT(w)) return;
-  if (atomicCAS(&D.nw[g], w, w | NW_SLOT_MASK) != w) return;
-  uint32_t sl = atomicAdd(&D.n_slots[r], 1u);
-  if (sl >= D.S) {
-    atomicSub(&D.n_slots[r], 1u); D.nw[g] = w;
-    atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull);
-    return;
-  }
-  size_t sidx = (size_t)r * D.S + sl;
-  D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
-  D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
-  D.nw[g] = w | (sl + 1);
-  // the replica's exception list: x may already be on it (a dead node has a non-zero word)
-  uint32_t n = D.exc_cnt[r]; bool listed = false;
-  for (uint32_t j = 0; j < n && j < SW_EXC_MAX; j++)
-    if (D.exc_ent[(size_t)r * SW_EXC_MAX + j].x == x) { listed = true; D.exc_ent[(size_t)r * SW_EXC_MAX + j].y = w | (sl + 1); }
-  if (!listed) { uint32_t pos = atomicAdd(&D.exc_cnt[r], 1u); if (pos < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + pos] = make_uint2(x, w | (sl + 1)); }
+// A fold census record (dst = NONE; swim_device.h): what the acting observers of ONE shard hold about
+// subject g = replica*N + node — rec.z = their common key or FOLD_POISON, rec.w = how many hold an explicit view.
+// Every shard receives every shard's records and accumulates them; k_fold_apply decides.
+__device__ __forceinline__ void fold_accumulate(DevRef D, uint4 rec) {
+  const uint32_t g = rec.y;
+  atomicAdd(&D.fg_cnt[g], rec.w); atomicMin(&D.fg_kmin[g], rec.z); atomicMax(&D.fg_kmax[g], rec.z);
 }
 
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
 __device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l) {
-  if (rec.x == NONE) { grant_slot(D, rec.z, rec.y); return NONE; }     // subject-slot request
+  if (rec.x == NONE) { fold_accumulate(D, rec); return NONE; }          // fold census record
   uint32_t r = rec.x / D.N, x = rec.x % D.N;
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
   uint32_t w = D.nw[rec.x];
@@ -949,7 +984,7 @@ __device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l
   if (w & NW_ATTACHED) { if (rec.y != SWIM_SUBJECT_PIGGY) capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
   l = (size_t)r * D.nloc + (x - D.i0);
   if (rec.y == SWIM_SUBJECT_PIGGY) {               // a piggy-back order for a node with nothing queued is a no-op
-    if (!q_bit(D, l) || (D.ablate & 256u)) return NONE;   // (queues do not change between k_begin and k_resolve)
+    if (!q_bit(D, l)) return NONE;                // (queues do not change between k_begin and k_resolve)
   }
   return atomicAdd(&D.in_cnt[l], 1u);
 }
@@ -985,10 +1020,7 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
     uint32_t r = rec.x / D.N, x = rec.x % D.N, type = rec.w >> 30;
     if (filter && type != SWIM_MSG_USER && rec.y != x) {
       uint32_t ws = D.nw[(size_t)r * D.N + rec.y];
-      if (NW_HAS_SLOT(ws)) {
-        size_t ci = ((size_t)r * D.S + NW_SLOT(ws)) * D.nloc + (x - D.i0);
-        if (noop_given_view(D, D.va[ci], ci, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30))) { c_filt++; continue; }
-      }
+      if (noop_at_receiver(D, r, (size_t)r * D.nloc + (x - D.i0), ws, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30), false, rec)) { c_filt++; continue; }
     }
     c_edges++;
     size_t l; uint32_t pos = inbox_reserve(D, rec, l);
@@ -1029,7 +1061,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
     uint32_t c_edges = 0, c_filt = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (cn[j] && !(D.ablate & 128u)) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
+      if (cn[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
     for (uint32_t a = b + 4 * D.n_seg; a < D.NB; a += D.n_seg) {      // only with very fine quanta (G > 4)
       uint2 cc = D.carry_cl[a]; uint32_t c = cc.x;
       __syncthreads();
@@ -1056,25 +1088,33 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restri
   deliver_span(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 
-// host-side stimulus (leave/update) needs a slot before the tick: single-threaded variant
-__device__ void alloc_slot(DevRef D, uint32_t r, uint32_t x) {
+// swim_watch / inject_*: give subject x a watch slot (census, first-* stamps, trace).  Single-threaded (host-side
+// stimulus, between ticks); slot_maxinc is seeded by k_watch_seed right after.
+__device__ void alloc_slot(DevRef D, uint32_t r, uint32_t x, uint32_t* fresh) {
   size_t g = (size_t)r * D.N + x;
   uint32_t w = D.nw[g];
   if (NW_HAS_SLOT(w)) return;
   uint32_t sl = D.n_slots[r];
-  if (sl >= D.S) { atomicOr(D.err, SW_ERR_SUBJ_OVF); atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull); return; }
+  if (sl >= D.S) { atomicAdd(stat_ptr(D, ST_SUBJ_OVF), 1ull); return; }
   D.n_slots[r] = sl + 1;
   size_t sidx = (size_t)r * D.S + sl;
-  D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = 1;
-  D.slot_susp[sidx] = 0; D.slot_mindl[sidx] = NONE;
+  D.subj_node[sidx] = x; D.slot_dirty[sidx] = 1; D.slot_maxinc[sidx] = SW_KINC(base_key_of(D, r, x, w));
   atomicOr(&D.nw[g], sl + 1);
-  // keep the replica's exception list exact without a rescan (single-threaded here)
-  uint32_t n = D.exc_cnt[r];
-  if (n <= SW_EXC_MAX) {
-    bool listed = false; const uint32_t wn = w | (sl + 1);
-    for (uint32_t j = 0; j < n; j++) if (D.exc_ent[(size_t)r * SW_EXC_MAX + j].x == x) { listed = true; D.exc_ent[(size_t)r * SW_EXC_MAX + j].y = wn; }
-    if (!listed) { if (n < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + n] = make_uint2(x, wn); D.exc_cnt[r] = n + 1; }
+  if (fresh) { uint32_t pos = atomicAdd(&fresh[0], 1u); if (pos < 1023) fresh[1 + pos] = (uint32_t)sidx; }
+}
+// the highest incarnation any local observer holds of a freshly watched subject (n_current is counted against it)
+__global__ void __launch_bounds__(SW_BLOCK) k_watch_seed(const SwDev* __restrict__ Dp, const uint32_t* fresh) {
+  SW_DEV_BIND
+  if (blockIdx.y >= fresh[0] || blockIdx.y >= 1023) return;
+  const uint32_t sidx = fresh[1 + blockIdx.y], r = sidx / D.S, x = D.subj_node[sidx];
+  if (!(D.nw[(size_t)r * D.N + x] & NW_SUBJECT)) return;
+  uint32_t m = 0;
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
+    uint4 e; uint32_t fs;
+    if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) m = SW_KINC(e.y) > m ? SW_KINC(e.y) : m;
   }
+  for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_down(m, off); m = v > m ? v : m; }
+  if (sw_lane() == 0 && m) atomicMax(&D.slot_maxinc[sidx], m);
 }
 // =================================================================================================
 // k_resolve — handleAlive/handleSuspect/handleDead/handleUserEvent for everything that reached a
@@ -1082,11 +1122,21 @@ __device__ void alloc_slot(DevRef D, uint32_t r, uint32_t x) {
 // duplicates applied once.  Literal aliveNode/suspectNode/deadNode/refute (state.go) and
 // suspicion.Confirm (suspicion.go) against the observer's own view column.
 // =================================================================================================
+// The word of node x of replica r just changed from `old` to `now` inside a tick kernel: keep the replica's exception
+// list (the {id, word} pairs of the non-zero words, staged in LDS by k_begin's roles) equal to nw.
+__device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_t now) {
+  uint2* ent = D.exc_ent + (size_t)r * SW_EXC_MAX;
+  if (old == 0) { uint32_t pos = atomicAdd(&D.exc_cnt[r], 1u); if (pos < SW_EXC_MAX) ent[pos] = make_uint2(x, now); return; }
+  uint32_t n = D.exc_cnt[r]; if (n > SW_EXC_MAX) return;               // unusable anyway
+  for (uint32_t j = 0; j < n; j++) if (ent[j].x == x) atomicOr(&ent[j].y, now & ~old);
+}
 struct NodeCtx {
   DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
+  uint32_t vnum = NONE, vdl = NONE - 1;             // explicit views held / earliest suspicion deadline: fetched on first use
+  bool vnum_dirty = false, vdl_dirty = false;
   uint4 h0;
   __device__ NodeCtx(DevRef d, BlockStats& s) : D(d), S(s) {}
 
@@ -1101,6 +1151,8 @@ struct NodeCtx {
   __device__ void store() {
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
+    if (vnum_dirty) D.vnum[l] = vnum;
+    if (vdl_dirty) D.vdl[l] = vdl;
   }
 
   // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
@@ -1128,87 +1180,122 @@ struct NodeCtx {
     if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc }; D.events[pos] = ev; }
     else atomicOr(D.err, SW_ERR_EVENT_OVF);
   }
-  // the observer's record of a subject is edited in registers (a = {key, since, nconf, conf0}) and
-  // written back once by the caller
-  __device__ void set_view(size_t sidx, uint4& a, uint32_t inc, uint32_t st, bool touch_since) {
-    a.x = SW_KEY(inc, st);
-    if (touch_since) a.y = now_ms(D, t);
-    if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
-    D.slot_dirty[sidx] = 1;
+  // ---- the observer's explicit view of a subject: looked up once per message (the home slot's entry and the
+  // subject's node word are independent loads), edited in registers, written back once
+  struct View { uint32_t slot, free_slot, w; uint4 e; bool fresh; };
+  __device__ View lookup(uint32_t x) {
+    View v; v.fresh = false;
+    v.w = D.nw[(size_t)r * D.N + x];
+    v.slot = vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], v.e, v.free_slot);
+    // no explicit view: the base row's — except that a node always sees ITSELF alive at its own incarnation
+    if (v.slot == NONE) v.e = make_uint4(x, x == o ? SW_KEY(self_inc, SWIM_STATE_ALIVE) : base_key_of(D, r, x, v.w), 0, 0);
+    return v;
   }
-  __device__ void refute(size_t sidx, uint4& a, uint32_t accused) {
+  // make the view explicit (created from the base row).  false = the observer already holds view_cap explicit views
+  // (its view of itself always fits): the caller ignores the rumour, counted in view_drops.
+  __device__ bool make(View& v, uint32_t x) {
+    if (v.slot != NONE) return true;
+    if (vnum == NONE) vnum = D.vnum[l];
+    if (vnum >= D.view_cap + (x == o ? 1u : 0u) || v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
+    vnum++; vnum_dirty = true;
+    v.slot = v.free_slot; v.fresh = true;
+    if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
+      const uint32_t old = atomicOr(&D.nw[(size_t)r * D.N + x], NW_SUBJECT);
+      if (!(old & NW_SUBJECT)) exc_note(D, r, x, old, old | NW_SUBJECT);
+    }
+    return true;
+  }
+  __device__ __forceinline__ void put(const View& v) { D.vt[(size_t)v.slot * NL + l] = v.e; }
+  __device__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
+    v.e.y = SW_KEY(inc, st);
+    if (touch_since) v.e.z = now_ms(D, t);
+    if (NW_HAS_SLOT(v.w)) {
+      const size_t sidx = (size_t)r * D.S + NW_SLOT(v.w);
+      if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
+      D.slot_dirty[sidx] = 1;
+    }
+  }
+  __device__ void arm_deadline(const View& v) {           // a suspicion timer was (re)armed: keep the gates' bounds
+    const uint32_t dl = v.e.z + sel8(D.susp_timeout, vw_nconf(v.e.w));
+    if (vdl == NONE - 1) vdl = D.vdl[l];
+    if (dl < vdl) { vdl = dl; vdl_dirty = true; if (dl < D.dl_blk[l / SW_BLOCK]) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
+  }
+  __device__ void refute(uint32_t accused) {
     uint32_t inc = self_inc + 1;
     if (accused >= inc) inc = accused + 1;
     self_inc = inc;
     uint2 h = D.ph[l];                                     // awareness lives with the probe state
     D.ph[l].y = p_pack(p_epoch(h.y), awareness_apply(D, p_aw(h.y), +1), p_stage(h.y), p_nackm(h.y));
-    set_view(sidx, a, inc, SWIM_STATE_ALIVE, false);
+    View me = lookup(o);
+    if (make(me, o)) { me.e.w = 0; set_view(me, inc, SWIM_STATE_ALIVE, false); put(me); }
     broadcast(o, SWIM_MSG_ALIVE, inc, 0);
     S.add(ST_REFUTES);
   }
   __device__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
-    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
-    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint4 a = D.va[ci];
-    uint32_t key = a.x; bool local = x == o;
+    const bool local = x == o;
     if (local && leaving) return;
-    if (!local && inc <= SW_KINC(key)) return;
-    if (local && inc < SW_KINC(key)) return;
-    a.z = 0;                                               // delete(m.nodeTimers, a.Node)
-    uint32_t old = SW_KST(key);
-    if (local) { if (inc == SW_KINC(key)) { D.va[ci] = a; return; } refute(sidx, a, inc); }
-    else {
-      broadcast(x, SWIM_MSG_ALIVE, inc, upd);
-      set_view(sidx, a, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
-      S.add(ST_APPL0);
-      if (o == D.watch) {
-        if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
-        else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
-      }
+    if (local) {                                           // a node's view of itself carries its own incarnation (header): no lookup
+      if (inc <= self_inc) return;
+      refute(inc); return;
     }
-    D.va[ci] = a;
+    View v = lookup(x);
+    const uint32_t key = v.e.y;
+    if (inc <= SW_KINC(key)) return;
+    if (!make(v, x)) return;
+    v.e.w = 0;                                             // delete(m.nodeTimers, a.Node)
+    const uint32_t old = SW_KST(key);
+    broadcast(x, SWIM_MSG_ALIVE, inc, upd);
+    set_view(v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
+    put(v);
+    S.add(ST_APPL0);
+    if (o == D.watch) {
+      if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
+      else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
+    }
   }
   __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
-    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
-    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint4 a = D.va[ci];
-    uint32_t key = a.x;
+    View v = lookup(x);
+    const uint32_t key = v.e.y;
     if (inc < SW_KINC(key)) return;
-    if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from)
-      uint32_t nc = a.z;
-      if (nc >= D.susp_k || a.w == from) return;
-      uint4 b = nc ? D.vb[ci] : make_uint4(0, 0, 0, 0);
+    if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from) (the base row is never Suspect)
+      uint32_t nc = vw_nconf(v.e.w);
+      if (nc >= D.susp_k || vw_conf0(v.e.w) == from) return;
+      const size_t ci = (size_t)v.slot * NL + l;
+      uint4 b = nc ? D.vc[ci] : make_uint4(0, 0, 0, 0);
       if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
-      if (nc <= 3) D.vb[ci] = b;
-      a.z = nc; D.va[ci] = a;
-      D.slot_dirty[sidx] = 1; S.add(ST_CONFIRMS);
+      if (nc <= 3) D.vc[ci] = b;
+      v.e.w = vw_pack(vw_conf0(v.e.w), nc); put(v);
+      arm_deadline(v);
+      if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
+      S.add(ST_CONFIRMS);
       broadcast(x, SWIM_MSG_SUSPECT, inc, from);
       return;
     }
     if (SW_KST(key) != SWIM_STATE_ALIVE) return;
-    if (x == o) { refute(sidx, a, inc); D.va[ci] = a; return; }
+    if (x == o) { refute(inc); return; }
+    if (!make(v, x)) return;
     broadcast(x, SWIM_MSG_SUSPECT, inc, from);
-    set_view(sidx, a, inc, SWIM_STATE_SUSPECT, true);
-    a.z = 0; a.w = from;                                   // newSuspicion(from, k, min, max)
-    D.va[ci] = a;
+    set_view(v, inc, SWIM_STATE_SUSPECT, true);
+    v.e.w = vw_pack(from, 0);                              // newSuspicion(from, k, min, max)
+    put(v);
+    arm_deadline(v);
     S.add(ST_APPL1);
   }
   __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
-    uint32_t w = D.nw[(size_t)r * D.N + x]; if (!NW_HAS_SLOT(w)) return;
-    size_t sidx = (size_t)r * D.S + NW_SLOT(w), ci = sidx * D.nloc + k;
-    uint4 a = D.va[ci];
-    uint32_t key = a.x;
+    View v = lookup(x);
+    const uint32_t key = v.e.y;
     if (inc < SW_KINC(key)) return;
-    uint32_t old = SW_KST(key);
+    const uint32_t old = SW_KST(key);
     if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
-    a.z = 0;
-    if (x == o && !leaving) { refute(sidx, a, inc); D.va[ci] = a; return; }
+    if (x == o && !leaving) { refute(inc); return; }
+    if (!make(v, x)) return;
+    v.e.w = 0;
     broadcast(x, SWIM_MSG_DEAD, inc, from);
-    uint32_t st = from == x ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
-    set_view(sidx, a, inc, st, true);
-    D.va[ci] = a;
+    const uint32_t st = from == x ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+    set_view(v, inc, st, true);
+    put(v);
     S.add(ST_APPL2);
     if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
   }
@@ -1368,20 +1455,20 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ D
   uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
   if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) return;
   __shared__ uint32_t acc[CEN_WORDS];
-  if (threadIdx.x < CEN_WORDS) acc[threadIdx.x] = threadIdx.x == CEN_MINDL ? NONE : 0;
+  if (threadIdx.x < CEN_WORDS) acc[threadIdx.x] = 0;
   __syncthreads();
   uint32_t x = D.subj_node[sidx], maxinc = D.slot_maxinc[sidx];
-  uint32_t obs = 0, st[4] = { 0, 0, 0, 0 }, cur = 0, mindl = NONE;
+  uint32_t obs = 0, st[4] = { 0, 0, 0, 0 }, cur = 0;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
+  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx);
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     uint32_t o = D.i0 + k;
     if (o == x || (nw[o] & NW_DEAD)) continue;
-    size_t ci = (size_t)sidx * D.nloc + k;
-    uint4 a = D.va[ci];
-    uint32_t key = a.x, s = SW_KST(key);
+    uint32_t key = bkey;
+    if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
+    const uint32_t s = SW_KST(key);
     obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
     cur += SW_KINC(key) == maxinc;
-    if (s == SWIM_STATE_SUSPECT) { uint32_t dl = a.y + sel8(D.susp_timeout, a.z & 7u); mindl = dl < mindl ? dl : mindl; }
   }
   uint32_t vals[6] = { obs, st[0], st[1], st[2], st[3], cur };
 #pragma unroll
@@ -1390,11 +1477,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ D
     for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
     if (sw_lane() == 0 && v) atomicAdd(&acc[j], v);
   }
-  for (int off = 32; off; off >>= 1) { uint32_t o2 = __shfl_down(mindl, off); mindl = o2 < mindl ? o2 : mindl; }
-  if (sw_lane() == 0) atomicMin(&acc[CEN_MINDL], mindl);
   __syncthreads();
   if (threadIdx.x < 6) { if (acc[threadIdx.x]) atomicAdd(&D.cen_acc[(size_t)sidx * CEN_WORDS + threadIdx.x], acc[threadIdx.x]); }
-  else if (threadIdx.x == CEN_MINDL) atomicMin(&D.cen_acc[(size_t)sidx * CEN_WORDS + CEN_MINDL], acc[CEN_MINDL]);
 }
 
 // fold the accumulators of a dirty slot into its cached census and stamp the first-times
@@ -1403,8 +1487,7 @@ __device__ void census_commit(DevRef D, uint32_t sidx, uint32_t now) {
   uint32_t* a = &D.cen_acc[(size_t)sidx * CEN_WORDS];
   c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
   c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
-  D.slot_susp[sidx] = a[CEN_ST1]; D.slot_mindl[sidx] = a[CEN_MINDL];
-  for (int j = 0; j < CEN_WORDS; j++) a[j] = j == CEN_MINDL ? NONE : 0;
+  for (int j = 0; j < CEN_WORDS; j++) a[j] = 0;
   if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
   if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
   if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
@@ -1417,8 +1500,10 @@ __device__ void rebuild_exceptions(DevRef D, uint32_t r, uint32_t* s_n) {
   if (threadIdx.x == 0) *s_n = 0;
   __syncthreads();
   const uint32_t* nw = D.nw + (size_t)r * D.N;
-  for (uint32_t x = threadIdx.x; x < D.N; x += blockDim.x)
+  for (uint32_t x = threadIdx.x; x < D.N; x += blockDim.x) {
+    if (*(volatile uint32_t*)s_n > SW_EXC_MAX) break;          // more than the list holds: unusable, no need to finish the scan
     if (nw[x]) { uint32_t pos = atomicAdd(s_n, 1u); if (pos < SW_EXC_MAX) D.exc_ent[(size_t)r * SW_EXC_MAX + pos] = make_uint2(x, nw[x]); }
+  }
   __syncthreads();
   if (threadIdx.x == 0) { D.exc_cnt[r] = *s_n; D.exc_dirty[r] = 0; }
   __syncthreads();
@@ -1427,6 +1512,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild(const SwDev* __restric
   SW_DEV_BIND
   __shared__ uint32_t s_n;
   rebuild_exceptions(D, r, &s_n);
+}
+// after a fold tick: node words changed (subject bits fell) if anything was folded
+__global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild_folded(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  __shared__ uint32_t s_n;
+  if (!*D.fold_any) return;
+  rebuild_exceptions(D, blockIdx.x, &s_n);
 }
 
 __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ Dp, uint32_t* last_cnt) {
@@ -1483,28 +1575,29 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= NL) return;
-  D.hdr[l] = make_uint4(1, 0, 0, 0);
+  D.hdr[l] = make_uint4(1, 0, 0, (D.flags & SWIM_F_SERF_EVENTS) ? 1u : 0u);   // serf.Create: eventClock.Increment()
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.in_cnt[l] = 0;
+  D.in_cnt[l] = 0; D.vnum[l] = 0; D.vdl[l] = NONE;
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
     D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK;
+    D.dl_blk[l / SW_BLOCK] = NONE;
   }
+  if (l < D.R) D.acting[l] = D.N;
 }
-__global__ void k_init_views(const SwDev* __restrict__ Dp) {
+__global__ void k_init_base(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
-  size_t n = (size_t)D.R * D.S * D.nloc, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  D.va[i] = make_uint4(SW_BASE_KEY, 0, 0, 0); D.vb[i] = make_uint4(0, 0, 0, 0);
+  size_t n = (size_t)D.R * D.N, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) D.bk[i] = SW_BASE_KEY;
 }
 __global__ void k_init_slots(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.R * D.S) return;
-  D.subj_node[i] = NONE; D.slot_dirty[i] = 0; D.slot_maxinc[i] = 1; D.slot_susp[i] = 0; D.slot_mindl[i] = NONE;
-  for (int j = 0; j < CEN_WORDS; j++) D.cen_acc[(size_t)i * CEN_WORDS + j] = j == CEN_MINDL ? NONE : 0;
+  D.subj_node[i] = NONE; D.slot_dirty[i] = 0; D.slot_maxinc[i] = 1;
+  for (int j = 0; j < CEN_WORDS; j++) D.cen_acc[(size_t)i * CEN_WORDS + j] = 0;
   swim_census c; memset(&c, 0, sizeof c);
   c.first_suspect_ms = c.first_dead_ms = c.all_dead_ms = c.all_current_ms = NONE;
   D.census[i] = c;
@@ -1512,10 +1605,22 @@ __global__ void k_init_slots(const SwDev* __restrict__ Dp) {
 
 enum { INJ_KILL = 0, INJ_REVIVE = 1, INJ_LEAVE = 2, INJ_UPDATE = 3 };
 
-__global__ void k_inject_alloc(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n) {
+// watch slots for the nodes named in a stimulus call (while slots remain); fresh[0] = how many were new, fresh[1..] = which
+__global__ void k_inject_alloc(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n, uint32_t* fresh) {
   SW_DEV_BIND
-  if (threadIdx.x || blockIdx.x) return;
-  for (uint32_t a = 0; a < n; a++) alloc_slot(D, r, ids[a]);
+  __shared__ uint32_t s_stop;
+  if (threadIdx.x == 0) {
+    fresh[0] = 0;
+    uint32_t a = 0;
+    for (; a < n && D.n_slots[r] < D.S; a++) alloc_slot(D, r, ids[a], fresh);
+    s_stop = a;
+  }
+  __syncthreads();
+  // out of slots: the rest is only counted (subject_overflow), in parallel — a partition names 10^5 nodes
+  uint32_t c = 0;
+  for (uint32_t a = s_stop + threadIdx.x; a < n; a += blockDim.x) c += !NW_HAS_SLOT(D.nw[(size_t)r * D.N + ids[a]]);
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+  if (sw_lane() == 0 && c) atomicAdd(stat_ptr(D, ST_SUBJ_OVF), (unsigned long long)c);
 }
 __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ Dp, int op, uint32_t r, const uint32_t* ids, uint32_t n) {
   SW_DEV_BIND
@@ -1528,42 +1633,41 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
     size_t l = (size_t)r * D.nloc + (x - D.i0);
     if (op == INJ_KILL) {
       uint32_t old = atomicOr(&D.nw[g], NW_DEAD);
-      if (local && !(old & NW_INERT)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);     // it was being acted for
+      if (!(old & NW_INERT)) {                               // it was being acted for
+        atomicSub(&D.acting[r], 1u);
+        if (local) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);
+      }
     } else if (op == INJ_REVIVE) {
       uint32_t old = atomicAnd(&D.nw[g], ~NW_DEAD);
+      if ((old & NW_DEAD) && !(old & NW_ATTACHED)) {
+        atomicAdd(&D.acting[r], 1u);
+        if (local) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
+      }
       if (local) {
-        if ((old & NW_DEAD) && !(old & NW_ATTACHED)) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
         uint2 h = D.ph[l];
         D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.in_cnt[l] = 0;
+        // a node that comes back resumes its old views, whose suspicion timers may be long overdue: its bound
+        // counts again in the block's gate
+        const uint32_t d = D.vdl[l];
+        if (d != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], d);
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
       c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = (size_t)D.R * D.nloc;
       c.load();
-      uint32_t w = D.nw[g];
-      if (NW_HAS_SLOT(w)) {
-        if (op == INJ_LEAVE) { c.leaving = 1; c.dead_node(x, c.self_inc, x); }   // memberlist.Leave
-        else {                                                                    // memberlist.UpdateNode
-          c.self_inc++;
-          size_t sidx = (size_t)r * D.S + NW_SLOT(w);
-          uint4 a = D.va[sidx * D.nloc + c.k];
-          c.set_view(sidx, a, c.self_inc, SWIM_STATE_ALIVE, false);
-          D.va[sidx * D.nloc + c.k] = a;
-          c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
-        }
-        c.store();
-        q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
+      if (op == INJ_LEAVE) { c.leaving = 1; c.dead_node(x, c.self_inc, x); }   // memberlist.Leave
+      else {                                                                    // memberlist.UpdateNode
+        c.self_inc++;
+        NodeCtx::View me = c.lookup(x);
+        if (c.make(me, x)) { c.set_view(me, c.self_inc, SWIM_STATE_ALIVE, false); c.put(me); }
+        c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
       }
+      c.store();
+      q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
     }
   }
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
-    for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) {
-      D.slot_dirty[(size_t)r * D.S + sl] = 1;
-      // The expire role's gate (suspect count and earliest deadline of the last census) only covers observers that were
-      // running then.  A node that comes back resumes its old views, whose suspicion timers may be long overdue: open
-      // the gate so that the next tick scans the column; the census at the end of that tick closes it again.
-      if (op == INJ_REVIVE) { D.slot_susp[(size_t)r * D.S + sl] = 1; D.slot_mindl[(size_t)r * D.S + sl] = 0; }
-    }
+    for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
 }
 __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
@@ -1579,13 +1683,14 @@ __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
     if (!(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);          // no longer one of the nodes the simulator acts for
     q_bit_lane(D, l, false, true);
   }
+  if (!(old & NW_INERT)) atomicSub(&D.acting[r], 1u);
 }
-__global__ void k_set_partition(const SwDev* __restrict__ Dp, uint32_t r, const uint8_t* group) {
+__global__ void k_set_partition(const SwDev* __restrict__ Dp, uint32_t r, const uint8_t* group, uint32_t first, uint32_t n) {
   SW_DEV_BIND
-  uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= D.N) return;
-  size_t g = (size_t)r * D.N + x;
-  D.nw[g] = (D.nw[g] & ~0x7F000000u) | (((uint32_t)group[x] & 0x7Fu) << 24);
+  uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  size_t g = (size_t)r * D.N + first + a;
+  D.nw[g] = (D.nw[g] & ~0x7F000000u) | (((uint32_t)group[a] & 0x7Fu) << 24);
 }
 // serf.UserEvent at the origin: stamp, Increment, handleUserEvent locally, queue
 __global__ void k_user_event(const SwDev* __restrict__ Dp, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
@@ -1656,25 +1761,180 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restri
 }
 __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restrict__ Dp, unsigned long long* out) {
   SW_DEV_BIND
-  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
-  if (sl >= D.n_slots[r]) return;
-  uint32_t x = D.subj_node[sidx];
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   uint64_t d = 0;
-  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
-    size_t ci = (size_t)sidx * D.nloc + k;
-    uint4 a = D.va[ci];
-    uint32_t key = a.x, since = a.y;
-    if (key == SW_BASE_KEY && since == 0) continue;
-    uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)x * 0x100000001B3ull) ^ ((uint64_t)(D.i0 + k) << 8);
-    d += sw_h3(9, id, ((uint64_t)key << 32) | since);
-    if (SW_KST(key) == SWIM_STATE_SUSPECT) {
-      uint32_t nc = a.z; uint4 cf = D.vb[ci];
-      d += sw_h3(10, id, nc);
-      d += sw_h3(11, id, a.w);
-      if (nc >= 1) d += sw_h3(12, id, cf.x);
-      if (nc >= 2) d += sw_h3(13, id, cf.y);
-      if (nc >= 3) d += sw_h3(14, id, cf.z);
+  if (l < NL) {
+    const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
+    uint32_t left = D.vnum[l];
+    for (uint32_t sl = 0; sl < D.VT && left; sl++) {          // explicit views
+      const uint4 a = D.vt[(size_t)sl * NL + l];
+      if (a.x == VT_EMPTY) continue;
+      left--;
+      const uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)a.x * 0x100000001B3ull) ^ ((uint64_t)o << 8);
+      d += sw_h3(9, id, ((uint64_t)a.y << 32) | a.z);
+      if (SW_KST(a.y) == SWIM_STATE_SUSPECT) {
+        const uint32_t nc = vw_nconf(a.w); const uint4 cf = D.vc[(size_t)sl * NL + l];
+        d += sw_h3(10, id, nc);
+        d += sw_h3(11, id, vw_conf0(a.w));
+        if (nc >= 1) d += sw_h3(12, id, cf.x);
+        if (nc >= 2) d += sw_h3(13, id, cf.y);
+        if (nc >= 3) d += sw_h3(14, id, cf.z);
+      }
     }
+    const uint64_t g = (uint64_t)r * D.N + o;                  // the base row: every shard digests its own id range
+    const uint32_t bk = D.bk[g];
+    if (bk != SW_BASE_KEY) d += sw_h3(15, g, bk);
   }
   digest_commit(d, out);
+}
+
+// swim_view / swim_members: one observer's explicit views, gathered for the host: out[0] = count, then {vt, vc} pairs
+__global__ void k_gather_views(const SwDev* __restrict__ Dp, uint32_t r, uint32_t o, uint32_t* out, uint32_t cap) {
+  SW_DEV_BIND
+  if (threadIdx.x || blockIdx.x) return;
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)r * D.nloc + (o - D.i0);
+  uint32_t n = 0;
+  for (uint32_t sl = 0; sl < D.VT; sl++) {
+    const uint4 a = D.vt[(size_t)sl * NL + l];
+    if (a.x == VT_EMPTY) continue;
+    if (n < cap) { const uint4 c = D.vc[(size_t)sl * NL + l]; uint32_t* w = out + 4 + (size_t)n * 8; w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = 0; }
+    n++;
+  }
+  out[0] = n;
+}
+// swim_census_get for a subject without a watch slot: pass 0 = highest incarnation any local observer holds, pass 1 = the
+// live observers' views by state and how many are at that incarnation.  acc = {obs, st0..st3, cur, maxinc}
+__global__ void __launch_bounds__(SW_BLOCK) k_census_adhoc(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x, int pass, uint32_t* acc) {
+  SW_DEV_BIND
+  const uint32_t* nw = D.nw + (size_t)r * D.N;
+  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx), maxinc = acc[6];
+  uint32_t vals[7] = { 0, 0, 0, 0, 0, 0, SW_KINC(bkey) };
+  for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
+    const uint32_t o = D.i0 + k;
+    uint32_t key = bkey;
+    if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
+    if (pass == 0) { vals[6] = SW_KINC(key) > vals[6] ? SW_KINC(key) : vals[6]; continue; }
+    if (o == x || (nw[o] & NW_DEAD)) continue;
+    vals[0]++; vals[1 + SW_KST(key)]++; vals[5] += SW_KINC(key) == maxinc;
+  }
+  if (pass == 0) {
+    uint32_t m = vals[6];
+    for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_down(m, off); m = v > m ? v : m; }
+    if (sw_lane() == 0) atomicMax(&acc[6], m);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    uint32_t v = vals[j];
+    for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+    if (sw_lane() == 0 && v) atomicAdd(&acc[j], v);
+  }
+}
+
+// =================================================================================================
+// fold (oracle: fold_census / fold_apply) — every fold_period ticks a subject on which ALL
+// acting observers of the whole population hold the same settled explicit view moves into the base row and its
+// entries are freed.  k_fold_scan: what this shard's acting observers hold; k_fold_emit: one record per
+// subject and shard into the tick's outbound lists; k_deliver accumulates every shard's records (fg_*);
+// k_fold_apply (between k_deliver and k_resolve) decides and frees.
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  const uint32_t now = now_ms(D, *D.tick);
+  uint32_t left = 0, r = 0;
+  if (l < NL) {
+    r = (uint32_t)(l / D.nloc);
+    if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = D.vnum[l];
+  }
+  for (uint32_t sl = 0; sl < D.VT; sl++) {
+    if (!__any(left != 0)) break;
+    uint4 a = make_uint4(VT_EMPTY, 0, 0, 0);
+    if (left) a = D.vt[(size_t)sl * NL + l];
+    bool have = a.x != VT_EMPTY;
+    if (have) left--;
+    const uint32_t g = r * D.N + a.x, st = SW_KST(a.y);
+    const bool bad = st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - a.z > D.gossip_to_dead_ms));
+    // lanes of a wave mostly hold the same subject in the same slot (one failure per cluster): one atomic set per
+    // distinct (subject, key, settled) triple present in the wave
+    uint64_t todo = __ballot(have);
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1;
+      const uint32_t g0 = __shfl(g, leader), k0 = __shfl(a.y, leader); const bool b0 = __shfl((int)bad, leader) != 0;
+      const bool mine = have && g == g0 && a.y == k0 && bad == b0;
+      const uint64_t mm = __ballot(mine);
+      if (sw_lane() == leader) {
+        atomicAdd(&D.fl_cnt[g0], (uint32_t)__popcll(mm)); atomicMin(&D.fl_kmin[g0], k0); atomicMax(&D.fl_kmax[g0], k0);
+        if (b0) D.fl_bad[g0] = 1;
+      }
+      todo &= ~mm;
+    }
+  }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_emit(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t n = (size_t)D.R * D.N, g = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  uint32_t cnt = g < n ? D.fl_cnt[g] : 0;
+  uint4 rec = make_uint4(NONE, (uint32_t)g, FOLD_POISON, cnt);
+  if (cnt && !D.fl_bad[g]) { const uint32_t a = D.fl_kmin[g]; if (a == D.fl_kmax[g]) rec.z = a; }
+  if (!__any(cnt != 0)) return;
+  for (uint32_t sh = 0; sh < D.n_shards; sh++) wave_append(D, sh, cnt != 0, rec);
+  if (D.n_shards > 1 && cnt) *D.act = 1;
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (l >= NL) return;
+  uint32_t n = D.vnum[l];
+  if (!n) return;
+  const uint32_t r = (uint32_t)(l / D.nloc), m = D.VT - 1;
+  const uint32_t acting = D.acting[r];
+  uint32_t freed = 0, folded_own = 0;
+  for (uint32_t sl = 0; sl < D.VT; ) {
+    const uint4 a = D.vt[(size_t)sl * NL + l];
+    bool fold = false;
+    if (a.x != VT_EMPTY) {
+      const uint32_t g = r * D.N + a.x, k = D.fg_kmin[g];
+      fold = D.fg_cnt[g] == acting && k == D.fg_kmax[g] && k != FOLD_POISON;
+      if (fold) {
+        // every holder writes the same values: the base row's new entry; the subject bit falls (nobody holds a view now)
+        D.bk[g] = k;
+        const uint32_t w = D.nw[g], wn = (w & ~(NW_SUBJECT | NW_BASEMOD)) | (k != SW_BASE_KEY ? NW_BASEMOD : 0u);
+        if (w != wn) { atomicAnd(&D.nw[g], ~NW_SUBJECT); if (k != SW_BASE_KEY) atomicOr(&D.nw[g], NW_BASEMOD); else atomicAnd(&D.nw[g], ~NW_BASEMOD); }
+        if (NW_HAS_SLOT(w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(w)] = 1;
+        if (a.x == D.i0 + (uint32_t)(l % D.nloc)) folded_own++;
+      }
+    }
+    if (!fold) { sl++; continue; }
+    // backward-shift deletion; an entry may move into slot sl, so it is looked at again
+    uint32_t i = sl, j = sl;
+    for (;;) {
+      j = (j + 1) & m;
+      const uint4 ej = D.vt[(size_t)j * NL + l];
+      if (ej.x == VT_EMPTY) break;
+      const uint32_t k = vt_home(D, ej.x);
+      if (i <= j ? (i < k && k <= j) : (i < k || k <= j)) continue;
+      D.vt[(size_t)i * NL + l] = ej; D.vc[(size_t)i * NL + l] = D.vc[(size_t)j * NL + l];
+      i = j;
+    }
+    D.vt[(size_t)i * NL + l].x = VT_EMPTY;
+    n--; freed++;
+  }
+  if (freed) {
+    D.vnum[l] = n; *D.fold_any = 1;
+    atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
+  }
+  (void)folded_own;
+}
+// stats: a folded subject is counted once, by the shard that owns its id (its own lane need not hold a view)
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_count(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  bool f = false;
+  if (l < NL) {
+    const uint32_t r = (uint32_t)(l / D.nloc), g = r * D.N + D.i0 + (uint32_t)(l % D.nloc), k = D.fg_kmin[g];
+    f = D.fg_cnt[g] && D.fg_cnt[g] == D.acting[r] && k == D.fg_kmax[g] && k != FOLD_POISON;
+  }
+  const uint64_t mm = __ballot(f);
+  if (mm && sw_lane() == 0) atomicAdd(stat_ptr(D, ST_FOLDS), (unsigned long long)__popcll(mm));
 }

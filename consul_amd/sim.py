@@ -174,6 +174,10 @@ class Sim:
         self._ck("swim_inject_partition",
                  self._l.swim_inject_partition(self._h, replica, g.ctypes.data_as(C.POINTER(abi.u8))))
 
+    def watch(self, replica: int, subject: int):
+        """Keep census / first-* stamps / trace of `subject` from now on (swim_watch)."""
+        self._ck("swim_watch", self._l.swim_watch(self._h, replica, subject))
+
     def set_loss(self, prob: float):
         self._ck("swim_set_loss", self._l.swim_set_loss(self._h, min(int(prob * 2**32), 2**32 - 1)))
 

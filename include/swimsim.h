@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 2u
+#define SWIM_ABI_VERSION 3u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -116,7 +116,18 @@ typedef struct swim_config {
   uint32_t phase_chunk;             /* nodes per stagger chunk (power of 2); 0 = auto       */
   uint32_t queue_cap;               /* per-node TransmitLimitedQueue slots (<= 32)          */
   uint32_t inbox_cap;               /* per-node per-tick inbox slots                        */
-  uint32_t subject_cap;             /* per-replica subject slots (nodes with non-base views)*/
+  uint32_t subject_cap;             /* per-replica WATCH slots: subjects whose census, first-suspect/first-dead
+                                       stamps and per-tick trace are maintained (swim_watch; every node named in
+                                       an inject_* call is watched automatically while slots remain)          */
+  uint32_t view_cap;                /* per-observer bound on explicit (non-base) views: what an observer knows
+                                       that the replica's base row does not say.  A rumour that would need one
+                                       more entry is ignored and counted in view_drops (never silent).  Sized
+                                       like Serf's queue rule max(2N, 4096) at small N
+                                       (internal/gossip/libserf/serf.go:25-27); 0 = min(n_nodes, 32)            */
+  uint32_t fold_interval_ms;        /* every so often a subject on which ALL acting observers agree (same
+                                       incarnation and state, not Suspect, Dead for longer than
+                                       GossipToTheDeadTime) is folded into the base row and its entries are
+                                       freed (SURVEY §7 hard part 1, App. D k_reap_fold); 0 = never            */
   uint32_t event_queue_cap;         /* per-node serf user-event queue slots (<= 32)         */
   uint32_t event_buffer;            /* serf EventBuffer ring size (default 512)             */
   uint32_t loss_q32;                /* packet loss prob * 2^32 (0 = lossless)               */
@@ -140,6 +151,8 @@ typedef struct swim_derived {
   uint32_t push_pull_scale;         /* pushPullScale multiplier                             */
   uint32_t push_pull_period_ticks;  /* PushPullInterval * scale / quantum (0 = off)         */
   uint32_t packet_budget;           /* UDPBufferSize - compoundHeaderOverhead               */
+  uint32_t view_cap;                /* resolved swim_config.view_cap                         */
+  uint32_t fold_period_ticks;       /* fold_interval_ms / quantum, rounded up (0 = off)      */
 } swim_derived;
 
 /* one row of an observer's member list: serf.Member / memberlist.Node reduced to integers
@@ -213,6 +226,9 @@ typedef struct swim_stats_t {
   uint64_t piggybacks;              /* pings/acks/... that carried at least one broadcast        */
   uint64_t msgs_piggybacked;        /* broadcasts carried that way (also counted in msgs_sent)   */
   uint64_t probe_tcp_acks;          /* probes saved by the TCP fallback ping (SWIM_F_TCP_FALLBACK)*/
+  uint64_t view_drops;              /* rumours ignored because the observer already held view_cap explicit views */
+  uint64_t folds;                   /* subjects folded into the base row (counted by the shard owning the id)   */
+  uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;
@@ -298,6 +314,11 @@ int swim_members(swim_sim* sim, uint32_t replica, uint32_t observer, swim_member
 /* one row of the above */
 int swim_view(swim_sim* sim, uint32_t replica, uint32_t observer, uint32_t subject,
               swim_member* out);
+/* Track `subject` in a watch slot from now on (census with first-* stamps, per-tick trace).  SWIM_OK if it is or was
+ * already watched; SWIM_EOVERFLOW (counted in subject_overflow) when all subject_cap slots are taken — the simulation
+ * itself never depends on a watch slot, and swim_census_get still answers for an unwatched subject (counted on
+ * demand, first-* stamps SWIM_NONE). */
+int swim_watch(swim_sim* sim, uint32_t replica, uint32_t subject);
 /* serf.Config.EventCh drained by lanEventHandler (server_serf.go:270): events seen by
  * cfg.watch_node of every replica, oldest first */
 int swim_poll_events(swim_sim* sim, swim_event* out, size_t cap, size_t* n_out);

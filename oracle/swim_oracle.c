@@ -155,7 +155,7 @@ int swim_config_preset(swim_config* c, int preset) {
   /* ping{SeqNo,Node,SourceAddr,SourcePort,SourceNode}, indirectPingReq{+Target,Port,Nack}, ackResp{SeqNo,Payload}
    * (serf's ping delegate puts a coordinate in Payload), nackResp{SeqNo} — msgpack with field names */
   c->ctl_len[SWIM_CTL_PING] = 86; c->ctl_len[SWIM_CTL_INDIRECT] = 122; c->ctl_len[SWIM_CTL_ACK] = 108; c->ctl_len[SWIM_CTL_NACK] = 13;
-  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8;
+  c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8; c->view_cap = 0; c->fold_interval_ms = 0;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
   return SWIM_OK;
@@ -164,7 +164,8 @@ int swim_config_preset(swim_config* c, int preset) {
 static int validate(const swim_config* c) {
   if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
   if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
-  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 30)) return SWIM_ERANGE;
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 29)) return SWIM_ERANGE;
+  if (c->view_cap > (1u << 20)) return SWIM_ERANGE;
   if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
   if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
   if (c->suspicion_mult < 1 || c->suspicion_mult > 6 || c->retransmit_mult < 1) return SWIM_EINVAL;
@@ -220,6 +221,9 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
     d->push_pull_period_ticks = (uint32_t)per; }
   /* state.go gossip(): bytesAvail = UDPBufferSize - compoundHeaderOverhead(2) - labelOverhead(0) */
   d->packet_budget = c->udp_buffer_size > 2 ? c->udp_buffer_size - 2 : 0;
+  if (d->retransmit_limit > 255) return SWIM_ERANGE;       /* transmits is an 8-bit field */
+  d->view_cap = c->view_cap ? c->view_cap : (c->n_nodes < 32 ? c->n_nodes : 32);
+  d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -233,7 +237,14 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
 
-typedef struct { uint32_t key, since, conf[CONF_MAX]; uint8_t nconf; } view_t;
+/* one explicit view: what an observer knows about `subj` beyond the replica's base row */
+typedef struct { uint32_t subj, key, since, conf[CONF_MAX]; uint8_t nconf; } view_t;
+/* an observer's explicit views: open addressing (linear probing, backward-shift deletion), grown on demand, at most
+ * cfg.view_cap entries (+1 for the node's view of itself).  Layout is private to this file: everything observable
+ * (digest, census, members) is keyed by (observer, subject). */
+typedef struct { view_t* e; uint32_t n, slots; } vtab;
+#define V_EMPTY 0xFFFFFFFFu
+#define FOLD_POISON 0xFFFFFFFFu
 #define KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
 #define KINC(k) ((k) >> 2)
 #define KST(k) ((k) & 3u)
@@ -250,13 +261,13 @@ typedef struct {
   uint32_t ev_clock, evqlen, evqseq; qent* evq; evslot* ring;
   /* per-tick inbox */
   uint32_t in_cnt; swim_edge* inbox;
+  vtab vt; uint32_t vdl;          /* explicit views; earliest suspicion deadline among them (a lower bound, SWIM_NONE = none) */
 } node_t;
 
+/* a watch slot: census, first-* stamps and trace of one subject (observation only; the protocol never looks here) */
 typedef struct {
   uint32_t node;            /* subject id */
-  view_t* col;              /* [n_local] observer views */
   uint8_t dirty;
-  uint32_t susp_count, min_deadline;
   uint32_t max_inc;
   swim_census census;       /* cached; first_* fields persistent */
   uint32_t* trace;          /* [trace_ticks][5] */
@@ -271,7 +282,10 @@ struct swim_sim {
   uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
   edgevec captured;              /* rumours sent to attached nodes: {dst = replica*N+attached, ..}, src kept in cap_src */
   uint32_t* cap_src; uint32_t cap_src_cap;
-  uint32_t* node_slot;           /* [R*N] replicated */
+  uint32_t* node_slot;           /* [R*N] replicated: watch slot of a subject, SWIM_NONE = not watched */
+  uint32_t* base_key;            /* [R*N] replicated: the view every observer holds unless it has an explicit one */
+  uint32_t* subj_cnt;            /* [R*N] explicit views of this subject held by the local observers */
+  uint32_t *f_cnt, *f_kmin, *f_kmax; uint8_t* f_bad; uint32_t* f_touched; uint32_t f_ntouched, f_cap;  /* fold accumulators [R*N] */
   node_t* nodes;                 /* [R*nloc] */
   qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous */
   swim_edge* inbox_slab;
@@ -310,30 +324,88 @@ static void record_event(swim_sim* s, uint32_t r, uint32_t type, uint32_t node, 
   s->events[s->n_events++] = e;
 }
 
-/* observer o's view of subject x: the base view unless x has a subject slot */
+/* ---- an observer's explicit views --------------------------------------------------------------- */
+static inline uint32_t vt_home(const vtab* t, uint32_t x) { return fmix32(x) & (t->slots - 1); }
+static view_t* vt_find(const vtab* t, uint32_t x) {
+  if (!t->n) return NULL;
+  for (uint32_t i = vt_home(t, x);; i = (i + 1) & (t->slots - 1)) {
+    if (t->e[i].subj == x) return &t->e[i];
+    if (t->e[i].subj == V_EMPTY) return NULL;
+  }
+}
+static int vt_grow(vtab* t) {
+  uint32_t ns = t->slots ? t->slots * 2 : 4;
+  view_t* ne = (view_t*)malloc((size_t)ns * sizeof(view_t)); if (!ne) return SWIM_ENOMEM;
+  for (uint32_t i = 0; i < ns; i++) ne[i].subj = V_EMPTY;
+  vtab old = *t; t->e = ne; t->slots = ns;
+  for (uint32_t i = 0; i < old.slots; i++) if (old.e[i].subj != V_EMPTY) {
+    uint32_t j = vt_home(t, old.e[i].subj); while (t->e[j].subj != V_EMPTY) j = (j + 1) & (ns - 1);
+    t->e[j] = old.e[i];
+  }
+  free(old.e); return SWIM_OK;
+}
+static view_t* vt_insert(vtab* t, uint32_t x) {            /* x is known to be absent */
+  if ((t->n + 1) * 2 > t->slots && vt_grow(t)) return NULL;
+  uint32_t j = vt_home(t, x); while (t->e[j].subj != V_EMPTY) j = (j + 1) & (t->slots - 1);
+  memset(&t->e[j], 0, sizeof(view_t)); t->e[j].subj = x; t->n++;
+  return &t->e[j];
+}
+static void vt_erase(vtab* t, view_t* v) {                 /* backward-shift deletion */
+  uint32_t m = t->slots - 1, i = (uint32_t)(v - t->e), j = i;
+  for (;;) {
+    j = (j + 1) & m;
+    if (t->e[j].subj == V_EMPTY) break;
+    uint32_t k = vt_home(t, t->e[j].subj);
+    if (i <= j ? (i < k && k <= j) : (i < k || k <= j)) continue;
+    t->e[i] = t->e[j]; i = j;
+  }
+  t->e[i].subj = V_EMPTY; t->n--;
+}
+
+/* observer o's explicit view of subject x, or NULL: then it holds the base row's */
 static view_t* view_ptr(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
-  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
-  if (sl == SWIM_NONE) return NULL;
-  return &s->slots[(size_t)r * s->cfg.subject_cap + sl].col[o - s->i0];
+  if (!s->subj_cnt[(size_t)r * s->N + x]) return NULL;     /* nobody here has news about x */
+  return vt_find(&node_at(s, r, o)->vt, x);
+}
+/* what o holds about x without an explicit view: the base row's — except that a node always sees ITSELF alive at
+ * its own incarnation (the base row may have moved on while it was away) */
+static inline uint32_t implicit_key(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
+  return x == o ? KEY(node_at(s, r, o)->self_inc, SWIM_STATE_ALIVE) : s->base_key[(size_t)r * s->N + x];
 }
 static uint32_t view_key(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, uint32_t* since) {
   view_t* v = view_ptr(s, r, o, x);
-  if (!v) { if (since) *since = 0; return BASE_KEY; }
+  if (!v) { if (since) *since = 0; return implicit_key(s, r, o, x); }
   if (since) *since = v->since;
   return v->key;
 }
+/* the explicit view of x at o, created from the base row when o has none yet.  NULL = o already holds view_cap
+ * explicit views (its view of itself always fits): the caller ignores the rumour, counted in view_drops. */
+static view_t* view_make(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
+  node_t* nd = node_at(s, r, o);
+  view_t* v = vt_find(&nd->vt, x);
+  if (v) return v;
+  if (nd->vt.n >= s->d.view_cap + (x == o ? 1u : 0u)) { s->st.view_drops++; return NULL; }
+  v = vt_insert(&nd->vt, x);
+  if (!v) { s->st.view_drops++; return NULL; }
+  v->key = implicit_key(s, r, o, x);
+  s->subj_cnt[(size_t)r * s->N + x]++;
+  return v;
+}
 
-/* give subject x an override column, initialised to the base view for every observer */
+/* swim_watch: census / first-* stamps / trace of subject x from now on */
+static uint32_t current_max_inc(swim_sim* s, uint32_t r, uint32_t x) {
+  uint32_t m = KINC(s->base_key[(size_t)r * s->N + x]);
+  if (s->subj_cnt[(size_t)r * s->N + x])
+    for (uint32_t k = 0; k < s->nloc; k++) { view_t* v = vt_find(&s->nodes[(size_t)r * s->nloc + k].vt, x); if (v && KINC(v->key) > m) m = KINC(v->key); }
+  return m;
+}
 static int alloc_slot(swim_sim* s, uint32_t r, uint32_t x) {
   size_t g = (size_t)r * s->N + x;
   if (s->node_slot[g] != SWIM_NONE) return SWIM_OK;
   if (s->n_slots[r] >= s->cfg.subject_cap) { s->st.subject_overflow++; return SWIM_EOVERFLOW; }
   uint32_t sl = s->n_slots[r]++;
   slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
-  t->node = x; t->dirty = 1; t->susp_count = 0; t->min_deadline = SWIM_NONE; t->max_inc = 1;
-  t->col = (view_t*)calloc(s->nloc, sizeof(view_t));
-  if (!t->col) return SWIM_ENOMEM;
-  for (uint32_t k = 0; k < s->nloc; k++) t->col[k].key = BASE_KEY;
+  t->node = x; t->dirty = 1; t->max_inc = current_max_inc(s, r, x);
   memset(&t->census, 0, sizeof t->census);
   t->census.first_suspect_ms = t->census.first_dead_ms = t->census.all_dead_ms = t->census.all_current_ms = SWIM_NONE;
   if (s->cfg.trace_ticks) t->trace = (uint32_t*)calloc((size_t)s->cfg.trace_ticks * 5, sizeof(uint32_t));
@@ -425,23 +497,30 @@ static void awareness_delta(swim_sim* s, node_t* nd, int delta) {
 /* state.go aliveNode / suspectNode / deadNode / refute, applied at observer o                 */
 /* ------------------------------------------------------------------------------------------ */
 
-static void set_view(swim_sim* s, uint32_t r, slot_t* t, view_t* v, uint32_t inc, uint32_t st, int touch_since) {
-  uint32_t old = KST(v->key);
-  if (old == SWIM_STATE_SUSPECT && st != SWIM_STATE_SUSPECT) t->susp_count--;
-  if (old != SWIM_STATE_SUSPECT && st == SWIM_STATE_SUSPECT) t->susp_count++;
+static void set_view(swim_sim* s, uint32_t r, uint32_t x, view_t* v, uint32_t inc, uint32_t st, int touch_since) {
   v->key = KEY(inc, st);
   if (touch_since) v->since = now_ms(s);
-  if (inc > t->max_inc) t->max_inc = inc;
-  t->dirty = 1; (void)r;
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
+  if (sl != SWIM_NONE) { slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; if (inc > t->max_inc) t->max_inc = inc; t->dirty = 1; }
+}
+static void touch_slot(swim_sim* s, uint32_t r, uint32_t x) {
+  uint32_t sl = s->node_slot[(size_t)r * s->N + x];
+  if (sl != SWIM_NONE) s->slots[(size_t)r * s->cfg.subject_cap + sl].dirty = 1;
+}
+/* a suspicion timer was (re)armed at observer nd: keep its earliest-deadline bound */
+static void arm_deadline(swim_sim* s, node_t* nd, const view_t* v) {
+  uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
+  if (dl < nd->vdl) nd->vdl = dl;
 }
 
 /* refute: nextIncarnation / skipIncarnation past the accuser, awareness +1, broadcast alive */
-static void refute(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, slot_t* t, view_t* v, uint32_t accused_inc) {
+static void refute(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t accused_inc) {
   uint32_t inc = nd->self_inc + 1;
   if (accused_inc >= inc) inc = accused_inc + 1;
   nd->self_inc = inc;
   awareness_delta(s, nd, +1);
-  set_view(s, r, t, v, inc, SWIM_STATE_ALIVE, 0);
+  view_t* v = view_make(s, r, o, o);                      /* a node's view of itself always fits */
+  if (v) { v->nconf = 0; set_view(s, r, o, v, inc, SWIM_STATE_ALIVE, 0); }
   broadcast(s, nd, o, SWIM_MSG_ALIVE, inc, 0);
   s->st.refutes++;
 }
@@ -449,66 +528,64 @@ static void refute(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, slot_t* t, v
 /* `upd` (carried in the alive record's from field) = the alive came from UpdateNode, i.e. its
  * Meta differs from the previous incarnation's; a refutation re-sends the same Meta */
 static void alive_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t upd) {
-  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;
-  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
+  uint32_t key = view_key(s, r, o, x, NULL);
   int local = (x == o);
   if (local && nd->leaving) return;                       /* "if m.hasLeft() && a.Node == self" */
-  if (!local && inc <= KINC(v->key)) return;
-  if (local && inc < KINC(v->key)) return;
-  v->nconf = 0;                                           /* delete(m.nodeTimers, a.Node) */
-  uint32_t old = KST(v->key);
+  if (!local && inc <= KINC(key)) return;
+  if (local && inc < KINC(key)) return;
   if (local) {
-    if (inc == KINC(v->key)) return;                      /* same incarnation, same meta */
-    refute(s, r, o, nd, t, v, inc);
-  } else {
-    broadcast(s, nd, x, SWIM_MSG_ALIVE, inc, upd);
-    set_view(s, r, t, v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
-    s->st.msgs_applied[SWIM_MSG_ALIVE]++;
-    if (o == s->cfg.watch_node) {
-      if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(s, r, SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
-      else if (upd) record_event(s, r, SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);   /* NotifyUpdate: meta changed */
-    }
+    if (inc == KINC(key)) return;                         /* same incarnation, same meta */
+    refute(s, r, o, nd, inc);
+    return;
+  }
+  view_t* v = view_make(s, r, o, x); if (!v) return;
+  v->nconf = 0;                                           /* delete(m.nodeTimers, a.Node) */
+  uint32_t old = KST(key);
+  broadcast(s, nd, x, SWIM_MSG_ALIVE, inc, upd);
+  set_view(s, r, x, v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
+  s->st.msgs_applied[SWIM_MSG_ALIVE]++;
+  if (o == s->cfg.watch_node) {
+    if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(s, r, SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
+    else if (upd) record_event(s, r, SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);   /* NotifyUpdate: meta changed */
   }
 }
 
 static void suspect_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t from) {
-  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;   /* never heard of it */
-  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
-  if (inc < KINC(v->key)) return;
-  if (KST(v->key) == SWIM_STATE_SUSPECT) {                /* a timer exists: suspicion.Confirm(from) */
+  view_t* v = view_ptr(s, r, o, x);
+  uint32_t key = v ? v->key : implicit_key(s, r, o, x);
+  if (inc < KINC(key)) return;
+  if (KST(key) == SWIM_STATE_SUSPECT) {                   /* a timer exists: suspicion.Confirm(from) (the base row is never Suspect) */
     if (v->nconf >= s->d.suspicion_k) return;
     for (uint32_t i = 0; i <= v->nconf && i < CONF_MAX; i++) if (v->conf[i] == from) return;
     v->nconf++;
     if (v->nconf < CONF_MAX) v->conf[v->nconf] = from;
-    uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
-    if (dl < t->min_deadline) t->min_deadline = dl;
-    t->dirty = 1; s->st.confirmations++;
+    arm_deadline(s, nd, v);
+    touch_slot(s, r, x); s->st.confirmations++;
     broadcast(s, nd, x, SWIM_MSG_SUSPECT, inc, from);
     return;
   }
-  if (KST(v->key) != SWIM_STATE_ALIVE) return;
-  if (x == o) { refute(s, r, o, nd, t, v, inc); return; }
+  if (KST(key) != SWIM_STATE_ALIVE) return;
+  if (x == o) { refute(s, r, o, nd, inc); return; }
+  if (!v && !(v = view_make(s, r, o, x))) return;
   broadcast(s, nd, x, SWIM_MSG_SUSPECT, inc, from);
-  set_view(s, r, t, v, inc, SWIM_STATE_SUSPECT, 1);
+  set_view(s, r, x, v, inc, SWIM_STATE_SUSPECT, 1);
   v->nconf = 0; v->conf[0] = from;                        /* newSuspicion(from, k, min, max) */
-  uint32_t dl = v->since + s->d.suspicion_timeout_ms[0];
-  if (dl < t->min_deadline) t->min_deadline = dl;
+  arm_deadline(s, nd, v);
   s->st.msgs_applied[SWIM_MSG_SUSPECT]++;
 }
 
 static void dead_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t inc, uint32_t from) {
-  uint32_t sl = s->node_slot[(size_t)r * s->N + x]; if (sl == SWIM_NONE) return;
-  slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; view_t* v = &t->col[o - s->i0];
-  if (inc < KINC(v->key)) return;
-  uint32_t old = KST(v->key);
+  view_t* v = view_ptr(s, r, o, x);
+  uint32_t key = v ? v->key : implicit_key(s, r, o, x);
+  if (inc < KINC(key)) return;
+  uint32_t old = KST(key);
   if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
+  if (x == o && !nd->leaving) { refute(s, r, o, nd, inc); return; }
+  if (!v && !(v = view_make(s, r, o, x))) return;
   v->nconf = 0;
-  if (x == o) {
-    if (!nd->leaving) { refute(s, r, o, nd, t, v, inc); return; }
-    broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
-  } else broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
+  broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
   uint32_t st = (from == x) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
-  set_view(s, r, t, v, inc, st, 1);
+  set_view(s, r, x, v, inc, st, 1);
   s->st.msgs_applied[SWIM_MSG_DEAD]++;
   if (o == s->cfg.watch_node && x != o)
     record_event(s, r, st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
@@ -554,8 +631,11 @@ static void emit_from(swim_sim* s, uint32_t src, uint32_t r, uint32_t dst, uint3
 static void emit(swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
   emit_from(s, SWIM_NONE, r, dst, subject, inc, type, from);
 }
-static void emit_slot_request(swim_sim* s, uint32_t r, uint32_t x) {
-  swim_edge e = { SWIM_NONE, x, r, 0 };
+/* control record of the fold census (dst = SWIM_NONE): what this shard's acting observers hold about subject g =
+ * replica*N + node — `verdict` = their common key, or FOLD_POISON when they disagree or a view is not settled yet;
+ * `cnt` = how many of them hold an explicit view.  Goes to every shard, this one included. */
+static void emit_fold_record(swim_sim* s, uint32_t g, uint32_t verdict, uint32_t cnt) {
+  swim_edge e = { SWIM_NONE, g, verdict, cnt };
   for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++) ev_push(&s->out[sh], e);
 }
 
@@ -585,18 +665,22 @@ static int reach(const swim_sim* s, uint32_t r, uint32_t a, uint32_t b, uint32_t
 static void phase_expire(swim_sim* s) {
   uint32_t now = now_ms(s);
   for (uint32_t r = 0; r < s->R; r++)
-    for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
-      slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
-      if (!t->susp_count || now < t->min_deadline) continue;
-      for (uint32_t k = 0; k < s->nloc; k++) {
-        view_t* v = &t->col[k]; uint32_t o = s->i0 + k;
-        if (KST(v->key) != SWIM_STATE_SUSPECT || !acts(s, r, o)) continue;
-        if (now >= v->since + s->d.suspicion_timeout_ms[v->nconf]) {
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t o = s->i0 + k; node_t* nd = &s->nodes[(size_t)r * s->nloc + k];
+      if (now < nd->vdl || !acts(s, r, o)) continue;       /* vdl is a lower bound of the node's deadlines */
+      uint32_t next = SWIM_NONE;
+      for (uint32_t i = 0; i < nd->vt.slots; i++) {
+        view_t* v = &nd->vt.e[i];
+        if (v->subj == V_EMPTY || KST(v->key) != SWIM_STATE_SUSPECT) continue;
+        uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
+        if (now >= dl) {
           /* a timer is not a packet: straight into the node's own inbox (not part of swim_debug_edges) */
-          ev_push(&s->in, mk_edge(s, r, o, t->node, KINC(v->key), SWIM_MSG_DEAD, o));
+          ev_push(&s->in, mk_edge(s, r, o, v->subj, KINC(v->key), SWIM_MSG_DEAD, o));
           s->st.edges++; s->st.suspicion_timeouts++;
         }
+        if (dl < next) next = dl;   /* a fired timer keeps the bound low until the verdict is merged (it may be dropped) */
       }
+      nd->vdl = next;
     }
 }
 
@@ -636,7 +720,6 @@ static void probe_conclude(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   uint32_t x = nd->pr_target;
   awareness_delta(s, nd, (int)nd->pr_nack_miss);
   s->st.probe_failures++; s->st.nacks_missed += nd->pr_nack_miss;
-  if (s->node_slot[(size_t)r * s->N + x] == SWIM_NONE) emit_slot_request(s, r, x);
   emit(s, r, o, x, nd->pr_inc, SWIM_MSG_SUSPECT, o);     /* node.Incarnation of the copy probe() took */
   nd->pr_target = SWIM_NONE; nd->pr_stage = 0;
 }
@@ -645,7 +728,7 @@ static void probe_conclude(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
 static void probe_start(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   uint32_t num_check = 0, x = SWIM_NONE, key = 0;
   while (num_check < s->N) {
-    if (nd->pr_cursor >= s->N) { nd->pr_epoch++; nd->pr_cursor = 0; num_check++; continue; }   /* resetNodes */
+    if (nd->pr_cursor >= s->N) { nd->pr_epoch = (nd->pr_epoch + 1) & 0xFFFFu; nd->pr_cursor = 0; num_check++; continue; }   /* resetNodes (epochs are 16 bits) */
     uint32_t c = probe_perm(seed_of(s, r), s->N, o, nd->pr_epoch, nd->pr_cursor++);
     key = view_key(s, r, o, c, NULL);
     if (c == o || KST(key) == SWIM_STATE_DEAD || KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
@@ -732,8 +815,8 @@ static void phase_probe(swim_sim* s) {
 static int noop_at_receiver(swim_sim* s, uint32_t r, uint32_t dst, const qent* m) {
   if (m->type == SWIM_MSG_USER || m->subject == dst || !is_local(s, dst)) return 0;
   view_t* v = view_ptr(s, r, dst, m->subject);
-  if (!v) return 0;
-  uint32_t vinc = KINC(v->key), st = KST(v->key);
+  uint32_t key = v ? v->key : s->base_key[(size_t)r * s->N + m->subject];
+  uint32_t vinc = KINC(key), st = KST(key);
   if (m->type == SWIM_MSG_ALIVE) return m->inc <= vinc;
   if (m->inc != vinc) return m->inc < vinc;
   if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return 1;
@@ -753,14 +836,14 @@ static int excl_pushpull(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* 
   return KST(view_key(s, r, o, x, NULL)) != SWIM_STATE_ALIVE;
 }
 static void send_state(swim_sim* s, uint32_t r, uint32_t owner, uint32_t dst) {
-  for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
-    slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
-    view_t* v = &t->col[owner - s->i0];
-    if (v->key == BASE_KEY) continue;                      /* the base row merges to nothing */
-    qent m = { t->node, KINC(v->key), 0, 0, 0, 0 };
+  const vtab* t = &node_at(s, r, owner)->vt;               /* what the base row says merges to nothing */
+  for (uint32_t i = 0; i < t->slots; i++) {
+    const view_t* v = &t->e[i];
+    if (v->subj == V_EMPTY) continue;
+    qent m = { v->subj, KINC(v->key), 0, 0, 0, 0 };
     switch (KST(v->key)) {
       case SWIM_STATE_ALIVE: m.type = SWIM_MSG_ALIVE; break;
-      case SWIM_STATE_LEFT: m.type = SWIM_MSG_DEAD; m.from = t->node; break;
+      case SWIM_STATE_LEFT: m.type = SWIM_MSG_DEAD; m.from = v->subj; break;
       default: m.type = SWIM_MSG_SUSPECT; m.from = dst; break;
     }
     if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, dst, &m)) { s->st.msgs_filtered++; continue; }
@@ -834,11 +917,86 @@ static int edge_cmp(const void* a, const void* b) {
   if (x->meta != y->meta) return x->meta < y->meta ? -1 : 1;
   return 0;
 }
-static int ctrl_cmp(const void* a, const void* b) {
-  const swim_edge *x = (const swim_edge*)a, *y = (const swim_edge*)b;
-  if (x->incarnation != y->incarnation) return x->incarnation < y->incarnation ? -1 : 1;
-  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
-  return 0;
+
+/* ------------------------------------------------------------------------------------------ */
+/* fold (simulator-only compaction; SURVEY §7 hard part 1, Appendix D k_reap_fold)             */
+/* Real memberlist keeps an N-entry map per node; here an observer stores only what differs    */
+/* from the replica's base row.  Every fold_period ticks: a subject on which EVERY acting node */
+/* of the population holds the same explicit view — same incarnation and state, not Suspect    */
+/* (a timer is running), and if Dead then for longer than GossipToTheDeadTime (so that nobody  */
+/* gossips to it any more) — becomes the base row's entry and all explicit views of it are     */
+/* freed, also those of nodes that are not running (a node that comes back has "caught up").   */
+/* The state-change time of a folded view reads 0.  Shards take the decision together: each    */
+/* sends what its own observers hold (emit_fold_record) with the tick's packets.               */
+/* ------------------------------------------------------------------------------------------ */
+static int fold_tick(const swim_sim* s) { return s->d.fold_period_ticks && s->tick && s->tick % s->d.fold_period_ticks == 0; }
+static void fold_touch(swim_sim* s, uint32_t g) {
+  if (s->f_ntouched == s->f_cap) { s->f_cap = s->f_cap ? s->f_cap * 2 : 256; s->f_touched = (uint32_t*)realloc(s->f_touched, (size_t)s->f_cap * 4); }
+  s->f_touched[s->f_ntouched++] = g;
+}
+static void fold_census(swim_sim* s) {
+  if (!fold_tick(s)) return;
+  uint32_t now = now_ms(s);
+  s->f_ntouched = 0;
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      if (!acts(s, r, s->i0 + k)) continue;
+      const vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
+      for (uint32_t i = 0; i < t->slots; i++) {
+        const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue;
+        uint32_t g = r * s->N + v->subj, st = KST(v->key);
+        if (!s->f_cnt[g]++) { fold_touch(s, g); s->f_kmin[g] = s->f_kmax[g] = v->key; s->f_bad[g] = 0; }
+        if (v->key < s->f_kmin[g]) s->f_kmin[g] = v->key;
+        if (v->key > s->f_kmax[g]) s->f_kmax[g] = v->key;
+        if (st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - v->since > s->cfg.gossip_to_dead_ms))) s->f_bad[g] = 1;
+      }
+    }
+  for (uint32_t i = 0; i < s->f_ntouched; i++) {
+    uint32_t g = s->f_touched[i];
+    emit_fold_record(s, g, (!s->f_bad[g] && s->f_kmin[g] == s->f_kmax[g]) ? s->f_kmin[g] : FOLD_POISON, s->f_cnt[g]);
+    s->f_cnt[g] = 0;
+  }
+  s->f_ntouched = 0;
+}
+static void fold_apply(swim_sim* s) {
+  if (!fold_tick(s)) return;
+  s->f_ntouched = 0;
+  for (uint32_t i = 0; i < s->in.n; i++) {
+    const swim_edge* e = &s->in.v[i]; if (e->dst != SWIM_NONE) continue;
+    uint32_t g = e->subject;
+    if (!s->f_cnt[g]) { fold_touch(s, g); s->f_kmin[g] = s->f_kmax[g] = e->incarnation; }
+    s->f_cnt[g] += e->meta;
+    if (e->incarnation < s->f_kmin[g]) s->f_kmin[g] = e->incarnation;
+    if (e->incarnation > s->f_kmax[g]) s->f_kmax[g] = e->incarnation;
+  }
+  if (!s->f_ntouched) return;
+  uint32_t* acting = (uint32_t*)calloc(s->R, 4);          /* acting nodes of the whole population (ground truth is replicated) */
+  for (uint32_t r = 0; r < s->R; r++) for (uint32_t x = 0; x < s->N; x++) acting[r] += (uint32_t)acts(s, r, x);
+  uint32_t any = 0;
+  for (uint32_t i = 0; i < s->f_ntouched; i++) {
+    uint32_t g = s->f_touched[i], r = g / s->N, x = g % s->N;
+    int ok = s->f_kmin[g] == s->f_kmax[g] && s->f_kmax[g] != FOLD_POISON && s->f_cnt[g] == acting[r];
+    s->f_cnt[g] = 0; s->f_bad[g] = (uint8_t)ok;           /* f_bad doubles as "fold this one" for the sweep below */
+    if (!ok) continue;
+    any = 1; s->base_key[g] = s->f_kmin[g];
+    if (is_local(s, x)) s->st.folds++;
+    touch_slot(s, r, x);
+  }
+  free(acting);
+  if (any)                                                 /* one sweep over the explicit views frees every folded subject's entries */
+    for (uint32_t r = 0; r < s->R; r++)
+      for (uint32_t k = 0; k < s->nloc; k++) {
+        vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
+        for (uint32_t i = 0; i < t->slots; ) {
+          view_t* v = &t->e[i];
+          if (v->subj != V_EMPTY && s->subj_cnt[r * s->N + v->subj] && s->f_bad[r * s->N + v->subj] == 1) {
+            s->subj_cnt[r * s->N + v->subj]--; s->st.fold_freed++;
+            vt_erase(t, v);                                /* an entry may have shifted into slot i: look at it again */
+          } else i++;
+        }
+      }
+  for (uint32_t i = 0; i < s->f_ntouched; i++) s->f_bad[s->f_touched[i]] = 0;
+  s->f_ntouched = 0;
 }
 
 /* sendMsg: extra := getBroadcasts(compoundOverhead, UDPBufferSize - len(msg) - compoundHeaderOverhead) — the
@@ -861,16 +1019,9 @@ static void piggyback(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t 
 
 /* packetListen -> handleCommand -> handleAlive/Suspect/Dead/User for everything that arrived */
 static void phase_deliver_resolve(swim_sim* s) {
-  /* subject-slot requests first, in (replica, id) order so every shard allocates identically */
-  uint32_t nc = 0;
-  for (uint32_t i = 0; i < s->in.n; i++) if (s->in.v[i].dst == SWIM_NONE) nc++;
-  if (nc) {
-    swim_edge* c = (swim_edge*)malloc(nc * sizeof(swim_edge)); uint32_t j = 0;
-    for (uint32_t i = 0; i < s->in.n; i++) if (s->in.v[i].dst == SWIM_NONE) c[j++] = s->in.v[i];
-    qsort(c, nc, sizeof(swim_edge), ctrl_cmp);
-    for (uint32_t i = 0; i < nc; i++) alloc_slot(s, c[i].incarnation, c[i].subject);
-    free(c);
-  }
+  /* fold census records of all shards first: a subject every acting observer of the whole population agrees on
+   * moves into the base row before this tick's arrivals are merged */
+  fold_apply(s);
   /* scatter into per-node inboxes */
   for (uint32_t i = 0; i < s->in.n; i++) {
     swim_edge e = s->in.v[i]; if (e.dst == SWIM_NONE) continue;
@@ -915,8 +1066,9 @@ static void census_slot(swim_sim* s, uint32_t r, slot_t* t) {
   for (uint32_t k = 0; k < s->nloc; k++) {
     uint32_t o = s->i0 + k;
     if (o == t->node || !s->gt_alive[(size_t)r * s->N + o]) continue;
-    c->n_observers++; c->by_state[KST(t->col[k].key)]++;
-    if (KINC(t->col[k].key) == t->max_inc) c->n_current++;
+    uint32_t key = view_key(s, r, o, t->node, NULL);
+    c->n_observers++; c->by_state[KST(key)]++;
+    if (KINC(key) == t->max_inc) c->n_current++;
   }
   uint32_t now = now_ms(s);
   if (c->first_suspect_ms == SWIM_NONE && c->by_state[SWIM_STATE_SUSPECT]) c->first_suspect_ms = now;
@@ -954,10 +1106,14 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
   s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1);
   s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
+  s->base_key = (uint32_t*)malloc(NT * 4); s->subj_cnt = (uint32_t*)calloc(NT, 4);
+  s->f_cnt = (uint32_t*)calloc(NT, 4); s->f_kmin = (uint32_t*)calloc(NT, 4); s->f_kmax = (uint32_t*)calloc(NT, 4); s->f_bad = (uint8_t*)calloc(NT, 1);
   s->slots = (slot_t*)calloc((size_t)s->R * cfg->subject_cap, sizeof(slot_t));
   s->n_slots = (uint32_t*)calloc(s->R, 4); s->out = (edgevec*)calloc(cfg->n_shards, sizeof(edgevec));
-  if (!s->gt_alive || !s->part || !s->attached || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out) { swim_destroy(s); return SWIM_ENOMEM; }
+  if (!s->gt_alive || !s->part || !s->attached || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out ||
+      !s->base_key || !s->subj_cnt || !s->f_cnt || !s->f_kmin || !s->f_kmax || !s->f_bad) { swim_destroy(s); return SWIM_ENOMEM; }
   memset(s->gt_alive, 1, NT); memset(s->node_slot, 0xFF, NT * 4);
+  for (size_t g = 0; g < NT; g++) s->base_key[g] = BASE_KEY;
   s->q_slab = (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
   s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
   s->inbox_slab = (swim_edge*)malloc(NL * cfg->inbox_cap * sizeof(swim_edge));
@@ -966,9 +1122,9 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
     node_t* nd = &s->nodes[g];
     nd->q = s->q_slab + g * cfg->queue_cap;
     nd->evq = s->evq_slab ? s->evq_slab + g * cfg->event_queue_cap : NULL;
-    nd->self_inc = 1; nd->pr_target = SWIM_NONE;
+    nd->self_inc = 1; nd->pr_target = SWIM_NONE; nd->vdl = SWIM_NONE;
     nd->inbox = s->inbox_slab + g * cfg->inbox_cap;
-    if (cfg->flags & SWIM_F_SERF_EVENTS) nd->ring = (evslot*)calloc(cfg->event_buffer, sizeof(evslot));
+    if (cfg->flags & SWIM_F_SERF_EVENTS) { nd->ring = (evslot*)calloc(cfg->event_buffer, sizeof(evslot)); nd->ev_clock = 1; }   /* serf.Create: eventClock.Increment() */
     if ((cfg->flags & SWIM_F_SERF_EVENTS) && !nd->ring) { swim_destroy(s); return SWIM_ENOMEM; }
   }
   *out = s; return SWIM_OK;
@@ -976,9 +1132,10 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
 
 int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
-  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) free(s->nodes[g].ring);
+  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].ring); free(s->nodes[g].vt.e); }
+  free(s->base_key); free(s->subj_cnt); free(s->f_cnt); free(s->f_kmin); free(s->f_kmax); free(s->f_bad); free(s->f_touched);
   free(s->inbox_slab);
-  if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) { free(s->slots[i].col); free(s->slots[i].trace); }
+  if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
   free(s->attached); free(s->captured.v); free(s->cap_src);
   free(s->q_slab); free(s->evq_slab);
@@ -1008,6 +1165,7 @@ int swim_tick_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
   for (uint32_t i = 0; i < s->cfg.n_shards; i++) s->out[i].n = 0;
   s->in.n = 0;
+  fold_census(s);
   phase_expire(s); phase_probe(s); phase_pushpull(s); phase_gossip(s);
   /* swim_debug_edges: what the roles emitted (orders excluded), then the carried broadcasts before the filter */
   s->last_edges.n = 0;
@@ -1067,7 +1225,7 @@ static void dirty_all(swim_sim* s, uint32_t r) {
 }
 int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
   int rc = chk(s, r, ids, n); if (rc) return rc;
-  for (size_t i = 0; i < n; i++) s->gt_alive[(size_t)r * s->N + ids[i]] = 0;
+  for (size_t i = 0; i < n; i++) { s->gt_alive[(size_t)r * s->N + ids[i]] = 0; (void)alloc_slot(s, r, ids[i]); }   /* watched while slots remain */
   dirty_all(s, r); return SWIM_OK;
 }
 int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
@@ -1082,7 +1240,7 @@ int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
 int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
   int rc = chk(s, r, ids, n); if (rc) return rc;
   for (size_t i = 0; i < n; i++) {
-    uint32_t x = ids[i]; rc = alloc_slot(s, r, x); if (rc) return rc;
+    uint32_t x = ids[i]; (void)alloc_slot(s, r, x);
     if (!is_local(s, x) || !s->gt_alive[(size_t)r * s->N + x]) continue;
     node_t* nd = node_at(s, r, x); nd->leaving = 1;
     dead_node(s, r, x, nd, x, nd->self_inc, x);
@@ -1093,18 +1251,23 @@ int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
 int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) {
   int rc = chk(s, r, ids, n); if (rc) return rc;
   for (size_t i = 0; i < n; i++) {
-    uint32_t x = ids[i]; rc = alloc_slot(s, r, x); if (rc) return rc;
+    uint32_t x = ids[i]; (void)alloc_slot(s, r, x);
     if (!is_local(s, x) || !s->gt_alive[(size_t)r * s->N + x]) continue;
     node_t* nd = node_at(s, r, x); nd->self_inc++;
-    slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + s->node_slot[(size_t)r * s->N + x]];
-    set_view(s, r, t, &t->col[x - s->i0], nd->self_inc, SWIM_STATE_ALIVE, 0);
+    view_t* v = view_make(s, r, x, x);                    /* a node's view of itself always fits */
+    if (v) set_view(s, r, x, v, nd->self_inc, SWIM_STATE_ALIVE, 0);
     broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 1);
   }
   return SWIM_OK;
 }
 int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
   if (!s || !g) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE; if (r >= s->R) return SWIM_ERANGE;
+  for (uint32_t i = 0; i < s->N; i++) if (g[i] > 127) return SWIM_ERANGE;     /* 7 bits, like the product library's node word */
   memcpy(s->part + (size_t)r * s->N, g, s->N); return SWIM_OK;
+}
+int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
+  if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
+  return alloc_slot(s, r, x);
 }
 int swim_set_loss(swim_sim* s, uint32_t q) { if (!s) return SWIM_EINVAL; s->loss_q32 = q; return SWIM_OK; }
 
@@ -1129,7 +1292,7 @@ int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out)
   if (!is_local(s, o)) return SWIM_ERANGE;
   view_t* v = view_ptr(s, r, o, x);
   memset(out, 0, sizeof *out); out->id = x;
-  uint32_t key = v ? v->key : BASE_KEY;
+  uint32_t key = v ? v->key : implicit_key(s, r, o, x);
   out->incarnation = KINC(key); out->state = (uint8_t)KST(key); out->state_change_ms = v ? v->since : 0;
   out->n_confirm = v && KST(key) == SWIM_STATE_SUSPECT ? v->nconf : 0;
   out->status = status_of(KST(key));
@@ -1172,10 +1335,11 @@ int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out)
 int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {
   if (!s || !out) return SWIM_EINVAL; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
   uint32_t sl = s->node_slot[(size_t)r * s->N + x];
-  if (sl == SWIM_NONE) {            /* nobody has news: everyone holds the base view */
-    memset(out, 0, sizeof *out);
-    for (uint32_t k = 0; k < s->nloc; k++) if (s->i0 + k != x && s->gt_alive[(size_t)r * s->N + s->i0 + k]) out->n_observers++;
-    out->by_state[SWIM_STATE_ALIVE] = out->n_current = out->n_observers;
+  if (sl == SWIM_NONE) {            /* not watched: counted on demand, no history */
+    slot_t tmp; memset(&tmp, 0, sizeof tmp);
+    tmp.node = x; tmp.max_inc = current_max_inc(s, r, x);
+    census_slot(s, r, &tmp);
+    *out = tmp.census;
     out->first_suspect_ms = out->first_dead_ms = out->all_dead_ms = out->all_current_ms = SWIM_NONE;
     return SWIM_OK;
   }
@@ -1225,17 +1389,21 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
         for (uint32_t b = 0; b < s->cfg.event_buffer; b++)
           for (uint32_t j = 0; j < nd->ring[b].n; j++) d += h3(8, g, ((uint64_t)nd->ring[b].ltime << 32) | nd->ring[b].ids[j]);
     }
-    for (uint32_t sl = 0; sl < s->n_slots[r]; sl++) {
-      slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl];
-      for (uint32_t k = 0; k < s->nloc; k++) {
-        view_t* v = &t->col[k]; if (v->key == BASE_KEY && v->since == 0) continue;
-        uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)t->node * 0x100000001B3ull) ^ ((uint64_t)(s->i0 + k) << 8);
+    for (uint32_t k = 0; k < s->nloc; k++) {               /* explicit views */
+      const vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
+      for (uint32_t i = 0; i < t->slots; i++) {
+        const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue;
+        uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)v->subj * 0x100000001B3ull) ^ ((uint64_t)(s->i0 + k) << 8);
         d += h3(9, id, ((uint64_t)v->key << 32) | v->since);
         if (KST(v->key) == SWIM_STATE_SUSPECT) {
           d += h3(10, id, v->nconf);
           for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX; j++) d += h3(11 + j, id, v->conf[j]);
         }
       }
+    }
+    for (uint32_t k = 0; k < s->nloc; k++) {               /* the base row (replicated: every shard digests its own id range) */
+      uint64_t g = (uint64_t)r * s->N + s->i0 + k;
+      if (s->base_key[g] != BASE_KEY) d += h3(15, g, s->base_key[g]);
     }
   }
   *out = d; return SWIM_OK;
@@ -1259,8 +1427,8 @@ static int attach(swim_sim* s, uint32_t r, uint32_t a) {
 int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, const swim_edge* m, size_t n) {
   int rc = attach(s, r, a); if (rc) return rc;
   if (dst >= s->N || (!m && n)) return SWIM_EINVAL;
-  for (size_t i = 0; i < n; i++)                       /* a rumour about somebody new needs a view column first */
-    if ((m[i].meta >> 30) != SWIM_MSG_USER) { if (m[i].subject >= s->N) return SWIM_ERANGE; alloc_slot(s, r, m[i].subject); }
+  for (size_t i = 0; i < n; i++)
+    if ((m[i].meta >> 30) != SWIM_MSG_USER && m[i].subject >= s->N) return SWIM_ERANGE;
   if (!is_local(s, dst) || !s->gt_alive[(size_t)r * s->N + dst] || s->attached[(size_t)r * s->N + dst]) return SWIM_OK;
   node_t* nd = node_at(s, r, dst);
   for (size_t i = 0; i < n; i++) {

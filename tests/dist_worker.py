@@ -17,7 +17,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
-    kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, queue_cap=16, inbox_cap=128,
+    kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, view_cap=128, queue_cap=16, inbox_cap=128,
               loss_q32=int(0.05 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     sh = ShardedSim(Sim(ora, preset(ora, abi.PRESET_LAN, shard_rank=rank, n_shards=world, **kw)),
                     TorchExchange(dist.group.WORLD, None))

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("n_shards", [2, 4])
 def test_in_process_shards_match_unsharded(oracle, n_shards):
-    kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, queue_cap=16, inbox_cap=128,
+    kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, view_cap=128, queue_cap=16, inbox_cap=128,
               loss_q32=int(0.05 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw))
                      for i in range(n_shards)], LocalExchange())

@@ -284,7 +284,7 @@ def test_state_precedence_matrix(oracle):
 
 def test_refute_bumps_incarnation_and_awareness(oracle):
     """A live node that hears it is suspected re-asserts itself with incarnation+1 (refute)."""
-    s = small(oracle, n_nodes=64, loss_q32=int(0.35 * 2**32), subject_cap=64, queue_cap=16, inbox_cap=64,
+    s = small(oracle, n_nodes=64, loss_q32=int(0.35 * 2**32), subject_cap=64, view_cap=64, queue_cap=16, inbox_cap=64,
               flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)        # UDP-only probing: loss alone must be able to raise suspicions
     assert s.derived.suspicion_min_ms > 6000                # no suspicion can run out during the lossy phase
     s.step_ms(6000)
@@ -417,9 +417,9 @@ def test_golden_infection_curves_32k(oracle):
 @pytest.mark.parametrize("kw", [
     dict(n_nodes=4096, n_replicas=2, seed=5),
     # inbox large enough that the UNfiltered run does not overflow it (a push-pull delivers every subject at once)
-    dict(n_nodes=1024, seed=9, subject_cap=512, queue_cap=32, inbox_cap=4096, loss_q32=int(0.1 * 2**32),
+    dict(n_nodes=1024, seed=9, subject_cap=512, view_cap=512, queue_cap=32, inbox_cap=4096, loss_q32=int(0.1 * 2**32),
          base_flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK),
-    dict(n_nodes=512, seed=2, suspicion_mult=6, subject_cap=64),              # k = 4 confirmations
+    dict(n_nodes=512, seed=2, suspicion_mult=6, subject_cap=64, view_cap=64),              # k = 4 confirmations
 ])
 def test_noop_filter_never_changes_node_state(oracle, kw):
     """SWIM_F_FILTER_NOOP drops at the sender what the receiver would ignore anyway: every integer of
@@ -445,7 +445,7 @@ def test_tcp_fallback_ping_rides_out_packet_loss(oracle):
     """probeNode's TCP fallback (on by default, as in memberlist): with 30 % UDP loss and nobody dead, direct and
     indirect probes fail now and then but the TCP ping always connects — no suspicion is ever raised; a node that
     really died is still detected at the usual pace.  Without the fallback the same loss produces false suspicions."""
-    kw = dict(n_nodes=512, seed=6, loss_q32=int(0.30 * 2**32), subject_cap=128, queue_cap=16, inbox_cap=128)
+    kw = dict(n_nodes=512, seed=6, loss_q32=int(0.30 * 2**32), subject_cap=128, view_cap=128, queue_cap=16, inbox_cap=128)
     s = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
     s.step_ms(20000)
     st = s.stats()
@@ -458,7 +458,7 @@ def test_tcp_fallback_ping_rides_out_packet_loss(oracle):
     st = t.stats()
     assert st["probe_tcp_acks"] == 0 and st["probe_failures"] > 0 and st["msgs_sent"][abi.MSG_SUSPECT] > 0
     # a partition is not packet loss: TCP cannot cross it either
-    u = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=64, seed=1, subject_cap=64, queue_cap=32, inbox_cap=256))
+    u = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=64, seed=1, subject_cap=64, view_cap=64, queue_cap=32, inbox_cap=256))
     u.partition(0, [1 if i < 8 else 0 for i in range(64)])
     u.step_ms(15000)
     assert u.stats()["probe_failures"] > 0 and u.stats()["probe_tcp_acks"] == 0

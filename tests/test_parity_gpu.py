@@ -93,7 +93,7 @@ def test_update_rumour_wan(hip, oracle):
 
 def test_loss_refute_and_partition(hip, oracle):
     """packet loss => false suspicions => refutes (incarnation bumps); then a partition."""
-    a, b = pair(hip, oracle, n_nodes=2048, seed=9, subject_cap=1024, queue_cap=32, inbox_cap=256,
+    a, b = pair(hip, oracle, n_nodes=2048, seed=9, subject_cap=1024, view_cap=1024, queue_cap=32, inbox_cap=256,
                 loss_q32=int(0.10 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     for s in (a, b):
         s.step_ms(20000)
@@ -131,7 +131,7 @@ def test_sharded_population_matches_unsharded(hip, oracle, n_shards):
     """the population block-partitioned over several simulators (all on this one
     device, records handed over in-process) must reproduce the unsharded oracle bit for bit."""
     from consul_amd.dist import LocalExchange, ShardedSim
-    kw = dict(n_nodes=4096, n_replicas=2, seed=5, subject_cap=256, queue_cap=16, inbox_cap=1024,
+    kw = dict(n_nodes=4096, n_replicas=2, seed=5, subject_cap=256, view_cap=256, queue_cap=16, inbox_cap=1024,
               loss_q32=int(0.05 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
     sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw))
                      for i in range(n_shards)], LocalExchange())
@@ -155,7 +155,7 @@ def test_sharded_quiet_cluster_stays_off_the_wire_and_wakes_up(hip, oracle):
     (swim_peer_activity): a quiescent sharded cluster exchanges nothing, and every way of waking it up (failure,
     update, user-visible leave) still reproduces the unsharded oracle bit for bit."""
     from consul_amd.dist import LocalExchange, ShardedSim
-    kw = dict(n_nodes=4096, seed=8, subject_cap=64, queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+    kw = dict(n_nodes=4096, seed=8, subject_cap=64, view_cap=64, queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
     sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
     ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
     for s in (sh, ref):
@@ -285,7 +285,7 @@ def _churn_and_flood(sims, n, seconds, rng_seed, events_per_s=3, churn=0.03):
 def test_churn_and_event_flood(hip, oracle, fanout):
     """Config #5's shape (Lifeguard on, churn, user-event flood) at 2 048 nodes, compared every two seconds.
     fan-out 5 runs the wide-array kernel variant with the Serf queue."""
-    kw = dict(n_nodes=2048, seed=21, gossip_nodes=fanout, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048,
+    kw = dict(n_nodes=2048, seed=21, gossip_nodes=fanout, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048, view_cap=2048,
               queue_cap=16, event_queue_cap=16, inbox_cap=512, push_pull_interval_ms=0)
     a, b = pair(hip, oracle, **kw)
     for step in range(8):
@@ -301,7 +301,7 @@ def test_churn_and_event_flood(hip, oracle, fanout):
 def test_churn_and_event_flood_sharded(hip, oracle):
     """The same on two HIP shards (sharded kernel variant with the Serf queue) against the unsharded oracle."""
     from consul_amd.dist import LocalExchange, ShardedSim
-    kw = dict(n_nodes=2048, seed=22, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048, queue_cap=16,
+    kw = dict(n_nodes=2048, seed=22, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=2048, view_cap=2048, queue_cap=16,
               event_queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
     sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
     ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
@@ -325,7 +325,7 @@ def test_queues_that_do_not_fit_the_lds_are_refused(hip):
 def test_tcp_fallback_under_loss_parity(hip, oracle):
     """Default flags (TCP fallback ping on) with 20 % packet loss, a real failure and a partition: the lossy probes are
     saved by TCP on both libraries alike, the dead node and the partitioned ones are still found out."""
-    a, b = pair(hip, oracle, n_nodes=2048, seed=13, subject_cap=256, queue_cap=16, inbox_cap=256, loss_q32=int(0.20 * 2**32))
+    a, b = pair(hip, oracle, n_nodes=2048, seed=13, subject_cap=256, view_cap=256, queue_cap=16, inbox_cap=256, loss_q32=int(0.20 * 2**32))
     mask = np.zeros(2048, dtype=np.uint8); mask[1000:1040] = 1
     for s in (a, b):
         s.step_ms(8000)

@@ -27,8 +27,8 @@ def scenario(s):
 def test_event_reaches_every_member_exactly_once(oracle):
     s = cluster(oracle)
     lts = scenario(s)
-    assert lts[0] == 0 and lts[1] == 1 and lts[2] == 0          # Lamport time: per-origin clock at fire time
-    assert lts[3] >= 2                                          # node 77 witnessed ltime 1 before firing
+    assert lts[0] == 1 and lts[1] == 2 and lts[2] == 1          # Lamport time: per-origin clock at fire time (serf.Create starts it at 1)
+    assert lts[3] >= 3                                          # node 77 witnessed ltime 1 before firing
     st = s.stats()
     assert st["user_events_delivered"] == 4 * 256               # each event delivered once per member
     assert st["user_events_deduped"] > 0                        # ...however many copies arrived
@@ -54,8 +54,8 @@ def test_events_share_the_packet_with_membership_rumours(oracle):
 def test_old_events_fall_out_of_the_window(oracle):
     """handleUserEvent drops an event whose LTime is more than EventBuffer behind the local clock."""
     s = cluster(oracle, n_nodes=64, event_buffer=4, event_queue_cap=16)
-    for i in range(12):                                         # a burst: LTimes 0..11 leave node 5 together
-        assert s.user_event(0, 5, 100 + i) == i
+    for i in range(12):                                         # a burst: LTimes 1..12 leave node 5 together
+        assert s.user_event(0, 5, 100 + i) == i + 1
     s.step_ms(6000)
     st = s.stats()
     # the whole burst rides one packet and is applied in ascending LTime order, so a first copy is always

@@ -35,7 +35,7 @@ def draw_case(rng):
     if rng.random() < 0.5:
         flags |= abi.F_SERF_EVENTS
     kw = dict(n_nodes=n, n_replicas=int(rng.integers(1, 4)), seed=int(rng.integers(1, 1 << 30)), flags=flags,
-              gossip_nodes=int(rng.integers(1, 6)), indirect_checks=int(rng.integers(0, 5)), subject_cap=min(n, 1024),
+              gossip_nodes=int(rng.integers(1, 6)), indirect_checks=int(rng.integers(0, 5)), subject_cap=min(n, 1024), view_cap=min(n, 1024),
               queue_cap=int(rng.choice([2, 4, 8, 16])), event_queue_cap=int(rng.choice([2, 4, 8])), inbox_cap=4096,
               loss_q32=int(float(rng.choice([0, 0, 0.05, 0.25])) * 2**32), phase_chunk=chunk,
               suspicion_mult=int(rng.integers(3, 8)), retransmit_mult=int(rng.integers(1, 5)),
