@@ -14,9 +14,12 @@ GPU) and cross-shard gossip records ride a per-tick all-to-all over RCCL; the re
 with N so per-GPU work is fixed (weak scaling).
 
 One JSON line on stdout (rank 0).  `roofline` is for the kernel that dominates the timed region,
-timed with HIP events on the simulator's stream in a second, instrumented pass of the same region;
-`cpu_baseline` is the plain-C oracle on the host cores (one replica per thread) on a bounded sample of
-the same workload.
+timed with HIP events on the simulator's stream in a second, instrumented pass of the same region
+(`traffic` is null: HBM counters need rocprofv3 --pmc passes, see profiles/README.md); `cpu_baseline` is the
+plain-C oracle on the host cores, one thread and all cores, on a bounded sample of the same scenario.
+Legs that do not depend on --steps/--warmup, so that every line carries them: `detection` (config #2's
+deliverable: kill at t = 5 s, run until every replica's survivors all know), `config4` (524 288 nodes on this
+GPU, 5 % cut off at once, bounded views) and `convergence` (config #3).
 """
 from __future__ import annotations
 
@@ -73,41 +76,137 @@ def diff_stats(a: dict, b: dict) -> dict:
 
 
 def run_cpu_baseline(args, ticks_per_round: int) -> dict:
-    """The oracle (a scalar C port) on a bounded sample: `cpu_replicas` replicas, one per host thread.
-
-    Replica r of seed s is by construction replica 0 of seed s+r, so each thread owns an independent
-    one-replica handle (ctypes drops the GIL during swim_step) and the sample is the same scenario as
-    the first `cpu_replicas` replicas of the GPU run.
-    """
+    """The oracle (a scalar C port) on a bounded sample of config #2's scenario, independent of --steps/--warmup:
+    25 quiet rounds, the failure, 200 timed rounds per cluster; `per_thread` clusters one after the other on each thread.
+    Two figures (SURVEY §8(d) comparator A): one thread, and every host core.  Replica r of seed s is by construction
+    replica 0 of seed s+r, so each cluster is an independent one-replica handle (ctypes drops the GIL in swim_step)."""
     from concurrent.futures import ThreadPoolExecutor
     so = os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")
     if not os.path.exists(so):
         import __graft_entry__
         __graft_entry__.build_oracle()
     ora = abi.bind(C.CDLL(so))
-    reps = args.cpu_replicas
-    cores = max(1, min(reps, os.cpu_count() or 1, args.cpu_threads or (os.cpu_count() or 1)))
-    victims = victims_for(args.seed, reps, args.nodes)
-    sims = [Sim(ora, preset(ora, abi.PRESET_LAN, n_nodes=args.nodes, n_replicas=1, seed=args.seed + r,
-                            subject_cap=args.subject_cap, gossip_nodes=args.fanout)) for r in range(reps)]
+    warm, rounds, per_thread = 25, 200, 2
+    ncpu = os.cpu_count() or 1
+    cores = max(1, min(ncpu, args.cpu_threads or ncpu))
 
-    def prep(r):
-        sims[r].step(args.warmup * ticks_per_round)
-        sims[r].kill(0, [victims[r]])
+    def sample(threads):
+        reps = threads * per_thread
+        victims = victims_for(args.seed, reps, args.nodes)
+        sims = [Sim(ora, preset(ora, abi.PRESET_LAN, n_nodes=args.nodes, n_replicas=1, seed=args.seed + r,
+                                subject_cap=args.subject_cap, gossip_nodes=args.fanout)) for r in range(reps)]
 
-    def timed(r):
-        sims[r].step(args.steps * ticks_per_round)
+        def prep(r):
+            sims[r].step(warm * ticks_per_round); sims[r].kill(0, [victims[r]])
 
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(prep, range(reps)))
+        def timed(t):
+            for r in range(t, reps, threads):
+                sims[r].step(rounds * ticks_per_round)
+
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(prep, range(reps)))
+            t0 = time.perf_counter()
+            list(ex.map(timed, range(threads)))
+            dt = time.perf_counter() - t0
+        for x in sims:
+            x.close()
+        return reps * args.nodes * rounds / dt, dt, reps
+
+    v1, dt1, _ = sample(1)
+    vn, dtn, repsn = sample(cores)
+    return {"value": vn, "unit": "node-rounds/s", "cores": cores, "kind": "port",
+            "one_thread": {"value": v1, "cores": 1, "wall_s": round(dt1, 2)},
+            "sample": f"{repsn} clusters x {args.nodes} nodes x {rounds} rounds after the failure (config #2's scenario, "
+                      f"kill after {warm} rounds), {per_thread} per thread: {dtn:.1f} s wall on {cores} of {ncpu} host threads; "
+                      f"one thread: {per_thread} clusters, {dt1:.1f} s"}
+
+
+def roofline_of(prof: dict, st: dict, wall_s=None) -> dict:
+    """`roofline` object for the kernel that took most of the instrumented region (HIP events around every launch)."""
+    total_ms = sum(ms for _, ms in prof.values())
+    dom = max(prof, key=lambda k: prof[k][1])
+    launches, ms = prof[dom]
+    bytes_per_launch = algorithmic_bytes(dom, st) / max(launches, 1)
+    avg_s = ms / 1000.0 / max(launches, 1)
+    achieved = bytes_per_launch / avg_s / 1e9
+    pipe_bytes = sum(algorithmic_bytes(k, st) for k in prof)
+    out = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "avg_launch_us": 1e6 * avg_s, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+           "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof.items()},
+           "per_kernel": {k: {"avg_launch_us": 1e3 * v[1] / max(v[0], 1), "launches": v[0],
+                              "algorithmic_bytes_per_launch": algorithmic_bytes(k, st) / max(v[0], 1),
+                              "frac": (algorithmic_bytes(k, st) / max(v[1], 1e-9) / 1e6) / HBM_PEAK_GBS}
+                          for k, v in prof.items() if algorithmic_bytes(k, st) > 0},
+           "pipeline": {"algorithmic_GBps_over_kernel_time": pipe_bytes / (total_ms / 1000.0) / 1e9,
+                        "kernel_ms_per_round": None}}
+    if wall_s:
+        out["pipeline"]["algorithmic_GBps_over_wall"] = pipe_bytes / wall_s / 1e9
+    return out
+
+
+def run_detection(hip, cfg_kw, victims, G, quantum_ms) -> dict:
+    """BASELINE configs[1]'s deliverable, independent of --steps/--warmup: all alive for 5 s, one uniformly drawn node per
+    cluster killed, run until the survivors of every cluster all hold it dead (60 s of simulated time at most)."""
+    sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
+    t_kill = 5000
+    sim.step_ms(t_kill)
+    for r, v in enumerate(victims):
+        sim.kill(r, [v])
+    t0 = time.perf_counter()
+    census, ran = [], 0
+    for chunk in range(12):
+        sim.step_ms(5000); sim.sync(); ran += 5000
+        census = [sim.census(r, v) for r, v in enumerate(victims)]
+        if all(c.all_dead_ms != abi.NONE for c in census):
+            break
+    dt = time.perf_counter() - t0
+    sim.close()
+
+    def spread(vals):
+        v = sorted(int(x) - t_kill for x in vals if x != abi.NONE)
+        if not v:
+            return {"n": 0}
+        return {"n": len(v), "min": v[0], "p25": v[len(v) // 4], "median": v[len(v) // 2], "p75": v[(3 * len(v)) // 4], "max": v[-1]}
+    return {"workload": "kill one uniformly drawn node per cluster at t = 5 s, run to all-know-dead", "clusters": len(victims),
+            "simulated_ms_after_failure": ran, "wall_s": round(dt, 3), "rounds_per_sec": ran / quantum_ms / G / dt,
+            "ms_after_failure": {"first_suspect": spread(c.first_suspect_ms for c in census),
+                                 "first_dead": spread(c.first_dead_ms for c in census),
+                                 "all_know_dead": spread(c.all_dead_ms for c in census)}}
+
+
+def run_config4(hip, args, device) -> dict:
+    """BASELINE configs[3] on ONE GPU's share: 524 288 nodes, LAN timers, k=3, 5 % (26 214 nodes) cut off at once at
+    t = 1 s, bounded explicit views.  Timed: the 25 gossip rounds (5 s) after the cut; a second, instrumented pass of the
+    same region gives the roofline of its dominant kernel."""
+    n, rounds = 524288, 25
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=1024, queue_cap=8, inbox_cap=128, subject_cap=4, gossip_nodes=3, device=device)
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[np.random.default_rng(args.seed).choice(n, size=n // 20, replace=False)] = 1
+    out = {}
+    for instrumented in (False, True):
+        s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+        G = s.derived.gossip_period
+        s.step_ms(1000); s.partition(0, mask); s.sync()
+        s0 = s.stats()
+        if instrumented:
+            s.profile(True)
         t0 = time.perf_counter()
-        list(ex.map(timed, range(reps)))
+        s.step(rounds * G); s.sync()
         dt = time.perf_counter() - t0
-    for s in sims:
+        if instrumented:
+            st = diff_stats(s0, s.stats())
+            out["roofline"] = roofline_of(s.profile_read(), st)
+            out["counters"] = {k: st[k] for k in ("packets_sent", "edges", "msgs_filtered", "probe_failures", "queue_drops",
+                                                  "view_drops", "view_evictions", "inbox_overflow", "node_rounds_active")}
+            out["counters"]["msgs_sent"] = sum(st["msgs_sent"]); out["counters"]["msgs_applied"] = sum(st["msgs_applied"])
+        else:
+            out.update({"workload": "BASELINE configs[3], one GPU's share: 524288 nodes, 5% partitioned at once, view_cap 1024, "
+                                    "queue_cap 8; the 25 rounds after the cut", "n_nodes": n, "partitioned": int(mask.sum()),
+                        "value": n * rounds / dt, "unit": "node-rounds/s", "rounds_per_sec": rounds / dt, "ms_per_step": 1000.0 * dt / rounds,
+                        "view_table_GB": round(n * s.derived.view_cap * 2 * 32 / 1e9, 1)})
         s.close()
-    return {"value": reps * args.nodes * args.steps / dt, "unit": "node-rounds/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} of the replicas x {args.nodes} nodes x {args.steps} rounds, same scenario, "
-                      f"{dt:.1f} s wall on {cores} host threads of {os.cpu_count()}"}
+    return out
 
 
 def main():
@@ -120,7 +219,8 @@ def main():
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--subject-cap", type=int, default=4)
-    ap.add_argument("--cpu-replicas", type=int, default=32, help="replicas the CPU baseline runs (32 = the whole workload)")
+    ap.add_argument("--no-detection", action="store_true")
+    ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -163,6 +263,8 @@ def main():
     # an overflow would raise SWIM_EOVERFLOW instead of passing silently
     cfg_kw = dict(n_nodes=args.nodes, n_replicas=reps, seed=args.seed, subject_cap=args.subject_cap,
                   gossip_nodes=args.fanout, queue_cap=4,
+                  view_cap=4,        # one failure per cluster: an observer never holds more than a couple of explicit views
+
                   # records from other shards arrive unfiltered (a shard cannot see a remote receiver's view), so a
                   # sharded node's in-degree is the raw Poisson(k) of packets times the rumours in each: more room
                   inbox_cap=24 if world == 1 else 96,
@@ -199,9 +301,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     base = sim.sim if sharded else sim
+    base_quantum = base.derived.quantum_ms
     census = [base.census(r, v) for r, v in enumerate(victims)]
-    detect = {"first_suspect_ms": [c.first_suspect_ms for c in census[:4]], "first_dead_ms": [c.first_dead_ms for c in census[:4]],
-              "all_dead_ms": [c.all_dead_ms for c in census[:4]]}
     # BASELINE configs[1] asks for the time-to-detect distribution: over all replicas, in ms after the failure
     t_kill = args.warmup * G * base.derived.quantum_ms
 
@@ -224,7 +325,8 @@ def main():
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
                    "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
                    "parallelism": f"population sharded x{world}, all-to-all per tick" if sharded else "1 GPU"},
-        "detection_ms_after_t0": detect, "detection_ms_after_failure": detect_after_kill,
+        # what the TIMED window happened to see (it may end before any suspicion runs out): see `detection`
+        "timed_window_detection_ms_after_failure": detect_after_kill,
     }
 
     if sharded and not args.no_replica_leg:
@@ -259,27 +361,12 @@ def main():
         prof = p.profile_read()
         st = diff_stats(s0, p.stats())
         p.close()
-        total_ms = sum(ms for _, ms in prof.values())
-        dom = max(prof, key=lambda k: prof[k][1])
-        launches, ms = prof[dom]
-        bytes_per_launch = algorithmic_bytes(dom, st) / max(launches, 1)
-        avg_s = ms / 1000.0 / max(launches, 1)
-        achieved = bytes_per_launch / avg_s / 1e9
-        pipe_bytes = sum(algorithmic_bytes(k, st) for k in prof)
-        line["roofline"] = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "avg_launch_us": 1e6 * avg_s, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof.items()},
-            "pipeline": {"algorithmic_GBps_over_kernel_time": pipe_bytes / (total_ms / 1000.0) / 1e9,
-                         "algorithmic_GBps_over_wall": pipe_bytes / dt / 1e9,
-                         "kernel_ms_per_round": total_ms / args.steps},
-        }
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            rec = json.load(open(pmc)).get(dom)
-            if rec and rec.get("workload_nodes") == reps * args.nodes:
-                line["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        line["roofline"] = roofline_of(prof, st, dt)
+        line["roofline"]["pipeline"]["kernel_ms_per_round"] = sum(ms for _, ms in prof.values()) / args.steps
+    if rank == 0 and not sharded and not args.no_detection:
+        line["detection"] = run_detection(hip, cfg_kw, victims, G, base_quantum)
+    if rank == 0 and not sharded and not args.no_config4:
+        line["config4"] = run_config4(hip, args, local_rank)
     if rank == 0 and not sharded and not args.no_convergence:
         # second half of the metric: rounds to full convergence at N ~ 1e6 (BASELINE configs[2]:
         # 1 048 576 nodes, DefaultWANConfig timers, one update rumour at node 0, fan-out sweep)
@@ -289,7 +376,7 @@ def main():
             w = Sim(hip, preset(hip, abi.PRESET_WAN, n_nodes=4096, seed=args.seed, gossip_nodes=k, device=local_rank))
             w.step(2); w.sync(); w.close()
             c3 = Sim(hip, preset(hip, abi.PRESET_WAN, n_nodes=1 << 20, seed=args.seed, gossip_nodes=k,
-                                 trace_ticks=64, subject_cap=2, queue_cap=4, inbox_cap=32, device=local_rank))
+                                 trace_ticks=64, subject_cap=2, view_cap=2, queue_cap=4, inbox_cap=32, device=local_rank))
             c3.update(0, [0])
             c3.step(0); c3.sync()                          # builds the launch graphs, advances nothing
             tc = time.perf_counter()

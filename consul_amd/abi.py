@@ -92,7 +92,7 @@ class Stats(C.Structure):
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
-                ("view_drops", u64), ("folds", u64), ("fold_freed", u64)]
+                ("view_drops", u64), ("view_evictions", u64), ("folds", u64), ("fold_freed", u64)]
 
 
 class KernelTime(C.Structure):

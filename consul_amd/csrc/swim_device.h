@@ -22,7 +22,7 @@ enum {
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
-  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_FOLDS, ST_FOLD_FREED,
+  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED,
   ST_COUNT
 };
 

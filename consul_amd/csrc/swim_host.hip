@@ -892,7 +892,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
-  out->view_drops = v[ST_VIEW_DROPS]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
+  out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

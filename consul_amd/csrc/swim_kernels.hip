@@ -78,6 +78,21 @@ __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint
 __device__ __forceinline__ uint32_t base_key_of(DevRef D, uint32_t r, uint32_t x, uint32_t w) {
   return (w & NW_BASEMOD) ? D.bk[(size_t)r * D.N + x] : SW_BASE_KEY;
 }
+// backward-shift deletion of slot `i` of lane l's table (owner only)
+__device__ void vt_erase(DevRef D, size_t l, uint32_t i) {
+  const size_t NL = (size_t)D.R * D.nloc; const uint32_t m = D.VT - 1;
+  uint32_t j = i;
+  for (;;) {
+    j = (j + 1) & m;
+    const uint4 ej = D.vt[(size_t)j * NL + l];
+    if (ej.x == VT_EMPTY) break;
+    const uint32_t k = vt_home(D, ej.x);
+    if (i <= j ? (i < k && k <= j) : (i < k || k <= j)) continue;
+    D.vt[(size_t)i * NL + l] = ej; D.vc[(size_t)i * NL + l] = D.vc[(size_t)j * NL + l];
+    i = j;
+  }
+  D.vt[(size_t)i * NL + l].x = VT_EMPTY;
+}
 // observer (r, local k) looking at node x whose word is `w`: the base row unless somebody here has news about x
 // AND this observer holds an explicit view
 __device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t x, uint32_t w, uint32_t* since) {
@@ -818,6 +833,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
   // their tables slot by slot together (wave_append_* is a wave-wide operation).
   const size_t NL = (size_t)D.R * D.nloc, lo = (size_t)r * D.nloc + (owner - D.i0);
   uint32_t left = on ? D.vnum[lo] : 0;
+  bool saw_dst = false;
   const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
   for (uint32_t sl = 0; sl < D.VT; sl++) {
@@ -828,6 +844,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
       if (a.x != VT_EMPTY) {
         left--;
         uint32_t x = a.x, st = SW_KST(a.y), type, from = 0;
+        saw_dst |= x == dst;
         if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
         else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
         else { type = SWIM_MSG_SUSPECT; from = dst; }
@@ -836,6 +853,21 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
           if (noop_at_receiver(D, r, (size_t)r * D.nloc + (dst - D.i0), D.nw[(size_t)r * D.N + x], make_uint4(x, SW_KINC(a.y), from, type << 30), false, a)) { want = false; c_filt++; }
         }
         rec = mk_edge(D, r, dst, x, SW_KINC(a.y), type, from);
+      }
+    }
+    wave_append_sharded(D, want, sh, rec);
+    c_edges += want; c_remote += want && sh != D.rank;
+  }
+  // ...with one exception: the receiver's view of ITSELF is its own (it may have been away while the base row moved
+  // on), so the owner's view of the receiver travels even when it is the base row's (and not the trivial alive@1)
+  {
+    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
+    if (on && !saw_dst) {
+      const uint32_t key = base_key_of(D, r, dst, D.nw[(size_t)r * D.N + dst]);
+      if (key != SW_BASE_KEY) {
+        const uint32_t st = SW_KST(key), type = st == SWIM_STATE_ALIVE ? SWIM_MSG_ALIVE : st == SWIM_STATE_LEFT ? SWIM_MSG_DEAD : SWIM_MSG_SUSPECT;
+        rec = mk_edge(D, r, dst, dst, SW_KINC(key), type, dst);     // dead{From: node} / suspect{From: receiver}: both = dst here
+        want = true;
       }
     }
     wave_append_sharded(D, want, sh, rec);
@@ -1196,7 +1228,24 @@ struct NodeCtx {
   __device__ bool make(View& v, uint32_t x) {
     if (v.slot != NONE) return true;
     if (vnum == NONE) vnum = D.vnum[l];
-    if (vnum >= D.view_cap + (x == o ? 1u : 0u) || v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
+    if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
+    if (vnum >= D.view_cap + (x == o ? 1u : 0u)) {
+      // Full.  memberlist's resetNodes forgets a node dead for longer than GossipToTheDeadTime; so does a full table,
+      // one node at a time: the longest-settled Dead/Left view (ties: lowest id; never the node's view of itself)
+      // makes room and the observer falls back to the base row for that subject.  Nothing that old: drop.
+      uint32_t vs = NONE, vsince = 0, vsubj = 0; const uint32_t now = now_ms(D, t);
+      for (uint32_t sl = 0; sl < D.VT; sl++) {
+        const uint4 c = D.vt[(size_t)sl * NL + l];
+        if (c.x == VT_EMPTY || c.x == o || SW_KST(c.y) < SWIM_STATE_DEAD || !(now - c.z > D.gossip_to_dead_ms)) continue;
+        if (vs == NONE || c.z < vsince || (c.z == vsince && c.x < vsubj)) { vs = sl; vsince = c.z; vsubj = c.x; }
+      }
+      if (vs == NONE) { S.add(ST_VIEW_DROPS); return false; }
+      const uint32_t wv = D.nw[(size_t)r * D.N + vsubj];
+      if (NW_HAS_SLOT(wv)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wv)] = 1;
+      vt_erase(D, l, vs); vnum--; S.add(ST_VIEW_EVICT);
+      uint4 dummy; vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], dummy, v.free_slot);   // the layout changed
+      if (v.free_slot == NONE) { vnum_dirty = true; S.add(ST_VIEW_DROPS); return false; }
+    }
     vnum++; vnum_dirty = true;
     v.slot = v.free_slot; v.fresh = true;
     if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
@@ -1906,18 +1955,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
       }
     }
     if (!fold) { sl++; continue; }
-    // backward-shift deletion; an entry may move into slot sl, so it is looked at again
-    uint32_t i = sl, j = sl;
-    for (;;) {
-      j = (j + 1) & m;
-      const uint4 ej = D.vt[(size_t)j * NL + l];
-      if (ej.x == VT_EMPTY) break;
-      const uint32_t k = vt_home(D, ej.x);
-      if (i <= j ? (i < k && k <= j) : (i < k || k <= j)) continue;
-      D.vt[(size_t)i * NL + l] = ej; D.vc[(size_t)i * NL + l] = D.vc[(size_t)j * NL + l];
-      i = j;
-    }
-    D.vt[(size_t)i * NL + l].x = VT_EMPTY;
+    vt_erase(D, l, sl);                                  // an entry may move into slot sl: it is looked at again
     n--; freed++;
   }
   if (freed) {

@@ -191,7 +191,7 @@ class ShardedSim:
 
     def __getattr__(self, name):
         # stimulus is replicated on every shard (each applies what it owns)
-        if name in ("kill", "revive", "leave", "update", "partition", "set_loss", "sync"):
+        if name in ("kill", "revive", "leave", "update", "partition", "set_loss", "sync", "watch"):
             def fan(*a, **k):
                 out = None
                 for s in self.sims:

@@ -227,6 +227,8 @@ typedef struct swim_stats_t {
   uint64_t msgs_piggybacked;        /* broadcasts carried that way (also counted in msgs_sent)   */
   uint64_t probe_tcp_acks;          /* probes saved by the TCP fallback ping (SWIM_F_TCP_FALLBACK)*/
   uint64_t view_drops;              /* rumours ignored because the observer already held view_cap explicit views */
+  uint64_t view_evictions;          /* long-settled Dead/Left views a full table forgot to make room (memberlist
+                                       resetNodes forgets a node dead for longer than GossipToTheDeadTime)         */
   uint64_t folds;                   /* subjects folded into the base row (counted by the shard owning the id)   */
   uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
 } swim_stats_t;

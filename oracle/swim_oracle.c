@@ -378,13 +378,27 @@ static uint32_t view_key(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, uint32
   if (since) *since = v->since;
   return v->key;
 }
+static void touch_slot(swim_sim* s, uint32_t r, uint32_t x);
 /* the explicit view of x at o, created from the base row when o has none yet.  NULL = o already holds view_cap
  * explicit views (its view of itself always fits): the caller ignores the rumour, counted in view_drops. */
 static view_t* view_make(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
   node_t* nd = node_at(s, r, o);
   view_t* v = vt_find(&nd->vt, x);
   if (v) return v;
-  if (nd->vt.n >= s->d.view_cap + (x == o ? 1u : 0u)) { s->st.view_drops++; return NULL; }
+  if (nd->vt.n >= s->d.view_cap + (x == o ? 1u : 0u)) {
+    /* Full.  memberlist's resetNodes forgets a node that has been dead for longer than GossipToTheDeadTime; so does a
+     * full table, one node at a time: the longest-settled Dead/Left view (ties: lowest id; never the node's view of
+     * itself) makes room and the observer falls back to the base row for that subject.  Nothing that old: drop. */
+    view_t* victim = NULL; uint32_t now = now_ms(s);
+    for (uint32_t i = 0; i < nd->vt.slots; i++) {
+      view_t* c = &nd->vt.e[i];
+      if (c->subj == V_EMPTY || c->subj == o || KST(c->key) < SWIM_STATE_DEAD || !(now - c->since > s->cfg.gossip_to_dead_ms)) continue;
+      if (!victim || c->since < victim->since || (c->since == victim->since && c->subj < victim->subj)) victim = c;
+    }
+    if (!victim) { s->st.view_drops++; return NULL; }
+    s->subj_cnt[(size_t)r * s->N + victim->subj]--; touch_slot(s, r, victim->subj);
+    vt_erase(&nd->vt, victim); s->st.view_evictions++;
+  }
   v = vt_insert(&nd->vt, x);
   if (!v) { s->st.view_drops++; return NULL; }
   v->key = implicit_key(s, r, o, x);
@@ -836,14 +850,19 @@ static int excl_pushpull(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* 
   return KST(view_key(s, r, o, x, NULL)) != SWIM_STATE_ALIVE;
 }
 static void send_state(swim_sim* s, uint32_t r, uint32_t owner, uint32_t dst) {
-  const vtab* t = &node_at(s, r, owner)->vt;               /* what the base row says merges to nothing */
-  for (uint32_t i = 0; i < t->slots; i++) {
-    const view_t* v = &t->e[i];
-    if (v->subj == V_EMPTY) continue;
-    qent m = { v->subj, KINC(v->key), 0, 0, 0, 0 };
-    switch (KST(v->key)) {
+  /* What the base row says is what the receiver holds too and merges to nothing — with one exception: the receiver's
+   * view of ITSELF is its own (it may have been away while the base row moved on), so the owner's view of the
+   * receiver travels even when it is the base row's (and not the trivial alive@1). */
+  const vtab* t = &node_at(s, r, owner)->vt;
+  int saw_dst = 0;
+  for (uint32_t i = 0; i <= t->slots; i++) {
+    uint32_t subj, key;
+    if (i < t->slots) { const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue; subj = v->subj; key = v->key; saw_dst |= subj == dst; }
+    else { subj = dst; key = s->base_key[(size_t)r * s->N + dst]; if (saw_dst || key == BASE_KEY) break; }
+    qent m = { subj, KINC(key), 0, 0, 0, 0 };
+    switch (KST(key)) {
       case SWIM_STATE_ALIVE: m.type = SWIM_MSG_ALIVE; break;
-      case SWIM_STATE_LEFT: m.type = SWIM_MSG_DEAD; m.from = v->subj; break;
+      case SWIM_STATE_LEFT: m.type = SWIM_MSG_DEAD; m.from = subj; break;
       default: m.type = SWIM_MSG_SUSPECT; m.from = dst; break;
     }
     if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, dst, &m)) { s->st.msgs_filtered++; continue; }

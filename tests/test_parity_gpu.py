@@ -15,7 +15,7 @@ STAT_KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "pac
              "msgs_applied", "probes", "probe_acks", "probe_indirect_acks", "probe_failures", "nacks_missed",
              "refutes", "suspicion_timeouts", "confirmations", "edges", "msgs_filtered", "push_pulls", "queue_drops",
              "inbox_overflow", "piggybacks", "msgs_piggybacked",
-             "subject_overflow"]
+             "subject_overflow", "view_drops", "folds", "fold_freed"]
 
 
 def pair(hip, oracle, which=abi.PRESET_LAN, **kw):
@@ -365,8 +365,12 @@ def test_randomised_parity_cases(hip, oracle):
     spec = importlib.util.spec_from_file_location(
         "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    # the cases of seed 131 whose configuration is accepted and which run to the end without overflowing a bounded structure
+    # (that depends on the draw alone: established with `tools/fuzz_parity.py --backend oracle --seed 131`); every one of
+    # them must match the oracle
+    cases = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 20, 21, 23, 24, 25, 26, 29, 30, 32, 33, 34, 36]
     tally = {}
-    for k in range(30):
+    for k in cases:
         res = fz.run_case(k, hip, oracle, 131, False)
         tally[res] = tally.get(res, 0) + 1
-    assert not tally.get("mismatch") and tally.get("ok", 0) >= 15, tally
+    assert tally == {"ok": len(cases)}, tally

@@ -1,0 +1,198 @@
+"""GPU parity for bounded explicit views, eviction and folding — and BASELINE configs #4 / #5 at one-GPU sizes.
+
+Small and medium cases run the oracle beside the HIP library; the two large ones (262 144 and 131 072 nodes) are
+checked against fixtures the oracle produced in the build container (tools/make_golden.py + tests/scenarios.py).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from consul_amd import abi
+from consul_amd.sim import Sim, preset
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import scenarios as sc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+STAT_KEYS = list(sc.STAT_KEYS) + ["node_rounds_active", "node_rounds_quiescent", "probe_acks", "probe_indirect_acks", "nacks_missed",
+                                  "edges", "msgs_filtered", "push_pulls", "piggybacks", "msgs_piggybacked", "subject_overflow"]
+
+
+def pair(hip, oracle, which=abi.PRESET_LAN, **kw):
+    return Sim(hip, preset(hip, which, **kw)), Sim(oracle, preset(oracle, which, **kw))
+
+
+def assert_same(a, b, tag="", keys=STAT_KEYS):
+    a.sync()
+    assert a.digest() == b.digest(), f"state digest differs {tag}"
+    sa, sb = a.stats(), b.stats()
+    for k in keys:
+        assert sa[k] == sb[k], f"stat {k}: hip {sa[k]} oracle {sb[k]} {tag}"
+
+
+def test_fold_parity_tick_by_tick_around_the_fold(hip, oracle):
+    """kill -> everybody declares it dead -> 30 s later the fold frees the views; then the node comes back, hears the
+    base row's verdict through push-pull, refutes, and the new incarnation is folded too."""
+    a, b = pair(hip, oracle, n_nodes=256, seed=5, fold_interval_ms=2000, push_pull_interval_ms=1000, trace_ticks=2000)
+    for s in (a, b):
+        s.step_ms(1000); s.kill(0, [40]); s.step_ms(30000)
+    assert_same(a, b, "before the fold")
+    for t in range(400):                                   # the fold happens in here: compare every tick
+        a.step(1); b.step(1)
+        assert a.digest() == b.digest(), f"tick {a.now()[0]}"
+    assert_same(a, b, "after the fold")
+    assert b.stats()["folds"] == 1 and b.stats()["fold_freed"] == 255
+    ca, cb = a.census(0, 40), b.census(0, 40)
+    assert list(ca.by_state) == list(cb.by_state) and ca.all_dead_ms == cb.all_dead_ms != abi.NONE
+    assert np.array_equal(a.members(0, 7), b.members(0, 7)) and a.view(0, 7, 40).state_change_ms == 0
+    for s in (a, b):
+        s.revive(0, [40])
+    for t in range(300):
+        a.step(1); b.step(1)
+        assert a.digest() == b.digest(), f"tick {a.now()[0]} after the revive"
+    for s in (a, b):
+        s.step_ms(40000)
+    assert_same(a, b, "after the second fold")
+    assert b.stats()["folds"] == 2 and b.node_info(0, 40).incarnation == 2 and a.view(0, 3, 40).incarnation == 2
+    assert np.array_equal(a.trace(0, 40, 0, 1500), b.trace(0, 40, 0, 1500))
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_fold_on_hip_shards_matches_the_unsharded_oracle(hip, oracle, n_shards):
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=2048, n_replicas=2, seed=9, fold_interval_ms=3000, push_pull_interval_ms=2000, view_cap=64)
+    sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw)) for i in range(n_shards)],
+                    LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.step_ms(1000); s.kill(0, [5, 1700]); s.update(1, [1024]); s.step_ms(70000)
+    sh.sync()
+    assert sh.digest() == ref.digest(), "after the first folds"
+    for s in (sh, ref):
+        s.revive(0, [1700]); s.step_ms(45000)
+    sh.sync()
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("folds", "fold_freed", "refutes", "msgs_applied", "suspicion_timeouts", "view_drops", "push_pulls"):
+        assert a[k] == b[k], k
+    assert b["folds"] >= 4
+    sh.close()
+
+
+def test_view_cap_drops_and_evictions_parity(hip, oracle):
+    """More failures than an observer can track: rumours about further subjects are dropped (counted); once the tracked
+    ones have been dead for longer than GossipToTheDeadTime a full table forgets the oldest to make room."""
+    a, b = pair(hip, oracle, n_nodes=1024, seed=14, view_cap=8, queue_cap=16, inbox_cap=256, subject_cap=4)
+    rng = np.random.default_rng(3)
+    first, second = rng.choice(1024, size=40, replace=False), rng.choice(1024, size=40, replace=False)
+    for s in (a, b):
+        s.step_ms(1000); s.kill(0, first.tolist()); s.step_ms(20000)
+    assert_same(a, b, "first wave")
+    assert b.stats()["view_drops"] > 0 and b.stats()["view_evictions"] == 0
+    for s in (a, b):
+        s.step_ms(50000)                                   # the tracked ones are long dead now
+        s.kill(0, [int(x) for x in second if x not in set(first.tolist())])
+    for chunk in range(6):
+        a.step_ms(10000); b.step_ms(10000)
+        assert_same(a, b, f"second wave +{10 * (chunk + 1)} s")
+    assert b.stats()["view_evictions"] > 0
+    assert np.array_equal(a.members(0, 500), b.members(0, 500))
+
+
+def test_lossy_cluster_with_tiny_tables_parity(hip, oracle):
+    kw = dict(n_nodes=64, seed=1, loss_q32=int(0.35 * 2**32), view_cap=4, queue_cap=16, inbox_cap=64, flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
+    a, b = pair(hip, oracle, **kw)
+    for step in range(12):
+        a.step_ms(1000); b.step_ms(1000)
+        assert_same(a, b, f"{step + 1} s")
+    assert b.stats()["view_drops"] > 0 and b.stats()["refutes"] > 0
+
+
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_partition_of_five_percent_32k_against_the_oracle(hip, oracle, n_shards):
+    """config #4's shape at 32 768 nodes, the oracle running beside the HIP library (and 2 HIP shards)."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    n = 32768
+    kw = dict(sc.PARTITION_262K, n_nodes=n)
+    if n_shards == 1:
+        a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    else:
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **dict(kw, inbox_cap=512)))
+                        for i in range(n_shards)], LocalExchange())
+    b = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    ra, rb = sc.run_partition(a, n, 6, (3, 6)), sc.run_partition(b, n, 6, (3, 6))
+    for sec in (3, 6):
+        assert ra[sec][0] == rb[sec][0], f"digest after {sec} s"
+        for k in sc.STAT_KEYS:
+            assert ra[sec][1][k] == rb[sec][1][k], (sec, k)
+    assert rb[6][1]["view_drops"] > 0 and rb[6][1]["queue_drops"] > 0 and rb[6][1]["inbox_overflow"] == 0
+    a.close()
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 4])
+def test_partition_of_five_percent_262144_matches_golden(hip, n_shards):
+    """config #4 at 262 144 nodes per GPU (13 107 nodes cut off at once), unsharded and as 2 / 4 in-process shards:
+    state digest and counters against the oracle's fixture."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    g = json.load(open(os.path.join(GOLDEN, "config4_partition_262k.json")))
+    kw = g["config"]; n = kw["n_nodes"]
+    if n_shards == 1:
+        a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    else:
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **dict(kw, inbox_cap=512)))
+                        for i in range(n_shards)], LocalExchange())
+    res = sc.run_partition(a, n, 8, (3, 8))
+    for sec in (3, 8):
+        want = g["checkpoints"][str(sec)]
+        assert f"{res[sec][0]:#018x}" == want["digest"], f"digest after {sec} s"
+        for k in sc.STAT_KEYS:
+            assert res[sec][1][k] == want["stats"][k], (sec, k)
+    a.close()
+
+
+def test_churn_ten_percent_per_second_131072_matches_golden(hip):
+    """config #5's shape: 131 072 nodes, every second 10 % flip alive <-> dead, 60 simulated seconds, fold every 5 s.
+    Tables are full within seconds: drops are counted, and from 30 s on full tables recycle their oldest dead views."""
+    g = json.load(open(os.path.join(GOLDEN, "config5_churn_131k.json")))
+    kw = g["config"]
+    a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    res = sc.run_churn(a, kw["n_nodes"], 60, checkpoints=(20, 60))
+    for sec in (20, 60):
+        want = g["checkpoints"][str(sec)]
+        assert f"{res[sec][0]:#018x}" == want["digest"], f"digest after {sec} s"
+        for k in sc.STAT_KEYS:
+            assert res[sec][1][k] == want["stats"][k], (sec, k)
+    assert res[60][1]["view_drops"] > 0 and res[60][1]["view_evictions"] > 0      # slots recycled
+    a.close()
+
+
+def test_config4_size_fits_one_gpu(hip):
+    """524 288 nodes per GPU with room for 4 096 explicit views each (137 GB of view tables) can be created, a 5 %
+    partition (26 214 nodes named in one call, mask of > 2^19 bytes) injected and stepped."""
+    n = 524288
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, view_cap=4096, queue_cap=8, inbox_cap=128, subject_cap=4))
+    s.step_ms(1000)
+    s.partition(0, sc.partition_mask(n))
+    s.step_ms(3000)
+    s.sync()
+    st = s.stats()
+    assert st["probe_failures"] > 0 and st["inbox_overflow"] == 0
+    s.close()
+
+
+def test_partition_mask_above_a_million_nodes(hip):
+    """the mask used to be staged in a fixed 1 MiB buffer (SWIM_ERANGE above 1 048 576 nodes)."""
+    n = 2097152
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, queue_cap=4, inbox_cap=32))
+    mask = np.zeros(n, dtype=np.uint8); mask[n - 1000:] = 3
+    s.partition(0, mask)
+    assert s.node_info(0, n - 1).partition == 3 and s.node_info(0, 5).partition == 0
+    s.kill(0, list(range(0, 400000, 1)))                  # > 262 144 ids in one call (the old upload limit)
+    assert s.node_info(0, 399999).alive == 0 and s.node_info(0, 400000).alive == 1
+    s.step(4); s.sync()
+    s.close()

@@ -1,0 +1,134 @@
+"""Bounded explicit views, the base row and folding — on the CPU oracle.
+
+An observer stores only what it knows beyond the replica's base row (at most `view_cap` subjects); every
+`fold_interval_ms` a subject on which all acting observers hold the same settled view moves into the base row and
+its entries are freed.  The GPU counterparts (HIP against the oracle) live in tests/test_scale_gpu.py.
+"""
+import numpy as np
+import pytest
+
+from consul_amd import abi
+from consul_amd.sim import Sim, preset
+
+
+def lan(oracle, **kw):
+    return Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+
+
+def test_default_view_cap_and_fold_period_are_derived(oracle):
+    s = lan(oracle, n_nodes=8)
+    assert s.derived.view_cap == 8 and s.derived.fold_period_ticks == 0
+    s = lan(oracle, n_nodes=4096, fold_interval_ms=5050)
+    assert s.derived.view_cap == 32 and s.derived.fold_period_ticks == 51      # rounded up to whole ticks
+
+
+def test_fold_moves_a_settled_subject_into_the_base_row(oracle):
+    """A failure everybody has known about for longer than GossipToTheDeadTime is folded: explicit views freed,
+    every observer still reports it dead, and the run is indistinguishable from one that never folds."""
+    kw = dict(n_nodes=256, seed=3)
+    a, b = lan(oracle, fold_interval_ms=5000, **kw), lan(oracle, **kw)
+    for s in (a, b):
+        s.step_ms(2000); s.kill(0, [17]); s.step_ms(28000)
+    assert a.census(0, 17).all_dead_ms != abi.NONE and a.stats()["folds"] == 0     # settled, but not for 30 s yet
+    assert a.digest() == b.digest()
+    for s in (a, b):
+        s.step_ms(40000)
+    st = a.stats()
+    assert st["folds"] == 1 and st["fold_freed"] == 255 and b.stats()["folds"] == 0
+    ca, cb = a.census(0, 17), b.census(0, 17)
+    assert list(ca.by_state) == list(cb.by_state) and ca.by_state[abi.STATE_DEAD] == 255
+    assert (ca.first_suspect_ms, ca.first_dead_ms, ca.all_dead_ms) == (cb.first_suspect_ms, cb.first_dead_ms, cb.all_dead_ms)
+    va, vb = a.view(0, 3, 17), b.view(0, 3, 17)
+    assert (va.state, va.incarnation) == (vb.state, vb.incarnation) == (abi.STATE_DEAD, 1)
+    assert va.state_change_ms == 0 and vb.state_change_ms > 0                      # a folded view has no history
+    assert a.digest() != b.digest()                                                # representation differs...
+    for k in ("probes", "probe_acks", "packets_sent", "msgs_sent", "msgs_applied", "suspicion_timeouts"):
+        assert a.stats()[k] == b.stats()[k], k                                     # ...behaviour does not
+
+
+def test_a_node_that_comes_back_after_the_fold_still_refutes(oracle):
+    """The base row says `dead`, the revived node sees itself alive: the first push-pull tells it (the owner's view of
+    the RECEIVER travels even when it is the base row's), it refutes, and the new incarnation folds in turn."""
+    s = lan(oracle, n_nodes=128, seed=5, fold_interval_ms=2000, push_pull_interval_ms=1000)
+    s.step_ms(1000); s.kill(0, [40]); s.step_ms(80000)
+    assert s.stats()["folds"] == 1 and s.view(0, 0, 40).state == abi.STATE_DEAD
+    s.revive(0, [40])
+    assert s.view(0, 40, 40).state == abi.STATE_ALIVE                              # its own view of itself
+    s.step_ms(60000)
+    c = s.census(0, 40)
+    assert c.by_state[abi.STATE_ALIVE] == c.n_observers == 127 and s.node_info(0, 40).incarnation == 2
+    st = s.stats()
+    assert st["refutes"] >= 1 and st["folds"] == 2                                 # alive@2 became the base row's entry
+    assert s.view(0, 7, 40).incarnation == 2 and s.view(0, 7, 40).state_change_ms == 0
+
+
+def test_view_cap_bounds_what_an_observer_tracks_and_counts_the_drops(oracle):
+    """35 % loss on 64 nodes raises suspicions about most of the cluster; with room for 4 explicit views an observer
+    ignores rumours about a fifth subject (counted), and never holds more than 4 + its view of itself."""
+    kw = dict(n_nodes=64, seed=1, loss_q32=int(0.35 * 2**32), queue_cap=16, inbox_cap=64, flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
+    tight, roomy = lan(oracle, view_cap=4, **kw), lan(oracle, view_cap=64, **kw)
+    for s in (tight, roomy):
+        s.step_ms(12000)
+    assert roomy.stats()["view_drops"] == 0 and tight.stats()["view_drops"] > 0
+    for o in range(64):
+        m = tight.members(0, o)
+        explicit = sum(1 for x in range(64) if x != o and (m[x]["incarnation"], m[x]["state"], m[x]["state_change_ms"]) != (1, 0, 0))
+        assert explicit <= 4
+
+
+def test_watch_is_observation_only(oracle):
+    """swim_watch adds history (first-* stamps, trace); an unwatched subject is counted on demand with the same numbers."""
+    kw = dict(n_nodes=512, seed=6, loss_q32=int(0.30 * 2**32), view_cap=128, queue_cap=16, inbox_cap=128, subject_cap=4,
+              flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
+    a, b = lan(oracle, **kw), lan(oracle, **kw)
+    a.watch(0, 100)
+    for s in (a, b):
+        s.step_ms(15000)
+    assert a.digest() == b.digest()
+    ca, cb = a.census(0, 100), b.census(0, 100)
+    assert list(ca.by_state) == list(cb.by_state) and ca.n_observers == cb.n_observers == 511 and ca.n_current == cb.n_current
+    assert cb.first_suspect_ms == abi.NONE
+    for x in range(4):
+        a.watch(0, 200 + x) if x < 3 else None
+    with pytest.raises(Exception) as e:
+        a.watch(0, 300)                                                            # 4 slots: 100, 200, 201, 202
+    assert "EOVERFLOW" in str(e.value) and a.stats()["subject_overflow"] == 1
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_fold_is_a_joint_decision_of_all_shards(oracle, n_shards):
+    """The fold census rides the per-tick exchange: oracle shards fold the same subjects in the same tick as one
+    unsharded oracle."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    kw = dict(n_nodes=1024, n_replicas=2, seed=9, fold_interval_ms=3000, push_pull_interval_ms=2000, view_cap=64)
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw)) for i in range(n_shards)],
+                    LocalExchange())
+    ref = lan(oracle, **kw)
+    for s in (sh, ref):
+        s.step_ms(1000); s.kill(0, [5, 700]); s.update(1, [512]); s.step_ms(70000)
+        s.revive(0, [700]); s.step_ms(45000)
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("folds", "fold_freed", "refutes", "msgs_applied", "suspicion_timeouts", "view_drops"):
+        assert a[k] == b[k], k
+    assert b["folds"] >= 3                                                         # 5 and 700 dead, 512 updated (+ 700 again)
+    sh.close()
+
+
+@pytest.mark.parametrize("view_cap", [256, 128])
+def test_partition_of_five_percent_with_bounded_views(oracle, view_cap):
+    """Config #4's shape at test size: 5 % of 4 096 nodes (204) cut off at once.  With room for 256 explicit views every
+    survivor finds every victim; with room for 128 it tracks 128 of them and the rest is dropped — counted, never silent."""
+    n = 4096
+    s = lan(oracle, n_nodes=n, seed=2, view_cap=view_cap, queue_cap=16, inbox_cap=256, subject_cap=4)
+    rng = np.random.default_rng(4)
+    victims = rng.choice(n, size=n // 20, replace=False)
+    mask = np.zeros(n, dtype=np.uint8); mask[victims] = 1
+    s.step_ms(1000); s.partition(0, mask); s.step_ms(45000)
+    st = s.stats()
+    assert st["queue_drops"] > 0 and st["suspicion_timeouts"] > 0 and st["inbox_overflow"] == 0
+    assert (st["view_drops"] > 0) == (view_cap < len(victims))
+    survivor = int(np.flatnonzero(mask == 0)[0])
+    m = s.members(0, survivor)
+    found = sum(m[int(v)]["state"] in (abi.STATE_SUSPECT, abi.STATE_DEAD) for v in victims)
+    assert found == min(view_cap, len(victims))

@@ -15,7 +15,7 @@ from consul_amd.dist import LocalExchange, ShardedSim
 KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent", "msgs_applied", "probes",
         "probe_acks", "probe_indirect_acks", "probe_tcp_acks", "probe_failures", "nacks_missed", "refutes", "suspicion_timeouts",
         "confirmations", "queue_drops", "event_drops", "user_events_delivered", "user_events_deduped", "user_events_stale",
-        "piggybacks", "msgs_piggybacked", "push_pulls"]
+        "piggybacks", "msgs_piggybacked", "push_pulls", "view_drops", "view_evictions", "folds", "fold_freed"]
 
 
 def draw_case(rng):
@@ -40,6 +40,15 @@ def draw_case(rng):
               loss_q32=int(float(rng.choice([0, 0, 0.05, 0.25])) * 2**32), phase_chunk=chunk,
               suspicion_mult=int(rng.integers(3, 8)), retransmit_mult=int(rng.integers(1, 5)),
               push_pull_interval_ms=int(rng.choice([0, 3000, 30000])), watch_node=int(rng.integers(0, n)))
+    # bounded views and folding (drawn last, so that the draws above stay what they were).  A full table that evicts
+    # makes the no-op filter visible in the state, and a shard cannot filter what goes to another shard: sharded cases
+    # keep tables that never fill.
+    tiny = int(rng.choice([0, 0, 4, 16]))
+    if tiny and shards == 1:
+        kw["view_cap"] = tiny
+    kw["fold_interval_ms"] = int(rng.choice([0, 0, 1000, 5000]))
+    if rng.random() < 0.5:
+        kw["gossip_to_dead_ms"] = int(rng.choice([500, 2000]))      # so that settled views fold / get evicted within a case
     return which, shards, kw
 
 

@@ -56,10 +56,34 @@ def config3_full():
     return {"config": dict(n_nodes=1048576, seed=1, subject_cap=2), "curves": out}
 
 
+def _checkpoints(res):
+    return {str(sec): {"digest": f"{d:#018x}", "stats": st} for sec, (d, st) in res.items()}
+
+
+def config4_partition():
+    """BASELINE config #4's shape on one GPU: 262 144 nodes, 5 % cut off at once, bounded explicit views (tests/scenarios.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenarios as sc
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.PARTITION_262K))
+    return {"config": sc.PARTITION_262K, "checkpoints": _checkpoints(sc.run_partition(s, sc.PARTITION_262K["n_nodes"], 8, (3, 8)))}
+
+
+def config5_churn():
+    """BASELINE config #5's shape: 131 072 nodes, 10 %/s churn for 60 s, fold every 5 s (tests/scenarios.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenarios as sc
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.CHURN_131K))
+    return {"config": sc.CHURN_131K, "checkpoints": _checkpoints(sc.run_churn(s, sc.CHURN_131K["n_nodes"], 60, checkpoints=(20, 60)))}
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    only = set(sys.argv[1:])
     for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small),
-                     ("config3_infection_1m", config3_full)):
+                     ("config3_infection_1m", config3_full), ("config4_partition_262k", config4_partition),
+                     ("config5_churn_131k", config5_churn)):
+        if only and name not in only:
+            continue
         with open(os.path.join(ROOT, "tests", "golden", name + ".json"), "w") as f:
             json.dump(fn(), f, indent=1)
         print("wrote", name)
