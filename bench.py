@@ -180,7 +180,7 @@ def run_config4(hip, args, device) -> dict:
     t = 1 s, bounded explicit views.  Timed: the 25 gossip rounds (5 s) after the cut; a second, instrumented pass of the
     same region gives the roofline of its dominant kernel."""
     n, rounds = 524288, 25
-    kw = dict(n_nodes=n, seed=args.seed, view_cap=1024, queue_cap=8, inbox_cap=128, subject_cap=4, gossip_nodes=3, device=device)
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=1024, queue_cap=8, inbox_cap=256, subject_cap=4, gossip_nodes=3, device=device)
     mask = np.zeros(n, dtype=np.uint8)
     mask[np.random.default_rng(args.seed).choice(n, size=n // 20, replace=False)] = 1
     out = {}
@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--subject-cap", type=int, default=4)
+    ap.add_argument("--main-only", action="store_true", help="only the timed region (profiling runs): no roofline pass, no extra legs, no CPU baseline")
     ap.add_argument("--no-detection", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all cores)")
@@ -230,6 +231,8 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
     args = ap.parse_args()
+    if args.main_only:
+        args.no_cpu_baseline = args.no_roofline = args.no_convergence = args.no_detection = args.no_config4 = True
 
     # Libraries (RCCL prints a version banner) must not reach stdout: the contract is ONE JSON line.
     sys.stdout.flush()

@@ -53,3 +53,25 @@ def run_churn(sim, n, seconds, share=0.10, rng_seed=45, checkpoints=()):
             st = sim.stats()
             out[sec] = (sim.digest(), {k: st[k] for k in STAT_KEYS})
     return out
+
+
+HEAL_2K = dict(n_nodes=2048, seed=2, view_cap=1024, queue_cap=16, inbox_cap=2048, subject_cap=4, push_pull_interval_ms=2000,
+               fold_interval_ms=5000)
+
+
+def run_partition_heal(sim, n, checkpoints=(46, 76, 136)):
+    """5 % cut off for 45 s (both sides start declaring each other dead), then the cut heals and
+    push-pull anti-entropy brings everybody back: returns {second: (digest, stats subset)}."""
+    mask = partition_mask(n, rng_seed=4)
+    out = {}
+    sim.step_ms(1000)
+    sim.partition(0, mask)
+    for sec in range(2, max(checkpoints) + 1):
+        if sec == 47:
+            sim.partition(0, np.zeros(n, dtype=np.uint8))
+        sim.step_ms(1000)
+        if sec in checkpoints:
+            sim.sync()
+            st = sim.stats()
+            out[sec] = (sim.digest(), {k: st[k] for k in STAT_KEYS + ("push_pulls",)})
+    return out

@@ -59,7 +59,7 @@ def test_fold_parity_tick_by_tick_around_the_fold(hip, oracle):
         s.step_ms(40000)
     assert_same(a, b, "after the second fold")
     assert b.stats()["folds"] == 2 and b.node_info(0, 40).incarnation == 2 and a.view(0, 3, 40).incarnation == 2
-    assert np.array_equal(a.trace(0, 40, 0, 1500), b.trace(0, 40, 0, 1500))
+    assert np.array_equal(a.trace(0, 40, 0, 1400), b.trace(0, 40, 0, 1400))
 
 
 @pytest.mark.parametrize("n_shards", [2, 4])
@@ -171,11 +171,23 @@ def test_churn_ten_percent_per_second_131072_matches_golden(hip):
     a.close()
 
 
+def test_partition_heal_parity(hip, oracle):
+    """SURVEY §8(f) rank 3 (tests/scenarios.py run_partition_heal): cut, mutual suspicion, heal through push-pull, fold."""
+    n = sc.HEAL_2K["n_nodes"]
+    a, b = pair(hip, oracle, **sc.HEAL_2K)
+    ra, rb = sc.run_partition_heal(a, n), sc.run_partition_heal(b, n)
+    for sec in sorted(rb):
+        assert ra[sec][0] == rb[sec][0], f"digest after {sec} s"
+        assert ra[sec][1] == rb[sec][1], f"counters after {sec} s"
+    assert rb[136][1]["folds"] == rb[136][1]["refutes"] > 0
+    assert np.array_equal(a.members(0, 0), b.members(0, 0)) and (b.members(0, 0)["state"] == abi.STATE_ALIVE).all()
+
+
 def test_config4_size_fits_one_gpu(hip):
     """524 288 nodes per GPU with room for 4 096 explicit views each (137 GB of view tables) can be created, a 5 %
     partition (26 214 nodes named in one call, mask of > 2^19 bytes) injected and stepped."""
     n = 524288
-    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, view_cap=4096, queue_cap=8, inbox_cap=128, subject_cap=4))
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, view_cap=4096, queue_cap=8, inbox_cap=256, subject_cap=4))
     s.step_ms(1000)
     s.partition(0, sc.partition_mask(n))
     s.step_ms(3000)

@@ -132,3 +132,24 @@ def test_partition_of_five_percent_with_bounded_views(oracle, view_cap):
     m = s.members(0, survivor)
     found = sum(m[int(v)]["state"] in (abi.STATE_SUSPECT, abi.STATE_DEAD) for v in victims)
     assert found == min(view_cap, len(victims))
+
+
+def test_partition_heals_through_push_pull(oracle):
+    """5 % of 2 048 nodes cut off for 45 s — the majority declares them dead, they start declaring
+    the majority dead — then the cut heals: push-pull tells every victim what the others think of it (Dead is relayed as
+    Suspect), it refutes, and 90 s later every node holds every node alive again and the new incarnations are folded."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scenarios as sc
+    n = sc.HEAL_2K["n_nodes"]
+    s = lan(oracle, **sc.HEAL_2K)
+    res = sc.run_partition_heal(s, n)
+    mask = sc.partition_mask(n, rng_seed=4)
+    victims, survivor = np.flatnonzero(mask), int(np.flatnonzero(mask == 0)[0])
+    assert res[46][1]["suspicion_timeouts"] > 0 and res[46][1]["refutes"] == 0          # cut off: nobody can refute
+    assert res[136][1]["refutes"] >= len(victims) and res[136][1]["inbox_overflow"] == 0 and res[136][1]["view_drops"] == 0
+    for o in (survivor, int(victims[0]), int(victims[-1])):
+        m = s.members(0, o)
+        assert (m["state"] == abi.STATE_ALIVE).all(), f"observer {o} still holds somebody not alive"
+    assert all(s.node_info(0, int(v)).incarnation >= 2 for v in victims[:20])
+    assert res[136][1]["folds"] == res[136][1]["refutes"]                               # every refutation ended up in the base row
