@@ -95,6 +95,10 @@ class Stats(C.Structure):
                 ("view_drops", u64), ("view_evictions", u64), ("folds", u64), ("fold_freed", u64)]
 
 
+class XchgHandle(C.Structure):
+    _fields_ = [("bytes", u8 * 96)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 24), ("launches", u64), ("total_ms", C.c_double)]
 
@@ -123,6 +127,9 @@ PROTOTYPES = {
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_tick_end": (C.c_int, [SimP]),
     "swim_tick_end_begin": (C.c_int, [SimP]),
+    "swim_xchg_export": (C.c_int, [SimP, P(XchgHandle)]),
+    "swim_xchg_connect": (C.c_int, [SimP, P(XchgHandle)]),
+    "swim_xchg_step": (C.c_int, [SimP, u32]),
     "swim_inject_kill": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),

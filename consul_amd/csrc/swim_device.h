@@ -40,6 +40,7 @@ enum {
 #define SW_ERR_EVENT_OVF 0x10u
 #define SW_ERR_PEND_OVF 0x20u
 #define SW_ERR_CARRY_OVF 0x40u
+#define SW_ERR_XCHG_TIMEOUT 0x100u  /* swim_xchg_step: a source shard's flag did not arrive in time (reported as SWIM_ESTATE) */
 #define SW_ERR_VIEW_CORRUPT 0x80u   /* an observer's view table lost its free slot: cannot happen (load <= (view_cap+1)/VT <= 1/2) */
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
@@ -121,8 +122,10 @@ struct SwDev {
   uint32_t VT, vt_shift, view_cap, fold_period;
   uint4* vt;             // [VT][NL]
   uint4* vc;             // [VT][NL]
-  uint32_t* vnum;        // [NL] explicit views held
-  uint32_t* vdl;         // [NL] earliest suspicion deadline among them (lower bound; NONE = none)
+  uint4* vmeta;          // [NL] {explicit views held, how many of them are Suspect,
+                         //       earliest suspicion deadline among them (a lower bound; NONE = none),
+                         //       earliest time a view becomes evictable (Dead/Left for longer than GossipToTheDeadTime;
+                         //       a lower bound; NONE = never) — what a full table checks before it scans itself}
   uint32_t* dl_blk;      // [NL/256] lower bound of the block's vdl over the lanes the simulator acts for
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
   uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)
@@ -169,6 +172,11 @@ struct SwDev {
   uint32_t out_cap[SW_MAX_SHARDS];
   // rumours sent to attached nodes (memberlist.Transport bridge): {sender, subject, incarnation, meta} + target
   uint4* cap; uint32_t* cap_dst; uint32_t* cap_cnt; uint32_t cap_cap;
+  // swim_xchg_*: peer-mapped mailboxes.  mb_tab[sh] = base of shard sh's mailbox as mapped HERE (own included);
+  // layout: header lines [2 parities][n_shards sources][16 words: flag, count, any] then record areas
+  // [2][n_shards][mail_cap] of 16-byte records.  A source writes its area in the destination's mailbox.
+  uint8_t** mb_tab; uint32_t mail_cap, xchg_timeout_ms;
+  uint32_t* xin_cnt;     // [n_shards] records each source delivered this tick
   // events, stats, errors
   swim_event* events;
   uint32_t* ev_cnt;

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "swim_kernels.hip"
 
@@ -44,6 +45,10 @@ struct swim_sim {
   size_t scratch_bytes = 0;
   uint32_t* d_fresh = nullptr;         // [1024] watch slots allocated by the last stimulus call (count, then slot indices)
   void *fold_zero = nullptr, *fold_ones = nullptr; size_t fold_zero_bytes = 0, fold_ones_bytes = 0;   // fold accumulators, by initial value
+  // swim_xchg_*: own mailbox, the peers' mailboxes as mapped here, the captured exchange tick
+  uint8_t* mailbox = nullptr; size_t mailbox_bytes = 0; uint32_t mail_cap = 0;
+  std::vector<void*> ipc_opened; bool xchg_connected = false;
+  hipGraphExec_t graph_xchg = nullptr;
   uint4* in_buf = nullptr;             // records received from other shards
   uint32_t in_cap = 0, in_count = 0;
   uint32_t out_counts[SW_MAX_SHARDS + 1];  // host copy for swim_outbound / swim_activity (counts, then the activity word)
@@ -224,6 +229,7 @@ static void drop_graphs(swim_sim* s) {
   for (int i = 0; i < 2; i++)
     if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
   if (s->graph_end_begin) { (void)hipGraphExecDestroy(s->graph_end_begin); s->graph_end_begin = nullptr; }
+  if (s->graph_xchg) { (void)hipGraphExecDestroy(s->graph_xchg); s->graph_xchg = nullptr; }
 }
 
 extern "C" int swim_destroy(swim_sim* s) {
@@ -249,6 +255,7 @@ extern "C" int swim_destroy(swim_sim* s) {
   }
 #endif
   drop_graphs(s);
+  for (void* p : s->ipc_opened) (void)hipIpcCloseMemHandle(p);
   for (void* p : s->allocs) (void)hipFree(p);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -309,7 +316,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
-  DALLOC(s, D.vnum, NL); DALLOC(s, D.vdl, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+  DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
   {   // fold accumulators, grouped by the value a fold tick resets them to
     const size_t n = D.fold_period ? NT : 1;
     uint32_t* z; DALLOC(s, z, 5 * n + 16); s->fold_zero = z; s->fold_zero_bytes = (5 * n + 16) * 4;
@@ -327,7 +334,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const uint32_t gossip_lanes = D.fast_blocks ? cdiv(cdiv(D.nloc, D.CH), D.G) * D.CH : (cdiv(nchunks, D.G) + 1) * D.CH;
   const uint32_t probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
   BeginPlan& pl = s->plan;
-  pl.nb_expire = cdiv(NB, 64 * (SW_BLOCK / 64));    // expire: one wave looks after 64 node blocks' deadline bounds
+  pl.nb_expire = (uint32_t)NB;                      // expire: one block per 256-node block, out after one word unless a deadline bound passed
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
@@ -360,12 +367,13 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
   DALLOC(s, D.seg, e_cap); DALLOC(s, D.seg_cnt, D.n_seg); DALLOC(s, D.seg_last, D.n_seg);
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
-    // own shard: probe verdicts, slot requests, push-pull; other shards: their share of the gossip records, the acks'
-    // piggy-back orders, carried broadcasts, and push-pull — whose every exchange sends one record per subject in use,
-    // all of a boundary tick's exchanges possibly to the same shard
-    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * (D.S + 1);
-    uint64_t cap = sh == D.rank ? 2 * NL + 4096 + pp_burst
-                                : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards + NL + pp_burst;
+    // own shard: probe verdicts, fold census records, push-pull; other shards: their share of the gossip records, the
+    // acks' piggy-back orders, carried broadcasts, fold census records, and push-pull — whose every exchange sends one
+    // record per explicit view of the sender, all of a boundary tick's exchanges possibly to the same shard
+    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * ((uint64_t)D.view_cap + 3);   // explicit views + own view of the receiver + the pull request
+    const uint64_t fold_burst = D.fold_period ? NT : 0;        // a fold tick: at most one census record per node of the population
+    uint64_t cap = sh == D.rank ? 2 * NL + 4096 + pp_burst + fold_burst
+                                : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards + NL + pp_burst + fold_burst;
     if (cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
     D.out_cap[sh] = (uint32_t)cap;
     DALLOC(s, D.out[sh], cap);
@@ -385,6 +393,15 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     uint64_t in_cap = 0;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) if (sh != D.rank) in_cap += D.out_cap[sh];
     s->in_cap = (uint32_t)std::min<uint64_t>(in_cap, 0x7FFFFFFFull); DALLOC(s, s->in_buf, s->in_cap);
+    // swim_xchg_*: the mailbox the other shards write into (every shard sizes its lists alike, so a source's area
+    // holds whatever its list for this shard can)
+    uint32_t mc = 0; for (uint32_t sh = 0; sh < D.n_shards; sh++) if (sh != D.rank) mc = std::max(mc, D.out_cap[sh]);
+    s->mail_cap = D.mail_cap = mc;
+    s->mailbox_bytes = (size_t)2 * D.n_shards * 64 + (size_t)2 * D.n_shards * mc * sizeof(uint4);
+    DALLOC(s, s->mailbox, s->mailbox_bytes); HIPCK(s, hipMemset(s->mailbox, 0, (size_t)2 * D.n_shards * 64));
+    DALLOC(s, D.mb_tab, SW_MAX_SHARDS); DALLOC(s, D.xin_cnt, SW_MAX_SHARDS); HIPCK(s, hipMemset(D.xin_cnt, 0, SW_MAX_SHARDS * 4));
+    D.xchg_timeout_ms = 2000;
+    if (const char* e = getenv("SWIMSIM_XCHG_TIMEOUT_MS")) D.xchg_timeout_ms = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
   }
 
   hipStream_t st = s->stream;
@@ -485,6 +502,10 @@ static int check_device_errors(swim_sim* s) {
   HIPCK(s, hipMemcpyAsync(&e, s->D.err, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
   HIPCK(s, hipGetLastError());
+  if (e & SW_ERR_XCHG_TIMEOUT) {
+    snprintf(s->err, sizeof s->err, "swim_xchg_step: a source shard did not deliver within %u ms (is every shard stepping?)", s->D.xchg_timeout_ms);
+    return SWIM_ESTATE;
+  }
   if (e) {
     snprintf(s->err, sizeof s->err, "bounded structure overflowed:%s%s%s%s%s%s%s",
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
@@ -584,6 +605,77 @@ extern "C" int swim_tick_end_begin(swim_sim* s) {
   } else { launch_end(s, f0); launch_begin(s, f1); }
   advance(s, 1);
   s->out_counts_valid = false; s->in_count = 0;
+  return SWIM_OK;
+}
+// ---------------------------------------------------------------------------------------------
+// device-driven exchange (swimsim.h): peer-mapped mailboxes, no host round trip
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct XchgHandle { hipIpcMemHandle_t ipc; uint64_t ptr; uint32_t pid, rank, n_shards, mail_cap, magic; };
+static_assert(sizeof(XchgHandle) <= SWIM_XCHG_HANDLE_BYTES, "handle does not fit");
+const uint32_t kXchgMagic = 0x58434847u;
+}
+extern "C" int swim_xchg_export(swim_sim* s, swim_xchg_handle* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  if (s->D.n_shards < 2 || !s->mailbox) return SWIM_ESTATE;
+  XchgHandle h; memset(&h, 0, sizeof h);
+  HIPCK(s, hipIpcGetMemHandle(&h.ipc, s->mailbox));
+  h.ptr = (uint64_t)(uintptr_t)s->mailbox; h.pid = (uint32_t)getpid(); h.rank = s->D.rank; h.n_shards = s->D.n_shards;
+  h.mail_cap = s->mail_cap; h.magic = kXchgMagic;
+  memset(out, 0, sizeof *out); memcpy(out->bytes, &h, sizeof h);
+  return SWIM_OK;
+}
+extern "C" int swim_xchg_connect(swim_sim* s, const swim_xchg_handle* all) {
+  if (!s || !all) return SWIM_EINVAL;
+  if (s->D.n_shards < 2 || !s->mailbox || s->in_tick) return SWIM_ESTATE;
+  uint8_t* tab[SW_MAX_SHARDS] = { nullptr };
+  for (uint32_t sh = 0; sh < s->D.n_shards; sh++) {
+    if (sh == s->D.rank) { tab[sh] = s->mailbox; continue; }
+    XchgHandle h; memcpy(&h, all[sh].bytes, sizeof h);
+    if (h.magic != kXchgMagic || h.rank != sh || h.n_shards != s->D.n_shards || h.mail_cap != s->mail_cap) {
+      snprintf(s->err, sizeof s->err, "swim_xchg_connect: handle %u does not belong to this population", sh); return SWIM_EINVAL;
+    }
+    if (h.pid == (uint32_t)getpid()) tab[sh] = (uint8_t*)(uintptr_t)h.ptr;      // same process: the pointer itself
+    else {
+      void* p = nullptr;
+      HIPCK(s, hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess));
+      s->ipc_opened.push_back(p); tab[sh] = (uint8_t*)p;
+    }
+  }
+  HIPCK(s, hipMemcpy(s->D.mb_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+  s->xchg_connected = true;
+  return SWIM_OK;
+}
+static void launch_xchg(swim_sim* s) {
+  SwDev& D = s->D; hipStream_t st = s->stream;
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(s->mail_cap, SW_BLOCK * 8), 64));
+  hipLaunchKernelGGL(k_xchg_copy, dim3(xb, D.n_shards), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_xchg_signal, dim3(1), dim3(64), 0, st, (const SwDev*)s->d_D);
+  hipLaunchKernelGGL(k_xchg_wait, dim3(1), dim3(64), 0, st, (const SwDev*)s->d_D);
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver_mail, dim3(xb, D.n_shards), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
+}
+extern "C" int swim_xchg_step(swim_sim* s, uint32_t n) {
+  if (!s) return SWIM_EINVAL;
+  if (!s->xchg_connected || s->in_tick) return SWIM_ESTATE;
+  const bool use_graph = !s->profiling && s->use_graphs;
+  for (uint32_t i = 0; i < n; i++) {
+    const bool fold = fold_tick(s, s->tick);
+    if (use_graph && !fold) {
+      if (!s->graph_xchg) {
+        hipGraph_t g = nullptr;
+        HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        launch_begin(s, false); launch_xchg(s); launch_end(s, false);
+        HIPCK(s, hipStreamEndCapture(s->stream, &g));
+        hipError_t e = hipGraphInstantiate(&s->graph_xchg, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
+      }
+      HIPCK(s, hipGraphLaunch(s->graph_xchg, s->stream));
+    } else { launch_begin(s, fold); launch_xchg(s); launch_end(s, fold); }
+    advance(s, 1);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "launch failed: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
   return SWIM_OK;
 }
 extern "C" int swim_tick_end(swim_sim* s) {

@@ -316,53 +316,46 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
 // timeout lapses => deadNode(dead{inc, node, from: self}), delivered to self via the common inbox.
 // =================================================================================================
 __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos);
-// Gate: dl_blk[node block] is a lower bound of the earliest deadline among the block's acting lanes, vdl[lane] of
-// the lane's own timers.  One wave looks after 64 node blocks (one coalesced read); only a block whose bound has
-// passed has its 256 lanes looked at, and only a lane whose own bound has passed walks its view table.
+// Gate: dl_blk[node block] is a lower bound of the earliest deadline among the block's acting lanes, vmeta[lane].z of
+// the lane's own timers.  One block per 256-node block: out after one word unless the bound has passed; only a lane
+// whose own bound has passed walks its view table.
 __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
   (void)nb;
-  const uint32_t t = *D.tick, now = now_ms(D, t), lane = sw_lane();
-  const size_t NL = (size_t)D.R * D.nloc;
-  const uint32_t first_nb = (b * (SW_BLOCK / 64) + threadIdx.x / 64) * 64;
-  const uint32_t mine = first_nb + lane < D.NB ? D.dl_blk[first_nb + lane] : NONE;
-  uint64_t due = __ballot(now >= mine);
-  uint32_t fired = 0;
-  while (due) {
-    const uint32_t j = (uint32_t)__ffsll((long long)due) - 1; due &= due - 1;
-    const uint32_t nbk = first_nb + j;
-    uint32_t newmin = NONE;
-    for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
-      const size_t l = (size_t)nbk * SW_BLOCK + part * 64 + lane;
-      if (l >= NL) continue;
-      uint32_t d = D.vdl[l];
-      if (d == NONE) continue;
-      const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
-      if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;           // its timers rest; a revive lowers dl_blk again
-      if (now >= d) {
-        uint32_t next = NONE, left = D.vnum[l];
-        for (uint32_t sl = 0; sl < D.VT && left; sl++) {
-          const uint4 e = D.vt[(size_t)sl * NL + l];
-          if (e.x == VT_EMPTY) continue;
-          left--;
-          if (SW_KST(e.y) != SWIM_STATE_SUSPECT) continue;
-          const uint32_t dl = e.z + sel8(D.susp_timeout, vw_nconf(e.w));
-          if (now >= dl) {
-            // a timer is not a packet: the verdict goes straight into the node's own inbox line
-            inbox_place(D, mk_edge(D, r, o, e.x, SW_KINC(e.y), SWIM_MSG_DEAD, o), l, atomicAdd(&D.in_cnt[l], 1u));
-            fired++;
-          }
-          next = dl < next ? dl : next;   // a fired timer keeps the bound low until its verdict is merged
+  const uint32_t t = *D.tick, now = now_ms(D, t);
+  if (now < D.dl_blk[b]) return;
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)b * SW_BLOCK + threadIdx.x;
+  uint32_t fired = 0, d = NONE;
+  if (l < NL) {
+    const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
+    const uint4 vm = D.vmeta[l];
+    d = vm.z;
+    if (D.nw[(size_t)r * D.N + o] & NW_INERT) d = NONE;              // its timers rest; a revive lowers dl_blk again
+    else if (now >= d) {
+      uint32_t next = NONE, left = vm.y;                             // Suspect views still to be found
+      for (uint32_t sl = 0; sl < D.VT && left; sl++) {
+        const uint4 e = D.vt[(size_t)sl * NL + l];
+        if (e.x == VT_EMPTY || SW_KST(e.y) != SWIM_STATE_SUSPECT) continue;
+        left--;
+        const uint32_t dl = e.z + sel8(D.susp_timeout, vw_nconf(e.w));
+        if (now >= dl) {
+          // a timer is not a packet: the verdict goes straight into the node's own inbox line
+          inbox_place(D, mk_edge(D, r, o, e.x, SW_KINC(e.y), SWIM_MSG_DEAD, o), l, atomicAdd(&D.in_cnt[l], 1u));
+          fired++;
         }
-        d = next; D.vdl[l] = d;
+        next = dl < next ? dl : next;   // a fired timer keeps the bound low until its verdict is merged
       }
-      newmin = d < newmin ? d : newmin;
+      d = next; D.vmeta[l].z = d;
     }
-    for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(newmin, off); newmin = v < newmin ? v : newmin; }
-    if (lane == 0) D.dl_blk[nbk] = newmin;
   }
+  uint32_t m = d;
+  for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
+  __shared__ uint32_t s_min[SW_BLOCK / 64];
+  if (sw_lane() == 0) s_min[threadIdx.x / 64] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t v = s_min[0]; for (uint32_t j = 1; j < SW_BLOCK / 64; j++) v = s_min[j] < v ? s_min[j] : v; D.dl_blk[b] = v; }
   if (__any(fired != 0)) {
     for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-    if (lane == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+    if (sw_lane() == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
   }
 }
 
@@ -832,7 +825,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
   // what the base row says merges to nothing: only the owner's explicit views travel.  The lanes of the wave walk
   // their tables slot by slot together (wave_append_* is a wave-wide operation).
   const size_t NL = (size_t)D.R * D.nloc, lo = (size_t)r * D.nloc + (owner - D.i0);
-  uint32_t left = on ? D.vnum[lo] : 0;
+  uint32_t left = on ? D.vmeta[lo].x : 0;
   bool saw_dst = false;
   const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
@@ -1114,6 +1107,66 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
   if (n > D.out_cap_tab[D.rank]) n = D.out_cap_tab[D.rank];
   deliver_span(D, D.out_tab[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
 }
+// ---- swim_xchg_*: device-driven exchange through peer-mapped mailboxes (swim_device.h) ----------------------------
+__device__ __forceinline__ uint32_t* mb_hdr(DevRef D, uint8_t* base, uint32_t parity, uint32_t src) {
+  return (uint32_t*)(base + ((size_t)parity * D.n_shards + src) * 64);
+}
+__device__ __forceinline__ uint4* mb_rec(DevRef D, uint8_t* base, uint32_t parity, uint32_t src) {
+  return (uint4*)(base + (size_t)2 * D.n_shards * 64) + ((size_t)parity * D.n_shards + src) * D.mail_cap;
+}
+// my segment for shard blockIdx.y goes into my area of ITS mailbox (stores over xGMI / through the shared L2)
+__global__ void __launch_bounds__(SW_BLOCK) k_xchg_copy(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t dst = blockIdx.y;
+  if (dst == D.rank) return;
+  uint32_t n = D.out_cnt[dst]; n = n < D.out_cap_tab[dst] ? n : D.out_cap_tab[dst]; n = n < D.mail_cap ? n : D.mail_cap;
+  const uint4* src = D.out_tab[dst];
+  uint4* to = mb_rec(D, D.mb_tab[dst], *D.tick & 1u, D.rank);
+  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) to[e] = src[e];
+}
+// ...then count + activity word, and the flag (release, system scope): one thread per destination
+__global__ void k_xchg_signal(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t dst = threadIdx.x, t = *D.tick;
+  if (dst >= D.n_shards || dst == D.rank) return;
+  uint32_t any = *D.act;
+  for (uint32_t sh = 0; sh < D.n_shards; sh++) any |= D.out_cnt[sh];
+  uint32_t n = D.out_cnt[dst];
+  if (n > D.out_cap_tab[dst] || n > D.mail_cap) { atomicOr(D.err, SW_ERR_EDGE_OVF); n = n < D.mail_cap ? (n < D.out_cap_tab[dst] ? n : D.out_cap_tab[dst]) : D.mail_cap; }
+  uint32_t* h = mb_hdr(D, D.mb_tab[dst], t & 1u, D.rank);
+  h[1] = n; h[2] = any != 0;
+  __threadfence_system();
+  __hip_atomic_store(&h[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait for the flags of my sources (acquire); their counts; the population's activity word for the next tick
+__global__ void k_xchg_wait(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  __shared__ uint32_t s_any;
+  const uint32_t src = threadIdx.x, t = *D.tick;
+  if (threadIdx.x == 0) { uint32_t a = *D.act; for (uint32_t sh = 0; sh < D.n_shards; sh++) a |= D.out_cnt[sh]; s_any = a != 0; }
+  __syncthreads();
+  if (src < D.n_shards && src != D.rank) {
+    uint32_t* h = mb_hdr(D, D.mb_tab[D.rank], t & 1u, src);
+    const unsigned long long t0 = wall_clock64(), limit = (unsigned long long)D.xchg_timeout_ms * 100000ull;   // 100 MHz
+    uint32_t n = 0; bool ok = false;
+    if (!(*D.err & SW_ERR_XCHG_TIMEOUT))            // after one time-out the run is void anyway: do not wait again
+      for (;;) {
+        if (__hip_atomic_load(&h[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == t + 1) { ok = true; break; }
+        if (wall_clock64() - t0 > limit) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    if (ok) { n = h[1]; if (h[2]) atomicOr(&s_any, 1u); } else atomicOr(D.err, SW_ERR_XCHG_TIMEOUT);
+    D.xin_cnt[src] = n < D.mail_cap ? n : D.mail_cap;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { D.xin_cnt[D.rank] = 0; *D.peer_act = s_any; }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_deliver_mail(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t src = blockIdx.y;
+  if (src == D.rank) return;
+  deliver_span(D, mb_rec(D, D.mb_tab[D.rank], *D.tick & 1u, src), D.xin_cnt[src], blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
+}
 // records handed over by other shards (swim_inbound)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restrict__ Dp, const uint4* edges, uint32_t n) {
   SW_DEV_BIND
@@ -1167,13 +1220,14 @@ struct NodeCtx {
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
-  uint32_t vnum = NONE, vdl = NONE - 1;             // explicit views held / earliest suspicion deadline: fetched on first use
-  bool vnum_dirty = false, vdl_dirty = false;
+  uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
+  __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
   uint4 h0;
   __device__ NodeCtx(DevRef d, BlockStats& s) : D(d), S(s) {}
 
-  __device__ void load() {
-    h0 = D.hdr[l];
+  __device__ void load() { load(D.hdr[l]); }
+  __device__ void load(uint4 h) {
+    h0 = h;
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
@@ -1183,17 +1237,18 @@ struct NodeCtx {
   __device__ void store() {
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
-    if (vnum_dirty) D.vnum[l] = vnum;
-    if (vdl_dirty) D.vdl[l] = vdl;
+    if (vm_dirty) D.vmeta[l] = vm;
   }
 
   // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
   __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t seq, bool named,
                              uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
     uint32_t n = len;
-    if (named)
-      for (uint32_t j = 0; j < n; j++)
-        if (qb[(size_t)j * NL].x == subject) { qb[(size_t)j * NL] = qb[(size_t)(n - 1) * NL]; n--; break; }
+    if (named) {                                   // at most one entry per subject: no early exit, so that the loads overlap
+      uint32_t hit = NONE;
+      for (uint32_t j = 0; j < n; j++) hit = qb[(size_t)j * NL].x == subject ? j : hit;
+      if (hit != NONE) { if (hit != n - 1) qb[(size_t)hit * NL] = qb[(size_t)(n - 1) * NL]; n--; }
+    }
     uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq));
     if (n == cap) {
       uint32_t w = NONE, wmeta = e.w;
@@ -1227,26 +1282,33 @@ struct NodeCtx {
   // (its view of itself always fits): the caller ignores the rumour, counted in view_drops.
   __device__ bool make(View& v, uint32_t x) {
     if (v.slot != NONE) return true;
-    if (vnum == NONE) vnum = D.vnum[l];
+    need_vm();
     if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
-    if (vnum >= D.view_cap + (x == o ? 1u : 0u)) {
+    if (vm.x >= D.view_cap + (x == o ? 1u : 0u)) {
       // Full.  memberlist's resetNodes forgets a node dead for longer than GossipToTheDeadTime; so does a full table,
       // one node at a time: the longest-settled Dead/Left view (ties: lowest id; never the node's view of itself)
       // makes room and the observer falls back to the base row for that subject.  Nothing that old: drop.
-      uint32_t vs = NONE, vsince = 0, vsubj = 0; const uint32_t now = now_ms(D, t);
+      const uint32_t now = now_ms(D, t);
+      if (now < vm.w) { S.add(ST_VIEW_DROPS); return false; }          // nothing can be that old yet: no need to look
+      uint32_t vs = NONE, vsince = 0, vsubj = 0, ev1 = NONE, ev2 = NONE;   // the two earliest evictable times
       for (uint32_t sl = 0; sl < D.VT; sl++) {
         const uint4 c = D.vt[(size_t)sl * NL + l];
-        if (c.x == VT_EMPTY || c.x == o || SW_KST(c.y) < SWIM_STATE_DEAD || !(now - c.z > D.gossip_to_dead_ms)) continue;
+        if (c.x == VT_EMPTY || c.x == o || SW_KST(c.y) < SWIM_STATE_DEAD) continue;
+        const uint32_t ev = c.z + D.gossip_to_dead_ms + 1;
+        if (ev < ev1) { ev2 = ev1; ev1 = ev; } else if (ev < ev2) ev2 = ev;
+        if (!(now - c.z > D.gossip_to_dead_ms)) continue;
         if (vs == NONE || c.z < vsince || (c.z == vsince && c.x < vsubj)) { vs = sl; vsince = c.z; vsubj = c.x; }
       }
-      if (vs == NONE) { S.add(ST_VIEW_DROPS); return false; }
+      vm_dirty = true;
+      if (vs == NONE) { vm.w = ev1; S.add(ST_VIEW_DROPS); return false; }
+      vm.w = ev2;                                                      // the victim had the earliest one
       const uint32_t wv = D.nw[(size_t)r * D.N + vsubj];
       if (NW_HAS_SLOT(wv)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wv)] = 1;
-      vt_erase(D, l, vs); vnum--; S.add(ST_VIEW_EVICT);
+      vt_erase(D, l, vs); vm.x--; S.add(ST_VIEW_EVICT);
       uint4 dummy; vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], dummy, v.free_slot);   // the layout changed
-      if (v.free_slot == NONE) { vnum_dirty = true; S.add(ST_VIEW_DROPS); return false; }
+      if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
     }
-    vnum++; vnum_dirty = true;
+    vm.x++; vm_dirty = true;
     v.slot = v.free_slot; v.fresh = true;
     if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
       const uint32_t old = atomicOr(&D.nw[(size_t)r * D.N + x], NW_SUBJECT);
@@ -1256,8 +1318,16 @@ struct NodeCtx {
   }
   __device__ __forceinline__ void put(const View& v) { D.vt[(size_t)v.slot * NL + l] = v.e; }
   __device__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
+    const uint32_t old = v.fresh ? (uint32_t)SWIM_STATE_ALIVE : SW_KST(v.e.y);     // (a fresh view comes from the base row: never Suspect)
+    v.fresh = false;
     v.e.y = SW_KEY(inc, st);
     if (touch_since) v.e.z = now_ms(D, t);
+    if ((old == SWIM_STATE_SUSPECT) != (st == SWIM_STATE_SUSPECT)) {
+      need_vm(); vm_dirty = true;
+      if (st == SWIM_STATE_SUSPECT) vm.y++;
+      else if (--vm.y == 0) vm.z = NONE;                               // no timer left: the bound is exact again
+    }
+    if (st >= SWIM_STATE_DEAD) { need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
     if (NW_HAS_SLOT(v.w)) {
       const size_t sidx = (size_t)r * D.S + NW_SLOT(v.w);
       if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
@@ -1266,8 +1336,8 @@ struct NodeCtx {
   }
   __device__ void arm_deadline(const View& v) {           // a suspicion timer was (re)armed: keep the gates' bounds
     const uint32_t dl = v.e.z + sel8(D.susp_timeout, vw_nconf(v.e.w));
-    if (vdl == NONE - 1) vdl = D.vdl[l];
-    if (dl < vdl) { vdl = dl; vdl_dirty = true; if (dl < D.dl_blk[l / SW_BLOCK]) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
+    need_vm();
+    if (dl < vm.z) { vm.z = dl; vm_dirty = true; if (dl < D.dl_blk[l / SW_BLOCK]) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
   }
   __device__ void refute(uint32_t accused) {
     uint32_t inc = self_inc + 1;
@@ -1443,17 +1513,20 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ 
     // the whole 64-byte line (count + first five messages) in one go, parked in the lane's LDS column
     // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
     // stay cache resident instead of pulling in the node's 64-byte message line)
+    // Something reached this block: count, message line and header of every lane are fetched together (one round
+    // trip instead of three dependent ones; the lines of lanes that got nothing are wasted bandwidth, not latency).
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
     uint32_t cnt = D.in_cnt[l];
+    s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
+    const uint4 hdr0 = D.hdr[l];
     if (cnt) {
-      s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
       D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
       const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
       NodeCtx n(D, S);
       n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
-      n.load();
+      n.load(hdr0);
       bool have_last = false; uint64_t lhi = 0, llo = 0;
       for (;;) {
         bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
@@ -1596,8 +1669,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     *D.tick = t + 1;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
-    for (uint32_t j = 0; j < SW_PP_LISTS; j++) D.pp_cnt[((t & 1u) * SW_PP_LISTS + j) * 16] = 0;   // answered
   }
+  if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
 __global__ void k_census_commit(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
@@ -1627,7 +1700,7 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp) {
   D.hdr[l] = make_uint4(1, 0, 0, (D.flags & SWIM_F_SERF_EVENTS) ? 1u : 0u);   // serf.Create: eventClock.Increment()
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.in_cnt[l] = 0; D.vnum[l] = 0; D.vdl[l] = NONE;
+  D.in_cnt[l] = 0; D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
@@ -1697,7 +1770,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
         D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.in_cnt[l] = 0;
         // a node that comes back resumes its old views, whose suspicion timers may be long overdue: its bound
         // counts again in the block's gate
-        const uint32_t d = D.vdl[l];
+        const uint32_t d = D.vmeta[l].z;
         if (d != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], d);
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
@@ -1814,7 +1887,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
   uint64_t d = 0;
   if (l < NL) {
     const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
-    uint32_t left = D.vnum[l];
+    uint32_t left = D.vmeta[l].x;
     for (uint32_t sl = 0; sl < D.VT && left; sl++) {          // explicit views
       const uint4 a = D.vt[(size_t)sl * NL + l];
       if (a.x == VT_EMPTY) continue;
@@ -1894,7 +1967,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
   uint32_t left = 0, r = 0;
   if (l < NL) {
     r = (uint32_t)(l / D.nloc);
-    if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = D.vnum[l];
+    if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = D.vmeta[l].x;
   }
   for (uint32_t sl = 0; sl < D.VT; sl++) {
     if (!__any(left != 0)) break;
@@ -1934,11 +2007,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
   SW_DEV_BIND
   const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l >= NL) return;
-  uint32_t n = D.vnum[l];
-  if (!n) return;
-  const uint32_t r = (uint32_t)(l / D.nloc), m = D.VT - 1;
+  uint4 vm = D.vmeta[l];
+  if (!vm.x) return;
+  const uint32_t r = (uint32_t)(l / D.nloc);
   const uint32_t acting = D.acting[r];
-  uint32_t freed = 0, folded_own = 0;
+  uint32_t freed = 0;
   for (uint32_t sl = 0; sl < D.VT; ) {
     const uint4 a = D.vt[(size_t)sl * NL + l];
     bool fold = false;
@@ -1951,18 +2024,18 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
         const uint32_t w = D.nw[g], wn = (w & ~(NW_SUBJECT | NW_BASEMOD)) | (k != SW_BASE_KEY ? NW_BASEMOD : 0u);
         if (w != wn) { atomicAnd(&D.nw[g], ~NW_SUBJECT); if (k != SW_BASE_KEY) atomicOr(&D.nw[g], NW_BASEMOD); else atomicAnd(&D.nw[g], ~NW_BASEMOD); }
         if (NW_HAS_SLOT(w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(w)] = 1;
-        if (a.x == D.i0 + (uint32_t)(l % D.nloc)) folded_own++;
       }
     }
     if (!fold) { sl++; continue; }
+    // (the acting observers agree on a settled view; a node that is not running may still hold a suspicion)
+    if (SW_KST(a.y) == SWIM_STATE_SUSPECT && --vm.y == 0) vm.z = NONE;
     vt_erase(D, l, sl);                                  // an entry may move into slot sl: it is looked at again
-    n--; freed++;
+    vm.x--; freed++;
   }
   if (freed) {
-    D.vnum[l] = n; *D.fold_any = 1;
+    D.vmeta[l] = vm; *D.fold_any = 1;
     atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
   }
-  (void)folded_own;
 }
 // stats: a folded subject is counted once, by the shard that owns its id (its own lane need not hold a view)
 __global__ void __launch_bounds__(SW_BLOCK) k_fold_count(const SwDev* __restrict__ Dp) {

@@ -168,6 +168,23 @@ class LocalExchange:
             s.sync()
 
 
+class LibraryExchange:
+    """The library's own device-driven exchange (swim_xchg_*: peer-mapped mailboxes, no host round trip, no collective).
+    `gather` turns this process's handle(s) into the list of all shards' handles, indexed by rank — identity when every
+    shard lives here, an all-gather (torch.distributed.all_gather_object, a pipe, files) when there is one per process."""
+
+    def __init__(self, gather=None):
+        self.gather = gather
+        self.connected = False
+
+    def connect(self, sims: Sequence[Sim]):
+        mine = {s.cfg.shard_rank: s.xchg_export() for s in sims}
+        handles = self.gather(mine) if self.gather else [mine[r] for r in range(len(sims))]
+        for s in sims:
+            s.xchg_connect(handles)
+        self.connected = True
+
+
 class ShardedSim:
     """Drive one or more shards of the same population in lock step."""
 
@@ -178,6 +195,12 @@ class ShardedSim:
 
     def step(self, n_ticks: int = 1):
         if n_ticks <= 0:
+            return
+        if isinstance(self.exchange, LibraryExchange):
+            if not self.exchange.connected:
+                self.exchange.connect(self.sims)
+            for s in self.sims:                # asynchronous on the product library: the shards' streams meet on the device
+                s.xchg_step(n_ticks)
             return
         for s in self.sims:
             s.tick_begin()

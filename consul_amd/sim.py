@@ -150,6 +150,22 @@ class Sim:
     def tick_end_begin(self):
         self._ck("swim_tick_end_begin", self._l.swim_tick_end_begin(self._h))
 
+    # -- device-driven exchange (swim_xchg_*) ----------------------------------------------------
+    def xchg_export(self) -> bytes:
+        h = abi.XchgHandle()
+        self._ck("swim_xchg_export", self._l.swim_xchg_export(self._h, C.byref(h)))
+        return bytes(h.bytes)
+
+    def xchg_connect(self, handles: Sequence[bytes]):
+        """`handles[rank]` = xchg_export() of every shard of the population (the own entry is ignored)."""
+        arr = (abi.XchgHandle * len(handles))()
+        for i, b in enumerate(handles):
+            C.memmove(arr[i].bytes, b, len(b))
+        self._ck("swim_xchg_connect", self._l.swim_xchg_connect(self._h, arr))
+
+    def xchg_step(self, n_ticks: int = 1):
+        self._ck("swim_xchg_step", self._l.swim_xchg_step(self._h, n_ticks))
+
     # -- stimulus -----------------------------------------------------------------------------
     def kill(self, replica: int, ids: Iterable[int]):
         a, p, n = _ids(ids)

@@ -291,6 +291,25 @@ int swim_tick_end_begin(swim_sim* sim);
 int swim_peer_activity(swim_sim* sim, int active);
 int swim_activity(swim_sim* sim, int* active);
 
+/* ---- device-driven exchange between the shards of one population (peer-mapped mailboxes over xGMI) -------
+ * The split tick above leaves the exchange to the caller (consul_amd/dist.py uses RCCL).  This is the library's own: every
+ * shard owns a mailbox in its HBM (one area per source shard, double buffered by tick parity), exports it as an IPC handle,
+ * maps everybody else's, and from then on a tick is: begin -> copy my per-destination segments into the destinations'
+ * mailboxes (stores over xGMI, or through the shared L2 when two shards share a device) -> release one flag per destination
+ * -> wait for the flags of my sources -> deliver -> end.  No host round trip, no collective; counts and the activity word
+ * travel in the mailbox header.  One shard per process (or several handles in one process); the handles are plain bytes
+ * and can be passed over any channel (a pipe, a file, an all-gather).  The oracle implements the same calls on host memory
+ * for shards that live in ONE process (its handle is a pointer), so the CPU suite covers the protocol. */
+#define SWIM_XCHG_HANDLE_BYTES 96
+typedef struct swim_xchg_handle { uint8_t bytes[SWIM_XCHG_HANDLE_BYTES]; } swim_xchg_handle;
+int swim_xchg_export(swim_sim* sim, swim_xchg_handle* out);
+/* all[n_shards], indexed by shard rank (the own entry is ignored) */
+int swim_xchg_connect(swim_sim* sim, const swim_xchg_handle* all);
+/* swim_step for a connected shard: n_ticks whole ticks including the exchange.  Asynchronous on the product library
+ * (swim_sync waits and reports a peer that did not show up within the time-out as SWIM_ESTATE).  Every shard of the
+ * population must make the same calls. */
+int swim_xchg_step(swim_sim* sim, uint32_t n_ticks);
+
 /* ---- stimulus (fault injection is native; the reference kills nodes with Shutdown(),
  *      agent/consul/server_test.go:725) ----------------------------------------------------- */
 int swim_inject_kill(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);

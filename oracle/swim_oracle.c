@@ -297,6 +297,8 @@ struct swim_sim {
   swim_event* events; size_t n_events, cap_events;
   swim_stats_t st;
   uint32_t loss_q32;
+  /* swim_xchg_*: the other shards of the population (same process) and ticks one of them already ran on our behalf */
+  struct swim_sim** xpeers; uint32_t xcredit;
   char err[256];
 };
 
@@ -1156,7 +1158,7 @@ int swim_destroy(swim_sim* s) {
   free(s->inbox_slab);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
-  free(s->attached); free(s->captured.v); free(s->cap_src);
+  free(s->attached); free(s->captured.v); free(s->cap_src); free(s->xpeers);
   free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->carry[0].v); free(s->carry[1].v); free(s->events); free(s);
@@ -1220,6 +1222,40 @@ int swim_tick_end(swim_sim* s) {
   phase_deliver_resolve(s); phase_bookkeep(s);
   s->st.ticks++; if ((s->tick + 1) % s->d.gossip_period == 0) s->st.gossip_rounds++;
   s->tick++; s->in_tick = 0;
+  return SWIM_OK;
+}
+/* swim_xchg_* on host memory, for shards that live in one process and are driven from one thread: the handle is the
+ * shard's address; the first shard asked to run tick t runs it for the whole population (begin everywhere, hand the
+ * per-destination segments over, end everywhere) and leaves the others a credit, so that every shard can make the same
+ * calls as on the product library, in any order. */
+int swim_xchg_export(swim_sim* s, swim_xchg_handle* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  memset(out, 0, sizeof *out); memcpy(out->bytes, &s, sizeof s);
+  return SWIM_OK;
+}
+int swim_xchg_connect(swim_sim* s, const swim_xchg_handle* all) {
+  if (!s || !all) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE;
+  free(s->xpeers); s->xpeers = (swim_sim**)calloc(s->cfg.n_shards, sizeof(swim_sim*)); if (!s->xpeers) return SWIM_ENOMEM;
+  for (uint32_t i = 0; i < s->cfg.n_shards; i++) {
+    swim_sim* p; memcpy(&p, all[i].bytes, sizeof p);
+    if (i == s->cfg.shard_rank) p = s;
+    if (!p || p->cfg.n_shards != s->cfg.n_shards || p->cfg.shard_rank != i || p->N != s->N || p->R != s->R) { free(s->xpeers); s->xpeers = NULL; return SWIM_EINVAL; }
+    s->xpeers[i] = p;
+  }
+  return SWIM_OK;
+}
+int swim_xchg_step(swim_sim* s, uint32_t n) {
+  if (!s) return SWIM_EINVAL; if (!s->xpeers || s->in_tick) return SWIM_ESTATE;
+  uint32_t W = s->cfg.n_shards; int rc;
+  for (uint32_t t = 0; t < n; t++) {
+    if (s->xcredit) { s->xcredit--; continue; }
+    for (uint32_t i = 0; i < W; i++) if ((rc = swim_tick_begin(s->xpeers[i]))) return rc;
+    for (uint32_t i = 0; i < W; i++) for (uint32_t j = 0; j < W; j++) if (i != j) {
+      edgevec* o = &s->xpeers[i]->out[j];
+      if (o->n && (rc = swim_inbound(s->xpeers[j], o->v, o->n))) return rc;
+    }
+    for (uint32_t i = 0; i < W; i++) { if ((rc = swim_tick_end(s->xpeers[i]))) return rc; if (s->xpeers[i] != s) s->xpeers[i]->xcredit++; }
+  }
   return SWIM_OK;
 }
 int swim_tick_end_begin(swim_sim* s) { int rc = swim_tick_end(s); return rc ? rc : swim_tick_begin(s); }

@@ -11,7 +11,7 @@ import sys
 import pytest
 
 from consul_amd import abi
-from consul_amd.dist import LocalExchange, ShardedSim
+from consul_amd.dist import LibraryExchange, LocalExchange, ShardedSim
 from consul_amd.sim import Sim, preset
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,6 +33,24 @@ def test_in_process_shards_match_unsharded(oracle, n_shards):
     for k in ("msgs_sent", "refutes", "probe_failures", "msgs_applied", "packets_sent", "confirmations"):
         assert a[k] == b[k], k
     assert a["edges_remote"] > 0 and b["edges_remote"] == 0
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_library_exchange_calls_on_the_oracle(oracle, n_shards):
+    """swim_xchg_export / connect / step (the product library's device-driven exchange) as the oracle implements them for
+    shards of one process: same calls, same result as the unsharded run — including fold ticks."""
+    kw = dict(n_nodes=1024, n_replicas=2, seed=9, fold_interval_ms=3000, push_pull_interval_ms=2000, view_cap=64)
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw)) for i in range(n_shards)],
+                    LibraryExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.step_ms(1000); s.kill(0, [5, 700]); s.update(1, [512]); s.step_ms(50000)
+    assert sh.digest() == ref.digest() and sh.stats()["folds"] == ref.stats()["folds"] >= 1
+    lone = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=256, n_shards=2, shard_rank=0))
+    with pytest.raises(Exception):
+        lone.xchg_step(1)                           # not connected
+    with pytest.raises(Exception):
+        sh.sims[0].xchg_connect([lone.xchg_export()] * n_shards)   # a handle of another population
 
 
 def test_split_tick_rejects_out_of_phase_calls(oracle):

@@ -187,7 +187,8 @@ def test_config4_size_fits_one_gpu(hip):
     """524 288 nodes per GPU with room for 4 096 explicit views each (137 GB of view tables) can be created, a 5 %
     partition (26 214 nodes named in one call, mask of > 2^19 bytes) injected and stepped."""
     n = 524288
-    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, view_cap=4096, queue_cap=8, inbox_cap=256, subject_cap=4))
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=1, view_cap=4096, queue_cap=8, inbox_cap=256, subject_cap=4,
+                        push_pull_interval_ms=0))       # (a push-pull would deliver a whole table in one tick: inbox_cap >= view_cap then)
     s.step_ms(1000)
     s.partition(0, sc.partition_mask(n))
     s.step_ms(3000)
@@ -208,3 +209,44 @@ def test_partition_mask_above_a_million_nodes(hip):
     assert s.node_info(0, 399999).alive == 0 and s.node_info(0, 400000).alive == 1
     s.step(4); s.sync()
     s.close()
+
+
+# ---- the library's own device-driven exchange (swim_xchg_*: peer-mapped mailboxes) ------------------------------------
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_library_exchange_in_process(hip, oracle, n_shards):
+    """2 / 4 HIP shards in this process, each on its own stream, meeting on the device through their mailboxes: no host
+    round trip per tick, same state as the unsharded oracle."""
+    from consul_amd.dist import LibraryExchange, ShardedSim
+    import xchg_scenario as xs
+    sh = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **xs.KW)) for i in range(n_shards)],
+                    LibraryExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **xs.KW))
+    xs.run(sh); xs.run(ref)
+    sh.sync()
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in ("folds", "fold_freed", "refutes", "msgs_applied", "suspicion_timeouts", "push_pulls", "probe_failures"):
+        assert a[k] == b[k], k
+    assert a["edges_remote"] > 0 and b["folds"] >= 2
+    sh.close()
+
+
+def test_library_exchange_two_processes_on_one_device(hip, oracle, tmp_path):
+    """World size 2 through the code path an 8-GPU run takes: two processes, both on device 0, mailboxes mapped with
+    hipIpc, flags released/acquired at system scope.  Digests add up to the unsharded oracle's."""
+    import subprocess
+    import xchg_scenario as xs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "xchg_worker.py"), str(r), "2", str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    res = [open(os.path.join(tmp_path, f"r{r}")).read().split() for r in range(2)]
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **xs.KW))
+    xs.run(ref)
+    st = ref.stats()
+    assert (int(res[0][0]) + int(res[1][0])) & 0xFFFFFFFFFFFFFFFF == ref.digest()
+    assert int(res[0][1]) + int(res[1][1]) > 0                                   # records crossed between the processes
+    assert int(res[0][2]) + int(res[1][2]) == st["folds"] and int(res[0][3]) + int(res[1][3]) == st["refutes"]
+    assert int(res[0][4]) + int(res[1][4]) == sum(st["msgs_applied"])
