@@ -285,7 +285,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const bool serf = (cfg->flags & SWIM_F_SERF_EVENTS) != 0;
   D.N = cfg->n_nodes; D.R = cfg->n_replicas; D.nloc = D.N / cfg->n_shards; D.i0 = cfg->shard_rank * D.nloc;
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
-  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C - SW_INBOX_FAST : 0;
+  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C : 0;   // the overflow row has room for ALL C messages: a big inbox is sorted in it (k_resolve)
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
   D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
   D.quantum_ms = d.quantum_ms; D.k_gossip = cfg->gossip_nodes; D.k_indirect = cfg->indirect_checks;
@@ -334,7 +334,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   const uint32_t gossip_lanes = D.fast_blocks ? cdiv(cdiv(D.nloc, D.CH), D.G) * D.CH : (cdiv(nchunks, D.G) + 1) * D.CH;
   const uint32_t probe_lanes = (cdiv(cdiv(nchunks, D.G) + 1, D.P) + 1) * D.G * D.CH;
   BeginPlan& pl = s->plan;
-  pl.nb_expire = (uint32_t)NB;                      // expire: one block per 256-node block, out after one word unless a deadline bound passed
+  pl.nb_expire = cdiv(NB, SW_BLOCK / 64);           // expire: one wave per 256-node block, out after one word unless a deadline bound passed
   pl.nb_pend = 16;
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);

@@ -317,20 +317,25 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
 // =================================================================================================
 __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos);
 // Gate: dl_blk[node block] is a lower bound of the earliest deadline among the block's acting lanes, vmeta[lane].z of
-// the lane's own timers.  One block per 256-node block: out after one word unless the bound has passed; only a lane
-// whose own bound has passed walks its view table.
+// the lane's own timers.  One WAVE per 256-node block (four per workgroup, no barrier): out after one word unless the
+// bound has passed; only a lane whose own bound has passed walks its view table.
 __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
   (void)nb;
+  const uint32_t nbk = b * (SW_BLOCK / 64) + threadIdx.x / 64, lane = sw_lane();
+  if (nbk >= D.NB) return;
   const uint32_t t = *D.tick, now = now_ms(D, t);
-  if (now < D.dl_blk[b]) return;
-  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)b * SW_BLOCK + threadIdx.x;
-  uint32_t fired = 0, d = NONE;
-  if (l < NL) {
+  if (now < D.dl_blk[nbk]) return;
+  const size_t NL = (size_t)D.R * D.nloc;
+  uint32_t fired = 0, m = NONE;
+  for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
+    const size_t l = (size_t)nbk * SW_BLOCK + part * 64 + lane;
+    if (l >= NL) continue;
     const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
     const uint4 vm = D.vmeta[l];
-    d = vm.z;
-    if (D.nw[(size_t)r * D.N + o] & NW_INERT) d = NONE;              // its timers rest; a revive lowers dl_blk again
-    else if (now >= d) {
+    uint32_t d = vm.z;
+    if (d == NONE) continue;
+    if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;              // its timers rest; a revive lowers dl_blk again
+    if (now >= d) {
       uint32_t next = NONE, left = vm.y;                             // Suspect views still to be found
       for (uint32_t sl = 0; sl < D.VT && left; sl++) {
         const uint4 e = D.vt[(size_t)sl * NL + l];
@@ -346,16 +351,13 @@ __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
       }
       d = next; D.vmeta[l].z = d;
     }
+    m = d < m ? d : m;
   }
-  uint32_t m = d;
   for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
-  __shared__ uint32_t s_min[SW_BLOCK / 64];
-  if (sw_lane() == 0) s_min[threadIdx.x / 64] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t v = s_min[0]; for (uint32_t j = 1; j < SW_BLOCK / 64; j++) v = s_min[j] < v ? s_min[j] : v; D.dl_blk[b] = v; }
+  if (lane == 0) D.dl_blk[nbk] = m;
   if (__any(fired != 0)) {
     for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
-    if (sw_lane() == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+    if (lane == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
   }
 }
 
@@ -1220,6 +1222,7 @@ struct NodeCtx {
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
+  uint32_t dl_blk0 = 0;                               // the block's deadline bound as the kernel found it (0 = unknown: always lower it)
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
   uint4 h0;
@@ -1337,7 +1340,7 @@ struct NodeCtx {
   __device__ void arm_deadline(const View& v) {           // a suspicion timer was (re)armed: keep the gates' bounds
     const uint32_t dl = v.e.z + sel8(D.susp_timeout, vw_nconf(v.e.w));
     need_vm();
-    if (dl < vm.z) { vm.z = dl; vm_dirty = true; if (dl < D.dl_blk[l / SW_BLOCK]) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
+    if (dl < vm.z) { vm.z = dl; vm_dirty = true; if (dl < dl_blk0 || !dl_blk0) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
   }
   __device__ void refute(uint32_t accused) {
     uint32_t inc = self_inc + 1;
@@ -1493,6 +1496,37 @@ __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
   lo = ((uint64_t)e.z << 32) | (e.w & 0x3FFFFFFFu);
 }
 
+// A big inbox (a push-pull delivers a whole table in one tick) is sorted once instead of being searched for its minimum
+// per message: in-place heapsort of the 12-byte records {subject, incarnation, meta} by the canonical key, ascending.
+__device__ __forceinline__ bool rec_less(const uint32_t* a, uint32_t i, uint32_t j) {
+  uint64_t hi, lo, hj, lj;
+  edge_key(make_uint4(0, a[3 * i], a[3 * i + 1], a[3 * i + 2]), hi, lo);
+  edge_key(make_uint4(0, a[3 * j], a[3 * j + 1], a[3 * j + 2]), hj, lj);
+  return hi < hj || (hi == hj && lo < lj);
+}
+__device__ __forceinline__ void rec_swap(uint32_t* a, uint32_t i, uint32_t j) {
+  for (int w = 0; w < 3; w++) { uint32_t t = a[3 * i + w]; a[3 * i + w] = a[3 * j + w]; a[3 * j + w] = t; }
+}
+__device__ __attribute__((noinline)) void inbox_heapsort(uint32_t* a, uint32_t n) {
+  for (uint32_t start = n / 2; start-- > 0; )                      // heapify
+    for (uint32_t root = start;;) {
+      uint32_t c = 2 * root + 1; if (c >= n) break;
+      if (c + 1 < n && rec_less(a, c, c + 1)) c++;
+      if (!rec_less(a, root, c)) break;
+      rec_swap(a, root, c); root = c;
+    }
+  for (uint32_t end = n; end-- > 1; ) {
+    rec_swap(a, 0, end);
+    for (uint32_t root = 0;;) {
+      uint32_t c = 2 * root + 1; if (c >= end) break;
+      if (c + 1 < end && rec_less(a, c, c + 1)) c++;
+      if (!rec_less(a, root, c)) break;
+      rec_swap(a, root, c); root = c;
+    }
+  }
+}
+#define SW_INBOX_SORT_MIN 12      /* from this many messages on the inbox is sorted rather than searched */
+
 __global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
@@ -1503,6 +1537,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ 
     if (!D.in_any[blockIdx.x]) return;
   }
   if (threadIdx.x == 0) s_carry = 0;
+  const uint32_t dl_blk0 = D.dl_blk[blockIdx.x];
   BlockStats S; S.init(lds_stats);
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
   bool q_set = false, q_clr = false;
@@ -1518,7 +1553,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ 
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
     uint32_t cnt = D.in_cnt[l];
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-    const uint4 hdr0 = D.hdr[l];
+    const uint4 hdr0 = D.hdr[l], vm0 = D.vmeta[l];
     if (cnt) {
       D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
@@ -1526,10 +1561,24 @@ __global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ 
       const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
       NodeCtx n(D, S);
       n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
-      n.load(hdr0);
+      n.load(hdr0); n.vm = vm0; n.vm_have = true; n.dl_blk0 = dl_blk0;
       bool have_last = false; uint64_t lhi = 0, llo = 0;
+      const bool sorted = cnt >= SW_INBOX_SORT_MIN;
+      uint32_t next_j = 0;
+      if (sorted) {                                  // the five messages of the line join the row (it has room for all C), then one sort
+        uint32_t* row = D.inbox2 + l * D.C2 * 3;
+        for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
+        inbox_heapsort(row, cnt);
+      }
       for (;;) {
         bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
+        if (sorted) {
+          while (next_j < cnt && !have) {            // ascending; a duplicate (same key as the one before) is applied once
+            const uint32_t* m = row2 + next_j * 3; next_j++;
+            best = make_uint4(0, m[0], m[1], m[2]); edge_key(best, bhi, blo);
+            have = !(have_last && bhi == lhi && blo == llo);
+          }
+        } else
         for (uint32_t j = 0; j < cnt; j++) {
           uint4 e;                                   // {-, subject, inc, meta}
           if (j < SW_INBOX_FAST) { uint32_t w = 1 + 3 * j; e = make_uint4(0, IN_WORD(w), IN_WORD(w + 1), IN_WORD(w + 2)); }

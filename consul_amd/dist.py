@@ -199,8 +199,12 @@ class ShardedSim:
         if isinstance(self.exchange, LibraryExchange):
             if not self.exchange.connected:
                 self.exchange.connect(self.sims)
-            for s in self.sims:                # asynchronous on the product library: the shards' streams meet on the device
-                s.xchg_step(n_ticks)
+            if len(self.sims) == 1:            # one shard per process: the whole run goes down in one call
+                self.sims[0].xchg_step(n_ticks)
+            else:                              # several shards in this process (tests): keep their streams within a tick of
+                for _ in range(n_ticks):       # each other — a shard's wait kernel spins until its sources have signalled,
+                    for s in self.sims:        # and the runtime multiplexes streams onto a handful of hardware queues
+                        s.xchg_step(1)
             return
         for s in self.sims:
             s.tick_begin()
