@@ -30,7 +30,7 @@ u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
 
 class Config(C.Structure):
     _fields_ = [(n, u32) for n in (
-        "abi_version", "n_nodes", "n_replicas",
+        "abi_version", "n_nodes", "n_replicas", "n_initial",
         "gossip_nodes", "gossip_interval_ms", "probe_interval_ms", "probe_timeout_ms",
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
@@ -92,7 +92,7 @@ class Stats(C.Structure):
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
-                ("view_drops", u64), ("view_evictions", u64), ("folds", u64), ("fold_freed", u64)]
+                ("view_drops", u64), ("view_evictions", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64)]
 
 
 class XchgHandle(C.Structure):
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_update": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_inject_join": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u32]),
     "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
     "swim_set_loss": (C.c_int, [SimP, u32]),
     "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(u32)]),

@@ -22,7 +22,7 @@ enum {
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
-  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED,
+  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED, ST_JOINS, ST_JOIN_FAIL,
   ST_COUNT
 };
 
@@ -30,7 +30,7 @@ enum {
 // copy (block id % copies): same-address device atomics serialise at ~12 ns apiece, which at a few
 // thousand blocks per launch would cost more than the kernel itself.  The host sums the copies.
 #define SW_STAT_COPIES 256
-#define SW_STAT_STRIDE 48
+#define SW_STAT_STRIDE 56
 
 // sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync)
 #define SW_ERR_EDGE_OVF 0x1u
@@ -56,13 +56,16 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 //              observer that creates one, cleared when the subject is folded into the base row); clear =
 //              every local observer holds the base row's view, no table needs to be looked at
 //   bit 21     the base row's view of it is not alive@1 (read bk[])
-//   bits 20-0  watch slot + 1 (census / trace), 0 = not watched
+//   bit 20     alone: started by swim_inject_join, its join push-pull has not gone through (yet) — it knows nobody, so
+//              the simulator does not probe / gossip on its behalf; peers that hear of it treat it like anybody
+//   bits 19-0  watch slot + 1 (census / trace), 0 = not watched
 #define NW_DEAD 0x80000000u
 #define NW_ATTACHED 0x00800000u
 #define NW_SUBJECT 0x00400000u
 #define NW_BASEMOD 0x00200000u
-#define NW_INERT (NW_DEAD | NW_ATTACHED)           /* the simulator takes no action on behalf of this node */
-#define NW_SLOT_MASK 0x1FFFFFu
+#define NW_ALONE 0x00100000u
+#define NW_INERT (NW_DEAD | NW_ATTACHED | NW_ALONE) /* the simulator takes no action on behalf of this node */
+#define NW_SLOT_MASK 0xFFFFFu
 #define NW_PART(w) (((w) >> 24) & 0x7Fu)
 #define NW_SLOT(w) (((w) & NW_SLOT_MASK) - 1u)     /* 0xFFFFFFFF when none */
 #define NW_HAS_SLOT(w) (((w) & NW_SLOT_MASK) != 0u)
@@ -129,6 +132,16 @@ struct SwDev {
   uint32_t* dl_blk;      // [NL/256] lower bound of the block's vdl over the lanes the simulator acts for
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
   uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)
+  // dynamic membership (n_initial < n_nodes): estNumNodes() of lane l = base_known[r] + vnk[l] feeds retransmitLimit and
+  // suspicionTimeout like upstream; tables evaluated on the host with Go's float64 semantics
+  uint32_t dyn, suspicion_mult, suspicion_max_mult, probe_interval_ms, retransmit_mult, susp_k_cfg;
+  uint32_t rl_steps[12];  // retransmitLimit(n) = retransmit_mult * #{j : n >= rl_steps[j]}   (ceil(log10(n+1)) as a step function)
+  double susp_frac[8];    // ln(c+1)/ln(k+1) for c confirmations of k = susp_k_cfg
+  uint32_t* scale_milli;  // [N+1] int(max(1, log10(max(1, n))) * 1000)
+  uint32_t* base_known;   // [R] nodes the base row has heard of (incarnation > 0)
+  uint32_t* vnk;          // [NL] explicit views of nodes the base row has never heard of
+  uint2* join_list;       // swim_inject_join: {replica*N + node, via} of the nodes started since the last tick (every shard lists all)
+  uint32_t* join_cnt; uint32_t join_cap;
   // fold census: what this shard's acting observers hold (fl_*), what all shards reported (fg_*), per replica*N + id
   uint32_t *fl_cnt, *fl_kmin, *fl_kmax, *fl_bad, *fg_cnt, *fg_kmin, *fg_kmax;
   uint32_t* fold_any;    // [1] something was folded this tick (exception lists need a rebuild)
@@ -201,6 +214,7 @@ struct BeginPlan {
   uint32_t nb_pp;            // per replica: blocks over the push-pull-due node set (0 = push-pull off)
   uint32_t nb_ppreply;       // blocks answering the previous tick's pull requests
   uint32_t nb_carry;         // sharded runs: blocks moving carried broadcasts for other shards into their lists
+  uint32_t nb_join;          // blocks doing the join push-pull of freshly started nodes (0 or 1)
   uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry
 };
 #define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard */

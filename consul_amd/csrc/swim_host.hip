@@ -121,6 +121,7 @@ int validate(const swim_config* c) {
   if (c->flags & SWIM_F_SERF_EVENTS)
     if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
+  if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
   return SWIM_OK;
 }
@@ -317,6 +318,34 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
   DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+  {   // dynamic membership: the scaling laws as tables / constants with Go's float64 semantics
+    const uint32_t ni = cfg->n_initial ? cfg->n_initial : D.N;
+    D.dyn = ni < D.N ? 1u : 0u;
+    D.suspicion_mult = cfg->suspicion_mult; D.suspicion_max_mult = cfg->suspicion_max_timeout_mult;
+    D.probe_interval_ms = cfg->probe_interval_ms; D.retransmit_mult = cfg->retransmit_mult;
+    D.susp_k_cfg = (uint32_t)std::max(0, (int32_t)cfg->suspicion_mult - 2);
+    DALLOC(s, D.base_known, D.R); DALLOC(s, D.join_cnt, 1); D.join_cap = 65536; DALLOC(s, D.join_list, D.join_cap);
+    HIPCK(s, hipMemset(D.join_cnt, 0, 4));
+    for (int j = 0; j < 12; j++) D.rl_steps[j] = 0xFFFFFFFFu;
+    for (int j = 0; j < 8; j++) D.susp_frac[j] = 0.0;
+    if (D.dyn) {
+      DALLOC(s, D.vnk, NL);
+      // ceil(log10(n+1)) as a step function of n: step j+1 is reached at the smallest n with ceil(...) >= j+1 (binary search
+      // over the same float64 expression swim_config_derive uses)
+      auto steps = [](uint32_t n) { return (uint32_t)std::ceil(go_log10((double)n + 1.0)); };
+      for (uint32_t j = 0; j < 12; j++) {
+        if (steps(0x3FFFFFFFu) < j + 1) break;
+        uint32_t lo = 0, hi = 0x3FFFFFFFu;
+        while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (steps(mid) >= j + 1) hi = mid; else lo = mid + 1; }
+        D.rl_steps[j] = lo;
+      }
+      for (uint32_t c = 1; c < 8; c++) D.susp_frac[c] = std::log((double)c + 1.0) / std::log((double)D.susp_k_cfg + 1.0);
+      std::vector<uint32_t> sm((size_t)D.N + 1);
+      for (uint32_t n = 0; n <= D.N; n++) { double sc = std::max(1.0, go_log10(std::max(1.0, (double)n))); sm[n] = (uint32_t)(int64_t)(sc * 1000.0); }
+      DALLOC(s, D.scale_milli, (size_t)D.N + 1);
+      HIPCK(s, hipMemcpy(D.scale_milli, sm.data(), sm.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
   {   // fold accumulators, grouped by the value a fold tick resets them to
     const size_t n = D.fold_period ? NT : 1;
     uint32_t* z; DALLOC(s, z, 5 * n + 16); s->fold_zero = z; s->fold_zero_bytes = (5 * n + 16) * 4;
@@ -343,6 +372,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.roles = D.pp_period ? 0x1F : 0xF;
   const bool piggy = (cfg->flags & SWIM_F_PIGGYBACK) != 0;
   pl.nb_carry = D.n_shards > 1 ? 64 : 0;
+  pl.nb_join = 1;                                   // swim_inject_join also restarts nodes of a fixed population
   if (piggy && D.n_shards > 1) pl.roles |= 0x20;
   D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0);
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
@@ -432,8 +462,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
   HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
-  hipLaunchKernelGGL(k_init_base, dim3(cdiv(NT, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
+  const uint32_t n_initial = cfg->n_initial ? cfg->n_initial : D.N;
+  hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
+  hipLaunchKernelGGL(k_init_base, dim3(cdiv(NT, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
+  if (D.dyn) for (uint32_t r = 0; r < D.R; r++) hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, r);
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
@@ -451,7 +483,7 @@ static void launch_begin(swim_sim* s, bool fold) {
   SwDev& D = s->D; hipStream_t st = s->stream;
   BeginPlan pl = s->plan;
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
-  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + D.R * pl.nb_pp;
+  const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + pl.nb_join + D.R * pl.nb_pp;
   if (fold) {
     const size_t NL = (size_t)D.nloc * D.R, NT = (size_t)D.N * D.R;
     (void)hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st); (void)hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st);
@@ -478,8 +510,8 @@ static void launch_end(swim_sim* s, bool fold) {
                        (const uint4*)s->in_buf, s->in_count);
   }
   if (fold) {
+    hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
-    hipLaunchKernelGGL(k_fold_count, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (D.flags & SWIM_F_PIGGYBACK) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
@@ -773,6 +805,24 @@ extern "C" int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, si
 extern "C" int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_REVIVE, r, ids, n); }
 extern "C" int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_LEAVE, r, ids, n); }
 extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_UPDATE, r, ids, n); }
+extern "C" int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint32_t via) {
+  int rc = check_ids(s, r, ids, n);
+  if (rc) return rc;
+  if (via >= s->D.N) return SWIM_ERANGE;
+  if (!n) return SWIM_OK;
+  if (!s->D.join_cnt) return SWIM_ESTATE;
+  touched(s);
+  const size_t chunk = std::min<size_t>(s->scratch_bytes / 4, s->D.join_cap / 2);
+  for (size_t off = 0; off < n; off += chunk) {
+    const uint32_t c = (uint32_t)std::min(chunk, n - off);
+    HIPCK(s, hipMemcpyAsync(s->d_scratch, ids + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_inject_join, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c, via);
+    HIPCK(s, hipStreamSynchronize(s->stream));
+  }
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
 extern "C" int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
@@ -855,7 +905,7 @@ static void fill_member(swim_member* out, uint32_t x, uint32_t key, uint32_t sin
   memset(out, 0, sizeof *out); out->id = x;
   out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
   out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? (uint8_t)(wpack & 7u) : 0;
-  out->status = status_of(SW_KST(key));
+  out->status = SW_KINC(key) == 0 ? (uint8_t)SWIM_MEMBER_NONE : status_of(SW_KST(key));   // incarnation 0: never heard of it
 }
 extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap)) return SWIM_EINVAL;
@@ -984,7 +1034,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
-  out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
+  out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

@@ -78,6 +78,38 @@ __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint
 __device__ __forceinline__ uint32_t base_key_of(DevRef D, uint32_t r, uint32_t x, uint32_t w) {
   return (w & NW_BASEMOD) ? D.bk[(size_t)r * D.N + x] : SW_BASE_KEY;
 }
+// ---- dynamic membership: estNumNodes() of a lane and the scaling laws that take it (swim_device.h) ----------------
+__device__ __forceinline__ uint32_t est_n(DevRef D, uint32_t r, size_t l) { return D.dyn ? D.base_known[r] + D.vnk[l] : D.N; }
+__device__ __forceinline__ uint32_t retransmit_limit_n(DevRef D, uint32_t n) {
+  if (!D.dyn) return D.retransmit_limit;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 12; j++) c += n >= D.rl_steps[j];
+  return D.retransmit_mult * c;
+}
+__device__ __forceinline__ uint32_t susp_k_n(DevRef D, uint32_t n) { return !D.dyn ? D.susp_k : (n < D.susp_k_cfg + 2 ? 0u : D.susp_k_cfg); }
+// suspicion.go remainingSuspicionTime(c, k, 0, min, max) for a timer that started when the observer knew n nodes:
+// float64 exactly as the host evaluates it (no contraction into fused multiply-adds)
+__device__ uint32_t susp_timeout_n(DevRef D, uint32_t n, uint32_t c) {
+  if (!D.dyn) return sel8(D.susp_timeout, c & 7u);
+  const uint64_t min_ms = (uint64_t)D.suspicion_mult * D.scale_milli[n > D.N ? D.N : n] * D.probe_interval_ms / 1000;
+  const uint64_t max_ms = (uint64_t)D.suspicion_max_mult * min_ms;
+  const uint32_t k = susp_k_n(D, n);
+  if (k < 1 || c >= k) return (uint32_t)min_ms;
+  if (c == 0) return (uint32_t)max_ms;
+  const double frac = c == 1 ? D.susp_frac[1] : c == 2 ? D.susp_frac[2] : D.susp_frac[3];
+  const double max_s = __ddiv_rn((double)max_ms, 1000.0), min_s = __ddiv_rn((double)min_ms, 1000.0);
+  const double raw = __dsub_rn(max_s, __dmul_rn(frac, __dsub_rn(max_s, min_s)));
+  long long t = (long long)floor(__dmul_rn(1000.0, raw));
+  if (t < (long long)min_ms) t = (long long)min_ms;
+  return (uint32_t)t;
+}
+// deadline of the Suspect view in slot `sl` of lane l (entry e): in dynamic mode the timer's n sits in the confirmer record
+__device__ __forceinline__ uint32_t susp_deadline(DevRef D, size_t l, uint32_t sl, uint4 e) {
+  const uint32_t n0 = D.dyn ? D.vc[(size_t)sl * ((size_t)D.R * D.nloc) + l].w : 0;
+  return e.z + susp_timeout_n(D, n0, vw_nconf(e.w));
+}
+
 // backward-shift deletion of slot `i` of lane l's table (owner only)
 __device__ void vt_erase(DevRef D, size_t l, uint32_t i) {
   const size_t NL = (size_t)D.R * D.nloc; const uint32_t m = D.VT - 1;
@@ -298,6 +330,7 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
     if (x == o) continue;
     uint32_t since, key = view_of(D, r, k_local, x, w, &since), st = SW_KST(key);
     if (mode == 0) {
+      if (key < 4u) continue;                        // incarnation 0: never heard of it, not in this node's member list
       if (st == SWIM_STATE_LEFT) continue;
       if (st == SWIM_STATE_DEAD && now - since > D.gossip_to_dead_ms) continue;
     } else {
@@ -341,7 +374,7 @@ __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
         const uint4 e = D.vt[(size_t)sl * NL + l];
         if (e.x == VT_EMPTY || SW_KST(e.y) != SWIM_STATE_SUSPECT) continue;
         left--;
-        const uint32_t dl = e.z + sel8(D.susp_timeout, vw_nconf(e.w));
+        const uint32_t dl = susp_deadline(D, l, sl, e);
         if (now >= dl) {
           // a timer is not a packet: the verdict goes straight into the node's own inbox line
           inbox_place(D, mk_edge(D, r, o, e.x, SW_KINC(e.y), SWIM_MSG_DEAD, o), l, atomicAdd(&D.in_cnt[l], 1u));
@@ -556,9 +589,10 @@ __device__ __forceinline__ bool noop_given_view(DevRef D, uint32_t key, uint32_t
   if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
   if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
     uint32_t nc = vw_nconf(wpack);
-    if (nc >= D.susp_k || vw_conf0(wpack) == e.z) return true;
-    if (nc == 0) return false;
+    if (vw_conf0(wpack) == e.z) return true;
+    if (!D.dyn) { if (nc >= D.susp_k) return true; if (nc == 0) return false; }
     uint4 b = D.vc[vci];
+    if (D.dyn) { if (nc >= susp_k_n(D, b.w)) return true; if (nc == 0) return false; }
     return b.x == e.z || (nc >= 2 && b.y == e.z) || (nc >= 3 && b.z == e.z);
   }
   return false;
@@ -586,7 +620,7 @@ struct MetaQ { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j
 // one GetBroadcasts(overhead, limit) over a queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
 template <typename QV>
-__device__ uint32_t get_broadcasts(DevRef D, QV sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out) {
+__device__ uint32_t get_broadcasts(DevRef D, QV sq, uint32_t n, uint32_t& live, uint32_t overhead, int limit, int& used_out, uint32_t retransmit_limit) {
   uint32_t taken = 0; int used = 0;
   for (;;) {
     int free_b = limit - used - (int)overhead;
@@ -604,7 +638,7 @@ __device__ uint32_t get_broadcasts(DevRef D, QV sq, uint32_t n, uint32_t& live, 
   for (uint32_t j = 0; j < n; j++) {
     if (!((taken >> j) & 1u)) continue;
     uint32_t meta = sq.meta(j);
-    if (m_tr(meta) + 1 >= D.retransmit_limit) live &= ~(1u << j);          // Finished()
+    if (m_tr(meta) + 1 >= retransmit_limit) live &= ~(1u << j);            // Finished()
     else sq.meta(j) = m_pack(m_type(meta), m_tr(meta) + 1, m_seq(meta));
   }
   used_out = used;
@@ -676,13 +710,14 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1;
       live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
       // per peer one GetBroadcasts() (LDS only)
+      const uint32_t rl = retransmit_limit_n(D, est_n(D, r, l));
       uint32_t npk = 0;
       bool ok[KMAX];
       for (uint32_t p = 0; p < found; p++) {
         int used = 0, used2 = 0;
-        uint32_t tm = get_broadcasts(D, LdsQ{sq}, qlen, live_m, 2, (int)D.budget, used), te = 0;
+        uint32_t tm = get_broadcasts(D, LdsQ{sq}, qlen, live_m, 2, (int)D.budget, used, rl), te = 0;
         int avail = (int)D.budget - used;
-        if (serf && avail > 2 + 1) te = get_broadcasts(D, LdsQ{se}, evqlen, live_e, 3, avail, used2);
+        if (serf && avail > 2 + 1) te = get_broadcasts(D, LdsQ{se}, evqlen, live_e, 3, avail, used2, rl);
         if (!tm && !te) break;                       // "if len(msgs) == 0 { return }"
         c_pkt++;
         for (uint32_t m = tm; m; m &= m - 1) {
@@ -831,6 +866,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
   bool saw_dst = false;
   const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
+  bool saw_self = false;
   for (uint32_t sl = 0; sl < D.VT; sl++) {
     if (!__any(left != 0)) break;
     bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
@@ -839,7 +875,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
       if (a.x != VT_EMPTY) {
         left--;
         uint32_t x = a.x, st = SW_KST(a.y), type, from = 0;
-        saw_dst |= x == dst;
+        saw_dst |= x == dst; saw_self |= x == owner;
         if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
         else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
         else { type = SWIM_MSG_SUSPECT; from = dst; }
@@ -853,13 +889,24 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
     wave_append_sharded(D, want, sh, rec);
     c_edges += want; c_remote += want && sh != D.rank;
   }
+  // ...and the owner's view of ITSELF travels when the base row says something else about it (a node that has just
+  // joined: nobody has heard of it; a node that came back after it was folded as dead)
+  {
+    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
+    if (on && !saw_self) {
+      const uint32_t self = SW_KEY(D.hdr[lo].x, SWIM_STATE_ALIVE);
+      if (self != base_key_of(D, r, owner, D.nw[(size_t)r * D.N + owner])) { rec = mk_edge(D, r, dst, owner, SW_KINC(self), SWIM_MSG_ALIVE, 0); want = true; }
+    }
+    wave_append_sharded(D, want, sh, rec);
+    c_edges += want; c_remote += want && sh != D.rank;
+  }
   // ...with one exception: the receiver's view of ITSELF is its own (it may have been away while the base row moved
   // on), so the owner's view of the receiver travels even when it is the base row's (and not the trivial alive@1)
   {
     bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
     if (on && !saw_dst) {
       const uint32_t key = base_key_of(D, r, dst, D.nw[(size_t)r * D.N + dst]);
-      if (key != SW_BASE_KEY) {
+      if (key != SW_BASE_KEY && key >= 4u) {
         const uint32_t st = SW_KST(key), type = st == SWIM_STATE_ALIVE ? SWIM_MSG_ALIVE : st == SWIM_STATE_LEFT ? SWIM_MSG_DEAD : SWIM_MSG_SUSPECT;
         rec = mk_edge(D, r, dst, dst, SW_KINC(key), type, dst);     // dead{From: node} / suspect{From: receiver}: both = dst here
         want = true;
@@ -916,6 +963,34 @@ __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, 
     }
   }
   S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
+  S.flush(D);
+}
+
+// role: join — swim_inject_join: the join push-pull (pushPullNode(join=true)) of the nodes started since the last tick:
+// their state to `via` and a pull request; via answers through the ordinary reply list one tick later
+__device__ __forceinline__ void role_join(DevRef D, uint32_t* lds_stats) {
+  const uint32_t n = *D.join_cnt < D.join_cap ? *D.join_cnt : D.join_cap;
+  if (!n) return;
+  BlockStats S; S.init(lds_stats);
+  uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
+  for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
+    const uint32_t e = e0 + threadIdx.x; bool on = false; uint32_t r = 0, o = 0, p = 0;
+    if (e < n) {
+      const uint2 j = D.join_list[e];
+      r = j.x / D.N; o = j.x % D.N; p = j.y;
+      const uint32_t wo = D.nw[j.x], wp = D.nw[(size_t)r * D.N + p];
+      if (o >= D.i0 && o < D.i0 + D.nloc && !(wo & (NW_DEAD | NW_ATTACHED)) && (wo & NW_ALONE)) {   // (every shard lists every joiner)
+        on = p != o && !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp);     // else the join fails (memberlist.Join returns an error)
+        S.add(on ? ST_JOINS : ST_JOIN_FAIL);
+      }
+    }
+    send_state(D, on, r, o, p, c_edges, c_remote, c_filt);
+    const uint32_t sh = on ? p / D.nloc : 0;
+    wave_append_sharded(D, on, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
+    c_edges += on; c_remote += on && sh != D.rank;
+  }
+  S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
+  if (D.n_shards > 1 && threadIdx.x == 0) *D.act = 1;
   S.flush(D);
 }
 
@@ -976,6 +1051,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp
     if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); ROLE_DONE(5); return; }
     b -= pl.nb_carry;
   }
+  if (b < pl.nb_join) { role_join(D, lds_stats); ROLE_DONE(7); return; }
+  b -= pl.nb_join;
   if (pl.roles & 16u) role_pushpull(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
   ROLE_DONE(6);
 #undef ROLE_DONE
@@ -1002,11 +1079,11 @@ __device__ __forceinline__ void fold_accumulate(DevRef D, uint4 rec) {
 }
 
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
-__device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l) {
+__device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l, const ExcList* X = nullptr) {
   if (rec.x == NONE) { fold_accumulate(D, rec); return NONE; }          // fold census record
   uint32_t r = rec.x / D.N, x = rec.x % D.N;
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
-  uint32_t w = D.nw[rec.x];
+  uint32_t w = (X && X->usable()) ? X->word(x) : D.nw[rec.x];           // (X: the list of the replica every record of this span belongs to)
   if (w & NW_DEAD) return NONE;                    // e.g. a push-pull reply to a requester that died meanwhile
   if (w & NW_ATTACHED) { if (rec.y != SWIM_SUBJECT_PIGGY) capture(D, NONE, rec.x, rec.y, rec.z, rec.w); return NONE; }
   l = (size_t)r * D.nloc + (x - D.i0);
@@ -1025,13 +1102,13 @@ __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint3
   if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
 }
 // four records per thread per trip: all four atomics are in flight before the first store
-__device__ __forceinline__ void deliver_span(DevRef D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride) {
+__device__ __forceinline__ void deliver_span(DevRef D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride, const ExcList* X = nullptr) {
   for (uint32_t e = first; e < n; e += 4 * stride) {
     uint4 rec[4]; size_t l[4]; uint32_t pos[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) if (e + j * stride < n) rec[j] = edges[e + j * stride];
 #pragma unroll
-    for (int j = 0; j < 4; j++) pos[j] = e + j * stride < n ? inbox_reserve(D, rec[j], l[j]) : NONE;
+    for (int j = 0; j < 4; j++) pos[j] = e + j * stride < n ? inbox_reserve(D, rec[j], l[j], X) : NONE;
 #pragma unroll
     for (int j = 0; j < 4; j++) inbox_place(D, rec[j], l[j], pos[j]);
   }
@@ -1061,6 +1138,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
   uint32_t b = blockIdx.x;
   if (b < D.n_seg) {
     uint32_t n = D.seg_cnt[b], last = D.seg_last[b];
+    // a segment holds records of ONE replica: its exception list (the few nodes whose word is not 0) in LDS saves the
+    // node-word read of every record
+    __shared__ uint32_t lds_exc[2 * SW_EXC_MAX];
+    ExcList X; X.n = SW_EXC_MAX + 1; X.id = lds_exc; X.w = lds_exc + SW_EXC_MAX;
+    if (n) X.stage(D, b < D.R * D.nb_gossip ? b / D.nb_gossip : (b - D.R * D.nb_gossip) / D.nb_probe, lds_exc);
     uint32_t cn[4] = { 0, 0, 0, 0 }, cl[4] = { 0, 0, 0, 0 };
     // anything carried into this tick?  (uniform words: k_resolve stamps carry_stamp with the tick its picks
     // travel in, so a tick without piggy-backed broadcasts costs this block nothing more)
@@ -1082,7 +1164,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
         if (cl[j] | cn[j]) D.carry_cl[a] = make_uint2(0, cn[j]);
       }
     }
-    if (n) deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK);
+    if (n) deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK, &X);
     if (threadIdx.x == 0 && n) D.seg_cnt[b] = 0;
     if (!piggy) return;
     uint32_t c_edges = 0, c_filt = 0;
@@ -1307,11 +1389,13 @@ struct NodeCtx {
       vm.w = ev2;                                                      // the victim had the earliest one
       const uint32_t wv = D.nw[(size_t)r * D.N + vsubj];
       if (NW_HAS_SLOT(wv)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wv)] = 1;
+      if (D.dyn && SW_KINC(base_key_of(D, r, vsubj, wv)) == 0) D.vnk[l]--;
       vt_erase(D, l, vs); vm.x--; S.add(ST_VIEW_EVICT);
       uint4 dummy; vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], dummy, v.free_slot);   // the layout changed
       if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
     }
     vm.x++; vm_dirty = true;
+    if (D.dyn && x != o && v.e.y < 4u) D.vnk[l]++;          // a node the base row has never heard of: this observer now has (itself it counts from the start)
     v.slot = v.free_slot; v.fresh = true;
     if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
       const uint32_t old = atomicOr(&D.nw[(size_t)r * D.N + x], NW_SUBJECT);
@@ -1337,8 +1421,8 @@ struct NodeCtx {
       D.slot_dirty[sidx] = 1;
     }
   }
-  __device__ void arm_deadline(const View& v) {           // a suspicion timer was (re)armed: keep the gates' bounds
-    const uint32_t dl = v.e.z + sel8(D.susp_timeout, vw_nconf(v.e.w));
+  __device__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
+    const uint32_t dl = v.e.z + susp_timeout_n(D, n0, vw_nconf(v.e.w));
     need_vm();
     if (dl < vm.z) { vm.z = dl; vm_dirty = true; if (dl < dl_blk0 || !dl_blk0) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
   }
@@ -1381,15 +1465,16 @@ struct NodeCtx {
     if (inc < SW_KINC(key)) return;
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from) (the base row is never Suspect)
       uint32_t nc = vw_nconf(v.e.w);
-      if (nc >= D.susp_k || vw_conf0(v.e.w) == from) return;
+      if ((!D.dyn && nc >= D.susp_k) || vw_conf0(v.e.w) == from) return;
       const size_t ci = (size_t)v.slot * NL + l;
-      uint4 b = nc ? D.vc[ci] : make_uint4(0, 0, 0, 0);
+      uint4 b = (nc || D.dyn) ? D.vc[ci] : make_uint4(0, 0, 0, 0);     // (dynamic membership: the timer's n sits in b.w)
+      if (D.dyn && nc >= susp_k_n(D, b.w)) return;
       if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
       if (nc <= 3) D.vc[ci] = b;
       v.e.w = vw_pack(vw_conf0(v.e.w), nc); put(v);
-      arm_deadline(v);
+      arm_deadline(v, b.w);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       S.add(ST_CONFIRMS);
       broadcast(x, SWIM_MSG_SUSPECT, inc, from);
@@ -1402,7 +1487,9 @@ struct NodeCtx {
     set_view(v, inc, SWIM_STATE_SUSPECT, true);
     v.e.w = vw_pack(from, 0);                              // newSuspicion(from, k, min, max)
     put(v);
-    arm_deadline(v);
+    uint32_t n0 = 0;
+    if (D.dyn) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
+    arm_deadline(v, n0);
     S.add(ST_APPL1);
   }
   __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
@@ -1434,9 +1521,10 @@ struct NodeCtx {
     MetaQ mm{lds_meta + threadIdx.x}, me{lds_meta + (size_t)D.Q * SW_BLOCK + threadIdx.x};
     for (uint32_t j = 0; j < qlen; j++) mm.meta(j) = qm.at(j).w;
     for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
-    uint32_t tm = get_broadcasts(D, mm, qlen, live_m, 2, limit, used), te = 0;
+    const uint32_t rl = retransmit_limit_n(D, est_n(D, r, l));
+    uint32_t tm = get_broadcasts(D, mm, qlen, live_m, 2, limit, used, rl), te = 0;
     int avail = limit - used;
-    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2);
+    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
     if (!(tm | te)) return;
     const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
     c_pig++;
@@ -1527,7 +1615,9 @@ __device__ __attribute__((noinline)) void inbox_heapsort(uint32_t* a, uint32_t n
 }
 #define SW_INBOX_SORT_MIN 12      /* from this many messages on the inbox is sorted rather than searched */
 
-__global__ void __launch_bounds__(SW_BLOCK) k_resolve(const SwDev* __restrict__ Dp) {
+// (five waves per SIMD instead of the four the register allocator would settle for: the kernel is a chain of dependent
+// memory round trips, and it is the number of lanes in flight that hides them)
+__global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];
@@ -1713,11 +1803,30 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     any = __syncthreads_or(any != 0);
     if (threadIdx.x == 0) *D.act = any ? 1u : 0u;
   }
+  // swim_inject_join: a node whose join push-pull went out this tick stops being alone — from the next tick on it probes
+  // and gossips like everybody.  Ground truth is replicated, so every shard does this for every joiner.
+  if (D.join_cnt && *D.join_cnt) {
+    const uint32_t n = *D.join_cnt < D.join_cap ? *D.join_cnt : D.join_cap;
+    for (uint32_t e = threadIdx.x; e < n; e += SW_BLOCK) {
+      const uint2 j = D.join_list[e];
+      const uint32_t r = j.x / D.N, o = j.x % D.N, p = j.y, wo = D.nw[j.x], wp = D.nw[(size_t)r * D.N + p];
+      if ((wo & (NW_DEAD | NW_ATTACHED)) || !(wo & NW_ALONE)) continue;
+      if (!(p != o && !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp))) continue;
+      atomicAnd(&D.nw[j.x], ~NW_ALONE); atomicAdd(&D.acting[r], 1u);
+      if (o >= D.i0 && o < D.i0 + D.nloc) atomicAdd(&D.alive_cnt[((size_t)r * D.nloc + (o - D.i0)) / SW_BLOCK], 1u);
+      D.exc_dirty[r] = 1;
+      for (uint32_t sl = 0; sl < D.n_slots[r]; sl++) D.slot_dirty[(size_t)r * D.S + sl] = 1;
+    }
+    __syncthreads();
+    __shared__ uint32_t s_exc_n;
+    for (uint32_t r = 0; r < D.R; r++) if (D.exc_dirty[r]) rebuild_exceptions(D, r, &s_exc_n);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     *D.tick = t + 1;
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
+    if (D.join_cnt) *D.join_cnt = 0;           // the joins of this tick are under way
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
@@ -1742,26 +1851,32 @@ __global__ void __launch_bounds__(SW_BLOCK) k_count_live(const SwDev* __restrict
 // =================================================================================================
 // initialisation, stimulus, digest
 // =================================================================================================
-__global__ void k_init_nodes(const SwDev* __restrict__ Dp) {
+__global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
   SW_DEV_BIND
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= NL) return;
   D.hdr[l] = make_uint4(1, 0, 0, (D.flags & SWIM_F_SERF_EVENTS) ? 1u : 0u);   // serf.Create: eventClock.Increment()
+  if (D.vnk) D.vnk[l] = 0;
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
   D.in_cnt[l] = 0; D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
-    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK;
+    uint32_t in_blk = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK, started = 0;       // lanes of this block that run at t = 0
+    for (uint32_t j = 0; j < in_blk; j++) started += D.i0 + (uint32_t)((l + j) % D.nloc) < n_initial;
+    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = started;
     D.dl_blk[l / SW_BLOCK] = NONE;
   }
-  if (l < D.R) D.acting[l] = D.N;
+  if (l < D.R) { D.acting[l] = n_initial; D.base_known[l] = n_initial; }
 }
-__global__ void k_init_base(const SwDev* __restrict__ Dp) {
+__global__ void k_init_base(const SwDev* __restrict__ Dp, uint32_t n_initial) {
   SW_DEV_BIND
   size_t n = (size_t)D.R * D.N, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) D.bk[i] = SW_BASE_KEY;
+  if (i >= n) return;
+  const bool member = (uint32_t)(i % D.N) < n_initial;      // the rest has not been started: nobody has heard of it
+  D.bk[i] = member ? SW_BASE_KEY : SW_KEY(0, SWIM_STATE_DEAD);
+  D.nw[i] = member ? 0u : (NW_DEAD | NW_BASEMOD);
 }
 __global__ void k_init_slots(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
@@ -1810,7 +1925,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
       }
     } else if (op == INJ_REVIVE) {
       uint32_t old = atomicAnd(&D.nw[g], ~NW_DEAD);
-      if ((old & NW_DEAD) && !(old & NW_ATTACHED)) {
+      if ((old & NW_DEAD) && !(old & (NW_ATTACHED | NW_ALONE))) {
         atomicAdd(&D.acting[r], 1u);
         if (local) atomicAdd(&D.alive_cnt[l / SW_BLOCK], 1u);
       }
@@ -1839,6 +1954,43 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
   }
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
+  S.flush(D);
+}
+// swim_inject_join: serf.Create + serf.Join([via]) for nodes that are not running — a fresh process
+__global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n, uint32_t via) {
+  SW_DEV_BIND
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  const uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (a < n) {
+    const uint32_t x = ids[a]; const size_t g = (size_t)r * D.N + x;
+    const uint32_t old = D.nw[g];
+    if ((old & NW_DEAD) && !(old & NW_ATTACHED)) {          // (running already: Join on a live member is a no-op here)
+      atomicAnd(&D.nw[g], ~NW_DEAD); atomicOr(&D.nw[g], NW_ALONE);   // up, but it knows nobody until the join push-pull went through
+      { const uint32_t pos = atomicAdd(D.join_cnt, 1u); if (pos < D.join_cap) D.join_list[pos] = make_uint2((uint32_t)g, via); else atomicOr(D.err, SW_ERR_PEND_OVF); }
+      if (x >= D.i0 && x < D.i0 + D.nloc) {
+        const size_t NL = (size_t)D.R * D.nloc, l = (size_t)r * D.nloc + (x - D.i0);
+        // nothing queued, no views of its own (it holds the base row), clean probe state
+        for (uint32_t sl = 0; sl < D.VT; sl++) if (D.vt[(size_t)sl * NL + l].x != VT_EMPTY) D.vt[(size_t)sl * NL + l].x = VT_EMPTY;
+        D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
+        const uint32_t bkey = base_key_of(D, r, x, old);
+        if (D.vnk) D.vnk[l] = SW_KINC(bkey) == 0 ? 1u : 0u;  // it knows itself, whatever the base row says
+        uint4 h = D.hdr[l];
+        if (SW_KINC(bkey) != 0 || h.x > 1 || h.z) h.x++;     // a restart: past the incarnation others may remember
+        h.y = 0; D.hdr[l] = h;
+        const uint2 p = D.ph[l];
+        D.ph[l].y = p_pack(p_epoch(p.y), 0, 0, 0); D.pr0[l].x = NONE; D.in_cnt[l] = 0;
+        q_bit_lane(D, l, false, true);
+        NodeCtx c(D, S);
+        c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = NL;
+        c.load();
+        c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 0);       // memberlist setAlive
+        c.store();
+        q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
+      }
+    }
+  }
+  if (blockIdx.x == 0) for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
 }
 __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
@@ -2018,12 +2170,20 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
     r = (uint32_t)(l / D.nloc);
     if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = D.vmeta[l].x;
   }
-  for (uint32_t sl = 0; sl < D.VT; sl++) {
-    if (!__any(left != 0)) break;
+  // round VT stands for the node's view of ITSELF when that is implicit (alive at its own incarnation) and not what
+  // the base row says: it takes part in the census like an explicit view (there is nothing to free later)
+  bool acting = false, saw_self = false; uint32_t o = 0;
+  if (l < NL) { o = D.i0 + (uint32_t)(l % D.nloc); acting = !(D.nw[(size_t)r * D.N + o] & NW_INERT); }
+  for (uint32_t sl = 0; sl <= D.VT; sl++) {
+    if (sl < D.VT && !__any(left != 0)) { sl = D.VT - 1; continue; }
     uint4 a = make_uint4(VT_EMPTY, 0, 0, 0);
-    if (left) a = D.vt[(size_t)sl * NL + l];
+    if (sl < D.VT) { if (left) a = D.vt[(size_t)sl * NL + l]; }
+    else if (acting && !saw_self) {
+      const uint32_t self = SW_KEY(D.hdr[l].x, SWIM_STATE_ALIVE);
+      if (self != D.bk[(size_t)r * D.N + o]) a = make_uint4(o, self, 0, 0);
+    }
     bool have = a.x != VT_EMPTY;
-    if (have) left--;
+    if (have && sl < D.VT) { left--; saw_self |= a.x == o; }
     const uint32_t g = r * D.N + a.x, st = SW_KST(a.y);
     const bool bad = st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - a.z > D.gossip_to_dead_ms));
     // lanes of a wave mostly hold the same subject in the same slot (one failure per cluster): one atomic set per
@@ -2052,49 +2212,54 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_emit(const SwDev* __restrict_
   for (uint32_t sh = 0; sh < D.n_shards; sh++) wave_append(D, sh, cnt != 0, rec);
   if (D.n_shards > 1 && cnt) *D.act = 1;
 }
+// every shard takes the same decision for every subject g = replica*N + node from the same accumulated records:
+// fl_bad[g] = 0 no, 1 fold, 2 fold and the base row hears of the node for the first time
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_decide(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t n = (size_t)D.R * D.N, g = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  uint32_t code = 0, r = 0, x = 0; bool mine = false;
+  if (g < n) {
+    r = (uint32_t)(g / D.N); x = (uint32_t)(g % D.N);
+    const uint32_t k = D.fg_kmin[g], c = D.fg_cnt[g];
+    if (c && c == D.acting[r] && k == D.fg_kmax[g] && k != FOLD_POISON) {
+      const uint32_t old = D.bk[g];
+      code = (SW_KINC(old) == 0 && SW_KINC(k) != 0) ? 2u : 1u;
+      mine = x >= D.i0 && x < D.i0 + D.nloc;
+      // the base row's new entry; the subject bit falls (nobody holds a view any more once k_fold_apply is through)
+      D.bk[g] = k;
+      const uint32_t w = D.nw[g], wn = (w & ~(NW_SUBJECT | NW_BASEMOD)) | (k != SW_BASE_KEY ? NW_BASEMOD : 0u);
+      if (w != wn) D.nw[g] = wn;
+      if (NW_HAS_SLOT(w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(w)] = 1;
+      *D.fold_any = 1;
+      if (code == 2) { atomicAdd(&D.base_known[r], 1u); if (mine && D.dyn) D.vnk[(size_t)r * D.nloc + (x - D.i0)]--; }   // (it counted itself)
+    }
+    D.fl_bad[g] = code;
+  }
+  // stats: a folded subject is counted once, by the shard that owns its id
+  const uint64_t mm = __ballot(code != 0 && mine);
+  if (mm && sw_lane() == 0) atomicAdd(stat_ptr(D, ST_FOLDS), (unsigned long long)__popcll(mm));
+}
 __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l >= NL) return;
   uint4 vm = D.vmeta[l];
   if (!vm.x) return;
-  const uint32_t r = (uint32_t)(l / D.nloc);
-  const uint32_t acting = D.acting[r];
-  uint32_t freed = 0;
+  const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
+  uint32_t freed = 0, nk_less = 0;
   for (uint32_t sl = 0; sl < D.VT; ) {
     const uint4 a = D.vt[(size_t)sl * NL + l];
-    bool fold = false;
-    if (a.x != VT_EMPTY) {
-      const uint32_t g = r * D.N + a.x, k = D.fg_kmin[g];
-      fold = D.fg_cnt[g] == acting && k == D.fg_kmax[g] && k != FOLD_POISON;
-      if (fold) {
-        // every holder writes the same values: the base row's new entry; the subject bit falls (nobody holds a view now)
-        D.bk[g] = k;
-        const uint32_t w = D.nw[g], wn = (w & ~(NW_SUBJECT | NW_BASEMOD)) | (k != SW_BASE_KEY ? NW_BASEMOD : 0u);
-        if (w != wn) { atomicAnd(&D.nw[g], ~NW_SUBJECT); if (k != SW_BASE_KEY) atomicOr(&D.nw[g], NW_BASEMOD); else atomicAnd(&D.nw[g], ~NW_BASEMOD); }
-        if (NW_HAS_SLOT(w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(w)] = 1;
-      }
-    }
-    if (!fold) { sl++; continue; }
+    const uint32_t code = a.x != VT_EMPTY ? D.fl_bad[(size_t)r * D.N + a.x] : 0u;
+    if (!code) { sl++; continue; }
     // (the acting observers agree on a settled view; a node that is not running may still hold a suspicion)
     if (SW_KST(a.y) == SWIM_STATE_SUSPECT && --vm.y == 0) vm.z = NONE;
+    nk_less += code == 2 && a.x != o;
     vt_erase(D, l, sl);                                  // an entry may move into slot sl: it is looked at again
     vm.x--; freed++;
   }
   if (freed) {
-    D.vmeta[l] = vm; *D.fold_any = 1;
+    D.vmeta[l] = vm;
+    if (nk_less && D.dyn) D.vnk[l] -= nk_less;
     atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
   }
-}
-// stats: a folded subject is counted once, by the shard that owns its id (its own lane need not hold a view)
-__global__ void __launch_bounds__(SW_BLOCK) k_fold_count(const SwDev* __restrict__ Dp) {
-  SW_DEV_BIND
-  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
-  bool f = false;
-  if (l < NL) {
-    const uint32_t r = (uint32_t)(l / D.nloc), g = r * D.N + D.i0 + (uint32_t)(l % D.nloc), k = D.fg_kmin[g];
-    f = D.fg_cnt[g] && D.fg_cnt[g] == D.acting[r] && k == D.fg_kmax[g] && k != FOLD_POISON;
-  }
-  const uint64_t mm = __ballot(f);
-  if (mm && sw_lane() == 0) atomicAdd(stat_ptr(D, ST_FOLDS), (unsigned long long)__popcll(mm));
 }

@@ -183,6 +183,11 @@ class Sim:
         a, p, n = _ids(ids)
         self._ck("swim_inject_update", self._l.swim_inject_update(self._h, replica, p, n))
 
+    def join(self, replica: int, ids: Iterable[int], via: int):
+        """serf.Create + serf.Join([via]) for nodes that are not running."""
+        a, p, n = _ids(ids)
+        self._ck("swim_inject_join", self._l.swim_inject_join(self._h, replica, p, n, via))
+
     def partition(self, replica: int, group_of_node: Sequence[int]):
         g = np.ascontiguousarray(group_of_node, dtype=np.uint8)
         if g.size != self.cfg.n_nodes:

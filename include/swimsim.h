@@ -93,6 +93,10 @@ typedef struct swim_config {
   uint32_t abi_version;             /* SWIM_ABI_VERSION                                     */
   uint32_t n_nodes;                 /* N: virtual nodes per cluster replica                 */
   uint32_t n_replicas;              /* R: independent clusters, replica r uses seed+r       */
+  uint32_t n_initial;               /* members at t = 0: ids [0, n_initial) run and know each other; the rest of the id
+                                       space has not been started (nobody has heard of them) until swim_inject_join.
+                                       0 = all n_nodes.  With n_initial < n_nodes every node's estNumNodes() is its own
+                                       count of known nodes and feeds retransmitLimit / suspicionTimeout like upstream */
   /* memberlist.Config */
   uint32_t gossip_nodes;            /* GossipNodes        agent/agent.go:1419               */
   uint32_t gossip_interval_ms;      /* GossipInterval     agent/agent.go:1418               */
@@ -229,6 +233,9 @@ typedef struct swim_stats_t {
   uint64_t view_drops;              /* rumours ignored because the observer already held view_cap explicit views */
   uint64_t view_evictions;          /* long-settled Dead/Left views a full table forgot to make room (memberlist
                                        resetNodes forgets a node dead for longer than GossipToTheDeadTime)         */
+  uint64_t joins;                   /* join push-pulls carried out (swim_inject_join); a join whose `via` cannot be reached
+                                       is counted in join_failures (memberlist.Join returns an error)              */
+  uint64_t join_failures;
   uint64_t folds;                   /* subjects folded into the base row (counted by the shard owning the id)   */
   uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
 } swim_stats_t;
@@ -319,6 +326,12 @@ int swim_inject_leave(swim_sim* sim, uint32_t replica, const uint32_t* ids, size
 /* memberlist.UpdateNode (serf.SetTags, internal/gossip/libserf/serf.go:51): bump own
  * incarnation and broadcast alive — the "single rumour" of BASELINE config #3 */
 int swim_inject_update(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n);
+/* serf.Create + serf.Join([via]) for nodes that are not running (agent/consul/client.go:222, server.go:1461,
+ * agent/router/serf_flooder.go:81): a fresh process — empty queues, no views of its own, incarnation 1 on its first
+ * start and the previous one + 1 after a restart — that queues alive{self} (memberlist setAlive) and, in its first
+ * tick, does the join push-pull with `via` (pushPullNode(join=true): its state to via, via's back one tick later).
+ * Everybody who hears the alive{} takes the aliveNode path for a node it has never heard of (NotifyJoin). */
+int swim_inject_join(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n, uint32_t via);
 /* partition mask: nodes exchange packets only within the same group id (config #4) */
 int swim_inject_partition(swim_sim* sim, uint32_t replica, const uint8_t* group_of_node);
 int swim_set_loss(swim_sim* sim, uint32_t loss_q32);

@@ -174,6 +174,7 @@ static int validate(const swim_config* c) {
   if (c->flags & SWIM_F_SERF_EVENTS)
     if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
+  if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
   return SWIM_OK;
 }
@@ -238,7 +239,7 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
 
 /* one explicit view: what an observer knows about `subj` beyond the replica's base row */
-typedef struct { uint32_t subj, key, since, conf[CONF_MAX]; uint8_t nconf; } view_t;
+typedef struct { uint32_t subj, key, since, conf[CONF_MAX], n0; uint8_t nconf; } view_t;   /* n0 = estNumNodes() when the suspicion started */
 /* an observer's explicit views: open addressing (linear probing, backward-shift deletion), grown on demand, at most
  * cfg.view_cap entries (+1 for the node's view of itself).  Layout is private to this file: everything observable
  * (digest, census, members) is keyed by (observer, subject). */
@@ -262,6 +263,7 @@ typedef struct {
   /* per-tick inbox */
   uint32_t in_cnt; swim_edge* inbox;
   vtab vt; uint32_t vdl;          /* explicit views; earliest suspicion deadline among them (a lower bound, SWIM_NONE = none) */
+  uint32_t nk;                    /* explicit views of nodes the base row has never heard of (estNumNodes = base_known + nk) */
 } node_t;
 
 /* a watch slot: census, first-* stamps and trace of one subject (observation only; the protocol never looks here) */
@@ -280,11 +282,15 @@ struct swim_sim {
   uint32_t N, R, nloc, i0, tick; int in_tick;
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
   uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
+  uint8_t* alone;                /* [R*N] replicated: started by swim_inject_join, join push-pull not carried out (yet): it knows nobody */
   edgevec captured;              /* rumours sent to attached nodes: {dst = replica*N+attached, ..}, src kept in cap_src */
   uint32_t* cap_src; uint32_t cap_src_cap;
   uint32_t* node_slot;           /* [R*N] replicated: watch slot of a subject, SWIM_NONE = not watched */
   uint32_t* base_key;            /* [R*N] replicated: the view every observer holds unless it has an explicit one */
   uint32_t* subj_cnt;            /* [R*N] explicit views of this subject held by the local observers */
+  uint32_t* base_known;          /* [R] nodes the base row has heard of (incarnation > 0) */
+  int dyn;                       /* n_initial < n_nodes: estNumNodes() is per observer */
+  uint32_t* join_list; uint32_t n_join_pending, join_cap;   /* {replica*N + node, via} of the nodes started since the last tick (every shard lists all of them) */
   uint32_t *f_cnt, *f_kmin, *f_kmax; uint8_t* f_bad; uint32_t* f_touched; uint32_t f_ntouched, f_cap;  /* fold accumulators [R*N] */
   node_t* nodes;                 /* [R*nloc] */
   qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous */
@@ -313,7 +319,7 @@ static inline int is_local(const swim_sim* s, uint32_t i) { return i >= s->i0 &&
 static inline node_t* node_at(swim_sim* s, uint32_t r, uint32_t i) { return &s->nodes[(size_t)r * s->nloc + (i - s->i0)]; }
 static inline uint32_t shard_of(const swim_sim* s, uint32_t i) { return i / s->nloc; }
 /* does the simulator act for this node (running and not driven from outside) */
-static inline int acts(const swim_sim* s, uint32_t r, uint32_t i) { size_t g = (size_t)r * s->N + i; return s->gt_alive[g] && !s->attached[g]; }
+static inline int acts(const swim_sim* s, uint32_t r, uint32_t i) { size_t g = (size_t)r * s->N + i; return s->gt_alive[g] && !s->attached[g] && !s->alone[g]; }
 static inline uint32_t gphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk) % s->d.gossip_period; }
 static inline uint32_t pphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk / s->d.gossip_period) % s->d.probe_period; }
 
@@ -364,6 +370,34 @@ static void vt_erase(vtab* t, view_t* v) {                 /* backward-shift del
   t->e[i].subj = V_EMPTY; t->n--;
 }
 
+/* estNumNodes(): how many nodes this observer has heard of (alive or not) — the cluster size every scaling law uses */
+static inline uint32_t est_n(const swim_sim* s, uint32_t r, const node_t* nd) { return s->dyn ? s->base_known[r] + nd->nk : s->N; }
+/* util.go retransmitLimit for an observer that knows n nodes */
+static uint32_t retransmit_limit_n(const swim_sim* s, uint32_t n) {
+  if (!s->dyn) return s->d.retransmit_limit;
+  return s->cfg.retransmit_mult * (uint32_t)ceil(go_log10((double)n + 1.0));
+}
+/* suspicion.go: timeout of a suspicion that started when the observer knew n nodes, after `nconf` confirmations; and
+ * the k of that timer (SuspicionMult-2, or 0 when n-2 < k) */
+static uint32_t suspicion_k_n(const swim_sim* s, uint32_t n) {
+  if (!s->dyn) return s->d.suspicion_k;
+  int32_t k = (int32_t)s->cfg.suspicion_mult - 2; if (k < 0) k = 0;
+  if ((int64_t)n - 2 < k) k = 0;
+  return (uint32_t)k;
+}
+static uint32_t suspicion_timeout_n(const swim_sim* s, uint32_t n, uint32_t nconf) {
+  if (!s->dyn) return s->d.suspicion_timeout_ms[nconf];
+  double scale = go_log10(n < 1 ? 1.0 : (double)n); if (scale < 1.0) scale = 1.0;
+  int64_t scale_milli = (int64_t)(scale * 1000.0);
+  int64_t min_ms = (int64_t)s->cfg.suspicion_mult * scale_milli * ((int64_t)s->cfg.probe_interval_ms * 1000000) / 1000 / 1000000;
+  int64_t max_ms = (int64_t)s->cfg.suspicion_max_timeout_mult * min_ms;
+  uint32_t k = suspicion_k_n(s, n);
+  if (k < 1) return (uint32_t)min_ms;
+  if (nconf == 0) return (uint32_t)max_ms;
+  if (nconf >= k) return (uint32_t)min_ms;
+  return (uint32_t)remaining_suspicion_ms(nconf, k, 0, min_ms, max_ms);
+}
+
 /* observer o's explicit view of subject x, or NULL: then it holds the base row's */
 static view_t* view_ptr(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
   if (!s->subj_cnt[(size_t)r * s->N + x]) return NULL;     /* nobody here has news about x */
@@ -399,12 +433,14 @@ static view_t* view_make(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
     }
     if (!victim) { s->st.view_drops++; return NULL; }
     s->subj_cnt[(size_t)r * s->N + victim->subj]--; touch_slot(s, r, victim->subj);
+    if (KINC(s->base_key[(size_t)r * s->N + victim->subj]) == 0) nd->nk--;
     vt_erase(&nd->vt, victim); s->st.view_evictions++;
   }
   v = vt_insert(&nd->vt, x);
   if (!v) { s->st.view_drops++; return NULL; }
   v->key = implicit_key(s, r, o, x);
   s->subj_cnt[(size_t)r * s->N + x]++;
+  if (x != o && KINC(s->base_key[(size_t)r * s->N + x]) == 0) nd->nk++;   /* a node the base row has never heard of: this observer now has (itself it counts from the start) */
   return v;
 }
 
@@ -466,7 +502,7 @@ static void queue_push(swim_sim* s, qent* q, uint32_t* qlen, uint32_t* qseq, uin
 
 /* GetBroadcasts(overhead, limit): walk tiers by transmit count, inside a tier largest first then
  * newest, take what fits, bump transmits after the sweep, retire at retransmitLimit. */
-static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out) {
+static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out, uint32_t retransmit_limit) {
   uint32_t n = *qlen, taken = 0, cnt = 0; int32_t used = 0;
   for (;;) {
     int32_t free_b = limit - used - (int32_t)overhead;
@@ -483,7 +519,7 @@ static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhea
   uint32_t m = 0;
   for (uint32_t i = 0; i < n; i++) {
     if ((taken >> i) & 1u) {
-      if ((uint32_t)q[i].transmits + 1 >= s->d.retransmit_limit) continue;   /* Finished() */
+      if ((uint32_t)q[i].transmits + 1 >= retransmit_limit) continue;   /* Finished() */
       q[i].transmits++;
     }
     q[m++] = q[i];
@@ -525,7 +561,7 @@ static void touch_slot(swim_sim* s, uint32_t r, uint32_t x) {
 }
 /* a suspicion timer was (re)armed at observer nd: keep its earliest-deadline bound */
 static void arm_deadline(swim_sim* s, node_t* nd, const view_t* v) {
-  uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
+  uint32_t dl = v->since + suspicion_timeout_n(s, v->n0, v->nconf);
   if (dl < nd->vdl) nd->vdl = dl;
 }
 
@@ -571,7 +607,7 @@ static void suspect_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32
   uint32_t key = v ? v->key : implicit_key(s, r, o, x);
   if (inc < KINC(key)) return;
   if (KST(key) == SWIM_STATE_SUSPECT) {                   /* a timer exists: suspicion.Confirm(from) (the base row is never Suspect) */
-    if (v->nconf >= s->d.suspicion_k) return;
+    if (v->nconf >= suspicion_k_n(s, v->n0)) return;
     for (uint32_t i = 0; i <= v->nconf && i < CONF_MAX; i++) if (v->conf[i] == from) return;
     v->nconf++;
     if (v->nconf < CONF_MAX) v->conf[v->nconf] = from;
@@ -585,7 +621,7 @@ static void suspect_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32
   if (!v && !(v = view_make(s, r, o, x))) return;
   broadcast(s, nd, x, SWIM_MSG_SUSPECT, inc, from);
   set_view(s, r, x, v, inc, SWIM_STATE_SUSPECT, 1);
-  v->nconf = 0; v->conf[0] = from;                        /* newSuspicion(from, k, min, max) */
+  v->nconf = 0; v->conf[0] = from; v->n0 = est_n(s, r, nd);   /* newSuspicion(from, k, min, max): k, min, max from estNumNodes() now */
   arm_deadline(s, nd, v);
   s->st.msgs_applied[SWIM_MSG_SUSPECT]++;
 }
@@ -688,7 +724,7 @@ static void phase_expire(swim_sim* s) {
       for (uint32_t i = 0; i < nd->vt.slots; i++) {
         view_t* v = &nd->vt.e[i];
         if (v->subj == V_EMPTY || KST(v->key) != SWIM_STATE_SUSPECT) continue;
-        uint32_t dl = v->since + s->d.suspicion_timeout_ms[v->nconf];
+        uint32_t dl = v->since + suspicion_timeout_n(s, v->n0, v->nconf);
         if (now >= dl) {
           /* a timer is not a packet: straight into the node's own inbox (not part of swim_debug_edges) */
           ev_push(&s->in, mk_edge(s, r, o, v->subj, KINC(v->key), SWIM_MSG_DEAD, o));
@@ -719,6 +755,7 @@ static uint32_t k_random_nodes(swim_sim* s, uint32_t r, uint32_t o, uint32_t str
 static int excl_gossip(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* ctx) {
   (void)ctx; if (x == o) return 1;
   uint32_t since, key = view_key(s, r, o, x, &since);
+  if (KINC(key) == 0) return 1;                            /* never heard of it: not in this node's member list */
   switch (KST(key)) {
     case SWIM_STATE_ALIVE: case SWIM_STATE_SUSPECT: return 0;
     case SWIM_STATE_DEAD: return now_ms(s) - since > s->cfg.gossip_to_dead_ms;
@@ -837,7 +874,7 @@ static int noop_at_receiver(swim_sim* s, uint32_t r, uint32_t dst, const qent* m
   if (m->inc != vinc) return m->inc < vinc;
   if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return 1;
   if (m->type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
-    if (v->nconf >= s->d.suspicion_k) return 1;
+    if (v->nconf >= suspicion_k_n(s, v->n0)) return 1;
     for (uint32_t i = 0; i <= v->nconf && i < CONF_MAX; i++) if (v->conf[i] == m->from) return 1;
   }
   return 0;
@@ -857,10 +894,16 @@ static void send_state(swim_sim* s, uint32_t r, uint32_t owner, uint32_t dst) {
    * receiver travels even when it is the base row's (and not the trivial alive@1). */
   const vtab* t = &node_at(s, r, owner)->vt;
   int saw_dst = 0;
+  /* ...and the owner's view of ITSELF travels when the base row says something else about it (a node that has just
+   * joined: nobody has heard of it; a node that came back after it was folded as dead) */
+  if (!vt_find(t, owner)) {
+    uint32_t self = KEY(node_at(s, r, owner)->self_inc, SWIM_STATE_ALIVE);
+    if (self != s->base_key[(size_t)r * s->N + owner]) emit(s, r, dst, owner, KINC(self), SWIM_MSG_ALIVE, 0);
+  }
   for (uint32_t i = 0; i <= t->slots; i++) {
     uint32_t subj, key;
     if (i < t->slots) { const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue; subj = v->subj; key = v->key; saw_dst |= subj == dst; }
-    else { subj = dst; key = s->base_key[(size_t)r * s->N + dst]; if (saw_dst || key == BASE_KEY) break; }
+    else { subj = dst; key = s->base_key[(size_t)r * s->N + dst]; if (saw_dst || key == BASE_KEY || KINC(key) == 0) break; }
     qent m = { subj, KINC(key), 0, 0, 0, 0 };
     switch (KST(key)) {
       case SWIM_STATE_ALIVE: m.type = SWIM_MSG_ALIVE; break;
@@ -879,6 +922,19 @@ static void phase_pushpull(swim_sim* s) {
     if (acts(s, r, p)) send_state(s, r, p, o);
   }
   rq->n = 0;
+  /* swim_inject_join: the join push-pull (pushPullNode(join=true)) of the nodes started since the last tick */
+  for (uint32_t j = 0; j < s->n_join_pending; j++) {
+    uint32_t r = s->join_list[2 * j] / s->N, o = s->join_list[2 * j] % s->N, p = s->join_list[2 * j + 1];
+    size_t base = (size_t)r * s->N;
+    if (!s->gt_alive[base + o] || s->attached[base + o] || !s->alone[base + o]) continue;   /* killed again meanwhile */
+    int ok = p != o && s->gt_alive[base + p] && s->part[base + o] == s->part[base + p];
+    s->join_list[2 * j + 1] = ok ? p : SWIM_NONE;          /* tick end: a node whose join went through stops being alone */
+    if (!is_local(s, o)) continue;
+    if (!ok) { s->st.join_failures++; continue; }
+    s->st.joins++;
+    send_state(s, r, o, p);
+    emit(s, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0);
+  }
   /* stagger: node i is due in tick (i mod period), but exchanges start only on probe-interval boundaries
    * (everything due within the next ProbeInterval goes now) — memberlist's own stagger is a random point
    * of the whole interval, so second-granularity loses nothing and keeps most ticks free of this path */
@@ -911,9 +967,10 @@ static void phase_gossip(swim_sim* s) {
       uint32_t peers[8], np = k_random_nodes(s, r, o, STREAM_GOSSIP, s->cfg.gossip_nodes, excl_gossip, NULL, peers);
       for (uint32_t p = 0; p < np; p++) {
         qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
-        uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, (int32_t)s->d.packet_budget, msgs, &used);
+        const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
+        uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, (int32_t)s->d.packet_budget, msgs, &used, rl);
         int32_t avail = (int32_t)s->d.packet_budget - used;
-        if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2);
+        if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2, rl);
         if (!n) break;
         s->st.packets_sent++;
         for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
@@ -950,6 +1007,7 @@ static int edge_cmp(const void* a, const void* b) {
 /* The state-change time of a folded view reads 0.  Shards take the decision together: each    */
 /* sends what its own observers hold (emit_fold_record) with the tick's packets.               */
 /* ------------------------------------------------------------------------------------------ */
+static void dirty_all(swim_sim* s, uint32_t r);
 static int fold_tick(const swim_sim* s) { return s->d.fold_period_ticks && s->tick && s->tick % s->d.fold_period_ticks == 0; }
 static void fold_touch(swim_sim* s, uint32_t g) {
   if (s->f_ntouched == s->f_cap) { s->f_cap = s->f_cap ? s->f_cap * 2 : 256; s->f_touched = (uint32_t*)realloc(s->f_touched, (size_t)s->f_cap * 4); }
@@ -962,14 +1020,19 @@ static void fold_census(swim_sim* s) {
   for (uint32_t r = 0; r < s->R; r++)
     for (uint32_t k = 0; k < s->nloc; k++) {
       if (!acts(s, r, s->i0 + k)) continue;
-      const vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
-      for (uint32_t i = 0; i < t->slots; i++) {
-        const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue;
-        uint32_t g = r * s->N + v->subj, st = KST(v->key);
-        if (!s->f_cnt[g]++) { fold_touch(s, g); s->f_kmin[g] = s->f_kmax[g] = v->key; s->f_bad[g] = 0; }
-        if (v->key < s->f_kmin[g]) s->f_kmin[g] = v->key;
-        if (v->key > s->f_kmax[g]) s->f_kmax[g] = v->key;
-        if (st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - v->since > s->cfg.gossip_to_dead_ms))) s->f_bad[g] = 1;
+      const node_t* nd = &s->nodes[(size_t)r * s->nloc + k];
+      const vtab* t = &nd->vt;
+      /* slot `slots` stands for the node's view of ITSELF when that is implicit (alive at its own incarnation) and not
+       * what the base row says: it takes part in the census like an explicit view (there is nothing to free later) */
+      for (uint32_t i = 0; i <= t->slots; i++) {
+        uint32_t subj, key, since = 0;
+        if (i < t->slots) { const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue; subj = v->subj; key = v->key; since = v->since; }
+        else { subj = s->i0 + k; key = KEY(nd->self_inc, SWIM_STATE_ALIVE); if (vt_find(t, subj) || key == s->base_key[(size_t)r * s->N + subj]) break; }
+        uint32_t g = r * s->N + subj, st = KST(key);
+        if (!s->f_cnt[g]++) { fold_touch(s, g); s->f_kmin[g] = s->f_kmax[g] = key; s->f_bad[g] = 0; }
+        if (key < s->f_kmin[g]) s->f_kmin[g] = key;
+        if (key > s->f_kmax[g]) s->f_kmax[g] = key;
+        if (st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - since > s->cfg.gossip_to_dead_ms))) s->f_bad[g] = 1;
       }
     }
   for (uint32_t i = 0; i < s->f_ntouched; i++) {
@@ -997,9 +1060,14 @@ static void fold_apply(swim_sim* s) {
   for (uint32_t i = 0; i < s->f_ntouched; i++) {
     uint32_t g = s->f_touched[i], r = g / s->N, x = g % s->N;
     int ok = s->f_kmin[g] == s->f_kmax[g] && s->f_kmax[g] != FOLD_POISON && s->f_cnt[g] == acting[r];
-    s->f_cnt[g] = 0; s->f_bad[g] = (uint8_t)ok;           /* f_bad doubles as "fold this one" for the sweep below */
+    s->f_cnt[g] = 0; s->f_bad[g] = (uint8_t)ok;           /* f_bad doubles as "fold this one" (1, or 2: see below) for the sweep */
     if (!ok) continue;
-    any = 1; s->base_key[g] = s->f_kmin[g];
+    any = 1;
+    if (KINC(s->base_key[g]) == 0 && KINC(s->f_kmin[g]) != 0) {          /* the base row hears of it: 2 = the holders' nk falls, and its own */
+      s->base_known[r]++; s->f_bad[g] = 2;
+      if (is_local(s, x)) node_at(s, r, x)->nk--;
+    }
+    s->base_key[g] = s->f_kmin[g];
     if (is_local(s, x)) s->st.folds++;
     touch_slot(s, r, x);
   }
@@ -1010,8 +1078,9 @@ static void fold_apply(swim_sim* s) {
         vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
         for (uint32_t i = 0; i < t->slots; ) {
           view_t* v = &t->e[i];
-          if (v->subj != V_EMPTY && s->subj_cnt[r * s->N + v->subj] && s->f_bad[r * s->N + v->subj] == 1) {
+          if (v->subj != V_EMPTY && s->subj_cnt[r * s->N + v->subj] && s->f_bad[r * s->N + v->subj] >= 1) {
             s->subj_cnt[r * s->N + v->subj]--; s->st.fold_freed++;
+            if (s->f_bad[r * s->N + v->subj] == 2 && v->subj != s->i0 + k) s->nodes[(size_t)r * s->nloc + k].nk--;
             vt_erase(t, v);                                /* an entry may have shifted into slot i: look at it again */
           } else i++;
         }
@@ -1025,9 +1094,10 @@ static void fold_apply(swim_sim* s) {
 static void piggyback(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t receiver, uint32_t kind) {
   qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
   int32_t limit = (int32_t)s->d.packet_budget - (int32_t)s->cfg.ctl_len[kind & 3];
-  uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, limit, msgs, &used);
+  const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
+  uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, limit, msgs, &used, rl);
   int32_t avail = limit - used;
-  if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2);
+  if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2, rl);
   if (!n) return;
   s->st.piggybacks++; s->st.msgs_piggybacked += n;
   for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
@@ -1125,16 +1195,23 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   s->cfg = *cfg; s->d = d; s->N = cfg->n_nodes; s->R = cfg->n_replicas;
   s->nloc = s->N / cfg->n_shards; s->i0 = cfg->shard_rank * s->nloc; s->loss_q32 = cfg->loss_q32;
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
-  s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1);
+  s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1); s->alone = (uint8_t*)calloc(NT, 1);
   s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
   s->base_key = (uint32_t*)malloc(NT * 4); s->subj_cnt = (uint32_t*)calloc(NT, 4);
   s->f_cnt = (uint32_t*)calloc(NT, 4); s->f_kmin = (uint32_t*)calloc(NT, 4); s->f_kmax = (uint32_t*)calloc(NT, 4); s->f_bad = (uint8_t*)calloc(NT, 1);
   s->slots = (slot_t*)calloc((size_t)s->R * cfg->subject_cap, sizeof(slot_t));
   s->n_slots = (uint32_t*)calloc(s->R, 4); s->out = (edgevec*)calloc(cfg->n_shards, sizeof(edgevec));
-  if (!s->gt_alive || !s->part || !s->attached || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out ||
+  if (!s->gt_alive || !s->part || !s->attached || !s->alone || !s->node_slot || !s->nodes || !s->slots || !s->n_slots || !s->out ||
       !s->base_key || !s->subj_cnt || !s->f_cnt || !s->f_kmin || !s->f_kmax || !s->f_bad) { swim_destroy(s); return SWIM_ENOMEM; }
   memset(s->gt_alive, 1, NT); memset(s->node_slot, 0xFF, NT * 4);
   for (size_t g = 0; g < NT; g++) s->base_key[g] = BASE_KEY;
+  s->base_known = (uint32_t*)calloc(s->R, 4); if (!s->base_known) { swim_destroy(s); return SWIM_ENOMEM; }
+  { uint32_t ni = cfg->n_initial ? cfg->n_initial : s->N;
+    s->dyn = ni < s->N;
+    for (uint32_t r = 0; r < s->R; r++) {
+      s->base_known[r] = ni;
+      for (uint32_t x = ni; x < s->N; x++) { s->gt_alive[(size_t)r * s->N + x] = 0; s->base_key[(size_t)r * s->N + x] = KEY(0, SWIM_STATE_DEAD); }   /* not started, never heard of */
+    } }
   s->q_slab = (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
   s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
   s->inbox_slab = (swim_edge*)malloc(NL * cfg->inbox_cap * sizeof(swim_edge));
@@ -1154,11 +1231,11 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
 int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].ring); free(s->nodes[g].vt.e); }
-  free(s->base_key); free(s->subj_cnt); free(s->f_cnt); free(s->f_kmin); free(s->f_kmax); free(s->f_bad); free(s->f_touched);
+  free(s->base_key); free(s->subj_cnt); free(s->base_known); free(s->join_list); free(s->f_cnt); free(s->f_kmin); free(s->f_kmax); free(s->f_bad); free(s->f_touched);
   free(s->inbox_slab);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
-  free(s->attached); free(s->captured.v); free(s->cap_src); free(s->xpeers);
+  free(s->attached); free(s->alone); free(s->captured.v); free(s->cap_src); free(s->xpeers);
   free(s->q_slab); free(s->evq_slab);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->carry[0].v); free(s->carry[1].v); free(s->events); free(s);
@@ -1219,7 +1296,11 @@ int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
 }
 int swim_tick_end(swim_sim* s) {
   if (!s) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
-  phase_deliver_resolve(s); phase_bookkeep(s);
+  phase_deliver_resolve(s);
+  for (uint32_t j = 0; j < s->n_join_pending; j++)          /* joined: from the next tick on it probes and gossips like everybody */
+    if (s->join_list[2 * j + 1] != SWIM_NONE) { s->alone[s->join_list[2 * j]] = 0; dirty_all(s, s->join_list[2 * j] / s->N); }
+  s->n_join_pending = 0;
+  phase_bookkeep(s);
   s->st.ticks++; if ((s->tick + 1) % s->d.gossip_period == 0) s->st.gossip_rounds++;
   s->tick++; s->in_tick = 0;
   return SWIM_OK;
@@ -1320,6 +1401,29 @@ int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) {
   for (uint32_t i = 0; i < s->N; i++) if (g[i] > 127) return SWIM_ERANGE;     /* 7 bits, like the product library's node word */
   memcpy(s->part + (size_t)r * s->N, g, s->N); return SWIM_OK;
 }
+/* serf.Create + serf.Join([via]) for nodes that are not running (see swimsim.h) */
+int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint32_t via) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  if (via >= s->N) return SWIM_ERANGE;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t x = ids[i]; size_t g = (size_t)r * s->N + x;
+    if (s->gt_alive[g] || s->attached[g]) continue;       /* running already: Join on a live member is a no-op here */
+    s->gt_alive[g] = 1; s->alone[g] = 1;                  /* up, but it knows nobody until the join push-pull went through */
+    if (s->n_join_pending == s->join_cap) { s->join_cap = s->join_cap ? s->join_cap * 2 : 64; s->join_list = (uint32_t*)realloc(s->join_list, (size_t)s->join_cap * 8); }
+    s->join_list[2 * s->n_join_pending] = (uint32_t)g; s->join_list[2 * s->n_join_pending + 1] = via; s->n_join_pending++;
+    if (!is_local(s, x)) continue;
+    node_t* nd = node_at(s, r, x);
+    /* a fresh process: nothing queued, no views of its own (it holds the base row), clean probe state */
+    for (uint32_t j = 0; j < nd->vt.slots; j++) if (nd->vt.e[j].subj != V_EMPTY) { s->subj_cnt[(size_t)r * s->N + nd->vt.e[j].subj]--; touch_slot(s, r, nd->vt.e[j].subj); }
+    free(nd->vt.e); memset(&nd->vt, 0, sizeof nd->vt); nd->vdl = SWIM_NONE;
+    nd->nk = KINC(s->base_key[g]) == 0 ? 1u : 0u;          /* it knows itself, whatever the base row says */
+    nd->qlen = 0; nd->evqlen = 0; nd->in_cnt = 0; nd->awareness = 0; nd->leaving = 0;
+    nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->pr_nack_miss = 0;
+    if (KINC(s->base_key[g]) != 0 || nd->self_inc > 1 || nd->qseq) nd->self_inc++;   /* a restart: past the incarnation others may remember */
+    broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 0);   /* memberlist setAlive */
+  }
+  dirty_all(s, r); return SWIM_OK;
+}
 int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
   if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
   return alloc_slot(s, r, x);
@@ -1350,7 +1454,7 @@ int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out)
   uint32_t key = v ? v->key : implicit_key(s, r, o, x);
   out->incarnation = KINC(key); out->state = (uint8_t)KST(key); out->state_change_ms = v ? v->since : 0;
   out->n_confirm = v && KST(key) == SWIM_STATE_SUSPECT ? v->nconf : 0;
-  out->status = status_of(KST(key));
+  out->status = KINC(key) == 0 ? (uint8_t)SWIM_MEMBER_NONE : status_of(KST(key));   /* incarnation 0: never heard of it */
   if (x == o && node_at(s, r, o)->leaving && out->state == SWIM_STATE_ALIVE) out->status = SWIM_MEMBER_LEAVING;
   return SWIM_OK;
 }

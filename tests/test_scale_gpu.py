@@ -252,3 +252,85 @@ def test_library_exchange_processes_on_one_device(hip, oracle, tmp_path, world):
     assert tot[0] & 0xFFFFFFFFFFFFFFFF == ref.digest()
     assert tot[1] > 0                                                            # records crossed between the processes
     assert tot[2] == st["folds"] and tot[3] == st["refutes"] and tot[4] == sum(st["msgs_applied"])
+
+
+# ---- membership that changes: serf.Join, nodes nobody has heard of, estNumNodes() ---------------
+def test_cluster_grows_by_joins_parity(hip, oracle):
+    """3 members, 125 serf.Join calls one after the other, then a failure in the grown cluster: tick-by-tick digests while
+    the cluster grows (unknown-node path of aliveNode, join push-pull, fold of the new members into the base row, the
+    per-observer estNumNodes() in retransmitLimit and suspicionTimeout)."""
+    n = 128
+    kw = dict(n_nodes=n, n_initial=3, seed=2, view_cap=128, inbox_cap=512, fold_interval_ms=2000, watch_node=0, trace_ticks=0)
+    a, b = pair(hip, oracle, **kw)
+    for s in (a, b):
+        s.step_ms(1000)
+    for x in range(3, n):
+        for s in (a, b):
+            s.join(0, [x], via=x % 3 if x < 10 else x - 1)
+        for t in range(2):
+            a.step(1); b.step(1)
+            assert a.digest() == b.digest(), f"joiner {x}, tick {a.now()[0]}"
+    for s in (a, b):
+        s.step_ms(20000)
+    assert_same(a, b, "grown", keys=STAT_KEYS + ["joins", "join_failures"])
+    assert b.stats()["joins"] == n - 3 and b.stats()["folds"] == n - 3
+    assert a.poll_events() == b.poll_events()
+    assert np.array_equal(a.members(0, n - 1), b.members(0, n - 1)) and (b.members(0, n - 1)["status"] == abi.MEMBER_ALIVE).all()
+    for s in (a, b):
+        s.watch(0, 50); s.kill(0, [50]); s.step_ms(45000)
+    assert_same(a, b, "failure in the grown cluster")
+    ca, cb = a.census(0, 50), b.census(0, 50)
+    assert (ca.first_suspect_ms, ca.first_dead_ms, ca.all_dead_ms) == (cb.first_suspect_ms, cb.first_dead_ms, cb.all_dead_ms) and cb.all_dead_ms != abi.NONE
+
+
+def test_small_membership_in_a_large_id_space_parity(hip, oracle):
+    """4 members of a 4 096-id space: suspicionTimeout and retransmitLimit follow the member count (4 s .. 24 s), a join
+    through a dead member fails and leaves the node alone, a later join goes through."""
+    kw = dict(n_nodes=4096, n_initial=4, seed=3, watch_node=0, view_cap=16)
+    a, b = pair(hip, oracle, **kw)
+    for s in (a, b):
+        s.step_ms(2000); s.kill(0, [2])
+        s.join(0, [2000], via=2)                          # via is down
+        s.step_ms(1000)
+    assert_same(a, b, "failed join", keys=STAT_KEYS + ["joins", "join_failures"])
+    assert b.stats()["join_failures"] == 1 and b.view(0, 0, 2000).status == abi.MEMBER_NONE
+    for s in (a, b):
+        s.kill(0, [2000]); s.join(0, [2000, 3000], via=1)
+    for chunk in range(6):
+        a.step_ms(5000); b.step_ms(5000)
+        assert_same(a, b, f"+{5 * (chunk + 1)} s", keys=STAT_KEYS + ["joins", "join_failures"])
+    c = b.census(0, 2)
+    assert c.all_dead_ms != abi.NONE and 4000 <= c.first_dead_ms - c.first_suspect_ms <= 24000
+    assert b.view(0, 0, 3000).status == abi.MEMBER_ALIVE and b.view(0, 3000, 0).status == abi.MEMBER_ALIVE
+
+
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_restarts_with_incarnation_bump_parity(hip, oracle, n_shards):
+    """config #5's kill / rejoin: every second 3 % of a fixed population of 4 096 flips — the dead ones come back as fresh
+    processes (swim_inject_join: incarnation + 1, join push-pull through a random member)."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    n = 4096
+    kw = dict(n_nodes=n, seed=31, view_cap=256, queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+    if n_shards == 1:
+        a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    else:
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw)) for i in range(n_shards)], LocalExchange())
+    b = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    rng = np.random.default_rng(8)
+    dead = np.zeros(n, dtype=bool)
+    for sec in range(12):
+        flip = rng.choice(n, size=n * 3 // 100, replace=False)
+        kill, back = flip[~dead[flip]], flip[dead[flip]]
+        dead[flip] = ~dead[flip]
+        via = int(rng.choice(np.flatnonzero(~dead)))
+        for s in (a, b):
+            if len(kill): s.kill(0, kill.tolist())
+            if len(back): s.join(0, back.tolist(), via=via)
+            s.step_ms(1000)
+        a.sync()
+        assert a.digest() == b.digest(), f"after {sec + 1} s"
+    sa, sb = a.stats(), b.stats()
+    for k in ("joins", "join_failures", "refutes", "msgs_applied", "probe_failures", "packets_sent"):
+        assert sa[k] == sb[k], k
+    assert sb["joins"] > 50
+    a.close()
