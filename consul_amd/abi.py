@@ -24,6 +24,7 @@ PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
 F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK | F_TCP_FALLBACK
 SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
+INTENT_LEAVE, INTENT_PRUNE = 0x80000000, 0x40000000
 
 u8, u32, u64, i32 = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int32
 
@@ -35,7 +36,7 @@ class Config(C.Structure):
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
-        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "fold_interval_ms",
+        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device")] + [("seed", u64)]
 
@@ -46,7 +47,7 @@ class Derived(C.Structure):
         "retransmit_limit", "suspicion_k", "suspicion_min_ms", "suspicion_max_ms")] + [
         ("suspicion_timeout_ms", u32 * 8), ("node_scale_milli", u32),
         ("push_pull_scale", u32), ("push_pull_period_ticks", u32), ("packet_budget", u32),
-        ("view_cap", u32), ("fold_period_ticks", u32)]
+        ("view_cap", u32), ("fold_period_ticks", u32), ("reap_period_ticks", u32)]
 
 
 class Member(C.Structure):
@@ -92,7 +93,7 @@ class Stats(C.Structure):
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
-                ("view_drops", u64), ("view_evictions", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64)]
+                ("view_drops", u64), ("view_evictions", u64), ("intents_applied", u64), ("reaped", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64)]
 
 
 class XchgHandle(C.Structure):
@@ -134,6 +135,7 @@ PROTOTYPES = {
     "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_update": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
+    "swim_force_leave": (C.c_int, [SimP, u32, u32, u32, C.c_int, P(u32)]),
     "swim_inject_join": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u32]),
     "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
     "swim_set_loss": (C.c_int, [SimP, u32]),

@@ -22,7 +22,7 @@ enum {
   ST_REFUTES, ST_TIMEOUTS, ST_CONFIRMS, ST_EDGES, ST_EDGES_REMOTE,
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
-  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED, ST_JOINS, ST_JOIN_FAIL,
+  ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED, ST_JOINS, ST_JOIN_FAIL, ST_INTENTS, ST_REAPED,
   ST_COUNT
 };
 
@@ -74,7 +74,9 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 // (slot s of lane l at [s*NL + l]) so that lanes looking up the SAME subject — the hot case: one failure per
 // cluster — read consecutive 16-byte words.  Home slot by Fibonacci hashing, linear probing, backward-shift
 // deletion.  Only the owning lane writes its table (k_resolve, stimulus kernels, fold); everybody else reads.
-//   vt = {subject (VT_EMPTY = free), inc<<2|state, state-change ms, first accuser<<3 | confirmations}
+//   vt = {subject (VT_EMPTY = free), inc<<2|state, state-change ms,
+//         Suspect: first accuser<<4 | leaving<<3 | confirmations; otherwise: bit 0 = erased by serf's reaper or a prune
+//         (Dead / Left: status NONE), bit 1 = leaving (a leave intent was seen while the member was alive here)}
 //   vc = {2nd, 3rd, 4th confirmer, -}: only touched while a suspicion is being confirmed
 #define VT_EMPTY 0xFFFFFFFFu
 #define FOLD_POISON 0xFFFFFFFFu
@@ -123,6 +125,7 @@ struct SwDev {
   uint32_t* qbits;    // [NL/32] bit per lane: the node has something queued (exact; piggy-back orders are gated on it)
   // explicit views (see above) and what bounds them
   uint32_t VT, vt_shift, view_cap, fold_period;
+  uint32_t reap_period, reconnect_timeout_ms, tombstone_timeout_ms;   // serf's reaper (0 = off)
   uint4* vt;             // [VT][NL]
   uint4* vc;             // [VT][NL]
   uint4* vmeta;          // [NL] {explicit views held, how many of them are Suspect,
@@ -215,7 +218,7 @@ struct BeginPlan {
   uint32_t nb_ppreply;       // blocks answering the previous tick's pull requests
   uint32_t nb_carry;         // sharded runs: blocks moving carried broadcasts for other shards into their lists
   uint32_t nb_join;          // blocks doing the join push-pull of freshly started nodes (0 or 1)
-  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry
+  uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry, bit6 push-pull replies
 };
 #define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard */
 

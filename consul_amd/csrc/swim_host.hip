@@ -111,7 +111,7 @@ int64_t remaining_suspicion_ms(uint32_t n, uint32_t k, int64_t elapsed, int64_t 
 int validate(const swim_config* c) {
   if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
   if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
-  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 29)) return SWIM_ERANGE;   // first accuser<<3 | confirmations
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 28)) return SWIM_ERANGE;   // first accuser<<4 | leaving<<3 | confirmations
   if (c->view_cap > (1u << 20)) return SWIM_ERANGE;
   if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
   if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
@@ -202,6 +202,7 @@ extern "C" int swim_config_derive(const swim_config* c, swim_derived* d) {
   if (d->retransmit_limit > 255) return SWIM_ERANGE;     // transmits is an 8-bit field of the queue entry's meta word
   d->view_cap = c->view_cap ? c->view_cap : std::min<uint32_t>(c->n_nodes, 32);
   d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
+  d->reap_period_ticks = (c->reap_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -315,6 +316,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
   D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
+  D.reap_period = d.reap_period_ticks; D.reconnect_timeout_ms = cfg->reconnect_timeout_ms; D.tombstone_timeout_ms = cfg->tombstone_timeout_ms;
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
   DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
@@ -368,8 +370,9 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_probe = cdiv(probe_lanes, SW_BLOCK);
   pl.nb_gossip = cdiv(gossip_lanes, SW_BLOCK);
   pl.nb_pp = D.pp_period ? cdiv((uint64_t)cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period), SW_BLOCK) : 0;
-  pl.nb_ppreply = D.pp_period ? SW_PP_LISTS : 0;   // one block per request sub-list (4 blocks were a 40 us long pole every ProbeInterval)
-  pl.roles = D.pp_period ? 0x1F : 0xF;
+  pl.nb_ppreply = SW_PP_LISTS;                     // one block per request sub-list (4 blocks were a 40 us long pole every ProbeInterval);
+                                                   // also without scheduled push-pull: a join asks for a state exchange any time
+  pl.roles = (D.pp_period ? 0x1F : 0xF) | 0x40;
   const bool piggy = (cfg->flags & SWIM_F_PIGGYBACK) != 0;
   pl.nb_carry = D.n_shards > 1 ? 64 : 0;
   pl.nb_join = 1;                                   // swim_inject_join also restarts nodes of a fixed population
@@ -479,11 +482,23 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 // a fold tick carries four extra launches (scan + emit before k_begin, apply + count between k_deliver and k_resolve);
 // the captured tick graphs never contain one (swim_step / swim_tick_end_begin launch fold ticks eagerly)
 static bool fold_tick(const swim_sim* s, uint32_t tick) { return s->D.fold_period && tick && tick % s->D.fold_period == 0; }
-static void launch_begin(swim_sim* s, bool fold) {
+// ...and so does a reap tick (serf's reaper: one scan of the view tables before k_begin)
+static bool reap_tick(const swim_sim* s, uint32_t tick) { return s->D.reap_period && tick && tick % s->D.reap_period == 0; }
+static bool special_tick(const swim_sim* s, uint32_t tick) { return fold_tick(s, tick) || reap_tick(s, tick); }
+static uint32_t ticks_to_special(const swim_sim* s) {       // 0 = this tick is one; 0xFFFFFFFF = never
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint32_t per : { s->D.fold_period, s->D.reap_period })
+    if (per) best = std::min(best, (s->tick && s->tick % per == 0) ? 0u : per - s->tick % per);
+  return best;
+}
+#define SW_PLAIN_TICK 0xFFFFFFFFu   /* launch_begin / launch_end: an ordinary tick (what the captured graphs hold) */
+static void launch_begin(swim_sim* s, uint32_t tick) {
+  const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
   SwDev& D = s->D; hipStream_t st = s->stream;
   BeginPlan pl = s->plan;
   const size_t lds = (size_t)(D.Q + D.EQ) * SW_BLOCK * sizeof(uint4);
   const uint32_t grid = pl.nb_expire + pl.nb_pend + D.R * (pl.nb_probe + pl.nb_gossip) + pl.nb_ppreply + pl.nb_carry + pl.nb_join + D.R * pl.nb_pp;
+  if (tick != SW_PLAIN_TICK && reap_tick(s, tick)) hipLaunchKernelGGL(k_reap, dim3(cdiv((size_t)D.nloc * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   if (fold) {
     const size_t NL = (size_t)D.nloc * D.R, NT = (size_t)D.N * D.R;
     (void)hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st); (void)hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st);
@@ -500,7 +515,8 @@ static void launch_begin(swim_sim* s, bool fold) {
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
   }
 }
-static void launch_end(swim_sim* s, bool fold) {
+static void launch_end(swim_sim* s, uint32_t tick) {
+  const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
   { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
@@ -552,7 +568,7 @@ static int check_device_errors(swim_sim* s) {
 extern "C" int swim_tick_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
-  launch_begin(s, fold_tick(s, s->tick));
+  launch_begin(s, s->tick);
   s->in_tick = true; s->out_counts_valid = false; s->in_count = 0;
   return SWIM_OK;
 }
@@ -622,19 +638,19 @@ extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
 extern "C" int swim_tick_end_begin(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
-  const bool f0 = fold_tick(s, s->tick), f1 = fold_tick(s, s->tick + 1);
-  if (s->in_count == 0 && s->use_graphs && !s->profiling && !f0 && !f1) {
+  const bool plain = !special_tick(s, s->tick) && !special_tick(s, s->tick + 1);
+  if (s->in_count == 0 && s->use_graphs && !s->profiling && plain) {
     if (!s->graph_end_begin) {
       hipGraph_t g = nullptr;
       HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-      launch_end(s, false); launch_begin(s, false);
+      launch_end(s, SW_PLAIN_TICK); launch_begin(s, SW_PLAIN_TICK);
       HIPCK(s, hipStreamEndCapture(s->stream, &g));
       hipError_t e = hipGraphInstantiate(&s->graph_end_begin, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
     }
     HIPCK(s, hipGraphLaunch(s->graph_end_begin, s->stream));
-  } else { launch_end(s, f0); launch_begin(s, f1); }
+  } else { launch_end(s, s->tick); launch_begin(s, s->tick + 1); }
   advance(s, 1);
   s->out_counts_valid = false; s->in_count = 0;
   return SWIM_OK;
@@ -691,19 +707,18 @@ extern "C" int swim_xchg_step(swim_sim* s, uint32_t n) {
   if (!s->xchg_connected || s->in_tick) return SWIM_ESTATE;
   const bool use_graph = !s->profiling && s->use_graphs;
   for (uint32_t i = 0; i < n; i++) {
-    const bool fold = fold_tick(s, s->tick);
-    if (use_graph && !fold) {
+    if (use_graph && !special_tick(s, s->tick)) {
       if (!s->graph_xchg) {
         hipGraph_t g = nullptr;
         HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-        launch_begin(s, false); launch_xchg(s); launch_end(s, false);
+        launch_begin(s, SW_PLAIN_TICK); launch_xchg(s); launch_end(s, SW_PLAIN_TICK);
         HIPCK(s, hipStreamEndCapture(s->stream, &g));
         hipError_t e = hipGraphInstantiate(&s->graph_xchg, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "hipGraphInstantiate: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
       }
       HIPCK(s, hipGraphLaunch(s->graph_xchg, s->stream));
-    } else { launch_begin(s, fold); launch_xchg(s); launch_end(s, fold); }
+    } else { launch_begin(s, s->tick); launch_xchg(s); launch_end(s, s->tick); }
     advance(s, 1);
   }
   hipError_t e = hipGetLastError();
@@ -713,7 +728,7 @@ extern "C" int swim_xchg_step(swim_sim* s, uint32_t n) {
 extern "C" int swim_tick_end(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (!s->in_tick) return SWIM_ESTATE;
-  launch_end(s, fold_tick(s, s->tick));
+  launch_end(s, s->tick);
   s->in_tick = false; advance(s, 1);
   return SWIM_OK;
 }
@@ -724,7 +739,7 @@ extern "C" int swim_tick_end(swim_sim* s) {
 static int build_graph(swim_sim* s, int which, uint32_t ticks) {
   hipGraph_t g = nullptr;
   HIPCK(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-  for (uint32_t i = 0; i < ticks; i++) { launch_begin(s, false); launch_end(s, false); }
+  for (uint32_t i = 0; i < ticks; i++) { launch_begin(s, SW_PLAIN_TICK); launch_end(s, SW_PLAIN_TICK); }
   HIPCK(s, hipStreamEndCapture(s->stream, &g));
   hipError_t e = hipGraphInstantiate(&s->graph_exec[which], g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
@@ -743,12 +758,12 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
   uint32_t i = 0;
   while (i < n) {
     uint32_t adv = 1;
-    // ticks until the next fold tick (a fold tick itself is launched eagerly, with its extra kernels)
-    const uint32_t fp = s->D.fold_period, to_fold = !fp ? 0xFFFFFFFFu : fold_tick(s, s->tick) ? 0u : fp - s->tick % fp;
-    if (to_fold == 0) { launch_begin(s, true); launch_end(s, true); }
-    else if (use_graph && n - i >= SW_GRAPH_TICKS && to_fold >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
+    // ticks until the next fold / reap tick (such a tick is launched eagerly, with its extra kernels)
+    const uint32_t to_special = ticks_to_special(s);
+    if (to_special == 0) { launch_begin(s, s->tick); launch_end(s, s->tick); }
+    else if (use_graph && n - i >= SW_GRAPH_TICKS && to_special >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
     else if (use_graph) HIPCK(s, hipGraphLaunch(s->graph_exec[0], s->stream));
-    else { launch_begin(s, false); launch_end(s, false); }
+    else { launch_begin(s, SW_PLAIN_TICK); launch_end(s, SW_PLAIN_TICK); }
     advance(s, adv);
     i += adv;
   }
@@ -805,6 +820,19 @@ extern "C" int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, si
 extern "C" int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_REVIVE, r, ids, n); }
 extern "C" int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_LEAVE, r, ids, n); }
 extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_UPDATE, r, ids, n); }
+extern "C" int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint32_t* lt) {
+  if (!s) return SWIM_EINVAL;
+  if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
+  if (r >= s->D.R || origin >= s->D.N || node >= s->D.N) return SWIM_ERANGE;
+  touched(s);
+  hipLaunchKernelGGL(k_force_leave, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, origin,
+                     SWIM_INTENT_LEAVE | (prune ? SWIM_INTENT_PRUNE : 0u) | node, s->d_scratch);
+  uint32_t v = SWIM_NONE;
+  HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  if (lt) *lt = v;
+  return SWIM_OK;
+}
 extern "C" int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint32_t via) {
   int rc = check_ids(s, r, ids, n);
   if (rc) return rc;
@@ -901,11 +929,15 @@ static int gather_views(swim_sim* s, uint32_t r, uint32_t o, std::vector<std::pa
   for (uint32_t i = 0; i < n; i++) out.push_back({ w[4 + i * 8], HostView{ w[5 + i * 8], w[6 + i * 8], w[7 + i * 8] } });
   return SWIM_OK;
 }
-static void fill_member(swim_member* out, uint32_t x, uint32_t key, uint32_t since, uint32_t wpack) {
+// the Leaving mark of a view record: bit 3 of a Suspect view's word, bit 1 otherwise (swim_device.h)
+static bool view_leaving(uint32_t key, uint32_t w) { return SW_KST(key) == SWIM_STATE_SUSPECT ? ((w >> 3) & 1u) != 0 : ((w >> 1) & 1u) != 0; }
+// `erased`: serf's reaper (or a prune) removed the member from this observer's list
+static void fill_member(swim_member* out, uint32_t x, uint32_t key, uint32_t since, uint32_t wpack, bool erased = false, bool leaving = false) {
   memset(out, 0, sizeof *out); out->id = x;
   out->incarnation = SW_KINC(key); out->state = (uint8_t)SW_KST(key); out->state_change_ms = since;
   out->n_confirm = SW_KST(key) == SWIM_STATE_SUSPECT ? (uint8_t)(wpack & 7u) : 0;
-  out->status = SW_KINC(key) == 0 ? (uint8_t)SWIM_MEMBER_NONE : status_of(SW_KST(key));   // incarnation 0: never heard of it
+  out->status = (SW_KINC(key) == 0 || (erased && SW_KST(key) >= SWIM_STATE_DEAD)) ? (uint8_t)SWIM_MEMBER_NONE : status_of(SW_KST(key));   // incarnation 0: never heard of it
+  if (leaving && SW_KST(key) < SWIM_STATE_DEAD) out->status = SWIM_MEMBER_LEAVING;                     // a leave intent was seen
 }
 extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap)) return SWIM_EINVAL;
@@ -916,10 +948,11 @@ extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* ou
   int rc = n ? d2h(s, bk.data(), (const uint32_t*)D.bk + (size_t)r * D.N, n) : SWIM_OK;
   if (rc) return rc;
   uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
-  for (size_t x = 0; x < n; x++) fill_member(&out[x], (uint32_t)x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk[x], 0, 0);   // implicit views
+  // implicit views (a Failed / Left member of the base row was erased by every observer's reaper before it got there)
+  for (size_t x = 0; x < n; x++) fill_member(&out[x], (uint32_t)x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk[x], 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
   if ((rc = gather_views(s, r, o, ex))) return rc;
-  for (auto& e : ex) if (e.first < n) fill_member(&out[e.first], e.first, e.second.key, e.second.since, e.second.w);
+  for (auto& e : ex) if (e.first < n) fill_member(&out[e.first], e.first, e.second.key, e.second.since, e.second.w, e.first != o && (e.second.w & 1u), e.first != o && view_leaving(e.second.key, e.second.w));
   if (o < n && out[o].state == SWIM_STATE_ALIVE && (h.y & 0xFF)) out[o].status = SWIM_MEMBER_LEAVING;
   if (n_out) *n_out = D.N;
   return SWIM_OK;
@@ -931,10 +964,10 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   uint32_t bk = 0; int rc = d2h(s, &bk, (const uint32_t*)D.bk + (size_t)r * D.N + x, 1);
   if (rc) return rc;
   uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
-  fill_member(out, x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk, 0, 0);
+  fill_member(out, x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk, 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
   if ((rc = gather_views(s, r, o, ex))) return rc;
-  for (auto& e : ex) if (e.first == x) fill_member(out, x, e.second.key, e.second.since, e.second.w);
+  for (auto& e : ex) if (e.first == x) fill_member(out, x, e.second.key, e.second.since, e.second.w, x != o && (e.second.w & 1u), x != o && view_leaving(e.second.key, e.second.w));
   if (x == o && out->state == SWIM_STATE_ALIVE && (h.y & 0xFF)) out->status = SWIM_MEMBER_LEAVING;
   return SWIM_OK;
 }
@@ -1034,7 +1067,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->user_events_delivered = v[ST_UEV_DELIVERED]; out->user_events_deduped = v[ST_UEV_DEDUP];
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
-  out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
+  out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->intents_applied = v[ST_INTENTS]; out->reaped = v[ST_REAPED]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

@@ -54,8 +54,9 @@ __device__ __forceinline__ uint32_t now_ms(DevRef D, uint32_t t) { return t * D.
 // ---- an observer's explicit views (layout: swim_device.h) ------------------------------------------
 __device__ __forceinline__ uint32_t vt_home(DevRef D, uint32_t x) { return (x * 0x9E3779B1u) >> D.vt_shift; }
 __device__ __forceinline__ uint32_t vw_nconf(uint32_t w) { return w & 7u; }
-__device__ __forceinline__ uint32_t vw_conf0(uint32_t w) { return w >> 3; }
-__device__ __forceinline__ uint32_t vw_pack(uint32_t conf0, uint32_t nconf) { return (conf0 << 3) | nconf; }
+__device__ __forceinline__ uint32_t vw_conf0(uint32_t w) { return w >> 4; }
+__device__ __forceinline__ uint32_t vw_leaving(uint32_t w) { return (w >> 3) & 1u; }
+__device__ __forceinline__ uint32_t vw_pack(uint32_t conf0, uint32_t nconf, uint32_t leaving) { return (conf0 << 4) | (leaving << 3) | nconf; }
 // lane l's explicit view of subject x: its slot (entry in `e`), or NONE with `free_slot` = where it would go.
 // `first` = the home slot's entry when the caller fetched it already (together with other loads).
 __device__ __forceinline__ uint32_t vt_probe(DevRef D, size_t l, uint32_t x, uint4 first, uint4& e, uint32_t& free_slot) {
@@ -947,7 +948,7 @@ __device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, 
 #define SW_PP_LISTS 64
 __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   uint32_t t = *D.tick, li = t & 1u;
-  if (t == 0 || (t - 1) % D.P) return;              // requests only exist the tick after a boundary
+  if (t == 0) return;                               // (requests of scheduled exchanges exist the tick after a boundary; a join asks any time)
   BlockStats S; S.init(lds_stats);
   uint32_t sub_cap = D.pp_cap / SW_PP_LISTS, c_edges = 0, c_remote = 0, c_filt = 0;
   for (uint32_t sub = b; sub < SW_PP_LISTS; sub += nb) {
@@ -1045,7 +1046,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp
   b -= D.R * pl.nb_probe;
   if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
   b -= D.R * pl.nb_gossip;
-  if (b < pl.nb_ppreply) { if (pl.roles & 16u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); ROLE_DONE(4); return; }
+  if (b < pl.nb_ppreply) { if (pl.roles & 64u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); ROLE_DONE(4); return; }
   b -= pl.nb_ppreply;
   if (MULTI) {
     if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); ROLE_DONE(5); return; }
@@ -1473,7 +1474,7 @@ struct NodeCtx {
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
       if (nc <= 3) D.vc[ci] = b;
-      v.e.w = vw_pack(vw_conf0(v.e.w), nc); put(v);
+      v.e.w = vw_pack(vw_conf0(v.e.w), nc, vw_leaving(v.e.w)); put(v);
       arm_deadline(v, b.w);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       S.add(ST_CONFIRMS);
@@ -1485,7 +1486,7 @@ struct NodeCtx {
     if (!make(v, x)) return;
     broadcast(x, SWIM_MSG_SUSPECT, inc, from);
     set_view(v, inc, SWIM_STATE_SUSPECT, true);
-    v.e.w = vw_pack(from, 0);                              // newSuspicion(from, k, min, max)
+    v.e.w = vw_pack(from, 0, (v.e.w >> 1) & 1u);           // newSuspicion(from, k, min, max); a Leaving mark stays
     put(v);
     uint32_t n0 = 0;
     if (D.dyn) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
@@ -1500,9 +1501,11 @@ struct NodeCtx {
     if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
     if (x == o && !leaving) { refute(inc); return; }
     if (!make(v, x)) return;
+    // Left for a graceful leave (Node == From) and for a member a leave intent had marked Leaving here (serf handleNodeLeave)
+    const bool was_leaving = old == SWIM_STATE_SUSPECT ? vw_leaving(v.e.w) != 0 : ((v.e.w >> 1) & 1u) != 0;
     v.e.w = 0;
     broadcast(x, SWIM_MSG_DEAD, inc, from);
-    const uint32_t st = from == x ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+    const uint32_t st = (from == x || was_leaving) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
     set_view(v, inc, st, true);
     put(v);
     S.add(ST_APPL2);
@@ -1557,6 +1560,40 @@ struct NodeCtx {
     }
     qlen = nq; evqlen = ne;
   }
+  // serf handleNodeLeaveIntent for a force-leave (RemoveFailedNode): a member held Failed becomes Left (EventMemberLeave);
+  // with prune it is erased at once (EventMemberReap), also when it was Left already.  A member that is Alive or Suspect
+  // here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.
+  __device__ void leave_intent(uint32_t x, bool prune) {
+    if (x >= D.N || x == o) return;
+    View v = lookup(x);
+    const uint32_t key = v.e.y, st = SW_KST(key);
+    if (SW_KINC(key) == 0) return;
+    if (st < SWIM_STATE_DEAD) {                            // alive (or suspected) here: StatusLeaving — its death will read as a leave
+      if (!make(v, x)) return;
+      const uint32_t bit = st == SWIM_STATE_SUSPECT ? 8u : 2u;
+      if (v.fresh || !(v.e.w & bit)) {
+        v.e.w |= bit; v.fresh = false; put(v);
+        if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
+      }
+      return;
+    }
+    // erased already (serf no longer has the member; a Failed / Left member of the base row was erased before it got there)
+    if (v.slot != NONE ? (v.e.w & 1u) != 0 : D.reap_period != 0) return;
+    if (st == SWIM_STATE_LEFT && !prune) return;
+    if (!make(v, x)) return;
+    v.e.w = 0;
+    if (st == SWIM_STATE_DEAD) {
+      set_view(v, SW_KINC(key), SWIM_STATE_LEFT, true);
+      S.add(ST_INTENTS);
+      if (o == D.watch) record_event(SWIM_EVENT_MEMBER_LEAVE, x, 0, SW_KINC(key));
+    } else { v.fresh = false; need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
+    if (prune) {
+      v.e.w = 1u; S.add(ST_REAPED);
+      if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
+      if (o == D.watch) record_event(SWIM_EVENT_MEMBER_REAP, x, 0, SW_KINC(key));
+    }
+    put(v);
+  }
   // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
   __device__ void user_event(uint32_t id, uint32_t ltime) {
     if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
@@ -1570,8 +1607,11 @@ struct NodeCtx {
     if (n == 3) { S.add(ST_EVDROPS); return; }
     if (n == 0) sv.y = id; else if (n == 1) sv.z = id; else sv.w = id;
     n++; sv.x = (n << 30) | (ltime & 0x3FFFFFFFu); *slot = sv;
-    S.add(ST_UEV_DELIVERED);
-    if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
+    if (id & SWIM_INTENT_LEAVE) leave_intent(id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
+    else {
+      S.add(ST_UEV_DELIVERED);
+      if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
+    }
     uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
     queue_push(D.evq + l, D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
   }
@@ -2036,6 +2076,27 @@ __global__ void k_user_event(const SwDev* __restrict__ Dp, uint32_t r, uint32_t 
   }
   S.flush(D);
 }
+// serf.RemoveFailedNode[Prune] at the origin: stamp, Increment, handle the intent locally, queue it
+__global__ void k_force_leave(const SwDev* __restrict__ Dp, uint32_t r, uint32_t origin, uint32_t id, uint32_t* ltime_out) {
+  SW_DEV_BIND
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  if (threadIdx.x == 0) {
+    *ltime_out = NONE;
+    bool local = origin >= D.i0 && origin < D.i0 + D.nloc;
+    if (local && !(D.nw[(size_t)r * D.N + origin] & NW_DEAD)) {
+      NodeCtx c(D, S);
+      c.r = r; c.o = origin; c.k = origin - D.i0; c.t = *D.tick; c.l = (size_t)r * D.nloc + c.k; c.NL = (size_t)D.R * D.nloc;
+      c.load();
+      uint32_t lt = c.ev_clock; c.ev_clock++;
+      *ltime_out = lt;
+      c.user_event(id, lt);
+      c.store();
+      q_bit_lane(D, c.l, c.q_became_set(), c.q_became_clr());
+    }
+  }
+  S.flush(D);
+}
 // one node's self state, gathered for swim_node_info_get
 __global__ void k_gather_node(const SwDev* __restrict__ Dp, uint32_t r, uint32_t i, uint32_t* out) {
   SW_DEV_BIND
@@ -2095,6 +2156,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
       left--;
       const uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)a.x * 0x100000001B3ull) ^ ((uint64_t)o << 8);
       d += sw_h3(9, id, ((uint64_t)a.y << 32) | a.z);
+      if (SW_KST(a.y) >= SWIM_STATE_DEAD && (a.w & 1u)) d += sw_h3(16, id, 1);
+      if (SW_KST(a.y) == SWIM_STATE_SUSPECT ? vw_leaving(a.w) : (a.w >> 1) & 1u) d += sw_h3(17, id, 1);
       if (SW_KST(a.y) == SWIM_STATE_SUSPECT) {
         const uint32_t nc = vw_nconf(a.w); const uint4 cf = D.vc[(size_t)sl * NL + l];
         d += sw_h3(10, id, nc);
@@ -2154,6 +2217,36 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census_adhoc(const SwDev* __restri
   }
 }
 
+// serf.go handleReap (reap ticks only): at every observer the simulator acts for, a member Failed for longer than
+// ReconnectTimeout or Left for longer than TombstoneTimeout is erased (status NONE from then on) + EventMemberReap
+__global__ void __launch_bounds__(SW_BLOCK) k_reap(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (l >= NL) return;
+  uint32_t left = D.vmeta[l].x;
+  if (!left) return;
+  const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc), t = *D.tick, now = now_ms(D, t);
+  if (D.nw[(size_t)r * D.N + o] & NW_INERT) return;
+  uint32_t n = 0;
+  for (uint32_t sl = 0; sl < D.VT && left; sl++) {
+    uint4 e = D.vt[(size_t)sl * NL + l];
+    if (e.x == VT_EMPTY) continue;
+    left--;
+    const uint32_t st = SW_KST(e.y);
+    if (st < SWIM_STATE_DEAD || (e.w & 1u) || e.x == o) continue;
+    if (!(now - e.z > (st == SWIM_STATE_DEAD ? D.reconnect_timeout_ms : D.tombstone_timeout_ms))) continue;
+    D.vt[(size_t)sl * NL + l].w = e.w | 1u; n++;
+    const uint32_t wx = D.nw[(size_t)r * D.N + e.x];
+    if (NW_HAS_SLOT(wx)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wx)] = 1;
+    if (o == D.watch) {
+      uint32_t pos = atomicAdd(D.ev_cnt, 1u);
+      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, e.x, 0, SW_KINC(e.y) }; D.events[pos] = ev; }
+      else atomicOr(D.err, SW_ERR_EVENT_OVF);
+    }
+  }
+  if (n) atomicAdd(stat_ptr(D, ST_REAPED), (unsigned long long)n);
+}
+
 // =================================================================================================
 // fold (oracle: fold_census / fold_apply) — every fold_period ticks a subject on which ALL
 // acting observers of the whole population hold the same settled explicit view moves into the base row and its
@@ -2185,7 +2278,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
     bool have = a.x != VT_EMPTY;
     if (have && sl < D.VT) { left--; saw_self |= a.x == o; }
     const uint32_t g = r * D.N + a.x, st = SW_KST(a.y);
-    const bool bad = st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - a.z > D.gossip_to_dead_ms));
+    // (with the reaper on, a Failed / Left member stays an explicit view until serf has erased it here)
+    const bool bad = st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - a.z > D.gossip_to_dead_ms)) ||
+                     (D.reap_period && st >= SWIM_STATE_DEAD && sl < D.VT && !(a.w & 1u)) ||
+                     (st == SWIM_STATE_ALIVE && (a.w & 2u));       // (a Leaving mark is not something the base row can hold)
     // lanes of a wave mostly hold the same subject in the same slot (one failure per cluster): one atomic set per
     // distinct (subject, key, settled) triple present in the wave
     uint64_t todo = __ballot(have);

@@ -231,6 +231,9 @@ class ShardedSim:
         lt = [s.user_event(replica, origin, event_id) for s in self.sims]
         return min(lt)                      # non-owners answer NONE (0xFFFFFFFF)
 
+    def force_leave(self, replica: int, origin: int, node: int, prune: bool = False) -> int:
+        return min(s.force_leave(replica, origin, node, prune) for s in self.sims)
+
     def digest(self) -> int:
         return sum(s.digest() for s in self.sims) & 0xFFFFFFFFFFFFFFFF
 

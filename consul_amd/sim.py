@@ -188,6 +188,12 @@ class Sim:
         a, p, n = _ids(ids)
         self._ck("swim_inject_join", self._l.swim_inject_join(self._h, replica, p, n, via))
 
+    def force_leave(self, replica: int, origin: int, node: int, prune: bool = False) -> int:
+        """serf.RemoveFailedNode[Prune] called on `origin`; returns the intent's Lamport time."""
+        lt = abi.u32()
+        self._ck("swim_force_leave", self._l.swim_force_leave(self._h, replica, origin, node, int(prune), C.byref(lt)))
+        return lt.value
+
     def partition(self, replica: int, group_of_node: Sequence[int]):
         g = np.ascontiguousarray(group_of_node, dtype=np.uint8)
         if g.size != self.cfg.n_nodes:

@@ -128,6 +128,11 @@ typedef struct swim_config {
                                        more entry is ignored and counted in view_drops (never silent).  Sized
                                        like Serf's queue rule max(2N, 4096) at small N
                                        (internal/gossip/libserf/serf.go:25-27); 0 = min(n_nodes, 32)            */
+  /* serf's reaper (handleReap): every ReapInterval a member that has been Failed for longer than ReconnectTimeout, or Left
+   * for longer than TombstoneTimeout, is erased from the observer's member list (status NONE) and EventMemberReap is
+   * emitted (agent/consul/server_serf.go:279, timeouts agent/consul/config.go:640-641; the reference's tests run it at
+   * 250-300 ms: agent/consul/server_test.go:673-678).  0 = the reaper is off. */
+  uint32_t reap_interval_ms, reconnect_timeout_ms, tombstone_timeout_ms;
   uint32_t fold_interval_ms;        /* every so often a subject on which ALL acting observers agree (same
                                        incarnation and state, not Suspect, Dead for longer than
                                        GossipToTheDeadTime) is folded into the base row and its entries are
@@ -157,6 +162,7 @@ typedef struct swim_derived {
   uint32_t packet_budget;           /* UDPBufferSize - compoundHeaderOverhead               */
   uint32_t view_cap;                /* resolved swim_config.view_cap                         */
   uint32_t fold_period_ticks;       /* fold_interval_ms / quantum, rounded up (0 = off)      */
+  uint32_t reap_period_ticks;       /* reap_interval_ms / quantum, rounded up (0 = off)      */
 } swim_derived;
 
 /* one row of an observer's member list: serf.Member / memberlist.Node reduced to integers
@@ -233,6 +239,8 @@ typedef struct swim_stats_t {
   uint64_t view_drops;              /* rumours ignored because the observer already held view_cap explicit views */
   uint64_t view_evictions;          /* long-settled Dead/Left views a full table forgot to make room (memberlist
                                        resetNodes forgets a node dead for longer than GossipToTheDeadTime)         */
+  uint64_t intents_applied;         /* leave intents that turned a Failed member Left (swim_force_leave)          */
+  uint64_t reaped;                  /* (observer, member) pairs erased by the reaper or a prune                    */
   uint64_t joins;                   /* join push-pulls carried out (swim_inject_join); a join whose `via` cannot be reached
                                        is counted in join_failures (memberlist.Join returns an error)              */
   uint64_t join_failures;
@@ -332,6 +340,14 @@ int swim_inject_update(swim_sim* sim, uint32_t replica, const uint32_t* ids, siz
  * tick, does the join push-pull with `via` (pushPullNode(join=true): its state to via, via's back one tick later).
  * Everybody who hears the alive{} takes the aliveNode path for a node it has never heard of (NotifyJoin). */
 int swim_inject_join(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n, uint32_t via);
+/* serf.RemoveFailedNode / RemoveFailedNodePrune (agent/consul/client.go:272-274; `consul force-leave [-prune]`,
+ * agent/agent_endpoint_test.go:2524-2566, 2633-2677): `origin` broadcasts a Lamport-clocked leave intent on behalf of
+ * `node`; every member that holds `node` Failed turns it Left (EventMemberLeave), with prune also erases it at once
+ * (EventMemberReap).  Needs SWIM_F_SERF_EVENTS (the intent rides serf's broadcast queue and event-buffer dedupe).
+ * The Lamport time stamped on the intent is returned like swim_user_event's. */
+int swim_force_leave(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t node, int prune, uint32_t* ltime_out);
+#define SWIM_INTENT_LEAVE 0x80000000u   /* event id of a leave intent: SWIM_INTENT_LEAVE | prune << 30 | node */
+#define SWIM_INTENT_PRUNE 0x40000000u
 /* partition mask: nodes exchange packets only within the same group id (config #4) */
 int swim_inject_partition(swim_sim* sim, uint32_t replica, const uint8_t* group_of_node);
 int swim_set_loss(swim_sim* sim, uint32_t loss_q32);

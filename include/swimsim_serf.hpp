@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -161,6 +162,13 @@ class Cluster {
     uint64_t Seed = 1;
     uint32_t Device = 0;
     int EventBuffer = 512;
+    uint32_t Initial = 0;                  // members at t = 0 (0 = all Nodes); the others start with Serf::Join
+    uint32_t ViewCap = 0;                  // explicit views per member (0 = min(Nodes, 32))
+    // serf's reaper runs on the device for the whole pool (serf.Config.ReapInterval / ReconnectTimeout / TombstoneTimeout
+    // of the members; Consul: agent/consul/config.go:640-641).  ReapIntervalMs = 0: Members() applies the timeouts of the
+    // calling member's own Config on the host instead.
+    uint32_t ReapIntervalMs = 0, ReconnectTimeoutMs = 0, TombstoneTimeoutMs = 0;
+    uint32_t FoldIntervalMs = 0;
   };
   Cluster(const memberlist::Config& mc, const Options& o) : opts_(o) {
     check(swim_config_preset(&cfg_, SWIM_PRESET_LAN), "swim_config_preset");
@@ -173,6 +181,8 @@ class Cluster {
     cfg_.udp_buffer_size = (uint32_t)mc.UDPBufferSize; cfg_.push_pull_interval_ms = (uint32_t)mc.PushPullInterval.count();
     cfg_.queue_cap = o.QueueCap; cfg_.inbox_cap = o.InboxCap; cfg_.subject_cap = o.SubjectCap; cfg_.watch_node = o.WatchNode;
     cfg_.event_buffer = (uint32_t)o.EventBuffer; cfg_.flags |= SWIM_F_SERF_EVENTS;
+    cfg_.n_initial = o.Initial; cfg_.view_cap = o.ViewCap; cfg_.fold_interval_ms = o.FoldIntervalMs;
+    cfg_.reap_interval_ms = o.ReapIntervalMs; cfg_.reconnect_timeout_ms = o.ReconnectTimeoutMs; cfg_.tombstone_timeout_ms = o.TombstoneTimeoutMs;
     check(swim_config_derive(&cfg_, &derived_), "swim_config_derive");
     check(swim_create(&cfg_, &sim_), "swim_create");
   }
@@ -214,29 +224,31 @@ class Cluster {
 // One member's *serf.Serf.
 class Serf {
  public:
-  // serf.Create(conf): conf.NodeName must name a member of the pool ("node-<id>")
+  // serf.Create(conf): conf.NodeName must name a member of the pool ("node-<id>").  For an id that is not running (beyond
+  // Cluster::Options::Initial, or shut down earlier) this is a new process of that name: it starts with its first Join.
   static std::unique_ptr<Serf> Create(const Config& conf, std::shared_ptr<Cluster> pool, uint32_t id, uint32_t replica = 0) {
     if (!pool || id >= pool->config().n_nodes) throw Error("serf.Create: unknown member", SWIM_ERANGE);
     if (conf.UserEventSizeLimit > 9 * 1024) throw Error("serf.Create: user event size limit exceeds limit of 9216 bytes", SWIM_EINVAL);
     return std::unique_ptr<Serf>(new Serf(conf, std::move(pool), id, replica));
   }
 
-  // Members(): every member this node knows, with its serf status; failed/left members disappear once
-  // reaped (ReconnectTimeout / TombstoneTimeout, checked at ReapInterval granularity) — handleReap
+  // Members(): every member this node knows, with its serf status.  A member the reaper erased (handleReap: Failed for
+  // longer than ReconnectTimeout / Left for longer than TombstoneTimeout, looked at every ReapInterval), one that was
+  // pruned, and a node this member has never heard of are not listed.
   std::vector<Member> Members() {
     requireNotShutdown("Members");
     std::vector<swim_member> raw(pool_->config().n_nodes);
     size_t n = 0;
     check(swim_members(pool_->handle(), replica_, id_, raw.data(), raw.size(), &n), "swim_members");
+    const bool device_reaper = pool_->config().reap_interval_ms != 0;
     const int64_t now = pool_->Now().count();
     const int64_t reap_q = std::max<int64_t>(1, conf_.ReapInterval.count());
     std::vector<Member> out;
     for (size_t i = 0; i < n; i++) {
       const swim_member& r = raw[i];
       MemberStatus st = (MemberStatus)r.status;
-      if (removed_.count(r.id) && st != StatusAlive) continue;       // RemoveFailedNodePrune
-      if (forced_left_.count(r.id) && st == StatusFailed) st = StatusLeft;
-      if (st == StatusFailed || st == StatusLeft) {
+      if (st == StatusNone) continue;
+      if (!device_reaper && (st == StatusFailed || st == StatusLeft)) {   // the pool runs no reaper: this member's own timeouts
         int64_t limit = st == StatusFailed ? conf_.ReconnectTimeout.count() : conf_.TombstoneTimeout.count();
         int64_t checked = now / reap_q * reap_q;                     // the reaper only looks every ReapInterval
         if (checked - (int64_t)r.state_change_ms > limit) continue;
@@ -257,11 +269,25 @@ class Serf {
   int NumNodes() { return (int)Members().size(); }
   SerfState State() const { return state_; }
 
-  // Join: the pool starts converged, so every address is "contacted"; errors mirror serf.Join
+  // Join(existing, ignoreOld): serf.Join — a member that is not running yet (an id beyond Cluster::Options::Initial, or one
+  // that was shut down) starts and does the join push-pull with the first address that names a member ("node-<id>" or its
+  // 10.x.y.z[:port] address); returns how many of the addresses could be contacted, throws when none could (like serf).
   int Join(const std::vector<std::string>& existing, bool /*ignoreOld*/) {
     if (state_ == SerfShutdown) throw Error("Join: Serf can't Join after Shutdown", SWIM_ESTATE);
     if (state_ != SerfAlive) throw Error("Join: Serf can't Join after Leave or Shutdown", SWIM_ESTATE);
-    return (int)existing.size();
+    int contacted = 0; uint32_t via = SWIM_NONE;
+    for (auto& a : existing) {
+      uint32_t id;
+      if (!resolve(a, &id) || id == id_) continue;
+      swim_node_info ni;
+      if (swim_node_info_get(pool_->handle(), replica_, id, &ni) == SWIM_OK && ni.alive) { contacted++; if (via == SWIM_NONE) via = id; }
+    }
+    swim_node_info me; check(swim_node_info_get(pool_->handle(), replica_, id_, &me), "swim_node_info_get");
+    if (!me.alive) {                                    // a process that starts now
+      if (via == SWIM_NONE) throw Error("Join: failed to join any of the " + std::to_string(existing.size()) + " addresses", SWIM_ESTATE);
+      check(swim_inject_join(pool_->handle(), replica_, &id_, 1, via), "swim_inject_join");
+    }
+    return contacted;
   }
   // Leave: broadcast the intent (memberlist dead{Node==From} => StatusLeft at every peer)
   void Leave() {
@@ -292,8 +318,10 @@ class Serf {
     conf_.Tags = tags;
     check(swim_inject_update(pool_->handle(), replica_, &id_, 1), "swim_inject_update");   // memberlist.UpdateNode
   }
-  void RemoveFailedNode(const std::string& node) { forced_left_.insert({ idOf(node), true }); }
-  void RemoveFailedNodePrune(const std::string& node) { removed_.insert({ idOf(node), true }); }
+  // RemoveFailedNode / RemoveFailedNodePrune: a Lamport-clocked leave intent on behalf of `node`, gossiped to the pool
+  // (agent/consul/client.go:272-274); this member applies it at once
+  void RemoveFailedNode(const std::string& node) { forceLeave(node, false); }
+  void RemoveFailedNodePrune(const std::string& node) { forceLeave(node, true); }
   std::map<std::string, std::string> Stats() {
     swim_stats_t st; check(swim_stats(pool_->handle(), &st), "swim_stats");
     auto ms = Members();
@@ -321,6 +349,20 @@ class Serf {
   struct Fired { std::string name; std::vector<uint8_t> payload; bool coalesce; };
   Serf(const Config& c, std::shared_ptr<Cluster> p, uint32_t id, uint32_t r) : conf_(c), pool_(std::move(p)), id_(id), replica_(r) {
     if (conf_.NodeName.empty()) conf_.NodeName = Cluster::NodeName(id);
+  }
+  void forceLeave(const std::string& node, bool prune) {
+    requireNotShutdown("RemoveFailedNode");
+    uint32_t lt = 0;
+    check(swim_force_leave(pool_->handle(), replica_, id_, idOf(node), prune ? 1 : 0, &lt), "swim_force_leave");
+  }
+  // "node-7", "10.0.0.7" or "10.0.0.7:8301" -> 7
+  bool resolve(const std::string& a, uint32_t* id) const {
+    try {
+      if (a.rfind("node-", 0) == 0) { *id = (uint32_t)std::stoul(a.substr(5)); return *id < pool_->config().n_nodes; }
+      unsigned b0, b1, b2, b3;
+      if (std::sscanf(a.c_str(), "%u.%u.%u.%u", &b0, &b1, &b2, &b3) == 4 && b0 == 10) { *id = (b1 << 16) | (b2 << 8) | b3; return *id < pool_->config().n_nodes; }
+    } catch (...) {}
+    return false;
   }
   void requireNotShutdown(const char* what) const {
     if (state_ == SerfShutdown) throw Error(std::string(what) + ": Serf is shut down", SWIM_ESTATE);
@@ -359,7 +401,8 @@ class Serf {
           e.LTime = buf[i].ltime;
           if (it != catalog().end()) { e.Name = it->second.name; e.Payload = it->second.payload; e.Coalesce = it->second.coalesce; }
         } else {
-          MemberStatus st = e.Type == EventMemberFailed ? StatusFailed : e.Type == EventMemberLeave ? StatusLeft : StatusAlive;
+          MemberStatus st = e.Type == EventMemberFailed ? StatusFailed : e.Type == EventMemberLeave ? StatusLeft
+                          : e.Type == EventMemberReap ? StatusNone : StatusAlive;
           e.Members.push_back(makeMember(buf[i].node, st, buf[i].incarnation));
         }
         ch_.push_back(std::move(e));
@@ -372,7 +415,6 @@ class Serf {
   uint32_t id_, replica_;
   SerfState state_ = SerfAlive;
   std::deque<Event> ch_;
-  std::map<uint32_t, bool> removed_, forced_left_;
 };
 
 }  // namespace serf

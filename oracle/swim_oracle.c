@@ -164,7 +164,7 @@ int swim_config_preset(swim_config* c, int preset) {
 static int validate(const swim_config* c) {
   if (!c || c->abi_version != SWIM_ABI_VERSION) return SWIM_EINVAL;
   if (c->n_nodes < 2 || c->n_replicas < 1) return SWIM_EINVAL;
-  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 29)) return SWIM_ERANGE;
+  if ((uint64_t)c->n_nodes * c->n_replicas >= 0xFFFFFFFFull || c->n_nodes >= (1u << 28)) return SWIM_ERANGE;
   if (c->view_cap > (1u << 20)) return SWIM_ERANGE;
   if (!c->gossip_interval_ms || !c->probe_interval_ms || !c->probe_timeout_ms) return SWIM_EINVAL;
   if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
@@ -225,6 +225,7 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
   if (d->retransmit_limit > 255) return SWIM_ERANGE;       /* transmits is an 8-bit field */
   d->view_cap = c->view_cap ? c->view_cap : (c->n_nodes < 32 ? c->n_nodes : 32);
   d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
+  d->reap_period_ticks = (c->reap_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -239,7 +240,7 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
 
 /* one explicit view: what an observer knows about `subj` beyond the replica's base row */
-typedef struct { uint32_t subj, key, since, conf[CONF_MAX], n0; uint8_t nconf; } view_t;   /* n0 = estNumNodes() when the suspicion started */
+typedef struct { uint32_t subj, key, since, conf[CONF_MAX], n0; uint8_t nconf, reaped, leaving; } view_t;   /* n0 = estNumNodes() when the suspicion started; reaped = serf erased the member (handleReap / prune); leaving = a leave intent was seen while the member was alive here (serf StatusLeaving) */
 /* an observer's explicit views: open addressing (linear probing, backward-shift deletion), grown on demand, at most
  * cfg.view_cap entries (+1 for the node's view of itself).  Layout is private to this file: everything observable
  * (digest, census, members) is keyed by (observer, subject). */
@@ -550,7 +551,7 @@ static void awareness_delta(swim_sim* s, node_t* nd, int delta) {
 /* ------------------------------------------------------------------------------------------ */
 
 static void set_view(swim_sim* s, uint32_t r, uint32_t x, view_t* v, uint32_t inc, uint32_t st, int touch_since) {
-  v->key = KEY(inc, st);
+  v->key = KEY(inc, st); v->reaped = 0;
   if (touch_since) v->since = now_ms(s);
   uint32_t sl = s->node_slot[(size_t)r * s->N + x];
   if (sl != SWIM_NONE) { slot_t* t = &s->slots[(size_t)r * s->cfg.subject_cap + sl]; if (inc > t->max_inc) t->max_inc = inc; t->dirty = 1; }
@@ -591,7 +592,7 @@ static void alive_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
     return;
   }
   view_t* v = view_make(s, r, o, x); if (!v) return;
-  v->nconf = 0;                                           /* delete(m.nodeTimers, a.Node) */
+  v->nconf = 0; v->leaving = 0;                           /* delete(m.nodeTimers, a.Node); a newer life of the member is not leaving */
   uint32_t old = KST(key);
   broadcast(s, nd, x, SWIM_MSG_ALIVE, inc, upd);
   set_view(s, r, x, v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
@@ -636,11 +637,43 @@ static void dead_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t 
   if (!v && !(v = view_make(s, r, o, x))) return;
   v->nconf = 0;
   broadcast(s, nd, x, SWIM_MSG_DEAD, inc, from);
-  uint32_t st = (from == x) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+  /* Left for a graceful leave (Node == From) and for a member a leave intent had marked Leaving here (serf handleNodeLeave) */
+  uint32_t st = (from == x || v->leaving) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
+  v->leaving = 0;
   set_view(s, r, x, v, inc, st, 1);
   s->st.msgs_applied[SWIM_MSG_DEAD]++;
   if (o == s->cfg.watch_node && x != o)
     record_event(s, r, st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
+}
+
+/* serf.go handleNodeLeaveIntent for a force-leave (RemoveFailedNode): a member this observer holds Failed becomes Left
+ * (EventMemberLeave); with prune it is erased at once (EventMemberReap), also when it was Left already.  A member that is
+ * Alive or Suspect here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.  The Lamport
+ * ordering of the intent against the member's status time is not modelled. */
+static void leave_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, int prune) {
+  (void)nd;
+  if (x >= s->N || x == o) return;
+  view_t* v = view_ptr(s, r, o, x);
+  uint32_t key = v ? v->key : implicit_key(s, r, o, x), st = KST(key);
+  if (KINC(key) == 0) return;
+  if (st < SWIM_STATE_DEAD) {                              /* alive (or suspected) here: StatusLeaving — its death will read as a leave */
+    if (!v && !(v = view_make(s, r, o, x))) return;
+    if (!v->leaving) { v->leaving = 1; touch_slot(s, r, x); }
+    return;
+  }
+  /* erased already (serf no longer has the member; a Failed / Left member of the base row was erased before it got there) */
+  if (v ? v->reaped : s->d.reap_period_ticks != 0) return;
+  if (st == SWIM_STATE_LEFT && !prune) return;
+  if (!v && !(v = view_make(s, r, o, x))) return;
+  if (st == SWIM_STATE_DEAD) {
+    set_view(s, r, x, v, KINC(key), SWIM_STATE_LEFT, 1);
+    s->st.intents_applied++;
+    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_LEAVE, x, 0, KINC(key));
+  }
+  if (prune) {
+    v->reaped = 1; s->st.reaped++; touch_slot(s, r, x);
+    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_REAP, x, 0, KINC(key));
+  }
 }
 
 /* serf.go handleUserEvent + lamport.go Witness (Consul fires via server_ce.go:125-131 and
@@ -656,8 +689,11 @@ static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
   } else { sl->ltime = ltime; sl->n = 0; }
   if (sl->n == EV_PER_SLOT) { s->st.event_drops++; return; }
   sl->ids[sl->n++] = id;
-  s->st.user_events_delivered++;
-  if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
+  if (id & SWIM_INTENT_LEAVE) leave_intent(s, r, o, nd, id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
+  else {
+    s->st.user_events_delivered++;
+    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
+  }
   queue_push(s, nd->evq, &nd->evqlen, &nd->evqseq, s->cfg.event_queue_cap, 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
 }
 
@@ -1008,6 +1044,24 @@ static int edge_cmp(const void* a, const void* b) {
 /* sends what its own observers hold (emit_fold_record) with the tick's packets.               */
 /* ------------------------------------------------------------------------------------------ */
 static void dirty_all(swim_sim* s, uint32_t r);
+/* serf.go handleReap: every ReapInterval, at every observer the simulator acts for: Failed for longer than ReconnectTimeout
+ * or Left for longer than TombstoneTimeout => erased (status NONE from then on) + EventMemberReap */
+static void phase_reap(swim_sim* s) {
+  if (!s->d.reap_period_ticks || !s->tick || s->tick % s->d.reap_period_ticks) return;
+  uint32_t now = now_ms(s);
+  for (uint32_t r = 0; r < s->R; r++)
+    for (uint32_t k = 0; k < s->nloc; k++) {
+      uint32_t o = s->i0 + k; if (!acts(s, r, o)) continue;
+      vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
+      for (uint32_t i = 0; i < t->slots; i++) {
+        view_t* v = &t->e[i]; if (v->subj == V_EMPTY || v->reaped || v->subj == o) continue;
+        uint32_t st = KST(v->key);
+        if (st < SWIM_STATE_DEAD || !(now - v->since > (st == SWIM_STATE_DEAD ? s->cfg.reconnect_timeout_ms : s->cfg.tombstone_timeout_ms))) continue;
+        v->reaped = 1; s->st.reaped++; touch_slot(s, r, v->subj);
+        if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_REAP, v->subj, 0, KINC(v->key));
+      }
+    }
+}
 static int fold_tick(const swim_sim* s) { return s->d.fold_period_ticks && s->tick && s->tick % s->d.fold_period_ticks == 0; }
 static void fold_touch(swim_sim* s, uint32_t g) {
   if (s->f_ntouched == s->f_cap) { s->f_cap = s->f_cap ? s->f_cap * 2 : 256; s->f_touched = (uint32_t*)realloc(s->f_touched, (size_t)s->f_cap * 4); }
@@ -1025,14 +1079,18 @@ static void fold_census(swim_sim* s) {
       /* slot `slots` stands for the node's view of ITSELF when that is implicit (alive at its own incarnation) and not
        * what the base row says: it takes part in the census like an explicit view (there is nothing to free later) */
       for (uint32_t i = 0; i <= t->slots; i++) {
-        uint32_t subj, key, since = 0;
-        if (i < t->slots) { const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue; subj = v->subj; key = v->key; since = v->since; }
+        uint32_t subj, key, since = 0; int unreaped = 0;
+        if (i < t->slots) { const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue; subj = v->subj; key = v->key; since = v->since; unreaped = !v->reaped; }
         else { subj = s->i0 + k; key = KEY(nd->self_inc, SWIM_STATE_ALIVE); if (vt_find(t, subj) || key == s->base_key[(size_t)r * s->N + subj]) break; }
         uint32_t g = r * s->N + subj, st = KST(key);
         if (!s->f_cnt[g]++) { fold_touch(s, g); s->f_kmin[g] = s->f_kmax[g] = key; s->f_bad[g] = 0; }
         if (key < s->f_kmin[g]) s->f_kmin[g] = key;
         if (key > s->f_kmax[g]) s->f_kmax[g] = key;
         if (st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - since > s->cfg.gossip_to_dead_ms))) s->f_bad[g] = 1;
+        /* with the reaper on, a Failed / Left member stays an explicit view until serf has erased it here (the
+         * EventMemberReap must not be lost); in the base row it reads as erased */
+        if (s->d.reap_period_ticks && st >= SWIM_STATE_DEAD && unreaped) s->f_bad[g] = 1;
+        if (i < t->slots && t->e[i].leaving) s->f_bad[g] = 1;     /* a Leaving mark is not something the base row can hold */
       }
     }
   for (uint32_t i = 0; i < s->f_ntouched; i++) {
@@ -1264,6 +1322,7 @@ int swim_tick_begin(swim_sim* s) {
   for (uint32_t i = 0; i < s->cfg.n_shards; i++) s->out[i].n = 0;
   s->in.n = 0;
   fold_census(s);
+  phase_reap(s);
   phase_expire(s); phase_probe(s); phase_pushpull(s); phase_gossip(s);
   /* swim_debug_edges: what the roles emitted (orders excluded), then the carried broadcasts before the filter */
   s->last_edges.n = 0;
@@ -1443,6 +1502,20 @@ int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint3
   return SWIM_OK;
 }
 
+/* serf.RemoveFailedNode[Prune]: broadcast a leave intent on behalf of `node` (stamped with the origin's clock like any
+ * serf message, handled locally first, queued for gossip) */
+int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint32_t* lt) {
+  int rc = chk(s, r, &origin, 1); if (rc) return rc;
+  if (node >= s->N) return SWIM_ERANGE;
+  if (!(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
+  if (lt) *lt = SWIM_NONE;
+  if (!is_local(s, origin) || !s->gt_alive[(size_t)r * s->N + origin]) return SWIM_OK;
+  node_t* nd = node_at(s, r, origin);
+  uint32_t ltime = nd->ev_clock; nd->ev_clock++;
+  if (lt) *lt = ltime;
+  user_event(s, r, origin, nd, SWIM_INTENT_LEAVE | (prune ? SWIM_INTENT_PRUNE : 0u) | node, ltime);
+  return SWIM_OK;
+}
 static uint8_t status_of(uint32_t st) {
   return st == SWIM_STATE_DEAD ? SWIM_MEMBER_FAILED : st == SWIM_STATE_LEFT ? SWIM_MEMBER_LEFT : SWIM_MEMBER_ALIVE;
 }
@@ -1455,6 +1528,9 @@ int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_member* out)
   out->incarnation = KINC(key); out->state = (uint8_t)KST(key); out->state_change_ms = v ? v->since : 0;
   out->n_confirm = v && KST(key) == SWIM_STATE_SUSPECT ? v->nconf : 0;
   out->status = KINC(key) == 0 ? (uint8_t)SWIM_MEMBER_NONE : status_of(KST(key));   /* incarnation 0: never heard of it */
+  /* erased by serf's reaper (or a prune); a Failed / Left member of the base row was erased everywhere before it got there */
+  if (KST(key) >= SWIM_STATE_DEAD && x != o && (v ? v->reaped : s->d.reap_period_ticks != 0)) out->status = SWIM_MEMBER_NONE;
+  if (v && v->leaving && KST(key) < SWIM_STATE_DEAD && x != o) out->status = SWIM_MEMBER_LEAVING;   /* a leave intent was seen */
   if (x == o && node_at(s, r, o)->leaving && out->state == SWIM_STATE_ALIVE) out->status = SWIM_MEMBER_LEAVING;
   return SWIM_OK;
 }
@@ -1554,6 +1630,8 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
         const view_t* v = &t->e[i]; if (v->subj == V_EMPTY) continue;
         uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)v->subj * 0x100000001B3ull) ^ ((uint64_t)(s->i0 + k) << 8);
         d += h3(9, id, ((uint64_t)v->key << 32) | v->since);
+        if (v->reaped) d += h3(16, id, 1);
+        if (v->leaving) d += h3(17, id, 1);
         if (KST(v->key) == SWIM_STATE_SUSPECT) {
           d += h3(10, id, v->nconf);
           for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX; j++) d += h3(11 + j, id, v->conf[j]);

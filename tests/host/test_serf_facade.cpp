@@ -27,7 +27,10 @@ static serf::MemberStatus statusOf(const std::vector<serf::Member>& ms, const st
 }
 
 static void testLANReap() {
-  auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 3, 1, 8, 32, 8, 0, 1, 0, 512 });
+  // server_test.go:673-678: ReconnectTimeout 250 ms, TombstoneTimeout 250 ms, ReapInterval 300 ms — the pool's reaper runs on the device
+  serf::Cluster::Options o{ 3, 1, 8, 32, 8, 0, 1, 0, 512 };
+  o.ReapIntervalMs = 300; o.ReconnectTimeoutMs = 250; o.TombstoneTimeoutMs = 250;
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
   serf::Config c = serf::ConsulDefaultConfig();
   c.ReconnectTimeout = Duration(250); c.TombstoneTimeout = Duration(250); c.ReapInterval = Duration(300);
   auto s1 = serf::Serf::Create(c, pool, 0), s3 = serf::Serf::Create(c, pool, 2);
@@ -43,28 +46,74 @@ static void testLANReap() {
     if (ms.size() == 2 && statusOf(ms, "node-2") == serf::StatusNone) reaped = true;
   }
   EXPECT(sawFailed);
-  EXPECT(reaped);
-  serf::Event e; bool gotFailed = false;
-  while (s1->PollEvent(&e)) if (e.Type == serf::EventMemberFailed && e.Members[0].Name == "node-2") gotFailed = true;
-  EXPECT(gotFailed);
+  EXPECT(reaped);                                   // 3 -> 2 members (server_test.go:728-732)
+  serf::Event e; int gotFailed = 0, gotReap = 0;
+  while (s1->PollEvent(&e)) {
+    if (e.Type == serf::EventMemberFailed && e.Members[0].Name == "node-2") { gotFailed++; EXPECT(gotReap == 0); }
+    if (e.Type == serf::EventMemberReap && e.Members[0].Name == "node-2") gotReap++;     // lanEventHandler: server_serf.go:279
+  }
+  EXPECT(gotFailed == 1 && gotReap == 1);
   bool threw = false;
   try { s3->Join({ "x" }, false); } catch (const Error&) { threw = true; }
   EXPECT(threw);                                    // "Serf can't Join after Shutdown"
+  // a new process of the same name comes back (incarnation + 1) and is a member again for everybody
+  auto s3b = serf::Serf::Create(c, pool, 2);
+  EXPECT(s3b->Join({ "node-0" }, false) == 1);
+  pool->Advance(Duration(1000));
+  EXPECT(s1->Members().size() == 3 && statusOf(s1->Members(), "node-2") == serf::StatusAlive);
+  EXPECT(s3b->LocalMember().Incarnation == 2);
   std::printf("ok LANReap\n");
 }
 
 static void testForceLeaveAndPrune() {
   auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 16, 1, 8, 32, 8, 0, 2, 0, 512 });
   auto a1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0), a2 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 7);
+  auto a3 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 12);
   a2->Shutdown();
-  for (int i = 0; i < 200 && statusOf(a1->Members(), "node-7") != serf::StatusFailed; i++) pool->Advance(Duration(50));
+  for (int i = 0; i < 200 && (statusOf(a1->Members(), "node-7") != serf::StatusFailed || statusOf(a3->Members(), "node-7") != serf::StatusFailed); i++) pool->Advance(Duration(50));
   EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusFailed);   // agent_endpoint_test.go:2550
   a1->RemoveFailedNode("node-7");
-  EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusLeft);     // :2559-2565
+  EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusLeft);     // :2559-2565 — at once where it was called...
+  pool->Advance(Duration(1000));
+  EXPECT(statusOf(a3->Members(), "node-7") == serf::StatusLeft);     // ...and, the intent being gossiped, everywhere
+  serf::Event e; int leaves = 0;
+  while (a1->PollEvent(&e)) leaves += e.Type == serf::EventMemberLeave && e.Members[0].Name == "node-7";
+  EXPECT(leaves == 1);
   a1->RemoveFailedNodePrune("node-7");
   EXPECT(statusOf(a1->Members(), "node-7") == serf::StatusNone);     // :2668-2676 member erased
   EXPECT(a1->Members().size() == 15);
+  pool->Advance(Duration(1000));
+  EXPECT(a3->Members().size() == 15);
+  int reaps = 0;
+  while (a1->PollEvent(&e)) reaps += e.Type == serf::EventMemberReap && e.Members[0].Name == "node-7";
+  EXPECT(reaps == 1);
   std::printf("ok ForceLeave/Prune\n");
+}
+
+// agent/consul/server_test.go:509 TestServer_JoinLAN, client.go:222: members that start later join through a known one
+static void testJoinGrowsTheCluster() {
+  serf::Cluster::Options o{ 16, 1, 8, 64, 8, 0, 5, 0, 512 };
+  o.Initial = 3; o.ViewCap = 16; o.FoldIntervalMs = 1000;
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+  auto s1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0);
+  EXPECT(s1->Members().size() == 3);
+  std::vector<std::unique_ptr<serf::Serf>> late;
+  for (uint32_t id = 3; id < 16; id++) {
+    late.push_back(serf::Serf::Create(serf::ConsulDefaultConfig(), pool, id));
+    EXPECT(late.back()->Join({ id % 2 ? "node-0" : "10.0.0.1:8301" }, false) == 1);
+    pool->Advance(Duration(200));
+  }
+  pool->Advance(Duration(5000));
+  EXPECT(s1->Members().size() == 16 && s1->NumNodes() == 16);
+  EXPECT(late.back()->Members().size() == 16);
+  serf::Event e; int joins = 0;
+  while (s1->PollEvent(&e)) joins += e.Type == serf::EventMemberJoin;
+  EXPECT(joins == 13);                              // one EventMemberJoin per new member (server_serf.go:272)
+  bool threw = false;
+  try { auto lone = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 3); (void)lone; late[0]->Shutdown();
+        auto again = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 3); again->Join({ "node-99" }, false); } catch (const Error&) { threw = true; }
+  EXPECT(threw);                                    // no address could be contacted
+  std::printf("ok JoinGrowsTheCluster\n");
 }
 
 static void testGracefulLeave() {
@@ -114,7 +163,7 @@ static void testConfigPresets() {
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
-    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testGracefulLeave(); testUserEvent();
+    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;

@@ -334,3 +334,40 @@ def test_restarts_with_incarnation_bump_parity(hip, oracle, n_shards):
         assert sa[k] == sb[k], k
     assert sb["joins"] > 50
     a.close()
+
+
+# ---- serf's reaper and force-leave intents -------------------------------------------------------
+def test_reaper_and_force_leave_parity(hip, oracle):
+    """TestServer_LANReap / TestAgent_ForceLeave[Prune] shapes at 256 members, every tick compared: failures are reaped
+    after ReconnectTimeout (EventMemberReap, status NONE), a force-leave turns Failed into Left everywhere through a
+    gossiped Lamport-clocked intent, a prune erases at once; reaped members fold into the base row."""
+    kw = dict(n_nodes=256, seed=17, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=0, view_cap=32, event_queue_cap=8,
+              reap_interval_ms=1000, reconnect_timeout_ms=8000, tombstone_timeout_ms=3000, fold_interval_ms=2000, gossip_to_dead_ms=2000,
+              probe_interval_ms=200, probe_timeout_ms=100, gossip_interval_ms=100, suspicion_mult=2)
+    a, b = pair(hip, oracle, **kw)
+    for s in (a, b):
+        s.step_ms(1000); s.kill(0, [40, 41, 42]); s.leave(0, [60])
+    def lockstep(ms):
+        for _ in range(ms // a.derived.quantum_ms):
+            a.step(1); b.step(1)
+            assert a.digest() == b.digest(), f"tick {a.now()[0]}"
+    lockstep(4000)
+    assert b.view(0, 0, 40).status == abi.MEMBER_FAILED
+    for s in (a, b):
+        s.force_leave(0, 5, 40)                       # consul force-leave node-40, asked of member 5
+        s.force_leave(0, 9, 41, prune=True)           # consul force-leave -prune node-41
+    assert a.view(0, 5, 40).status == b.view(0, 5, 40).status == abi.MEMBER_LEFT
+    assert a.view(0, 9, 41).status == b.view(0, 9, 41).status == abi.MEMBER_NONE
+    lockstep(3000)
+    assert b.view(0, 200, 40).status == abi.MEMBER_LEFT and b.view(0, 200, 41).status == abi.MEMBER_NONE
+    lockstep(15000)
+    assert_same(a, b, "end", keys=STAT_KEYS + ["intents_applied", "reaped", "user_events_deduped"])
+    sb = b.stats()
+    assert sb["intents_applied"] >= 500 and sb["reaped"] >= 1000 and sb["folds"] >= 2
+    ea, eb = a.poll_events(), b.poll_events()
+    assert ea == eb
+    kinds = [(e[2], e[3]) for e in eb]
+    assert (abi.EVENT_MEMBER_REAP, 42) in kinds and (abi.EVENT_MEMBER_LEAVE, 40) in kinds and (abi.EVENT_MEMBER_REAP, 41) in kinds
+    assert (abi.EVENT_MEMBER_LEAVE, 60) in kinds and (abi.EVENT_MEMBER_REAP, 60) in kinds
+    ma, mb = a.members(0, 0), b.members(0, 0)
+    assert np.array_equal(ma, mb) and [int(mb[x]["status"]) for x in (40, 41, 42, 60)] == [abi.MEMBER_NONE] * 4
