@@ -109,16 +109,24 @@ struct Reader {
     Bytes v(p, p + n); p += n; return v;
   }
   std::string str() { Bytes v = raw(); return std::string(v.begin(), v.end()); }
-  void skip() {                                     // any value
+  // any value.  Packets come from a real, possibly remote node: every read is bounds-checked (u8/be16/... throw on a
+  // short buffer) and nesting is capped — a 64 KB packet of 0x91 bytes would otherwise recurse 64 K frames deep.
+  void skip(int depth = 0) {
+    if (depth > 32) throw DecodeError("msgpack nesting too deep");
+    if (left() < 1) throw DecodeError("truncated");
     uint8_t t = *p;
     if (t < 0x80 || t >= 0xe0 || t == 0xc0 || t == 0xc2 || t == 0xc3) { u8(); return; }
     if ((t & 0xE0) == 0xa0 || t == 0xd9 || t == 0xda || t == 0xdb || t == 0xc4 || t == 0xc5 || t == 0xc6) { raw(); return; }
-    if ((t & 0xF0) == 0x80 || t == 0xde || t == 0xdf) { size_t n = map(); for (size_t i = 0; i < 2 * n; i++) skip(); return; }
-    if ((t & 0xF0) == 0x90) { u8(); for (size_t i = 0; i < size_t(t & 0x0F); i++) skip(); return; }
-    if (t == 0xdc) { u8(); size_t n = be16(); for (size_t i = 0; i < n; i++) skip(); return; }
+    if ((t & 0xF0) == 0x80 || t == 0xde || t == 0xdf) { size_t n = map(); for (size_t i = 0; i < 2 * n; i++) skip(depth + 1); return; }
+    if ((t & 0xF0) == 0x90) { u8(); for (size_t i = 0; i < size_t(t & 0x0F); i++) skip(depth + 1); return; }
+    if (t == 0xdc) { u8(); size_t n = be16(); for (size_t i = 0; i < n; i++) skip(depth + 1); return; }
+    if (t == 0xdd) { u8(); size_t n = be32(); if (n > left()) throw DecodeError("truncated"); for (size_t i = 0; i < n; i++) skip(depth + 1); return; }
     if (t >= 0xcc && t <= 0xd3) { uint(); return; }
     if (t == 0xca) { u8(); be32(); return; }
     if (t == 0xcb) { u8(); be64(); return; }
+    // ext family: fixext 1/2/4/8/16, ext 8/16/32 — [type byte] + payload, skipped like go-msgpack does for unknown fields
+    if (t >= 0xd4 && t <= 0xd8) { u8(); size_t n = size_t(1) << (t - 0xd4); if (n + 1 > left()) throw DecodeError("truncated"); p += n + 1; return; }
+    if (t == 0xc7 || t == 0xc8 || t == 0xc9) { u8(); size_t n = t == 0xc7 ? u8() : t == 0xc8 ? be16() : be32(); if (n + 1 > left()) throw DecodeError("truncated"); p += n + 1; return; }
     throw DecodeError("unsupported msgpack type");
   }
 };
@@ -213,6 +221,17 @@ inline Ping decode_ping(const uint8_t* p, size_t n) {
   Ping m;
   decode_map(p, n, [&](const std::string& k, Reader& r) {
     if (k == "SeqNo") m.seq_no = uint32_t(r.uint()); else if (k == "Node") m.node = r.str();
+    else if (k == "SourceAddr") m.source_addr = r.raw(); else if (k == "SourcePort") m.source_port = uint16_t(r.uint());
+    else if (k == "SourceNode") m.source_node = r.str(); else return false;
+    return true;
+  });
+  return m;
+}
+inline IndirectPing decode_indirect_ping(const uint8_t* p, size_t n) {
+  IndirectPing m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) {
+    if (k == "SeqNo") m.seq_no = uint32_t(r.uint()); else if (k == "Target") m.target = r.raw(); else if (k == "Port") m.port = uint16_t(r.uint());
+    else if (k == "Node") m.node = r.str(); else if (k == "Nack") m.nack = r.boolean();
     else if (k == "SourceAddr") m.source_addr = r.raw(); else if (k == "SourcePort") m.source_port = uint16_t(r.uint());
     else if (k == "SourceNode") m.source_node = r.str(); else return false;
     return true;
@@ -354,7 +373,11 @@ inline Bytes to_packet(const std::vector<swim_edge>& rumours, const Naming& nm =
 // a packet written by the real node -> the rumour records to hand to swim_transport_write_to (edge.dst is left 0: the
 // call names the receiver).  Pings, acks and the other control messages carry no rumour and are counted in `control`;
 // names that are not "<prefix><id>" are counted in `foreign`.
-inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm = Naming(), size_t* control = nullptr, size_t* foreign = nullptr) {
+// A ping / indirect ping the real node sent: the bridge answers it on behalf of the virtual peer (BridgeTransport).
+struct Probe { bool indirect = false; uint32_t seq_no = 0; bool nack = false; std::string node; Bytes target; };
+struct UnsupportedPacket : DecodeError { using DecodeError::DecodeError; };   // compressMsg / encryptMsg: not decodable here
+inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm = Naming(), size_t* control = nullptr, size_t* foreign = nullptr,
+                                          std::vector<Probe>* probes = nullptr) {
   std::vector<swim_edge> out; size_t n_control = 0, n_foreign = 0;
   std::vector<Bytes> todo{ strip_crc(strip_label(packet, nullptr)) };
   while (!todo.empty()) {
@@ -379,7 +402,13 @@ inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm 
         uint32_t id = 0; for (size_t i = 0; i < u.payload.size() && i < 4; i++) id = id << 8 | u.payload[i];
         out.push_back(swim_edge{ 0, id, uint32_t(u.ltime), uint32_t(SWIM_MSG_USER) << 30 }); break;
       }
-      default: n_control++; break;                   // ping / indirect ping / ack / nack / push-pull / err
+      case kPing: { n_control++; if (probes) { Ping pg = decode_ping(body, n); Probe pr; pr.seq_no = pg.seq_no; pr.node = pg.node; probes->push_back(pr); } break; }
+      case kIndirectPing: { n_control++; if (probes) { IndirectPing ip = decode_indirect_ping(body, n); Probe pr; pr.indirect = true; pr.seq_no = ip.seq_no; pr.nack = ip.nack; pr.node = ip.node; pr.target = ip.target; probes->push_back(pr); } break; }
+      // memberlist's DefaultLANConfig has EnableCompression = true (Consul's default) and Consul may encrypt gossip: such a
+      // packet carries rumours this codec cannot see.  Losing them silently would be worse than refusing the packet.
+      case kCompress: throw UnsupportedPacket("compressMsg: configure the attached node with EnableCompression = false");
+      case kEncrypt: throw UnsupportedPacket("encryptMsg: gossip encryption is not supported by the bridge");
+      default: n_control++; break;                   // ack / nack / push-pull / err
     }
   }
   if (control) *control = n_control;
@@ -403,8 +432,15 @@ class BridgeTransport {
   int WriteTo(const Bytes& packet, const std::string& to) {
     uint32_t dst;
     if (!resolve(to, &dst)) return SWIM_EINVAL;
-    std::vector<swim_edge> recs = from_packet(packet, nm_, &control_seen_, &foreign_seen_);
-    if (recs.empty()) return SWIM_OK;                 // pings and acks: the simulator answers probes for the attached node
+    size_t control = 0, foreign = 0; std::vector<Probe> probes; std::vector<swim_edge> recs;
+    try { recs = from_packet(packet, nm_, &control, &foreign, &probes); }
+    catch (const UnsupportedPacket&) { unsupported_seen_++; return SWIM_EINVAL; }
+    control_seen_ += control; foreign_seen_ += foreign;
+    // probeNode of the real node: the virtual peer answers like handlePing / handleIndirectPing would — an ackResp when it
+    // (and, for an indirect ping, the target behind it) is running and in the real node's partition, a nackResp for a
+    // failed indirect ping that asked for one, silence otherwise (the real node's probe then times out, as it should)
+    for (const Probe& pr : probes) answer_probe(pr, dst);
+    if (recs.empty()) return SWIM_OK;
     return swim_transport_write_to(sim_, replica_, self_, dst, recs.data(), recs.size());
   }
   // Transport.PacketCh(): everything virtual peers sent to this node since the last call, one packet per sender and
@@ -412,6 +448,12 @@ class BridgeTransport {
   std::vector<Packet> Poll(size_t cap = 65536) {
     std::vector<swim_edge> got(cap); size_t n = 0;
     std::vector<Packet> out;
+    for (auto& a : acks_) {                            // answers to the real node's probes first
+      Bytes pkt = a.buf;
+      if (crc_) pkt = add_crc(pkt);
+      out.push_back(Packet{ add_label(pkt, label_), nm_.name_of(a.from_id), a.from_id });
+    }
+    acks_.clear();
     if (swim_transport_poll(sim_, replica_, self_, got.data(), got.size(), &n) != SWIM_OK) return out;
     for (size_t i = 0; i < n;) {
       size_t j = i; std::vector<swim_edge> batch;
@@ -424,10 +466,32 @@ class BridgeTransport {
     }
     return out;
   }
-  size_t control_messages_seen() const { return control_seen_; }
+  size_t control_messages_seen() const { return control_seen_; }     // accumulated over all WriteTo calls
   size_t foreign_names_seen() const { return foreign_seen_; }
+  size_t unsupported_packets_seen() const { return unsupported_seen_; }
+  size_t probes_answered() const { return probes_answered_; }
 
  private:
+  bool up_and_reachable(uint32_t id) const {
+    swim_node_info me, ni;
+    if (swim_node_info_get(sim_, replica_, self_, &me) != SWIM_OK || swim_node_info_get(sim_, replica_, id, &ni) != SWIM_OK) return false;
+    return ni.alive && ni.partition == me.partition;
+  }
+  void answer_probe(const Probe& pr, uint32_t dst) {
+    uint32_t named;
+    if (!pr.indirect) {
+      if (!pr.node.empty() && (!nm_.id_of(pr.node, &named) || named != dst)) return;      // handlePing: "got ping for unexpected node"
+      if (!up_and_reachable(dst)) return;
+      acks_.push_back(Packet{ encode(AckResp{ pr.seq_no, Bytes() }), std::string(), dst }); probes_answered_++;
+      return;
+    }
+    if (!up_and_reachable(dst)) return;                 // the relay itself is down: nothing comes back
+    uint32_t target = SWIM_NONE;
+    if (!(nm_.id_of(pr.node, &target)) && pr.target.size() == 4 && pr.target[0] == 10) target = uint32_t(pr.target[1]) << 16 | uint32_t(pr.target[2]) << 8 | pr.target[3];
+    const bool ok = target != SWIM_NONE && up_and_reachable(target);
+    if (ok) { acks_.push_back(Packet{ encode(AckResp{ pr.seq_no, Bytes() }), std::string(), dst }); probes_answered_++; }
+    else if (pr.nack) { acks_.push_back(Packet{ encode(NackResp{ pr.seq_no }), std::string(), dst }); probes_answered_++; }
+  }
   bool resolve(const std::string& to, uint32_t* id) const {
     if (nm_.id_of(to, id)) return true;
     unsigned a, b, c, d;
@@ -435,7 +499,8 @@ class BridgeTransport {
     return false;
   }
   swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_;
-  size_t control_seen_ = 0, foreign_seen_ = 0;
+  size_t control_seen_ = 0, foreign_seen_ = 0, unsupported_seen_ = 0, probes_answered_ = 0;
+  std::vector<Packet> acks_;                          // ackResp / nackResp waiting for the next Poll
 };
 
 }  // namespace wire

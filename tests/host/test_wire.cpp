@@ -154,11 +154,49 @@ int main() {
       CHECK(tr.WriteTo(add_label(add_crc(encode_suspect(Suspect{1, "node-20", "node-5"})), "dc1"), "10.0.0.7:8301") == 0);
       CHECK(tr.WriteTo(encode(Ping{1, "node-7", {}, 0, ""}), "node-7") == 0 && tr.control_messages_seen() == 1);
       CHECK(tr.WriteTo(suspect, "192.168.0.1:8301") == SWIM_EINVAL);
+      // a real node attached through the bridge probes its virtual peers — the bridge answers for them.
+      {
+        auto polled = tr.Poll();
+        bool got_ack = false;
+        for (const BridgeTransport::Packet& pk : polled) {
+          Bytes inner = strip_crc(strip_label(pk.buf, nullptr));
+          if (inner[0] == kAckResp) { AckResp a = decode_ack(inner.data() + 1, inner.size() - 1); got_ack = a.seq_no == 1 && pk.from == "node-7"; }
+        }
+        CHECK(got_ack && tr.probes_answered() == 1);                        // ping{SeqNo 1} to node-7 -> ackResp{SeqNo 1} from node-7
+        CHECK(tr.WriteTo(encode(Ping{2, "node-20", {}, 0, ""}), "node-20") == 0);   // node 20 is dead: no answer, the probe times out
+        CHECK(tr.WriteTo(encode(Ping{3, "node-8", {}, 0, ""}), "node-7") == 0);     // "got ping for unexpected node": dropped
+        IndirectPing ip; ip.seq_no = 4; ip.target = Bytes{10, 0, 0, 20}; ip.port = 8301; ip.node = "node-20"; ip.nack = true;
+        CHECK(tr.WriteTo(encode(ip), "node-7") == 0);                       // relay node-7 alive, target node-20 dead -> nackResp
+        ip.seq_no = 5; ip.target = Bytes{10, 0, 0, 8}; ip.node = "node-8";
+        CHECK(tr.WriteTo(encode(ip), "node-7") == 0);                       // relay and target alive -> ackResp
+        size_t acks = 0, nacks = 0;
+        for (const BridgeTransport::Packet& pk : tr.Poll()) {
+          Bytes inner = strip_crc(strip_label(pk.buf, nullptr));
+          if (inner[0] == kAckResp && decode_ack(inner.data() + 1, inner.size() - 1).seq_no == 5) acks++;
+          if (inner[0] == kNackResp) nacks++;
+          CHECK(!(inner[0] == kAckResp && decode_ack(inner.data() + 1, inner.size() - 1).seq_no == 2));
+        }
+        CHECK(acks == 1 && nacks == 1 && tr.control_messages_seen() == 5);   // counters accumulate over calls
+        // compressMsg / encryptMsg carry rumours this codec cannot see: refused, never swallowed
+        CHECK(tr.WriteTo(Bytes{kCompress, 0x81, 0xa4}, "node-7") == SWIM_EINVAL && tr.WriteTo(Bytes{kEncrypt, 1, 2, 3}, "node-7") == SWIM_EINVAL);
+        CHECK(tr.unsupported_packets_seen() == 2);
+      }
       CHECK(swim_step(sim, 2) == 0);
       CHECK(swim_view(sim, 0, 7, 20, &mv) == 0 && mv.state != SWIM_STATE_ALIVE);
       printf("backend %s\n", swim_backend());
       swim_destroy(sim);
     }
+  }
+  {   // Reader::skip() on hostile input — truncated map, deep nesting, ext types
+    auto throws = [](const Bytes& b) { try { decode_alive(b.data(), b.size()); } catch (const DecodeError&) { return true; } return false; };
+    CHECK(throws(Bytes{0x81, 0xa1, 'X'}));                                  // map of 1, unknown key, value missing: one byte past the buffer before
+    Bytes deep{0x81, 0xa1, 'X'}; deep.insert(deep.end(), 60000, 0x91); deep.push_back(0x01);
+    CHECK(throws(deep));                                                     // 60 000 nested fixarrays: depth cap, no stack overflow
+    Bytes ext{0x82, 0xa1, 'X', 0xd6, 0x05, 1, 2, 3, 4, 0xa4, 'N', 'o', 'd', 'e', 0xa1, 'n'};   // fixext4 under an unknown key is skipped
+    CHECK(decode_alive(ext.data(), ext.size()).node == "n");
+    Bytes arr32{0x82, 0xa1, 'X', 0xdd, 0, 0, 0, 2, 0x01, 0x02, 0xa4, 'N', 'o', 'd', 'e', 0xa1, 'm'};
+    CHECK(decode_alive(arr32.data(), arr32.size()).node == "m");
+    CHECK(throws(Bytes{0x81, 0xa1, 'X', 0xdd, 0xff, 0xff, 0xff, 0xff}));      // array32 claiming 4 G elements
   }
   if (failures) { printf("%d FAILED\n", failures); return 1; }
   printf("ALL PASSED\n");
