@@ -238,6 +238,11 @@ def main():
     ap.add_argument("--no-piggyback", action="store_true", help="ablation: SWIM_F_PIGGYBACK off (not memberlist's behaviour)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
+    ap.add_argument("--exchange", choices=("auto", "library", "rccl"), default="auto",
+                    help="N > 1: `library` = the library's own device-driven exchange (peer-mapped mailboxes over xGMI, no host round trip, "
+                         "no collective); `rccl` = split tick + RCCL all-gather / all-to-all from Python; `auto` = library, and rccl if the "
+                         "mailboxes cannot be set up or a peer's flag does not arrive")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the control group (gloo: several ranks on ONE device, tests)")
     args = ap.parse_args()
     if args.main_only:
         args.no_cpu_baseline = args.no_roofline = args.no_convergence = args.no_detection = args.no_config4 = True
@@ -257,16 +262,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
+    local_rank %= max(torch.cuda.device_count(), 1)      # (several ranks on one device: --dist-backend gloo)
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_exchange
+    on_dev = args.dist_backend == "nccl"
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_dev:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from consul_amd import lib
-    from consul_amd.dist import ShardedSim, TorchExchange
+    from consul_amd.dist import LibraryExchange, ShardedSim, TorchExchange
+    from consul_amd.sim import SwimError
     hip = lib.load()
     reps = args.replicas * world                       # weak scaling: replicas grow with the ranks
     # one failure per cluster => at most a couple of rumours queued per node: 4 queue slots (LDS per
@@ -283,18 +294,58 @@ def main():
                   flags=abi.F_DEFAULT & ~abi.F_PIGGYBACK if args.no_piggyback else abi.F_DEFAULT)
     victims = victims_for(args.seed, reps, args.nodes)
 
+    use_library = world > 1 and args.exchange in ("auto", "library")
+
+    def gather_handles(mine):                          # every rank's mailbox handle, by rank (plain bytes over the control group)
+        out = [None] * world
+        dist.all_gather_object(out, mine)
+        merged = {}
+        for d in out:
+            merged.update(d)
+        return [merged[r] for r in range(world)]
+
     def fresh():
         sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
-        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank)) if sharded else sim
+        if not sharded:
+            return sim
+        if use_library:
+            return ShardedSim(sim, LibraryExchange(gather_handles))
+        if not on_dev and world > 1:
+            raise SystemExit("--dist-backend gloo drives the control group only: use --exchange library for the records")
+        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank))
+
+    def allreduce_max(x: float) -> float:
+        t = torch.tensor([x], device="cuda" if on_dev else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_used = "library (peer-mapped mailboxes, device driven)" if use_library else "rccl all-gather + all-to-all per tick" if sharded else None
     sim = fresh()
     G = (sim.sim if sharded else sim).derived.gossip_period
-    sim.step(G); sim.sync()                            # first call builds the captured graphs
+    if use_library:
+        # every rank must take the same decision: a short probe run, then agree
+        ok = 1.0
+        try:
+            sim.step(G); sim.sync()
+        except (SwimError, OSError) as e:
+            print(f"[bench] library exchange unavailable on rank {rank}: {e}", file=sys.stderr)
+            ok = 0.0
+        ok = -allreduce_max(-ok)                       # min over ranks
+        if ok < 1.0:
+            if args.exchange == "library":
+                raise SystemExit("the library's device-driven exchange failed and --exchange library leaves no alternative")
+            sim.close()
+            use_library = False
+            exchange_used = "rccl all-gather + all-to-all per tick (the library's mailbox exchange could not be used: see stderr)"
+            sim = fresh()
+            sim.step(G); sim.sync()
+    else:
+        sim.step(G); sim.sync()                        # first call builds the captured graphs
     tq = time.perf_counter()
     sim.step((args.warmup - 1) * G if args.warmup > 1 else 0); sim.sync()
     quiescent_ms = 1000.0 * (time.perf_counter() - tq) / max(args.warmup - 1, 1)
@@ -308,9 +359,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = allreduce_max(dt)
     base = sim.sim if sharded else sim
     base_quantum = base.derived.quantum_ms
     census = [base.census(r, v) for r, v in enumerate(victims)]
@@ -335,7 +384,7 @@ def main():
                    "nodes_per_cluster": args.nodes, "replicas": reps, "fanout": args.fanout,
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
                    "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
-                   "parallelism": f"population sharded x{world}, all-to-all per tick" if sharded else "1 GPU"},
+                   "parallelism": f"population sharded x{world}, one exchange per tick: {exchange_used}" if sharded else "1 GPU"},
         # what the TIMED window happened to see (it may end before any suspicion runs out): see `detection`
         "timed_window_detection_ms_after_failure": detect_after_kill,
     }
@@ -352,11 +401,10 @@ def main():
         solo.sync(); barrier()
         ts = time.perf_counter()
         solo.step(args.steps * G); solo.sync(); barrier()
-        dts = torch.tensor([time.perf_counter() - ts], device="cuda", dtype=torch.float64)
-        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        dts = allreduce_max(time.perf_counter() - ts)
         solo.close()
-        line["replica_parallel"] = {"value": world * args.replicas * args.nodes * args.steps / float(dts.item()),
-                                    "unit": "node-rounds/s", "ms_per_step": 1000.0 * float(dts.item()) / args.steps,
+        line["replica_parallel"] = {"value": world * args.replicas * args.nodes * args.steps / dts,
+                                    "unit": "node-rounds/s", "ms_per_step": 1000.0 * dts / args.steps,
                                     "parallelism": f"{args.replicas} whole clusters per GPU x {world} GPUs, no data-path collective"}
 
     if rank == 0 and not sharded and not args.no_roofline:

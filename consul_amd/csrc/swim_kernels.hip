@@ -1305,7 +1305,8 @@ struct NodeCtx {
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
-  uint32_t dl_blk0 = 0;                               // the block's deadline bound as the kernel found it (0 = unknown: always lower it)
+  uint32_t dl_blk0 = 0;                               // the block's deadline bound as the kernel found it
+  uint32_t dl_new = NONE;                             // earliest deadline this lane armed (the caller lowers dl_blk with it)
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
   uint4 h0;
@@ -1425,7 +1426,8 @@ struct NodeCtx {
   __device__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
     const uint32_t dl = v.e.z + susp_timeout_n(D, n0, vw_nconf(v.e.w));
     need_vm();
-    if (dl < vm.z) { vm.z = dl; vm_dirty = true; if (dl < dl_blk0 || !dl_blk0) atomicMin(&D.dl_blk[l / SW_BLOCK], dl); }
+    if (dl < vm.z) { vm.z = dl; vm_dirty = true; }
+    if (dl < dl_new) dl_new = dl;                          // the block's bound is lowered once per block (k_resolve) / by the caller
   }
   __device__ void refute(uint32_t accused) {
     uint32_t inc = self_inc + 1;
@@ -1669,7 +1671,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(5
   if (threadIdx.x == 0) s_carry = 0;
   const uint32_t dl_blk0 = D.dl_blk[blockIdx.x];
   BlockStats S; S.init(lds_stats);
-  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
+  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0, dl_lane = NONE;
   bool q_set = false, q_clr = false;
   if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
   size_t NL = (size_t)D.R * D.nloc;
@@ -1678,20 +1680,21 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(5
     // the whole 64-byte line (count + first five messages) in one go, parked in the lane's LDS column
     // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
     // stay cache resident instead of pulling in the node's 64-byte message line)
-    // Something reached this block: count, message line and header of every lane are fetched together (one round
-    // trip instead of three dependent ones; the lines of lanes that got nothing are wasted bandwidth, not latency).
+    // (fetching message line and header of EVERY lane of a block that got something, to save a dependent round trip,
+    // was measured: no faster, more traffic — profiles/r02_ab_resolve_prefetch.txt)
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
     uint32_t cnt = D.in_cnt[l];
-    s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-    const uint4 hdr0 = D.hdr[l], vm0 = D.vmeta[l];
+    const uint4 vm0 = D.vmeta[l];
     if (cnt) {
+      s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
+      const uint4 hdr0 = D.hdr[l];
       D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
       if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
       const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
       NodeCtx n(D, S);
       n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
-      n.load(hdr0); n.vm = vm0; n.vm_have = true; n.dl_blk0 = dl_blk0;
+      n.load(hdr0); n.dl_blk0 = dl_blk0; n.vm = vm0; n.vm_have = true;
       bool have_last = false; uint64_t lhi = 0, llo = 0;
       const bool sorted = cnt >= SW_INBOX_SORT_MIN;
       uint32_t next_j = 0;
@@ -1734,11 +1737,18 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(5
         have_last = true; lhi = bhi; llo = blo;
       }
       n.store();
+      dl_lane = n.dl_new;
       c_pig = n.c_pig; c_sent01 = n.c_sent01; c_sent23 = n.c_sent23;
       q_set = n.q_became_set(); q_clr = n.q_became_clr();
     }
   }
   q_bits_wave(D, l, q_set, q_clr);
+  {   // suspicion timers armed by this block: one atomic per wave on the block's deadline bound (every lane of a cluster
+      // arms one within a few ticks of a failure: 256 same-address atomics per block serialised)
+    uint32_t m = dl_lane;
+    for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
+    if (sw_lane() == 0 && m < dl_blk0) atomicMin(&D.dl_blk[blockIdx.x], m);
+  }
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
@@ -1989,6 +1999,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
         c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 1);
       }
       c.store();
+      if (c.dl_new != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], c.dl_new);
       q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
     }
   }

@@ -13,7 +13,7 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswimsim.so")
+LIB_PATH = os.environ.get("SWIMSIM_LIB") or os.path.join(_HERE, "libswimsim.so")   # (SWIMSIM_LIB: A/B builds of the same HIP library)
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("swim_host.hip", "swim_kernels.hip", "swim_device.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "swimsim.h")
 

@@ -371,3 +371,21 @@ def test_reaper_and_force_leave_parity(hip, oracle):
     assert (abi.EVENT_MEMBER_LEAVE, 60) in kinds and (abi.EVENT_MEMBER_REAP, 60) in kinds
     ma, mb = a.members(0, 0), b.members(0, 0)
     assert np.array_equal(ma, mb) and [int(mb[x]["status"]) for x in (40, 41, 42, 60)] == [abi.MEMBER_NONE] * 4
+
+
+def test_bench_two_ranks_on_one_device_through_the_library_exchange(hip):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one rank per shard), with both ranks on this
+    box's one GPU: control group over gloo, records through the library's mailboxes.  One JSON line, n_gpus = 2."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "5", "--main-only", "--no-replica-leg",
+           "--replicas", "4", "--dist-backend", "gloo", "--exchange", "library"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 10 and "library" in d["config"]["parallelism"]
+    assert d["config"]["replicas"] == 8 and d["scaling"] == "weak"
