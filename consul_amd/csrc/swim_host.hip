@@ -38,6 +38,7 @@ struct swim_sim {
   std::vector<void*> allocs;
   uint32_t tick = 0;
   bool in_tick = false;
+  bool pristine = true;                // nothing has ever happened to this population (no stimulus of any kind): k_quiet may stand in for whole ticks
   uint64_t ticks_run = 0, rounds_run = 0;
   SwDev* d_D = nullptr;                // the descriptor the kernels read (device copy of D)
   uint32_t* d_last_cnt = nullptr;      // [n_shards] edge counts of the finished tick
@@ -472,6 +473,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
+  s->pristine = cfg->loss_q32 == 0 && !D.dyn && cfg->n_shards == 1;
   *out = s;
   return SWIM_OK;
 }
@@ -616,6 +618,7 @@ extern "C" int swim_activity(swim_sim* s, int* active) {
 // a host-side stimulus may fill queues behind the back of the activity word: raise it, and ignore the
 // caller's hint for the next tick (stimulus is replicated on every shard, so every shard does)
 static void touched(swim_sim* s) {
+  s->pristine = false;
   if (s->D.n_shards > 1) (void)hipMemsetD32Async((hipDeviceptr_t)s->D.act, 1, 1, s->stream);
   if (s->peer_act_host != 1) { (void)hipMemsetD32Async((hipDeviceptr_t)s->D.peer_act, 1, 1, s->stream); s->peer_act_host = 1; }
 }
@@ -756,6 +759,15 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
     if (rc) return rc;
   }
   uint32_t i = 0;
+  // A pristine population (see k_quiet) advances all but the last tick of the call in one launch.
+  if (s->pristine && use_graph && n >= 8 && !s->D.loss_q32 && !s->D.dyn && !(s->D.TQ % s->D.P == 0)) {
+    const uint32_t K = n - 1;
+    const size_t NL = (size_t)s->D.nloc * s->D.R;
+    hipLaunchKernelGGL(k_quiet, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, K);
+    hipLaunchKernelGGL(k_quiet_advance, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, K);
+    advance(s, K);
+    i = K;
+  }
   while (i < n) {
     uint32_t adv = 1;
     // ticks until the next fold / reap tick (such a tick is launched eagerly, with its extra kernels)
@@ -855,6 +867,7 @@ extern "C" int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
   if (r >= s->D.R || x >= s->D.N) return SWIM_ERANGE;
+  s->pristine = false;             // a watch slot wants its trace row every tick
   HIPCK(s, hipMemcpyAsync(s->d_scratch, &x, 4, hipMemcpyHostToDevice, s->stream));
   watch_ids(s, r, s->d_scratch, 1);
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
@@ -881,6 +894,7 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
 }
 extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
   if (!s) return SWIM_EINVAL;
+  if (q) s->pristine = false;
   if (s->D.loss_q32 != q) {       // the kernels read the descriptor from device memory: update it in place
     (void)hipStreamSynchronize(s->stream);
     s->D.loss_q32 = q;
@@ -1162,6 +1176,7 @@ static int attach(swim_sim* s, uint32_t r, uint32_t a) {
   if (r >= s->D.R || a >= s->D.N) return SWIM_ERANGE;
   uint64_t key = ((uint64_t)r << 32) | a;
   if (std::find(s->attached.begin(), s->attached.end(), key) != s->attached.end()) return SWIM_OK;
+  s->pristine = false;
   hipLaunchKernelGGL(k_attach, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, a);
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));

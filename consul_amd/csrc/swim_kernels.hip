@@ -1899,6 +1899,57 @@ __global__ void __launch_bounds__(SW_BLOCK) k_count_live(const SwDev* __restrict
 }
 
 // =================================================================================================
+// k_quiet — K ticks of a PRISTINE cluster in one launch.  A population in which nothing has ever happened (no stimulus
+// of any kind since swim_create, no packet loss, everybody a member from the start) cannot leave that state on its own:
+// every probe is acked in its own tick, no rumour exists, no timer runs, a push-pull moves a pull request and an empty
+// answer.  All that K such ticks change is each node's position in its probe order — and the counters.  (swim_step uses
+// this for all but the last tick of a call; the last one runs the five kernels, so every transient is where it would be.)
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_quiet(const SwDev* __restrict__ Dp, uint32_t K) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  const uint32_t t = *D.tick;
+  uint32_t c_probe = 0, c_quiet = 0, c_pp = 0;
+  if (l < NL) {
+    const uint32_t r = (uint32_t)(l / D.nloc), i = D.i0 + (uint32_t)(l % D.nloc), ch = i / D.CH;
+    const uint32_t gph = ch % D.G, pph = (ch / D.G) % D.P;
+    // gossip(): "no broadcasts" in every tick the node is due
+    { const uint32_t first = (gph + D.G - t % D.G) % D.G; if (first < K) c_quiet = (K - first + D.G - 1) / D.G; }
+    // probe(): walk the shuffled list (self is skipped, a wrap reshuffles); every ping is acked (awareness stays 0)
+    uint2 h = D.ph[l];
+    uint32_t cursor = h.x, epoch = p_epoch(h.y);
+    for (uint32_t tt = (pph + D.P - t % D.P) % D.P; tt < K; tt += D.P) {
+      uint32_t num_check = 0;
+      while (num_check < D.N) {
+        if (cursor >= D.N) { epoch = (epoch + 1) & 0xFFFFu; cursor = 0; num_check++; continue; }
+        const uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
+        if (c == i) { num_check++; continue; }
+        c_probe++; break;
+      }
+    }
+    if (cursor != h.x || epoch != p_epoch(h.y)) D.ph[l] = make_uint2(cursor, p_pack(epoch, p_aw(h.y), 0, 0));
+    // pushPull: node i is due in tick (i mod period), grouped to the probe-interval boundary before it: a pull request goes
+    // out (one edge), the peer's answer is empty
+    if (D.pp_period) {
+      const uint32_t per = D.pp_period, grp = D.P < per ? D.P : per;
+      for (uint32_t tb = (t + D.P - 1) / D.P * D.P; tb < t + K; tb += D.P)
+        c_pp += ((i % per) + per - (tb % per)) % per < grp;
+    }
+  }
+  uint32_t v0 = c_probe, v1 = c_quiet, v2 = c_pp;
+  for (int off = 32; off; off >>= 1) { v0 += __shfl_down(v0, off); v1 += __shfl_down(v1, off); v2 += __shfl_down(v2, off); }
+  if (sw_lane() == 0) {
+    if (v0) { atomicAdd(stat_ptr(D, ST_PROBES), (unsigned long long)v0); atomicAdd(stat_ptr(D, ST_ACKS), (unsigned long long)v0); }
+    if (v1) atomicAdd(stat_ptr(D, ST_QUIESCENT), (unsigned long long)v1);
+    if (v2) { atomicAdd(stat_ptr(D, ST_PUSHPULLS), (unsigned long long)v2); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)v2); }
+  }
+}
+__global__ void k_quiet_advance(const SwDev* __restrict__ Dp, uint32_t K) {
+  SW_DEV_BIND
+  if (threadIdx.x == 0 && blockIdx.x == 0) *D.tick += K;
+}
+
+// =================================================================================================
 // initialisation, stimulus, digest
 // =================================================================================================
 __global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
