@@ -66,6 +66,8 @@ enum { SWIM_EVENT_MEMBER_JOIN = 0, SWIM_EVENT_MEMBER_LEAVE = 1, SWIM_EVENT_MEMBE
  * (config.go upstream; the six Consul-exposed knobs are corroborated in-tree at
  * agent/config/runtime.go:1285-1427) */
 enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
+/* (SWIM_PRESET_WAN is memberlist's DefaultWANConfig: GossipNodes = 4.  Consul's own WAN pool overrides it with the LAN
+ * value 3, agent/config/default.go:88 — set gossip_nodes = 3 for that.) */
 
 /* config flags */
 #define SWIM_F_BUDDY_SUSPECT  0x1u /* probeNode: ping+suspect compound to a non-alive target  */

@@ -18,6 +18,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without a GPU skips the gpu-marked tests instead of failing them with SWIM_ENODEV."""
+    if os.path.exists("/dev/kfd"):
+        return
+    skip = pytest.mark.skip(reason="no AMD GPU here (/dev/kfd missing): run on the MI355X box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The plain-C checker (oracle/), built on demand."""
