@@ -531,7 +531,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (D.flags & SWIM_F_PIGGYBACK) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (D.flags & SWIM_F_PIGGYBACK) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));

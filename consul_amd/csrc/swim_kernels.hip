@@ -1305,7 +1305,6 @@ struct NodeCtx {
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
-  uint32_t dl_blk0 = 0;                               // the block's deadline bound as the kernel found it
   uint32_t dl_new = NONE;                             // earliest deadline this lane armed (the caller lowers dl_blk with it)
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
@@ -1657,105 +1656,140 @@ __device__ __attribute__((noinline)) void inbox_heapsort(uint32_t* a, uint32_t n
 }
 #define SW_INBOX_SORT_MIN 12      /* from this many messages on the inbox is sorted rather than searched */
 
-// (five waves per SIMD instead of the four the register allocator would settle for: the kernel is a chain of dependent
-// memory round trips, and it is the number of lanes in flight that hides them)
-__global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) k_resolve(const SwDev* __restrict__ Dp) {
+// A tile of SW_RTILE node blocks per workgroup.  Who got something this tick is sparse (a fifth of the nodes while a
+// rumour saturates a cluster, far fewer otherwise) and a lane's work is a chain of dependent memory round trips: lanes
+// that map 1:1 to nodes leave most of every wave idle through the whole chain.  So the workgroup first compacts the
+// tile's receivers (one coalesced read of the count words, wave ballots, a 16-entry prefix in LDS: ascending node order,
+// no atomics), then walks the compact list 256 at a time with full waves.  Everything indexed by node block (in_any,
+// dl_blk, the carry areas k_deliver drains) keeps that index.
+// (five waves per SIMD instead of the four the register allocator would settle for: it is the number of lanes in flight
+// that hides the round trips)
+#ifndef SW_RTILE
+#define SW_RTILE 4
+#endif
+#ifndef SW_RESOLVE_WAVES
+#define SW_RESOLVE_WAVES 5
+#endif
+__global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
   __shared__ uint32_t lds_stats[ST_COUNT];
-  __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
+  __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
   __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
-  if (D.fast_blocks) {                     // nothing reached this block of nodes: one word and out
-    if (!D.in_any[blockIdx.x]) return;
+  const uint32_t nb0 = blockIdx.x * SW_RTILE;
+  if (D.fast_blocks) {                     // nothing reached this tile: a few words and out
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t sb = 0; sb < SW_RTILE; sb++) any |= nb0 + sb < D.NB ? D.in_any[nb0 + sb] : 0u;
+    if (!any) return;
   }
-  if (threadIdx.x == 0) s_carry = 0;
-  const uint32_t dl_blk0 = D.dl_blk[blockIdx.x];
+  if (threadIdx.x < SW_RTILE) { s_carry[threadIdx.x] = 0; s_dl[threadIdx.x] = NONE; }
   BlockStats S; S.init(lds_stats);
-  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0, dl_lane = NONE;
-  bool q_set = false, q_clr = false;
-  if (D.fast_blocks && threadIdx.x == 0) D.in_any[blockIdx.x] = 0;
-  size_t NL = (size_t)D.R * D.nloc;
-  size_t l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
-  if (l < NL) {
-    // the whole 64-byte line (count + first five messages) in one go, parked in the lane's LDS column
-    // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
-    // stay cache resident instead of pulling in the node's 64-byte message line)
-    // (fetching message line and header of EVERY lane of a block that got something, to save a dependent round trip,
-    // was measured: no faster, more traffic — profiles/r02_ab_resolve_prefetch.txt)
-    const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
-    uint32_t cnt = D.in_cnt[l];
-    const uint4 vm0 = D.vmeta[l];
-    if (cnt) {
-      s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-      const uint4 hdr0 = D.hdr[l];
-      D.in_cnt[l] = 0;
-#define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
-      if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
-      const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-      NodeCtx n(D, S);
-      n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = *D.tick; n.l = l; n.NL = NL;
-      n.load(hdr0); n.dl_blk0 = dl_blk0; n.vm = vm0; n.vm_have = true;
-      bool have_last = false; uint64_t lhi = 0, llo = 0;
-      const bool sorted = cnt >= SW_INBOX_SORT_MIN;
-      uint32_t next_j = 0;
-      if (sorted) {                                  // the five messages of the line join the row (it has room for all C), then one sort
-        uint32_t* row = D.inbox2 + l * D.C2 * 3;
-        for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
-        inbox_heapsort(row, cnt);
-      }
-      for (;;) {
-        bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
-        if (sorted) {
-          while (next_j < cnt && !have) {            // ascending; a duplicate (same key as the one before) is applied once
-            const uint32_t* m = row2 + next_j * 3; next_j++;
-            best = make_uint4(0, m[0], m[1], m[2]); edge_key(best, bhi, blo);
-            have = !(have_last && bhi == lhi && blo == llo);
-          }
-        } else
-        for (uint32_t j = 0; j < cnt; j++) {
-          uint4 e;                                   // {-, subject, inc, meta}
-          if (j < SW_INBOX_FAST) { uint32_t w = 1 + 3 * j; e = make_uint4(0, IN_WORD(w), IN_WORD(w + 1), IN_WORD(w + 2)); }
-          else { const uint32_t* m = row2 + (j - SW_INBOX_FAST) * 3; e = make_uint4(0, m[0], m[1], m[2]); }
-          uint64_t hi, lo; edge_key(e, hi, lo);
-          if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;
-          if (!have || hi < bhi || (hi == bhi && lo < blo)) { have = true; bhi = hi; blo = lo; best = e; }
-        }
-        if (!have) break;
-        uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
-        if (best.y == SWIM_SUBJECT_PIGGY)
-          n.piggyback(best.z, type, &s_carry, D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + blockIdx.x) * D.carry_cap, lds_meta);
-        else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
-          uint32_t li = (n.t + 1) & 1u, sub = blockIdx.x % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
-          uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
-          if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
-          else atomicOr(D.err, SW_ERR_PEND_OVF);
-        }
-        else if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
-        else if (type == SWIM_MSG_SUSPECT) n.suspect_node(best.y, best.z, from);
-        else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
-        else n.user_event(best.y, best.z);
-        have_last = true; lhi = bhi; llo = blo;
-      }
-      n.store();
-      dl_lane = n.dl_new;
-      c_pig = n.c_pig; c_sent01 = n.c_sent01; c_sent23 = n.c_sent23;
-      q_set = n.q_became_set(); q_clr = n.q_became_clr();
+  const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)nb0 * SW_BLOCK;
+  // ---- the tile's receivers, compacted in ascending node order
+  uint32_t cnts[SW_RTILE];
+#pragma unroll
+  for (uint32_t sb = 0; sb < SW_RTILE; sb++) {
+    const size_t l = l0 + sb * SW_BLOCK + threadIdx.x;
+    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[nb0 + sb])) ? D.in_cnt[l] : 0u;
+    const uint64_t m = __ballot(cnts[sb] != 0);
+    if (sw_lane() == 0) s_wcnt[sb * (SW_BLOCK / 64) + threadIdx.x / 64] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  uint32_t n_act = 0;
+#pragma unroll
+  for (uint32_t sb = 0; sb < SW_RTILE; sb++) {
+    uint32_t base = 0;
+    for (uint32_t j = 0; j < SW_RTILE * (SW_BLOCK / 64); j++) { const uint32_t c = s_wcnt[j]; n_act += sb == 0 ? c : 0; base += j < sb * (SW_BLOCK / 64) + threadIdx.x / 64 ? c : 0; }
+    const uint64_t m = __ballot(cnts[sb] != 0);
+    if (cnts[sb]) {
+      const uint32_t c = cnts[sb] > 0x3FFFFFu ? 0x3FFFFFu : cnts[sb];
+      s_list[base + (uint32_t)__popcll(m & ((1ull << sw_lane()) - 1))] = (c << 10) | (sb * SW_BLOCK + threadIdx.x);
     }
   }
-  q_bits_wave(D, l, q_set, q_clr);
-  {   // suspicion timers armed by this block: one atomic per wave on the block's deadline bound (every lane of a cluster
-      // arms one within a few ticks of a failure: 256 same-address atomics per block serialised)
-    uint32_t m = dl_lane;
-    for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
-    if (sw_lane() == 0 && m < dl_blk0) atomicMin(&D.dl_blk[blockIdx.x], m);
+  if (D.fast_blocks && threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) D.in_any[nb0 + threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
+  const uint32_t t_now = *D.tick;
+  for (uint32_t a0 = 0; a0 < n_act; a0 += SW_BLOCK) {
+    if (a0 + threadIdx.x >= n_act) continue;
+    const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;
+    uint32_t cnt = ent >> 10;
+    const size_t l = l0 + (ent & 1023u);
+    // the whole 64-byte line (first five messages) in one go, parked in the lane's LDS column
+    // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
+    // stay cache resident instead of pulling in the node's 64-byte message line)
+    const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
+    s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
+    const uint4 hdr0 = D.hdr[l];
+    const uint4 vm0 = D.vmeta[l];
+    D.in_cnt[l] = 0;
+#define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
+    if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
+    const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
+    NodeCtx n(D, S);
+    n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
+    n.load(hdr0); n.vm = vm0; n.vm_have = true;
+    bool have_last = false; uint64_t lhi = 0, llo = 0;
+    const bool sorted = cnt >= SW_INBOX_SORT_MIN;
+    uint32_t next_j = 0;
+    if (sorted) {                                  // the five messages of the line join the row (it has room for all C), then one sort
+      uint32_t* row = D.inbox2 + l * D.C2 * 3;
+      for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
+      inbox_heapsort(row, cnt);
+    }
+    for (;;) {
+      bool have = false; uint64_t bhi = 0, blo = 0; uint4 best = make_uint4(0, 0, 0, 0);
+      if (sorted) {
+        while (next_j < cnt && !have) {            // ascending; a duplicate (same key as the one before) is applied once
+          const uint32_t* m = row2 + next_j * 3; next_j++;
+          best = make_uint4(0, m[0], m[1], m[2]); edge_key(best, bhi, blo);
+          have = !(have_last && bhi == lhi && blo == llo);
+        }
+      } else
+      for (uint32_t j = 0; j < cnt; j++) {
+        uint4 e;                                   // {-, subject, inc, meta}
+        if (j < SW_INBOX_FAST) { uint32_t w = 1 + 3 * j; e = make_uint4(0, IN_WORD(w), IN_WORD(w + 1), IN_WORD(w + 2)); }
+        else { const uint32_t* m = row2 + (j - SW_INBOX_FAST) * 3; e = make_uint4(0, m[0], m[1], m[2]); }
+        uint64_t hi, lo; edge_key(e, hi, lo);
+        if (have_last && (hi < lhi || (hi == lhi && lo <= llo))) continue;
+        if (!have || hi < bhi || (hi == bhi && lo < blo)) { have = true; bhi = hi; blo = lo; best = e; }
+      }
+      if (!have) break;
+      uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
+      if (best.y == SWIM_SUBJECT_PIGGY)
+        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, lds_meta);
+      else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
+        uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
+        uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
+        if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
+        else atomicOr(D.err, SW_ERR_PEND_OVF);
+      }
+      else if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
+      else if (type == SWIM_MSG_SUSPECT) n.suspect_node(best.y, best.z, from);
+      else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
+      else n.user_event(best.y, best.z);
+      have_last = true; lhi = bhi; llo = blo;
+    }
+    n.store();
+    // suspicion timers armed here: the block's deadline bound is lowered once per workgroup (every lane of a cluster arms
+    // one within a few ticks of a failure)
+    if (n.dl_new != NONE) atomicMin(&s_dl[sb], n.dl_new);
+    c_pig += n.c_pig; c_sent01 += n.c_sent01; c_sent23 += n.c_sent23;
+    q_bit_lane(D, l, n.q_became_set(), n.q_became_clr());
   }
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
     S.wave_add(ST_SENT0, s0); S.wave_add(ST_SENT1, s1); S.wave_add(ST_SENT2, s2); S.wave_add(ST_SENT3, s3);
   }
-  S.flush(D);                                      // (barrier inside: every lane's carry reservations are in)
-  if (threadIdx.x == 0 && s_carry) { D.carry_cl[blockIdx.x].x = s_carry; *D.carry_stamp = *D.tick + 1; }
+  S.flush(D);                                      // (barrier inside: every lane's carry reservations and deadlines are in)
+  if (threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) {
+    const uint32_t sb = threadIdx.x;
+    if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
+    if (s_dl[sb] != NONE && s_dl[sb] < D.dl_blk[nb0 + sb]) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);
+  }
 }
 
 // =================================================================================================
