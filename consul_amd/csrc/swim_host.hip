@@ -236,6 +236,26 @@ static void drop_graphs(swim_sim* s) {
 }
 
 extern "C" int swim_destroy(swim_sim* s) {
+#ifdef SWIMSIM_DIAG
+  if (s && getenv("SWIMSIM_RESOLVECLK")) {      // diagnostics: where the waves of k_resolve's LAST launches spent their lives
+    std::vector<uint32_t> c((size_t)RCLK_ROWS * 8);
+    if (hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_rclk), c.size() * 4) == hipSuccess) {
+      static const char* const nm[7] = { "compaction", "line+hdr+vmeta", "queue+first view", "messages", "write-back", "flush", "wave lifetime" };
+      double sum[7] = { 0 }; uint32_t mx[7] = { 0 }; size_t n = 0; double msgs = 0, passes = 0;
+      for (size_t w = 0; w < RCLK_ROWS; w++) {
+        const uint32_t* row = &c[w * 8];
+        if (!row[6]) continue;
+        n++; msgs += row[7] & 0xFFFFu; passes += row[7] >> 16;
+        for (int p = 0; p < 7; p++) { sum[p] += row[p]; if (row[p] > mx[p]) mx[p] = row[p]; }
+      }
+      if (n) {
+        fprintf(stderr, "[resolve clk] %zu waves that found work (s_memtime ticks)\n", n);
+        for (int p = 0; p < 7; p++) fprintf(stderr, "[resolve clk]   %-18s mean %9.1f  max %9u\n", nm[p], sum[p] / n, mx[p]);
+        fprintf(stderr, "[resolve clk]   list passes per wave %.2f; messages per lane, wave maximum: mean %.2f\n", passes / n, msgs / n);
+      }
+    }
+  }
+#endif
   if (!s) return SWIM_EINVAL;
   if (s->stream) (void)hipStreamSynchronize(s->stream);
 #ifdef SWIMSIM_DIAG
@@ -531,7 +551,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (D.flags & SWIM_F_PIGGYBACK) ? (size_t)(D.Q + D.EQ) * SW_BLOCK * 4 : 0, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));

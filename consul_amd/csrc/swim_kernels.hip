@@ -1023,8 +1023,11 @@ __device__ __forceinline__ void role_carry(DevRef D, uint32_t b, uint32_t nb, ui
 // k_begin — the fused first launch of a tick.  grid = nb_expire + nb_pend + R*(nb_probe + nb_gossip);
 // dynamic LDS = (Q+EQ) * 256 * 16 bytes (the gossip role's staged queues)
 // =================================================================================================
+#ifndef SW_BEGIN_WAVES
+#define SW_BEGIN_WAVES 5      /* 96 VGPRs, no scratch: one more wave per SIMD than the allocator would settle for */
+#endif
 template <int KMAX, bool SERF, bool MULTI>
-__global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp, BeginPlan pl) {
+__global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_BEGIN_WAVES, 8))) k_begin(const SwDev* __restrict__ Dp, BeginPlan pl) {
   SW_DEV_BIND
   extern __shared__ uint4 lds_q[];
   __shared__ uint32_t lds_stats[ST_COUNT];
@@ -1042,6 +1045,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_begin(const SwDev* __restrict__ Dp
   b -= pl.nb_expire;
   if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, MULTI ? *D.peer_act : 1u); ROLE_DONE(1); return; }
   b -= pl.nb_pend;
+  // (an XCD-aware block order — each XCD working on R/8 of the clusters, so that the gossip role's random reads of
+  // receivers' views share an L2 — was measured: no faster once every cluster is busy, slower while only some are, because
+  // the load then sits on a few XCDs; profiles/r02_ab_begin.txt)
   if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, MULTI ? *D.peer_act : 1u); ROLE_DONE(2); return; }
   b -= D.R * pl.nb_probe;
   if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
@@ -1300,7 +1306,11 @@ __device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_
   uint32_t n = D.exc_cnt[r]; if (n > SW_EXC_MAX) return;               // unusable anyway
   for (uint32_t j = 0; j < n; j++) if (ent[j].x == x) atomicOr(&ent[j].y, now & ~old);
 }
-struct NodeCtx {
+extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at file scope so that NodeCtxT's accesses stay LDS-typed, not generic)
+// LQ = the memberlist queue of the lane is staged in LDS (k_resolve: every queue access of the merge is then an LDS access
+// and the entries that changed are written back once); otherwise it is edited in HBM (the stimulus kernels).
+template <bool LQ>
+struct NodeCtxT {
   DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
@@ -1309,44 +1319,61 @@ struct NodeCtx {
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
   uint4 h0;
-  __device__ NodeCtx(DevRef d, BlockStats& s) : D(d), S(s) {}
+  uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * 256 + threadIdx.x]; entries to write back
+#define SQ(j) g_lds_dyn[(j) * SW_BLOCK + threadIdx.x]
+  __device__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
 
   __device__ void load() { load(D.hdr[l]); }
   __device__ void load(uint4 h) {
     h0 = h;
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
+  // LQ: fetch the queue into the LDS column (independent loads, issued together)
+  __device__ __forceinline__ void stage_queue() {
+    for (uint32_t j = 0; j < qlen; j++) SQ(j) = D.q[(size_t)j * NL + l];
+  }
+  __device__ __forceinline__ uint4 mq_get(uint32_t j) const { if constexpr (LQ) return SQ(j); else return D.q[(size_t)j * NL + l]; }
+  __device__ __forceinline__ uint32_t mq_x(uint32_t j) const { if constexpr (LQ) return SQ(j).x; else return D.q[(size_t)j * NL + l].x; }
+  __device__ __forceinline__ uint32_t mq_w(uint32_t j) const { if constexpr (LQ) return SQ(j).w; else return D.q[(size_t)j * NL + l].w; }
+  __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) { if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else D.q[(size_t)j * NL + l] = e; }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
   // did the node go from "nothing queued" to "something queued" (or back) since load()?
   __device__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
   __device__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
   __device__ void store() {
+    flush_view();
+    if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) { const uint32_t j = __ffs(m) - 1; D.q[(size_t)j * NL + l] = SQ(j); }
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
     if (vm_dirty) D.vmeta[l] = vm;
   }
 
-  // QueueBroadcast on the HBM-resident queue: same-subject invalidation, Prune() on overflow
-  __device__ void queue_push(uint4* qb, uint32_t cap, uint32_t& len, uint32_t seq, bool named,
+  // QueueBroadcast: same-subject invalidation, Prune() on overflow.  EV = the serf user-event queue (always in HBM)
+  template <bool EV>
+  __device__ void queue_push(uint32_t cap, uint32_t& len, uint32_t seq, bool named,
                              uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
+    uint4* const eb = D.evq + l;
     uint32_t n = len;
     if (named) {                                   // at most one entry per subject: no early exit, so that the loads overlap
       uint32_t hit = NONE;
-      for (uint32_t j = 0; j < n; j++) hit = qb[(size_t)j * NL].x == subject ? j : hit;
-      if (hit != NONE) { if (hit != n - 1) qb[(size_t)hit * NL] = qb[(size_t)(n - 1) * NL]; n--; }
+      for (uint32_t j = 0; j < n; j++) hit = (EV ? eb[(size_t)j * NL].x : mq_x(j)) == subject ? j : hit;
+      if (hit != NONE) {
+        if (hit != n - 1) { if (EV) eb[(size_t)hit * NL] = eb[(size_t)(n - 1) * NL]; else mq_set(hit, mq_get(n - 1)); }
+        n--;
+      }
     }
     uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq));
     if (n == cap) {
       uint32_t w = NONE, wmeta = e.w;
-      for (uint32_t j = 0; j < n; j++) { uint32_t mj = qb[(size_t)j * NL].w; if (ent_before(D, wmeta, mj)) { wmeta = mj; w = j; } }
+      for (uint32_t j = 0; j < n; j++) { uint32_t mj = EV ? eb[(size_t)j * NL].w : mq_w(j); if (ent_before(D, wmeta, mj)) { wmeta = mj; w = j; } }
       S.add(drop_stat);
-      if (w != NONE) qb[(size_t)w * NL] = e;
-    } else { qb[(size_t)n * NL] = e; n++; }
+      if (w != NONE) { if (EV) eb[(size_t)w * NL] = e; else mq_set(w, e); }
+    } else { if (EV) eb[(size_t)n * NL] = e; else mq_set(n, e); n++; }
     len = n;
     if (D.fast_blocks) D.q_any[l / SW_BLOCK] = 1;
   }
   __device__ void broadcast(uint32_t subject, uint32_t type, uint32_t inc, uint32_t from) {
-    queue_push(D.q + l, D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS); qseq++;
+    queue_push<false>(D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS); qseq++;
   }
   __device__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
     uint32_t pos = atomicAdd(D.ev_cnt, 1u);
@@ -1355,9 +1382,20 @@ struct NodeCtx {
   }
   // ---- the observer's explicit view of a subject: looked up once per message (the home slot's entry and the
   // subject's node word are independent loads), edited in registers, written back once
-  struct View { uint32_t slot, free_slot, w; uint4 e; bool fresh; };
+  struct View { uint32_t slot, free_slot, w; uint4 e; bool fresh; uint4 c; bool c_have; };   // c = the slot's confirmer record (vc), once fetched
+  // The inbox is applied in subject order, so consecutive messages mostly concern the same subject: its view is looked up
+  // once, edited in registers across those messages and written back when the subject changes (or at store()).
+  View cv; uint32_t cv_x = NONE; bool cv_dirty = false;
+  __device__ __forceinline__ void flush_view() { if (cv_dirty) { D.vt[(size_t)cv.slot * NL + l] = cv.e; cv_dirty = false; } }
+  // (handlers work on a by-value copy and hand it back: a reference into the context would pin the cache in scratch memory)
+  __device__ __forceinline__ View take_view(uint32_t x) {
+    if (cv_x == x) return cv;
+    flush_view(); cv_x = x;
+    return lookup(x);
+  }
+  __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
   __device__ View lookup(uint32_t x) {
-    View v; v.fresh = false;
+    View v; v.fresh = false; v.c_have = false;
     v.w = D.nw[(size_t)r * D.N + x];
     v.slot = vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], v.e, v.free_slot);
     // no explicit view: the base row's — except that a node always sees ITSELF alive at its own incarnation
@@ -1428,14 +1466,13 @@ struct NodeCtx {
     if (dl < vm.z) { vm.z = dl; vm_dirty = true; }
     if (dl < dl_new) dl_new = dl;                          // the block's bound is lowered once per block (k_resolve) / by the caller
   }
-  __device__ void refute(uint32_t accused) {
+  __device__ void refute(View& me, uint32_t accused) {           // me = this node's view of itself (the cached subject)
     uint32_t inc = self_inc + 1;
     if (accused >= inc) inc = accused + 1;
     self_inc = inc;
     uint2 h = D.ph[l];                                     // awareness lives with the probe state
     D.ph[l].y = p_pack(p_epoch(h.y), awareness_apply(D, p_aw(h.y), +1), p_stage(h.y), p_nackm(h.y));
-    View me = lookup(o);
-    if (make(me, o)) { me.e.w = 0; set_view(me, inc, SWIM_STATE_ALIVE, false); put(me); }
+    if (make(me, o)) { me.e.w = 0; set_view(me, inc, SWIM_STATE_ALIVE, false); put_later(me); }
     broadcast(o, SWIM_MSG_ALIVE, inc, 0);
     S.add(ST_REFUTES);
   }
@@ -1444,9 +1481,13 @@ struct NodeCtx {
     if (local && leaving) return;
     if (local) {                                           // a node's view of itself carries its own incarnation (header): no lookup
       if (inc <= self_inc) return;
-      refute(inc); return;
+      View me = take_view(o); refute(me, inc); cv = me; return;
     }
-    View v = lookup(x);
+    View v = take_view(x);
+    alive_other(v, x, inc, upd);
+    cv = v;
+  }
+  __device__ __forceinline__ void alive_other(View& v, uint32_t x, uint32_t inc, uint32_t upd) {
     const uint32_t key = v.e.y;
     if (inc <= SW_KINC(key)) return;
     if (!make(v, x)) return;
@@ -1454,7 +1495,7 @@ struct NodeCtx {
     const uint32_t old = SW_KST(key);
     broadcast(x, SWIM_MSG_ALIVE, inc, upd);
     set_view(v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
-    put(v);
+    put_later(v);
     S.add(ST_APPL0);
     if (o == D.watch) {
       if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
@@ -1462,20 +1503,25 @@ struct NodeCtx {
     }
   }
   __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
-    View v = lookup(x);
+    View v = take_view(x);
+    suspect_v(v, x, inc, from);
+    cv = v;
+  }
+  __device__ __forceinline__ void suspect_v(View& v, uint32_t x, uint32_t inc, uint32_t from) {
     const uint32_t key = v.e.y;
     if (inc < SW_KINC(key)) return;
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from) (the base row is never Suspect)
       uint32_t nc = vw_nconf(v.e.w);
       if ((!D.dyn && nc >= D.susp_k) || vw_conf0(v.e.w) == from) return;
       const size_t ci = (size_t)v.slot * NL + l;
-      uint4 b = (nc || D.dyn) ? D.vc[ci] : make_uint4(0, 0, 0, 0);     // (dynamic membership: the timer's n sits in b.w)
+      if (!v.c_have) { v.c = (nc || D.dyn) ? D.vc[ci] : make_uint4(0, 0, 0, 0); v.c_have = true; }   // (dynamic membership: the timer's n sits in c.w)
+      uint4 b = v.c;
       if (D.dyn && nc >= susp_k_n(D, b.w)) return;
       if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
-      if (nc <= 3) D.vc[ci] = b;
-      v.e.w = vw_pack(vw_conf0(v.e.w), nc, vw_leaving(v.e.w)); put(v);
+      if (nc <= 3) { D.vc[ci] = b; v.c = b; }
+      v.e.w = vw_pack(vw_conf0(v.e.w), nc, vw_leaving(v.e.w)); put_later(v);
       arm_deadline(v, b.w);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       S.add(ST_CONFIRMS);
@@ -1483,24 +1529,29 @@ struct NodeCtx {
       return;
     }
     if (SW_KST(key) != SWIM_STATE_ALIVE) return;
-    if (x == o) { refute(inc); return; }
+    if (x == o) { refute(v, inc); return; }
     if (!make(v, x)) return;
     broadcast(x, SWIM_MSG_SUSPECT, inc, from);
     set_view(v, inc, SWIM_STATE_SUSPECT, true);
     v.e.w = vw_pack(from, 0, (v.e.w >> 1) & 1u);           // newSuspicion(from, k, min, max); a Leaving mark stays
-    put(v);
+    put_later(v);
     uint32_t n0 = 0;
     if (D.dyn) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
+    v.c = make_uint4(0, 0, 0, n0); v.c_have = true;
     arm_deadline(v, n0);
     S.add(ST_APPL1);
   }
   __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
-    View v = lookup(x);
+    View v = take_view(x);
+    dead_v(v, x, inc, from);
+    cv = v;
+  }
+  __device__ __forceinline__ void dead_v(View& v, uint32_t x, uint32_t inc, uint32_t from) {
     const uint32_t key = v.e.y;
     if (inc < SW_KINC(key)) return;
     const uint32_t old = SW_KST(key);
     if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) return;
-    if (x == o && !leaving) { refute(inc); return; }
+    if (x == o && !leaving) { refute(v, inc); return; }
     if (!make(v, x)) return;
     // Left for a graceful leave (Node == From) and for a member a leave intent had marked Leaving here (serf handleNodeLeave)
     const bool was_leaving = old == SWIM_STATE_SUSPECT ? vw_leaving(v.e.w) != 0 : ((v.e.w >> 1) & 1u) != 0;
@@ -1508,7 +1559,7 @@ struct NodeCtx {
     broadcast(x, SWIM_MSG_DEAD, inc, from);
     const uint32_t st = (from == x || was_leaving) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
     set_view(v, inc, st, true);
-    put(v);
+    put_later(v);
     S.add(ST_APPL2);
     if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
   }
@@ -1516,23 +1567,23 @@ struct NodeCtx {
   // i.e. the memberlist queue and then the serf delegate's user events, for a ping/ack/... this node sent this
   // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
   // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
-  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_meta) {
+  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_emeta) {
+    static_assert(LQ, "the piggy-back pick works on the staged queue");
     const int limit = (int)D.budget - (int)sel4(D.ctl_len, kind & 3u);
     uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
     int used = 0, used2 = 0;
-    HbmQ qm{D.q + l, NL}, qe{D.evq + l, NL};
-    // the pick walks the queue several times: fetch the meta words once (independent loads), pick in LDS
-    MetaQ mm{lds_meta + threadIdx.x}, me{lds_meta + (size_t)D.Q * SW_BLOCK + threadIdx.x};
-    for (uint32_t j = 0; j < qlen; j++) mm.meta(j) = qm.at(j).w;
+    HbmQ qe{D.evq + l, NL};
+    // the user-event queue stays in HBM; the pick walks it several times, so its meta words are fetched once into LDS
+    MetaQ me{lds_emeta + threadIdx.x};
     for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
     const uint32_t rl = retransmit_limit_n(D, est_n(D, r, l));
-    uint32_t tm = get_broadcasts(D, mm, qlen, live_m, 2, limit, used, rl), te = 0;
+    uint32_t tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl), te = 0;
     int avail = limit - used;
     if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
     if (!(tm | te)) return;
     const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
     c_pig++;
-    for (uint32_t m = tm; m; m &= m - 1) { uint32_t ty = m_type(mm.meta(__ffs(m) - 1)); if (ty < 2) c_sent01 += 1u << (16 * ty); else c_sent23 += 1u << (16 * (ty - 2)); }
+    for (uint32_t m = tm; m; m &= m - 1) { uint32_t ty = m_type(SQ(__ffs(m) - 1).w); if (ty < 2) c_sent01 += 1u << (16 * ty); else c_sent23 += 1u << (16 * (ty - 2)); }
     c_sent23 += (uint32_t)__popc(te) << 16;
     if (receiver != NONE) {
       const uint32_t gdst = r * D.N + receiver;
@@ -1540,7 +1591,7 @@ struct NodeCtx {
       uint32_t pos = att ? 0 : atomicAdd(s_carry, cnt);
       if (!att && pos + cnt > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); pos = NONE; }
       for (uint32_t m = tm; m && pos != NONE; m &= m - 1) {
-        uint4 e = qm.at(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
+        uint4 e = SQ(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
         if (att) capture(D, o, gdst, e.x, e.y, meta); else area[pos++] = make_uint4(gdst, e.x, e.y, meta);
       }
       for (uint32_t m = te; m && pos != NONE; m &= m - 1) {
@@ -1548,11 +1599,11 @@ struct NodeCtx {
         if (att) capture(D, o, gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30); else area[pos++] = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
       }
     }
-    // write the bumped transmit counts back; retire what reached the retransmit limit (stable compaction,
-    // like the gossip role's write-back)
+    // the bumped transmit counts; what reached the retransmit limit retires (stable compaction, like the gossip role's
+    // write-back)
     uint32_t nq = 0, ne = 0;
     for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) {
-      if (nq != j) { uint4 e = qm.at(j); e.w = mm.meta(j); qm.at(nq) = e; } else if ((tm >> j) & 1u) qm.at(j).w = mm.meta(j);
+      if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j;
       nq++;
     }
     for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) {
@@ -1566,14 +1617,18 @@ struct NodeCtx {
   // here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.
   __device__ void leave_intent(uint32_t x, bool prune) {
     if (x >= D.N || x == o) return;
-    View v = lookup(x);
+    View v = take_view(x);
+    leave_intent_v(v, x, prune);
+    cv = v;
+  }
+  __device__ __forceinline__ void leave_intent_v(View& v, uint32_t x, bool prune) {
     const uint32_t key = v.e.y, st = SW_KST(key);
     if (SW_KINC(key) == 0) return;
     if (st < SWIM_STATE_DEAD) {                            // alive (or suspected) here: StatusLeaving — its death will read as a leave
       if (!make(v, x)) return;
       const uint32_t bit = st == SWIM_STATE_SUSPECT ? 8u : 2u;
       if (v.fresh || !(v.e.w & bit)) {
-        v.e.w |= bit; v.fresh = false; put(v);
+        v.e.w |= bit; v.fresh = false; put_later(v);
         if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       }
       return;
@@ -1593,7 +1648,7 @@ struct NodeCtx {
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       if (o == D.watch) record_event(SWIM_EVENT_MEMBER_REAP, x, 0, SW_KINC(key));
     }
-    put(v);
+    put_later(v);
   }
   // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
   __device__ void user_event(uint32_t id, uint32_t ltime) {
@@ -1614,9 +1669,11 @@ struct NodeCtx {
       if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
     }
     uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
-    queue_push(D.evq + l, D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
+    queue_push<true>(D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
   }
 };
+#undef SQ
+typedef NodeCtxT<false> NodeCtx;       // the stimulus kernels edit the queue in HBM
 
 // canonical order key of an inbox record: (user?, subject, type) then (incarnation, from)
 __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
@@ -1664,20 +1721,33 @@ __device__ __attribute__((noinline)) void inbox_heapsort(uint32_t* a, uint32_t n
 // dl_blk, the carry areas k_deliver drains) keeps that index.
 // (five waves per SIMD instead of the four the register allocator would settle for: it is the number of lanes in flight
 // that hides the round trips)
+#ifdef SWIMSIM_DIAG
+// diagnostics (SWIMSIM_RESOLVECLK): where a wave of k_resolve spends its life.  Every wave leaves its s_memtime deltas per
+// phase in its own row (plain stores, no atomics: the probe must not serialise what it measures); later launches overwrite
+// earlier ones, the host reduces at swim_destroy.  Row: [0..5] phases, [6] lifetime, [7] passes << 16 | max messages per lane
+#define RCLK_ROWS 65536
+__device__ uint32_t g_rclk[RCLK_ROWS][8];
+#define RCLK_MARK(p) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); rclk_acc[p] += (uint32_t)(now_ - rclk_t); rclk_t = now_; } while (0)
+#else
+#define RCLK_MARK(p) do { } while (0)
+#endif
 #ifndef SW_RTILE
 #define SW_RTILE 4
 #endif
 #ifndef SW_RESOLVE_WAVES
-#define SW_RESOLVE_WAVES 5
+#define SW_RESOLVE_WAVES 4
 #endif
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
-  extern __shared__ uint32_t lds_meta[];         // [(Q+EQ)][256] meta words of the lane's queues (piggy-back pick)
+  uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
   __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
   __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
   const uint32_t nb0 = blockIdx.x * SW_RTILE;
+#ifdef SWIMSIM_DIAG
+  unsigned long long rclk_t = __builtin_amdgcn_s_memtime(); const unsigned long long rclk_t0 = rclk_t; uint32_t rclk_it = 0, rclk_acc[6] = { 0, 0, 0, 0, 0, 0 };
+#endif
   if (D.fast_blocks) {                     // nothing reached this tile: a few words and out
     uint32_t any = 0;
 #pragma unroll
@@ -1712,6 +1782,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   __syncthreads();
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
   const uint32_t t_now = *D.tick;
+  RCLK_MARK(0);                                    // compaction
   for (uint32_t a0 = 0; a0 < n_act; a0 += SW_BLOCK) {
     if (a0 + threadIdx.x >= n_act) continue;
     const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;
@@ -1728,12 +1799,21 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-    NodeCtx n(D, S);
+    NodeCtxT<true> n(D, S);
     n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
-    bool have_last = false; uint64_t lhi = 0, llo = 0;
+    RCLK_MARK(1);                                  // line + header + vmeta
+    // second round trip: the queue (into LDS) and, in the same breath, the view of the subject the first message of the line
+    // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)
+    n.stage_queue();
     const bool sorted = cnt >= SW_INBOX_SORT_MIN;
+    if (!sorted) {
+      const uint32_t gx = IN_WORD(1), gty = IN_WORD(3) >> 30;
+      if (gx < D.N && gty != SWIM_MSG_USER && gx != n.o) { n.cv = n.lookup(gx); n.cv_x = gx; }
+    }
+    bool have_last = false; uint64_t lhi = 0, llo = 0;
     uint32_t next_j = 0;
+    RCLK_MARK(2);                                  // queue staged, first view fetched
     if (sorted) {                                  // the five messages of the line join the row (it has room for all C), then one sort
       uint32_t* row = D.inbox2 + l * D.C2 * 3;
       for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
@@ -1759,7 +1839,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
       if (!have) break;
       uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
       if (best.y == SWIM_SUBJECT_PIGGY)
-        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, lds_meta);
+        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + (size_t)D.Q * SW_BLOCK));
       else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
         uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
         uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
@@ -1771,14 +1851,22 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
       else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
       else n.user_event(best.y, best.z);
       have_last = true; lhi = bhi; llo = blo;
+#ifdef SWIMSIM_DIAG
+      rclk_it++;
+#endif
     }
+    RCLK_MARK(3);                                  // the messages
     n.store();
     // suspicion timers armed here: the block's deadline bound is lowered once per workgroup (every lane of a cluster arms
     // one within a few ticks of a failure)
     if (n.dl_new != NONE) atomicMin(&s_dl[sb], n.dl_new);
     c_pig += n.c_pig; c_sent01 += n.c_sent01; c_sent23 += n.c_sent23;
     q_bit_lane(D, l, n.q_became_set(), n.q_became_clr());
+    RCLK_MARK(4);                                  // write-back
   }
+#ifdef SWIMSIM_DIAG
+  { uint32_t m = rclk_it; for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v > m ? v : m; } rclk_it = m; }
+#endif
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
@@ -1790,6 +1878,14 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
     if (s_dl[sb] != NONE && s_dl[sb] < D.dl_blk[nb0 + sb]) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);
   }
+#ifdef SWIMSIM_DIAG
+  RCLK_MARK(5);                                    // tallies, flush
+  if (sw_lane() == 0) {
+    uint32_t* row = g_rclk[(blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64) % RCLK_ROWS];
+    for (int p = 0; p < 6; p++) row[p] = rclk_acc[p];
+    row[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - rclk_t0); row[7] = ((n_act + SW_BLOCK - 1) / SW_BLOCK) << 16 | (rclk_it & 0xFFFFu);
+  }
+#endif
 }
 
 // =================================================================================================
