@@ -52,19 +52,27 @@ def algorithmic_bytes(kernel: str, st: dict) -> float:
     per active node-round: emit side 16 (header) + 8m (queue slots) + k(4+4m) (edges out);
     delivery side k(4+4m) (edges in); merge k*m*8 (view RMW) + 16+8m (header/slot write-back);
     per quiescent node-round 16; per probe 40.  k, m are the measured packets/node and msgs/packet.
+
+    The 8-byte view access of a rumour is charged to the kernel that makes it: with SWIM_F_FILTER_NOOP the sender's side
+    reads the receiver's view and drops the rumour when it would change nothing, so a FILTERED rumour's 8 bytes belong to
+    k_begin (gossip) or k_deliver (a broadcast carried by a ping/ack), and only what is delivered reaches k_resolve.
+    The sum over the three kernels is what it was without that split.
     """
     active, quiet = st["node_rounds_active"], st["node_rounds_quiescent"]
     pkts, msgs = st["packets_sent"], sum(st["msgs_sent"])
     pb, pbm = st.get("piggybacks", 0), st.get("msgs_piggybacked", 0)   # carriers with a load / broadcasts they carried
     applied = sum(st["msgs_applied"])
     gm = msgs - pbm                                                     # broadcasts sent by gossip() itself
+    filtered = min(st.get("msgs_filtered", 0), msgs)
+    f_gossip = filtered * gm / max(msgs, 1)                             # (the counter does not say where a rumour was dropped:
+    f_carried = filtered - f_gossip                                     #  split in proportion to what each side sent)
     if kernel == "k_begin":       # fused: gossip select/emit + probe (+ timers); a piggy-back order is 8 B of the probe's 40
         return (16.0 * (active + quiet) + 8.0 * (gm / max(pkts, 1)) * active + 4.0 * pkts + 4.0 * gm
-                + 40.0 * st["probes"])
+                + 40.0 * st["probes"] + 8.0 * f_gossip)
     if kernel == "k_deliver":     # gossip packets + the carried broadcasts (and their carriers' orders)
-        return 4.0 * (pkts + pb) + 4.0 * msgs
+        return 4.0 * (pkts + pb) + 4.0 * msgs + 8.0 * f_carried
     if kernel == "k_resolve":     # merges + the piggy-back pick (8 B queue slot per carried broadcast, read and written)
-        return 8.0 * msgs + 24.0 * applied + 16.0 * pbm
+        return 8.0 * (msgs - filtered) + 24.0 * applied + 16.0 * pbm
     return 0.0
 
 
