@@ -84,6 +84,7 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 struct SwDev {
   // dimensions
   uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB;
+  uint32_t n_shift, nloc_shift;   // log2 of N / nloc when that is a power of two (division and remainder by shift and mask), else 0xFFFFFFFF
   uint32_t G, P, TQ, CH, quantum_ms;
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
   uint32_t budget, flags, watch, trace_ticks, n_shards, rank, fast_blocks, pp_period;

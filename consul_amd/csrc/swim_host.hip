@@ -307,6 +307,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   memset(&D, 0, sizeof D);
   const bool serf = (cfg->flags & SWIM_F_SERF_EVENTS) != 0;
   D.N = cfg->n_nodes; D.R = cfg->n_replicas; D.nloc = D.N / cfg->n_shards; D.i0 = cfg->shard_rank * D.nloc;
+  D.n_shift = (D.N & (D.N - 1)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(D.N);
+  D.nloc_shift = (D.nloc & (D.nloc - 1)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(D.nloc);
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
   D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C : 0;   // the overflow row has room for ALL C messages: a big inbox is sorted in it (k_resolve)
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;

@@ -150,6 +150,13 @@ __device__ __forceinline__ bool reach(DevRef D, uint32_t r, uint32_t t, uint32_t
   return !lost(D, r, t, rng_node, leg);
 }
 
+// division and remainder by N (nodes per cluster) and nloc (nodes of a cluster on this shard): every BASELINE cluster size is a
+// power of two, and a 32-bit division is ~30 instructions in kernels that are short of issue slots (the branch is uniform)
+__device__ __forceinline__ uint32_t div_n(DevRef D, uint32_t x) { return D.n_shift != NONE ? x >> D.n_shift : x / D.N; }
+__device__ __forceinline__ uint32_t mod_n(DevRef D, uint32_t x) { return D.n_shift != NONE ? x & (D.N - 1u) : x % D.N; }
+__device__ __forceinline__ uint32_t div_nloc(DevRef D, size_t l) { return D.nloc_shift != NONE ? (uint32_t)(l >> D.nloc_shift) : (uint32_t)(l / D.nloc); }
+__device__ __forceinline__ uint32_t mod_nloc(DevRef D, size_t l) { return D.nloc_shift != NONE ? (uint32_t)l & (D.nloc - 1u) : (uint32_t)(l % D.nloc); }
+
 // ---- the replica's exception list, staged in LDS by the first SW_EXC_MAX lanes of a block ----------
 struct ExcList {
   uint32_t* id; uint32_t* w; uint32_t n;           // n > SW_EXC_MAX: unusable, fall back to nw
@@ -316,7 +323,7 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
   // independent random reads in flight) instead of one dependent read per loop trip
   uint32_t x4[4], w4[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) x4[j] = d.get(j) % D.N;
+  for (int j = 0; j < 4; j++) x4[j] = mod_n(D, d.get(j));
   if (X.usable()) {
 #pragma unroll
     for (int j = 0; j < 4; j++) w4[j] = X.word(x4[j]);                 // no memory access
@@ -327,7 +334,7 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
   for (uint64_t i = 0; i < tries && found < want; i++) {
     uint32_t x, w;
     if (i < 4) { x = i == 0 ? x4[0] : i == 1 ? x4[1] : i == 2 ? x4[2] : x4[3]; w = i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]; }
-    else { x = d.get((uint32_t)i) % D.N; w = X.usable() ? X.word(x) : nw[x]; }
+    else { x = mod_n(D, d.get((uint32_t)i)); w = X.usable() ? X.word(x) : nw[x]; }
     if (x == o) continue;
     uint32_t since, key = view_of(D, r, k_local, x, w, &since), st = SW_KST(key);
     if (mode == 0) {
@@ -1088,7 +1095,7 @@ __device__ __forceinline__ void fold_accumulate(DevRef D, uint4 rec) {
 // reserve: one returning atomic on the count word of the node's 64-byte inbox line
 __device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l, const ExcList* X = nullptr) {
   if (rec.x == NONE) { fold_accumulate(D, rec); return NONE; }          // fold census record
-  uint32_t r = rec.x / D.N, x = rec.x % D.N;
+  uint32_t r = div_n(D, rec.x), x = mod_n(D, rec.x);
   if (x < D.i0 || x >= D.i0 + D.nloc) return NONE;
   uint32_t w = (X && X->usable()) ? X->word(x) : D.nw[rec.x];           // (X: the list of the replica every record of this span belongs to)
   if (w & NW_DEAD) return NONE;                    // e.g. a push-pull reply to a requester that died meanwhile
@@ -1128,7 +1135,7 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
   for (uint32_t e = threadIdx.x; e < n; e += SW_BLOCK) {
     uint4 rec = area[e];
     if (rec.x == SW_DST_VOID) continue;              // left for another shard in k_begin
-    uint32_t r = rec.x / D.N, x = rec.x % D.N, type = rec.w >> 30;
+    uint32_t r = div_n(D, rec.x), x = mod_n(D, rec.x), type = rec.w >> 30;
     if (filter && type != SWIM_MSG_USER && rec.y != x) {
       uint32_t ws = D.nw[(size_t)r * D.N + rec.y];
       if (noop_at_receiver(D, r, (size_t)r * D.nloc + (x - D.i0), ws, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30), false, rec)) { c_filt++; continue; }
@@ -1309,6 +1316,8 @@ __device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_
 extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at file scope so that NodeCtxT's accesses stay LDS-typed, not generic)
 // LQ = the memberlist queue of the lane is staged in LDS (k_resolve: every queue access of the merge is then an LDS access
 // and the entries that changed are written back once); otherwise it is edited in HBM (the stimulus kernels).
+// (Every method is __forceinline__: left to the inliner's threshold, one more statement in a method made it a call, the
+// context was passed by pointer and lived in scratch memory — 646 scratch instructions in k_resolve.)
 template <bool LQ>
 struct NodeCtxT {
   DevRef D; BlockStats& S;
@@ -1321,10 +1330,10 @@ struct NodeCtxT {
   uint4 h0;
   uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * 256 + threadIdx.x]; entries to write back
 #define SQ(j) g_lds_dyn[(j) * SW_BLOCK + threadIdx.x]
-  __device__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
+  __device__ __forceinline__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
 
-  __device__ void load() { load(D.hdr[l]); }
-  __device__ void load(uint4 h) {
+  __device__ __forceinline__ void load() { load(D.hdr[l]); }
+  __device__ __forceinline__ void load(uint4 h) {
     h0 = h;
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
@@ -1338,9 +1347,9 @@ struct NodeCtxT {
   __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) { if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else D.q[(size_t)j * NL + l] = e; }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
   // did the node go from "nothing queued" to "something queued" (or back) since load()?
-  __device__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
-  __device__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
-  __device__ void store() {
+  __device__ __forceinline__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
+  __device__ __forceinline__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
+  __device__ __forceinline__ void store() {
     flush_view();
     if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) { const uint32_t j = __ffs(m) - 1; D.q[(size_t)j * NL + l] = SQ(j); }
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
@@ -1350,7 +1359,7 @@ struct NodeCtxT {
 
   // QueueBroadcast: same-subject invalidation, Prune() on overflow.  EV = the serf user-event queue (always in HBM)
   template <bool EV>
-  __device__ void queue_push(uint32_t cap, uint32_t& len, uint32_t seq, bool named,
+  __device__ __forceinline__ void queue_push(uint32_t cap, uint32_t& len, uint32_t seq, bool named,
                              uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
     uint4* const eb = D.evq + l;
     uint32_t n = len;
@@ -1372,10 +1381,10 @@ struct NodeCtxT {
     len = n;
     if (D.fast_blocks) D.q_any[l / SW_BLOCK] = 1;
   }
-  __device__ void broadcast(uint32_t subject, uint32_t type, uint32_t inc, uint32_t from) {
+  __device__ __forceinline__ void broadcast(uint32_t subject, uint32_t type, uint32_t inc, uint32_t from) {
     queue_push<false>(D.Q, qlen, qseq, true, subject, type, inc, from, ST_QDROPS); qseq++;
   }
-  __device__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
+  __device__ __forceinline__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
     uint32_t pos = atomicAdd(D.ev_cnt, 1u);
     if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc }; D.events[pos] = ev; }
     else atomicOr(D.err, SW_ERR_EVENT_OVF);
@@ -1394,7 +1403,7 @@ struct NodeCtxT {
     return lookup(x);
   }
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
-  __device__ View lookup(uint32_t x) {
+  __device__ __forceinline__ View lookup(uint32_t x) {
     View v; v.fresh = false; v.c_have = false;
     v.w = D.nw[(size_t)r * D.N + x];
     v.slot = vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], v.e, v.free_slot);
@@ -1404,7 +1413,7 @@ struct NodeCtxT {
   }
   // make the view explicit (created from the base row).  false = the observer already holds view_cap explicit views
   // (its view of itself always fits): the caller ignores the rumour, counted in view_drops.
-  __device__ bool make(View& v, uint32_t x) {
+  __device__ __forceinline__ bool make(View& v, uint32_t x) {
     if (v.slot != NONE) return true;
     need_vm();
     if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
@@ -1443,7 +1452,7 @@ struct NodeCtxT {
     return true;
   }
   __device__ __forceinline__ void put(const View& v) { D.vt[(size_t)v.slot * NL + l] = v.e; }
-  __device__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
+  __device__ __forceinline__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
     const uint32_t old = v.fresh ? (uint32_t)SWIM_STATE_ALIVE : SW_KST(v.e.y);     // (a fresh view comes from the base row: never Suspect)
     v.fresh = false;
     v.e.y = SW_KEY(inc, st);
@@ -1460,13 +1469,13 @@ struct NodeCtxT {
       D.slot_dirty[sidx] = 1;
     }
   }
-  __device__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
+  __device__ __forceinline__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
     const uint32_t dl = v.e.z + susp_timeout_n(D, n0, vw_nconf(v.e.w));
     need_vm();
     if (dl < vm.z) { vm.z = dl; vm_dirty = true; }
     if (dl < dl_new) dl_new = dl;                          // the block's bound is lowered once per block (k_resolve) / by the caller
   }
-  __device__ void refute(View& me, uint32_t accused) {           // me = this node's view of itself (the cached subject)
+  __device__ __forceinline__ void refute(View& me, uint32_t accused) {           // me = this node's view of itself (the cached subject)
     uint32_t inc = self_inc + 1;
     if (accused >= inc) inc = accused + 1;
     self_inc = inc;
@@ -1476,7 +1485,7 @@ struct NodeCtxT {
     broadcast(o, SWIM_MSG_ALIVE, inc, 0);
     S.add(ST_REFUTES);
   }
-  __device__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
+  __device__ __forceinline__ void alive_node(uint32_t x, uint32_t inc, uint32_t upd) {
     const bool local = x == o;
     if (local && leaving) return;
     if (local) {                                           // a node's view of itself carries its own incarnation (header): no lookup
@@ -1502,7 +1511,7 @@ struct NodeCtxT {
       else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
     }
   }
-  __device__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
+  __device__ __forceinline__ void suspect_node(uint32_t x, uint32_t inc, uint32_t from) {
     View v = take_view(x);
     suspect_v(v, x, inc, from);
     cv = v;
@@ -1541,7 +1550,7 @@ struct NodeCtxT {
     arm_deadline(v, n0);
     S.add(ST_APPL1);
   }
-  __device__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
+  __device__ __forceinline__ void dead_node(uint32_t x, uint32_t inc, uint32_t from) {
     View v = take_view(x);
     dead_v(v, x, inc, from);
     cv = v;
@@ -1567,7 +1576,7 @@ struct NodeCtxT {
   // i.e. the memberlist queue and then the serf delegate's user events, for a ping/ack/... this node sent this
   // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
   // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
-  __device__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_emeta) {
+  __device__ __forceinline__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_emeta) {
     static_assert(LQ, "the piggy-back pick works on the staged queue");
     const int limit = (int)D.budget - (int)sel4(D.ctl_len, kind & 3u);
     uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
@@ -1615,7 +1624,7 @@ struct NodeCtxT {
   // serf handleNodeLeaveIntent for a force-leave (RemoveFailedNode): a member held Failed becomes Left (EventMemberLeave);
   // with prune it is erased at once (EventMemberReap), also when it was Left already.  A member that is Alive or Suspect
   // here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.
-  __device__ void leave_intent(uint32_t x, bool prune) {
+  __device__ __forceinline__ void leave_intent(uint32_t x, bool prune) {
     if (x >= D.N || x == o) return;
     View v = take_view(x);
     leave_intent_v(v, x, prune);
@@ -1651,7 +1660,7 @@ struct NodeCtxT {
     put_later(v);
   }
   // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
-  __device__ void user_event(uint32_t id, uint32_t ltime) {
+  __device__ __forceinline__ void user_event(uint32_t id, uint32_t ltime) {
     if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
     if (ltime >= ev_clock) ev_clock = ltime + 1;
     if (ev_clock > D.EB && ltime < ev_clock - D.EB) { S.add(ST_UEV_STALE); return; }
@@ -1800,7 +1809,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
     NodeCtxT<true> n(D, S);
-    n.r = (uint32_t)(l / D.nloc); n.k = (uint32_t)(l % D.nloc); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
+    n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
     RCLK_MARK(1);                                  // line + header + vmeta
     // second round trip: the queue (into LDS) and, in the same breath, the view of the subject the first message of the line
