@@ -126,15 +126,15 @@ def run_cpu_baseline(args, ticks_per_round: int) -> dict:
             x.close()
         return reps * args.nodes * rounds / dt, dt, reps
 
-    per_thread = 2
-    v1, dt1, _ = sample(1)
+    per_thread = 4
+    v1, dt1, n1 = sample(1)
     per_thread = 1
     vn, dtn, repsn = sample(cores)
     return {"value": vn, "unit": "node-rounds/s", "cores": cores, "kind": "port",
             "one_thread": {"value": v1, "cores": 1, "wall_s": round(dt1, 2)},
             "sample": f"{repsn} clusters x {args.nodes} nodes x {rounds} rounds after the failure (config #2's scenario, "
                       f"kill after {warm} rounds), {per_thread} per thread: {dtn:.1f} s wall on {cores} of {ncpu} host threads; "
-                      f"one thread: 2 clusters one after the other, {dt1:.1f} s"}
+                      f"one thread: {n1} clusters one after the other, {dt1:.1f} s"}
 
 
 def roofline_of(prof: dict, st: dict, wall_s=None) -> dict:
