@@ -46,6 +46,33 @@ def victims_for(seed: int, reps: int, n: int):
     return [int(rng.integers(n)) for _ in range(reps)]
 
 
+class MultiSim:
+    """The clusters of config #2 are independent simulations: spread over several library handles (one HIP stream each) their
+    tick kernels overlap on the GPU — the tail of one handle's launch runs next to the head of another's.  Replica r of a
+    handle seeded s is replica 0 of a handle seeded s + r, so every cluster is the one it would be in a single handle."""
+
+    def __init__(self, sims, per):
+        self.sims, self.per, self.derived = sims, per, sims[0].derived
+
+    def step(self, n):
+        for s in self.sims:                                # asynchronous: every stream has its launches queued before any is awaited
+            s.step(n)
+
+    def sync(self):
+        for s in self.sims:
+            s.sync()
+
+    def kill(self, r, ids):
+        self.sims[r // self.per].kill(r % self.per, ids)
+
+    def census(self, r, x):
+        return self.sims[r // self.per].census(r % self.per, x)
+
+    def close(self):
+        for s in self.sims:
+            s.close()
+
+
 def algorithmic_bytes(kernel: str, st: dict) -> float:
     """SURVEY.md §8(d) per-unit bytes, split by the kernel that moves them.
 
@@ -234,6 +261,9 @@ def main():
     ap.add_argument("--replicas", type=int, default=32, help="cluster replicas per GPU (seeds seed..)")
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--handles", type=int, default=2,
+                    help="N = 1: spread the clusters over this many library handles, one stream each (their kernels overlap); "
+                         "1 = one handle, one launch per kernel and tick for all clusters")
     ap.add_argument("--subject-cap", type=int, default=4)
     ap.add_argument("--main-only", action="store_true", help="only the timed region (profiling runs): no roofline pass, no extra legs, no CPU baseline")
     ap.add_argument("--no-detection", action="store_true")
@@ -312,7 +342,13 @@ def main():
             merged.update(d)
         return [merged[r] for r in range(world)]
 
-    def fresh():
+    handles = args.handles if (not sharded and args.handles > 1 and reps % args.handles == 0) else 1
+
+    def fresh(multi=True):
+        if multi and handles > 1:
+            per = reps // handles
+            return MultiSim([Sim(hip, preset(hip, abi.PRESET_LAN, **dict(cfg_kw, n_replicas=per, seed=args.seed + g * per)))
+                             for g in range(handles)], per)
         sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
         if not sharded:
             return sim
@@ -392,7 +428,10 @@ def main():
                    "nodes_per_cluster": args.nodes, "replicas": reps, "fanout": args.fanout,
                    "virtual_nodes": reps * args.nodes, "ticks_per_round": G,
                    "rounds_per_sec": args.steps / dt, "quiescent_ms_per_step": quiescent_ms,
-                   "parallelism": f"population sharded x{world}, one exchange per tick: {exchange_used}" if sharded else "1 GPU"},
+                   "handles": handles,
+                   "parallelism": f"population sharded x{world}, one exchange per tick: {exchange_used}" if sharded else
+                                  (f"1 GPU, the clusters on {handles} library handles (one HIP stream each; `single_handle` = all in one)"
+                                   if handles > 1 else "1 GPU")},
         # what the TIMED window happened to see (it may end before any suspicion runs out): see `detection`
         "timed_window_detection_ms_after_failure": detect_after_kill,
     }
@@ -415,9 +454,23 @@ def main():
                                     "unit": "node-rounds/s", "ms_per_step": 1000.0 * dts / args.steps,
                                     "parallelism": f"{args.replicas} whole clusters per GPU x {world} GPUs, no data-path collective"}
 
+    if rank == 0 and handles > 1 and not args.main_only:
+        # the same region with every cluster in ONE handle (one launch per kernel and tick): what the roofline pass instruments
+        one = fresh(multi=False)
+        one.step(G); one.sync()
+        one.step((args.warmup - 1) * G if args.warmup > 1 else 0)
+        for r, v in enumerate(victims):
+            one.kill(r, [v])
+        one.sync()
+        t1 = time.perf_counter()
+        one.step(args.steps * G); one.sync()
+        dt1 = time.perf_counter() - t1
+        one.close()
+        line["single_handle"] = {"value": reps * args.nodes * args.steps / dt1, "unit": "node-rounds/s", "ms_per_step": 1000.0 * dt1 / args.steps}
     if rank == 0 and not sharded and not args.no_roofline:
-        # instrumented pass over the same region: HIP events around every launch on the sim's stream
-        p = fresh()
+        # instrumented pass over the same region: HIP events around every launch on the sim's stream (one handle: the launches
+        # are then the ones `single_handle` times; with several handles the same kernels run at 1/handles of the size, overlapped)
+        p = fresh(multi=False)
         p.step(args.warmup * G)
         for r, v in enumerate(victims):
             p.kill(r, [v])
@@ -428,7 +481,7 @@ def main():
         prof = p.profile_read()
         st = diff_stats(s0, p.stats())
         p.close()
-        line["roofline"] = roofline_of(prof, st, dt)
+        line["roofline"] = roofline_of(prof, st, dt)          # (pipeline.algorithmic_GBps_over_wall: over the headline run's wall time)
         line["roofline"]["pipeline"]["kernel_ms_per_round"] = sum(ms for _, ms in prof.values()) / args.steps
     if rank == 0 and not sharded and not args.no_detection:
         line["detection"] = run_detection(hip, cfg_kw, victims, G, base_quantum)
