@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NONE = 0xFFFFFFFF
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE = 0, -22, -12, -19, -34, -75, -71
@@ -21,7 +21,7 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
 (EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
-F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK, F_COORDINATES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK | F_TCP_FALLBACK
 SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
 INTENT_LEAVE, INTENT_PRUNE = 0x80000000, 0x40000000
@@ -38,7 +38,15 @@ class Config(C.Structure):
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
         "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
-        "shard_rank", "n_shards", "device")] + [("seed", u64)]
+        "shard_rank", "n_shards", "device", "rtt_scale_us", "rtt_height_us", "rtt_jitter_us")] + [("seed", u64)]
+
+
+COORD_DIMS = 8
+
+
+class Coordinate(C.Structure):
+    """coordinate.Coordinate (serf/coordinate), seconds"""
+    _fields_ = [("vec", C.c_double * COORD_DIMS), ("error", C.c_double), ("adjustment", C.c_double), ("height", C.c_double)]
 
 
 class Derived(C.Structure):
@@ -93,7 +101,8 @@ class Stats(C.Structure):
                 ("event_drops", u64), ("user_events_delivered", u64),
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
-                ("view_drops", u64), ("view_evictions", u64), ("intents_applied", u64), ("reaped", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64)]
+                ("view_drops", u64), ("view_evictions", u64), ("intents_applied", u64), ("reaped", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64),
+                ("coord_updates", u64), ("coord_resets", u64)]
 
 
 class XchgHandle(C.Structure):
@@ -148,6 +157,9 @@ PROTOTYPES = {
     "swim_census_get": (C.c_int, [SimP, u32, u32, P(Census)]),
     "swim_trace_read": (C.c_int, [SimP, u32, u32, u32, u32, P(u32)]),
     "swim_stats": (C.c_int, [SimP, P(Stats)]),
+    "swim_coordinate_get": (C.c_int, [SimP, u32, u32, P(Coordinate)]),
+    "swim_coordinate_distance": (C.c_double, [P(Coordinate), P(Coordinate)]),
+    "swim_rtt_truth": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
     "swim_debug_edges": (C.c_int, [SimP, P(Edge), C.c_size_t, P(C.c_size_t)]),
     "swim_state_digest": (C.c_int, [SimP, P(u64)]),
     "swim_profile": (C.c_int, [SimP, C.c_int]),

@@ -12,6 +12,9 @@
 #define SW_EXC_MAX 16               /* per-replica list of nodes whose node word is non-zero */
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
+#define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
+#define SW_COORD_FILTER 3        /* LatencyFilterSize */
+#define SW_COORD_PEERS 16        /* peers whose latency samples a node retains (serf's map is unbounded: DESIGN §8) */
 
 // counters mirrored 1:1 into swim_stats_t by the host
 enum {
@@ -23,6 +26,7 @@ enum {
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
   ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED, ST_JOINS, ST_JOIN_FAIL, ST_INTENTS, ST_REAPED,
+  ST_COORD_UPD, ST_COORD_RESET,
   ST_COUNT
 };
 
@@ -30,7 +34,7 @@ enum {
 // copy (block id % copies): same-address device atomics serialise at ~12 ns apiece, which at a few
 // thousand blocks per launch would cost more than the kernel itself.  The host sums the copies.
 #define SW_STAT_COPIES 256
-#define SW_STAT_STRIDE 56
+#define SW_STAT_STRIDE 64
 
 // sticky device error bits (reported as SWIM_EOVERFLOW by swim_sync)
 #define SW_ERR_EDGE_OVF 0x1u
@@ -154,6 +158,15 @@ struct SwDev {
   uint32_t* n_slots;     // [R]
   uint32_t* slot_dirty;  // [R*S]
   uint32_t* slot_maxinc; // [R*S]
+  // SWIM_F_COORDINATES (serf/coordinate): per lane a coordinate.Coordinate, the adjustment window, the latency filter of the last
+  // SW_COORD_PEERS peers; the probers that got a direct ack this tick are listed by k_begin, k_coord_update computes their new
+  // coordinates from everybody's coordinate as of the start of the tick into c_new, k_coord_commit stores them
+  swim_coordinate* coord;   // [NL]; nullptr = coordinates off
+  double* c_adj;            // [NL][SW_COORD_WINDOW]
+  uint32_t* c_adj_idx;      // [NL]
+  uint4* c_lf;              // [NL][SW_COORD_PEERS][2]: {peer, n, s0, s1}, {s2, last, -, -}
+  uint2* c_list; uint32_t* c_cnt; uint32_t c_cap; swim_coordinate* c_new;
+  uint32_t rtt_scale_us, rtt_height_us, rtt_jitter_us;
   uint32_t* cen_acc;     // [R*S][CEN_WORDS] accumulators
   swim_census* census;   // [R*S] cached
   uint32_t* trace;       // [R*S][trace_ticks][5]
@@ -228,7 +241,7 @@ struct BeginPlan {
 #define SW_KST(k) ((k) & 3u)
 #define SW_BASE_KEY SW_KEY(1, SWIM_STATE_ALIVE)
 
-enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4, SW_STREAM_PUSHPULL = 5 };
+enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4, SW_STREAM_PUSHPULL = 5, SW_STREAM_TRUTH = 6, SW_STREAM_RTT = 7, SW_STREAM_COORD = 8 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10: counter-based, so a draw depends on (seed, stream, tick, node, index) only.

@@ -124,6 +124,7 @@ int validate(const swim_config* c) {
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
+  if ((c->flags & SWIM_F_COORDINATES) && (c->n_shards != 1 || c->rtt_scale_us > 10000000u || c->rtt_height_us > 1000000u || c->rtt_jitter_us > 1000000u)) return SWIM_EINVAL;
   return SWIM_OK;
 }
 uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -156,6 +157,7 @@ extern "C" int swim_config_preset(swim_config* c, int preset) {
   c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8; c->view_cap = 0; c->fold_interval_ms = 0;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
+  c->rtt_scale_us = 40000; c->rtt_height_us = 2000; c->rtt_jitter_us = 0;
   return SWIM_OK;
 }
 
@@ -380,6 +382,12 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   }
   DALLOC(s, D.subj_node, NS); DALLOC(s, D.n_slots, D.R); DALLOC(s, D.slot_dirty, NS);
   DALLOC(s, D.slot_maxinc, NS);
+  if (cfg->flags & SWIM_F_COORDINATES) {
+    DALLOC(s, D.coord, NL); DALLOC(s, D.c_adj, NL * SW_COORD_WINDOW); DALLOC(s, D.c_adj_idx, NL); DALLOC(s, D.c_lf, NL * SW_COORD_PEERS * 2);
+    D.c_cap = (uint32_t)std::min<size_t>(NL, (size_t)D.R * cdiv(cdiv(D.nloc, d.probe_period), SW_BLOCK) * SW_BLOCK + (size_t)D.R * 2 * SW_BLOCK);   // at most the probe-due lanes of a tick
+    DALLOC(s, D.c_list, D.c_cap); DALLOC(s, D.c_new, D.c_cap); DALLOC(s, D.c_cnt, 1);
+    D.rtt_scale_us = cfg->rtt_scale_us; D.rtt_height_us = cfg->rtt_height_us; D.rtt_jitter_us = cfg->rtt_jitter_us;
+  }
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
   if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
 
@@ -495,7 +503,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
-  s->pristine = cfg->loss_q32 == 0 && !D.dyn && cfg->n_shards == 1;
+  if (D.coord) { HIPCK(s, hipMemsetAsync(D.c_cnt, 0, 4, st)); hipLaunchKernelGGL(k_coord_init, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D); HIPCK(s, hipStreamSynchronize(st)); }
+  s->pristine = cfg->loss_q32 == 0 && !D.dyn && cfg->n_shards == 1 && !D.coord;      // (coordinates move in quiet ticks too)
   *out = s;
   return SWIM_OK;
 }
@@ -537,6 +546,10 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
   } else {
     ProfScope p(s, PK_BEGIN);
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
+  }
+  if (D.coord) {      // serf's ping delegate: the probers k_begin listed update their coordinates (from everybody's as of the start of the tick)
+    hipLaunchKernelGGL(k_coord_update, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    hipLaunchKernelGGL(k_coord_commit, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
 }
 static void launch_end(swim_sim* s, uint32_t tick) {
@@ -1104,6 +1117,39 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->user_events_stale = v[ST_UEV_STALE]; out->msgs_filtered = v[ST_FILTERED]; out->push_pulls = v[ST_PUSHPULLS];
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
   out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->intents_applied = v[ST_INTENTS]; out->reaped = v[ST_REAPED]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
+  out->coord_updates = v[ST_COORD_UPD]; out->coord_resets = v[ST_COORD_RESET];
+  return SWIM_OK;
+}
+
+// ---- network coordinates (SWIM_F_COORDINATES) ---------------------------------------------------------------
+extern "C" int swim_coordinate_get(swim_sim* s, uint32_t replica, uint32_t node, swim_coordinate* out) {
+  if (!s || !out || replica >= s->D.R || node >= s->D.N) return SWIM_EINVAL;
+  if (!s->D.coord) return SWIM_ESTATE;
+  return d2h(s, out, (const swim_coordinate*)s->D.coord + ((size_t)replica * s->D.nloc + (node - s->D.i0)), 1);
+}
+// librtt.ComputeDistance (internal/gossip/librtt/rtt.go:16-22) = a.DistanceTo(b).Seconds(): host arithmetic on two PODs
+// (x86-64 without FMA: every operation rounds once, like Go)
+extern "C" double swim_coordinate_distance(const swim_coordinate* a, const swim_coordinate* b) {
+  if (!a || !b) return INFINITY;
+  double sum = 0.0;
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) { const double d = a->vec[i] - b->vec[i]; sum += d * d; }
+  double dist = std::sqrt(sum) + a->height + b->height;
+  const double adjusted = dist + a->adjustment + b->adjustment;
+  if (adjusted > 0.0) dist = adjusted;
+  const int64_t ns = (int64_t)(dist * 1.0e9);                      // time.Duration: whole nanoseconds, truncated
+  return (double)(ns / 1000000000) + (double)(ns % 1000000000) / 1e9;
+}
+extern "C" int swim_rtt_truth(swim_sim* s, uint32_t replica, uint32_t a, uint32_t b, uint32_t* rtt_us) {
+  if (!s || !rtt_us || replica >= s->D.R || a >= s->D.N || b >= s->D.N) return SWIM_EINVAL;
+  uint32_t w[2][4]; const uint64_t sr = s->cfg.seed + replica; const uint32_t ids[2] = { a, b };
+  for (int j = 0; j < 2; j++) sw_philox(ids[j], 0, 0, 0x54525554u, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_TRUTH, w[j]);
+  double sum = 0.0; uint32_t h = 0;
+  for (int k = 0; k < 3; k++) {
+    const double d = (double)(uint32_t)(((uint64_t)w[0][k] * s->cfg.rtt_scale_us) >> 32) - (double)(uint32_t)(((uint64_t)w[1][k] * s->cfg.rtt_scale_us) >> 32);
+    sum += d * d;
+  }
+  for (int j = 0; j < 2; j++) h += (uint32_t)(((uint64_t)w[j][3] * s->cfg.rtt_height_us) >> 32);
+  *rtt_us = (uint32_t)std::sqrt(sum) + h;
   return SWIM_OK;
 }
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {

@@ -472,6 +472,7 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
   const uint32_t* nw = D.nw + (size_t)r * D.N;
   bool e_buddy = false, e_self = false, c_probe = false, c_ack = false, e_pend = false;
   bool o_ping = false, o_ack = false;                // piggy-back orders: for my ping, for the target's ack
+  uint32_t c_x = NONE;                               // SWIM_F_COORDINATES: the target whose direct ack came back (serf's ping delegate)
   uint32_t o_ping_rcv = NONE, o_ack_rcv = NONE, o_x = 0;
   uint4 rec_buddy = make_uint4(0, 0, 0, 0), rec_self = rec_buddy; uint32_t buddy_sh = 0;
   size_t l = 0;
@@ -514,7 +515,7 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
           if (SW_KST(key) == SWIM_STATE_ALIVE && piggy_hint(D, r, i, peer_active)) { o_ping = true; o_ping_rcv = fwd ? x : NONE; }
           if (fwd && piggy_hint(D, r, x, peer_active)) { o_ack = true; o_ack_rcv = ack ? i : NONE; }
         }
-        if (ack) { aw = awareness_apply(D, aw, -1); c_ack = true; }
+        if (ack) { aw = awareness_apply(D, aw, -1); c_ack = true; c_x = x; }
         else {
           stage = 1; nackm = 1; e_pend = true;
           D.pr0[l] = make_uint4(x, SW_KINC(key), t + D.P * (aw + 1), t);   // awareness.ScaleTimeout(ProbeInterval)
@@ -526,6 +527,17 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
   }
   S.count(ST_PROBES, c_probe); S.count(ST_ACKS, c_ack);
 
+  if (D.coord && __any(c_ack)) {                    // NotifyPingComplete: list the prober for k_coord_update (one atomic per wave)
+    const uint64_t mask = __ballot(c_ack);
+    const uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(D.c_cnt, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (c_ack) {
+      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+      if (pos < D.c_cap) D.c_list[pos] = make_uint2((uint32_t)l, c_x); else atomicOr(D.err, SW_ERR_PEND_OVF);
+    }
+  }
   // everything below is off the common path: wave-aggregated appends suffice
   if (__any(e_pend)) {
     uint32_t li = t % (D.TQ + 1);
@@ -1024,6 +1036,205 @@ __device__ __forceinline__ void role_carry(DevRef D, uint32_t b, uint32_t nb, ui
   }
   S.wave_add(ST_EDGES, c_rem); S.wave_add(ST_EDGES_REMOTE, c_rem);
   S.flush(D);
+}
+
+
+// =================================================================================================
+// serf/coordinate — Vivaldi network coordinates (SWIM_F_COORDINATES).  serf v0.10.4
+// coordinate/{config,coordinate,client}.go and ping_delegate.go restated for one lane; in-tree pin:
+// librtt.ComputeDistance (internal/gossip/librtt/rtt.go:16-22).  f64 throughout, every operation through a
+// round-to-nearest intrinsic so that nothing is contracted into an FMA: Go rounds after every operation, and so
+// does the checker.  No MFMA: 8-wide vectors, one update per probing node and second.
+// =================================================================================================
+// hipcc's __dmul_rn/__dadd_rn are plain '*' and '+': without this the compiler still fuses them into v_fma_f64 (-ffp-contract=
+// fast-honor-pragmas is the HIP default), which is what made the first device run differ from Go-style rounding by 1-3 ulp.
+// File scope from here on; everything below that is not a coordinate is integer work.  lib.py also passes -ffp-contract=off.
+#pragma clang fp contract(off)
+#define SW_VIVALDI_ERROR_MAX 1.5
+#define SW_VIVALDI_CE 0.25
+#define SW_VIVALDI_CC 0.25
+#define SW_COORD_HEIGHT_MIN 10.0e-6
+#define SW_COORD_GRAVITY_RHO 150.0
+#define SW_COORD_ZERO 1.0e-6
+__device__ __forceinline__ double cmul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double cadd(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double csub(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ double cdiv_(double a, double b) { return __ddiv_rn(a, b); }
+__device__ __forceinline__ void coord_fresh(swim_coordinate& c) {     // NewCoordinate
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) c.vec[i] = 0.0;
+  c.error = SW_VIVALDI_ERROR_MAX; c.adjustment = 0.0; c.height = SW_COORD_HEIGHT_MIN;
+}
+__device__ __forceinline__ bool coord_valid(const swim_coordinate& c) {
+  bool ok = isfinite(c.error) && isfinite(c.adjustment) && isfinite(c.height);
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) ok = ok && isfinite(c.vec[i]);
+  return ok;
+}
+__device__ __forceinline__ double vec_magnitude(const double* v) {
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) sum = cadd(sum, cmul(v[i], v[i]));
+  return __dsqrt_rn(sum);
+}
+__device__ __forceinline__ double coord_raw_distance(const swim_coordinate& a, const swim_coordinate& b) {
+  double d[SWIM_COORD_DIMS];
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) d[i] = csub(a.vec[i], b.vec[i]);
+  return cadd(cadd(vec_magnitude(d), a.height), b.height);
+}
+// DistanceTo(...).Seconds(): through time.Duration (int64 nanoseconds, truncated) and back
+__device__ __forceinline__ double coord_distance_seconds(const swim_coordinate& a, const swim_coordinate& b) {
+  double dist = coord_raw_distance(a, b);
+  const double adjusted = cadd(cadd(dist, a.adjustment), b.adjustment);
+  if (adjusted > 0.0) dist = adjusted;
+  const long long ns = (long long)cmul(dist, 1.0e9);
+  return cadd((double)(ns / 1000000000ll), cdiv_((double)(ns % 1000000000ll), 1e9));
+}
+// unitVectorAt: direction from b to a; coincident points get a random one (rand.Float64() - 0.5 per dimension)
+__device__ __forceinline__ double coord_unit_vector(DevRef D, uint32_t r, uint32_t o, uint32_t t, uint32_t salt, const double* a, const double* b, double* unit) {
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = csub(a[i], b[i]);
+  double mag = vec_magnitude(unit);
+  if (mag > SW_COORD_ZERO) {
+    const double inv = cdiv_(1.0, mag);
+#pragma unroll
+    for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = cmul(unit[i], inv);
+    return mag;
+  }
+  SwDraws d; d.init(seed_of(D, r), SW_STREAM_COORD, t, o);
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = csub(cdiv_((double)d.get(salt * SWIM_COORD_DIMS + (uint32_t)i), 4294967296.0), 0.5);
+  mag = vec_magnitude(unit);
+  if (mag > SW_COORD_ZERO) {
+    const double inv = cdiv_(1.0, mag);
+#pragma unroll
+    for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = cmul(unit[i], inv);
+    return 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = 0.0;
+  unit[0] = 1.0;
+  return 0.0;
+}
+__device__ __forceinline__ void coord_apply_force(DevRef D, uint32_t r, uint32_t o, uint32_t t, uint32_t salt, swim_coordinate& c, double force, const swim_coordinate& other) {
+  double unit[SWIM_COORD_DIMS];
+  const double mag = coord_unit_vector(D, r, o, t, salt, c.vec, other.vec, unit);
+#pragma unroll
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) c.vec[i] = cadd(c.vec[i], cmul(unit[i], force));
+  if (mag > SW_COORD_ZERO) {
+    c.height = cadd(cdiv_(cmul(cadd(c.height, other.height), force), mag), c.height);
+    if (!(c.height >= SW_COORD_HEIGHT_MIN) && !isnan(c.height)) c.height = SW_COORD_HEIGHT_MIN;   // math.Max: NaN stays NaN
+  }
+}
+// the latency model: hidden position and access-link height of a node, microseconds (swimsim.h, swim_config.rtt_*)
+__device__ __forceinline__ void rtt_truth_of(DevRef D, uint32_t r, uint32_t i, uint32_t pos[3], uint32_t& h) {
+  uint32_t w[4]; const uint64_t sr = seed_of(D, r);
+  sw_philox(i, 0, 0, 0x54525554u, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_TRUTH, w);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pos[k] = (uint32_t)(((uint64_t)w[k] * D.rtt_scale_us) >> 32);
+  h = (uint32_t)(((uint64_t)w[3] * D.rtt_height_us) >> 32);
+}
+__device__ __forceinline__ uint32_t rtt_between(DevRef D, uint32_t r, uint32_t a, uint32_t b) {
+  uint32_t pa[3], pb[3], ha, hb; rtt_truth_of(D, r, a, pa, ha); rtt_truth_of(D, r, b, pb, hb);
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const double d = csub((double)pa[k], (double)pb[k]); sum = cadd(sum, cmul(d, d)); }
+  return (uint32_t)__dsqrt_rn(sum) + ha + hb;
+}
+// Client.latencyFilter: the median of the last LatencyFilterSize round-trip times seen from this peer (microseconds)
+__device__ __forceinline__ uint32_t coord_latency_filter(DevRef D, size_t l, uint32_t t, uint32_t peer, uint32_t rtt_us) {
+  uint4* tab = D.c_lf + l * SW_COORD_PEERS * 2;
+  uint32_t hit = NONE, vic = 0, vic_last = 0; bool vic_free = false;
+  for (uint32_t j = 0; j < SW_COORD_PEERS; j++) {
+    const uint4 a = tab[2 * j]; const uint32_t last = tab[2 * j + 1].y;
+    if (a.y && a.x == peer) { hit = j; break; }
+    if (vic_free) continue;
+    if (!a.y) { vic = j; vic_free = true; } else if (j == 0 || last < vic_last) { vic = j; vic_last = last; }
+  }
+  uint32_t n = 0, s0 = 0, s1 = 0, s2 = 0;
+  if (hit != NONE) { const uint4 a = tab[2 * hit]; n = a.y; s0 = a.z; s1 = a.w; s2 = tab[2 * hit + 1].x; }
+  else hit = vic;
+  if (n == SW_COORD_FILTER) { s0 = s1; s1 = s2; n--; }
+  if (n == 0) s0 = rtt_us; else if (n == 1) s1 = rtt_us; else s2 = rtt_us;
+  n++;
+  tab[2 * hit] = make_uint4(peer, n, s0, s1); tab[2 * hit + 1] = make_uint4(s2, t, 0, 0);
+  // sorted[n / 2]
+  if (n == 1) return s0;
+  if (n == 2) return s0 > s1 ? s0 : s1;
+  const uint32_t lo = s0 < s1 ? s0 : s1, hi = s0 < s1 ? s1 : s0;
+  return s2 < lo ? lo : (s2 > hi ? hi : s2);
+}
+// serf pingDelegate.NotifyPingComplete -> Client.Update(other, coord, rtt) for every prober k_begin listed: the ack's payload
+// is the acker's coordinate as of the START of this tick (D.coord is only written by k_coord_commit)
+__global__ void __launch_bounds__(SW_BLOCK) k_coord_update(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x, n = *D.c_cnt < D.c_cap ? *D.c_cnt : D.c_cap;
+  bool upd = false, reset = false;
+  if (e < n) {
+    const uint2 ent = D.c_list[e];
+    const size_t l = ent.x; const uint32_t x = ent.y, r = div_nloc(D, l), o = D.i0 + mod_nloc(D, l), t = *D.tick;
+    const swim_coordinate other = D.coord[(size_t)r * D.nloc + (x - D.i0)];
+    swim_coordinate c = D.coord[l];
+    uint32_t rtt_us = rtt_between(D, r, o, x);
+    if (D.rtt_jitter_us) {
+      uint32_t w[4]; const uint64_t sr = seed_of(D, r);
+      sw_philox(t, o, 0, 0x52545431u, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_RTT, w);
+      rtt_us += (uint32_t)(((uint64_t)w[0] * D.rtt_jitter_us) >> 32);
+    }
+    upd = true;
+    const uint32_t med_us = coord_latency_filter(D, l, t, x, rtt_us);
+    const double rtt = cdiv_((double)((unsigned long long)med_us * 1000ull), 1e9);
+    {   // updateVivaldi
+      const double dist = coord_distance_seconds(c, other);
+      const double rs = rtt < SW_COORD_ZERO ? SW_COORD_ZERO : rtt;
+      const double wrongness = cdiv_(fabs(csub(dist, rs)), rs);
+      double total = cadd(c.error, other.error); if (total < SW_COORD_ZERO) total = SW_COORD_ZERO;
+      const double weight = cdiv_(c.error, total);
+      c.error = cadd(cmul(cmul(SW_VIVALDI_CE, weight), wrongness), cmul(c.error, csub(1.0, cmul(SW_VIVALDI_CE, weight))));
+      if (c.error > SW_VIVALDI_ERROR_MAX) c.error = SW_VIVALDI_ERROR_MAX;
+      const double delta = cmul(SW_VIVALDI_CC, weight), force = cmul(delta, csub(rs, dist));
+      coord_apply_force(D, r, o, t, 0, c, force, other);
+    }
+    {   // updateAdjustment
+      const double dist = coord_raw_distance(c, other);
+      double* adj = D.c_adj + l * SW_COORD_WINDOW;
+      const uint32_t idx = D.c_adj_idx[l];
+      adj[idx] = csub(rtt, dist); D.c_adj_idx[l] = (idx + 1) % SW_COORD_WINDOW;
+      double sum = 0.0;
+      for (int i = 0; i < SW_COORD_WINDOW; i++) sum = cadd(sum, adj[i]);
+      c.adjustment = cdiv_(sum, cmul(2.0, (double)SW_COORD_WINDOW));
+    }
+    {   // updateGravity
+      swim_coordinate origin; coord_fresh(origin);
+      const double dist = coord_distance_seconds(origin, c), q = cdiv_(dist, SW_COORD_GRAVITY_RHO), force = cmul(-1.0, cmul(q, q));
+      coord_apply_force(D, r, o, t, 1, c, force, origin);
+    }
+    if (!coord_valid(c)) { reset = true; coord_fresh(c); }
+    D.c_new[e] = c;
+  }
+  const uint64_t mu = __ballot(upd), mr = __ballot(reset);
+  if (sw_lane() == 0) {
+    if (mu) atomicAdd(stat_ptr(D, ST_COORD_UPD), (unsigned long long)__popcll(mu));
+    if (mr) atomicAdd(stat_ptr(D, ST_COORD_RESET), (unsigned long long)__popcll(mr));
+  }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_coord_commit(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x, n = *D.c_cnt < D.c_cap ? *D.c_cnt : D.c_cap;
+  if (e < n) D.coord[D.c_list[e].x] = D.c_new[e];
+}
+// a fresh process (swim_inject_join): a fresh coordinate client
+__device__ __forceinline__ void coord_reset_lane(DevRef D, size_t l) {
+  swim_coordinate c; coord_fresh(c); D.coord[l] = c;
+  for (int i = 0; i < SW_COORD_WINDOW; i++) D.c_adj[l * SW_COORD_WINDOW + i] = 0.0;
+  D.c_adj_idx[l] = 0;
+  for (int j = 0; j < SW_COORD_PEERS * 2; j++) D.c_lf[l * SW_COORD_PEERS * 2 + j] = make_uint4(0, 0, 0, 0);
+}
+__global__ void k_coord_init(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < NL) coord_reset_lane(D, l);
 }
 
 // =================================================================================================
@@ -2016,6 +2227,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     for (uint32_t sh = 0; sh < D.n_shards; sh++) { last_cnt[sh] = D.out_cnt[sh]; D.out_cnt[sh] = 0; }
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
     if (D.join_cnt) *D.join_cnt = 0;           // the joins of this tick are under way
+    if (D.c_cnt) *D.c_cnt = 0;                 // this tick's coordinate updates are committed
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
@@ -2222,6 +2434,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         const uint2 p = D.ph[l];
         D.ph[l].y = p_pack(p_epoch(p.y), 0, 0, 0); D.pr0[l].x = NONE; D.in_cnt[l] = 0;
         q_bit_lane(D, l, false, true);
+        if (D.coord) coord_reset_lane(D, l);                  // a fresh process: a fresh coordinate client
         NodeCtx c(D, S);
         c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = NL;
         c.load();
@@ -2341,6 +2554,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restri
         if (n >= 2) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.z);
         if (n >= 3) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.w);
       }
+    if (D.coord) {                               // coordinates: the raw bits
+      const double* f = (const double*)&D.coord[l];
+      for (uint32_t j = 0; j < SWIM_COORD_DIMS + 3; j++) d += sw_h3(20 + j, g, (uint64_t)__double_as_longlong(f[j]));
+    }
   }
   digest_commit(d, out);
 }

@@ -30,7 +30,7 @@ def build(force: bool = False) -> str:
         if os.path.exists(LIB_PATH):
             return LIB_PATH
         raise FileNotFoundError("libswimsim.so sources are missing")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-shared", "-fPIC",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value", "-shared", "-fPIC",
            "-o", LIB_PATH, SOURCES[0]]
     subprocess.run(cmd, check=True)
     return LIB_PATH

@@ -252,6 +252,22 @@ class Sim:
             self._h, replica, subject, first_tick, n, out.ctypes.data_as(C.POINTER(abi.u32))))
         return out
 
+    def coordinate(self, replica: int, node: int) -> abi.Coordinate:
+        """serf.GetCoordinate() of a virtual node (SWIM_F_COORDINATES)"""
+        o = abi.Coordinate()
+        self._ck("swim_coordinate_get", self._l.swim_coordinate_get(self._h, replica, node, C.byref(o)))
+        return o
+
+    def distance(self, a, b) -> float:
+        """librtt.ComputeDistance: seconds; +inf when either coordinate is None"""
+        return float(self._l.swim_coordinate_distance(C.byref(a) if a is not None else None, C.byref(b) if b is not None else None))
+
+    def rtt_truth(self, replica: int, a: int, b: int) -> int:
+        """the latency model's round-trip time between two nodes, microseconds, without jitter"""
+        o = abi.u32()
+        self._ck("swim_rtt_truth", self._l.swim_rtt_truth(self._h, replica, a, b, C.byref(o)))
+        return int(o.value)
+
     def stats(self) -> dict:
         o = abi.Stats()
         self._ck("swim_stats", self._l.swim_stats(self._h, C.byref(o)))

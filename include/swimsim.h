@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 3u
+#define SWIM_ABI_VERSION 4u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -86,6 +86,11 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
  * a TCP ping goes out next to the indirect probes.  TCP rides out packet loss, so it reaches every running node of
  * the same partition; contact counts as a successful probe. */
 #define SWIM_F_TCP_FALLBACK   0x20u
+/* serf/coordinate (Vivaldi network coordinates): every node keeps a coordinate.Coordinate and updates it
+ * on each DIRECT probe ack with the acker's coordinate and the measured round-trip time (serf ping_delegate.go
+ * NotifyPingComplete -> coordinate.Client.Update).  Round-trip times come from the latency model below (rtt_*).
+ * Unsharded handles only (an ack from another shard would have to carry the coordinate).  Not in SWIM_F_DEFAULT. */
+#define SWIM_F_COORDINATES    0x40u
 #define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK | SWIM_F_TCP_FALLBACK)
 
 /* ---- configuration ---------------------------------------------------------------------- */
@@ -147,8 +152,21 @@ typedef struct swim_config {
   uint32_t trace_ticks;             /* per-tick census history capacity (0 = off)           */
   uint32_t shard_rank, n_shards;    /* block partition of every replica's node ids          */
   uint32_t device;                  /* HIP device ordinal (product library)                 */
+  /* SWIM_F_COORDINATES — the latency model the probes measure (the simulator has no wires): node i sits at a hidden point
+   * of a cube with edge rtt_scale_us (three Philox words of stream "truth", in microseconds of round-trip time) behind an
+   * access link of rtt_height_us * u (a fourth word); rtt(i, j) = floor(|p_i - p_j|) + h_i + h_j + jitter, jitter uniform in
+   * [0, rtt_jitter_us) per probe.  Heights are what Vivaldi's height term is for.  Presets: 40 000 / 2 000 / 0. */
+  uint32_t rtt_scale_us, rtt_height_us, rtt_jitter_us;
   uint64_t seed;
 } swim_config;
+
+/* coordinate.Coordinate (serf/coordinate/coordinate.go), Dimensionality = 8 (coordinate.DefaultConfig; Consul never changes
+ * it).  Seconds. */
+#define SWIM_COORD_DIMS 8
+typedef struct swim_coordinate {
+  double vec[SWIM_COORD_DIMS];
+  double error, adjustment, height;
+} swim_coordinate;
 
 /* closed-form constants of memberlist util.go / suspicion.go */
 typedef struct swim_derived {
@@ -248,6 +266,8 @@ typedef struct swim_stats_t {
   uint64_t join_failures;
   uint64_t folds;                   /* subjects folded into the base row (counted by the shard owning the id)   */
   uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
+  uint64_t coord_updates;           /* coordinate.Client.Update calls (one per direct probe ack, SWIM_F_COORDINATES) */
+  uint64_t coord_resets;            /* ... that left an invalid coordinate and reset it (Client.stats.Resets)     */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;
@@ -382,6 +402,17 @@ int swim_trace_read(swim_sim* sim, uint32_t replica, uint32_t subject, uint32_t 
                     uint32_t n, uint32_t* out_rows5);
 /* serf.Stats() / memberlist metrics (agent/consul/server.go:1749, SURVEY §5 metrics row) */
 int swim_stats(swim_sim* sim, swim_stats_t* out);
+
+/* ---- network coordinates (SWIM_F_COORDINATES) ---------------------------------------------- */
+/* serf.GetCoordinate() of a virtual node / GetCachedCoordinate(name) as any observer would eventually cache it
+ * (RouterSerfCluster, agent/router/router.go:62-67; agent/consul/server_ce.go:117-119) */
+int swim_coordinate_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_coordinate* out);
+/* librtt.ComputeDistance (internal/gossip/librtt/rtt.go:16-22): a.DistanceTo(b).Seconds() — the raw distance plus both
+ * adjustments when that is positive, through time.Duration (truncated to whole nanoseconds); +Inf when either is NULL.
+ * Pure host arithmetic, no handle needed. */
+double swim_coordinate_distance(const swim_coordinate* a, const swim_coordinate* b);
+/* the latency model's round-trip time between two nodes without jitter, microseconds (to judge the coordinates against) */
+int swim_rtt_truth(swim_sim* sim, uint32_t replica, uint32_t a, uint32_t b, uint32_t* rtt_us);
 /* the edge list of the most recent tick (after emit, before delivery), for parity tests */
 int swim_debug_edges(swim_sim* sim, swim_edge* out, size_t cap, size_t* n_out);
 /* order-independent 64-bit digest over all integer node state (self state, queues, views,

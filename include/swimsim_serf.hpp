@@ -103,6 +103,18 @@ struct EventDelegate {
 }  // namespace memberlist
 
 // =================================================================================================
+// serf/coordinate.Coordinate is the ABI's POD; librtt.ComputeDistance (internal/gossip/librtt/rtt.go:16-22) on top of it
+namespace coordinate { using Coordinate = swim_coordinate; }
+namespace librtt {
+inline double ComputeDistance(const coordinate::Coordinate* a, const coordinate::Coordinate* b) { return swim_coordinate_distance(a, b); }
+// GenerateCoordinate (rtt.go:59-64, tests only): NewCoordinate(DefaultConfig()) at `rtt` from the origin, no height
+inline coordinate::Coordinate GenerateCoordinate(std::chrono::nanoseconds rtt) {
+  coordinate::Coordinate c{};
+  c.error = 1.5; c.vec[0] = std::chrono::duration<double>(rtt).count();
+  return c;
+}
+}  // namespace librtt
+
 namespace serf {
 
 enum MemberStatus { StatusNone = 0, StatusAlive = 1, StatusLeaving = 2, StatusLeft = 3, StatusFailed = 4 };
@@ -169,6 +181,11 @@ class Cluster {
     // calling member's own Config on the host instead.
     uint32_t ReapIntervalMs = 0, ReconnectTimeoutMs = 0, TombstoneTimeoutMs = 0;
     uint32_t FoldIntervalMs = 0;
+    // serf.Config.DisableCoordinates = false (Consul's LAN and WAN pools both keep coordinates: agent/consul/config.go:589-591
+    // only tunes how often they are written to the catalog): every member keeps a Vivaldi coordinate, updated on each direct
+    // probe ack.  The latency the probes measure is the simulator's model (swimsim.h, swim_config.rtt_*).
+    bool Coordinates = false;
+    uint32_t RttScaleUs = 40000, RttHeightUs = 2000, RttJitterUs = 0;
   };
   Cluster(const memberlist::Config& mc, const Options& o) : opts_(o) {
     check(swim_config_preset(&cfg_, SWIM_PRESET_LAN), "swim_config_preset");
@@ -183,6 +200,7 @@ class Cluster {
     cfg_.event_buffer = (uint32_t)o.EventBuffer; cfg_.flags |= SWIM_F_SERF_EVENTS;
     cfg_.n_initial = o.Initial; cfg_.view_cap = o.ViewCap; cfg_.fold_interval_ms = o.FoldIntervalMs;
     cfg_.reap_interval_ms = o.ReapIntervalMs; cfg_.reconnect_timeout_ms = o.ReconnectTimeoutMs; cfg_.tombstone_timeout_ms = o.TombstoneTimeoutMs;
+    if (o.Coordinates) { cfg_.flags |= SWIM_F_COORDINATES; cfg_.rtt_scale_us = o.RttScaleUs; cfg_.rtt_height_us = o.RttHeightUs; cfg_.rtt_jitter_us = o.RttJitterUs; }
     check(swim_config_derive(&cfg_, &derived_), "swim_config_derive");
     check(swim_create(&cfg_, &sim_), "swim_create");
   }
@@ -268,6 +286,17 @@ class Serf {
   }
   int NumNodes() { return (int)Members().size(); }
   SerfState State() const { return state_; }
+
+  // GetCoordinate(): this member's network coordinate; GetCachedCoordinate(name): the coordinate of another member as this one
+  // would cache it from that member's acks (RouterSerfCluster, agent/router/router.go:62-67; the simulator hands out the
+  // member's current coordinate — the cache of a real agent lags by at most one probe cycle).  false = unknown name.
+  coordinate::Coordinate GetCoordinate() { coordinate::Coordinate c; check(swim_coordinate_get(pool_->handle(), replica_, id_, &c), "swim_coordinate_get"); return c; }
+  bool GetCachedCoordinate(const std::string& name, coordinate::Coordinate* out) {
+    uint32_t id = 0;
+    if (!out || !resolve(name, &id)) return false;
+    check(swim_coordinate_get(pool_->handle(), replica_, id, out), "swim_coordinate_get");
+    return true;
+  }
 
   // Join(existing, ignoreOld): serf.Join — a member that is not running yet (an id beyond Cluster::Options::Initial, or one
   // that was shut down) starts and does the join push-pull with the first address that names a member ("node-<id>" or its

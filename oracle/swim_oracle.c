@@ -44,7 +44,7 @@
 /* RNG and hashing                                                                             */
 /* ------------------------------------------------------------------------------------------ */
 
-enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4, STREAM_PUSHPULL = 5 };
+enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4, STREAM_PUSHPULL = 5, STREAM_TRUTH = 6, STREAM_RTT = 7, STREAM_COORD = 8 };
 
 /* Philox4x32-10 (Salmon et al., SC'11; Random123).  Pinned by kat vectors in the tests. */
 static void philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) {
@@ -158,6 +158,7 @@ int swim_config_preset(swim_config* c, int preset) {
   c->queue_cap = 8; c->inbox_cap = 32; c->subject_cap = 8; c->view_cap = 0; c->fold_interval_ms = 0;
   c->event_queue_cap = 8; c->event_buffer = 512;
   c->flags = SWIM_F_DEFAULT; c->watch_node = 0; c->n_shards = 1; c->seed = 1;
+  c->rtt_scale_us = 40000; c->rtt_height_us = 2000; c->rtt_jitter_us = 0;
   return SWIM_OK;
 }
 
@@ -176,6 +177,7 @@ static int validate(const swim_config* c) {
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
+  if ((c->flags & SWIM_F_COORDINATES) && (c->n_shards != 1 || c->rtt_scale_us > 10000000u || c->rtt_height_us > 1000000u || c->rtt_jitter_us > 1000000u)) return SWIM_EINVAL;
   return SWIM_OK;
 }
 
@@ -267,6 +269,13 @@ typedef struct {
   uint32_t nk;                    /* explicit views of nodes the base row has never heard of (estNumNodes = base_known + nk) */
 } node_t;
 
+/* serf/coordinate client state of one node (SWIM_F_COORDINATES) */
+#define COORD_WINDOW 20          /* AdjustmentWindowSize */
+#define COORD_FILTER 3           /* LatencyFilterSize */
+#define COORD_PEERS 16           /* peers whose latency samples a node retains (serf's map is unbounded: DESIGN §8) */
+typedef struct { uint32_t peer, n, s[COORD_FILTER], last; } lf_ent;   /* samples in microseconds, oldest first; last = tick of last use */
+typedef struct { swim_coordinate c; double adj[COORD_WINDOW]; uint32_t adj_idx; lf_ent lf[COORD_PEERS]; } coord_state;
+
 /* a watch slot: census, first-* stamps and trace of one subject (observation only; the protocol never looks here) */
 typedef struct {
   uint32_t node;            /* subject id */
@@ -306,6 +315,8 @@ struct swim_sim {
   uint32_t loss_q32;
   /* swim_xchg_*: the other shards of the population (same process) and ticks one of them already ran on our behalf */
   struct swim_sim** xpeers; uint32_t xcredit;
+  coord_state* cs;               /* [R*nloc] SWIM_F_COORDINATES */
+  swim_coordinate* c_new; uint32_t* c_list; uint32_t c_n;   /* this tick's updates: computed from the coordinates as of the start of the tick, committed at its end */
   char err[256];
 };
 
@@ -804,6 +815,152 @@ static int excl_indirect(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, void* 
   return KST(view_key(s, r, o, x, NULL)) != SWIM_STATE_ALIVE;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* serf/coordinate — Vivaldi network coordinates (SWIM_F_COORDINATES).  UPSTREAM-RECALL of     */
+/* serf v0.10.4 coordinate/{config,coordinate,client}.go and serf/ping_delegate.go; the in-tree */
+/* pins are librtt.ComputeDistance and its test table (internal/gossip/librtt/rtt.go:16-22,     */
+/* rtt_test.go:16-75).  Compiled with -ffp-contract=off: every operation rounds once, like Go.  */
+/* ------------------------------------------------------------------------------------------ */
+#define VIVALDI_ERROR_MAX 1.5      /* coordinate.DefaultConfig(): VivaldiErrorMax, VivaldiCE, VivaldiCC, HeightMin, GravityRho */
+#define VIVALDI_CE 0.25
+#define VIVALDI_CC 0.25
+#define COORD_HEIGHT_MIN 10.0e-6
+#define COORD_GRAVITY_RHO 150.0
+#define COORD_ZERO_THRESHOLD 1.0e-6
+
+static void coord_new(swim_coordinate* c) {              /* NewCoordinate */
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) c->vec[i] = 0.0;
+  c->error = VIVALDI_ERROR_MAX; c->adjustment = 0.0; c->height = COORD_HEIGHT_MIN;
+}
+static int coord_valid(const swim_coordinate* c) {       /* IsValid: every component finite */
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) if (!isfinite(c->vec[i])) return 0;
+  return isfinite(c->error) && isfinite(c->adjustment) && isfinite(c->height);
+}
+static double vec_magnitude(const double* v) { double sum = 0.0; for (int i = 0; i < SWIM_COORD_DIMS; i++) sum += v[i] * v[i]; return sqrt(sum); }
+static double coord_raw_distance(const swim_coordinate* a, const swim_coordinate* b) {   /* rawDistanceTo */
+  double d[SWIM_COORD_DIMS]; for (int i = 0; i < SWIM_COORD_DIMS; i++) d[i] = a->vec[i] - b->vec[i];
+  return vec_magnitude(d) + a->height + b->height;
+}
+/* DistanceTo(...).Seconds(): through time.Duration — int64 nanoseconds, truncated — and back */
+static double coord_distance_seconds(const swim_coordinate* a, const swim_coordinate* b) {
+  double dist = coord_raw_distance(a, b), adjusted = dist + a->adjustment + b->adjustment;
+  if (adjusted > 0.0) dist = adjusted;
+  int64_t ns = (int64_t)(dist * 1.0e9);
+  return (double)(ns / 1000000000) + (double)(ns % 1000000000) / 1e9;
+}
+double swim_coordinate_distance(const swim_coordinate* a, const swim_coordinate* b) {
+  if (!a || !b) return INFINITY;
+  return coord_distance_seconds(a, b);
+}
+/* unitVectorAt: the direction from b to a; coincident points get a random direction (rand.Float64() - 0.5 per dimension) */
+static double coord_unit_vector(swim_sim* s, uint32_t r, uint32_t o, uint32_t salt, const double* a, const double* b, double* unit) {
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = a[i] - b[i];
+  double mag = vec_magnitude(unit);
+  if (mag > COORD_ZERO_THRESHOLD) { double inv = 1.0 / mag; for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = unit[i] * inv; return mag; }
+  draws_t d; draws_init(&d, seed_of(s, r), STREAM_COORD, s->tick, o);
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = (double)draws_get(&d, salt * SWIM_COORD_DIMS + (uint32_t)i) / 4294967296.0 - 0.5;
+  mag = vec_magnitude(unit);
+  if (mag > COORD_ZERO_THRESHOLD) { double inv = 1.0 / mag; for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = unit[i] * inv; return 0.0; }
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) unit[i] = 0.0;
+  unit[0] = 1.0; return 0.0;
+}
+static void coord_apply_force(swim_sim* s, uint32_t r, uint32_t o, uint32_t salt, swim_coordinate* c, double force, const swim_coordinate* other) {
+  double unit[SWIM_COORD_DIMS], mag = coord_unit_vector(s, r, o, salt, c->vec, other->vec, unit);
+  for (int i = 0; i < SWIM_COORD_DIMS; i++) c->vec[i] = c->vec[i] + unit[i] * force;
+  if (mag > COORD_ZERO_THRESHOLD) {
+    c->height = (c->height + other->height) * force / mag + c->height;
+    if (!(c->height >= COORD_HEIGHT_MIN)) c->height = isnan(c->height) ? c->height : COORD_HEIGHT_MIN;   /* math.Max(height, HeightMin): NaN stays NaN */
+  }
+}
+/* the latency model: hidden position and access-link height of a node, microseconds */
+static void rtt_truth_of(swim_sim* s, uint32_t r, uint32_t i, uint32_t pos[3], uint32_t* h) {
+  uint32_t key[2], c[4] = { i, 0, 0, 0x54525554u }, w[4];
+  stream_key(seed_of(s, r), STREAM_TRUTH, key); philox4x32(c, key, w);
+  for (int k = 0; k < 3; k++) pos[k] = (uint32_t)(((uint64_t)w[k] * s->cfg.rtt_scale_us) >> 32);
+  *h = (uint32_t)(((uint64_t)w[3] * s->cfg.rtt_height_us) >> 32);
+}
+static uint32_t rtt_between(swim_sim* s, uint32_t r, uint32_t a, uint32_t b) {
+  uint32_t pa[3], pb[3], ha, hb; rtt_truth_of(s, r, a, pa, &ha); rtt_truth_of(s, r, b, pb, &hb);
+  double sum = 0.0;
+  for (int k = 0; k < 3; k++) { double d = (double)pa[k] - (double)pb[k]; sum += d * d; }
+  return (uint32_t)sqrt(sum) + ha + hb;
+}
+int swim_rtt_truth(swim_sim* s, uint32_t replica, uint32_t a, uint32_t b, uint32_t* rtt_us) {
+  if (!s || !rtt_us || replica >= s->R || a >= s->N || b >= s->N) return SWIM_EINVAL;
+  *rtt_us = rtt_between(s, replica, a, b);
+  return SWIM_OK;
+}
+int swim_coordinate_get(swim_sim* s, uint32_t replica, uint32_t node, swim_coordinate* out) {
+  if (!s || !out || replica >= s->R || node >= s->N) return SWIM_EINVAL;
+  if (!s->cs) return SWIM_ESTATE;
+  *out = s->cs[(size_t)replica * s->nloc + (node - s->i0)].c;
+  return SWIM_OK;
+}
+/* Client.latencyFilter: the median of the last LatencyFilterSize round-trip times seen from this peer */
+static uint32_t coord_latency_filter(swim_sim* s, coord_state* st, uint32_t peer, uint32_t rtt_us) {
+  lf_ent* e = NULL;
+  for (int j = 0; j < COORD_PEERS; j++) if (st->lf[j].n && st->lf[j].peer == peer) { e = &st->lf[j]; break; }
+  if (!e) {                                              /* a free entry, else the one unused for longest (ties: lowest index) */
+    e = &st->lf[0];
+    for (int j = 0; j < COORD_PEERS; j++) { if (!st->lf[j].n) { e = &st->lf[j]; break; } if (st->lf[j].last < e->last) e = &st->lf[j]; }
+    e->peer = peer; e->n = 0;
+  }
+  if (e->n == COORD_FILTER) { for (int j = 1; j < COORD_FILTER; j++) e->s[j - 1] = e->s[j]; e->n--; }
+  e->s[e->n++] = rtt_us; e->last = s->tick;
+  uint32_t sorted[COORD_FILTER];
+  for (uint32_t j = 0; j < e->n; j++) sorted[j] = e->s[j];
+  for (uint32_t j = 1; j < e->n; j++) for (uint32_t k = j; k > 0 && sorted[k - 1] > sorted[k]; k--) { uint32_t t = sorted[k]; sorted[k] = sorted[k - 1]; sorted[k - 1] = t; }
+  return sorted[e->n / 2];
+}
+/* serf pingDelegate.NotifyPingComplete -> Client.Update(other, coord, rtt): node o got a direct ack from x.  The ack's payload
+ * is x's coordinate as of the START of this tick (determinisation: x may be updating its own in the same tick). */
+static void coord_update(swim_sim* s, uint32_t r, uint32_t o, uint32_t x) {
+  coord_state* st = &s->cs[(size_t)r * s->nloc + (o - s->i0)];
+  const swim_coordinate* other = &s->cs[(size_t)r * s->nloc + (x - s->i0)].c;
+  uint32_t rtt_us = rtt_between(s, r, o, x);
+  if (s->cfg.rtt_jitter_us) {
+    uint32_t key[2], c[4] = { s->tick, o, 0, 0x52545431u }, w[4];
+    stream_key(seed_of(s, r), STREAM_RTT, key); philox4x32(c, key, w);
+    rtt_us += (uint32_t)(((uint64_t)w[0] * s->cfg.rtt_jitter_us) >> 32);
+  }
+  s->st.coord_updates++;
+  uint32_t med_us = coord_latency_filter(s, st, x, rtt_us);
+  double rtt = (double)((uint64_t)med_us * 1000u) / 1e9;          /* time.Duration(ns).Seconds() below one second */
+  swim_coordinate c = st->c;
+  /* updateVivaldi */
+  {
+    double dist = coord_distance_seconds(&c, other);
+    double rs = rtt < COORD_ZERO_THRESHOLD ? COORD_ZERO_THRESHOLD : rtt;
+    double wrongness = fabs(dist - rs) / rs;
+    double total = c.error + other->error; if (total < COORD_ZERO_THRESHOLD) total = COORD_ZERO_THRESHOLD;
+    double weight = c.error / total;
+    c.error = VIVALDI_CE * weight * wrongness + c.error * (1.0 - VIVALDI_CE * weight);
+    if (c.error > VIVALDI_ERROR_MAX) c.error = VIVALDI_ERROR_MAX;
+    double delta = VIVALDI_CC * weight, force = delta * (rs - dist);
+    coord_apply_force(s, r, o, 0, &c, force, other);
+  }
+  /* updateAdjustment */
+  {
+    double dist = coord_raw_distance(&c, other);
+    st->adj[st->adj_idx] = rtt - dist; st->adj_idx = (st->adj_idx + 1) % COORD_WINDOW;
+    double sum = 0.0; for (int i = 0; i < COORD_WINDOW; i++) sum += st->adj[i];
+    c.adjustment = sum / (2.0 * (double)COORD_WINDOW);
+  }
+  /* updateGravity: a pull towards the origin */
+  {
+    swim_coordinate origin; coord_new(&origin);
+    double dist = coord_distance_seconds(&origin, &c), q = dist / COORD_GRAVITY_RHO, force = -1.0 * (q * q);
+    coord_apply_force(s, r, o, 1, &c, force, &origin);
+  }
+  if (!coord_valid(&c)) { s->st.coord_resets++; coord_new(&c); }
+  s->c_new[s->c_n] = c; s->c_list[s->c_n++] = (uint32_t)((size_t)r * s->nloc + (o - s->i0));
+}
+static void coord_commit(swim_sim* s) {
+  for (uint32_t j = 0; j < s->c_n; j++) s->cs[s->c_list[j]].c = s->c_new[j];
+  s->c_n = 0;
+}
+
 /* probeNode's failure epilogue: awareness delta then suspectNode(suspect{inc, node, self}) */
 static void probe_conclude(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   uint32_t x = nd->pr_target;
@@ -832,7 +989,7 @@ static void probe_start(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   int ack = fwd && !lost(s, r, o, 17);
   if (KST(key) == SWIM_STATE_ALIVE) piggy_order(s, r, o, fwd ? x : SWIM_NONE, SWIM_CTL_PING, o);   /* else: ping+suspect compound, sent raw */
   if (fwd) piggy_order(s, r, x, ack ? o : SWIM_NONE, SWIM_CTL_ACK, o);
-  if (ack) { awareness_delta(s, nd, -1); s->st.probe_acks++; return; }
+  if (ack) { awareness_delta(s, nd, -1); s->st.probe_acks++; if (s->cs) coord_update(s, r, o, x); return; }
   nd->pr_target = x; nd->pr_inc = KINC(key); nd->pr_t0 = s->tick; nd->pr_stage = 1; nd->pr_nack_miss = 1;
   nd->pr_deadline = s->tick + s->d.probe_period * ((uint32_t)nd->awareness + 1);   /* awareness.ScaleTimeout */
 }
@@ -1274,6 +1431,11 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
   s->inbox_slab = (swim_edge*)malloc(NL * cfg->inbox_cap * sizeof(swim_edge));
   if (!s->q_slab || !s->inbox_slab || ((cfg->flags & SWIM_F_SERF_EVENTS) && !s->evq_slab)) { swim_destroy(s); return SWIM_ENOMEM; }
+  if (cfg->flags & SWIM_F_COORDINATES) {
+    s->cs = (coord_state*)calloc(NL, sizeof(coord_state)); s->c_new = (swim_coordinate*)malloc(NL * sizeof(swim_coordinate)); s->c_list = (uint32_t*)malloc(NL * sizeof(uint32_t));
+    if (!s->cs || !s->c_new || !s->c_list) { swim_destroy(s); return SWIM_ENOMEM; }
+    for (size_t g = 0; g < NL; g++) coord_new(&s->cs[g].c);
+  }
   for (size_t g = 0; g < NL; g++) {
     node_t* nd = &s->nodes[g];
     nd->q = s->q_slab + g * cfg->queue_cap;
@@ -1294,7 +1456,7 @@ int swim_destroy(swim_sim* s) {
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
   free(s->attached); free(s->alone); free(s->captured.v); free(s->cap_src); free(s->xpeers);
-  free(s->q_slab); free(s->evq_slab);
+  free(s->q_slab); free(s->evq_slab); free(s->cs); free(s->c_new); free(s->c_list);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->carry[0].v); free(s->carry[1].v); free(s->events); free(s);
   return SWIM_OK;
@@ -1359,6 +1521,7 @@ int swim_tick_end(swim_sim* s) {
   for (uint32_t j = 0; j < s->n_join_pending; j++)          /* joined: from the next tick on it probes and gossips like everybody */
     if (s->join_list[2 * j + 1] != SWIM_NONE) { s->alone[s->join_list[2 * j]] = 0; dirty_all(s, s->join_list[2 * j] / s->N); }
   s->n_join_pending = 0;
+  if (s->cs) coord_commit(s);
   phase_bookkeep(s);
   s->st.ticks++; if ((s->tick + 1) % s->d.gossip_period == 0) s->st.gossip_rounds++;
   s->tick++; s->in_tick = 0;
@@ -1477,6 +1640,7 @@ int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uin
     free(nd->vt.e); memset(&nd->vt, 0, sizeof nd->vt); nd->vdl = SWIM_NONE;
     nd->nk = KINC(s->base_key[g]) == 0 ? 1u : 0u;          /* it knows itself, whatever the base row says */
     nd->qlen = 0; nd->evqlen = 0; nd->in_cnt = 0; nd->awareness = 0; nd->leaving = 0;
+    if (s->cs) { coord_state* st = &s->cs[nd - s->nodes]; memset(st, 0, sizeof *st); coord_new(&st->c); }   /* a fresh process: a fresh coordinate client */
     nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->pr_nack_miss = 0;
     if (KINC(s->base_key[g]) != 0 || nd->self_inc > 1 || nd->qseq) nd->self_inc++;   /* a restart: past the incarnation others may remember */
     broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 0);   /* memberlist setAlive */
@@ -1637,6 +1801,11 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
           for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX; j++) d += h3(11 + j, id, v->conf[j]);
         }
       }
+    }
+    if (s->cs) for (uint32_t k = 0; k < s->nloc; k++) {      /* coordinates: the raw bits */
+      const coord_state* st = &s->cs[(size_t)r * s->nloc + k]; uint64_t g = (uint64_t)r * s->N + s->i0 + k, bits;
+      const double* f = (const double*)&st->c;
+      for (uint32_t j = 0; j < SWIM_COORD_DIMS + 3; j++) { memcpy(&bits, &f[j], 8); d += h3(20 + j, g, bits); }
     }
     for (uint32_t k = 0; k < s->nloc; k++) {               /* the base row (replicated: every shard digests its own id range) */
       uint64_t g = (uint64_t)r * s->N + s->i0 + k;

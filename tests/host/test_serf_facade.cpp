@@ -6,6 +6,7 @@
 //   TestClientServer_UserEvent    agent/consul/client_test.go:756-830   (event "foo" arrives once)
 // with the reference's shrunk test timers (server_test.go:221-237).
 // Links against any library exporting include/swimsim.h; the library under test is named on argv.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -160,10 +161,43 @@ static void testConfigPresets() {
   std::printf("ok ConfigPresets\n");
 }
 
+// internal/gossip/librtt/rtt_test.go:16-75 (TestRTT_ComputeDistance) through the facade, then coordinates of a running pool: the
+// distances a member computes from GetCoordinate / GetCachedCoordinate approach the latency the probes measured
+// (agent/router/router.go:537-660 sorts datacenters and servers by exactly this number)
+static void testCoordinates() {
+  using namespace std::chrono_literals;
+  auto g = [](std::chrono::nanoseconds d) { return librtt::GenerateCoordinate(d); };
+  auto c0 = g(0ms), c8 = g(8ms), c10 = g(10ms);
+  EXPECT(librtt::ComputeDistance(&c0, &c10) == 0.010);
+  EXPECT(librtt::ComputeDistance(&c10, &c10) == 0.0);
+  EXPECT(librtt::ComputeDistance(&c8, &c10) == 0.002);
+  EXPECT(librtt::ComputeDistance(&c10, &c8) == 0.002);
+  EXPECT(std::isinf(librtt::ComputeDistance(nullptr, &c8)) && std::isinf(librtt::ComputeDistance(&c8, nullptr)) && std::isinf(librtt::ComputeDistance(nullptr, nullptr)));
+
+  serf::Cluster::Options o; o.Nodes = 32; o.Coordinates = true; o.Seed = 21;
+  auto pool = std::make_shared<serf::Cluster>(memberlist::DefaultLANConfig(), o);
+  serf::Config conf = serf::ConsulDefaultConfig(); conf.NodeName = "node-4";
+  auto s4 = serf::Serf::Create(conf, pool, 4);
+  pool->Advance(Duration(600000));                     // ten minutes: 600 probes per member
+  auto mine = s4->GetCoordinate();
+  int close = 0, seen = 0;
+  for (uint32_t x : { 0u, 7u, 13u, 21u, 30u }) {
+    coordinate::Coordinate theirs;
+    EXPECT(s4->GetCachedCoordinate(serf::Cluster::NodeName(x), &theirs));
+    uint32_t us = 0; EXPECT(swim_rtt_truth(pool->handle(), 0, 4, x, &us) == SWIM_OK);
+    const double est = librtt::ComputeDistance(&mine, &theirs), truth = us * 1e-6;
+    seen++; if (std::fabs(est - truth) < 0.1 * truth) close++;
+  }
+  EXPECT(seen == 5 && close >= 4);
+  coordinate::Coordinate none;
+  EXPECT(!s4->GetCachedCoordinate("no-such-node", &none));
+  std::printf("ok Coordinates\n");
+}
+
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
-    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent();
+    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;
