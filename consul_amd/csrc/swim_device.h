@@ -137,6 +137,10 @@ struct SwDev {
                          //       earliest suspicion deadline among them (a lower bound; NONE = none),
                          //       earliest time a view becomes evictable (Dead/Left for longer than GossipToTheDeadTime;
                          //       a lower bound; NONE = never) — what a full table checks before it scans itself}
+  // k_resolve's launch order (longest job first): in a busy cluster the nodes of a probe-due chunk ALL receive in the tick they
+  // probe (each gets the piggy-back order for its own ping), so the tiles holding such chunks carry several times the work of
+  // the others; rs_order[t % P][j] = the tile workgroup j takes in such a tick, those tiles first (host-built at create)
+  uint32_t* rs_order; uint32_t rs_T;
   uint32_t* dl_blk;      // [NL/256] lower bound of the block's vdl over the lanes the simulator acts for
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
   uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)

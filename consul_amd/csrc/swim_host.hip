@@ -238,6 +238,73 @@ static void drop_graphs(swim_sim* s) {
 }
 
 extern "C" int swim_destroy(swim_sim* s) {
+#ifdef SWIMSIM_WAVECLK
+  if (s) for (int kk = 0; kk < 2; kk++) {         // diagnostics: the workgroups of the last k_begin / k_deliver launch
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    std::vector<unsigned long long> c((size_t)BCLK_ROWS * 4);
+    if (hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_bclk), c.size() * 8, (size_t)kk * BCLK_ROWS * 4 * 8) != hipSuccess) continue;
+    unsigned long long last = 0;
+    for (size_t w = 0; w < BCLK_ROWS; w++) last = std::max(last, c[w * 4]);
+    std::vector<const unsigned long long*> rows; unsigned long long k0 = ~0ull, k1 = 0;
+    for (size_t w = 0; w < BCLK_ROWS; w++) { const unsigned long long* r = &c[w * 4]; if (r[0] && last - r[0] < 20000) { rows.push_back(r); k0 = std::min(k0, r[0]); k1 = std::max(k1, r[1]); } }
+    if (rows.empty()) continue;
+    const double us = 0.01;
+    fprintf(stderr, "[block clk] %s, last launch: %zu workgroups, span %.1f us\n", kk ? "k_deliver" : "k_begin", rows.size(), (k1 - k0) * us);
+    if (!kk) {
+      static const char* const names[8] = { "expire", "pending", "probe", "gossip", "ppreply", "carry", "pushpull", "join" };
+      for (unsigned role = 0; role < 8; role++) {
+        std::vector<double> d; double first = 1e30, lastend = 0;
+        for (auto r : rows) if (r[2] == role) { d.push_back((r[1] - r[0]) * us); first = std::min(first, (r[0] - k0) * us); lastend = std::max(lastend, (r[1] - k0) * us); }
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, "[block clk]   %-8s %6zu blocks, first start %.1f, last end %.1f; duration us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", names[role], d.size(), first, lastend, d[d.size() / 10], d[d.size() / 2], d[d.size() * 9 / 10], d[d.size() * 99 / 100], d.back());
+      }
+    } else {
+      std::vector<std::pair<double, unsigned long long>> d;
+      for (auto r : rows) d.push_back({ (r[1] - r[0]) * us, r[2] });
+      std::sort(d.begin(), d.end());
+      fprintf(stderr, "[block clk]   duration us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f (records of the slowest: %llu)\n", d[d.size() / 10].first, d[d.size() / 2].first, d[d.size() * 9 / 10].first, d[d.size() * 99 / 100].first, d.back().first, d.back().second & 0x3FFFFFFFull);
+      double rec[4] = { 0, 0, 0, 0 }, dur[4] = { 0, 0, 0, 0 };      // by record count: 0, 1..256, 257..1024, more
+      for (auto r : rows) { const unsigned long long n = r[2] & 0x3FFFFFFFull; const int b = n == 0 ? 0 : n <= 256 ? 1 : n <= 1024 ? 2 : 3; rec[b] += 1; dur[b] += (r[1] - r[0]) * us; }
+      static const char* const bn[4] = { "no records", "1..256", "257..1024", "more" };
+      for (int b = 0; b < 4; b++) if (rec[b]) fprintf(stderr, "[block clk]   blocks with %-10s %6.0f, mean duration %.1f us\n", bn[b], rec[b], dur[b] / rec[b]);
+    }
+    const int NBK = 24; const double bw = (k1 - k0) * us / NBK;
+    std::vector<int> alive(NBK, 0);
+    for (auto r : rows) { int a = std::min<int>(NBK - 1, (int)((r[0] - k0) * us / bw)), b = std::min<int>(NBK - 1, (int)((r[1] - k0) * us / bw)); for (int i = a; i <= b; i++) alive[i]++; }
+    fprintf(stderr, "[block clk]   workgroups alive per %.1f us bucket:", bw);
+    for (int i = 0; i < NBK; i++) fprintf(stderr, " %d", alive[i]);
+    fprintf(stderr, "\n");
+  }
+  if (s) {                                       // diagnostics: the profile of k_resolve's last launch, wave by wave (s_memtime = 100 MHz)
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    std::vector<unsigned long long> c((size_t)WCLK_ROWS * 6);
+    if (hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_wclk), c.size() * 8) == hipSuccess) {
+      unsigned long long last = 0;
+      for (size_t w = 0; w < WCLK_ROWS; w++) last = std::max(last, c[w * 6]);
+      std::vector<const unsigned long long*> rows;
+      unsigned long long k0 = ~0ull, k1 = 0;
+      for (size_t w = 0; w < WCLK_ROWS; w++) { const unsigned long long* r = &c[w * 6]; if (r[0] && last - r[0] < 20000) { rows.push_back(r); k0 = std::min(k0, r[0]); k1 = std::max(k1, r[3]); } }
+      if (!rows.empty()) {
+        const double us = 0.01;
+        fprintf(stderr, "[wave clk] k_resolve, last launch: %zu waves that found work, span %.1f us\n", rows.size(), (k1 - k0) * us);
+        double ph[3] = { 0, 0, 0 }, life = 0; double by_pass[4][2] = { { 0 } };
+        for (auto r : rows) { ph[0] += (r[1] - r[0]) * us; ph[1] += (r[2] - r[1]) * us; ph[2] += (r[3] - r[2]) * us; life += (r[3] - r[0]) * us;
+          const int p = std::min<int>(3, (int)((r[4] + 255) / 256)); by_pass[p][0] += 1; by_pass[p][1] += (r[3] - r[0]) * us; }
+        fprintf(stderr, "[wave clk]   mean us: compaction %.1f  list walk %.1f  flush %.1f  lifetime %.1f\n", ph[0] / rows.size(), ph[1] / rows.size(), ph[2] / rows.size(), life / rows.size());
+        for (int p = 0; p < 4; p++) if (by_pass[p][0]) fprintf(stderr, "[wave clk]   tiles with %d%s list pass(es): %.0f waves, mean lifetime %.1f us\n", p, p == 3 ? "+" : "", by_pass[p][0], by_pass[p][1] / by_pass[p][0]);
+        const int NBK = 40; const double bw = (k1 - k0) * us / NBK;
+        std::vector<int> alive(NBK, 0), started(NBK, 0), ended(NBK, 0);
+        for (auto r : rows) { int a = std::min<int>(NBK - 1, (int)((r[0] - k0) * us / bw)), b = std::min<int>(NBK - 1, (int)((r[3] - k0) * us / bw)); started[a]++; ended[b]++; for (int i = a; i <= b; i++) alive[i]++; }
+        fprintf(stderr, "[wave clk]   per %.1f us bucket: waves alive / started / ended\n", bw);
+        for (int i = 0; i < NBK; i++) fprintf(stderr, "[wave clk]   %6.1f  %5d %5d %5d\n", i * bw, alive[i], started[i], ended[i]);
+        std::vector<double> lt; for (auto r : rows) lt.push_back((r[3] - r[0]) * us);
+        std::sort(lt.begin(), lt.end());
+        fprintf(stderr, "[wave clk]   lifetime us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", lt.front(), lt[lt.size() / 10], lt[lt.size() / 2], lt[lt.size() * 9 / 10], lt[lt.size() * 99 / 100], lt.back());
+      }
+    }
+  }
+#endif
 #ifdef SWIMSIM_DIAG
   if (s && getenv("SWIMSIM_RESOLVECLK")) {      // diagnostics: where the waves of k_resolve's LAST launches spent their lives
     std::vector<uint32_t> c((size_t)RCLK_ROWS * 8);
@@ -345,6 +412,25 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
   DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+#ifndef SW_RESOLVE_PLAIN_ORDER
+  if (D.CH >= 64 && NB > 4 * SW_RTILE) {        // the longest-job-first order of k_resolve's tiles, per probe phase (swim_device.h)
+    const uint32_t T = (uint32_t)cdiv(NB, SW_RTILE);
+    std::vector<uint32_t> ord((size_t)D.P * T), due(T);
+    for (uint32_t ph = 0; ph < D.P; ph++) {
+      for (uint32_t tl = 0; tl < T; tl++) {
+        uint32_t n = 0;
+        for (size_t l = (size_t)tl * SW_RTILE * SW_BLOCK; l < std::min<size_t>(NL, (size_t)(tl + 1) * SW_RTILE * SW_BLOCK); l += std::min<uint32_t>(D.CH, SW_BLOCK))
+          n += ((D.i0 + (uint32_t)(l % D.nloc)) / D.CH / D.G) % D.P == ph;
+        due[tl] = n;
+      }
+      uint32_t* o = &ord[(size_t)ph * T];
+      for (uint32_t tl = 0; tl < T; tl++) o[tl] = tl;
+      std::stable_sort(o, o + T, [&](uint32_t a, uint32_t b) { return due[a] > due[b]; });
+    }
+    DALLOC(s, D.rs_order, ord.size()); D.rs_T = T;
+    HIPCK(s, hipMemcpy(D.rs_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice));
+  }
+#endif
   {   // dynamic membership: the scaling laws as tables / constants with Go's float64 semantics
     const uint32_t ni = cfg->n_initial ? cfg->n_initial : D.N;
     D.dyn = ni < D.N ? 1u : 0u;

@@ -1244,6 +1244,12 @@ __global__ void k_coord_init(const SwDev* __restrict__ Dp) {
 #ifndef SW_BEGIN_WAVES
 #define SW_BEGIN_WAVES 5      /* 96 VGPRs, no scratch: one more wave per SIMD than the allocator would settle for */
 #endif
+#ifdef SWIMSIM_WAVECLK
+// diagnostics (-DSWIMSIM_WAVECLK builds only): entry and exit time of every workgroup of k_begin (by role) and k_deliver
+#define BCLK_ROWS 32768
+__device__ unsigned long long g_bclk[2][BCLK_ROWS][4];
+#define BCLK_OUT(k, t_in_, tag) do { if (threadIdx.x == 0) { unsigned long long* row_ = g_bclk[k][blockIdx.x % BCLK_ROWS]; row_[0] = (t_in_); row_[1] = wall_clock64(); row_[2] = (tag); row_[3] = blockIdx.x; } } while (0)
+#endif
 template <int KMAX, bool SERF, bool MULTI>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_BEGIN_WAVES, 8))) k_begin(const SwDev* __restrict__ Dp, BeginPlan pl) {
   SW_DEV_BIND
@@ -1251,7 +1257,10 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_cnt[SW_MAX_SHARDS], s_base[SW_MAX_SHARDS], lds_exc[2 * SW_EXC_MAX];
   uint32_t b = blockIdx.x;
-#ifdef SWIMSIM_DIAG
+#ifdef SWIMSIM_WAVECLK
+  const unsigned long long t_in = wall_clock64();
+#define ROLE_DONE(id) BCLK_OUT(0, t_in, id)
+#elif defined(SWIMSIM_DIAG)
   // diagnostics (SWIMSIM_ROLECLK): when did the first block of a role start, when did its last block end
   const unsigned long long t_in = D.role_clk ? wall_clock64() : 0;
 #define ROLE_DONE(id) do { if (D.role_clk && threadIdx.x == 0) { uint32_t tk = *D.tick; if (tk < D.role_clk_ticks) { \
@@ -1361,6 +1370,12 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint32_t b = blockIdx.x;
+#ifdef SWIMSIM_WAVECLK
+  const unsigned long long t_in = wall_clock64();
+#define DCLK(tag) BCLK_OUT(1, t_in, tag)
+#else
+#define DCLK(tag) do { } while (0)
+#endif
   if (b < D.n_seg) {
     uint32_t n = D.seg_cnt[b], last = D.seg_last[b];
     // a segment holds records of ONE replica: its exception list (the few nodes whose word is not 0) in LDS saves the
@@ -1391,7 +1406,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
     }
     if (n) deliver_span(D, D.seg + (size_t)b * D.seg_cap, n, threadIdx.x, SW_BLOCK, &X);
     if (threadIdx.x == 0 && n) D.seg_cnt[b] = 0;
-    if (!piggy) return;
+    if (!piggy) { DCLK(n); return; }
     uint32_t c_edges = 0, c_filt = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1409,12 +1424,15 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
         if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
       }
     }
+    DCLK(n + cn[0] + cn[1] + cn[2] + cn[3]);
     return;
   }
   b -= D.n_seg;
   uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
   if (n > D.out_cap_tab[D.rank]) n = D.out_cap_tab[D.rank];
   deliver_span(D, D.out_tab[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
+  DCLK(1u << 30);
+#undef DCLK
 }
 // ---- swim_xchg_*: device-driven exchange through peer-mapped mailboxes (swim_device.h) ----------------------------
 __device__ __forceinline__ uint32_t* mb_hdr(DevRef D, uint8_t* base, uint32_t parity, uint32_t src) {
@@ -1951,6 +1969,17 @@ __device__ uint32_t g_rclk[RCLK_ROWS][8];
 #else
 #define RCLK_MARK(p) do { } while (0)
 #endif
+#ifdef SWIMSIM_WAVECLK
+// diagnostics, second kind (-DSWIMSIM_WAVECLK builds only): four s_memtime stamps per wave of k_resolve (entry, list compacted, list
+// walked, tallies flushed), taken OUTSIDE the loops — a handful of scalar instructions, so that the probe does not change
+// what it measures the way the per-phase accumulators of SWIMSIM_RESOLVECLK do.  Row per wave; the host keeps the rows of the
+// last launch (by entry time) and prints the launch's profile at swim_destroy.
+#define WCLK_ROWS 32768
+__device__ unsigned long long g_wclk[WCLK_ROWS][6];
+#define WCLK(i) wclk[i] = wall_clock64()      /* s_memrealtime: 100 MHz whatever the shader clock does */
+#else
+#define WCLK(i) do { } while (0)
+#endif
 #ifndef SW_RTILE
 #define SW_RTILE 4
 #endif
@@ -1964,7 +1993,10 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
   __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
   __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
-  const uint32_t nb0 = blockIdx.x * SW_RTILE;
+  const uint32_t nb0 = (D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + blockIdx.x] : blockIdx.x) * SW_RTILE;   // heavy tiles first
+#ifdef SWIMSIM_WAVECLK
+  unsigned long long wclk[4]; WCLK(0);
+#endif
 #ifdef SWIMSIM_DIAG
   unsigned long long rclk_t = __builtin_amdgcn_s_memtime(); const unsigned long long rclk_t0 = rclk_t; uint32_t rclk_it = 0, rclk_acc[6] = { 0, 0, 0, 0, 0, 0 };
 #endif
@@ -2003,6 +2035,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
   const uint32_t t_now = *D.tick;
   RCLK_MARK(0);                                    // compaction
+  WCLK(1);
   for (uint32_t a0 = 0; a0 < n_act; a0 += SW_BLOCK) {
     if (a0 + threadIdx.x >= n_act) continue;
     const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;
@@ -2087,6 +2120,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SWIMSIM_DIAG
   { uint32_t m = rclk_it; for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v > m ? v : m; } rclk_it = m; }
 #endif
+  WCLK(2);
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
@@ -2098,6 +2132,13 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
     if (s_dl[sb] != NONE && s_dl[sb] < D.dl_blk[nb0 + sb]) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);
   }
+#ifdef SWIMSIM_WAVECLK
+  WCLK(3);
+  if (sw_lane() == 0) {
+    unsigned long long* row = g_wclk[(blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64) % WCLK_ROWS];
+    row[0] = wclk[0]; row[1] = wclk[1]; row[2] = wclk[2]; row[3] = wclk[3]; row[4] = n_act; row[5] = blockIdx.x;
+  }
+#endif
 #ifdef SWIMSIM_DIAG
   RCLK_MARK(5);                                    // tallies, flush
   if (sw_lane() == 0) {
