@@ -9,6 +9,6 @@ fi
 for f in _ab/lib_*.so; do
   case $f in *base*) continue;; esac
   echo "== parity with $f"
-  SWIMSIM_LIB=$PWD/$f timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_coordinates_gpu.py -m gpu -x -q 2>&1 | tail -4
+  SWIMSIM_LIB=$PWD/$f timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_coordinates_gpu.py tests/test_properties_gpu.py -m gpu -x -q 2>&1 | tail -4
 done
 bash tools/ab_libs.sh
