@@ -24,6 +24,7 @@ GPU, 5 % cut off at once, bounded views) and `convergence` (config #3).
 from __future__ import annotations
 
 import argparse
+import bisect
 import ctypes as C
 import json
 import os
@@ -51,8 +52,12 @@ class MultiSim:
     tick kernels overlap on the GPU — the tail of one handle's launch runs next to the head of another's.  Replica r of a
     handle seeded s is replica 0 of a handle seeded s + r, so every cluster is the one it would be in a single handle."""
 
-    def __init__(self, sims, per):
-        self.sims, self.per, self.derived = sims, per, sims[0].derived
+    def __init__(self, sims, first):
+        self.sims, self.first, self.derived = sims, first, sims[0].derived       # first[g] = the cluster handle g starts with
+
+    def _where(self, r):
+        g = bisect.bisect_right(self.first, r) - 1
+        return self.sims[g], r - self.first[g]
 
     def step(self, n):
         for s in self.sims:                                # asynchronous: every stream has its launches queued before any is awaited
@@ -63,10 +68,12 @@ class MultiSim:
             s.sync()
 
     def kill(self, r, ids):
-        self.sims[r // self.per].kill(r % self.per, ids)
+        sim, k = self._where(r)
+        sim.kill(k, ids)
 
     def census(self, r, x):
-        return self.sims[r // self.per].census(r % self.per, x)
+        sim, k = self._where(r)
+        return sim.census(k, x)
 
     def close(self):
         for s in self.sims:
@@ -261,7 +268,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=32, help="cluster replicas per GPU (seeds seed..)")
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--handles", type=int, default=2,
+    ap.add_argument("--handles", type=int, default=3,
                     help="N = 1: spread the clusters over this many library handles, one stream each (their kernels overlap); "
                          "1 = one handle, one launch per kernel and tick for all clusters")
     ap.add_argument("--subject-cap", type=int, default=4)
@@ -342,13 +349,14 @@ def main():
             merged.update(d)
         return [merged[r] for r in range(world)]
 
-    handles = args.handles if (not sharded and args.handles > 1 and reps % args.handles == 0) else 1
+    handles = min(args.handles, reps) if (not sharded and args.handles > 1) else 1
 
     def fresh(multi=True):
         if multi and handles > 1:
-            per = reps // handles
-            return MultiSim([Sim(hip, preset(hip, abi.PRESET_LAN, **dict(cfg_kw, n_replicas=per, seed=args.seed + g * per)))
-                             for g in range(handles)], per)
+            sizes = [reps // handles + (1 if g < reps % handles else 0) for g in range(handles)]      # 32 on 3: 11 + 11 + 10
+            first = [sum(sizes[:g]) for g in range(handles)]
+            return MultiSim([Sim(hip, preset(hip, abi.PRESET_LAN, **dict(cfg_kw, n_replicas=sizes[g], seed=args.seed + first[g])))
+                             for g in range(handles)], first)
         sim = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
         if not sharded:
             return sim

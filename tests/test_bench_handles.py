@@ -11,10 +11,11 @@ from consul_amd.sim import Sim, preset       # noqa: E402
 
 
 def test_clusters_spread_over_handles_are_the_clusters_of_one_handle(oracle):
-    n, reps, seed = 512, 4, 11
+    n, reps, seed = 512, 5, 11                        # 5 clusters on 3 handles: 2 + 2 + 1, like 32 on 3 = 11 + 11 + 10
     kw = dict(n_nodes=n, subject_cap=2, view_cap=4, queue_cap=4, inbox_cap=24)
     one = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_replicas=reps, seed=seed, **kw))
-    two = MultiSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, n_replicas=reps // 2, seed=seed + g * (reps // 2), **kw)) for g in range(2)], reps // 2)
+    sizes, first = [2, 2, 1], [0, 2, 4]
+    two = MultiSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, n_replicas=sizes[g], seed=seed + first[g], **kw)) for g in range(3)], first)
     victims = victims_for(seed, reps, n)
     for s in (one, two):
         s.step(20)

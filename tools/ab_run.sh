@@ -12,3 +12,7 @@ for f in _ab/lib_*.so; do
   SWIMSIM_LIB=$PWD/$f timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_coordinates_gpu.py tests/test_properties_gpu.py -m gpu -x -q 2>&1 | tail -4
 done
 bash tools/ab_libs.sh
+# ...and the default window (where k_begin is the dominant kernel), untraced
+for f in _ab/lib_*.so; do
+  SWIMSIM_LIB=$PWD/$f python bench.py --main-only 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f default window: value %.3e  ms/step %.4f' % (d['value'], d['ms_per_step']))"
+done
