@@ -8,12 +8,12 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NONE = 0xFFFFFFFF
 
-OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE = 0, -22, -12, -19, -34, -75, -71
+OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE, EIO = 0, -22, -12, -19, -34, -75, -71, -5
 ERRNAMES = {EINVAL: "SWIM_EINVAL", ENOMEM: "SWIM_ENOMEM", ENODEV: "SWIM_ENODEV",
-            ERANGE: "SWIM_ERANGE", EOVERFLOW: "SWIM_EOVERFLOW", ESTATE: "SWIM_ESTATE"}
+            ERANGE: "SWIM_ERANGE", EOVERFLOW: "SWIM_EOVERFLOW", ESTATE: "SWIM_ESTATE", EIO: "SWIM_EIO"}
 
 STATE_ALIVE, STATE_SUSPECT, STATE_DEAD, STATE_LEFT = 0, 1, 2, 3
 MSG_ALIVE, MSG_SUSPECT, MSG_DEAD, MSG_USER = 0, 1, 2, 3
@@ -162,6 +162,8 @@ PROTOTYPES = {
     "swim_rtt_truth": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
     "swim_debug_edges": (C.c_int, [SimP, P(Edge), C.c_size_t, P(C.c_size_t)]),
     "swim_state_digest": (C.c_int, [SimP, P(u64)]),
+    "swim_checkpoint_save": (C.c_int, [SimP, C.c_char_p]),
+    "swim_checkpoint_load": (C.c_int, [SimP, C.c_char_p]),
     "swim_profile": (C.c_int, [SimP, C.c_int]),
     "swim_profile_read": (C.c_int, [SimP, P(KernelTime), C.c_size_t, P(C.c_size_t)]),
     "swim_transport_write_to": (C.c_int, [SimP, u32, u32, u32, P(Edge), C.c_size_t]),

@@ -36,6 +36,8 @@ struct swim_sim {
   BeginKernel begin_kernel = nullptr;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;     // (swim_checkpoint_*: every device array is state unless listed in `structural`)
+  std::vector<void*> structural;       // arrays that hold THIS handle's device pointers or nothing worth keeping: never saved, never overwritten
   uint32_t tick = 0;
   bool in_tick = false;
   bool pristine = true;                // nothing has ever happened to this population (no stimulus of any kind): k_quiet may stand in for whole ticks
@@ -220,7 +222,7 @@ static int dalloc(swim_sim* s, T** p, size_t count) {
   void* v = nullptr;
   size_t bytes = std::max<size_t>(count * sizeof(T), 64);
   HIPCK(s, hipMalloc(&v, bytes));
-  s->allocs.push_back(v);
+  s->allocs.push_back(v); s->alloc_bytes.push_back(bytes);
   *p = (T*)v;
   return SWIM_OK;
 }
@@ -581,6 +583,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   }
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
+  s->structural = { (void*)s->d_D, (void*)D.out_tab, (void*)D.mb_tab, (void*)s->d_scratch, (void*)s->mailbox, (void*)s->in_buf };
   HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
   const uint32_t n_initial = cfg->n_initial ? cfg->n_initial : D.N;
   hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
@@ -1281,6 +1284,89 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
   *n_out = total;
   return SWIM_OK;
 }
+// ---- checkpoint / resume (swimsim.h) -----------------------------------------------------------------------------
+// Every device array was allocated through dalloc() in an order that depends on the configuration alone, so the state of a
+// population is the contents of those arrays in that order plus a handful of host words.  The descriptor, the pointer
+// tables and the scratch/staging buffers are this handle's own and are left alone.
+struct CkHeader {
+  char magic[8], backend[16];
+  uint32_t abi, tick, loss_q32, peer_act, n_arrays, n_events; uint8_t pristine, pad[3];
+  uint64_t ticks_run, rounds_run;
+  swim_config cfg;
+};
+static bool ck_is_state(const swim_sim* s, size_t i) {
+  return s->allocs[i] && std::find(s->structural.begin(), s->structural.end(), s->allocs[i]) == s->structural.end();
+}
+static int ck_legal(swim_sim* s) {
+  if (s->in_tick || s->in_count) return SWIM_ESTATE;
+  if (!s->attached.empty() || !s->captured.empty() || s->xchg_connected) { snprintf(s->err, sizeof s->err, "checkpoints do not cover attached transport-bridge nodes or a connected exchange"); return SWIM_ESTATE; }
+  return SWIM_OK;
+}
+extern "C" int swim_checkpoint_save(swim_sim* s, const char* path) {
+  if (!s || !path) return SWIM_EINVAL;
+  if (int rc = ck_legal(s)) return rc;
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  FILE* f = fopen(path, "wb");
+  if (!f) { snprintf(s->err, sizeof s->err, "cannot write %s", path); return SWIM_EIO; }
+  CkHeader h; memset(&h, 0, sizeof h);
+  memcpy(h.magic, "SWIMCKPT", 8); strncpy(h.backend, swim_backend(), sizeof h.backend - 1);
+  h.abi = SWIM_ABI_VERSION; h.tick = s->tick; h.loss_q32 = s->D.loss_q32; h.peer_act = s->peer_act_host; h.pristine = s->pristine;
+  h.ticks_run = s->ticks_run; h.rounds_run = s->rounds_run; h.cfg = s->cfg; h.n_events = (uint32_t)s->pending_events.size();
+  for (size_t i = 0; i < s->allocs.size(); i++) h.n_arrays += ck_is_state(s, i);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && (s->pending_events.empty() || fwrite(s->pending_events.data(), sizeof(swim_event), s->pending_events.size(), f) == s->pending_events.size());
+  const size_t CH = (size_t)32 << 20;
+  std::vector<char> buf(CH);
+  for (size_t i = 0; ok && i < s->allocs.size(); i++) {
+    if (!ck_is_state(s, i)) continue;
+    const uint64_t bytes = s->alloc_bytes[i];
+    ok = fwrite(&bytes, 8, 1, f) == 1;
+    for (size_t off = 0; ok && off < bytes; off += CH) {
+      const size_t c = std::min<size_t>(CH, bytes - off);
+      if (hipMemcpy(buf.data(), (const char*)s->allocs[i] + off, c, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); snprintf(s->err, sizeof s->err, "device read failed"); return SWIM_EIO; }
+      ok = fwrite(buf.data(), 1, c, f) == c;
+    }
+  }
+  if (fclose(f) != 0) ok = false;
+  if (!ok) snprintf(s->err, sizeof s->err, "short write to %s", path);
+  return ok ? SWIM_OK : SWIM_EIO;
+}
+extern "C" int swim_checkpoint_load(swim_sim* s, const char* path) {
+  if (!s || !path) return SWIM_EINVAL;
+  if (int rc = ck_legal(s)) return rc;
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  FILE* f = fopen(path, "rb");
+  if (!f) { snprintf(s->err, sizeof s->err, "cannot read %s", path); return SWIM_EIO; }
+  CkHeader h;
+  uint32_t n_arrays = 0;
+  for (size_t i = 0; i < s->allocs.size(); i++) n_arrays += ck_is_state(s, i);
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SWIMCKPT", 8) || strncmp(h.backend, swim_backend(), sizeof h.backend) || h.abi != SWIM_ABI_VERSION ||
+      memcmp(&h.cfg, &s->cfg, sizeof h.cfg) || h.n_arrays != n_arrays) {
+    fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another library, ABI or configuration"); return SWIM_EINVAL;
+  }
+  std::vector<swim_event> ev(h.n_events);
+  bool ok = h.n_events == 0 || fread(ev.data(), sizeof(swim_event), h.n_events, f) == h.n_events;
+  const size_t CH = (size_t)32 << 20;
+  std::vector<char> buf(CH);
+  for (size_t i = 0; ok && i < s->allocs.size(); i++) {
+    if (!ck_is_state(s, i)) continue;
+    uint64_t bytes = 0;
+    ok = fread(&bytes, 8, 1, f) == 1;
+    if (ok && bytes != s->alloc_bytes[i]) { fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another configuration (array %zu)", i); return SWIM_EINVAL; }   // (nothing was overwritten yet only if i is the first)
+    for (size_t off = 0; ok && off < bytes; off += CH) {
+      const size_t c = std::min<size_t>(CH, bytes - off);
+      ok = fread(buf.data(), 1, c, f) == c;
+      if (ok && hipMemcpy((char*)s->allocs[i] + off, buf.data(), c, hipMemcpyHostToDevice) != hipSuccess) { fclose(f); snprintf(s->err, sizeof s->err, "device write failed"); return SWIM_EIO; }
+    }
+  }
+  fclose(f);
+  if (!ok) { snprintf(s->err, sizeof s->err, "checkpoint truncated: the handle's state is undefined"); return SWIM_EIO; }
+  s->tick = h.tick; s->pristine = h.pristine != 0; s->ticks_run = h.ticks_run; s->rounds_run = h.rounds_run; s->peer_act_host = h.peer_act;
+  s->pending_events = std::move(ev); s->out_counts_valid = false; s->in_count = 0;
+  if (s->D.loss_q32 != h.loss_q32) { s->D.loss_q32 = h.loss_q32; HIPCK(s, hipMemcpy(s->d_D, &s->D, sizeof s->D, hipMemcpyHostToDevice)); }
+  return SWIM_OK;
+}
+
 extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;

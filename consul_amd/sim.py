@@ -7,6 +7,7 @@ library and nothing else; tests construct `Sim(oracle_cdll, cfg)` to drive the c
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -316,6 +317,14 @@ class Sim:
         cnt = C.c_size_t()
         self._ck("swim_profile_read", self._l.swim_profile_read(self._h, buf, 32, C.byref(cnt)))
         return {k.name.decode(): (int(k.launches), float(k.total_ms)) for k in buf[: cnt.value]}
+
+    def save(self, path: str) -> None:
+        """swim_checkpoint_save: the whole population, between two ticks, into a file"""
+        self._ck("swim_checkpoint_save", self._l.swim_checkpoint_save(self._h, os.fsencode(path)))
+
+    def load(self, path: str) -> None:
+        """swim_checkpoint_load: back into a handle created from the same configuration"""
+        self._ck("swim_checkpoint_load", self._l.swim_checkpoint_load(self._h, os.fsencode(path)))
 
     def digest(self) -> int:
         o = abi.u64()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 4u
+#define SWIM_ABI_VERSION 5u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -37,6 +37,7 @@ extern "C" {
 #define SWIM_ERANGE    (-34)  /* id / replica / buffer capacity out of range                */
 #define SWIM_EOVERFLOW (-75)  /* a bounded structure overflowed; results are not trustworthy */
 #define SWIM_ESTATE    (-71)  /* call not legal in the current tick phase                   */
+#define SWIM_EIO       (-5)   /* a checkpoint file could not be written or read             */
 
 #define SWIM_NONE 0xFFFFFFFFu
 #define SWIM_SUBJECT_PULL 0xFFFFFFFEu  /* edge.subject of a push-pull request; edge.incarnation = requester */
@@ -418,6 +419,18 @@ int swim_debug_edges(swim_sim* sim, swim_edge* out, size_t cap, size_t* n_out);
 /* order-independent 64-bit digest over all integer node state (self state, queues, views,
  * suspicion timers, serf clocks) — "checksum of checksums" for full-size parity */
 int swim_state_digest(swim_sim* sim, uint64_t* out);
+
+/* ---- checkpoint / resume -------------------------------------------------------
+ * The whole population between two ticks — every array of the structure-of-arrays state, the clock, the counters, pending
+ * joins and events — into a file, and back into a handle created from the SAME swim_config (compared byte for byte).  A run
+ * continued from a checkpoint is the run that was never interrupted: digests, counters, censuses and events agree tick for
+ * tick.  Upstream's nearest relative is serf's snapshotter (conf.SnapshotPath, agent/consul/server_serf.go:236-239: ONE
+ * node's member list and clocks, replayed at restart so that it can rejoin); a simulator's unit is the population.
+ * The file belongs to the library that wrote it (backend string and ABI version in the header): SWIM_EINVAL for a foreign
+ * file or another configuration, SWIM_EIO when it cannot be written / is truncated (the handle's state is then undefined),
+ * SWIM_ESTATE inside a tick, on a handle with attached transport-bridge nodes or a connected swim_xchg exchange. */
+int swim_checkpoint_save(swim_sim* sim, const char* path);
+int swim_checkpoint_load(swim_sim* sim, const char* path);
 
 /* ---- per-kernel timing (bench.py's roofline leg; memberlist's own counterpart is the
  *      metrics.MeasureSince("memberlist","gossip"/"probeNode") timers) ---------------------------

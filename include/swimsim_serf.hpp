@@ -222,6 +222,11 @@ class Cluster {
     if (group.size() != cfg_.n_nodes) throw Error("Partition: one group id per node", SWIM_EINVAL);
     check(swim_inject_partition(sim_, replica, group.data()), "swim_inject_partition");
   }
+  // the whole population into a file between two Advance() calls, and back into a Cluster built with the same Options
+  // (swim_checkpoint_save / _load; serf's own snapshotter — conf.SnapshotPath, agent/consul/server_serf.go:236-239 — keeps one
+  // node's member list, the simulator keeps everybody's)
+  void Checkpoint(const std::string& path) { check(swim_checkpoint_save(sim_, path.c_str()), "swim_checkpoint_save"); }
+  void Restore(const std::string& path) { check(swim_checkpoint_load(sim_, path.c_str()), "swim_checkpoint_load"); }
   void SetPacketLoss(double p) { check(swim_set_loss(sim_, (uint32_t)std::min(4294967295.0, p * 4294967296.0)), "swim_set_loss"); }
 
   swim_sim* handle() const { return sim_; }

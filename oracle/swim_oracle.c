@@ -1858,6 +1858,112 @@ int swim_transport_poll(swim_sim* s, uint32_t r, uint32_t a, swim_edge* o, size_
   return SWIM_OK;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* checkpoint / resume: the whole population between two ticks, into a file and    */
+/* back into a handle created from the SAME configuration.  The file is private to the library */
+/* that wrote it (the backend string is part of the header); the product library writes its    */
+/* own.  Nothing of this is upstream's format: serf's snapshotter keeps ONE node's member list */
+/* (conf.SnapshotPath, agent/consul/server_serf.go:236-239); this is the simulator's state.    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { char magic[8], backend[16]; uint32_t abi, tick, loss_q32, n_join_pending, f_ntouched, xcredit; uint64_t n_events; swim_config cfg; swim_stats_t st; } ck_header;
+static int ck_wr(FILE* f, const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+static int ck_rd(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+static int ck_wr_vec(FILE* f, const edgevec* e) { return ck_wr(f, &e->n, 4) && ck_wr(f, e->v, (size_t)e->n * sizeof(swim_edge)); }
+static int ck_rd_vec(FILE* f, edgevec* e) {
+  uint32_t n; if (!ck_rd(f, &n, 4)) return 0;
+  if (n > e->cap) { swim_edge* v = (swim_edge*)realloc(e->v, (size_t)n * sizeof(swim_edge)); if (!v) return 0; e->v = v; e->cap = n; }
+  e->n = n; return ck_rd(f, e->v, (size_t)n * sizeof(swim_edge));
+}
+int swim_checkpoint_save(swim_sim* s, const char* path) {
+  if (!s || !path) return SWIM_EINVAL;
+  if (s->in_tick || s->c_n) return SWIM_ESTATE;
+  FILE* f = fopen(path, "wb"); if (!f) return SWIM_EIO;
+  const size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R, NS = (size_t)s->R * s->cfg.subject_cap;
+  ck_header h; memset(&h, 0, sizeof h);
+  memcpy(h.magic, "SWIMCKPT", 8); strncpy(h.backend, swim_backend(), sizeof h.backend - 1);
+  h.abi = SWIM_ABI_VERSION; h.tick = s->tick; h.loss_q32 = s->loss_q32; h.n_join_pending = s->n_join_pending; h.f_ntouched = s->f_ntouched; h.xcredit = s->xcredit;
+  h.n_events = s->n_events; h.cfg = s->cfg; h.st = s->st;
+  int ok = ck_wr(f, &h, sizeof h);
+  ok = ok && ck_wr(f, s->gt_alive, NT) && ck_wr(f, s->part, NT) && ck_wr(f, s->attached, NT) && ck_wr(f, s->alone, NT);
+  ok = ok && ck_wr(f, s->node_slot, NT * 4) && ck_wr(f, s->base_key, NT * 4) && ck_wr(f, s->subj_cnt, NT * 4);
+  ok = ok && ck_wr(f, s->f_cnt, NT * 4) && ck_wr(f, s->f_kmin, NT * 4) && ck_wr(f, s->f_kmax, NT * 4) && ck_wr(f, s->f_bad, NT);
+  ok = ok && ck_wr(f, s->f_touched, (size_t)s->f_ntouched * 4) && ck_wr(f, s->join_list, (size_t)s->n_join_pending * 8);
+  ok = ok && ck_wr(f, s->base_known, (size_t)s->R * 4) && ck_wr(f, s->n_slots, (size_t)s->R * 4);
+  ok = ok && ck_wr(f, s->nodes, NL * sizeof(node_t)) && ck_wr(f, s->q_slab, NL * s->cfg.queue_cap * sizeof(qent));
+  if (s->evq_slab) ok = ok && ck_wr(f, s->evq_slab, NL * s->cfg.event_queue_cap * sizeof(qent));
+  for (size_t g = 0; ok && g < NL; g++) {
+    const node_t* nd = &s->nodes[g];
+    if (nd->ring) ok = ck_wr(f, nd->ring, (size_t)s->cfg.event_buffer * sizeof(evslot));
+    ok = ok && ck_wr(f, nd->vt.e, (size_t)nd->vt.slots * sizeof(view_t));       /* (n and slots travel with the node) */
+  }
+  ok = ok && ck_wr(f, s->slots, NS * sizeof(slot_t));
+  for (size_t i = 0; ok && i < NS; i++) if (s->slots[i].trace) ok = ck_wr(f, s->slots[i].trace, (size_t)s->cfg.trace_ticks * 5 * 4);
+  for (uint32_t i = 0; ok && i < s->cfg.n_shards; i++) ok = ck_wr_vec(f, &s->out[i]);
+  ok = ok && ck_wr_vec(f, &s->in) && ck_wr_vec(f, &s->last_edges) && ck_wr_vec(f, &s->carry[0]) && ck_wr_vec(f, &s->carry[1]);
+  ok = ok && ck_wr_vec(f, &s->pp_reply[0]) && ck_wr_vec(f, &s->pp_reply[1]) && ck_wr_vec(f, &s->captured) && ck_wr(f, s->cap_src, (size_t)s->captured.n * 4);
+  ok = ok && ck_wr(f, s->events, (size_t)s->n_events * sizeof(swim_event));
+  if (s->cs) ok = ok && ck_wr(f, s->cs, NL * sizeof(coord_state));
+  if (fclose(f) != 0) ok = 0;
+  return ok ? SWIM_OK : SWIM_EIO;
+}
+int swim_checkpoint_load(swim_sim* s, const char* path) {
+  if (!s || !path) return SWIM_EINVAL;
+  if (s->in_tick) return SWIM_ESTATE;
+  FILE* f = fopen(path, "rb"); if (!f) return SWIM_EIO;
+  const size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R, NS = (size_t)s->R * s->cfg.subject_cap;
+  ck_header h;
+  if (!ck_rd(f, &h, sizeof h)) { fclose(f); return SWIM_EINVAL; }
+  if (memcmp(h.magic, "SWIMCKPT", 8) || strncmp(h.backend, swim_backend(), sizeof h.backend) || h.abi != SWIM_ABI_VERSION || memcmp(&h.cfg, &s->cfg, sizeof h.cfg)) {
+    fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another library, ABI or configuration"); return SWIM_EINVAL;
+  }
+  int ok = 1;
+  ok = ok && ck_rd(f, s->gt_alive, NT) && ck_rd(f, s->part, NT) && ck_rd(f, s->attached, NT) && ck_rd(f, s->alone, NT);
+  ok = ok && ck_rd(f, s->node_slot, NT * 4) && ck_rd(f, s->base_key, NT * 4) && ck_rd(f, s->subj_cnt, NT * 4);
+  ok = ok && ck_rd(f, s->f_cnt, NT * 4) && ck_rd(f, s->f_kmin, NT * 4) && ck_rd(f, s->f_kmax, NT * 4) && ck_rd(f, s->f_bad, NT);
+  if (ok && h.f_ntouched > s->f_cap) { uint32_t* v = (uint32_t*)realloc(s->f_touched, (size_t)h.f_ntouched * 4); if (v) { s->f_touched = v; s->f_cap = h.f_ntouched; } else ok = 0; }
+  if (ok && h.n_join_pending > s->join_cap) { uint32_t* v = (uint32_t*)realloc(s->join_list, (size_t)h.n_join_pending * 8); if (v) { s->join_list = v; s->join_cap = h.n_join_pending; } else ok = 0; }
+  ok = ok && ck_rd(f, s->f_touched, (size_t)h.f_ntouched * 4) && ck_rd(f, s->join_list, (size_t)h.n_join_pending * 8);
+  ok = ok && ck_rd(f, s->base_known, (size_t)s->R * 4) && ck_rd(f, s->n_slots, (size_t)s->R * 4);
+  /* the nodes: plain data except four pointers, which stay this handle's (the view table is re-sized to what was saved) */
+  for (size_t g = 0; ok && g < NL; g++) {
+    node_t* nd = &s->nodes[g], keep = *nd;
+    ok = ck_rd(f, nd, sizeof *nd);
+    nd->q = keep.q; nd->evq = keep.evq; nd->ring = keep.ring; nd->inbox = keep.inbox; nd->vt.e = keep.vt.e;
+    if (ok && nd->vt.slots != keep.vt.slots) {
+      view_t* e = nd->vt.slots ? (view_t*)malloc((size_t)nd->vt.slots * sizeof(view_t)) : NULL;
+      if (nd->vt.slots && !e) { nd->vt.slots = keep.vt.slots; nd->vt.n = 0; ok = 0; } else { free(nd->vt.e); nd->vt.e = e; }
+    }
+  }
+  ok = ok && ck_rd(f, s->q_slab, NL * s->cfg.queue_cap * sizeof(qent));
+  if (s->evq_slab) ok = ok && ck_rd(f, s->evq_slab, NL * s->cfg.event_queue_cap * sizeof(qent));
+  for (size_t g = 0; ok && g < NL; g++) {
+    node_t* nd = &s->nodes[g];
+    if (nd->ring) ok = ck_rd(f, nd->ring, (size_t)s->cfg.event_buffer * sizeof(evslot));
+    ok = ok && ck_rd(f, nd->vt.e, (size_t)nd->vt.slots * sizeof(view_t));
+  }
+  for (size_t i = 0; ok && i < NS; i++) {                 /* the watch slots: plain data except the trace pointer */
+    slot_t* t = &s->slots[i]; uint32_t* mine = t->trace;
+    ok = ck_rd(f, t, sizeof *t);
+    const int had = t->trace != NULL; t->trace = mine;
+    if (ok && had && !t->trace) { t->trace = (uint32_t*)calloc((size_t)s->cfg.trace_ticks * 5, 4); ok = t->trace != NULL; }
+    if (ok && !had && t->trace) { free(t->trace); t->trace = NULL; }
+  }
+  for (size_t i = 0; ok && i < NS; i++) if (s->slots[i].trace) ok = ck_rd(f, s->slots[i].trace, (size_t)s->cfg.trace_ticks * 5 * 4);
+  for (uint32_t i = 0; ok && i < s->cfg.n_shards; i++) ok = ck_rd_vec(f, &s->out[i]);
+  ok = ok && ck_rd_vec(f, &s->in) && ck_rd_vec(f, &s->last_edges) && ck_rd_vec(f, &s->carry[0]) && ck_rd_vec(f, &s->carry[1]);
+  ok = ok && ck_rd_vec(f, &s->pp_reply[0]) && ck_rd_vec(f, &s->pp_reply[1]) && ck_rd_vec(f, &s->captured);
+  if (ok && s->captured.n > s->cap_src_cap) { uint32_t* v = (uint32_t*)realloc(s->cap_src, (size_t)s->captured.n * 4); if (v) { s->cap_src = v; s->cap_src_cap = s->captured.n; } else ok = 0; }
+  ok = ok && ck_rd(f, s->cap_src, (size_t)s->captured.n * 4);
+  if (ok && h.n_events > s->cap_events) { swim_event* v = (swim_event*)realloc(s->events, (size_t)h.n_events * sizeof(swim_event)); if (v) { s->events = v; s->cap_events = (size_t)h.n_events; } else ok = 0; }
+  ok = ok && ck_rd(f, s->events, (size_t)h.n_events * sizeof(swim_event));
+  if (s->cs) ok = ok && ck_rd(f, s->cs, NL * sizeof(coord_state));
+  fclose(f);
+  if (!ok) { snprintf(s->err, sizeof s->err, "checkpoint truncated or out of memory: the handle's state is undefined"); return SWIM_EIO; }
+  s->tick = h.tick; s->loss_q32 = h.loss_q32; s->n_join_pending = h.n_join_pending; s->f_ntouched = h.f_ntouched; s->xcredit = h.xcredit;
+  s->n_events = (size_t)h.n_events; s->st = h.st; s->c_n = 0; s->in_tick = 0;
+  return SWIM_OK;
+}
+
 int swim_profile(swim_sim* s, int enable) { (void)enable; return s ? SWIM_OK : SWIM_EINVAL; }
 int swim_profile_read(swim_sim* s, swim_kernel_time* out, size_t cap, size_t* n_out) {
   (void)out; (void)cap; if (!s || !n_out) return SWIM_EINVAL; *n_out = 0; return SWIM_OK;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
 
 #include "../../include/swimsim_serf.hpp"
 
@@ -192,12 +193,39 @@ static void testCoordinates() {
   coordinate::Coordinate none;
   EXPECT(!s4->GetCachedCoordinate("no-such-node", &none));
   std::printf("ok Coordinates\n");
+
+}
+
+// a cluster restored from a checkpoint goes on exactly like the one that was never stopped: same failure verdict at the same time
+static void testCheckpointRestore() {
+  const std::string path = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/swimsim_facade_" + std::to_string((long)getpid()) + ".ck";
+  serf::Cluster::Options o{ 32, 1, 8, 32, 8, 0, 3, 0, 512 };
+  auto a = std::make_shared<serf::Cluster>(testTimers(), o);
+  auto sa = serf::Serf::Create(serf::ConsulDefaultConfig(), a, 0);
+  a->Advance(std::chrono::seconds(2)); a->Kill({ 7 });
+  a->Advance(std::chrono::milliseconds(300));
+  a->Checkpoint(path);
+  auto b = std::make_shared<serf::Cluster>(testTimers(), o);
+  auto sb = serf::Serf::Create(serf::ConsulDefaultConfig(), b, 0);
+  b->Restore(path);
+  std::remove(path.c_str());
+  int failed_a = -1, failed_b = -1;
+  for (int i = 0; i < 400 && (failed_a < 0 || failed_b < 0); i++) {
+    a->Advance(std::chrono::milliseconds(100)); b->Advance(std::chrono::milliseconds(100));
+    if (failed_a < 0 && statusOf(sa->Members(), "node-7") == serf::StatusFailed) failed_a = i;
+    if (failed_b < 0 && statusOf(sb->Members(), "node-7") == serf::StatusFailed) failed_b = i;
+  }
+  EXPECT(failed_a >= 0 && failed_a == failed_b);
+  bool threw = false;
+  try { b->Restore(path); } catch (const Error& e) { threw = e.code == SWIM_EIO; }
+  EXPECT(threw);                                    // the file is gone
+  std::printf("ok CheckpointRestore\n");
 }
 
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
-    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates();
+    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates(); testCheckpointRestore();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;

@@ -16,3 +16,7 @@ bash tools/ab_libs.sh
 for f in _ab/lib_*.so; do
   SWIMSIM_LIB=$PWD/$f python bench.py --main-only 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f default window: value %.3e  ms/step %.4f' % (d['value'], d['ms_per_step']))"
 done
+# ...and the driver's window on ONE handle, untraced (what the roofline pass instruments)
+for f in _ab/lib_*.so; do
+  SWIMSIM_LIB=$PWD/$f python bench.py --main-only --handles 1 --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f driver window, one handle: value %.3e  ms/step %.4f' % (d['value'], d['ms_per_step']))"
+done
