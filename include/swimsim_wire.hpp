@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -257,6 +258,87 @@ inline UserEvent decode_user_event(const uint8_t* p, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// compression (util.go compressPayload / decompressPayload): Go's compress/lzw, LSB order, 8-bit literals — GIF's
+// variable-width LZW: codes of 9..12 bits packed least-significant-bit first, clear = 256, eof = 257, first free code
+// 258; the encoder opens with a clear code and clears again when the table is full.  memberlist's DefaultLANConfig (and
+// so Consul) has EnableCompression = true: a real node sends [compressMsg][msgpack {Algo: 0, Buf: lzw(payload)}] whenever
+// that is shorter than the payload.  UPSTREAM-RECALL for the framing; the coder itself is pinned against an independent
+// implementation of the same format (a GIF encoder / decoder) in tests/test_wire_lzw.py.
+// ---------------------------------------------------------------------------------------------------------------
+inline Bytes lzw_encode(const Bytes& in) {
+  Bytes out; uint32_t bits = 0; unsigned nbits = 0, width = 9;
+  auto emit = [&](uint32_t code) { bits |= code << nbits; nbits += width; while (nbits >= 8) { out.push_back(uint8_t(bits)); bits >>= 8; nbits -= 8; } };
+  const uint32_t kClear = 256, kEof = 257, kMax = 4095;
+  std::map<uint32_t, uint32_t> table;               // (prefix code << 8 | byte) -> code
+  uint32_t hi = kEof, overflow = 512;
+  auto inc_hi = [&]() -> bool {                      // writer.go incHi: false = out of codes, the table was reset
+    hi++;
+    if (hi == overflow) { width++; overflow <<= 1; }
+    if (hi == kMax) { emit(kClear); width = 9; hi = kEof; overflow = 512; table.clear(); return false; }
+    return true;
+  };
+  emit(kClear);
+  if (!in.empty()) {
+    uint32_t code = in[0];
+    for (size_t i = 1; i < in.size(); i++) {
+      const uint32_t key = code << 8 | in[i];
+      auto it = table.find(key);
+      if (it != table.end()) { code = it->second; continue; }
+      emit(code); code = in[i];
+      if (inc_hi()) table[key] = hi;
+    }
+    emit(code); inc_hi();
+  }
+  emit(kEof);
+  if (nbits) out.push_back(uint8_t(bits));
+  return out;
+}
+inline Bytes lzw_decode(const uint8_t* p, size_t n, size_t limit = size_t(1) << 24) {
+  Bytes out; uint32_t bits = 0; unsigned nbits = 0, width = 9;
+  const uint32_t kClear = 256, kEof = 257, kInvalid = 0xFFFF;
+  std::vector<uint16_t> prefix(4096); std::vector<uint8_t> suffix(4096);
+  uint32_t hi = kEof, overflow = 512, last = kInvalid;
+  size_t i = 0;
+  for (;;) {
+    while (nbits < width) { if (i >= n) throw DecodeError("lzw: truncated"); bits |= uint32_t(p[i++]) << nbits; nbits += 8; }
+    const uint32_t code = bits & ((1u << width) - 1); bits >>= width; nbits -= width;
+    if (code < kClear) {
+      out.push_back(uint8_t(code));
+      if (last != kInvalid) { suffix[hi] = uint8_t(code); prefix[hi] = uint16_t(last); }
+    } else if (code == kClear) { width = 9; hi = kEof; overflow = 512; last = kInvalid; continue; }
+    else if (code == kEof) return out;
+    else if (code <= hi) {
+      Bytes rev; uint32_t c = code;
+      if (code == hi && last != kInvalid) {          // the code being defined: the last expansion followed by its own head
+        c = last; while (c >= kClear) c = prefix[c];
+        rev.push_back(uint8_t(c)); c = last;
+      } else if (code == hi) throw DecodeError("lzw: invalid code");
+      while (c >= kClear) { rev.push_back(suffix[c]); c = prefix[c]; }
+      rev.push_back(uint8_t(c));
+      out.insert(out.end(), rev.rbegin(), rev.rend());
+      if (last != kInvalid) { suffix[hi] = uint8_t(c); prefix[hi] = uint16_t(last); }
+    } else throw DecodeError("lzw: invalid code");
+    if (out.size() > limit) throw DecodeError("lzw: output too large");
+    last = code; hi++;
+    if (hi >= overflow) { if (width == 12) { last = kInvalid; hi--; } else { width++; overflow = 1u << width; } }
+  }
+}
+struct Compress { uint32_t algo = 0; Bytes buf; };     // net.go `compress{Algo compressionType; Buf []byte}`, lzwAlgo = 0
+inline Bytes encode(const Compress& m) { Bytes b{kCompress}; Writer w{b}; w.map(2); w.str("Algo"); w.uint(m.algo); w.str("Buf"); w.bytes(m.buf, true); return b; }
+inline Compress decode_compress(const uint8_t* p, size_t n) {
+  Compress m;
+  decode_map(p, n, [&](const std::string& k, Reader& r) { if (k == "Algo") m.algo = uint32_t(r.uint()); else if (k == "Buf") m.buf = r.raw(); else return false; return true; });
+  return m;
+}
+// compressPayload as rawSendMsgPacket uses it: the compressed form only when it is shorter
+inline Bytes maybe_compress(const Bytes& msg) { Bytes c = encode(Compress{ 0, lzw_encode(msg) }); return c.size() < msg.size() ? c : msg; }
+inline Bytes decompress(const uint8_t* body, size_t n) {
+  Compress c = decode_compress(body, n);
+  if (c.algo != 0) throw DecodeError("compressMsg: unknown algorithm");
+  return lzw_decode(c.buf.data(), c.buf.size());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // framing: compound packets (util.go makeCompoundMessage / decodeCompoundMessage), label (label.go), CRC (net.go)
 // ---------------------------------------------------------------------------------------------------------------
 // [compoundMsg][n u8][n x len u16 BE][payloads]; more than 255 messages span several packets
@@ -375,7 +457,7 @@ inline Bytes to_packet(const std::vector<swim_edge>& rumours, const Naming& nm =
 // names that are not "<prefix><id>" are counted in `foreign`.
 // A ping / indirect ping the real node sent: the bridge answers it on behalf of the virtual peer (BridgeTransport).
 struct Probe { bool indirect = false; uint32_t seq_no = 0; bool nack = false; std::string node; Bytes target; };
-struct UnsupportedPacket : DecodeError { using DecodeError::DecodeError; };   // compressMsg / encryptMsg: not decodable here
+struct UnsupportedPacket : DecodeError { using DecodeError::DecodeError; };   // encryptMsg: not decodable here
 inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm = Naming(), size_t* control = nullptr, size_t* foreign = nullptr,
                                           std::vector<Probe>* probes = nullptr) {
   std::vector<swim_edge> out; size_t n_control = 0, n_foreign = 0;
@@ -404,9 +486,10 @@ inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm 
       }
       case kPing: { n_control++; if (probes) { Ping pg = decode_ping(body, n); Probe pr; pr.seq_no = pg.seq_no; pr.node = pg.node; probes->push_back(pr); } break; }
       case kIndirectPing: { n_control++; if (probes) { IndirectPing ip = decode_indirect_ping(body, n); Probe pr; pr.indirect = true; pr.seq_no = ip.seq_no; pr.nack = ip.nack; pr.node = ip.node; pr.target = ip.target; probes->push_back(pr); } break; }
-      // memberlist's DefaultLANConfig has EnableCompression = true (Consul's default) and Consul may encrypt gossip: such a
-      // packet carries rumours this codec cannot see.  Losing them silently would be worse than refusing the packet.
-      case kCompress: throw UnsupportedPacket("compressMsg: configure the attached node with EnableCompression = false");
+      // memberlist's DefaultLANConfig has EnableCompression = true (Consul's default): the payload is a whole message again
+      case kCompress: todo.push_back(decompress(body, n)); break;
+      // Consul may encrypt gossip: such a packet carries rumours this codec cannot see.  Losing them silently would be worse
+      // than refusing the packet.
       case kEncrypt: throw UnsupportedPacket("encryptMsg: gossip encryption is not supported by the bridge");
       default: n_control++; break;                   // ack / nack / push-pull / err
     }
@@ -424,8 +507,10 @@ class BridgeTransport {
  public:
   struct Packet { Bytes buf; std::string from; uint32_t from_id; };   // memberlist.Packet{Buf, From}; from_id SWIM_NONE: not a gossip packet
 
-  BridgeTransport(swim_sim* sim, uint32_t replica, uint32_t self_id, Naming naming = Naming(), std::string label = std::string(), bool crc = true)
-      : sim_(sim), replica_(replica), self_(self_id), nm_(std::move(naming)), label_(std::move(label)), crc_(crc) {}
+  // `compress` = memberlist.Config.EnableCompression of the virtual peers (DefaultLANConfig: true): what they send is compressed
+  // when that is shorter, before the CRC and the label like rawSendMsgPacket does; compressed packets are always accepted
+  BridgeTransport(swim_sim* sim, uint32_t replica, uint32_t self_id, Naming naming = Naming(), std::string label = std::string(), bool crc = true, bool compress = false)
+      : sim_(sim), replica_(replica), self_(self_id), nm_(std::move(naming)), label_(std::move(label)), crc_(crc), compress_(compress) {}
 
   // Transport.WriteToAddress(b, Address{Addr, Name}): `to` is the receiver's node name ("node-7") or its "10.a.b.c[:port]"
   // address.  Returns 0, a SWIM_E* code, or SWIM_EINVAL for an address outside the virtual cluster.
@@ -434,7 +519,7 @@ class BridgeTransport {
     if (!resolve(to, &dst)) return SWIM_EINVAL;
     size_t control = 0, foreign = 0; std::vector<Probe> probes; std::vector<swim_edge> recs;
     try { recs = from_packet(packet, nm_, &control, &foreign, &probes); }
-    catch (const UnsupportedPacket&) { unsupported_seen_++; return SWIM_EINVAL; }
+    catch (const DecodeError&) { unsupported_seen_++; return SWIM_EINVAL; }      // encrypted, or malformed (a hostile or truncated packet): refused whole
     control_seen_ += control; foreign_seen_ += foreign;
     // probeNode of the real node: the virtual peer answers like handlePing / handleIndirectPing would — an ackResp when it
     // (and, for an indirect ping, the target behind it) is running and in the real node's partition, a nackResp for a
@@ -459,6 +544,7 @@ class BridgeTransport {
       size_t j = i; std::vector<swim_edge> batch;
       while (j < n && got[j].dst == got[i].dst && batch.size() < 255) { swim_edge e = got[j]; e.dst = 0; batch.push_back(e); j++; }
       Bytes pkt = to_packet(batch, nm_);
+      if (compress_) pkt = maybe_compress(pkt);
       if (crc_) pkt = add_crc(pkt);
       pkt = add_label(pkt, label_);
       out.push_back(Packet{ std::move(pkt), got[i].dst == SWIM_NONE ? std::string() : nm_.name_of(got[i].dst), got[i].dst });
@@ -498,7 +584,7 @@ class BridgeTransport {
     if (sscanf(to.c_str(), "%u.%u.%u.%u", &a, &b, &c, &d) == 4 && a == 10 && b < 256 && c < 256 && d < 256) { *id = b << 16 | c << 8 | d; return true; }
     return false;
   }
-  swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_;
+  swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_, compress_;
   size_t control_seen_ = 0, foreign_seen_ = 0, unsupported_seen_ = 0, probes_answered_ = 0;
   std::vector<Packet> acks_;                          // ackResp / nackResp waiting for the next Poll
 };

@@ -177,15 +177,40 @@ int main() {
           CHECK(!(inner[0] == kAckResp && decode_ack(inner.data() + 1, inner.size() - 1).seq_no == 2));
         }
         CHECK(acks == 1 && nacks == 1 && tr.control_messages_seen() == 5);   // counters accumulate over calls
-        // compressMsg / encryptMsg carry rumours this codec cannot see: refused, never swallowed
+        // encryptMsg carries rumours this codec cannot see: refused, never swallowed; a malformed compressMsg likewise
         CHECK(tr.WriteTo(Bytes{kCompress, 0x81, 0xa4}, "node-7") == SWIM_EINVAL && tr.WriteTo(Bytes{kEncrypt, 1, 2, 3}, "node-7") == SWIM_EINVAL);
         CHECK(tr.unsupported_packets_seen() == 2);
+        // a compressed packet (memberlist's default: EnableCompression) is opened: the suspicion inside reaches node 7
+        {
+          std::vector<Bytes> many;
+          for (int k = 0; k < 6; k++) many.push_back(encode_suspect(Suspect{1, "node-21", "node-5"}));     // repetitive enough to shrink
+          Bytes compound = make_compound(many)[0], packed = maybe_compress(compound);
+          CHECK(packed[0] == kCompress && packed.size() < compound.size());
+          CHECK(decompress(packed.data() + 1, packed.size() - 1) == compound);
+          swim_member before; CHECK(swim_view(sim, 0, 7, 21, &before) == 0 && before.state == SWIM_STATE_ALIVE);
+          CHECK(tr.WriteTo(add_label(add_crc(packed), ""), "node-7") == 0);
+          CHECK(swim_step(sim, 1) == 0);
+          swim_member after; CHECK(swim_view(sim, 0, 7, 21, &after) == 0 && after.state == SWIM_STATE_SUSPECT);
+        }
       }
       CHECK(swim_step(sim, 2) == 0);
       CHECK(swim_view(sim, 0, 7, 20, &mv) == 0 && mv.state != SWIM_STATE_ALIVE);
       printf("backend %s\n", swim_backend());
       swim_destroy(sim);
     }
+  }
+  {   // compress/lzw (LSB, 8-bit literals) as memberlist's compressPayload uses it: round trips, the table-full reset, hostile input
+    auto rt = [](const Bytes& in) { Bytes z = lzw_encode(in); return lzw_decode(z.data(), z.size()) == in; };
+    CHECK(rt(Bytes{}) && rt(Bytes{42}) && rt(Bytes(1000, 7)));
+    Bytes text; for (int i = 0; i < 3000; i++) text.push_back(uint8_t("memberlist"[i % 10]));
+    CHECK(rt(text) && lzw_encode(text).size() < text.size() / 5);
+    Bytes noise; uint32_t x = 1; for (int i = 0; i < 40000; i++) { x = x * 1664525u + 1013904223u; noise.push_back(uint8_t(x >> 24)); }
+    CHECK(rt(noise));                                                        // > 4 096 codes: the encoder clears and starts over
+    Bytes kwk; for (int i = 0; i < 500; i++) kwk.push_back('a');             // aaaa...: every code is the one being defined
+    CHECK(rt(kwk));
+    CHECK(lzw_encode(Bytes{}) == (Bytes{0x00, 0x03, 0x02}));                 // clear (9 bits), eof (9 bits), padded: 0x100 | 0x101 << 9
+    auto bad = [](const Bytes& z) { try { lzw_decode(z.data(), z.size()); } catch (const DecodeError&) { return true; } return false; };
+    CHECK(bad(Bytes{}) && bad(Bytes{0x00, 0x01}) && bad(Bytes{0x00, 0xff, 0xff, 0xff}));   // truncated; no eof; a code beyond the table
   }
   {   // Reader::skip() on hostile input — truncated map, deep nesting, ext types
     auto throws = [](const Bytes& b) { try { decode_alive(b.data(), b.size()); } catch (const DecodeError&) { return true; } return false; };
