@@ -265,7 +265,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200, help="timed gossip rounds")
     ap.add_argument("--warmup", type=int, default=25, help="untimed gossip rounds before the failure")
     ap.add_argument("--nodes", type=int, default=65536)
-    ap.add_argument("--replicas", type=int, default=32, help="cluster replicas per GPU (seeds seed..)")
+    ap.add_argument("--replicas", type=int, default=64, help="cluster replicas per GPU (seeds seed..); rounds 1 and 2 up to BENCH_r02 ran 32: see batch_scaling")
     ap.add_argument("--fanout", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--handles", type=int, default=3,
@@ -353,7 +353,7 @@ def main():
 
     def fresh(multi=True):
         if multi and handles > 1:
-            sizes = [reps // handles + (1 if g < reps % handles else 0) for g in range(handles)]      # 32 on 3: 11 + 11 + 10
+            sizes = [reps // handles + (1 if g < reps % handles else 0) for g in range(handles)]      # 64 on 3: 22 + 21 + 21
             first = [sum(sizes[:g]) for g in range(handles)]
             return MultiSim([Sim(hip, preset(hip, abi.PRESET_LAN, **dict(cfg_kw, n_replicas=sizes[g], seed=args.seed + first[g])))
                              for g in range(handles)], first)
@@ -475,6 +475,29 @@ def main():
         dt1 = time.perf_counter() - t1
         one.close()
         line["single_handle"] = {"value": reps * args.nodes * args.steps / dt1, "unit": "node-rounds/s", "ms_per_step": 1000.0 * dt1 / args.steps}
+    if rank == 0 and not sharded and not args.main_only:
+        # how the same region scales with the number of clusters batched on the GPU (same handles, same window): a tick has a
+        # fixed part (five launches, each at least one chain of dependent accesses long) that more clusters amortise
+        line["batch_scaling"] = {}
+        for other in (32, 128):
+            if other == reps:
+                continue
+            sizes = [other // handles + (1 if g < other % handles else 0) for g in range(handles)]
+            first = [sum(sizes[:g]) for g in range(handles)]
+            ms = MultiSim([Sim(hip, preset(hip, abi.PRESET_LAN, **dict(cfg_kw, n_replicas=sizes[g], seed=args.seed + first[g])))
+                           for g in range(handles)], first)
+            vic = victims_for(args.seed, other, args.nodes)
+            ms.step(G); ms.sync()
+            ms.step((args.warmup - 1) * G if args.warmup > 1 else 0)
+            for r, v in enumerate(vic):
+                ms.kill(r, [v])
+            ms.sync()
+            tb = time.perf_counter()
+            ms.step(args.steps * G); ms.sync()
+            dtb = time.perf_counter() - tb
+            ms.close()
+            line["batch_scaling"][str(other)] = {"value": other * args.nodes * args.steps / dtb, "ms_per_step": 1000.0 * dtb / args.steps}
+        line["batch_scaling"][str(reps)] = {"value": value, "ms_per_step": 1000.0 * dt / args.steps}
     if rank == 0 and not sharded and not args.no_roofline:
         # instrumented pass over the same region: HIP events around every launch on the sim's stream (one handle: the launches
         # are then the ones `single_handle` times; with several handles the same kernels run at 1/handles of the size, overlapped)
