@@ -2,8 +2,9 @@
 """bench.py — SWIM hot-path throughput on MI355X (BASELINE.json metric: gossip rounds/sec x nodes).
 
 Workload at N=1 = BASELINE.json configs[1]: 65 536-node clusters, memberlist DefaultLANConfig,
-fan-out k=3, single failure injection, one cluster replica per seed 1..32 batched on the GPU
-(2 097 152 virtual nodes = lanes).  Warm-up = the pre-failure phase (default 25 rounds = 5 s of
+fan-out k=3, single failure injection, one cluster replica per seed 1..64 batched on the GPU
+(4 194 304 virtual nodes = lanes; `batch_scaling` in the line has the same window with 32 and 128), spread over three
+library handles (HIP streams).  Warm-up = the pre-failure phase (default 25 rounds = 5 s of
 simulated time), then one uniformly drawn node per replica is killed and the timed region runs K
 gossip rounds (default 200 = 40 s simulated: probe failure -> suspicion -> confirmations -> dead ->
 dissemination -> quiescence).  A "step" is one gossip round = GossipInterval/quantum ticks of the
