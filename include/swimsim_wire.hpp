@@ -416,6 +416,58 @@ inline Bytes strip_crc(const Bytes& packet) {
 // ---------------------------------------------------------------------------------------------------------------
 // How virtual node ids appear to a real memberlist node.  The defaults match the cgo shim of INTEGRATION.md
 // (name "node-<id>", address 10.x.y.z, serf port 8301, protocol/delegate versions {1,5,2,2,5,4}).
+// ---------------------------------------------------------------------------------------------------------------
+// the stream side: push-pull (net.go sendLocalState / readRemoteState).  On a TCP connection the initiator writes
+// [label header]? then ONE message: [pushPullMsg][msgpack pushPullHeader{Nodes, UserStateLen, Join}] followed by Nodes
+// msgpack pushNodeState{Name, Addr, Port, Meta, Incarnation, State, Vsn} values back to back and UserStateLen bytes of the
+// delegate's state (serf's messagePushPull) — the whole thing wrapped in compressMsg when compression is on (rawSendMsgStream)
+// — and reads the same back.  UPSTREAM-RECALL like the packet structs above.
+// ---------------------------------------------------------------------------------------------------------------
+struct PushNodeState { std::string name; Bytes addr; uint16_t port = 0; Bytes meta; uint32_t incarnation = 0; uint32_t state = 0; Bytes vsn; };
+struct PushPull { bool join = false; std::vector<PushNodeState> nodes; Bytes user_state; };
+inline Bytes encode(const PushPull& m) {
+  Bytes b{kPushPull}; Writer w{b};
+  w.map(3); w.str("Nodes"); w.uint(m.nodes.size()); w.str("UserStateLen"); w.uint(m.user_state.size()); w.str("Join"); w.boolean(m.join);
+  for (const PushNodeState& n : m.nodes) {
+    w.map(7); w.str("Name"); w.str(n.name); w.str("Addr"); w.bytes(n.addr, true); w.str("Port"); w.uint(n.port); w.str("Meta"); w.bytes(n.meta, true);
+    w.str("Incarnation"); w.uint(n.incarnation); w.str("State"); w.uint(n.state); w.str("Vsn"); w.bytes(n.vsn, true);
+  }
+  b.insert(b.end(), m.user_state.begin(), m.user_state.end());
+  return b;
+}
+// the bytes AFTER the pushPullMsg byte; a node count or state length the buffer cannot hold is refused before anything is allocated
+inline PushPull decode_push_pull(const uint8_t* p, size_t n) {
+  Reader r(p, n); PushPull m; uint64_t nodes = 0, ulen = 0;
+  { size_t k = r.map(); for (size_t i = 0; i < k; i++) { std::string key = r.str();
+      if (key == "Nodes") nodes = r.uint(); else if (key == "UserStateLen") ulen = r.uint(); else if (key == "Join") m.join = r.boolean(); else r.skip(); } }
+  if (nodes > r.left() || ulen > r.left()) throw DecodeError("push-pull header promises more than the stream holds");
+  m.nodes.reserve(size_t(nodes));
+  for (uint64_t j = 0; j < nodes; j++) {
+    PushNodeState s; size_t k = r.map();
+    for (size_t i = 0; i < k; i++) { std::string key = r.str();
+      if (key == "Name") s.name = r.str(); else if (key == "Addr") s.addr = r.raw(); else if (key == "Port") s.port = uint16_t(r.uint());
+      else if (key == "Meta") s.meta = r.raw(); else if (key == "Incarnation") s.incarnation = uint32_t(r.uint()); else if (key == "State") s.state = uint32_t(r.uint());
+      else if (key == "Vsn") s.vsn = r.raw(); else r.skip(); }
+    m.nodes.push_back(std::move(s));
+  }
+  if (ulen > r.left()) throw DecodeError("truncated");
+  m.user_state.assign(r.p, r.p + ulen);
+  return m;
+}
+// what a peer writes on / reads from the connection: optional label header, optional compressMsg wrapper
+inline Bytes to_stream(const PushPull& m, const std::string& label, bool compress) {
+  Bytes b = encode(m);
+  if (compress) b = maybe_compress(b);
+  return add_label(b, label);
+}
+inline PushPull from_stream(const Bytes& stream, std::string* label = nullptr) {
+  Bytes b = strip_label(stream, label);
+  if (!b.empty() && b[0] == kEncrypt) throw DecodeError("encryptMsg: gossip encryption is not supported by the bridge");
+  if (!b.empty() && b[0] == kCompress) b = decompress(b.data() + 1, b.size() - 1);
+  if (b.empty() || b[0] != kPushPull) throw DecodeError("expected a push-pull message on the stream");
+  return decode_push_pull(b.data() + 1, b.size() - 1);
+}
+
 struct Naming {
   std::string prefix = "node-";
   uint16_t port = 8301;
@@ -509,8 +561,10 @@ class BridgeTransport {
 
   // `compress` = memberlist.Config.EnableCompression of the virtual peers (DefaultLANConfig: true): what they send is compressed
   // when that is shorter, before the CRC and the label like rawSendMsgPacket does; compressed packets are always accepted
-  BridgeTransport(swim_sim* sim, uint32_t replica, uint32_t self_id, Naming naming = Naming(), std::string label = std::string(), bool crc = true, bool compress = false)
-      : sim_(sim), replica_(replica), self_(self_id), nm_(std::move(naming)), label_(std::move(label)), crc_(crc), compress_(compress) {}
+  // `n_nodes` = swim_config.n_nodes of the handle (the size of a member list; only PushPull needs it)
+  BridgeTransport(swim_sim* sim, uint32_t replica, uint32_t self_id, Naming naming = Naming(), std::string label = std::string(), bool crc = true, bool compress = false,
+                  uint32_t n_nodes = 0)
+      : sim_(sim), replica_(replica), self_(self_id), nm_(std::move(naming)), label_(std::move(label)), crc_(crc), compress_(compress), n_nodes_(n_nodes) {}
 
   // Transport.WriteToAddress(b, Address{Addr, Name}): `to` is the receiver's node name ("node-7") or its "10.a.b.c[:port]"
   // address.  Returns 0, a SWIM_E* code, or SWIM_EINVAL for an address outside the virtual cluster.
@@ -552,6 +606,42 @@ class BridgeTransport {
     }
     return out;
   }
+  // Transport.DialAddressTimeout + the stream exchange of pushPullNode (what memberlist.Join and the periodic push-pull of the
+  // real node do over TCP): `to` answers with its whole view — one pushNodeState per member it knows, the attached node among
+  // them — after merging what the real node sent the way mergeState does: Alive -> alive, Left -> dead{From: the node itself},
+  // Dead and Suspect -> suspect{From: the receiver} (a remote Dead is never trusted directly).  Names outside the virtual cluster
+  // are counted as foreign.  The reply is framed like the request (label, compression per the constructor).  Throws DecodeError
+  // for a stream it cannot read; returns an empty vector when `to` is not a running, reachable virtual member (the dial fails).
+  Bytes PushPull(const Bytes& stream, const std::string& to) {
+    uint32_t dst;
+    if (!resolve(to, &dst) || n_nodes_ == 0) return {};
+    wire::PushPull in = from_stream(stream, nullptr);
+    if (dst == self_ || !up_and_reachable(dst)) return {};
+    std::vector<swim_edge> recs;
+    for (const PushNodeState& n : in.nodes) {
+      uint32_t id;
+      if (!nm_.id_of(n.name, &id)) { foreign_seen_++; continue; }
+      switch (n.state) {
+        case SWIM_STATE_ALIVE: recs.push_back(swim_edge{ 0, id, n.incarnation, uint32_t(SWIM_MSG_ALIVE) << 30 }); break;
+        case SWIM_STATE_LEFT: recs.push_back(swim_edge{ 0, id, n.incarnation, uint32_t(SWIM_MSG_DEAD) << 30 | (id & 0x3FFFFFFFu) }); break;
+        default: recs.push_back(swim_edge{ 0, id, n.incarnation, uint32_t(SWIM_MSG_SUSPECT) << 30 | (dst & 0x3FFFFFFFu) }); break;
+      }
+    }
+    if (!recs.empty() && swim_transport_write_to(sim_, replica_, self_, dst, recs.data(), recs.size()) != SWIM_OK) return {};
+    // the peer's local state as of now (what it has merged in this tick's arrivals shows from the next tick on, as for any packet)
+    std::vector<swim_member> members(n_nodes_); size_t got = 0;
+    if (swim_members(sim_, replica_, dst, members.data(), members.size(), &got) != SWIM_OK) return {};
+    wire::PushPull out; out.join = false;
+    for (size_t i = 0; i < got; i++) {
+      const swim_member& m = members[i];
+      if (m.status == SWIM_MEMBER_NONE) continue;                  // never heard of / erased by the reaper: not in its member list
+      PushNodeState s; s.name = nm_.name_of(m.id); s.addr = nm_.addr_of(m.id); s.port = nm_.port; s.incarnation = m.incarnation; s.state = m.state; s.vsn = nm_.vsn;
+      out.nodes.push_back(std::move(s));
+    }
+    push_pulls_++;
+    return to_stream(out, label_, compress_);
+  }
+  size_t push_pulls_answered() const { return push_pulls_; }
   size_t control_messages_seen() const { return control_seen_; }     // accumulated over all WriteTo calls
   size_t foreign_names_seen() const { return foreign_seen_; }
   size_t unsupported_packets_seen() const { return unsupported_seen_; }
@@ -584,7 +674,7 @@ class BridgeTransport {
     if (sscanf(to.c_str(), "%u.%u.%u.%u", &a, &b, &c, &d) == 4 && a == 10 && b < 256 && c < 256 && d < 256) { *id = b << 16 | c << 8 | d; return true; }
     return false;
   }
-  swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_, compress_;
+  swim_sim* sim_; uint32_t replica_, self_; Naming nm_; std::string label_; bool crc_, compress_; uint32_t n_nodes_; size_t push_pulls_ = 0;
   size_t control_seen_ = 0, foreign_seen_ = 0, unsupported_seen_ = 0, probes_answered_ = 0;
   std::vector<Packet> acks_;                          // ackResp / nackResp waiting for the next Poll
 };

@@ -192,12 +192,55 @@ int main() {
           CHECK(swim_step(sim, 1) == 0);
           swim_member after; CHECK(swim_view(sim, 0, 7, 21, &after) == 0 && after.state == SWIM_STATE_SUSPECT);
         }
+        // the stream side: the real node dials node-7 and pushes its state (memberlist.Join / the periodic push-pull); node 7 merges
+        // it the way mergeState does and answers with its whole member list
+        {
+          BridgeTransport tp(sim, 0, 5, Naming(), "dc1", true, true, cfg.n_nodes);
+          PushPull mine; mine.join = true;
+          auto st = [](const char* name, uint32_t inc, uint32_t state) { PushNodeState n; n.name = name; n.addr = Bytes{10, 0, 0, 1}; n.port = 8301; n.incarnation = inc; n.state = state; n.vsn = Bytes{1, 5, 2, 2, 5, 4}; return n; };
+          mine.nodes = { st("node-5", 3, SWIM_STATE_ALIVE), st("node-22", 1, SWIM_STATE_DEAD), st("node-23", 1, SWIM_STATE_LEFT), st("consul-server-9", 1, SWIM_STATE_ALIVE) };
+          Bytes reply = tp.PushPull(to_stream(mine, "dc1", true), "node-7");
+          CHECK(!reply.empty() && reply[0] == kHasLabel && tp.push_pulls_answered() == 1 && tp.foreign_names_seen() == 1);
+          std::string lab; PushPull theirs = from_stream(reply, &lab);
+          CHECK(lab == "dc1" && !theirs.join && theirs.nodes.size() == cfg.n_nodes && theirs.user_state.empty());
+          size_t dead = 0, me = 0;
+          for (const PushNodeState& n : theirs.nodes) {
+            if (n.name == "node-20" || n.name == "node-9") dead += n.state != SWIM_STATE_ALIVE;
+            if (n.name == "node-5") me += n.state == SWIM_STATE_ALIVE && n.addr == (Bytes{10, 0, 0, 5}) && n.port == 8301;
+          }
+          CHECK(dead == 2 && me == 1);                                       // what node 7 knows: the two failures, and the attached node alive
+          CHECK(swim_step(sim, 1) == 0);
+          swim_member m22, m23, m5;
+          CHECK(swim_view(sim, 0, 7, 22, &m22) == 0 && m22.state == SWIM_STATE_SUSPECT);      // a remote Dead is only a suspicion here
+          CHECK(swim_view(sim, 0, 7, 23, &m23) == 0 && m23.state == SWIM_STATE_LEFT);
+          CHECK(swim_view(sim, 0, 7, 5, &m5) == 0 && m5.state == SWIM_STATE_ALIVE && m5.incarnation == 3);
+          CHECK(tp.PushPull(to_stream(mine, "dc1", false), "node-20").empty());              // node 20 is down: the dial fails
+          bool threw = false;
+          try { tp.PushPull(Bytes{kHasLabel, 3, 'd', 'c', '1', kSuspect, 0x80}, "node-7"); } catch (const DecodeError&) { threw = true; }
+          CHECK(threw);                                                      // not a push-pull message
+        }
       }
       CHECK(swim_step(sim, 2) == 0);
       CHECK(swim_view(sim, 0, 7, 20, &mv) == 0 && mv.state != SWIM_STATE_ALIVE);
       printf("backend %s\n", swim_backend());
       swim_destroy(sim);
     }
+  }
+  {   // push-pull on the stream: header, node states back to back, the delegate's bytes behind them
+    PushPull pp; pp.join = true; pp.user_state = Bytes{9, 8, 7};
+    PushNodeState a; a.name = "node-1"; a.addr = Bytes{10, 0, 0, 1}; a.port = 8301; a.incarnation = 7; a.state = 0; a.vsn = Bytes{1, 5, 2, 2, 5, 4};
+    PushNodeState b = a; b.name = "node-2"; b.state = 3; b.meta = Bytes{1, 2};
+    pp.nodes = { a, b };
+    Bytes w = encode(pp);
+    const Bytes head{kPushPull, 0x83, 0xa5, 'N', 'o', 'd', 'e', 's', 0x02, 0xac, 'U', 's', 'e', 'r', 'S', 't', 'a', 't', 'e', 'L', 'e', 'n', 0x03, 0xa4, 'J', 'o', 'i', 'n', 0xc3, 0x87, 0xa4, 'N', 'a', 'm', 'e'};
+    CHECK(w.size() > head.size() && Bytes(w.begin(), w.begin() + head.size()) == head && Bytes(w.end() - 3, w.end()) == pp.user_state);
+    PushPull back = decode_push_pull(w.data() + 1, w.size() - 1);
+    CHECK(back.join && back.nodes.size() == 2 && back.nodes[1].name == "node-2" && back.nodes[1].state == 3 && back.nodes[1].meta == b.meta &&
+          back.nodes[0].addr == a.addr && back.nodes[0].port == 8301 && back.nodes[0].incarnation == 7 && back.nodes[0].vsn == a.vsn && back.user_state == pp.user_state);
+    for (bool z : { false, true }) { std::string lab; PushPull s2 = from_stream(to_stream(pp, "dc1", z), &lab); CHECK(lab == "dc1" && s2.nodes.size() == 2 && s2.user_state == pp.user_state); }
+    auto bad = [](const Bytes& x) { try { decode_push_pull(x.data(), x.size()); } catch (const DecodeError&) { return true; } return false; };
+    CHECK(bad(Bytes(w.begin() + 1, w.end() - 5)));                           // the delegate's bytes cut short
+    CHECK(bad(Bytes{0x81, 0xa5, 'N', 'o', 'd', 'e', 's', 0xce, 0x7f, 0xff, 0xff, 0xff}));   // two billion nodes promised, none there
   }
   {   // compress/lzw (LSB, 8-bit literals) as memberlist's compressPayload uses it: round trips, the table-full reset, hostile input
     auto rt = [](const Bytes& in) { Bytes z = lzw_encode(in); return lzw_decode(z.data(), z.size()) == in; };
