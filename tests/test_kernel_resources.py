@@ -1,0 +1,47 @@
+"""Register, scratch and occupancy budget of the tick kernels, from the compiler's own report (hipcc cross-compiles gfx950
+without a GPU).  What the design rests on — k_begin at five waves per SIMD, k_resolve at four without a spilled context, the
+others light — is easy to lose with one more statement in a handler (a context that fell out of registers made
+k_resolve twice as slow); this test says so on the CPU box, before anything is measured."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel (mangled-name fragment) -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
+BUDGET = {
+    "k_beginILi4ELb0ELb0E": (96, 16, 5),       # the bench's instantiation: fan-out <= 4, no serf events, one shard
+    "k_beginILi8ELb1ELb1E": (96, 96, 5),       # the heaviest one (fan-out 8, serf events, sharded)
+    "9k_deliverPK": (64, 0, 7),
+    "9k_resolvePK": (128, 64, 4),              # 48 bytes: the call frame of the in-place heapsort of big inboxes (cold path)
+    "8k_censusPK": (32, 0, 8),
+    "8k_finishPK": (64, 0, 8),
+    "7k_quietPK": (40, 0, 8),
+    "14k_coord_updatePK": (128, 0, 4),
+}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="no hipcc here")
+def test_tick_kernels_stay_within_their_register_budget(tmp_path):
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-c",
+                          "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "dev.o"), os.path.join(ROOT, "consul_amd", "csrc", "swim_host.hip")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rep = {}
+    cur = None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = rep.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split()[0]] = int(m.group(2))
+    for frag, (vgpr, scratch, waves) in BUDGET.items():
+        hits = {k: v for k, v in rep.items() if frag in k}
+        assert len(hits) == 1, (frag, list(hits))
+        name, r = next(iter(hits.items()))
+        assert r["VGPRs"] <= vgpr and r["ScratchSize"] <= scratch and r["Occupancy"] >= waves, (name, r, (vgpr, scratch, waves))
