@@ -421,9 +421,36 @@ class Serf {
     return h;
   }
   static std::map<uint32_t, Fired>& catalog() { static std::map<uint32_t, Fired> c; return c; }
-  // swim_poll_events -> EventCh (only the pool's watch node has its events recorded)
+  // A member other than the pool's watch node: the device records no event stream for it, so its MEMBER events are derived
+  // from its own member list, one snapshot per pump() (= per PollEvent / EventBacklog / EventChFull call): join (first seen, or
+  // back from Failed / Left), failed, leave, reap (gone from the list).  Coarser than the watch node's stream, which is exact tick
+  // by tick: a transition that happens and reverts between two calls is not seen; EventMemberUpdate and user events are not
+  // derived (an incarnation bump may be a refutation as well as a tag change).  The first snapshot is the baseline.
+  void pump_by_diff() {
+    if (state_ == SerfShutdown) return;
+    std::vector<swim_member> raw(pool_->config().n_nodes);
+    size_t n = 0;
+    check(swim_members(pool_->handle(), replica_, id_, raw.data(), raw.size(), &n), "swim_members");
+    std::map<uint32_t, std::pair<MemberStatus, uint32_t>> now;
+    for (size_t i = 0; i < n; i++) if (raw[i].status != StatusNone && raw[i].id != id_) now[raw[i].id] = { (MemberStatus)raw[i].status, raw[i].incarnation };
+    if (diff_primed_) {
+      const Duration at = pool_->Now();
+      auto emit = [&](EventType t, uint32_t id, MemberStatus st, uint32_t inc) { Event e; e.Type = t; e.At = at; e.Members.push_back(makeMember(id, st, inc)); ch_.push_back(std::move(e)); };
+      for (const auto& kv : now) {
+        auto was = seen_.find(kv.first);
+        const MemberStatus st = kv.second.first, old = was == seen_.end() ? StatusNone : was->second.first;
+        const bool up = st == StatusAlive || st == StatusLeaving, was_up = old == StatusAlive || old == StatusLeaving;
+        if (up && !was_up) emit(EventMemberJoin, kv.first, StatusAlive, kv.second.second);
+        else if (st == StatusFailed && old != StatusFailed) emit(EventMemberFailed, kv.first, StatusFailed, kv.second.second);
+        else if (st == StatusLeft && old != StatusLeft) emit(EventMemberLeave, kv.first, StatusLeft, kv.second.second);
+      }
+      for (const auto& kv : seen_) if (!now.count(kv.first)) emit(EventMemberReap, kv.first, StatusNone, kv.second.second);
+    }
+    seen_ = std::move(now); diff_primed_ = true;
+  }
+  // swim_poll_events -> EventCh (only the pool's watch node has its events recorded on the device)
   void pump() {
-    if (id_ != pool_->config().watch_node) return;
+    if (id_ != pool_->config().watch_node) { pump_by_diff(); return; }
     swim_event buf[256]; size_t n = 0;
     do {
       check(swim_poll_events(pool_->handle(), buf, 256, &n), "swim_poll_events");
@@ -449,6 +476,7 @@ class Serf {
   uint32_t id_, replica_;
   SerfState state_ = SerfAlive;
   std::deque<Event> ch_;
+  std::map<uint32_t, std::pair<MemberStatus, uint32_t>> seen_; bool diff_primed_ = false;   // pump_by_diff: the previous snapshot
 };
 
 }  // namespace serf

@@ -67,6 +67,33 @@ static void testLANReap() {
   std::printf("ok LANReap\n");
 }
 
+// every *serf.Serf on the pool has an EventCh, not only the one the device records for: a second server sees the same failure and
+// the same reap in its own channel (derived from its member list)
+static void testEventsForEveryHandle() {
+  serf::Cluster::Options o{ 16, 1, 8, 32, 8, 0, 1, 0, 512 };
+  o.ReapIntervalMs = 300; o.ReconnectTimeoutMs = 250; o.TombstoneTimeoutMs = 250;
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+  serf::Config c = serf::ConsulDefaultConfig();
+  auto watch = serf::Serf::Create(c, pool, 0), other = serf::Serf::Create(c, pool, 9), victim = serf::Serf::Create(c, pool, 5);
+  pool->Advance(Duration(500));
+  serf::Event e;
+  while (other->PollEvent(&e)) {}                   // the baseline snapshot: no events for what was there from the start
+  victim->Shutdown();
+  int failedW = 0, reapW = 0, failedO = 0, reapO = 0, joinO = 0;
+  for (int i = 0; i < 100; i++) {
+    pool->Advance(Duration(50));
+    while (watch->PollEvent(&e)) if (e.Members.size() && e.Members[0].Name == "node-5") { failedW += e.Type == serf::EventMemberFailed; reapW += e.Type == serf::EventMemberReap; }
+    while (other->PollEvent(&e)) if (e.Members.size() && e.Members[0].Name == "node-5") { EXPECT(e.Type != serf::EventMemberReap || failedO == 1); failedO += e.Type == serf::EventMemberFailed; reapO += e.Type == serf::EventMemberReap; }
+  }
+  EXPECT(failedW == 1 && reapW == 1);
+  EXPECT(failedO == 1 && reapO == 1);               // failed before reaped, once each
+  auto back = serf::Serf::Create(c, pool, 5);       // a new process of that name
+  EXPECT(back->Join({ "node-0" }, false) == 1);
+  for (int i = 0; i < 40; i++) { pool->Advance(Duration(50)); while (other->PollEvent(&e)) if (e.Members.size() && e.Members[0].Name == "node-5") joinO += e.Type == serf::EventMemberJoin; }
+  EXPECT(joinO == 1);
+  std::printf("ok EventsForEveryHandle\n");
+}
+
 static void testForceLeaveAndPrune() {
   auto pool = std::make_shared<serf::Cluster>(testTimers(), serf::Cluster::Options{ 16, 1, 8, 32, 8, 0, 2, 0, 512 });
   auto a1 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 0), a2 = serf::Serf::Create(serf::ConsulDefaultConfig(), pool, 7);
@@ -225,7 +252,7 @@ static void testCheckpointRestore() {
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
-    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates(); testCheckpointRestore();
+    testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates(); testCheckpointRestore(); testEventsForEveryHandle();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;
