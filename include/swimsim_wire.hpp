@@ -53,7 +53,8 @@ struct Writer {
   void be16(uint16_t v) { u8(uint8_t(v >> 8)); u8(uint8_t(v)); }
   void be32(uint32_t v) { be16(uint16_t(v >> 16)); be16(uint16_t(v)); }
   void be64(uint64_t v) { be32(uint32_t(v >> 32)); be32(uint32_t(v)); }
-  void map(size_t n) { if (n < 16) u8(uint8_t(0x80 | n)); else { u8(0xde); be16(uint16_t(n)); } }
+  void map(size_t n) { if (n < 16) u8(uint8_t(0x80 | n)); else if (n <= 0xFFFF) { u8(0xde); be16(uint16_t(n)); } else { u8(0xdf); be32(uint32_t(n)); } }
+  void array(size_t n) { if (n < 16) u8(uint8_t(0x90 | n)); else if (n <= 0xFFFF) { u8(0xdc); be16(uint16_t(n)); } else { u8(0xdd); be32(uint32_t(n)); } }
   void uint(uint64_t v) {
     if (v < 128) u8(uint8_t(v));
     else if (v <= 0xFF) { u8(0xcc); u8(uint8_t(v)); }
@@ -85,6 +86,14 @@ struct Reader {
     if (t == 0xde) return be16();
     if (t == 0xdf) return be32();
     throw DecodeError("expected a map");
+  }
+  size_t array() {
+    uint8_t t = u8();
+    if (t == 0xc0) return 0;                          // a nil slice
+    if ((t & 0xF0) == 0x90) return t & 0x0F;
+    if (t == 0xdc) return be16();
+    if (t == 0xdd) return be32();
+    throw DecodeError("expected an array");
   }
   uint64_t uint() {
     uint8_t t = u8();
@@ -454,6 +463,55 @@ inline PushPull decode_push_pull(const uint8_t* p, size_t n) {
   m.user_state.assign(r.p, r.p + ulen);
   return m;
 }
+// The delegate's bytes behind the node list are serf's own push-pull message (serf/messages.go messagePushPull, sent by
+// delegate.LocalState, merged by delegate.MergeRemoteState): [messagePushPullType = 2][msgpack {LTime, StatusLTimes{name: ltime},
+// LeftMembers[], EventLTime, Events[{LTime, Events[{Name, Payload}]}], QueryLTime}].  UPSTREAM-RECALL.  What the simulator can fill
+// in for a virtual member: its event clock (for LTime and EventLTime: one clock here, three in serf — DESIGN §8) and the members
+// it holds as Left; no per-member status times, no recent-event buffer, no queries.
+struct SerfUserEvents { uint64_t ltime = 0; std::vector<std::pair<std::string, Bytes>> events; };
+struct SerfPushPull { uint64_t ltime = 0, event_ltime = 0, query_ltime = 0; std::vector<std::pair<std::string, uint64_t>> status_ltimes;
+                      std::vector<std::string> left_members; std::vector<SerfUserEvents> events; };
+inline Bytes encode(const SerfPushPull& m) {
+  Bytes b{kSerfPushPull}; Writer w{b};
+  w.map(6); w.str("LTime"); w.uint(m.ltime);
+  w.str("StatusLTimes"); w.map(m.status_ltimes.size()); for (const auto& kv : m.status_ltimes) { w.str(kv.first); w.uint(kv.second); }
+  w.str("LeftMembers"); w.array(m.left_members.size()); for (const std::string& n : m.left_members) w.str(n);
+  w.str("EventLTime"); w.uint(m.event_ltime);
+  w.str("Events"); w.array(m.events.size());
+  for (const SerfUserEvents& ue : m.events) {
+    w.map(2); w.str("LTime"); w.uint(ue.ltime); w.str("Events"); w.array(ue.events.size());
+    for (const auto& ev : ue.events) { w.map(2); w.str("Name"); w.str(ev.first); w.str("Payload"); w.bytes(ev.second, true); }
+  }
+  w.str("QueryLTime"); w.uint(m.query_ltime);
+  return b;
+}
+inline SerfPushPull decode_serf_push_pull(const uint8_t* p, size_t n) {       // the bytes AFTER the messagePushPullType byte
+  Reader r(p, n); SerfPushPull m;
+  size_t k = r.map();
+  for (size_t i = 0; i < k; i++) {
+    std::string key = r.str();
+    if (key == "LTime") m.ltime = r.uint(); else if (key == "EventLTime") m.event_ltime = r.uint(); else if (key == "QueryLTime") m.query_ltime = r.uint();
+    else if (key == "StatusLTimes") { size_t c = r.map(); if (c > r.left()) throw DecodeError("truncated"); for (size_t j = 0; j < c; j++) { std::string name = r.str(); m.status_ltimes.emplace_back(std::move(name), r.uint()); } }
+    else if (key == "LeftMembers") { size_t c = r.array(); if (c > r.left()) throw DecodeError("truncated"); for (size_t j = 0; j < c; j++) m.left_members.push_back(r.str()); }
+    else if (key == "Events") {
+      size_t c = r.array(); if (c > r.left()) throw DecodeError("truncated");
+      for (size_t j = 0; j < c; j++) {
+        if (r.left() && *r.p == 0xc0) { r.u8(); continue; }                   // a nil *userEvents
+        SerfUserEvents ue; size_t f = r.map();
+        for (size_t q = 0; q < f; q++) {
+          std::string kk = r.str();
+          if (kk == "LTime") ue.ltime = r.uint();
+          else if (kk == "Events") { size_t ce = r.array(); if (ce > r.left()) throw DecodeError("truncated");
+            for (size_t x = 0; x < ce; x++) { std::string nm; Bytes pl; size_t g = r.map(); for (size_t y = 0; y < g; y++) { std::string k3 = r.str(); if (k3 == "Name") nm = r.str(); else if (k3 == "Payload") pl = r.raw(); else r.skip(); } ue.events.emplace_back(std::move(nm), std::move(pl)); } }
+          else r.skip();
+        }
+        m.events.push_back(std::move(ue));
+      }
+    }
+    else r.skip();
+  }
+  return m;
+}
 // what a peer writes on / reads from the connection: optional label header, optional compressMsg wrapper
 inline Bytes to_stream(const PushPull& m, const std::string& label, bool compress) {
   Bytes b = encode(m);
@@ -637,6 +695,13 @@ class BridgeTransport {
       if (m.status == SWIM_MEMBER_NONE) continue;                  // never heard of / erased by the reaper: not in its member list
       PushNodeState s; s.name = nm_.name_of(m.id); s.addr = nm_.addr_of(m.id); s.port = nm_.port; s.incarnation = m.incarnation; s.state = m.state; s.vsn = nm_.vsn;
       out.nodes.push_back(std::move(s));
+    }
+    // serf's delegate state behind the list: the peer's event clock and the members it holds as Left (what the simulator has)
+    {
+      SerfPushPull sp; swim_node_info ni;
+      if (swim_node_info_get(sim_, replica_, dst, &ni) == SWIM_OK) sp.ltime = sp.event_ltime = ni.event_clock;
+      for (size_t i = 0; i < got; i++) if (members[i].status == SWIM_MEMBER_LEFT) sp.left_members.push_back(nm_.name_of(members[i].id));
+      out.user_state = encode(sp);
     }
     push_pulls_++;
     return to_stream(out, label_, compress_);

@@ -40,6 +40,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 5; i++) { PushNodeState n; n.name = "node-" + std::to_string(i); n.addr = Bytes{10, 0, 0, uint8_t(i)}; n.port = 8301; n.incarnation = 1 + i; n.state = i % 4; n.vsn = Bytes{1, 5, 2, 2, 5, 4}; pp.nodes.push_back(n); }
     seeds.push_back(to_stream(pp, "dc1", false)); seeds.push_back(to_stream(pp, "", true)); }
   for (const Bytes& p : parts) seeds.push_back(p);
+  { SerfPushPull sp; sp.ltime = 9; sp.status_ltimes = { {"node-1", 4} }; sp.left_members = { "node-2" }; SerfUserEvents ue; ue.ltime = 3; ue.events = { {"e", Bytes{1}} }; sp.events = { ue };
+    Bytes w = encode(sp); seeds.push_back(Bytes(w.begin() + 1, w.end())); }
   long threw = 0, ok = 0;
   for (long it = 0; it < iters; it++) {
     Bytes in;
@@ -52,6 +54,7 @@ int main(int argc, char** argv) {
     } catch (const DecodeError&) { threw++; } catch (const std::length_error&) { threw++; }
     try { (void)from_stream(in, nullptr); ok++; } catch (const DecodeError&) { threw++; }
     try { (void)lzw_decode(in.data(), in.size(), 1 << 20); ok++; } catch (const DecodeError&) { threw++; }
+    try { (void)decode_serf_push_pull(in.data(), in.size()); ok++; } catch (const DecodeError&) { threw++; }
   }
   // and the seeds themselves still decode
   size_t control = 0, foreign = 0;

@@ -202,7 +202,10 @@ int main() {
           Bytes reply = tp.PushPull(to_stream(mine, "dc1", true), "node-7");
           CHECK(!reply.empty() && reply[0] == kHasLabel && tp.push_pulls_answered() == 1 && tp.foreign_names_seen() == 1);
           std::string lab; PushPull theirs = from_stream(reply, &lab);
-          CHECK(lab == "dc1" && !theirs.join && theirs.nodes.size() == cfg.n_nodes && theirs.user_state.empty());
+          CHECK(lab == "dc1" && !theirs.join && theirs.nodes.size() == cfg.n_nodes);
+          CHECK(!theirs.user_state.empty() && theirs.user_state[0] == kSerfPushPull);          // serf's delegate state: event clock, left members
+          SerfPushPull sst = decode_serf_push_pull(theirs.user_state.data() + 1, theirs.user_state.size() - 1);
+          CHECK(sst.ltime == sst.event_ltime && sst.events.empty() && sst.status_ltimes.empty() && sst.left_members.empty());
           size_t dead = 0, me = 0;
           for (const PushNodeState& n : theirs.nodes) {
             if (n.name == "node-20" || n.name == "node-9") dead += n.state != SWIM_STATE_ALIVE;
@@ -241,6 +244,19 @@ int main() {
     auto bad = [](const Bytes& x) { try { decode_push_pull(x.data(), x.size()); } catch (const DecodeError&) { return true; } return false; };
     CHECK(bad(Bytes(w.begin() + 1, w.end() - 5)));                           // the delegate's bytes cut short
     CHECK(bad(Bytes{0x81, 0xa5, 'N', 'o', 'd', 'e', 's', 0xce, 0x7f, 0xff, 0xff, 0xff}));   // two billion nodes promised, none there
+  }
+  {   // serf's own push-pull message, the bytes memberlist carries as "user state"
+    SerfPushPull sp; sp.ltime = 41; sp.event_ltime = 17; sp.query_ltime = 3; sp.status_ltimes = { {"node-1", 40}, {"node-2", 12} }; sp.left_members = { "node-9" };
+    SerfUserEvents ue; ue.ltime = 16; ue.events = { {"deploy", Bytes{1, 2, 3}}, {"x", Bytes{}} }; sp.events = { ue };
+    Bytes w = encode(sp);
+    const Bytes head{kSerfPushPull, 0x86, 0xa5, 'L', 'T', 'i', 'm', 'e', 41, 0xac, 'S', 't', 'a', 't', 'u', 's', 'L', 'T', 'i', 'm', 'e', 's', 0x82, 0xa6, 'n', 'o', 'd', 'e', '-', '1', 40};
+    CHECK(w.size() > head.size() && Bytes(w.begin(), w.begin() + head.size()) == head);
+    SerfPushPull back = decode_serf_push_pull(w.data() + 1, w.size() - 1);
+    CHECK(back.ltime == 41 && back.event_ltime == 17 && back.query_ltime == 3 && back.status_ltimes == sp.status_ltimes && back.left_members == sp.left_members);
+    CHECK(back.events.size() == 1 && back.events[0].ltime == 16 && back.events[0].events == ue.events);
+    Bytes nil_slices{0x83, 0xa5, 'L', 'T', 'i', 'm', 'e', 5, 0xab, 'L', 'e', 'f', 't', 'M', 'e', 'm', 'b', 'e', 'r', 's', 0xc0, 0xa6, 'E', 'v', 'e', 'n', 't', 's', 0x91, 0xc0};
+    SerfPushPull z = decode_serf_push_pull(nil_slices.data(), nil_slices.size());               // Go's nil slices and nil pointers
+    CHECK(z.ltime == 5 && z.left_members.empty() && z.events.empty());
   }
   {   // compress/lzw (LSB, 8-bit literals) as memberlist's compressPayload uses it: round trips, the table-full reset, hostile input
     auto rt = [](const Bytes& in) { Bytes z = lzw_encode(in); return lzw_decode(z.data(), z.size()) == in; };
