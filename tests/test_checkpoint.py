@@ -93,3 +93,46 @@ def test_refusals(oracle, tmp_path):
         a.save(path)                                    # inside a tick
     assert e.value.rc == abi.ESTATE
     a.close(); other.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_schedules_resume_identically(oracle, tmp_path, seed):
+    """random configuration, random stimulus before and after a checkpoint taken at a random tick"""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([64, 128, 256]))
+    kw = dict(n_nodes=n, n_replicas=int(rng.integers(1, 3)), n_initial=int(n - rng.integers(0, 9)), seed=int(rng.integers(1, 1 << 30)),
+              subject_cap=16, view_cap=int(rng.choice([8, 24])), queue_cap=int(rng.choice([4, 8])), inbox_cap=64, event_queue_cap=8, event_buffer=64,
+              flags=abi.F_DEFAULT | abi.F_SERF_EVENTS | (abi.F_COORDINATES if rng.integers(2) else 0),
+              fold_interval_ms=int(rng.choice([0, 5000])), reap_interval_ms=int(rng.choice([0, 3000])), reconnect_timeout_ms=8000, tombstone_timeout_ms=8000)
+    reps = kw["n_replicas"]
+
+    def schedule(k):
+        out = []
+        for _ in range(k):
+            out.append((int(rng.integers(5, 60)), int(rng.integers(7)), int(rng.integers(reps)), int(rng.integers(kw["n_initial"])), int(rng.integers(1 << 20))))
+        return out
+
+    def play(s, sched):
+        for ticks, op, r, x, ev in sched:
+            s.step(ticks)
+            try:
+                if op == 0: s.kill(r, [x])
+                elif op == 1: s.revive(r, [x])
+                elif op == 2: s.leave(r, [x])
+                elif op == 3: s.user_event(r, x, ev)
+                elif op == 4: s.set_loss(0.0 if ev & 1 else 0.05)
+                elif op == 5: s.join(r, [x], via=(x + 1) % kw["n_initial"])
+                else: s.update(r, [x])
+            except SwimError:
+                pass                                     # e.g. an event from a node that is down: the same refusal on both runs
+    before, after = schedule(int(rng.integers(3, 9))), schedule(int(rng.integers(3, 9)))
+    path = str(tmp_path / "r.ck")
+    a = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    play(a, before); a.save(path); d0 = a.digest(); play(a, after); a.step(50); a.sync()
+    b = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    b.load(path)
+    assert b.digest() == d0
+    play(b, after); b.step(50); b.sync()
+    assert a.digest() == b.digest() and a.stats() == b.stats() and a.poll_events() == b.poll_events()
+    a.close(); b.close()
