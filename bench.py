@@ -273,6 +273,7 @@ def main():
                     help="N = 1: spread the clusters over this many library handles, one stream each (their kernels overlap); "
                          "1 = one handle, one launch per kernel and tick for all clusters")
     ap.add_argument("--subject-cap", type=int, default=4)
+    ap.add_argument("--mass-rows", type=int, default=0, help="rows of the dense pair store per cluster (swim_config.mass_rows): the victim's views in 12-byte pairs")
     ap.add_argument("--main-only", action="store_true", help="only the timed region (profiling runs): no roofline pass, no extra legs, no CPU baseline")
     ap.add_argument("--no-detection", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
@@ -330,7 +331,7 @@ def main():
     # gossip block scales with queue_cap) and 24 inbox slots (in-degree is Poisson(k)) are ample, and
     # an overflow would raise SWIM_EOVERFLOW instead of passing silently
     cfg_kw = dict(n_nodes=args.nodes, n_replicas=reps, seed=args.seed, subject_cap=args.subject_cap,
-                  gossip_nodes=args.fanout, queue_cap=4,
+                  gossip_nodes=args.fanout, queue_cap=4, mass_rows=args.mass_rows,
                   view_cap=4,        # one failure per cluster: an observer never holds more than a couple of explicit views
 
                   # records from other shards arrive unfiltered (a shard cannot see a remote receiver's view), so a

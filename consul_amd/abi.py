@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NONE = 0xFFFFFFFF
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE, EIO = 0, -22, -12, -19, -34, -75, -71, -5
@@ -36,7 +36,7 @@ class Config(C.Structure):
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
-        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
+        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "mass_rows", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
         "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device", "rtt_scale_us", "rtt_height_us", "rtt_jitter_us")] + [("seed", u64)]
 
@@ -102,7 +102,7 @@ class Stats(C.Structure):
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
                 ("view_drops", u64), ("view_evictions", u64), ("intents_applied", u64), ("reaped", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64),
-                ("coord_updates", u64), ("coord_resets", u64)]
+                ("coord_updates", u64), ("coord_resets", u64), ("inbox_peak", u64)]
 
 
 class XchgHandle(C.Structure):

@@ -46,6 +46,7 @@ enum {
 #define SW_ERR_CARRY_OVF 0x40u
 #define SW_ERR_XCHG_TIMEOUT 0x100u  /* swim_xchg_step: a source shard's flag did not arrive in time (reported as SWIM_ESTATE) */
 #define SW_ERR_VIEW_CORRUPT 0x80u   /* an observer's view table lost its free slot: cannot happen (load <= (view_cap+1)/VT <= 1/2) */
+#define SW_ERR_MASS_RANGE 0x200u    /* a pair of the dense store would need an incarnation >= 2^26 or a tick >= 2^20 */
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
 enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
@@ -62,14 +63,17 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 //   bit 21     the base row's view of it is not alive@1 (read bk[])
 //   bit 20     alone: started by swim_inject_join, its join push-pull has not gone through (yet) — it knows nobody, so
 //              the simulator does not probe / gossip on its behalf; peers that hear of it treat it like anybody
-//   bits 19-0  watch slot + 1 (census / trace), 0 = not watched
+//   bit 19     mass: the subject owns a ROW of the dense pair store (mrow[]): every local observer's view of it lives at
+//              [row][observer] of three 4-byte planes (12 bytes per pair) instead of in the observers' hash tables
+//   bits 18-0  watch slot + 1 (census / trace), 0 = not watched
 #define NW_DEAD 0x80000000u
 #define NW_ATTACHED 0x00800000u
 #define NW_SUBJECT 0x00400000u
 #define NW_BASEMOD 0x00200000u
 #define NW_ALONE 0x00100000u
 #define NW_INERT (NW_DEAD | NW_ATTACHED | NW_ALONE) /* the simulator takes no action on behalf of this node */
-#define NW_SLOT_MASK 0xFFFFFu
+#define NW_MASS 0x00080000u
+#define NW_SLOT_MASK 0x7FFFFu
 #define NW_PART(w) (((w) >> 24) & 0x7Fu)
 #define NW_SLOT(w) (((w) & NW_SLOT_MASK) - 1u)     /* 0xFFFFFFFF when none */
 #define NW_HAS_SLOT(w) (((w) & NW_SLOT_MASK) != 0u)
@@ -84,6 +88,30 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 //   vc = {2nd, 3rd, 4th confirmer, -}: only touched while a suspicion is being confirmed
 #define VT_EMPTY 0xFFFFFFFFu
 #define FOLD_POISON 0xFFFFFFFFu
+
+// ---- the dense pair store for mass events (swim_config.mass_rows) -------------------------------------------
+// A failure of thousands of nodes at once (BASELINE config #4: 5 % cut off; config #5: 10 %/s churn) makes every observer hold
+// an explicit view of every victim: 524 288 x 26 214 pairs on one GPU.  At the 64 bytes a pair costs in the hash tables that
+// is 880 GB; here it is 12: a subject named in a stimulus call owns a ROW, and pair (row, observer) is three words in three
+// planes [R][M][nloc] (observer-contiguous, so the lanes of a wave that look at the same subject read one 256-byte run):
+//   A  bits 1-0 state, 3-2 confirmations, 4 leaving, 5 erased by serf's reaper / a prune, 31-6 incarnation (26 bits)
+//      0 = the observer holds no explicit view of the subject (the base row's); an explicit view has incarnation >= 1
+//   B  bits 19-0 state-change TICK (ms / quantum), 31-20 first accuser, low 12 bits
+//   C  bits 9-0 first accuser, high 10 bits; 31-10 second accuser (the first confirmer)
+// Identities of accusers matter only while confirmations < k (suspicion.Confirm returns early after that), so k <= 2 needs two
+// (memberlist's LAN and Local presets; WAN's k = 4 keeps using the hash tables).  Which subject sits in which row — or in no
+// row at all — never shows in any result: digests, censuses and member lists are keyed by (observer, subject).
+// Ranges (checked: SW_ERR_MASS_RANGE): incarnation < 2^26, tick < 2^20, node ids < 2^22.
+#define SW_MASS_SLOT 0x80000000u        /* View::free_slot / slot of a pair of the dense store: this flag | row */
+#define MA_STATE(a) ((a) & 3u)
+#define MA_NCONF(a) (((a) >> 2) & 3u)
+#define MA_LEAVING(a) (((a) >> 4) & 1u)
+#define MA_ERASED(a) (((a) >> 5) & 1u)
+#define MA_INC(a) ((a) >> 6)
+#define MA_KEY(a) ((MA_INC(a) << 2) | MA_STATE(a))
+#define MB_TICK(b) ((b) & 0xFFFFFu)
+#define M_CONF0(b, c) (((b) >> 20) | (((c) & 0x3FFu) << 12))
+#define M_CONF1(c) ((c) >> 10)
 
 struct SwDev {
   // dimensions
@@ -142,6 +170,15 @@ struct SwDev {
   // the others; rs_order[t % P][j] = the tile workgroup j takes in such a tick, those tiles first (host-built at create)
   uint32_t* rs_order; uint32_t rs_T;
   uint32_t* dl_blk;      // [NL/256] lower bound of the block's vdl over the lanes the simulator acts for
+  // the dense pair store (see above): M rows per replica; mrow[g] = row of subject g = replica*N + node (NONE: none),
+  // mrow_subj[r*M + row] = node (NONE: the row is free), m_free[r*M ..] = stack of free rows, m_nfree[r] = its height
+  uint32_t M, nbl;                       // nbl = 256-observer blocks per replica on this shard
+  uint32_t *mrow, *mrow_subj, *m_free, *m_nfree;
+  uint32_t *mA, *mB, *mC;                // [R][M][nloc]
+  uint32_t* m_tile_dl;                   // [R][M][nbl] lower bound of the suspicion deadlines of a row's 256-observer tile (acting observers)
+  uint32_t* m_row_dl;                    // [R*M] ... of the whole row
+  uint32_t* mcnt;                        // [NL] pairs of the dense store this observer holds (present)
+  uint32_t* peak;                        // [1] the largest inbox any node has had in one tick (swim_stats_t.inbox_peak)
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
   uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)
   // dynamic membership (n_initial < n_nodes): estNumNodes() of lane l = base_known[r] + vnk[l] feeds retransmitLimit and

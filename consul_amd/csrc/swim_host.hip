@@ -127,6 +127,10 @@ int validate(const swim_config* c) {
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
   if ((c->flags & SWIM_F_COORDINATES) && (c->n_shards != 1 || c->rtt_scale_us > 10000000u || c->rtt_height_us > 1000000u || c->rtt_jitter_us > 1000000u)) return SWIM_EINVAL;
+  if (c->mass_rows) {   // the dense pair store: two accuser names per pair, incarnation 26 bits, ids 22 bits, no per-timer n, no reaper
+    if (c->suspicion_mult > 4 || (c->n_initial && c->n_initial != c->n_nodes) || c->reap_interval_ms) return SWIM_EINVAL;
+    if (c->n_nodes > (1u << 22) || c->mass_rows > c->n_nodes) return SWIM_ERANGE;
+  }
   return SWIM_OK;
 }
 uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -414,6 +418,18 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
   DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+  D.M = cfg->mass_rows; D.nbl = cdiv(D.nloc, SW_BLOCK);
+  if (D.M) {   // the dense pair store (swim_device.h): 12 bytes per (row, observer)
+    const size_t RM = (size_t)D.R * D.M, pairs = RM * D.nloc;
+    if (RM >= 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
+    DALLOC(s, D.mrow, NT); DALLOC(s, D.mrow_subj, RM); DALLOC(s, D.m_free, RM); DALLOC(s, D.m_nfree, D.R);
+    DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
+    DALLOC(s, D.m_tile_dl, RM * D.nbl); DALLOC(s, D.m_row_dl, RM); DALLOC(s, D.mcnt, NL);
+    HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
+    HIPCK(s, hipMemsetAsync(D.mB, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mC, 0, pairs * 4, s->stream));
+    HIPCK(s, hipMemsetAsync(D.m_tile_dl, 0xFF, RM * D.nbl * 4, s->stream));
+  }
+  DALLOC(s, D.peak, 1); HIPCK(s, hipMemsetAsync(D.peak, 0, 4, s->stream));
 #ifndef SW_RESOLVE_PLAIN_ORDER
   if (D.CH >= 64 && NB > 4 * SW_RTILE) {        // the longest-job-first order of k_resolve's tiles, per probe phase (swim_device.h)
     const uint32_t T = (uint32_t)cdiv(NB, SW_RTILE);
@@ -538,7 +554,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
-  s->scratch_bytes = std::max<size_t>(1 << 20, std::min<size_t>((size_t)D.VT * 32 + 64, (size_t)1 << 26));   // an observer's views fit (swim_members)
+  s->scratch_bytes = std::max<size_t>(1 << 20, std::min<size_t>(((size_t)D.VT + D.M) * 32 + 64, (size_t)1 << 26));   // an observer's views fit (swim_members)
   { uint8_t* p; DALLOC(s, p, s->scratch_bytes); s->d_scratch = (uint32_t*)p; }
   DALLOC(s, s->d_fresh, 1024);
   if (D.n_shards > 1) {   // what all the other shards together may address to this one in a tick (their lists are sized like ours)
@@ -590,6 +606,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   hipLaunchKernelGGL(k_init_base, dim3(cdiv(NT, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
   if (D.dyn) for (uint32_t r = 0; r < D.R; r++) hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, r);
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv(NS, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
+  if (D.M) hipLaunchKernelGGL(k_mass_init, dim3(cdiv((size_t)D.R * D.M, 256)), dim3(256), 0, st, (const SwDev*)s->d_D);
   HIPCK(s, hipStreamSynchronize(st));
   HIPCK(s, hipGetLastError());
   if (D.coord) { HIPCK(s, hipMemsetAsync(D.c_cnt, 0, 4, st)); hipLaunchKernelGGL(k_coord_init, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D); HIPCK(s, hipStreamSynchronize(st)); }
@@ -625,8 +642,10 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     const size_t NL = (size_t)D.nloc * D.R, NT = (size_t)D.N * D.R;
     (void)hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st); (void)hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st);
     hipLaunchKernelGGL(k_fold_scan, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    if (D.M) hipLaunchKernelGGL(k_fold_scan_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
+  if (D.M) hipLaunchKernelGGL(k_expire_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's suspicion timers
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
@@ -654,6 +673,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   if (fold) {
     hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    if (D.M) hipLaunchKernelGGL(k_fold_apply_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
@@ -685,7 +705,7 @@ static int check_device_errors(swim_sim* s) {
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
              e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
              e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "",
-             e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : (e & SW_ERR_VIEW_CORRUPT ? " view-table(corrupt)" : ""));
+             e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : (e & SW_ERR_VIEW_CORRUPT ? " view-table(corrupt)" : (e & SW_ERR_MASS_RANGE ? " dense-store-field-range" : "")));
     return SWIM_EOVERFLOW;
   }
   return SWIM_OK;
@@ -945,6 +965,7 @@ static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n
     const uint32_t c = (uint32_t)std::min(chunk, n - off);
     HIPCK(s, hipMemcpyAsync(s->d_scratch, ids + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
     watch_ids(s, r, s->d_scratch, c);
+    if (s->D.M) hipLaunchKernelGGL(k_mass_alloc, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c);
     hipLaunchKernelGGL(k_inject, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, op, r, (const uint32_t*)s->d_scratch, c);
     HIPCK(s, hipStreamSynchronize(s->stream));          // ids is caller memory; the scratch buffer is reused
   }
@@ -980,6 +1001,7 @@ extern "C" int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, si
   for (size_t off = 0; off < n; off += chunk) {
     const uint32_t c = (uint32_t)std::min(chunk, n - off);
     HIPCK(s, hipMemcpyAsync(s->d_scratch, ids + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
+    if (s->D.M) hipLaunchKernelGGL(k_mass_alloc, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c);
     hipLaunchKernelGGL(k_inject_join, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c, via);
     HIPCK(s, hipStreamSynchronize(s->stream));
   }
@@ -1012,6 +1034,20 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
     hipLaunchKernelGGL(k_set_partition, dim3(cdiv(c, 256)), dim3(256), 0, s->stream, (const SwDev*)s->d_D, r, (const uint8_t*)s->d_scratch, (uint32_t)off, c);
     HIPCK(s, hipStreamSynchronize(s->stream));
   }
+  if (s->D.M) {   // the dense store: the nodes outside the largest group are about to be suspected by everybody in it
+    uint32_t cnt[128] = { 0 }, big = 0;
+    for (uint32_t i = 0; i < s->D.N; i++) cnt[g[i]]++;
+    for (uint32_t k = 1; k < 128; k++) if (cnt[k] > cnt[big]) big = k;
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < s->D.N; i++) if (g[i] != big) ids.push_back(i);
+    const size_t chunk = s->scratch_bytes / 4;
+    for (size_t off = 0; off < ids.size(); off += chunk) {
+      const uint32_t c = (uint32_t)std::min(chunk, ids.size() - off);
+      HIPCK(s, hipMemcpyAsync(s->d_scratch, ids.data() + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
+      hipLaunchKernelGGL(k_mass_alloc, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c);
+      HIPCK(s, hipStreamSynchronize(s->stream));
+    }
+  }
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
@@ -1029,7 +1065,7 @@ extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
 extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
-  if (r >= s->D.R || origin >= s->D.N) return SWIM_ERANGE;
+  if (r >= s->D.R || origin >= s->D.N || id > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;   // bits 31-30 mark serf's intents, never a user event
   touched(s);
   hipLaunchKernelGGL(k_user_event, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, origin, id, s->d_scratch);
   uint32_t v = SWIM_NONE;
@@ -1057,7 +1093,7 @@ static bool is_local(const swim_sim* s, uint32_t i) { return i >= s->D.i0 && i <
 struct HostView { uint32_t key, since, w; };
 static int gather_views(swim_sim* s, uint32_t r, uint32_t o, std::vector<std::pair<uint32_t, HostView>>& out) {
   const SwDev& D = s->D;
-  const uint32_t cap = (uint32_t)std::min<size_t>(D.VT, (s->scratch_bytes - 16) / 32);
+  const uint32_t cap = (uint32_t)std::min<size_t>((size_t)D.VT + D.M, (s->scratch_bytes - 16) / 32);
   hipLaunchKernelGGL(k_gather_views, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, o, s->d_scratch, cap);
   std::vector<uint32_t> w(4 + (size_t)cap * 8);
   int rc = d2h(s, w.data(), (const uint32_t*)s->d_scratch, w.size());
@@ -1207,6 +1243,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
   out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->intents_applied = v[ST_INTENTS]; out->reaped = v[ST_REAPED]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   out->coord_updates = v[ST_COORD_UPD]; out->coord_resets = v[ST_COORD_RESET];
+  { uint32_t pk = 0; if ((rc = d2h(s, &pk, (const uint32_t*)s->D.peak, 1))) return rc; out->inbox_peak = pk; }
   return SWIM_OK;
 }
 
@@ -1375,6 +1412,7 @@ extern "C" int swim_state_digest(swim_sim* s, uint64_t* out) {
   const size_t NL = (size_t)D.R * D.nloc;
   hipLaunchKernelGGL(k_digest_nodes, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
   hipLaunchKernelGGL(k_digest_views, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
+  if (D.M) hipLaunchKernelGGL(k_digest_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, acc);
   unsigned long long v[64 * 8]; int rc = d2h(s, v, (const unsigned long long*)acc, 64 * 8);
   if (rc) return rc;
   uint64_t d = 0;
@@ -1433,7 +1471,7 @@ extern "C" int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint
   touched(s);
   std::vector<swim_edge> recs(m, m + n);
   for (auto& e : recs) {
-    if ((e.meta >> 30) != SWIM_MSG_USER && e.subject >= s->D.N) return SWIM_ERANGE;
+    if ((e.meta >> 30) != SWIM_MSG_USER ? e.subject >= s->D.N : e.subject > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;   // (a user event never carries intent bits)
     e.dst = r * s->D.N + dst;
   }
   uint8_t* drec = (uint8_t*)s->d_scratch;

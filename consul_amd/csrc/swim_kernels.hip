@@ -75,6 +75,31 @@ __device__ __forceinline__ uint32_t vt_probe(DevRef D, size_t l, uint32_t x, uin
 __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint4& e, uint32_t& free_slot) {
   return vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * ((size_t)D.R * D.nloc) + l], e, free_slot);
 }
+// ---- the dense pair store (swim_device.h): pair (row of the subject, observer) --------------------------------------------
+__device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) { return ((size_t)r * D.M + row) * D.nloc + k; }
+// a pair as a view-table entry {subject, inc<<2|state, state-change ms, w} (w as in vt) + the second accuser
+__device__ __forceinline__ uint4 m_unpack(DevRef D, uint32_t x, uint32_t a, uint32_t b, uint32_t c, uint32_t& conf1) {
+  conf1 = M_CONF1(c);
+  const uint32_t w = MA_STATE(a) == SWIM_STATE_SUSPECT ? vw_pack(M_CONF0(b, c), MA_NCONF(a), MA_LEAVING(a)) : (MA_ERASED(a) | (MA_LEAVING(a) << 1));
+  return make_uint4(x, MA_KEY(a), MB_TICK(b) * D.quantum_ms, w);
+}
+__device__ __forceinline__ void m_store(DevRef D, size_t idx, uint4 e, uint32_t conf1) {
+  const uint32_t st = SW_KST(e.y), inc = SW_KINC(e.y), tick = e.z / D.quantum_ms;
+  uint32_t nconf = 0, leaving, erased = 0, conf0 = 0;
+  if (st == SWIM_STATE_SUSPECT) { nconf = vw_nconf(e.w); leaving = vw_leaving(e.w); conf0 = vw_conf0(e.w); if (!nconf) conf1 = 0; }
+  else { erased = e.w & 1u; leaving = (e.w >> 1) & 1u; conf1 = 0; }
+  if (inc >= (1u << 26) || tick >= (1u << 20) || nconf > 3u) atomicOr(D.err, SW_ERR_MASS_RANGE);
+  D.mA[idx] = st | (nconf << 2) | (leaving << 4) | (erased << 5) | (inc << 6);
+  D.mB[idx] = (tick & 0xFFFFFu) | ((conf0 & 0xFFFu) << 20);
+  D.mC[idx] = ((conf0 >> 12) & 0x3FFu) | (conf1 << 10);
+}
+// a suspicion timer of pair (row, lane k of replica r) was (re)armed: keep the row's and the tile's bounds (k_expire_mass)
+__device__ __forceinline__ void m_arm(DevRef D, uint32_t r, uint32_t row, uint32_t k, uint32_t dl) {
+  uint32_t* t = &D.m_tile_dl[((size_t)r * D.M + row) * D.nbl + k / SW_BLOCK];
+  if (dl < *t) atomicMin(t, dl);
+  uint32_t* rw = &D.m_row_dl[(size_t)r * D.M + row];
+  if (dl < *rw) atomicMin(rw, dl);
+}
 // what the base row says about the node whose word is w
 __device__ __forceinline__ uint32_t base_key_of(DevRef D, uint32_t r, uint32_t x, uint32_t w) {
   return (w & NW_BASEMOD) ? D.bk[(size_t)r * D.N + x] : SW_BASE_KEY;
@@ -130,7 +155,11 @@ __device__ void vt_erase(DevRef D, size_t l, uint32_t i) {
 // AND this observer holds an explicit view
 __device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t x, uint32_t w, uint32_t* since) {
   *since = 0;
-  if (w & NW_SUBJECT) {
+  if (w & NW_MASS) {
+    const size_t idx = m_idx(D, r, D.mrow[(size_t)r * D.N + x], k);
+    const uint32_t a = D.mA[idx];
+    if (a) { if (MA_STATE(a) == SWIM_STATE_DEAD) *since = MB_TICK(D.mB[idx]) * D.quantum_ms; return MA_KEY(a); }   // (callers look at `since` of Dead views only)
+  } else if (w & NW_SUBJECT) {
     uint4 e; uint32_t fs;
     if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) { *since = e.z; return e.y; }
   }
@@ -621,6 +650,24 @@ __device__ __forceinline__ bool noop_given_view(DevRef D, uint32_t key, uint32_t
 // subject in the receiver's table when the caller fetched it already (have_first)
 __device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr, uint32_t ws, uint4 e, bool have_first, uint4 first) {
   const size_t NL = (size_t)D.R * D.nloc;
+  if (ws & NW_MASS) {                              // the pair of the dense store: one 4-byte read decides all but suspect-on-suspect
+    const size_t idx = m_idx(D, r, D.mrow[(size_t)r * D.N + e.x], (uint32_t)(lr - (size_t)r * D.nloc));
+    const uint32_t a = have_first ? first.x : D.mA[idx];
+    if (a) {
+      const uint32_t type = m_type(e.w), vinc = MA_INC(a), st = MA_STATE(a);
+      if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
+      if (e.y != vinc) return e.y < vinc;
+      if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
+      if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
+        const uint32_t nc = MA_NCONF(a);
+        if (nc >= D.susp_k) return true;
+        const uint32_t b = D.mB[idx], c = D.mC[idx];
+        return M_CONF0(b, c) == e.z || (nc >= 1 && M_CONF1(c) == e.z);
+      }
+      return false;
+    }
+    return noop_given_view(D, base_key_of(D, r, e.x, ws), 0, 0, e);
+  }
   if (ws & NW_SUBJECT) {
     uint4 v; uint32_t fs;
     if (!have_first) first = D.vt[(size_t)vt_home(D, e.x) * NL + lr];
@@ -754,11 +801,12 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       // case — every lane gossips about the same subject — that is the entry itself); rumours beyond the first take
       // the one-at-a-time path.
       if (filter) {
-        uint4 va0[KMAX]; const uint32_t h0 = (ws0 & NW_SUBJECT) ? vt_home(D, e0.x) : 0;
+        uint4 va0[KMAX]; const bool m0 = (ws0 & NW_MASS) != 0;                 // rumour 0's subject owns a row of the dense store: 4 bytes per receiver
+        const uint32_t h0 = (ws0 & NW_SUBJECT) ? vt_home(D, e0.x) : 0, row0 = m0 ? D.mrow[(size_t)r * D.N + e0.x] : 0;
 #pragma unroll
         for (int p = 0; p < KMAX; p++) {
-          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && (ws0 & NW_SUBJECT);
-          va0[p] = need ? D.vt[(size_t)h0 * NL + (size_t)r * D.nloc + (peers[p] - D.i0)] : make_uint4(0, 0, 0, 0);
+          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && (ws0 & (NW_SUBJECT | NW_MASS));
+          va0[p] = !need ? make_uint4(0, 0, 0, 0) : m0 ? make_uint4(D.mA[m_idx(D, r, row0, peers[p] - D.i0)], 0, 0, 0) : D.vt[(size_t)h0 * NL + (size_t)r * D.nloc + (peers[p] - D.i0)];
         }
 #pragma unroll
         for (int p = 0; p < KMAX; p++) {
@@ -908,6 +956,43 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
     }
     wave_append_sharded(D, want, sh, rec);
     c_edges += want; c_remote += want && sh != D.rank;
+  }
+  // ...and the owner's pairs of the dense store.  One exchange at a time, the whole wave on it: 64 rows per step (a lane
+  // walking its 26 214 rows alone would hold the launch for tens of milliseconds)
+  if (D.M) {
+    uint64_t todo = __ballot(on && D.mcnt[lo] != 0);
+    const uint32_t lane = sw_lane();
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1; todo &= todo - 1;
+      const uint32_t r_ = __shfl(r, leader), own_ = __shfl(owner, leader), dst_ = __shfl(dst, leader), sh_ = __shfl(sh, leader);
+      uint32_t left_ = __shfl(on ? D.mcnt[lo] : 0u, leader);
+      const bool filt_ = (D.flags & SWIM_F_FILTER_NOOP) && sh_ == D.rank;
+      uint64_t hit_dst = 0, hit_self = 0;
+      for (uint32_t row0 = 0; row0 < D.M && left_; row0 += 64) {
+        const uint32_t row = row0 + lane;
+        bool present = false, want = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t x = NONE;
+        if (row < D.M) {
+          x = D.mrow_subj[(size_t)r_ * D.M + row];
+          if (x != NONE) {
+            const uint32_t a = D.mA[m_idx(D, r_, row, own_ - D.i0)];
+            if (a) {
+              present = true; want = true;
+              const uint32_t st = MA_STATE(a); uint32_t type, from = 0;
+              if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
+              else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
+              else { type = SWIM_MSG_SUSPECT; from = dst_; }
+              if (filt_ && x != dst_ && noop_at_receiver(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
+              rec = mk_edge(D, r_, dst_, x, MA_INC(a), type, from);
+            }
+          }
+        }
+        left_ -= (uint32_t)__popcll(__ballot(present));
+        hit_dst |= __ballot(present && x == dst_); hit_self |= __ballot(present && x == own_);
+        wave_append(D, sh_, want, rec);
+        c_edges += want; c_remote += want && sh_ != D.rank;
+      }
+      if (lane == leader) { saw_dst |= hit_dst != 0; saw_self |= hit_self != 0; }
+    }
   }
   // ...and the owner's view of ITSELF travels when the base row says something else about it (a node that has just
   // joined: nobody has heard of it; a node that came back after it was folded as dead)
@@ -1519,11 +1604,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_watch_seed(const SwDev* __restrict
   SW_DEV_BIND
   if (blockIdx.y >= fresh[0] || blockIdx.y >= 1023) return;
   const uint32_t sidx = fresh[1 + blockIdx.y], r = sidx / D.S, x = D.subj_node[sidx];
-  if (!(D.nw[(size_t)r * D.N + x] & NW_SUBJECT)) return;
+  const uint32_t wx = D.nw[(size_t)r * D.N + x];
+  if (!(wx & (NW_SUBJECT | NW_MASS))) return;
   uint32_t m = 0;
+  const uint32_t row = (wx & NW_MASS) ? D.mrow[(size_t)r * D.N + x] : 0;
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     uint4 e; uint32_t fs;
-    if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) m = SW_KINC(e.y) > m ? SW_KINC(e.y) : m;
+    if (wx & NW_MASS) { const uint32_t a = D.mA[m_idx(D, r, row, k)]; m = MA_INC(a) > m ? MA_INC(a) : m; }
+    else if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) m = SW_KINC(e.y) > m ? SW_KINC(e.y) : m;
   }
   for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_down(m, off); m = v > m ? v : m; }
   if (sw_lane() == 0 && m) atomicMax(&D.slot_maxinc[sidx], m);
@@ -1624,7 +1712,12 @@ struct NodeCtxT {
   // The inbox is applied in subject order, so consecutive messages mostly concern the same subject: its view is looked up
   // once, edited in registers across those messages and written back when the subject changes (or at store()).
   View cv; uint32_t cv_x = NONE; bool cv_dirty = false;
-  __device__ __forceinline__ void flush_view() { if (cv_dirty) { D.vt[(size_t)cv.slot * NL + l] = cv.e; cv_dirty = false; } }
+  __device__ __forceinline__ static bool v_mass(const View& v) { return (v.free_slot & SW_MASS_SLOT) && v.free_slot != NONE; }
+  __device__ __forceinline__ void put(const View& v) {
+    if (v_mass(v)) m_store(D, m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k), v.e, v.c.x);
+    else D.vt[(size_t)v.slot * NL + l] = v.e;
+  }
+  __device__ __forceinline__ void flush_view() { if (cv_dirty) { put(cv); cv_dirty = false; } }
   // (handlers work on a by-value copy and hand it back: a reference into the context would pin the cache in scratch memory)
   __device__ __forceinline__ View take_view(uint32_t x) {
     if (cv_x == x) return cv;
@@ -1633,8 +1726,15 @@ struct NodeCtxT {
   }
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
   __device__ __forceinline__ View lookup(uint32_t x) {
-    View v; v.fresh = false; v.c_have = false;
+    View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
     v.w = D.nw[(size_t)r * D.N + x];
+    if (v.w & NW_MASS) {                                   // the subject owns a row of the dense store: pair (row, this lane)
+      const uint32_t row = D.mrow[(size_t)r * D.N + x]; const size_t idx = m_idx(D, r, row, k);
+      const uint32_t a = D.mA[idx], b = D.mB[idx], c = D.mC[idx];
+      v.free_slot = SW_MASS_SLOT | row; v.c = make_uint4(0, 0, 0, 0); v.c_have = true;
+      if (a) { v.slot = v.free_slot; v.e = m_unpack(D, x, a, b, c, v.c.x); return v; }
+      v.slot = NONE;
+    } else
     v.slot = vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], v.e, v.free_slot);
     // no explicit view: the base row's — except that a node always sees ITSELF alive at its own incarnation
     if (v.slot == NONE) v.e = make_uint4(x, x == o ? SW_KEY(self_inc, SWIM_STATE_ALIVE) : base_key_of(D, r, x, v.w), 0, 0);
@@ -1644,6 +1744,7 @@ struct NodeCtxT {
   // (its view of itself always fits): the caller ignores the rumour, counted in view_drops.
   __device__ __forceinline__ bool make(View& v, uint32_t x) {
     if (v.slot != NONE) return true;
+    if (v_mass(v)) { v.slot = v.free_slot; v.fresh = true; D.mcnt[l]++; return true; }   // the dense store has room for every observer
     need_vm();
     if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
     if (vm.x >= D.view_cap + (x == o ? 1u : 0u)) {
@@ -1680,18 +1781,17 @@ struct NodeCtxT {
     }
     return true;
   }
-  __device__ __forceinline__ void put(const View& v) { D.vt[(size_t)v.slot * NL + l] = v.e; }
   __device__ __forceinline__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
     const uint32_t old = v.fresh ? (uint32_t)SWIM_STATE_ALIVE : SW_KST(v.e.y);     // (a fresh view comes from the base row: never Suspect)
     v.fresh = false;
     v.e.y = SW_KEY(inc, st);
     if (touch_since) v.e.z = now_ms(D, t);
-    if ((old == SWIM_STATE_SUSPECT) != (st == SWIM_STATE_SUSPECT)) {
+    if (!v_mass(v) && (old == SWIM_STATE_SUSPECT) != (st == SWIM_STATE_SUSPECT)) {
       need_vm(); vm_dirty = true;
       if (st == SWIM_STATE_SUSPECT) vm.y++;
       else if (--vm.y == 0) vm.z = NONE;                               // no timer left: the bound is exact again
     }
-    if (st >= SWIM_STATE_DEAD) { need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
+    if (st >= SWIM_STATE_DEAD && !v_mass(v)) { need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
     if (NW_HAS_SLOT(v.w)) {
       const size_t sidx = (size_t)r * D.S + NW_SLOT(v.w);
       if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
@@ -1700,6 +1800,7 @@ struct NodeCtxT {
   }
   __device__ __forceinline__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
     const uint32_t dl = v.e.z + susp_timeout_n(D, n0, vw_nconf(v.e.w));
+    if (v_mass(v)) { m_arm(D, r, v.free_slot & ~SW_MASS_SLOT, k, dl); return; }
     need_vm();
     if (dl < vm.z) { vm.z = dl; vm_dirty = true; }
     if (dl < dl_new) dl_new = dl;                          // the block's bound is lowered once per block (k_resolve) / by the caller
@@ -1751,14 +1852,14 @@ struct NodeCtxT {
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from) (the base row is never Suspect)
       uint32_t nc = vw_nconf(v.e.w);
       if ((!D.dyn && nc >= D.susp_k) || vw_conf0(v.e.w) == from) return;
-      const size_t ci = (size_t)v.slot * NL + l;
+      const size_t ci = (size_t)v.slot * NL + l;          // (a pair of the dense store carries its accusers along: c_have)
       if (!v.c_have) { v.c = (nc || D.dyn) ? D.vc[ci] : make_uint4(0, 0, 0, 0); v.c_have = true; }   // (dynamic membership: the timer's n sits in c.w)
       uint4 b = v.c;
       if (D.dyn && nc >= susp_k_n(D, b.w)) return;
       if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
-      if (nc <= 3) { D.vc[ci] = b; v.c = b; }
+      if (nc <= 3) { if (!v_mass(v)) D.vc[ci] = b; v.c = b; }
       v.e.w = vw_pack(vw_conf0(v.e.w), nc, vw_leaving(v.e.w)); put_later(v);
       arm_deadline(v, b.w);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
@@ -1774,7 +1875,7 @@ struct NodeCtxT {
     v.e.w = vw_pack(from, 0, (v.e.w >> 1) & 1u);           // newSuspicion(from, k, min, max); a Leaving mark stays
     put_later(v);
     uint32_t n0 = 0;
-    if (D.dyn) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
+    if (D.dyn && !v_mass(v)) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
     v.c = make_uint4(0, 0, 0, n0); v.c_have = true;
     arm_deadline(v, n0);
     S.add(ST_APPL1);
@@ -1880,7 +1981,8 @@ struct NodeCtxT {
       set_view(v, SW_KINC(key), SWIM_STATE_LEFT, true);
       S.add(ST_INTENTS);
       if (o == D.watch) record_event(SWIM_EVENT_MEMBER_LEAVE, x, 0, SW_KINC(key));
-    } else { v.fresh = false; need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
+    } else if (v_mass(v)) v.fresh = false;
+    else { v.fresh = false; need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
     if (prune) {
       v.e.w = 1u; S.add(ST_REAPED);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
@@ -2032,7 +2134,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   }
   if (D.fast_blocks && threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) D.in_any[nb0 + threadIdx.x] = 0;
   __syncthreads();
-  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;
+  uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0, c_peak = 0;
   const uint32_t t_now = *D.tick;
   RCLK_MARK(0);                                    // compaction
   WCLK(1);
@@ -2050,6 +2152,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     const uint4 vm0 = D.vmeta[l];
     D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
+    c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
     NodeCtxT<true> n(D, S);
@@ -2121,6 +2224,10 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   { uint32_t m = rclk_it; for (int off = 32; off; off >>= 1) { uint32_t v = __shfl_xor(m, off); m = v > m ? v : m; } rclk_it = m; }
 #endif
   WCLK(2);
+  if (__any(c_peak > 5u)) {                        // swim_stats_t.inbox_peak (the 64-byte line holds five: smaller inboxes never raise it past 5)
+    for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(c_peak, off); c_peak = v > c_peak ? v : c_peak; }
+    if (sw_lane() == 0 && c_peak > *D.peak) atomicMax(D.peak, c_peak);
+  }
   if (D.flags & SWIM_F_PIGGYBACK) {
     uint32_t s0 = c_sent01 & 0xFFFFu, s1 = c_sent01 >> 16, s2 = c_sent23 & 0xFFFFu, s3 = c_sent23 >> 16;
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
@@ -2162,12 +2269,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ D
   uint32_t x = D.subj_node[sidx], maxinc = D.slot_maxinc[sidx];
   uint32_t obs = 0, st[4] = { 0, 0, 0, 0 }, cur = 0;
   const uint32_t* nw = D.nw + (size_t)r * D.N;
-  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx);
+  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx), mrow_x = (wx & NW_MASS) ? D.mrow[(size_t)r * D.N + x] : 0;
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     uint32_t o = D.i0 + k;
     if (o == x || (nw[o] & NW_DEAD)) continue;
     uint32_t key = bkey;
-    if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
+    if (wx & NW_MASS) { const uint32_t a = D.mA[m_idx(D, r, mrow_x, k)]; if (a) key = MA_KEY(a); }
+    else if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
     const uint32_t s = SW_KST(key);
     obs++; st[0] += s == 0; st[1] += s == 1; st[2] += s == 2; st[3] += s == 3;
     cur += SW_KINC(key) == maxinc;
@@ -2353,6 +2461,7 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
   D.in_cnt[l] = 0; D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
+  if (D.mcnt) D.mcnt[l] = 0;
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
@@ -2429,6 +2538,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
         // counts again in the block's gate
         const uint32_t d = D.vmeta[l].z;
         if (d != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], d);
+        if (D.M && D.mcnt[l])                                  // ... and so do its suspicions in the dense store
+          for (uint32_t row = 0; row < D.M; row++) {
+            if (D.mrow_subj[(size_t)r * D.M + row] == NONE) continue;
+            const size_t idx = m_idx(D, r, row, x - D.i0);
+            const uint32_t a = D.mA[idx];
+            if (a && MA_STATE(a) == SWIM_STATE_SUSPECT) m_arm(D, r, row, x - D.i0, MB_TICK(D.mB[idx]) * D.quantum_ms + susp_timeout_n(D, 0, MA_NCONF(a)));
+          }
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
@@ -2467,6 +2583,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         // nothing queued, no views of its own (it holds the base row), clean probe state
         for (uint32_t sl = 0; sl < D.VT; sl++) if (D.vt[(size_t)sl * NL + l].x != VT_EMPTY) D.vt[(size_t)sl * NL + l].x = VT_EMPTY;
         D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
+        if (D.M && D.mcnt[l]) { for (uint32_t row = 0; row < D.M; row++) { const size_t idx = m_idx(D, r, row, x - D.i0); if (D.mA[idx]) D.mA[idx] = 0; } D.mcnt[l] = 0; }
         const uint32_t bkey = base_key_of(D, r, x, old);
         if (D.vnk) D.vnk[l] = SW_KINC(bkey) == 0 ? 1u : 0u;  // it knows itself, whatever the base row says
         uint4 h = D.hdr[l];
@@ -2621,9 +2738,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
         const uint32_t nc = vw_nconf(a.w); const uint4 cf = D.vc[(size_t)sl * NL + l];
         d += sw_h3(10, id, nc);
         d += sw_h3(11, id, vw_conf0(a.w));
-        if (nc >= 1) d += sw_h3(12, id, cf.x);
-        if (nc >= 2) d += sw_h3(13, id, cf.y);
-        if (nc >= 3) d += sw_h3(14, id, cf.z);
+        // (the accusers that can still matter: suspicion.Confirm returns early once k confirmations are in, so the k-th
+        // confirmer's name is never looked at again)
+        const uint32_t kk = susp_k_n(D, cf.w);
+        if (nc >= 1 && kk > 1) d += sw_h3(12, id, cf.x);
+        if (nc >= 2 && kk > 2) d += sw_h3(13, id, cf.y);
+        if (nc >= 3 && kk > 3) d += sw_h3(14, id, cf.z);
       }
     }
     const uint64_t g = (uint64_t)r * D.N + o;                  // the base row: every shard digests its own id range
@@ -2633,6 +2753,30 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
   digest_commit(d, out);
 }
 
+// the pairs of the dense store, hashed exactly like the explicit views of the hash tables: one workgroup per row
+__global__ void __launch_bounds__(SW_BLOCK) k_digest_mass(const SwDev* __restrict__ Dp, unsigned long long* out) {
+  SW_DEV_BIND
+  const uint32_t r = blockIdx.x / D.M, row = blockIdx.x % D.M, x = D.mrow_subj[blockIdx.x];
+  uint64_t d = 0;
+  if (x != NONE)
+    for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
+      const size_t idx = m_idx(D, r, row, k);
+      const uint32_t a = D.mA[idx];
+      if (!a) continue;
+      uint32_t c1; const uint4 e = m_unpack(D, x, a, D.mB[idx], D.mC[idx], c1);
+      const uint64_t id = ((uint64_t)r << 40) ^ ((uint64_t)x * 0x100000001B3ull) ^ ((uint64_t)(D.i0 + k) << 8);
+      d += sw_h3(9, id, ((uint64_t)e.y << 32) | e.z);
+      if (SW_KST(e.y) >= SWIM_STATE_DEAD && (e.w & 1u)) d += sw_h3(16, id, 1);
+      if (SW_KST(e.y) == SWIM_STATE_SUSPECT ? vw_leaving(e.w) : (e.w >> 1) & 1u) d += sw_h3(17, id, 1);
+      if (SW_KST(e.y) == SWIM_STATE_SUSPECT) {
+        const uint32_t nc = vw_nconf(e.w);
+        d += sw_h3(10, id, nc);
+        d += sw_h3(11, id, vw_conf0(e.w));
+        if (nc >= 1 && D.susp_k > 1) d += sw_h3(12, id, c1);
+      }
+    }
+  digest_commit(d, out);
+}
 // swim_view / swim_members: one observer's explicit views, gathered for the host: out[0] = count, then {vt, vc} pairs
 __global__ void k_gather_views(const SwDev* __restrict__ Dp, uint32_t r, uint32_t o, uint32_t* out, uint32_t cap) {
   SW_DEV_BIND
@@ -2645,6 +2789,18 @@ __global__ void k_gather_views(const SwDev* __restrict__ Dp, uint32_t r, uint32_
     if (n < cap) { const uint4 c = D.vc[(size_t)sl * NL + l]; uint32_t* w = out + 4 + (size_t)n * 8; w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = 0; }
     n++;
   }
+  if (D.M && D.mcnt[l]) {                       // ... and its pairs of the dense store, in the same form
+    const uint32_t nr = D.M;
+    for (uint32_t row = 0; row < nr; row++) {
+      const uint32_t x = D.mrow_subj[(size_t)r * D.M + row];
+      if (x == NONE) continue;
+      const size_t idx = m_idx(D, r, row, o - D.i0);
+      const uint32_t a = D.mA[idx];
+      if (!a) continue;
+      if (n < cap) { uint32_t c1; const uint4 e = m_unpack(D, x, a, D.mB[idx], D.mC[idx], c1); uint32_t* w = out + 4 + (size_t)n * 8; w[0] = e.x; w[1] = e.y; w[2] = e.z; w[3] = e.w; w[4] = c1; w[5] = 0; w[6] = 0; w[7] = 0; }
+      n++;
+    }
+  }
   out[0] = n;
 }
 // swim_census_get for a subject without a watch slot: pass 0 = highest incarnation any local observer holds, pass 1 = the
@@ -2652,12 +2808,13 @@ __global__ void k_gather_views(const SwDev* __restrict__ Dp, uint32_t r, uint32_
 __global__ void __launch_bounds__(SW_BLOCK) k_census_adhoc(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x, int pass, uint32_t* acc) {
   SW_DEV_BIND
   const uint32_t* nw = D.nw + (size_t)r * D.N;
-  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx), maxinc = acc[6];
+  const uint32_t wx = nw[x], bkey = base_key_of(D, r, x, wx), maxinc = acc[6], mrow_x = (wx & NW_MASS) ? D.mrow[(size_t)r * D.N + x] : 0;
   uint32_t vals[7] = { 0, 0, 0, 0, 0, 0, SW_KINC(bkey) };
   for (uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x; k < D.nloc; k += gridDim.x * SW_BLOCK) {
     const uint32_t o = D.i0 + k;
     uint32_t key = bkey;
-    if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
+    if (wx & NW_MASS) { const uint32_t a = D.mA[m_idx(D, r, mrow_x, k)]; if (a) key = MA_KEY(a); }
+    else if (wx & NW_SUBJECT) { uint4 e; uint32_t fs; if (vt_find(D, (size_t)r * D.nloc + k, x, e, fs) != NONE) key = e.y; }
     if (pass == 0) { vals[6] = SW_KINC(key) > vals[6] ? SW_KINC(key) : vals[6]; continue; }
     if (o == x || (nw[o] & NW_DEAD)) continue;
     vals[0]++; vals[1 + SW_KST(key)]++; vals[5] += SW_KINC(key) == maxinc;
@@ -2732,7 +2889,9 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
     if (sl < D.VT) { if (left) a = D.vt[(size_t)sl * NL + l]; }
     else if (acting && !saw_self) {
       const uint32_t self = SW_KEY(D.hdr[l].x, SWIM_STATE_ALIVE);
-      if (self != D.bk[(size_t)r * D.N + o]) a = make_uint4(o, self, 0, 0);
+      const uint32_t wo = D.nw[(size_t)r * D.N + o];
+      const bool in_store = (wo & NW_MASS) && D.mA[m_idx(D, r, D.mrow[(size_t)r * D.N + o], o - D.i0)] != 0;   // (k_fold_scan_mass counts that one)
+      if (self != D.bk[(size_t)r * D.N + o] && !in_store) a = make_uint4(o, self, 0, 0);
     }
     bool have = a.x != VT_EMPTY;
     if (have && sl < D.VT) { left--; saw_self |= a.x == o; }
@@ -2817,4 +2976,146 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
     if (nk_less && D.dyn) D.vnk[l] -= nk_less;
     atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
   }
+}
+
+// =================================================================================================
+// the dense pair store (swim_device.h): suspicion timers, fold, row allocation
+// =================================================================================================
+// suspectNode's time.AfterFunc for the pairs of the dense store: one workgroup per row; out after one word unless the row's
+// bound has passed, then only the 256-observer tiles whose bound has passed are looked at (one wave per tile).  A verdict goes
+// straight into the observer's inbox like role_expire's.
+__global__ void __launch_bounds__(SW_BLOCK) k_expire_mass(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t rr = blockIdx.x, now = now_ms(D, *D.tick);
+  if (now < D.m_row_dl[rr]) return;
+  const uint32_t r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr], lane = sw_lane(), wave = threadIdx.x / 64;
+  __shared__ uint32_t s_min[SW_BLOCK / 64];
+  uint32_t row_min = NONE, fired = 0;
+  if (x != NONE) {
+    uint32_t* tiles = D.m_tile_dl + (size_t)rr * D.nbl;
+    for (uint32_t tile = wave; tile < D.nbl; tile += SW_BLOCK / 64) {
+      const uint32_t tb = tiles[tile];
+      if (now < tb) { row_min = tb < row_min ? tb : row_min; continue; }
+      uint32_t m = NONE;
+      for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
+        const uint32_t k = tile * SW_BLOCK + part * 64 + lane;
+        if (k >= D.nloc) continue;
+        const size_t idx = m_idx(D, r, row, k);
+        const uint32_t a = D.mA[idx];
+        if (MA_STATE(a) != SWIM_STATE_SUSPECT) continue;
+        const uint32_t o = D.i0 + k;
+        if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;          // its timers rest; a revive lowers the bounds again
+        const uint32_t dl = MB_TICK(D.mB[idx]) * D.quantum_ms + susp_timeout_n(D, 0, MA_NCONF(a));
+        if (now >= dl) {
+          const size_t l = (size_t)r * D.nloc + k;
+          inbox_place(D, mk_edge(D, r, o, x, MA_INC(a), SWIM_MSG_DEAD, o), l, atomicAdd(&D.in_cnt[l], 1u));
+          fired++;
+        }
+        m = dl < m ? dl : m;           // a fired timer keeps the bound low until its verdict is merged
+      }
+      for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
+      if (lane == 0) tiles[tile] = m;
+      row_min = m < row_min ? m : row_min;
+    }
+  }
+  for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(row_min, off); row_min = v < row_min ? v : row_min; }
+  if (lane == 0) s_min[wave] = row_min;
+  if (__any(fired != 0)) {
+    for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
+    if (lane == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t m = s_min[0]; for (uint32_t w = 1; w < SW_BLOCK / 64; w++) m = s_min[w] < m ? s_min[w] : m; D.m_row_dl[rr] = m; }
+}
+// fold census of the dense store (k_fold_scan's counterpart): what the acting observers hold about the row's subject
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_mass(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t rr = blockIdx.x, r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr];
+  if (x == NONE) return;
+  const uint32_t now = now_ms(D, *D.tick);
+  __shared__ uint32_t s_cnt, s_kmin, s_kmax, s_bad;
+  if (threadIdx.x == 0) { s_cnt = 0; s_kmin = NONE; s_kmax = 0; s_bad = 0; }
+  __syncthreads();
+  uint32_t cnt = 0, kmin = NONE, kmax = 0, bad = 0;
+  for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
+    const size_t idx = m_idx(D, r, row, k);
+    const uint32_t a = D.mA[idx];
+    if (!a || (D.nw[(size_t)r * D.N + D.i0 + k] & NW_INERT)) continue;
+    const uint32_t st = MA_STATE(a), key = MA_KEY(a);
+    bad |= st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - MB_TICK(D.mB[idx]) * D.quantum_ms > D.gossip_to_dead_ms)) ||
+           (D.reap_period && st >= SWIM_STATE_DEAD && !MA_ERASED(a)) || (st == SWIM_STATE_ALIVE && MA_LEAVING(a));
+    cnt++; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax;
+  }
+  for (int off = 32; off; off >>= 1) {
+    cnt += __shfl_down(cnt, off); bad |= __shfl_down(bad, off);
+    const uint32_t a = __shfl_down(kmin, off), b = __shfl_down(kmax, off); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+  }
+  if (sw_lane() == 0 && cnt) { atomicAdd(&s_cnt, cnt); atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); if (bad) s_bad = 1; }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) {
+    const size_t g = (size_t)r * D.N + x;
+    atomicAdd(&D.fl_cnt[g], s_cnt); atomicMin(&D.fl_kmin[g], s_kmin); atomicMax(&D.fl_kmax[g], s_kmax);
+    if (s_bad) D.fl_bad[g] = 1;
+  }
+}
+// a folded subject's row is cleared (every observer's pair, running or not) and goes back to the free stack
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_apply_mass(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t rr = blockIdx.x, r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr];
+  if (x == NONE) return;
+  const size_t g = (size_t)r * D.N + x;
+  if (!D.fl_bad[g]) return;
+  uint32_t freed = 0;
+  for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
+    const size_t idx = m_idx(D, r, row, k);
+    if (D.mA[idx]) { D.mA[idx] = 0; D.mcnt[(size_t)r * D.nloc + k]--; freed++; }
+  }
+  for (uint32_t tl = threadIdx.x; tl < D.nbl; tl += SW_BLOCK) D.m_tile_dl[(size_t)rr * D.nbl + tl] = NONE;
+  for (int off = 32; off; off >>= 1) freed += __shfl_down(freed, off);
+  if (sw_lane() == 0 && freed) atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
+  if (threadIdx.x == 0) {
+    D.m_row_dl[rr] = NONE; D.mrow[g] = NONE; D.mrow_subj[rr] = NONE;
+    atomicAnd(&D.nw[g], ~NW_MASS);
+    const uint32_t pos = atomicAdd(&D.m_nfree[r], 1u);
+    D.m_free[(size_t)r * D.M + pos] = row;
+  }
+}
+// Rows for the nodes a stimulus call names (kill / revive / leave / update / join, the minority sides of a partition), while
+// rows remain and nobody on this shard holds a hash-table view of the node yet.  One workgroup, the list in order: who gets a
+// row when they run out does not depend on scheduling.  (Which row is immaterial.)
+#define SW_MROW_PENDING 0xFFFFFFFEu
+__global__ void __launch_bounds__(SW_BLOCK) k_mass_alloc(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n) {
+  SW_DEV_BIND
+  __shared__ uint32_t s_w[SW_BLOCK / 64];
+  const uint32_t lane = sw_lane(), wave = threadIdx.x / 64;
+  for (uint32_t a0 = 0; a0 < n; a0 += SW_BLOCK) {
+    const uint32_t a = a0 + threadIdx.x;
+    bool want = false; size_t g = 0; uint32_t x = 0;
+    if (a < n) {
+      x = ids[a]; g = (size_t)r * D.N + x;
+      if (!(D.nw[g] & (NW_MASS | NW_SUBJECT)) && atomicCAS(&D.mrow[g], NONE, SW_MROW_PENDING) == NONE) want = true;   // (a list may name a node twice)
+    }
+    const uint64_t mask = __ballot(want);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < SW_BLOCK / 64; w++) { base += w < wave ? s_w[w] : 0; total += s_w[w]; }
+    const uint32_t avail = D.m_nfree[r], my = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+    if (want) {
+      if (my < avail) {
+        const uint32_t row = D.m_free[(size_t)r * D.M + (avail - 1 - my)];
+        D.mrow_subj[(size_t)r * D.M + row] = x; D.mrow[g] = row;
+        atomicOr(&D.nw[g], NW_MASS);
+      } else D.mrow[g] = NONE;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) D.m_nfree[r] = avail - (total < avail ? total : avail);
+    __syncthreads();
+  }
+}
+__global__ void k_mass_init(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)D.R * D.M;
+  if (i < n) { D.mrow_subj[i] = NONE; D.m_row_dl[i] = NONE; D.m_free[i] = D.M - 1 - (uint32_t)(i % D.M); }   // (row 0 is handed out first)
+  if (i < D.R) D.m_nfree[i] = D.M;
 }

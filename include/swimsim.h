@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 5u
+#define SWIM_ABI_VERSION 6u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -136,6 +136,14 @@ typedef struct swim_config {
                                        more entry is ignored and counted in view_drops (never silent).  Sized
                                        like Serf's queue rule max(2N, 4096) at small N
                                        (internal/gossip/libserf/serf.go:25-27); 0 = min(n_nodes, 32)            */
+  uint32_t mass_rows;               /* per replica: rows of the DENSE pair store for mass events (BASELINE configs #4 / #5: thousands
+                                       of subjects every observer hears about).  A node named in a stimulus call (kill, revive,
+                                       leave, update, join, the minority sides of a partition) gets a row while rows remain, and
+                                       every observer's view of it then costs 12 bytes in [row][observer] planes instead of a
+                                       64-byte hash-table entry counted against view_cap: memory = 12 B x mass_rows x nodes on the
+                                       shard x replicas.  Representation only: no result depends on which subject has a row.
+                                       Needs SuspicionMult <= 4 (two accuser names per pair), a fixed population (n_initial = 0),
+                                       n_nodes <= 2^22, the reaper off.  The checker ignores the field.  0 = off              */
   /* serf's reaper (handleReap): every ReapInterval a member that has been Failed for longer than ReconnectTimeout, or Left
    * for longer than TombstoneTimeout, is erased from the observer's member list (status NONE) and EventMemberReap is
    * emitted (agent/consul/server_serf.go:279, timeouts agent/consul/config.go:640-641; the reference's tests run it at
@@ -269,6 +277,9 @@ typedef struct swim_stats_t {
   uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
   uint64_t coord_updates;           /* coordinate.Client.Update calls (one per direct probe ack, SWIM_F_COORDINATES) */
   uint64_t coord_resets;            /* ... that left an invalid coordinate and reset it (Client.stats.Resets)     */
+  uint64_t inbox_peak;              /* the largest number of messages one node received in one tick, counted from six on (five
+                                       fit the node's inbox line; 0 = never more).  Sizes inbox_cap: a state exchange delivers
+                                       a whole table at once                                                        */
 } swim_stats_t;
 
 typedef struct swim_sim swim_sim;
@@ -378,6 +389,9 @@ int swim_set_loss(swim_sim* sim, uint32_t loss_q32);
  * event_id stands for hash(name,payload); returns the Lamport time stamped on it */
 int swim_user_event(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t event_id,
                     uint32_t* ltime_out);
+/* user-event ids are 30 bits: bits 31-30 of the id word distinguish serf's intent messages (messageLeaveType; SWIM_INTENT_*)
+ * from user events on the shared broadcast queue.  A larger id is refused (SWIM_ERANGE) — never reinterpreted as an intent. */
+#define SWIM_EVENT_ID_MAX 0x3FFFFFFFu
 
 /* ---- observation ---------------------------------------------------------------------------- */
 /* serf.Members() as seen by `observer` (agent/consul/client.go:234, server.go:1508): writes

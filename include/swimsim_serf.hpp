@@ -418,7 +418,7 @@ class Serf {
     for (unsigned char c : name) { h ^= c; h *= 16777619u; }
     h ^= 0xFF; h *= 16777619u;
     for (unsigned char c : payload) { h ^= c; h *= 16777619u; }
-    return h;
+    return (h ^ (h >> 30)) & SWIM_EVENT_ID_MAX;        // 30 bits (xor-folded): bits 31-30 of an id word mark serf's intents
   }
   static std::map<uint32_t, Fired>& catalog() { static std::map<uint32_t, Fired> c; return c; }
   // A member other than the pool's watch node: the device records no event stream for it, so its MEMBER events are derived

@@ -592,6 +592,7 @@ inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm 
         if (n < 1 || body[0] != kSerfUserEvent) { n_control++; break; }       // serf joins/leaves/queries: not modelled
         UserEvent u = decode_user_event(body + 1, n - 1);
         uint32_t id = 0; for (size_t i = 0; i < u.payload.size() && i < 4; i++) id = id << 8 | u.payload[i];
+        id &= SWIM_EVENT_ID_MAX;                                                   // (bits 31-30 of an id word mark serf's intents)
         out.push_back(swim_edge{ 0, id, uint32_t(u.ltime), uint32_t(SWIM_MSG_USER) << 30 }); break;
       }
       case kPing: { n_control++; if (probes) { Ping pg = decode_ping(body, n); Probe pr; pr.seq_no = pg.seq_no; pr.node = pg.node; probes->push_back(pr); } break; }

@@ -1344,6 +1344,7 @@ static void phase_deliver_resolve(swim_sim* s) {
     for (uint32_t k = 0; k < s->nloc; k++) {
       uint32_t o = s->i0 + k; node_t* nd = node_at(s, r, o);
       if (!nd->in_cnt) continue;
+      if (nd->in_cnt > 5 && nd->in_cnt > s->st.inbox_peak) s->st.inbox_peak = nd->in_cnt;   /* (counted from six on: see swimsim.h) */
       qsort(nd->inbox, nd->in_cnt, sizeof(swim_edge), edge_cmp);
       for (uint32_t i = 0; i < nd->in_cnt; i++) {
         swim_edge e = nd->inbox[i];
@@ -1657,6 +1658,7 @@ int swim_set_loss(swim_sim* s, uint32_t q) { if (!s) return SWIM_EINVAL; s->loss
 int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
   int rc = chk(s, r, &origin, 1); if (rc) return rc;
   if (!(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
+  if (id > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;           /* bits 31-30 mark serf's intents (messageLeaveType), never a user event */
   if (lt) *lt = SWIM_NONE;
   if (!is_local(s, origin) || !s->gt_alive[(size_t)r * s->N + origin]) return SWIM_OK;
   node_t* nd = node_at(s, r, origin);
@@ -1798,7 +1800,9 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
         if (v->leaving) d += h3(17, id, 1);
         if (KST(v->key) == SWIM_STATE_SUSPECT) {
           d += h3(10, id, v->nconf);
-          for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX; j++) d += h3(11 + j, id, v->conf[j]);
+          /* the accusers that can still matter: Confirm() returns early once k confirmations are in, so the name of the
+           * k-th confirmer is never looked at again (the first accuser always is hashed) */
+          for (uint32_t j = 0; j <= v->nconf && j < CONF_MAX && (j == 0 || j < suspicion_k_n(s, v->n0)); j++) d += h3(11 + j, id, v->conf[j]);
         }
       }
     }
@@ -1834,7 +1838,7 @@ int swim_transport_write_to(swim_sim* s, uint32_t r, uint32_t a, uint32_t dst, c
   int rc = attach(s, r, a); if (rc) return rc;
   if (dst >= s->N || (!m && n)) return SWIM_EINVAL;
   for (size_t i = 0; i < n; i++)
-    if ((m[i].meta >> 30) != SWIM_MSG_USER && m[i].subject >= s->N) return SWIM_ERANGE;
+    if ((m[i].meta >> 30) != SWIM_MSG_USER ? m[i].subject >= s->N : m[i].subject > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;   /* (a user event never carries intent bits) */
   if (!is_local(s, dst) || !s->gt_alive[(size_t)r * s->N + dst] || s->attached[(size_t)r * s->N + dst]) return SWIM_OK;
   node_t* nd = node_at(s, r, dst);
   for (size_t i = 0; i < n; i++) {

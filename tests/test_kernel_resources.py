@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel (mangled-name fragment) -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
     "k_beginILi4ELb0ELb0E": (96, 16, 5),       # the bench's instantiation: fan-out <= 4, no serf events, one shard
-    "k_beginILi8ELb1ELb1E": (96, 96, 5),       # the heaviest one (fan-out 8, serf events, sharded)
+    "k_beginILi8ELb1ELb1E": (96, 128, 5),      # the heaviest one (fan-out 8, serf events, sharded)
     "9k_deliverPK": (64, 0, 7),
     "9k_resolvePK": (128, 64, 4),              # 48 bytes: the call frame of the in-place heapsort of big inboxes (cold path)
     "8k_censusPK": (32, 0, 8),

@@ -1,0 +1,118 @@
+"""The dense pair store (swim_config.mass_rows) is a REPRESENTATION: a subject named in a stimulus call keeps
+every observer's view of it in 12-byte pairs of [row][observer] planes instead of 64-byte hash-table entries counted
+against view_cap.  No result may depend on it.  So here the HIP library runs with rows and a view_cap far too small for
+the scenario, the checker — which has no such store — with a view_cap that holds everything, and every integer of state
+must agree: digests, counters, censuses, member lists, edge lists."""
+import numpy as np
+import pytest
+
+from consul_amd import abi
+from consul_amd.sim import Sim, preset
+from test_parity_gpu import STAT_KEYS, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(hip, oracle, hip_kw, ora_kw, which=abi.PRESET_LAN, **kw):
+    return Sim(hip, preset(hip, which, **{**kw, **hip_kw})), Sim(oracle, preset(oracle, which, **{**kw, **ora_kw}))
+
+
+def test_single_failure_in_a_row_lockstep(hip, oracle):
+    """config #2's shape: the one victim per cluster owns row 0; every tick compared (edge lists, digests)."""
+    a, b = pair(hip, oracle, dict(mass_rows=2, view_cap=4), dict(view_cap=4), n_nodes=4096, n_replicas=3, seed=11, subject_cap=4)
+    victims = [17, 4000, 2048]
+    for s in (a, b):
+        s.step_ms(3000)
+        for r, v in enumerate(victims):
+            s.kill(r, [v])
+    for t in range(120):
+        a.step(1); b.step(1)
+        assert np.array_equal(a.edges(), b.edges()), f"edge list differs at tick {a.now()[0]}"
+        assert a.digest() == b.digest(), f"digest differs at tick {a.now()[0]}"
+    for chunk in range(6):
+        a.step_ms(5000); b.step_ms(5000)
+        assert_same(a, b, list(enumerate(victims)), tag=f"chunk {chunk}")
+    assert a.census(0, 17).all_dead_ms != abi.NONE
+    assert np.array_equal(a.members(0, 3), b.members(0, 3))
+    assert a.stats()["view_drops"] == 0
+
+
+@pytest.mark.parametrize("n,share,seed", [(4096, 0.05, 44), (16384, 0.02, 7)])
+def test_mass_failure_matches_the_checker(hip, oracle, n, share, seed):
+    """5 % of the nodes stop at once: every survivor ends up holding every victim dead.  The HIP library keeps those views in
+    rows (its hash tables hold 8 entries); the checker in hash tables that hold them all."""
+    nv = int(n * share)
+    victims = np.random.default_rng(seed).choice(n, size=nv, replace=False)
+    a, b = pair(hip, oracle, dict(mass_rows=nv + 8, view_cap=8), dict(view_cap=nv + 64),
+                n_nodes=n, seed=seed, queue_cap=32, inbox_cap=2 * nv + 256, subject_cap=8)
+    for s in (a, b):
+        s.step_ms(1000)
+        s.kill(0, victims.tolist())
+    watched = [(0, int(v)) for v in victims[:8]]
+    for sec in range(0, 70, 2):
+        a.step_ms(2000); b.step_ms(2000)
+        assert_same(a, b, watched, tag=f"t={sec + 3}s")
+    st = a.stats()
+    assert st["view_drops"] == 0 and st["suspicion_timeouts"] > nv and st["msgs_applied"][2] > 0
+    assert st["inbox_peak"] == b.stats()["inbox_peak"]
+    for _, v in watched[:3]:
+        ca = a.census(0, v)
+        assert ca.by_state[2] + ca.by_state[3] >= 0.99 * ca.n_observers
+    assert np.array_equal(a.members(0, 1), b.members(0, 1))
+
+
+def test_partition_heal_with_rows_and_folds(hip, oracle):
+    """SURVEY §8(f) rank 3 with the minority in rows: 5 % cut off for 45 s, both sides declare each other dead, the cut heals,
+    push-pull brings everybody back, folds free the rows."""
+    import scenarios as sc
+    n = 2048
+    a, b = pair(hip, oracle, dict(mass_rows=160), dict(), **sc.HEAL_2K)
+    ra, rb = sc.run_partition_heal(a, n), sc.run_partition_heal(b, n)
+    assert ra == rb
+    assert a.stats()["folds"] > 0 and a.stats()["view_drops"] == 0
+
+
+def test_leave_update_revive_join_in_rows(hip, oracle):
+    a, b = pair(hip, oracle, dict(mass_rows=16, view_cap=4), dict(view_cap=64), n_nodes=1024, seed=2, subject_cap=16, n_initial=0,
+                fold_interval_ms=4000, push_pull_interval_ms=3000, inbox_cap=128)
+    for s in (a, b):
+        s.step_ms(1000)
+        s.leave(0, [5, 900])
+        s.update(0, [77])
+        s.step_ms(3000)
+        s.kill(0, [5, 900, 33, 600])
+        s.step_ms(8000)
+        s.revive(0, [33])          # comes back with its old views, refutes
+        s.step_ms(2000)
+    assert_same(a, b, [(0, 33), (0, 5), (0, 77)], tag="after revive")
+    for s in (a, b):
+        s.step_ms(20000)
+        s.join(0, [600], via=3)    # a fresh process: clears its column of the store
+        s.step_ms(30000)
+    assert_same(a, b, [(0, 33), (0, 600)], tag="after join")
+    assert np.array_equal(a.members(0, 600), b.members(0, 600))
+    assert np.array_equal(a.members(0, 8), b.members(0, 8))
+
+
+def test_churn_recycles_rows_through_folds(hip, oracle):
+    """config #5's shape, small: every second 10 % flip alive <-> dead; every node becomes a subject sooner or later, folds give
+    rows back, later kills take them again."""
+    import scenarios as sc
+    n = 2048
+    kw = dict(n_nodes=n, seed=12, queue_cap=16, inbox_cap=4096, subject_cap=4, fold_interval_ms=5000)
+    a, b = pair(hip, oracle, dict(mass_rows=n, view_cap=4), dict(view_cap=n), **kw)
+    ra, rb = sc.run_churn(a, n, 40, checkpoints=(10, 20, 30, 40)), sc.run_churn(b, n, 40, checkpoints=(10, 20, 30, 40))
+    assert ra == rb
+    assert a.stats()["view_drops"] == 0
+
+
+def test_rows_run_out_gracefully(hip, oracle):
+    """More subjects than rows: the rest lives in the hash tables, results unchanged (view_cap holds them)."""
+    n, nv = 2048, 64
+    victims = np.random.default_rng(3).choice(n, size=nv, replace=False)
+    a, b = pair(hip, oracle, dict(mass_rows=16), dict(), n_nodes=n, seed=3, view_cap=128, queue_cap=16, inbox_cap=512)
+    for s in (a, b):
+        s.step_ms(1000); s.kill(0, victims.tolist())
+    for sec in range(10):
+        a.step_ms(4000); b.step_ms(4000)
+        assert_same(a, b, tag=f"t={4 * sec + 5}s")
