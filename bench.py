@@ -41,6 +41,9 @@ from consul_amd import abi  # noqa: E402
 from consul_amd.sim import Sim, preset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+TRAFFIC_NOTE = ("profiles/r02_pmc_driver.json (driver window, one handle, per launch): k_resolve 104 MB with FETCH_SIZE as counted / 159 MB with the "
+                "guide's x2 for FETCH_SIZE (calibrated for wide coalesced reads only; these kernels scatter 16-64 B, so quote 13-20x the "
+                "algorithmic 7.8 MB), k_begin 168 MB (2.2x), k_deliver 63 MB (4.3x)")
 
 
 def victims_for(seed: int, reps: int, n: int):
@@ -175,7 +178,13 @@ def run_cpu_baseline(args, ticks_per_round: int) -> dict:
 def roofline_of(prof: dict, st: dict, wall_s=None) -> dict:
     """`roofline` object for the kernel that took most of the instrumented region (HIP events around every launch)."""
     total_ms = sum(ms for _, ms in prof.values())
-    dom = max(prof, key=lambda k: prof[k][1])
+    # The headline kernel: among the kernels that take at least a fifth of the region's kernel time, the one FURTHEST below its
+    # roofline (round 2 reported whichever kernel led by time, and the fraction swung 10x when k_begin and k_resolve traded
+    # places by a microsecond)
+    def frac_of(k):
+        return algorithmic_bytes(k, st) / max(prof[k][1], 1e-9) / 1e6 / HBM_PEAK_GBS
+    heavy = [k for k in prof if prof[k][1] >= 0.2 * total_ms and algorithmic_bytes(k, st) > 0] or [max(prof, key=lambda k: prof[k][1])]
+    dom = min(heavy, key=frac_of)
     launches, ms = prof[dom]
     bytes_per_launch = algorithmic_bytes(dom, st) / max(launches, 1)
     avg_s = ms / 1000.0 / max(launches, 1)
@@ -183,6 +192,14 @@ def roofline_of(prof: dict, st: dict, wall_s=None) -> dict:
     pipe_bytes = sum(algorithmic_bytes(k, st) for k in prof)
     out = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "headline_rule": "lowest algorithmic fraction among kernels with >= 20 % of the region's kernel time",
+           # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE), not from this run:
+           "traffic_source": TRAFFIC_NOTE,
+           # what the chip delivers for the access pattern these kernels have (tools/scatter_roofline.hip, 8 GB working set,
+           # 8 waves per SIMD): dependent 64-byte-line gathers 3.1 TB/s, 16-byte gathers 0.66 TB/s (41 G accesses/s), 16-byte
+           # scattered stores 0.36 TB/s, returning 4-byte atomics 20-27 G/s
+           "scatter_ceiling": {"line_64B_GBps": 3112.0, "gather_16B_GBps": 661.0, "gather_16B_Gacc_per_s": 41.3, "store_16B_GBps": 357.0,
+                               "atomic_4B_Gacc_per_s": 19.7, "frac_of_64B_line_ceiling": achieved / 3112.0, "source": "profiles/r03_scatter_roofline.txt"},
            "avg_launch_us": 1e6 * avg_s, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
            "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof.items()},
            "per_kernel": {k: {"avg_launch_us": 1e3 * v[1] / max(v[0], 1), "launches": v[0],
@@ -227,36 +244,111 @@ def run_detection(hip, cfg_kw, victims, G, quantum_ms) -> dict:
 
 
 def run_config4(hip, args, device) -> dict:
-    """BASELINE configs[3] on ONE GPU's share: 524 288 nodes, LAN timers, k=3, 5 % (26 214 nodes) cut off at once at
-    t = 1 s, bounded explicit views.  Timed: the 25 gossip rounds (5 s) after the cut; a second, instrumented pass of the
-    same region gives the roofline of its dominant kernel."""
-    n, rounds = 524288, 25
-    kw = dict(n_nodes=n, seed=args.seed, view_cap=256, queue_cap=8, inbox_cap=512, subject_cap=4, gossip_nodes=3, device=device)   # inbox: a push-pull delivers a whole table in one tick
-    mask = np.zeros(n, dtype=np.uint8)
-    mask[np.random.default_rng(args.seed).choice(n, size=n // 20, replace=False)] = 1
-    out = {}
-    for instrumented in (False, True):
-        s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
-        G = s.derived.gossip_period
-        s.step_ms(1000); s.partition(0, mask); s.sync()
-        s0 = s.stats()
-        if instrumented:
-            s.profile(True)
-        t0 = time.perf_counter()
-        s.step(rounds * G); s.sync()
-        dt = time.perf_counter() - t0
-        if instrumented:
-            st = diff_stats(s0, s.stats())
-            out["roofline"] = roofline_of(s.profile_read(), st)
-            out["counters"] = {k: st[k] for k in ("packets_sent", "edges", "msgs_filtered", "probe_failures", "queue_drops",
-                                                  "view_drops", "view_evictions", "inbox_overflow", "node_rounds_active")}
-            out["counters"]["msgs_sent"] = sum(st["msgs_sent"]); out["counters"]["msgs_applied"] = sum(st["msgs_applied"])
-        else:
-            out.update({"workload": "BASELINE configs[3], one GPU's share: 524288 nodes, 5% partitioned at once, view_cap 256, "
-                                    "queue_cap 8; the 25 rounds after the cut", "n_nodes": n, "partitioned": int(mask.sum()),
-                        "value": n * rounds / dt, "unit": "node-rounds/s", "rounds_per_sec": rounds / dt, "ms_per_step": 1000.0 * dt / rounds,
-                        "view_table_GB": round(n * s.derived.view_cap * 2 * 32 / 1e9, 1)})
-        s.close()
+    """BASELINE configs[3] on ONE GPU's share, with nothing dropped: N nodes (default 524 288 = 1/8 of the 4 194 304), LAN timers,
+    k = 3, 5 % of them (uniformly drawn) unreachable at once at t = 1 s; run until every survivor holds every victim dead
+    (swim_detection_get).  The victims are STOPPED: for the survivors — whose detection the config measures — a minority that
+    is cut off and one that is down are the same thing (no packet crosses either way), while the cut-off minority's own views
+    of the majority would be another 13 G pairs beside the survivors' 13 G.  Every survivor's view of every victim
+    lives in the dense pair store (mass_rows): view_drops must be 0.  memberlist's queue is unbounded; ours holds queue_cap
+    entries with Prune() semantics — `queue_cap_cost` has what smaller caps cost in rounds (measured at 262 144 nodes)."""
+    n, share = args.config4_nodes, 0.05
+    nv = int(n * share)
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=args.config4_queue_cap, inbox_cap=min(2 * nv + 256, 8192),
+              subject_cap=4, gossip_nodes=3, device=device)
+    victims = np.random.default_rng(args.seed).choice(n, size=nv, replace=False)
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    G, q = s.derived.gossip_period, s.derived.quantum_ms
+    s.step_ms(1000); s.kill(0, victims.tolist()); s.sync()
+    s0 = s.stats()
+    t0 = time.perf_counter()
+    curve, done, heavy = [], None, None
+    budget = args.config4_budget_s
+    sec = 0
+    while sec < 4000:
+        step = 10 if sec < 100 else 50
+        s.step_ms(1000 * step); sec += step
+        s.sync()
+        pairs, by = s.detection(0)
+        wall = time.perf_counter() - t0
+        curve.append({"t_s": sec, "wall_s": round(wall, 2), "dead_fraction": round((by[2] + by[3]) / max(pairs, 1), 6), "suspect_fraction": round(by[1] / max(pairs, 1), 6)})
+        if sec == 60:
+            heavy = wall
+        if pairs and by[2] + by[3] == pairs:
+            done = sec
+            break
+        if wall > budget:
+            break
+    dt = time.perf_counter() - t0
+    st = diff_stats(s0, s.stats())
+    ticks = sec * 1000 // q
+    out = {"workload": f"BASELINE configs[3], one GPU's share: {n} nodes, {nv} stopped at once at t = 1 s, LAN timers, k = 3; run to full detection "
+                       f"(every survivor holds every victim dead); dense pair store, queue_cap {kw['queue_cap']}",
+           "n_nodes": n, "victims": nv, "pairs": int((n - nv)) * nv,
+           "detection_complete": done is not None,
+           "rounds_to_full_detection": done * 1000 // q // G if done else None, "simulated_s_to_full_detection": done,
+           "simulated_s": sec, "wall_s": round(dt, 2), "rounds_per_sec": sec * 1000 / q / G / dt, "value": n * (sec * 1000 / q / G) / dt, "unit": "node-rounds/s",
+           "first_60_s": {"wall_s": round(heavy, 2), "ms_per_round": 1000.0 * heavy / (60000 / q / G)} if heavy else None,
+           "view_drops": st["view_drops"], "view_evictions": st["view_evictions"], "queue_cap": kw["queue_cap"], "queue_drops": st["queue_drops"],
+           "queue_depth_peak": kw["queue_cap"] if st["queue_drops"] else None,
+           "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"], "push_pulls": st["push_pulls"],
+           "edges": st["edges"], "msgs_applied": sum(st["msgs_applied"]), "suspicion_timeouts": st["suspicion_timeouts"],
+           # what would cross xGMI if this population were one of 8 shards: 7/8 of the records, 16 bytes each
+           "a2a_bytes_per_tick_if_one_of_8_shards": {"mean": 16.0 * 7 / 8 * st["edges"] / max(ticks, 1)},
+           "pair_store_GB": round(12.0 * (nv + 8) * n / 1e9, 1),
+           "queue_cap_cost": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
+                              "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}},
+           "curve": curve[:12] + curve[12::4]}
+    s.close()
+    return out
+
+
+def run_config5(hip, args, device) -> dict:
+    """BASELINE configs[4]'s shape on one GPU: N nodes (default 65 536), LAN timers, Lifeguard on (the default flags), 10 % of the
+    nodes flip alive <-> dead every second (kill / revive: a node that comes back refutes with a higher incarnation), and a flood
+    of serf user events (E per second from uniformly drawn live origins, Lamport-clocked, 512-slot event buffer).  Every node is
+    a subject sooner or later: all views live in the dense pair store (mass_rows = N), nothing may be dropped."""
+    n, secs, E = args.config5_nodes, args.config5_seconds, args.config5_events
+    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=16, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+              fold_interval_ms=5000, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=abi.NONE, device=device)
+    s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    G, q = s.derived.gossip_period, s.derived.quantum_ms
+    rng = np.random.default_rng(args.seed + 5)
+    dead = np.zeros(n, dtype=bool)
+    s.step_ms(1000); s.sync()
+    s0 = s.stats()
+    t0 = time.perf_counter()
+    fired = 0
+    for sec in range(secs):
+        flip = rng.choice(n, size=n // 10, replace=False)
+        kill, revive = flip[~dead[flip]], flip[dead[flip]]
+        dead[flip] = ~dead[flip]
+        if len(kill):
+            s.kill(0, kill.tolist())
+        if len(revive):
+            s.revive(0, revive.tolist())
+        live = np.flatnonzero(~dead)
+        for origin in rng.choice(live, size=E, replace=False):
+            s.user_event(0, int(origin), int(rng.integers(1 << 30)))
+            fired += 1
+        s.step_ms(1000)
+    s.sync()
+    dt = time.perf_counter() - t0
+    st = diff_stats(s0, s.stats())
+    live = np.flatnonzero(~dead)
+    clocks = [s.node_info(0, int(i)).event_clock for i in rng.choice(live, size=min(256, len(live)), replace=False)]
+    rounds = secs * 1000 / q / G
+    out = {"workload": f"BASELINE configs[4]'s shape on one GPU: {n} nodes, LAN timers, Lifeguard on, 10 %/s churn (kill / revive), {E} serf user events/s; "
+                       f"{secs} s simulated; dense pair store for every node",
+           "n_nodes": n, "simulated_s": secs, "wall_s": round(dt, 2), "rounds_per_sec": rounds / dt, "value": n * rounds / dt, "unit": "node-rounds/s",
+           "events_fired": fired, "event_deliveries": st["user_events_delivered"], "event_deliveries_per_simulated_s": st["user_events_delivered"] / secs,
+           "event_deliveries_per_wall_s": st["user_events_delivered"] / dt,
+           "mean_coverage_of_an_event": st["user_events_delivered"] / max(fired, 1) / max(len(live), 1),
+           "dedupe_hits": st["user_events_deduped"], "stale_events": st["user_events_stale"], "event_drops": st["event_drops"],
+           "lamport_clock_spread": {"sampled_live_nodes": len(clocks), "min": int(min(clocks)), "max": int(max(clocks))},
+           "refutes": st["refutes"], "suspicion_timeouts": st["suspicion_timeouts"], "folds": st["folds"],
+           "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"],
+           "pair_store_GB": round(12.0 * n * n / 1e9, 1)}
+    s.close()
     return out
 
 
@@ -277,6 +369,13 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="only the timed region (profiling runs): no roofline pass, no extra legs, no CPU baseline")
     ap.add_argument("--no-detection", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--config4-nodes", type=int, default=262144, help="config4 leg: nodes on this GPU (524288 = one GPU's share of BASELINE configs[3]: profiles/r03_config4_524k.json)")
+    ap.add_argument("--config4-queue-cap", type=int, default=32)
+    ap.add_argument("--config4-budget-s", type=float, default=400.0, help="config4 leg: give up (detection_complete false) after this much wall time")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--config5-nodes", type=int, default=65536)
+    ap.add_argument("--config5-seconds", type=int, default=20)
+    ap.add_argument("--config5-events", type=int, default=50, help="config5 leg: serf user events fired per simulated second")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -292,7 +391,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the control group (gloo: several ranks on ONE device, tests)")
     args = ap.parse_args()
     if args.main_only:
-        args.no_cpu_baseline = args.no_roofline = args.no_convergence = args.no_detection = args.no_config4 = True
+        args.no_cpu_baseline = args.no_roofline = args.no_convergence = args.no_detection = args.no_config4 = args.no_config5 = True
 
     # Libraries (RCCL prints a version banner) must not reach stdout: the contract is ONE JSON line.
     sys.stdout.flush()
@@ -520,6 +619,8 @@ def main():
         line["detection"] = run_detection(hip, cfg_kw, victims, G, base_quantum)
     if rank == 0 and not sharded and not args.no_config4:
         line["config4"] = run_config4(hip, args, local_rank)
+    if rank == 0 and not sharded and not args.no_config5:
+        line["config5"] = run_config5(hip, args, local_rank)
     if rank == 0 and not sharded and not args.no_convergence:
         # second half of the metric: rounds to full convergence at N ~ 1e6 (BASELINE configs[2]:
         # 1 048 576 nodes, DefaultWANConfig timers, one update rumour at node 0, fan-out sweep)

@@ -86,6 +86,10 @@ class Census(C.Structure):
                 ("all_current_ms", u32)]
 
 
+class Detection(C.Structure):
+    _fields_ = [("pairs", u64), ("by_state", u64 * 4)]
+
+
 class Edge(C.Structure):
     _fields_ = [("dst", u32), ("subject", u32), ("incarnation", u32), ("meta", u32)]
 
@@ -155,6 +159,7 @@ PROTOTYPES = {
     "swim_poll_events": (C.c_int, [SimP, P(Event), C.c_size_t, P(C.c_size_t)]),
     "swim_node_info_get": (C.c_int, [SimP, u32, u32, P(NodeInfo)]),
     "swim_census_get": (C.c_int, [SimP, u32, u32, P(Census)]),
+    "swim_detection_get": (C.c_int, [SimP, u32, P(Detection)]),
     "swim_trace_read": (C.c_int, [SimP, u32, u32, u32, u32, P(u32)]),
     "swim_stats": (C.c_int, [SimP, P(Stats)]),
     "swim_coordinate_get": (C.c_int, [SimP, u32, u32, P(Coordinate)]),

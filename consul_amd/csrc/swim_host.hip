@@ -5,7 +5,9 @@
 // in HBM, and enqueue the per-tick kernel sequence on one HIP stream (replayed from a hipGraph).
 // There is no CPU fallback: without a HIP device swim_create returns SWIM_ENODEV.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,7 +51,7 @@ struct swim_sim {
   uint32_t* d_fresh = nullptr;         // [1024] watch slots allocated by the last stimulus call (count, then slot indices)
   void *fold_zero = nullptr, *fold_ones = nullptr; size_t fold_zero_bytes = 0, fold_ones_bytes = 0;   // fold accumulators, by initial value
   // swim_xchg_*: own mailbox, the peers' mailboxes as mapped here, the captured exchange tick
-  uint8_t* mailbox = nullptr; size_t mailbox_bytes = 0; uint32_t mail_cap = 0;
+  uint8_t* mailbox = nullptr; size_t mailbox_bytes = 0; uint32_t mail_cap = 0; const char* mailbox_kind = "none";
   std::vector<void*> ipc_opened; bool xchg_connected = false;
   hipGraphExec_t graph_xchg = nullptr;
   uint4* in_buf = nullptr;             // records received from other shards
@@ -236,6 +238,24 @@ static int dalloc(swim_sim* s, T** p, size_t count) {
     if (rc_) { swim_destroy(s); return rc_; } \
   } while (0)
 
+namespace {
+// `nonce` says which PROCESS exported the mailbox (a pid does not: shards in different containers or pid namespaces often share
+// one); a raw pointer is only taken from a handle this very process exported (registry below), everything else is an IPC mapping.
+struct XchgHandle { hipIpcMemHandle_t ipc; uint64_t ptr, nonce; uint32_t rank, n_shards, mail_cap, magic; };
+static_assert(sizeof(XchgHandle) <= SWIM_XCHG_HANDLE_BYTES, "handle does not fit");
+const uint32_t kXchgMagic = 0x58434848u;
+std::mutex g_xchg_mu;
+std::vector<uint64_t> g_xchg_exported;       // mailboxes this process exported (and still owns)
+uint64_t process_nonce() {
+  static uint64_t n = [] {
+    uint64_t v = 0;
+    if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&v, 8, 1, f) != 1) v = 0; fclose(f); }
+    if (!v) v = ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&v ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    return v | 1u;
+  }();
+  return n;
+}
+}
 static void drop_graphs(swim_sim* s) {
   for (int i = 0; i < 2; i++)
     if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
@@ -353,6 +373,7 @@ extern "C" int swim_destroy(swim_sim* s) {
   }
 #endif
   drop_graphs(s);
+  if (s->mailbox) { std::lock_guard<std::mutex> g(g_xchg_mu); auto it = std::find(g_xchg_exported.begin(), g_xchg_exported.end(), (uint64_t)(uintptr_t)s->mailbox); if (it != g_xchg_exported.end()) g_xchg_exported.erase(it); }
   for (void* p : s->ipc_opened) (void)hipIpcCloseMemHandle(p);
   for (void* p : s->allocs) (void)hipFree(p);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -425,6 +446,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.mrow, NT); DALLOC(s, D.mrow_subj, RM); DALLOC(s, D.m_free, RM); DALLOC(s, D.m_nfree, D.R);
     DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
     DALLOC(s, D.m_tile_dl, RM * D.nbl); DALLOC(s, D.m_row_dl, RM); DALLOC(s, D.mcnt, NL);
+    DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mB, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mC, 0, pairs * 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.m_tile_dl, 0xFF, RM * D.nbl * 4, s->stream));
@@ -538,7 +560,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     // own shard: probe verdicts, fold census records, push-pull; other shards: their share of the gossip records, the
     // acks' piggy-back orders, carried broadcasts, fold census records, and push-pull — whose every exchange sends one
     // record per explicit view of the sender, all of a boundary tick's exchanges possibly to the same shard
-    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * ((uint64_t)D.view_cap + 3);   // explicit views + own view of the receiver + the pull request
+    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * ((uint64_t)D.view_cap + D.M + 3);   // explicit views + own view of the receiver + the pull request
     const uint64_t fold_burst = D.fold_period ? NT : 0;        // a fold tick: at most one census record per node of the population
     uint64_t cap = sh == D.rank ? 2 * NL + 4096 + pp_burst + fold_burst
                                 : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards + NL + pp_burst + fold_burst;
@@ -566,7 +588,20 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     uint32_t mc = 0; for (uint32_t sh = 0; sh < D.n_shards; sh++) if (sh != D.rank) mc = std::max(mc, D.out_cap[sh]);
     s->mail_cap = D.mail_cap = mc;
     s->mailbox_bytes = (size_t)2 * D.n_shards * 64 + (size_t)2 * D.n_shards * mc * sizeof(uint4);
-    DALLOC(s, s->mailbox, s->mailbox_bytes); HIPCK(s, hipMemset(s->mailbox, 0, (size_t)2 * D.n_shards * 64));
+    {   // The mailbox is written by OTHER devices over xGMI while this device's kernels poll its flags and then read its records
+        // inside one kernel (k_xchg_wait / k_deliver_mail): ordinary (coarse-grained) device memory is only coherent across
+        // devices at kernel boundaries, so the flag could arrive while stale record lines sit in this device's L2.
+        // Fine-grained memory is coherent at system scope for the release/acquire pair the kernels use.
+        // SWIMSIM_MAILBOX=coarse|fine|uncached overrides (experiments).
+      const char* mode = getenv("SWIMSIM_MAILBOX");
+      void* mb = nullptr; hipError_t e = hipErrorUnknown;
+      if (!mode || !strcmp(mode, "fine")) e = hipExtMallocWithFlags(&mb, s->mailbox_bytes, hipDeviceMallocFinegrained);
+      else if (!strcmp(mode, "uncached")) e = hipExtMallocWithFlags(&mb, s->mailbox_bytes, hipDeviceMallocUncached);
+      if (e != hipSuccess) { (void)hipGetLastError(); mb = nullptr; HIPCK(s, hipMalloc(&mb, s->mailbox_bytes)); s->mailbox_kind = "coarse"; }
+      else s->mailbox_kind = (mode && !strcmp(mode, "uncached")) ? "uncached" : "fine";
+      s->allocs.push_back(mb); s->alloc_bytes.push_back(s->mailbox_bytes); s->mailbox = (uint8_t*)mb;
+    }
+    HIPCK(s, hipMemset(s->mailbox, 0, (size_t)2 * D.n_shards * 64));
     DALLOC(s, D.mb_tab, SW_MAX_SHARDS); DALLOC(s, D.xin_cnt, SW_MAX_SHARDS); HIPCK(s, hipMemset(D.xin_cnt, 0, SW_MAX_SHARDS * 4));
     D.xchg_timeout_ms = 2000;
     if (const char* e = getenv("SWIMSIM_XCHG_TIMEOUT_MS")) D.xchg_timeout_ms = (uint32_t)std::max(1l, strtol(e, nullptr, 10));
@@ -645,7 +680,10 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     if (D.M) hipLaunchKernelGGL(k_fold_scan_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
-  if (D.M) hipLaunchKernelGGL(k_expire_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's suspicion timers
+  if (D.M) {   // the dense store's suspicion timers: list the due rows, then their due tiles over many waves
+    hipLaunchKernelGGL(k_expire_mass_due, dim3(cdiv((size_t)D.R * D.M, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    hipLaunchKernelGGL(k_expire_mass, dim3((uint32_t)std::min<uint64_t>(2048, cdiv((uint64_t)D.R * D.M * D.nbl, SW_BLOCK / 64))), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
   if (D.TQ % D.P == 0) {
     // degenerate timers: a node's indirect stage and its next probe fall in the same tick, in that order
     BeginPlan a = pl, b = pl; a.roles = 0x2; b.roles = pl.roles & ~0x2u;
@@ -805,18 +843,14 @@ extern "C" int swim_tick_end_begin(swim_sim* s) {
 // ---------------------------------------------------------------------------------------------
 // device-driven exchange (swimsim.h): peer-mapped mailboxes, no host round trip
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct XchgHandle { hipIpcMemHandle_t ipc; uint64_t ptr; uint32_t pid, rank, n_shards, mail_cap, magic; };
-static_assert(sizeof(XchgHandle) <= SWIM_XCHG_HANDLE_BYTES, "handle does not fit");
-const uint32_t kXchgMagic = 0x58434847u;
-}
 extern "C" int swim_xchg_export(swim_sim* s, swim_xchg_handle* out) {
   if (!s || !out) return SWIM_EINVAL;
   if (s->D.n_shards < 2 || !s->mailbox) return SWIM_ESTATE;
   XchgHandle h; memset(&h, 0, sizeof h);
   HIPCK(s, hipIpcGetMemHandle(&h.ipc, s->mailbox));
-  h.ptr = (uint64_t)(uintptr_t)s->mailbox; h.pid = (uint32_t)getpid(); h.rank = s->D.rank; h.n_shards = s->D.n_shards;
+  h.ptr = (uint64_t)(uintptr_t)s->mailbox; h.nonce = process_nonce(); h.rank = s->D.rank; h.n_shards = s->D.n_shards;
   h.mail_cap = s->mail_cap; h.magic = kXchgMagic;
+  { std::lock_guard<std::mutex> g(g_xchg_mu); if (std::find(g_xchg_exported.begin(), g_xchg_exported.end(), h.ptr) == g_xchg_exported.end()) g_xchg_exported.push_back(h.ptr); }
   memset(out, 0, sizeof *out); memcpy(out->bytes, &h, sizeof h);
   return SWIM_OK;
 }
@@ -824,13 +858,18 @@ extern "C" int swim_xchg_connect(swim_sim* s, const swim_xchg_handle* all) {
   if (!s || !all) return SWIM_EINVAL;
   if (s->D.n_shards < 2 || !s->mailbox || s->in_tick) return SWIM_ESTATE;
   uint8_t* tab[SW_MAX_SHARDS] = { nullptr };
+  for (void* p : s->ipc_opened) (void)hipIpcCloseMemHandle(p);      // a second connect: the earlier mappings go
+  s->ipc_opened.clear(); s->xchg_connected = false;
+  if (s->graph_xchg) { (void)hipGraphExecDestroy(s->graph_xchg); s->graph_xchg = nullptr; }
   for (uint32_t sh = 0; sh < s->D.n_shards; sh++) {
     if (sh == s->D.rank) { tab[sh] = s->mailbox; continue; }
     XchgHandle h; memcpy(&h, all[sh].bytes, sizeof h);
     if (h.magic != kXchgMagic || h.rank != sh || h.n_shards != s->D.n_shards || h.mail_cap != s->mail_cap) {
       snprintf(s->err, sizeof s->err, "swim_xchg_connect: handle %u does not belong to this population", sh); return SWIM_EINVAL;
     }
-    if (h.pid == (uint32_t)getpid()) tab[sh] = (uint8_t*)(uintptr_t)h.ptr;      // same process: the pointer itself
+    bool mine = false;
+    if (h.nonce == process_nonce()) { std::lock_guard<std::mutex> g(g_xchg_mu); mine = std::find(g_xchg_exported.begin(), g_xchg_exported.end(), h.ptr) != g_xchg_exported.end(); }
+    if (mine) tab[sh] = (uint8_t*)(uintptr_t)h.ptr;      // exported by this very process: the pointer itself
     else {
       void* p = nullptr;
       HIPCK(s, hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess));
@@ -1040,6 +1079,8 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
     for (uint32_t k = 1; k < 128; k++) if (cnt[k] > cnt[big]) big = k;
     std::vector<uint32_t> ids;
     for (uint32_t i = 0; i < s->D.N; i++) if (g[i] != big) ids.push_back(i);
+    if (ids.size() && ids.size() < s->D.M)      // rows to spare: the largest group's nodes too (what the minority sides will think of them)
+      for (uint32_t i = 0; i < s->D.N && ids.size() < (size_t)s->D.M + 1024; i++) if (g[i] == big) ids.push_back(i);
     const size_t chunk = s->scratch_bytes / 4;
     for (size_t off = 0; off < ids.size(); off += chunk) {
       const uint32_t c = (uint32_t)std::min(chunk, ids.size() - off);
@@ -1210,6 +1251,22 @@ extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census*
   hipLaunchKernelGGL(k_census_commit, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D);
   return d2h(s, out, (const swim_census*)D.census + (size_t)r * D.S + NW_SLOT(w), 1);
 }
+extern "C" int swim_detection_get(swim_sim* s, uint32_t r, swim_detection* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  const SwDev& D = s->D;
+  if (r >= D.R) return SWIM_ERANGE;
+  if (s->in_tick) return SWIM_ESTATE;
+  unsigned long long* acc = (unsigned long long*)s->d_scratch; uint32_t* grp = (uint32_t*)(acc + 8);
+  HIPCK(s, hipMemsetAsync(acc, 0, 64 + 129 * 4, s->stream));
+  hipLaunchKernelGGL(k_detect_groups, dim3(cdiv(D.nloc, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, grp);
+  hipLaunchKernelGGL(k_detect_base, dim3(cdiv(D.N, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)grp, acc);
+  hipLaunchKernelGGL(k_detect_tables, dim3(cdiv(D.nloc, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, acc);
+  if (D.M) hipLaunchKernelGGL(k_detect_rows, dim3(D.M), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, acc);
+  unsigned long long v[5]; int rc = d2h(s, v, (const unsigned long long*)acc, 5);
+  if (rc) return rc;
+  out->pairs = v[0]; for (int i = 0; i < 4; i++) out->by_state[i] = v[1 + i];
+  return SWIM_OK;
+}
 extern "C" int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
   if (!s || !rows) return SWIM_EINVAL;
   const SwDev& D = s->D;
@@ -1364,6 +1421,7 @@ extern "C" int swim_checkpoint_save(swim_sim* s, const char* path) {
       ok = fwrite(buf.data(), 1, c, f) == c;
     }
   }
+  ok = ok && fwrite("SWIMCKND", 8, 1, f) == 1;            // trailer: a file cut short is recognised before anything is loaded
   if (fclose(f) != 0) ok = false;
   if (!ok) snprintf(s->err, sizeof s->err, "short write to %s", path);
   return ok ? SWIM_OK : SWIM_EIO;
@@ -1381,8 +1439,23 @@ extern "C" int swim_checkpoint_load(swim_sim* s, const char* path) {
       memcmp(&h.cfg, &s->cfg, sizeof h.cfg) || h.n_arrays != n_arrays) {
     fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another library, ABI or configuration"); return SWIM_EINVAL;
   }
-  std::vector<swim_event> ev(h.n_events);
+  if (h.n_events > (1u << 24)) { fclose(f); snprintf(s->err, sizeof s->err, "checkpoint header is damaged (events)"); return SWIM_EINVAL; }
+  std::vector<swim_event> ev;
+  try { ev.resize(h.n_events); } catch (const std::exception&) { fclose(f); return SWIM_ENOMEM; }
   bool ok = h.n_events == 0 || fread(ev.data(), sizeof(swim_event), h.n_events, f) == h.n_events;
+  {   // first pass: every array's size and the trailer, BEFORE anything on the device is overwritten (a refusal is a clean refusal)
+    const long data0 = ftell(f);
+    for (size_t i = 0; ok && i < s->allocs.size(); i++) {
+      if (!ck_is_state(s, i)) continue;
+      uint64_t bytes = 0;
+      ok = fread(&bytes, 8, 1, f) == 1;
+      if (ok && bytes != s->alloc_bytes[i]) { fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another configuration (array %zu)", i); return SWIM_EINVAL; }
+      ok = ok && fseek(f, (long)bytes, SEEK_CUR) == 0;
+    }
+    char tail[8] = { 0 };
+    if (!ok || fread(tail, 8, 1, f) != 1 || memcmp(tail, "SWIMCKND", 8)) { fclose(f); snprintf(s->err, sizeof s->err, "checkpoint truncated or damaged: nothing was loaded"); return SWIM_EIO; }
+    fseek(f, data0, SEEK_SET);
+  }
   const size_t CH = (size_t)32 << 20;
   std::vector<char> buf(CH);
   for (size_t i = 0; ok && i < s->allocs.size(); i++) {

@@ -1727,9 +1727,10 @@ struct NodeCtxT {
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
   __device__ __forceinline__ View lookup(uint32_t x) {
     View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
+    const uint32_t row = D.M ? D.mrow[(size_t)r * D.N + x] : NONE;      // (fetched next to the node word: one round trip, not two)
     v.w = D.nw[(size_t)r * D.N + x];
     if (v.w & NW_MASS) {                                   // the subject owns a row of the dense store: pair (row, this lane)
-      const uint32_t row = D.mrow[(size_t)r * D.N + x]; const size_t idx = m_idx(D, r, row, k);
+      const size_t idx = m_idx(D, r, row, k);
       const uint32_t a = D.mA[idx], b = D.mB[idx], c = D.mC[idx];
       v.free_slot = SW_MASS_SLOT | row; v.c = make_uint4(0, 0, 0, 0); v.c_have = true;
       if (a) { v.slot = v.free_slot; v.e = m_unpack(D, x, a, b, c, v.c.x); return v; }
@@ -2377,6 +2378,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     D.pend_cnt[(t + 1) % (D.TQ + 1)] = 0;      // the list the next tick appends to (just consumed)
     if (D.join_cnt) *D.join_cnt = 0;           // the joins of this tick are under way
     if (D.c_cnt) *D.c_cnt = 0;                 // this tick's coordinate updates are committed
+    if (D.m_due_cnt) *D.m_due_cnt = 0;         // the dense store's due rows were looked at
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
@@ -2981,22 +2983,37 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
 // =================================================================================================
 // the dense pair store (swim_device.h): suspicion timers, fold, row allocation
 // =================================================================================================
-// suspectNode's time.AfterFunc for the pairs of the dense store: one workgroup per row; out after one word unless the row's
-// bound has passed, then only the 256-observer tiles whose bound has passed are looked at (one wave per tile).  A verdict goes
-// straight into the observer's inbox like role_expire's.
+// suspectNode's time.AfterFunc for the pairs of the dense store, two launches: k_expire_mass_due lists the rows whose bound has
+// passed (one thread per row: a quiet tick costs one word per row); k_expire_mass spreads the 256-observer tiles of the listed
+// rows over its waves — one failure per cluster is ONE row with all the cluster's timers in it, a mass event thousands of rows
+// with a few due tiles each — and looks only into tiles whose own bound has passed.  A verdict goes straight into the
+// observer's inbox like role_expire's.
+__global__ void __launch_bounds__(SW_BLOCK) k_expire_mass_due(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t rr = blockIdx.x * SW_BLOCK + threadIdx.x, now = now_ms(D, *D.tick);
+  bool due = false;
+  if (rr < D.R * D.M && now >= D.m_row_dl[rr]) { D.m_row_dl[rr] = NONE; due = D.mrow_subj[rr] != NONE; }   // (k_expire_mass rebuilds the bound from the tiles')
+  const uint64_t mask = __ballot(due);
+  if (!mask) return;
+  const uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(D.m_due_cnt, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (due) D.m_due[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = rr;
+}
 __global__ void __launch_bounds__(SW_BLOCK) k_expire_mass(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
-  const uint32_t rr = blockIdx.x, now = now_ms(D, *D.tick);
-  if (now < D.m_row_dl[rr]) return;
-  const uint32_t r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr], lane = sw_lane(), wave = threadIdx.x / 64;
-  __shared__ uint32_t s_min[SW_BLOCK / 64];
-  uint32_t row_min = NONE, fired = 0;
-  if (x != NONE) {
-    uint32_t* tiles = D.m_tile_dl + (size_t)rr * D.nbl;
-    for (uint32_t tile = wave; tile < D.nbl; tile += SW_BLOCK / 64) {
-      const uint32_t tb = tiles[tile];
-      if (now < tb) { row_min = tb < row_min ? tb : row_min; continue; }
-      uint32_t m = NONE;
+  const uint32_t n_due = *D.m_due_cnt;
+  if (!n_due) return;
+  const uint32_t now = now_ms(D, *D.tick), lane = sw_lane();
+  const uint64_t items = (uint64_t)n_due * D.nbl, stride = (uint64_t)gridDim.x * (SW_BLOCK / 64);
+  uint32_t fired = 0;
+  for (uint64_t it = (uint64_t)blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64; it < items; it += stride) {
+    const uint32_t rr = D.m_due[it / D.nbl], tile = (uint32_t)(it % D.nbl), r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr];
+    uint32_t* tb = &D.m_tile_dl[(size_t)rr * D.nbl + tile];
+    uint32_t m = *tb;
+    if (now >= m) {
+      m = NONE;
       for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
         const uint32_t k = tile * SW_BLOCK + part * 64 + lane;
         if (k >= D.nloc) continue;
@@ -3014,18 +3031,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_expire_mass(const SwDev* __restric
         m = dl < m ? dl : m;           // a fired timer keeps the bound low until its verdict is merged
       }
       for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
-      if (lane == 0) tiles[tile] = m;
-      row_min = m < row_min ? m : row_min;
+      if (lane == 0) *tb = m;
     }
+    if (lane == 0 && m < D.m_row_dl[rr]) atomicMin(&D.m_row_dl[rr], m);
   }
-  for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(row_min, off); row_min = v < row_min ? v : row_min; }
-  if (lane == 0) s_min[wave] = row_min;
   if (__any(fired != 0)) {
     for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
     if (lane == 0) { atomicAdd(stat_ptr(D, ST_TIMEOUTS), (unsigned long long)fired); atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)fired); }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t m = s_min[0]; for (uint32_t w = 1; w < SW_BLOCK / 64; w++) m = s_min[w] < m ? s_min[w] : m; D.m_row_dl[rr] = m; }
 }
 // fold census of the dense store (k_fold_scan's counterpart): what the acting observers hold about the row's subject
 __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_mass(const SwDev* __restrict__ Dp) {
@@ -3118,4 +3131,69 @@ __global__ void k_mass_init(const SwDev* __restrict__ Dp) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)D.R * D.M;
   if (i < n) { D.mrow_subj[i] = NONE; D.m_row_dl[i] = NONE; D.m_free[i] = D.M - 1 - (uint32_t)(i % D.M); }   // (row 0 is handed out first)
   if (i < D.R) D.m_nfree[i] = D.M;
+}
+
+// =================================================================================================
+// swim_detection_get (swimsim.h): how the acting observers of this shard see the nodes out of their reach.  acc = {pairs,
+// state 0..3} as 64-bit sums (corrections wrap around), grp = acting observers per partition group [128] + their total [128]
+// =================================================================================================
+__device__ __forceinline__ void det_add(unsigned long long* acc, int i, long long v) {
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+  if (sw_lane() == 0 && v) atomicAdd(&acc[i], (unsigned long long)v);
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_detect_groups(const SwDev* __restrict__ Dp, uint32_t r, uint32_t* grp) {
+  SW_DEV_BIND
+  const uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (k >= D.nloc) return;
+  const uint32_t w = D.nw[(size_t)r * D.N + D.i0 + k];
+  if (!(w & NW_INERT)) { atomicAdd(&grp[NW_PART(w)], 1u); atomicAdd(&grp[128], 1u); }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_detect_base(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* grp, unsigned long long* acc) {
+  SW_DEV_BIND
+  const uint32_t x = blockIdx.x * SW_BLOCK + threadIdx.x;
+  long long n_obs = 0; uint32_t st = 0;
+  if (x < D.N) {
+    const uint32_t w = D.nw[(size_t)r * D.N + x];
+    n_obs = (w & NW_DEAD) ? (long long)grp[128] : (long long)grp[128] - (long long)grp[NW_PART(w)];
+    st = SW_KST(base_key_of(D, r, x, w));
+  }
+  det_add(acc, 0, n_obs);
+  for (uint32_t c = 0; c < 4; c++) det_add(acc, 1 + (int)c, st == c ? n_obs : 0);
+}
+// corrections by the explicit views: the hash tables (one lane per observer) ...
+__global__ void __launch_bounds__(SW_BLOCK) k_detect_tables(const SwDev* __restrict__ Dp, uint32_t r, unsigned long long* acc) {
+  SW_DEV_BIND
+  const uint32_t k = blockIdx.x * SW_BLOCK + threadIdx.x;
+  long long d[4] = { 0, 0, 0, 0 };
+  if (k < D.nloc) {
+    const size_t NL = (size_t)D.R * D.nloc, l = (size_t)r * D.nloc + k;
+    const uint32_t o = D.i0 + k, wo = D.nw[(size_t)r * D.N + o];
+    uint32_t left = (wo & NW_INERT) ? 0u : D.vmeta[l].x;
+    for (uint32_t sl = 0; sl < D.VT && left; sl++) {
+      const uint4 e = D.vt[(size_t)sl * NL + l];
+      if (e.x == VT_EMPTY) continue;
+      left--;
+      if (e.x == o) continue;
+      const uint32_t wx = D.nw[(size_t)r * D.N + e.x];
+      if (!(wx & NW_DEAD) && NW_PART(wx) == NW_PART(wo)) continue;          // within reach
+      d[SW_KST(base_key_of(D, r, e.x, wx))]--; d[SW_KST(e.y)]++;
+    }
+  }
+  for (int c = 0; c < 4; c++) det_add(acc, 1 + c, d[c]);
+}
+// ... and the dense store (one workgroup per row)
+__global__ void __launch_bounds__(SW_BLOCK) k_detect_rows(const SwDev* __restrict__ Dp, uint32_t r, unsigned long long* acc) {
+  SW_DEV_BIND
+  const uint32_t row = blockIdx.x, x = D.mrow_subj[(size_t)r * D.M + row];
+  if (x == NONE) return;
+  const uint32_t wx = D.nw[(size_t)r * D.N + x], bst = SW_KST(base_key_of(D, r, x, wx));
+  long long d[4] = { 0, 0, 0, 0 };
+  for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
+    const uint32_t a = D.mA[m_idx(D, r, row, k)], o = D.i0 + k;
+    if (!a || o == x) continue;
+    const uint32_t wo = D.nw[(size_t)r * D.N + o];
+    if ((wo & NW_INERT) || (!(wx & NW_DEAD) && NW_PART(wx) == NW_PART(wo))) continue;
+    d[bst]--; d[MA_STATE(a)]++;
+  }
+  for (int c = 0; c < 4; c++) det_add(acc, 1 + c, d[c]);
 }

@@ -247,8 +247,20 @@ class ShardedSim:
             for k, v in st.items():
                 if k in ("ticks", "gossip_rounds"):
                     continue
+                if k == "inbox_peak":
+                    tot[k] = max(tot[k], v)
+                    continue
                 tot[k] = [a + b for a, b in zip(tot[k], v)] if isinstance(v, list) else tot[k] + v
         return tot
+
+    def detection(self, replica: int = 0):
+        """swim_detection_get summed over the shards (each counts its own observers)."""
+        pairs, by = 0, [0, 0, 0, 0]
+        for s in self.sims:
+            p, b = s.detection(replica)
+            pairs += p
+            by = [x + y for x, y in zip(by, b)]
+        return pairs, by
 
     def close(self):
         if hasattr(self.exchange, "close"):

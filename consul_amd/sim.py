@@ -247,6 +247,12 @@ class Sim:
         self._ck("swim_census_get", self._l.swim_census_get(self._h, replica, subject, C.byref(o)))
         return o
 
+    def detection(self, replica: int = 0):
+        """(pairs, [alive, suspect, dead, left]) over (acting observer, unreachable subject) pairs: swim_detection_get."""
+        o = abi.Detection()
+        self._ck("swim_detection_get", self._l.swim_detection_get(self._h, replica, C.byref(o)))
+        return int(o.pairs), [int(x) for x in o.by_state]
+
     def trace(self, replica: int, subject: int, first_tick: int, n: int) -> np.ndarray:
         out = np.zeros((n, 5), dtype=np.uint32)
         self._ck("swim_trace_read", self._l.swim_trace_read(

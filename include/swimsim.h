@@ -411,6 +411,15 @@ int swim_watch(swim_sim* sim, uint32_t replica, uint32_t subject);
 int swim_poll_events(swim_sim* sim, swim_event* out, size_t cap, size_t* n_out);
 int swim_node_info_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_node_info* out);
 int swim_census_get(swim_sim* sim, uint32_t replica, uint32_t subject, swim_census* out);
+/* BASELINE config #4's deliverable ("rounds until all survivors mark all victims dead"), for any mix of stopped and
+ * partitioned nodes: over all ordered pairs (observer o, subject x != o) where o is a node of THIS shard the simulator acts
+ * for and x is out of o's reach right now (x is not running, or sits in another partition group), how o sees x.  Detection is
+ * complete when by_state[SWIM_STATE_DEAD] + by_state[SWIM_STATE_LEFT] == pairs.  A sharded population sums its shards'. */
+typedef struct swim_detection {
+  uint64_t pairs;                   /* (observer, unreachable subject) pairs                  */
+  uint64_t by_state[4];             /* the observers' views of those subjects, by SWIM_STATE_* */
+} swim_detection;
+int swim_detection_get(swim_sim* sim, uint32_t replica, swim_detection* out);
 /* per-tick census history of `subject` (infection / detection curves): rows for ticks
  * [first_tick, first_tick+n), each {by_state[4], n_current} = 5 x u32 */
 int swim_trace_read(swim_sim* sim, uint32_t replica, uint32_t subject, uint32_t first_tick,

@@ -450,7 +450,7 @@ inline PushPull decode_push_pull(const uint8_t* p, size_t n) {
   { size_t k = r.map(); for (size_t i = 0; i < k; i++) { std::string key = r.str();
       if (key == "Nodes") nodes = r.uint(); else if (key == "UserStateLen") ulen = r.uint(); else if (key == "Join") m.join = r.boolean(); else r.skip(); } }
   if (nodes > r.left() || ulen > r.left()) throw DecodeError("push-pull header promises more than the stream holds");
-  m.nodes.reserve(size_t(nodes));
+  m.nodes.reserve(size_t(std::min<uint64_t>(nodes, r.left() / 8)));     // (a node record is at least a map header and a few keys: never trust the count for memory)
   for (uint64_t j = 0; j < nodes; j++) {
     PushNodeState s; size_t k = r.map();
     for (size_t i = 0; i < k; i++) { std::string key = r.str();
@@ -570,7 +570,7 @@ struct Probe { bool indirect = false; uint32_t seq_no = 0; bool nack = false; st
 struct UnsupportedPacket : DecodeError { using DecodeError::DecodeError; };   // encryptMsg: not decodable here
 inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm = Naming(), size_t* control = nullptr, size_t* foreign = nullptr,
                                           std::vector<Probe>* probes = nullptr) {
-  std::vector<swim_edge> out; size_t n_control = 0, n_foreign = 0;
+  std::vector<swim_edge> out; size_t n_control = 0, n_foreign = 0, layers = 0;
   std::vector<Bytes> todo{ strip_crc(strip_label(packet, nullptr)) };
   while (!todo.empty()) {
     Bytes m = std::move(todo.back()); todo.pop_back();
@@ -598,7 +598,7 @@ inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm 
       case kPing: { n_control++; if (probes) { Ping pg = decode_ping(body, n); Probe pr; pr.seq_no = pg.seq_no; pr.node = pg.node; probes->push_back(pr); } break; }
       case kIndirectPing: { n_control++; if (probes) { IndirectPing ip = decode_indirect_ping(body, n); Probe pr; pr.indirect = true; pr.seq_no = ip.seq_no; pr.nack = ip.nack; pr.node = ip.node; pr.target = ip.target; probes->push_back(pr); } break; }
       // memberlist's DefaultLANConfig has EnableCompression = true (Consul's default): the payload is a whole message again
-      case kCompress: todo.push_back(decompress(body, n)); break;
+      case kCompress: if (++layers > 1) throw DecodeError("compressMsg inside compressMsg"); todo.push_back(decompress(body, n)); break;   // (memberlist compresses once)
       // Consul may encrypt gossip: such a packet carries rumours this codec cannot see.  Losing them silently would be worse
       // than refusing the packet.
       case kEncrypt: throw UnsupportedPacket("encryptMsg: gossip encryption is not supported by the bridge");
@@ -632,7 +632,7 @@ class BridgeTransport {
     if (!resolve(to, &dst)) return SWIM_EINVAL;
     size_t control = 0, foreign = 0; std::vector<Probe> probes; std::vector<swim_edge> recs;
     try { recs = from_packet(packet, nm_, &control, &foreign, &probes); }
-    catch (const DecodeError&) { unsupported_seen_++; return SWIM_EINVAL; }      // encrypted, or malformed (a hostile or truncated packet): refused whole
+    catch (const std::exception&) { unsupported_seen_++; return SWIM_EINVAL; }   // encrypted, or malformed (a hostile or truncated packet, also one that asks for absurd amounts of memory): refused whole
     control_seen_ += control; foreign_seen_ += foreign;
     // probeNode of the real node: the virtual peer answers like handlePing / handleIndirectPing would — an ackResp when it
     // (and, for an indirect ping, the target behind it) is running and in the real node's partition, a nackResp for a
@@ -674,7 +674,10 @@ class BridgeTransport {
   Bytes PushPull(const Bytes& stream, const std::string& to) {
     uint32_t dst;
     if (!resolve(to, &dst) || n_nodes_ == 0) return {};
-    wire::PushPull in = from_stream(stream, nullptr);
+    wire::PushPull in;
+    try { in = from_stream(stream, nullptr); }
+    catch (const DecodeError&) { throw; }
+    catch (const std::exception& e) { throw DecodeError(std::string("push-pull stream refused: ") + e.what()); }   // (bad_alloc / length_error of a hostile stream: one error type at the boundary)
     if (dst == self_ || !up_and_reachable(dst)) return {};
     std::vector<swim_edge> recs;
     for (const PushNodeState& n : in.nodes) {

@@ -1748,6 +1748,29 @@ int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {
   if (t->dirty) census_slot(s, r, t);
   *out = t->census; return SWIM_OK;
 }
+/* config #4's deliverable: how the acting observers of this shard see the nodes out of their reach (swimsim.h).  What the
+ * base row says about x is held by every observer without an explicit view: counted per subject in closed form, then
+ * corrected by the explicit views. */
+int swim_detection_get(swim_sim* s, uint32_t r, swim_detection* out) {
+  if (!s || !out) return SWIM_EINVAL; if (r >= s->R) return SWIM_ERANGE;
+  memset(out, 0, sizeof *out);
+  uint64_t cnt[256] = { 0 }, total = 0; size_t base = (size_t)r * s->N;
+  for (uint32_t k = 0; k < s->nloc; k++) { uint32_t o = s->i0 + k; if (acts(s, r, o)) { cnt[s->part[base + o]]++; total++; } }
+  for (uint32_t x = 0; x < s->N; x++) {
+    uint64_t n_obs = !s->gt_alive[base + x] ? total : total - cnt[s->part[base + x]];
+    out->pairs += n_obs; out->by_state[KST(s->base_key[base + x])] += n_obs;
+  }
+  for (uint32_t k = 0; k < s->nloc; k++) {
+    uint32_t o = s->i0 + k; if (!acts(s, r, o)) continue;
+    const vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
+    for (uint32_t i = 0; i < t->slots; i++) {
+      const view_t* v = &t->e[i]; if (v->subj == V_EMPTY || v->subj == o) continue;
+      if (s->gt_alive[base + v->subj] && s->part[base + v->subj] == s->part[base + o]) continue;   /* within reach */
+      out->by_state[KST(s->base_key[base + v->subj])]--; out->by_state[KST(v->key)]++;
+    }
+  }
+  return SWIM_OK;
+}
 int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_t n, uint32_t* rows) {
   if (!s || !rows) return SWIM_EINVAL; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
   uint32_t sl = s->node_slot[(size_t)r * s->N + x];

@@ -4,10 +4,9 @@ import numpy as np
 
 from consul_amd import abi
 
-# BASELINE config #4's shape on one GPU: 5 % of the nodes cut off at once (partition mask, both directions)
-PARTITION_262K = dict(n_nodes=262144, seed=11, view_cap=64, queue_cap=8, inbox_cap=128, subject_cap=4)
-# BASELINE config #5's shape: every second 10 % of the nodes flip alive <-> dead
-CHURN_131K = dict(n_nodes=131072, seed=12, view_cap=32, queue_cap=8, inbox_cap=128, subject_cap=4, fold_interval_ms=5000)
+# 5 % of the nodes cut off at once (partition mask, both directions) with views bounded at 64 per observer: what the CAPS do
+# (drops, evictions) — run at 32 768 nodes beside the checker; configs #4 / #5 themselves run with nothing dropped (below)
+PARTITION_CAPPED = dict(n_nodes=32768, seed=11, view_cap=64, queue_cap=8, inbox_cap=128, subject_cap=4)
 
 STAT_KEYS = ("packets_sent", "msgs_sent", "msgs_applied", "probes", "probe_failures", "suspicion_timeouts", "confirmations",
              "refutes", "queue_drops", "view_drops", "view_evictions", "folds", "fold_freed", "inbox_overflow")
@@ -74,4 +73,80 @@ def run_partition_heal(sim, n, checkpoints=(46, 76, 136)):
             sim.sync()
             st = sim.stats()
             out[sec] = (sim.digest(), {k: st[k] for k in STAT_KEYS + ("push_pulls",)})
+    return out
+
+
+# BASELINE config #4 with NOTHING dropped: 5 % of the nodes stop at once and the run goes on until every survivor holds every
+# victim dead.  The checker keeps the views in per-observer hash tables big enough for all of them; the HIP library in the dense
+# pair store (mass_rows) with hash tables of 8.  Common part first, then what differs by library.
+MASS_KILL_64K = dict(n_nodes=65536, seed=11, queue_cap=32, inbox_cap=6808, subject_cap=8)
+MASS_KILL_64K_ORACLE = dict(view_cap=3276 + 64)
+MASS_KILL_64K_HIP = dict(view_cap=8, mass_rows=3276 + 8)
+MASS_STAT_KEYS = STAT_KEYS + ("inbox_peak", "push_pulls", "edges")
+
+
+def mass_victims(n, share=0.05, rng_seed=44):
+    return np.random.default_rng(rng_seed).choice(n, size=int(n * share), replace=False)
+
+
+def run_mass_kill(sim, n, checkpoints, until_detected=True, limit_s=2000):
+    """1 s of quiet, the victims stop; {second: (digest, stats subset, detection)} at the checkpoints and at the first
+    multiple of 50 s at which detection is complete (key "done")."""
+    out = {}
+    sim.step_ms(1000)
+    sim.kill(0, mass_victims(n).tolist())
+    for sec in range(2, limit_s + 1):
+        sim.step_ms(1000)
+        at_check = sec in checkpoints
+        if at_check or (until_detected and sec % 50 == 0):
+            sim.sync()
+            pairs, by = sim.detection(0)
+            complete = pairs and by[2] + by[3] == pairs
+            if at_check or complete:
+                st = sim.stats()
+                rec = (sim.digest(), {k: st[k] for k in MASS_STAT_KEYS}, [pairs] + by)
+                if at_check:
+                    out[sec] = rec
+                if complete:
+                    out["done"] = (sec,) + rec
+                    break
+    return out
+
+
+# BASELINE config #5's shape with nothing dropped: 10 %/s churn (kill / revive) AND a flood of serf user events, Lifeguard on.
+# Every node becomes a subject: the checker holds N views per observer in its hash tables, the HIP library a row per node.
+CHURN_EVENTS_8K = dict(n_nodes=8192, seed=12, queue_cap=16, event_queue_cap=16, inbox_cap=8192, subject_cap=4, fold_interval_ms=5000,
+                       flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=0)
+CHURN_EVENTS_8K_ORACLE = dict(view_cap=8192)
+CHURN_EVENTS_8K_HIP = dict(view_cap=8, mass_rows=8192)
+EVENT_STAT_KEYS = STAT_KEYS + ("user_events_delivered", "user_events_deduped", "user_events_stale", "event_drops", "inbox_peak")
+
+
+def run_churn_events(sim, n, seconds, events_per_s=20, share=0.10, rng_seed=46, checkpoints=()):
+    """Every simulated second: `share` of the nodes flip alive <-> dead, then `events_per_s` user events are fired from
+    uniformly drawn live origins (never the watch node's slot 0 victim: origins are drawn among the running nodes)."""
+    rng = np.random.default_rng(rng_seed)
+    dead = np.zeros(n, dtype=bool)
+    out, ltimes, events = {}, [], []
+    for sec in range(1, seconds + 1):
+        flip = rng.choice(np.arange(1, n), size=int(n * share), replace=False)      # node 0 (the watch node) stays up
+        kill, revive = flip[~dead[flip]], flip[dead[flip]]
+        dead[flip] = ~dead[flip]
+        if len(kill):
+            sim.kill(0, kill.tolist())
+        if len(revive):
+            sim.revive(0, revive.tolist())
+        live = np.flatnonzero(~dead)
+        for origin in rng.choice(live, size=events_per_s, replace=False):
+            ltimes.append(sim.user_event(0, int(origin), int(rng.integers(1 << 30))))
+        sim.step_ms(1000)
+        while True:                                  # the watch node's EventCh, drained every second like a consumer would
+            got = sim.poll_events()
+            events.extend(got)
+            if len(got) < 4096:
+                break
+        if sec in checkpoints:
+            sim.sync()
+            st = sim.stats()
+            out[sec] = (sim.digest(), {k: st[k] for k in EVENT_STAT_KEYS}, list(ltimes), len(events), [x for e in events for x in e])
     return out

@@ -116,3 +116,62 @@ def test_rows_run_out_gracefully(hip, oracle):
     for sec in range(10):
         a.step_ms(4000); b.step_ms(4000)
         assert_same(a, b, tag=f"t={4 * sec + 5}s")
+
+
+def test_partition_both_directions_in_rows(hip, oracle):
+    """BASELINE config #4 as written — a partition mask, both directions: the majority declares the minority dead AND the
+    minority the majority.  With a row for every node both directions live in the dense store; compared with the checker
+    (state, counters, swim_detection_get) every 5 s for 200 s."""
+    n = 4096
+    mask = np.zeros(n, dtype=np.uint8); mask[np.random.default_rng(5).choice(n, size=n // 20, replace=False)] = 1
+    a, b = pair(hip, oracle, dict(mass_rows=n, view_cap=8), dict(view_cap=n), n_nodes=n, seed=5, queue_cap=32, inbox_cap=2 * n, subject_cap=4)
+    for s in (a, b):
+        s.step_ms(1000); s.partition(0, mask)
+    for sec in range(5, 200, 5):
+        a.step_ms(5000); b.step_ms(5000)
+        assert_same(a, b, tag=f"t={sec + 1}s")
+        da, db = a.detection(0), b.detection(0)
+        assert da == db, (sec, da, db)
+    # the majority (3 892 probers) is through with the 204 after ~100 s; the 204 — each probing one node a second, ever slower as
+    # their Lifeguard awareness rises — are still working on the 3 892
+    nv = int(mask.sum())
+    assert da[0] == 2 * nv * (n - nv) and nv * (n - nv) <= da[1][2] + da[1][3] < da[0] and a.stats()["view_drops"] == 0
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_mass_failure_sharded_in_process(hip, oracle, n_shards):
+    """The dense store is per shard (its columns are the shard's observers): 2 and 4 shards on one device against the unsharded
+    checker, records through the split tick (LocalExchange) and through the library's own mailboxes."""
+    from consul_amd.dist import LibraryExchange, LocalExchange, ShardedSim
+    n, nv = 8192, 400
+    victims = np.random.default_rng(9).choice(n, size=nv, replace=False)
+    kw = dict(n_nodes=n, seed=9, queue_cap=16, inbox_cap=2048, subject_cap=4, fold_interval_ms=20000)
+    for xchg in (LocalExchange, LibraryExchange):
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, mass_rows=nv + 8, view_cap=8, **kw)) for i in range(n_shards)], xchg())
+        b = Sim(oracle, preset(oracle, abi.PRESET_LAN, view_cap=nv + 64, **kw))
+        for s in (a, b):
+            s.step_ms(1000); s.kill(0, victims.tolist())
+        for sec in range(0, 60, 4):
+            a.step_ms(4000); b.step_ms(4000); a.sync()
+            assert a.digest() == b.digest(), (xchg.__name__, sec)
+            assert a.detection(0) == b.detection(0)
+        sa, sb = a.stats(), b.stats()
+        for k in ("msgs_applied", "suspicion_timeouts", "confirmations", "probe_failures", "packets_sent", "push_pulls", "folds"):
+            assert sa[k] == sb[k], k
+        assert sa["view_drops"] == 0
+        a.close(); b.close()
+
+
+def test_checkpoint_with_rows(hip, tmp_path):
+    """The dense store is ordinary state: a run resumed from a checkpoint taken in the middle of a mass event equals the
+    uninterrupted one."""
+    n, nv = 4096, 200
+    victims = np.random.default_rng(4).choice(n, size=nv, replace=False).tolist()
+    kw = dict(n_nodes=n, seed=4, mass_rows=nv + 8, view_cap=8, queue_cap=16, inbox_cap=1024)
+    a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw)); c = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    a.step_ms(1000); a.kill(0, victims); a.step_ms(12000)
+    path = str(tmp_path / "mass.ckpt")
+    a.save(path); c.load(path)
+    assert a.digest() == c.digest()
+    a.step_ms(30000); c.step_ms(30000)
+    assert a.digest() == c.digest() and a.stats() == c.stats() and a.detection(0) == c.detection(0)

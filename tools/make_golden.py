@@ -60,28 +60,44 @@ def _checkpoints(res):
     return {str(sec): {"digest": f"{d:#018x}", "stats": st} for sec, (d, st) in res.items()}
 
 
-def config4_partition():
-    """BASELINE config #4's shape on one GPU: 262 144 nodes, 5 % cut off at once, bounded explicit views (tests/scenarios.py)."""
+def config4_mass_kill():
+    """BASELINE config #4's dynamics with nothing dropped, 65 536 nodes: 3 276 nodes stop at once; to full detection."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import scenarios as sc
-    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.PARTITION_262K))
-    return {"config": sc.PARTITION_262K, "checkpoints": _checkpoints(sc.run_partition(s, sc.PARTITION_262K["n_nodes"], 8, (3, 8)))}
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.MASS_KILL_64K, **sc.MASS_KILL_64K_ORACLE))
+    res = sc.run_mass_kill(s, sc.MASS_KILL_64K["n_nodes"], (5, 15, 30, 60, 120, 300))
+    out = {"config": sc.MASS_KILL_64K, "oracle_only": sc.MASS_KILL_64K_ORACLE, "checkpoints": {}}
+    for k, v in res.items():
+        if k == "done":
+            out["done"] = {"second": v[0], "digest": f"{v[1]:#018x}", "stats": v[2], "detection": v[3]}
+        else:
+            out["checkpoints"][str(k)] = {"digest": f"{v[0]:#018x}", "stats": v[1], "detection": v[2]}
+    return out
 
 
-def config5_churn():
-    """BASELINE config #5's shape: 131 072 nodes, 10 %/s churn for 60 s, fold every 5 s (tests/scenarios.py)."""
+def config5_churn_events():
+    """BASELINE config #5's shape with nothing dropped, 8 192 nodes: 10 %/s churn and 20 serf user events/s for 40 s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import scenarios as sc
-    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.CHURN_131K))
-    return {"config": sc.CHURN_131K, "checkpoints": _checkpoints(sc.run_churn(s, sc.CHURN_131K["n_nodes"], 60, checkpoints=(20, 60)))}
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.CHURN_EVENTS_8K, **sc.CHURN_EVENTS_8K_ORACLE))
+    res = sc.run_churn_events(s, sc.CHURN_EVENTS_8K["n_nodes"], 40, checkpoints=(10, 20, 40))
+    return {"config": sc.CHURN_EVENTS_8K, "oracle_only": sc.CHURN_EVENTS_8K_ORACLE,
+            "checkpoints": {str(k): {"digest": f"{v[0]:#018x}", "stats": v[1], "ltimes_fnv": hash_list(v[2]), "watch_node_events": v[3],
+                                     "watch_node_events_fnv": hash_list(v[4])} for k, v in res.items()}}
+
+
+def hash_list(xs):
+    h = 0xcbf29ce484222325
+    for x in xs:
+        h = ((h ^ (int(x) & 0xFFFFFFFF)) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:#018x}"
 
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small),
-                     ("config3_infection_1m", config3_full), ("config4_partition_262k", config4_partition),
-                     ("config5_churn_131k", config5_churn)):
+                     ("config3_infection_1m", config3_full), ("config4_mass_kill_64k", config4_mass_kill), ("config5_churn_events_8k", config5_churn_events)):
         if only and name not in only:
             continue
         with open(os.path.join(ROOT, "tests", "golden", name + ".json"), "w") as f:
