@@ -302,13 +302,45 @@ def run_config4(hip, args, device) -> dict:
     return out
 
 
+def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, barrier, allreduce_max) -> dict:
+    """BASELINE configs[3] across the ranks: one population block-partitioned over the GPUs, 5 % stopped at once, the 30 s after
+    the failure (the phase in which every node learns of every victim: the exchange carries ~7/8 of all records).  Sized so that
+    the dense pair store fits: every rank holds (victims of the WHOLE population) x (its own observers) pairs of 12 bytes —
+    524 288 nodes on 2 ranks, 1 048 576 on 4 or 8 (the full 4 194 304 with 209 715 victims would need 1.3 TB per rank: DESIGN §4a)."""
+    from consul_amd.dist import LibraryExchange, ShardedSim
+    n = int(os.environ.get("SWIMSIM_BENCH_C4S_NODES", 0)) or (524288 if world <= 2 else 1048576)      # (the override: tests on one device)
+    nv = n // 20
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=16, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+              device=device, shard_rank=rank, n_shards=world)
+    victims = np.random.default_rng(args.seed).choice(n, size=nv, replace=False)
+    s = ShardedSim(Sim(hip, preset(hip, abi.PRESET_LAN, **kw)), LibraryExchange(gather_handles))
+    G, q = s.sim.derived.gossip_period, s.sim.derived.quantum_ms
+    s.step_ms(1000); s.kill(0, victims.tolist()); s.sync(); barrier()
+    t0 = time.perf_counter()
+    s.step_ms(30000); s.sync(); barrier()
+    dt = allreduce_max(time.perf_counter() - t0)
+    got = [None] * world
+    dist.all_gather_object(got, (s.sim.stats(), s.sim.detection(0)))
+    s.close()
+    st = {k: sum(g[0][k] for g in got) for k in ("edges", "edges_remote", "view_drops", "queue_drops", "inbox_overflow")}
+    pairs = sum(g[1][0] for g in got); dead = sum(g[1][1][2] + g[1][1][3] for g in got); susp = sum(g[1][1][1] for g in got)
+    ticks = 31000 // q
+    return {"workload": f"{n} nodes block-partitioned over {world} GPUs, {nv} stopped at once, LAN timers, k = 3: the 30 s after the failure; "
+                        "dense pair store per rank, the library's mailbox exchange",
+            "n_nodes": n, "victims": nv, "wall_s": round(dt, 2), "rounds_per_sec": 30000 / q / G / dt, "value": n * (30000 / q / G) / dt, "unit": "node-rounds/s",
+            "pairs": pairs, "suspect_fraction": susp / max(pairs, 1), "dead_fraction": dead / max(pairs, 1),
+            "a2a_bytes_per_tick_all_ranks": 16.0 * st["edges_remote"] / ticks, "a2a_bytes_per_tick_per_rank": 16.0 * st["edges_remote"] / ticks / world,
+            "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_overflow": st["inbox_overflow"],
+            "inbox_peak": max(g[0]["inbox_peak"] for g in got), "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
+
+
 def run_config5(hip, args, device) -> dict:
     """BASELINE configs[4]'s shape on one GPU: N nodes (default 65 536), LAN timers, Lifeguard on (the default flags), 10 % of the
     nodes flip alive <-> dead every second (kill / revive: a node that comes back refutes with a higher incarnation), and a flood
     of serf user events (E per second from uniformly drawn live origins, Lamport-clocked, 512-slot event buffer).  Every node is
     a subject sooner or later: all views live in the dense pair store (mass_rows = N), nothing may be dropped."""
     n, secs, E = args.config5_nodes, args.config5_seconds, args.config5_events
-    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=16, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=32, event_ids_per_ltime=62, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
               fold_interval_ms=5000, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=abi.NONE, device=device)
     s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
     G, q = s.derived.gossip_period, s.derived.quantum_ms
@@ -327,10 +359,11 @@ def run_config5(hip, args, device) -> dict:
         if len(revive):
             s.revive(0, revive.tolist())
         live = np.flatnonzero(~dead)
-        for origin in rng.choice(live, size=E, replace=False):
-            s.user_event(0, int(origin), int(rng.integers(1 << 30)))
-            fired += 1
-        s.step_ms(1000)
+        for tenth in range(10):                        # the events of a second arrive spread over it
+            for origin in rng.choice(live, size=E // 10, replace=False):
+                s.user_event(0, int(origin), int(rng.integers(1 << 30)))
+                fired += 1
+            s.step_ms(100)
     s.sync()
     dt = time.perf_counter() - t0
     st = diff_stats(s0, s.stats())
@@ -375,7 +408,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config5-nodes", type=int, default=65536)
     ap.add_argument("--config5-seconds", type=int, default=20)
-    ap.add_argument("--config5-events", type=int, default=50, help="config5 leg: serf user events fired per simulated second")
+    ap.add_argument("--config5-events", type=int, default=20, help="config5 leg: serf user events fired per simulated second")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -525,6 +558,14 @@ def main():
     detect_after_kill = {"first_suspect": spread(c.first_suspect_ms for c in census),
                          "first_dead": spread(c.first_dead_ms for c in census),
                          "all_know_dead": spread(c.all_dead_ms for c in census)}
+    sharded_digest = sharded_stats = None
+    if world > 1:
+        # correctness of the sharded run, in the line itself: the shards' state digests add up to the digest of the same clusters
+        # (same seeds, same victims, same ticks) run unsharded on one GPU — checked below on rank 0
+        mine = [None] * world
+        dist.all_gather_object(mine, (int(base.digest()), base.stats()))
+        sharded_digest = sum(d for d, _ in mine) & 0xFFFFFFFFFFFFFFFF
+        sharded_stats = {"edges_remote": sum(st["edges_remote"] for _, st in mine), "edges": sum(st["edges"] for _, st in mine)}
     sim.close()
 
     value = reps * args.nodes * args.steps / dt
@@ -545,6 +586,43 @@ def main():
         "timed_window_detection_ms_after_failure": detect_after_kill,
     }
 
+    if world > 1:
+        ticks = (args.warmup + args.steps) * G
+        line["exchange"] = {"kind": exchange_used, "a2a_bytes_per_tick_all_ranks": 16.0 * sharded_stats["edges_remote"] / ticks,
+                            "a2a_bytes_per_tick_per_rank": 16.0 * sharded_stats["edges_remote"] / ticks / world,
+                            "remote_share_of_records": sharded_stats["edges_remote"] / max(sharded_stats["edges"], 1)}
+        if rank == 0:
+            kw1 = dict(cfg_kw, shard_rank=0, n_shards=1, device=local_rank)
+            one = Sim(hip, preset(hip, abi.PRESET_LAN, **kw1))
+            one.step(args.warmup * G)
+            for r, v in enumerate(victims):
+                one.kill(r, [v])
+            one.step(args.steps * G); one.sync()
+            ud = int(one.digest()); one.close()
+            line["parity"] = {"what": "sum of the shards' state digests vs the same clusters run unsharded on one GPU (same seeds, victims, ticks)",
+                              "sharded_digest": f"{sharded_digest:#018x}", "unsharded_digest": f"{ud:#018x}", "match": sharded_digest == ud}
+        barrier()
+        if on_dev and args.exchange == "auto":
+            # the other exchange over the same window, so that both are in the line (µs per tick = ms_per_step / ticks_per_round)
+            other_lib = not use_library
+            try:
+                o = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
+                o = ShardedSim(o, LibraryExchange(gather_handles) if other_lib else TorchExchange(dist.group.WORLD, local_rank))
+                o.step(args.warmup * G)
+                for r, v in enumerate(victims):
+                    o.kill(r, [v])
+                o.sync(); barrier()
+                to = time.perf_counter()
+                o.step(args.steps * G); o.sync(); barrier()
+                dto = allreduce_max(time.perf_counter() - to)
+                o.close()
+                line["exchange"]["other"] = {"kind": "library (peer-mapped mailboxes)" if other_lib else "rccl all-gather + all-to-all per tick",
+                                             "value": reps * args.nodes * args.steps / dto, "ms_per_step": 1000.0 * dto / args.steps}
+            except (SwimError, OSError, RuntimeError) as e:
+                line["exchange"]["other"] = {"error": str(e)[:200]}
+        line["exchange"]["us_per_tick"] = 1000.0 * line["ms_per_step"] / G
+    if world > 1 and not args.no_config4:
+        line["config4_sharded"] = run_config4_sharded(hip, args, rank, world, local_rank, dist, gather_handles, barrier, allreduce_max)
     if sharded and not args.no_replica_leg:
         # The clusters of this workload are independent of each other, so the box can also simply run 32 whole clusters
         # per GPU with nothing on the wire (same scenario, captured-graph replay as at N=1): reported next to the

@@ -37,7 +37,7 @@ class Config(C.Structure):
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
         "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "mass_rows", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
-        "event_queue_cap", "event_buffer", "loss_q32", "flags", "watch_node", "trace_ticks",
+        "event_queue_cap", "event_buffer", "event_ids_per_ltime", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device", "rtt_scale_us", "rtt_height_us", "rtt_jitter_us")] + [("seed", u64)]
 
 

@@ -115,7 +115,7 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 
 struct SwDev {
   // dimensions
-  uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB;
+  uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB, EW;   // EW = 16-byte words per event-buffer slot (4*EW - 2 ids per Lamport time)
   uint32_t n_shift, nloc_shift;   // log2 of N / nloc when that is a power of two (division and remainder by shift and mask), else 0xFFFFFFFF
   uint32_t G, P, TQ, CH, quantum_ms;
   uint32_t k_gossip, k_indirect, retransmit_limit, susp_k, awareness_max, gossip_to_dead_ms;
@@ -145,7 +145,7 @@ struct SwDev {
   uint32_t* evseq;  // serf event-queue id generator
   uint4* q;         // [Q][NL]  {subject, inc, from, type<<30 | transmits<<22 | seq}
   uint4* evq;       // [EQ][NL] {event id, ltime, 0, meta}
-  uint4* ring;      // [EB][NL] {n<<30 | ltime, id0, id1, id2}
+  uint4* ring;      // [EB][EW][NL] word 0 {ltime, n, id0, id1}, then four ids per word
   // per-node inbox: one 64-byte line {count, 5 x 12-byte messages} that stays cache resident, plus an
   // overflow row for arrivals 6..C (a message = {subject, incarnation, type<<30|from})
   uint32_t* in_cnt; // [NL] arrivals this tick (dense: what the scatter's atomics work on)

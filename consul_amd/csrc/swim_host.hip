@@ -124,7 +124,7 @@ int validate(const swim_config* c) {
   if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
   if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
   if (c->flags & SWIM_F_SERF_EVENTS)
-    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
+    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1 || c->event_ids_per_ltime > 254) return SWIM_EINVAL;
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
@@ -408,6 +408,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
   D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C : 0;   // the overflow row has room for ALL C messages: a big inbox is sorted in it (k_resolve)
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
+  D.EW = serf ? ((cfg->event_ids_per_ltime ? cfg->event_ids_per_ltime : 14) + 2 + 3) / 4 : 0;
   D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
   D.quantum_ms = d.quantum_ms; D.k_gossip = cfg->gossip_nodes; D.k_indirect = cfg->indirect_checks;
   D.retransmit_limit = d.retransmit_limit; D.susp_k = d.suspicion_k; D.awareness_max = cfg->awareness_max_mult;
@@ -432,7 +433,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
-  if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB); DALLOC(s, D.evseq, NL); }
+  if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB * D.EW); DALLOC(s, D.evseq, NL); }
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
   D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
   D.reap_period = d.reap_period_ticks; D.reconnect_timeout_ms = cfg->reconnect_timeout_ms; D.tombstone_timeout_ms = cfg->tombstone_timeout_ms;
@@ -630,7 +631,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st)); HIPCK(s, hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st));
   if (serf) {
     HIPCK(s, hipMemsetAsync(D.evq, 0, NL * D.EQ * sizeof(uint4), st));
-    HIPCK(s, hipMemsetAsync(D.ring, 0, NL * D.EB * sizeof(uint4), st));
+    HIPCK(s, hipMemsetAsync(D.ring, 0, NL * D.EB * D.EW * sizeof(uint4), st));
   }
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor

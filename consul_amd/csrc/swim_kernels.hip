@@ -1991,19 +1991,30 @@ struct NodeCtxT {
     }
     put_later(v);
   }
-  // serf handleUserEvent + LamportClock.Witness; ring word0 = n<<30 | ltime
+  // serf handleUserEvent + LamportClock.Witness.  An event-buffer slot (one per LTime mod EventBuffer) is EW 16-byte words,
+  // slot-major: word 0 = {ltime, n, id0, id1}, then four ids per word — serf's slot is an unbounded list of the events
+  // stamped with that LTime; ours holds 4*EW - 2 (swim_config.event_ids_per_ltime; a flood stamps many events alike)
   __device__ __forceinline__ void user_event(uint32_t id, uint32_t ltime) {
     if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
     if (ltime >= ev_clock) ev_clock = ltime + 1;
     if (ev_clock > D.EB && ltime < ev_clock - D.EB) { S.add(ST_UEV_STALE); return; }
-    uint4* slot = D.ring + (size_t)(ltime % D.EB) * NL + l;
-    uint4 sv = *slot; uint32_t n = sv.x >> 30, lt = sv.x & 0x3FFFFFFFu;
-    if (n && lt == (ltime & 0x3FFFFFFFu)) {
-      if (sv.y == id || (n >= 2 && sv.z == id) || (n >= 3 && sv.w == id)) { S.add(ST_UEV_DEDUP); return; }
+    uint4* const slot = D.ring + (size_t)(ltime % D.EB) * D.EW * NL + l;      // word j at slot[j * NL]
+    uint4 w0 = slot[0]; uint32_t n = w0.y;
+    if (n && w0.x == ltime) {
+      bool dup = w0.z == id || (n >= 2 && w0.w == id);
+      for (uint32_t j = 1; !dup && 4 * j - 2 < n; j++) {
+        const uint4 w = slot[(size_t)j * NL]; const uint32_t m = n - (4 * j - 2);
+        dup = w.x == id || (m >= 2 && w.y == id) || (m >= 3 && w.z == id) || (m >= 4 && w.w == id);
+      }
+      if (dup) { S.add(ST_UEV_DEDUP); return; }
     } else n = 0;
-    if (n == 3) { S.add(ST_EVDROPS); return; }
-    if (n == 0) sv.y = id; else if (n == 1) sv.z = id; else sv.w = id;
-    n++; sv.x = (n << 30) | (ltime & 0x3FFFFFFFu); *slot = sv;
+    if (n == 4 * D.EW - 2) { S.add(ST_EVDROPS); return; }
+    if (n == 0) w0.z = id; else if (n == 1) w0.w = id;
+    else {
+      uint32_t* w = (uint32_t*)&slot[(size_t)((n + 2) / 4) * NL];
+      w[(n + 2) & 3u] = id;
+    }
+    n++; w0.x = ltime; w0.y = n; slot[0] = w0;
     if (id & SWIM_INTENT_LEAVE) leave_intent(id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
     else {
       S.add(ST_UEV_DELIVERED);
@@ -2709,10 +2720,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restri
     }
     if (D.flags & SWIM_F_SERF_EVENTS)
       for (uint32_t b = 0; b < D.EB; b++) {
-        uint4 sv = D.ring[(size_t)b * NL + l]; uint32_t n = sv.x >> 30, lt = sv.x & 0x3FFFFFFFu;
-        if (n >= 1) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.y);
-        if (n >= 2) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.z);
-        if (n >= 3) d += sw_h3(8, g, ((uint64_t)lt << 32) | sv.w);
+        const uint4* slot = D.ring + (size_t)b * D.EW * NL + l;
+        const uint4 w0 = slot[0]; const uint32_t n = w0.y, lt = w0.x;
+        for (uint32_t i = 0; i < n; i++) {
+          const uint32_t* w = (const uint32_t*)&slot[(size_t)((i + 2) / 4) * NL];
+          d += sw_h3(8, g, ((uint64_t)lt << 32) | w[(i + 2) & 3u]);
+        }
       }
     if (D.coord) {                               // coordinates: the raw bits
       const double* f = (const double*)&D.coord[l];

@@ -155,6 +155,9 @@ typedef struct swim_config {
                                        freed (SURVEY §7 hard part 1, App. D k_reap_fold); 0 = never            */
   uint32_t event_queue_cap;         /* per-node serf user-event queue slots (<= 32)         */
   uint32_t event_buffer;            /* serf EventBuffer ring size (default 512)             */
+  uint32_t event_ids_per_ltime;     /* distinct user events (and intents) a node remembers per Lamport time: serf's slot is an
+                                       unbounded list, and a flood stamps many events alike; one more with the same LTime is
+                                       dropped (event_drops).  Rounded up to 4k + 2; 0 = 14 (a 64-byte slot)              */
   uint32_t loss_q32;                /* packet loss prob * 2^32 (0 = lossless)               */
   uint32_t flags;                   /* SWIM_F_*                                             */
   uint32_t watch_node;              /* observer whose serf events are recorded (SWIM_NONE=off)*/

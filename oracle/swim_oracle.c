@@ -173,7 +173,7 @@ static int validate(const swim_config* c) {
   if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
   if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
   if (c->flags & SWIM_F_SERF_EVENTS)
-    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1) return SWIM_EINVAL;
+    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1 || c->event_ids_per_ltime > 254) return SWIM_EINVAL;
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
@@ -237,7 +237,6 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 
 #define QMAX 32
 #define CONF_MAX 4
-#define EV_PER_SLOT 3
 
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
 
@@ -254,7 +253,7 @@ typedef struct { view_t* e; uint32_t n, slots; } vtab;
 #define KST(k) ((k) & 3u)
 #define BASE_KEY KEY(1, SWIM_STATE_ALIVE)
 
-typedef struct { uint32_t ltime, ids[EV_PER_SLOT]; uint8_t n; } evslot;
+typedef uint32_t evslot;      /* an event-buffer slot is `ev_words` words: ltime, n, then n ids (serf: an unbounded list per LTime; ours: cfg.event_ids_per_ltime, rounded up to 4k + 2) */
 
 typedef struct {
   uint32_t self_inc;
@@ -290,6 +289,7 @@ typedef struct { swim_edge* v; uint32_t n, cap; } edgevec;
 struct swim_sim {
   swim_config cfg; swim_derived d;
   uint32_t N, R, nloc, i0, tick; int in_tick;
+  uint32_t ev_words;             /* words per event-buffer slot: ltime, n, ids */
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
   uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
   uint8_t* alone;                /* [R*N] replicated: started by swim_inject_join, join push-pull not carried out (yet): it knows nobody */
@@ -694,12 +694,12 @@ static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
   if (ltime >= nd->ev_clock) nd->ev_clock = ltime + 1;                 /* Witness */
   uint32_t cur = nd->ev_clock, bl = s->cfg.event_buffer;
   if (cur > bl && ltime < cur - bl) { s->st.user_events_stale++; return; }
-  evslot* sl = &nd->ring[ltime % bl];
-  if (sl->n && sl->ltime == ltime) {
-    for (uint32_t i = 0; i < sl->n; i++) if (sl->ids[i] == id) { s->st.user_events_deduped++; return; }
-  } else { sl->ltime = ltime; sl->n = 0; }
-  if (sl->n == EV_PER_SLOT) { s->st.event_drops++; return; }
-  sl->ids[sl->n++] = id;
+  uint32_t* sl = &nd->ring[(size_t)(ltime % bl) * s->ev_words];        /* {ltime, n, ids...} */
+  if (sl[1] && sl[0] == ltime) {
+    for (uint32_t i = 0; i < sl[1]; i++) if (sl[2 + i] == id) { s->st.user_events_deduped++; return; }
+  } else { sl[0] = ltime; sl[1] = 0; }
+  if (sl[1] == s->ev_words - 2) { s->st.event_drops++; return; }
+  sl[2 + sl[1]++] = id;
   if (id & SWIM_INTENT_LEAVE) leave_intent(s, r, o, nd, id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
   else {
     s->st.user_events_delivered++;
@@ -1409,6 +1409,7 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   if (!out) return SWIM_EINVAL;
   swim_sim* s = (swim_sim*)calloc(1, sizeof *s); if (!s) return SWIM_ENOMEM;
   s->cfg = *cfg; s->d = d; s->N = cfg->n_nodes; s->R = cfg->n_replicas;
+  s->ev_words = 4 * (((cfg->event_ids_per_ltime ? cfg->event_ids_per_ltime : 14) + 2 + 3) / 4);      /* 14 ids: a 64-byte slot */
   s->nloc = s->N / cfg->n_shards; s->i0 = cfg->shard_rank * s->nloc; s->loss_q32 = cfg->loss_q32;
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
   s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1); s->alone = (uint8_t*)calloc(NT, 1);
@@ -1443,7 +1444,7 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
     nd->evq = s->evq_slab ? s->evq_slab + g * cfg->event_queue_cap : NULL;
     nd->self_inc = 1; nd->pr_target = SWIM_NONE; nd->vdl = SWIM_NONE;
     nd->inbox = s->inbox_slab + g * cfg->inbox_cap;
-    if (cfg->flags & SWIM_F_SERF_EVENTS) { nd->ring = (evslot*)calloc(cfg->event_buffer, sizeof(evslot)); nd->ev_clock = 1; }   /* serf.Create: eventClock.Increment() */
+    if (cfg->flags & SWIM_F_SERF_EVENTS) { nd->ring = (evslot*)calloc((size_t)cfg->event_buffer * s->ev_words, sizeof(evslot)); nd->ev_clock = 1; }   /* serf.Create: eventClock.Increment() */
     if ((cfg->flags & SWIM_F_SERF_EVENTS) && !nd->ring) { swim_destroy(s); return SWIM_ENOMEM; }
   }
   *out = s; return SWIM_OK;
@@ -1811,7 +1812,7 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
       }
       if (nd->ring)
         for (uint32_t b = 0; b < s->cfg.event_buffer; b++)
-          for (uint32_t j = 0; j < nd->ring[b].n; j++) d += h3(8, g, ((uint64_t)nd->ring[b].ltime << 32) | nd->ring[b].ids[j]);
+          { const uint32_t* sl = &nd->ring[(size_t)b * s->ev_words]; for (uint32_t j = 0; j < sl[1]; j++) d += h3(8, g, ((uint64_t)sl[0] << 32) | sl[2 + j]); }
     }
     for (uint32_t k = 0; k < s->nloc; k++) {               /* explicit views */
       const vtab* t = &s->nodes[(size_t)r * s->nloc + k].vt;
@@ -1920,7 +1921,7 @@ int swim_checkpoint_save(swim_sim* s, const char* path) {
   if (s->evq_slab) ok = ok && ck_wr(f, s->evq_slab, NL * s->cfg.event_queue_cap * sizeof(qent));
   for (size_t g = 0; ok && g < NL; g++) {
     const node_t* nd = &s->nodes[g];
-    if (nd->ring) ok = ck_wr(f, nd->ring, (size_t)s->cfg.event_buffer * sizeof(evslot));
+    if (nd->ring) ok = ck_wr(f, nd->ring, (size_t)s->cfg.event_buffer * s->ev_words * sizeof(evslot));
     ok = ok && ck_wr(f, nd->vt.e, (size_t)nd->vt.slots * sizeof(view_t));       /* (n and slots travel with the node) */
   }
   ok = ok && ck_wr(f, s->slots, NS * sizeof(slot_t));
@@ -1965,7 +1966,7 @@ int swim_checkpoint_load(swim_sim* s, const char* path) {
   if (s->evq_slab) ok = ok && ck_rd(f, s->evq_slab, NL * s->cfg.event_queue_cap * sizeof(qent));
   for (size_t g = 0; ok && g < NL; g++) {
     node_t* nd = &s->nodes[g];
-    if (nd->ring) ok = ck_rd(f, nd->ring, (size_t)s->cfg.event_buffer * sizeof(evslot));
+    if (nd->ring) ok = ck_rd(f, nd->ring, (size_t)s->cfg.event_buffer * s->ev_words * sizeof(evslot));
     ok = ok && ck_rd(f, nd->vt.e, (size_t)nd->vt.slots * sizeof(view_t));
   }
   for (size_t i = 0; ok && i < NS; i++) {                 /* the watch slots: plain data except the trace pointer */

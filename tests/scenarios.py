@@ -115,7 +115,7 @@ def run_mass_kill(sim, n, checkpoints, until_detected=True, limit_s=2000):
 
 # BASELINE config #5's shape with nothing dropped: 10 %/s churn (kill / revive) AND a flood of serf user events, Lifeguard on.
 # Every node becomes a subject: the checker holds N views per observer in its hash tables, the HIP library a row per node.
-CHURN_EVENTS_8K = dict(n_nodes=8192, seed=12, queue_cap=16, event_queue_cap=16, inbox_cap=8192, subject_cap=4, fold_interval_ms=5000,
+CHURN_EVENTS_8K = dict(n_nodes=8192, seed=12, queue_cap=16, event_queue_cap=16, event_ids_per_ltime=30, inbox_cap=8192, subject_cap=4, fold_interval_ms=5000,
                        flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=0)
 CHURN_EVENTS_8K_ORACLE = dict(view_cap=8192)
 CHURN_EVENTS_8K_HIP = dict(view_cap=8, mass_rows=8192)

@@ -183,7 +183,7 @@ def test_churn_and_event_flood_8192_matches_golden(hip):
         assert hash_list(res[sec][2]) == want["ltimes_fnv"] and res[sec][3] == want["watch_node_events"]
         assert hash_list(res[sec][4]) == want["watch_node_events_fnv"]
     st = res[40][1]
-    assert st["view_drops"] == 0 and st["user_events_delivered"] > 100000 and st["user_events_deduped"] > 0 and st["folds"] > 0
+    assert st["view_drops"] == 0 and st["user_events_delivered"] > 100000 and st["user_events_deduped"] > 0 and st["refutes"] > 0
     a.close()
 
 
@@ -405,3 +405,21 @@ def test_bench_two_ranks_on_one_device_through_the_library_exchange(hip):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 10 and "library" in d["config"]["parallelism"]
     assert d["config"]["replicas"] == 8 and d["scaling"] == "weak"
+    assert d["parity"]["match"] is True and d["exchange"]["a2a_bytes_per_tick_all_ranks"] > 0
+
+
+def test_bench_sharded_config4_leg_two_ranks_on_one_device(hip):
+    """The N > 1 config-#4 leg of bench.py (one population over the ranks, dense pair store per rank, mailbox exchange), at a size
+    two ranks can share this box's one GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", SWIMSIM_BENCH_C4S_NODES="32768")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-replica-leg", "--replicas", "2",
+           "--dist-backend", "gloo", "--exchange", "library"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config4_sharded"]
+    assert c["n_nodes"] == 32768 and c["view_drops"] == 0 and c["inbox_overflow"] == 0 and c["pairs"] == (32768 - 1638) * 1638
+    assert c["suspect_fraction"] + c["dead_fraction"] > 0.5 and c["a2a_bytes_per_tick_all_ranks"] > 0 and d["parity"]["match"] is True
