@@ -36,7 +36,7 @@ class Config(C.Structure):
         "suspicion_mult", "retransmit_mult", "indirect_checks", "suspicion_max_timeout_mult",
         "awareness_max_mult", "gossip_to_dead_ms", "udp_buffer_size", "push_pull_interval_ms")] + [
         ("msg_len", u32 * 4), ("ctl_len", u32 * 4)] + [(n, u32) for n in (
-        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "mass_rows", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "fold_interval_ms",
+        "quantum_ms", "phase_chunk", "queue_cap", "inbox_cap", "subject_cap", "view_cap", "mass_rows", "reap_interval_ms", "reconnect_timeout_ms", "tombstone_timeout_ms", "reconnect_interval_ms", "fold_interval_ms",
         "event_queue_cap", "event_buffer", "event_ids_per_ltime", "loss_q32", "flags", "watch_node", "trace_ticks",
         "shard_rank", "n_shards", "device", "rtt_scale_us", "rtt_height_us", "rtt_jitter_us")] + [("seed", u64)]
 
@@ -55,7 +55,7 @@ class Derived(C.Structure):
         "retransmit_limit", "suspicion_k", "suspicion_min_ms", "suspicion_max_ms")] + [
         ("suspicion_timeout_ms", u32 * 8), ("node_scale_milli", u32),
         ("push_pull_scale", u32), ("push_pull_period_ticks", u32), ("packet_budget", u32),
-        ("view_cap", u32), ("fold_period_ticks", u32), ("reap_period_ticks", u32)]
+        ("view_cap", u32), ("fold_period_ticks", u32), ("reap_period_ticks", u32), ("reconnect_period_ticks", u32)]
 
 
 class Member(C.Structure):
@@ -64,7 +64,7 @@ class Member(C.Structure):
 
 
 class Event(C.Structure):
-    _fields_ = [(n, u32) for n in ("time_ms", "replica", "type", "node", "ltime", "incarnation")]
+    _fields_ = [(n, u32) for n in ("time_ms", "replica", "type", "node", "ltime", "incarnation", "observer")]
 
 
 class Rumour(C.Structure):
@@ -106,7 +106,7 @@ class Stats(C.Structure):
                 ("user_events_deduped", u64), ("user_events_stale", u64), ("msgs_filtered", u64), ("push_pulls", u64),
                 ("piggybacks", u64), ("msgs_piggybacked", u64), ("probe_tcp_acks", u64),
                 ("view_drops", u64), ("view_evictions", u64), ("intents_applied", u64), ("reaped", u64), ("joins", u64), ("join_failures", u64), ("folds", u64), ("fold_freed", u64),
-                ("coord_updates", u64), ("coord_resets", u64), ("inbox_peak", u64)]
+                ("coord_updates", u64), ("coord_resets", u64), ("reconnects", u64), ("reconnects_reached", u64), ("inbox_peak", u64)]
 
 
 class XchgHandle(C.Structure):
@@ -156,6 +156,7 @@ PROTOTYPES = {
     "swim_watch": (C.c_int, [SimP, u32, u32]),
     "swim_members": (C.c_int, [SimP, u32, u32, P(Member), C.c_size_t, P(C.c_size_t)]),
     "swim_view": (C.c_int, [SimP, u32, u32, u32, P(Member)]),
+    "swim_watch_events": (C.c_int, [SimP, u32, u32]),
     "swim_poll_events": (C.c_int, [SimP, P(Event), C.c_size_t, P(C.c_size_t)]),
     "swim_node_info_get": (C.c_int, [SimP, u32, u32, P(NodeInfo)]),
     "swim_census_get": (C.c_int, [SimP, u32, u32, P(Census)]),

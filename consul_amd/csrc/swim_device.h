@@ -26,7 +26,7 @@ enum {
   ST_QDROPS, ST_INBOX_OVF, ST_SUBJ_OVF, ST_EVDROPS,
   ST_UEV_DELIVERED, ST_UEV_DEDUP, ST_UEV_STALE, ST_FILTERED, ST_PUSHPULLS,
   ST_PIGGY, ST_PIGGY_MSGS, ST_TCPACKS, ST_VIEW_DROPS, ST_VIEW_EVICT, ST_FOLDS, ST_FOLD_FREED, ST_JOINS, ST_JOIN_FAIL, ST_INTENTS, ST_REAPED,
-  ST_COORD_UPD, ST_COORD_RESET,
+  ST_COORD_UPD, ST_COORD_RESET, ST_RECONNECTS, ST_RECONNECT_OK,
   ST_COUNT
 };
 
@@ -159,6 +159,7 @@ struct SwDev {
   // explicit views (see above) and what bounds them
   uint32_t VT, vt_shift, view_cap, fold_period;
   uint32_t reap_period, reconnect_timeout_ms, tombstone_timeout_ms;   // serf's reaper (0 = off)
+  uint32_t rc_period;                                                  // serf's reconnect(): ticks between a node's attempts (0 = off)
   uint4* vt;             // [VT][NL]
   uint4* vc;             // [VT][NL]
   uint4* vmeta;          // [NL] {explicit views held, how many of them are Suspect,
@@ -250,6 +251,8 @@ struct SwDev {
   uint8_t** mb_tab; uint32_t mail_cap, xchg_timeout_ms;
   uint32_t* xin_cnt;     // [n_shards] records each source delivered this tick
   // events, stats, errors
+  uint32_t ev_any;       // swim_watch_events was used: observers besides `watch` have an EventCh (ev_watch)
+  uint32_t* ev_watch;    // [R][SWIM_EVENT_WATCHERS] those observers; [R*SWIM_EVENT_WATCHERS + r] = how many
   swim_event* events;
   uint32_t* ev_cnt;
   uint32_t ev_cap;
@@ -283,7 +286,7 @@ struct BeginPlan {
 #define SW_KST(k) ((k) & 3u)
 #define SW_BASE_KEY SW_KEY(1, SWIM_STATE_ALIVE)
 
-enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4, SW_STREAM_PUSHPULL = 5, SW_STREAM_TRUTH = 6, SW_STREAM_RTT = 7, SW_STREAM_COORD = 8 };
+enum { SW_STREAM_GOSSIP = 1, SW_STREAM_PERM = 2, SW_STREAM_INDIRECT = 3, SW_STREAM_LOSS = 4, SW_STREAM_PUSHPULL = 5, SW_STREAM_TRUTH = 6, SW_STREAM_RTT = 7, SW_STREAM_COORD = 8, SW_STREAM_RECONNECT = 9 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10: counter-based, so a draw depends on (seed, stream, tick, node, index) only.

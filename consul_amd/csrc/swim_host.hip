@@ -214,6 +214,7 @@ extern "C" int swim_config_derive(const swim_config* c, swim_derived* d) {
   d->view_cap = c->view_cap ? c->view_cap : std::min<uint32_t>(c->n_nodes, 32);
   d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
   d->reap_period_ticks = (c->reap_interval_ms + q - 1) / q;
+  d->reconnect_period_ticks = (c->reconnect_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -437,6 +438,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
   D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
   D.reap_period = d.reap_period_ticks; D.reconnect_timeout_ms = cfg->reconnect_timeout_ms; D.tombstone_timeout_ms = cfg->tombstone_timeout_ms;
+  D.rc_period = d.reconnect_period_ticks;
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
   DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
@@ -535,7 +537,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   pl.nb_carry = D.n_shards > 1 ? 64 : 0;
   pl.nb_join = 1;                                   // swim_inject_join also restarts nodes of a fixed population
   if (piggy && D.n_shards > 1) pl.roles |= 0x20;
-  D.pp_cap = std::max<uint32_t>(4096, D.pp_period ? 8 * D.R * cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0);
+  D.pp_cap = std::max<uint32_t>(4096, 8 * D.R * ((D.pp_period ? cdiv(D.N, D.pp_period) * std::min(D.P, D.pp_period) : 0) +
+                                                  (D.rc_period ? cdiv(D.N, D.rc_period) * std::min(D.P, D.rc_period) : 0)));   // pull requests of a boundary tick: push-pull + serf reconnect
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
   s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1);
@@ -561,7 +564,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     // own shard: probe verdicts, fold census records, push-pull; other shards: their share of the gossip records, the
     // acks' piggy-back orders, carried broadcasts, fold census records, and push-pull — whose every exchange sends one
     // record per explicit view of the sender, all of a boundary tick's exchanges possibly to the same shard
-    const uint64_t pp_burst = (uint64_t)D.R * pl.nb_pp * SW_BLOCK * ((uint64_t)D.view_cap + D.M + 3);   // explicit views + own view of the receiver + the pull request
+    const uint64_t rc_lanes = D.rc_period ? (uint64_t)cdiv((uint64_t)cdiv(D.N, D.rc_period) * std::min(D.P, D.rc_period), SW_BLOCK) * SW_BLOCK : 0;
+    const uint64_t pp_burst = ((uint64_t)D.R * pl.nb_pp * SW_BLOCK + D.R * rc_lanes) * ((uint64_t)D.view_cap + D.M + 3);   // explicit views + own view of the receiver + the pull request
     const uint64_t fold_burst = D.fold_period ? NT : 0;        // a fold tick: at most one census record per node of the population
     uint64_t cap = sh == D.rank ? 2 * NL + 4096 + pp_burst + fold_burst
                                 : std::max<uint64_t>(e_cap / D.n_shards * 2, 4096) + 2 * NL / D.n_shards + NL + pp_burst + fold_burst;
@@ -575,6 +579,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.act = D.out_cnt + D.n_shards;                  // rides behind the counts so one gather fetches both
   DALLOC(s, D.peer_act, 1); HIPCK(s, hipMemsetD32Async((hipDeviceptr_t)D.peer_act, 1, 1, s->stream));
   D.ev_cap = 65536; DALLOC(s, D.events, D.ev_cap); DALLOC(s, D.ev_cnt, 1);
+  DALLOC(s, D.ev_watch, (size_t)D.R * SWIM_EVENT_WATCHERS + D.R); HIPCK(s, hipMemsetAsync(D.ev_watch, 0, ((size_t)D.R * SWIM_EVENT_WATCHERS + D.R) * 4, s->stream));
   D.cap_cap = 1 << 18; DALLOC(s, D.cap, D.cap_cap); DALLOC(s, D.cap_dst, D.cap_cap); DALLOC(s, D.cap_cnt, 1);
   DALLOC(s, D.stats, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE); DALLOC(s, D.err, 1);
   s->scratch_bytes = std::max<size_t>(1 << 20, std::min<size_t>(((size_t)D.VT + D.M) * 32 + 64, (size_t)1 << 26));   // an observer's views fit (swim_members)
@@ -659,10 +664,12 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
 static bool fold_tick(const swim_sim* s, uint32_t tick) { return s->D.fold_period && tick && tick % s->D.fold_period == 0; }
 // ...and so does a reap tick (serf's reaper: one scan of the view tables before k_begin)
 static bool reap_tick(const swim_sim* s, uint32_t tick) { return s->D.reap_period && tick && tick % s->D.reap_period == 0; }
-static bool special_tick(const swim_sim* s, uint32_t tick) { return fold_tick(s, tick) || reap_tick(s, tick); }
+// ...and a tick in which nodes are due for serf's reconnect() (probe-interval boundaries, when the feature is on)
+static bool reconnect_tick(const swim_sim* s, uint32_t tick) { return s->D.rc_period && tick && tick % s->D.P == 0; }
+static bool special_tick(const swim_sim* s, uint32_t tick) { return fold_tick(s, tick) || reap_tick(s, tick) || reconnect_tick(s, tick); }
 static uint32_t ticks_to_special(const swim_sim* s) {       // 0 = this tick is one; 0xFFFFFFFF = never
   uint32_t best = 0xFFFFFFFFu;
-  for (uint32_t per : { s->D.fold_period, s->D.reap_period })
+  for (uint32_t per : { s->D.fold_period, s->D.reap_period, s->D.rc_period ? s->D.P : 0u })
     if (per) best = std::min(best, (s->tick && s->tick % per == 0) ? 0u : per - s->tick % per);
   return best;
 }
@@ -680,6 +687,10 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_scan, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_scan_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
+  if (tick != SW_PLAIN_TICK && reconnect_tick(s, tick)) {
+    const uint32_t per = D.rc_period, grp = std::min(D.P, per);
+    hipLaunchKernelGGL(k_reconnect, dim3(cdiv((uint64_t)cdiv(D.N, per) * grp, SW_BLOCK), D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   if (D.M) {   // the dense store's suspicion timers: list the due rows, then their due tiles over many waves
     hipLaunchKernelGGL(k_expire_mass_due, dim3(cdiv((size_t)D.R * D.M, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
@@ -1187,6 +1198,25 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   if (x == o && out->state == SWIM_STATE_ALIVE && (h.y & 0xFF)) out->status = SWIM_MEMBER_LEAVING;
   return SWIM_OK;
 }
+extern "C" int swim_watch_events(swim_sim* s, uint32_t r, uint32_t node) {
+  if (!s) return SWIM_EINVAL;
+  SwDev& D = s->D;
+  if (r >= D.R || node >= D.N || !is_local(s, node)) return SWIM_ERANGE;
+  if (s->in_tick) return SWIM_ESTATE;
+  if (node == D.watch) return SWIM_OK;
+  std::vector<uint32_t> w(SWIM_EVENT_WATCHERS); uint32_t n = 0;
+  int rc = d2h(s, w.data(), (const uint32_t*)D.ev_watch + (size_t)r * SWIM_EVENT_WATCHERS, SWIM_EVENT_WATCHERS);
+  if (!rc) rc = d2h(s, &n, (const uint32_t*)D.ev_watch + (size_t)D.R * SWIM_EVENT_WATCHERS + r, 1);
+  if (rc) return rc;
+  for (uint32_t j = 0; j < n; j++) if (w[j] == node) return SWIM_OK;
+  if (n >= SWIM_EVENT_WATCHERS) return SWIM_EOVERFLOW;
+  const uint32_t n1 = n + 1;
+  HIPCK(s, hipMemcpy(D.ev_watch + (size_t)r * SWIM_EVENT_WATCHERS + n, &node, 4, hipMemcpyHostToDevice));
+  HIPCK(s, hipMemcpy(D.ev_watch + (size_t)D.R * SWIM_EVENT_WATCHERS + r, &n1, 4, hipMemcpyHostToDevice));
+  s->pristine = false;                 // (an EventCh wants every tick looked at)
+  if (!D.ev_any) { D.ev_any = 1; HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice)); }   // the kernels read the descriptor from device memory
+  return SWIM_OK;
+}
 extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
   uint32_t n = 0; int rc = d2h(s, &n, (const uint32_t*)s->D.ev_cnt, 1);
@@ -1199,7 +1229,7 @@ extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t
     HIPCK(s, hipMemsetAsync(s->D.ev_cnt, 0, 4, s->stream));
     // one lane appends in program order; lanes of different replicas interleave arbitrarily
     std::stable_sort(s->pending_events.begin() + base, s->pending_events.end(), [](const swim_event& a, const swim_event& b) {
-      return a.time_ms != b.time_ms ? a.time_ms < b.time_ms : a.replica < b.replica;
+      return a.time_ms != b.time_ms ? a.time_ms < b.time_ms : a.replica != b.replica ? a.replica < b.replica : a.observer < b.observer;
     });
   }
   size_t k = std::min(cap, s->pending_events.size());
@@ -1301,6 +1331,7 @@ extern "C" int swim_stats(swim_sim* s, swim_stats_t* out) {
   out->piggybacks = v[ST_PIGGY]; out->msgs_piggybacked = v[ST_PIGGY_MSGS]; out->probe_tcp_acks = v[ST_TCPACKS];
   out->view_drops = v[ST_VIEW_DROPS]; out->view_evictions = v[ST_VIEW_EVICT]; out->joins = v[ST_JOINS]; out->join_failures = v[ST_JOIN_FAIL]; out->intents_applied = v[ST_INTENTS]; out->reaped = v[ST_REAPED]; out->folds = v[ST_FOLDS]; out->fold_freed = v[ST_FOLD_FREED];
   out->coord_updates = v[ST_COORD_UPD]; out->coord_resets = v[ST_COORD_RESET];
+  out->reconnects = v[ST_RECONNECTS]; out->reconnects_reached = v[ST_RECONNECT_OK];
   { uint32_t pk = 0; if ((rc = d2h(s, &pk, (const uint32_t*)s->D.peak, 1))) return rc; out->inbox_peak = pk; }
   return SWIM_OK;
 }
@@ -1474,7 +1505,13 @@ extern "C" int swim_checkpoint_load(swim_sim* s, const char* path) {
   if (!ok) { snprintf(s->err, sizeof s->err, "checkpoint truncated: the handle's state is undefined"); return SWIM_EIO; }
   s->tick = h.tick; s->pristine = h.pristine != 0; s->ticks_run = h.ticks_run; s->rounds_run = h.rounds_run; s->peer_act_host = h.peer_act;
   s->pending_events = std::move(ev); s->out_counts_valid = false; s->in_count = 0;
-  if (s->D.loss_q32 != h.loss_q32) { s->D.loss_q32 = h.loss_q32; HIPCK(s, hipMemcpy(s->d_D, &s->D, sizeof s->D, hipMemcpyHostToDevice)); }
+  {   // two words of the descriptor follow the state: the loss rate, and whether any observer has an EventCh of its own
+    std::vector<uint32_t> nw(s->D.R); uint32_t any = 0;
+    if (int rc = d2h(s, nw.data(), (const uint32_t*)s->D.ev_watch + (size_t)s->D.R * SWIM_EVENT_WATCHERS, s->D.R)) return rc;
+    for (uint32_t v : nw) any |= v;
+    any = any ? 1u : 0u;
+    if (s->D.loss_q32 != h.loss_q32 || s->D.ev_any != any) { s->D.loss_q32 = h.loss_q32; s->D.ev_any = any; HIPCK(s, hipMemcpy(s->d_D, &s->D, sizeof s->D, hipMemcpyHostToDevice)); }
+  }
   return SWIM_OK;
 }
 

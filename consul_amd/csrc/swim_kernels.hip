@@ -1703,8 +1703,18 @@ struct NodeCtxT {
   }
   __device__ __forceinline__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
     uint32_t pos = atomicAdd(D.ev_cnt, 1u);
-    if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc }; D.events[pos] = ev; }
+    if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc, o }; D.events[pos] = ev; }
     else atomicOr(D.err, SW_ERR_EVENT_OVF);
+  }
+  // does this observer have an EventCh: cfg.watch_node, or one added with swim_watch_events (rare: the list is only looked at
+  // when the call was ever made)
+  __device__ __forceinline__ bool watching() const {
+    if (o == D.watch) return true;
+    if (!D.ev_any) return false;
+    const uint32_t* w = D.ev_watch + (size_t)r * SWIM_EVENT_WATCHERS; const uint32_t n = D.ev_watch[(size_t)D.R * SWIM_EVENT_WATCHERS + r];
+    bool hit = false;
+    for (uint32_t j = 0; j < n; j++) hit |= w[j] == o;
+    return hit;
   }
   // ---- the observer's explicit view of a subject: looked up once per message (the home slot's entry and the
   // subject's node word are independent loads), edited in registers, written back once
@@ -1837,7 +1847,7 @@ struct NodeCtxT {
     set_view(v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
     put_later(v);
     S.add(ST_APPL0);
-    if (o == D.watch) {
+    if (watching()) {
       if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
       else if (upd) record_event(SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);
     }
@@ -1901,7 +1911,7 @@ struct NodeCtxT {
     set_view(v, inc, st, true);
     put_later(v);
     S.add(ST_APPL2);
-    if (o == D.watch && x != o) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
+    if (x != o && watching()) record_event(st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
   }
   // sendMsg (net.go): extra := getBroadcasts(compoundOverhead, UDPBufferSize - len(msg) - compoundHeaderOverhead),
   // i.e. the memberlist queue and then the serf delegate's user events, for a ping/ack/... this node sent this
@@ -1981,13 +1991,13 @@ struct NodeCtxT {
     if (st == SWIM_STATE_DEAD) {
       set_view(v, SW_KINC(key), SWIM_STATE_LEFT, true);
       S.add(ST_INTENTS);
-      if (o == D.watch) record_event(SWIM_EVENT_MEMBER_LEAVE, x, 0, SW_KINC(key));
+      if (watching()) record_event(SWIM_EVENT_MEMBER_LEAVE, x, 0, SW_KINC(key));
     } else if (v_mass(v)) v.fresh = false;
     else { v.fresh = false; need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
     if (prune) {
       v.e.w = 1u; S.add(ST_REAPED);
       if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
-      if (o == D.watch) record_event(SWIM_EVENT_MEMBER_REAP, x, 0, SW_KINC(key));
+      if (watching()) record_event(SWIM_EVENT_MEMBER_REAP, x, 0, SW_KINC(key));
     }
     put_later(v);
   }
@@ -2018,7 +2028,7 @@ struct NodeCtxT {
     if (id & SWIM_INTENT_LEAVE) leave_intent(id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
     else {
       S.add(ST_UEV_DELIVERED);
-      if (o == D.watch) record_event(SWIM_EVENT_USER, id, ltime, 0);
+      if (watching()) record_event(SWIM_EVENT_USER, id, ltime, 0);
     }
     uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
     queue_push<true>(D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
@@ -2869,9 +2879,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reap(const SwDev* __restrict__ Dp)
     D.vt[(size_t)sl * NL + l].w = e.w | 1u; n++;
     const uint32_t wx = D.nw[(size_t)r * D.N + e.x];
     if (NW_HAS_SLOT(wx)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wx)] = 1;
-    if (o == D.watch) {
+    bool ev_ch = o == D.watch;
+    if (!ev_ch && D.ev_any) { const uint32_t nw_ = D.ev_watch[(size_t)D.R * SWIM_EVENT_WATCHERS + r]; for (uint32_t j = 0; j < nw_; j++) ev_ch |= D.ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + j] == o; }
+    if (ev_ch) {
       uint32_t pos = atomicAdd(D.ev_cnt, 1u);
-      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, e.x, 0, SW_KINC(e.y) }; D.events[pos] = ev; }
+      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, e.x, 0, SW_KINC(e.y), o }; D.events[pos] = ev; }
       else atomicOr(D.err, SW_ERR_EVENT_OVF);
     }
   }
@@ -3209,4 +3221,91 @@ __global__ void __launch_bounds__(SW_BLOCK) k_detect_rows(const SwDev* __restric
     d[bst]--; d[MA_STATE(a)]++;
   }
   for (int c = 0; c < 4; c++) det_add(acc, 1 + c, d[c]);
+}
+
+// =================================================================================================
+// serf.go reconnect() (swim_config.reconnect_interval_ms; the checker's phase_reconnect has the rule spelt out): on a
+// probe-interval boundary the nodes due within the next ProbeInterval count the members they hold Failed (explicit Dead views
+// serf has not erased), pass the failed/alive gate on a Philox word, pick the member with the smallest keyed hash and — when it
+// runs and is in reach — exchange state with it like a join does (its answer comes one tick later through the reply list).
+// grid = (blocks over the due set, R).  The dense store's rows are walked by the whole wave, one due node at a time.
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  BlockStats S; S.init(lds_stats);
+  const uint32_t t = *D.tick, r = blockIdx.y, a = blockIdx.x * SW_BLOCK + threadIdx.x, per = D.rc_period, grp = D.P < per ? D.P : per, lane = sw_lane();
+  const uint64_t i64 = (uint64_t)((t + a % grp) % per) + (uint64_t)(a / grp) * per;
+  const size_t NL = (size_t)D.R * D.nloc;
+  bool due = false; uint32_t o = 0; size_t l = 0;
+  if (i64 < D.N) {
+    o = (uint32_t)i64;
+    if (o >= D.i0 && o < D.i0 + D.nloc && !(D.nw[(size_t)r * D.N + o] & NW_INERT)) { due = true; l = (size_t)r * D.nloc + (o - D.i0); }
+  }
+  uint32_t w[4] = { 0, 0, 0, 0 };
+  if (due) { const uint64_t sr = seed_of(D, r); sw_philox(t, o, 0, 0x5245434Eu, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_RECONNECT, w); }
+  uint32_t n_failed = 0, best = NONE, best_h = 0;
+  if (due) {                                         // the hash table, one lane per due node
+    uint32_t left = D.vmeta[l].x;
+    for (uint32_t sl = 0; sl < D.VT && left; sl++) {
+      const uint4 e = D.vt[(size_t)sl * NL + l];
+      if (e.x == VT_EMPTY) continue;
+      left--;
+      if (e.x == o || SW_KST(e.y) != SWIM_STATE_DEAD || (e.w & 1u)) continue;
+      n_failed++;
+      const uint32_t h = sw_fmix32(e.x ^ w[1]);
+      if (best == NONE || h < best_h || (h == best_h && e.x < best)) { best = e.x; best_h = h; }
+    }
+  }
+  if (D.M) {                                         // the dense store, the wave on one due node at a time
+    uint64_t todo = __ballot(due && D.mcnt[l] != 0);
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1; todo &= todo - 1;
+      const uint32_t o_ = __shfl(o, leader), key_ = __shfl(w[1], leader);
+      uint32_t left_ = __shfl(due ? D.mcnt[l] : 0u, leader), cnt = 0, b = NONE, bh = 0;
+      for (uint32_t row0 = 0; row0 < D.M && left_; row0 += 64) {
+        const uint32_t row = row0 + lane; bool present = false;
+        if (row < D.M) {
+          const uint32_t x = D.mrow_subj[(size_t)r * D.M + row];
+          if (x != NONE) {
+            const uint32_t av = D.mA[m_idx(D, r, row, o_ - D.i0)];
+            present = av != 0;
+            if (av && x != o_ && MA_STATE(av) == SWIM_STATE_DEAD && !MA_ERASED(av)) {
+              cnt++;
+              const uint32_t h = sw_fmix32(x ^ key_);
+              if (b == NONE || h < bh || (h == bh && x < b)) { b = x; bh = h; }
+            }
+          }
+        }
+        left_ -= (uint32_t)__popcll(__ballot(present));
+      }
+      for (int off = 32; off; off >>= 1) {
+        cnt += __shfl_xor(cnt, off);
+        const uint32_t ob = __shfl_xor(b, off), obh = __shfl_xor(bh, off);
+        if (ob != NONE && (b == NONE || obh < bh || (obh == bh && ob < b))) { b = ob; bh = obh; }
+      }
+      if (lane == leader && cnt) {
+        n_failed += cnt;
+        if (best == NONE || bh < best_h || (bh == best_h && b < best)) { best = b; best_h = bh; }
+      }
+    }
+  }
+  bool go = false;
+  if (due && n_failed) {
+    const uint32_t members = est_n(D, r, l), alive = members > n_failed ? members - n_failed : 1u;
+    if ((uint64_t)w[0] * alive <= ((uint64_t)n_failed << 32)) {          // rand.Float32() <= prob
+      S.add(ST_RECONNECTS);
+      const uint32_t wo = D.nw[(size_t)r * D.N + o], wp = D.nw[(size_t)r * D.N + best];
+      go = !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp);                  // else the dial fails
+      if (go) S.add(ST_RECONNECT_OK);
+    }
+  }
+  uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
+  send_state(D, go, r, o, best, c_edges, c_remote, c_filt);
+  const uint32_t sh = go ? best / D.nloc : 0;
+  wave_append_sharded(D, go, sh, mk_edge(D, r, best, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
+  c_edges += go; c_remote += go && sh != D.rank;
+  S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
+  if (D.n_shards > 1 && __any(go) && lane == 0) *D.act = 1;
+  S.flush(D);
 }

@@ -235,7 +235,11 @@ class Sim:
         buf = (abi.Event * cap)()
         cnt = C.c_size_t()
         self._ck("swim_poll_events", self._l.swim_poll_events(self._h, buf, cap, C.byref(cnt)))
-        return [(e.time_ms, e.replica, e.type, e.node, e.ltime, e.incarnation) for e in buf[: cnt.value]]
+        return [(e.time_ms, e.replica, e.type, e.node, e.ltime, e.incarnation, e.observer) for e in buf[: cnt.value]]
+
+    def watch_events(self, replica: int, node: int):
+        """swim_watch_events: record this node's serf events too (an EventCh per agent)."""
+        self._ck("swim_watch_events", self._l.swim_watch_events(self._h, replica, node))
 
     def node_info(self, replica: int, node: int) -> abi.NodeInfo:
         o = abi.NodeInfo()

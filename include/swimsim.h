@@ -149,6 +149,13 @@ typedef struct swim_config {
    * emitted (agent/consul/server_serf.go:279, timeouts agent/consul/config.go:640-641; the reference's tests run it at
    * 250-300 ms: agent/consul/server_test.go:673-678).  0 = the reaper is off. */
   uint32_t reap_interval_ms, reconnect_timeout_ms, tombstone_timeout_ms;
+  uint32_t reconnect_interval_ms;   /* serf ReconnectInterval (serf default 30 s; Consul leaves it): every interval a node picks one
+                                       member it holds Failed — with probability failed/alive, like serf's reconnect() — and
+                                       tries to rejoin it: memberlist.Join([addr]) = a state exchange with that member, which
+                                       succeeds when it is running and in reach.  This is what heals a partition that lasted
+                                       longer than GossipToTheDeadTime: by then nobody gossips to, probes or push-pulls with
+                                       the other side any more.  Members erased by the reaper are not tried (serf: until
+                                       ReconnectTimeout, agent/consul/config.go:640).  0 = off                          */
   uint32_t fold_interval_ms;        /* every so often a subject on which ALL acting observers agree (same
                                        incarnation and state, not Suspect, Dead for longer than
                                        GossipToTheDeadTime) is folded into the base row and its entries are
@@ -195,6 +202,7 @@ typedef struct swim_derived {
   uint32_t view_cap;                /* resolved swim_config.view_cap                         */
   uint32_t fold_period_ticks;       /* fold_interval_ms / quantum, rounded up (0 = off)      */
   uint32_t reap_period_ticks;       /* reap_interval_ms / quantum, rounded up (0 = off)      */
+  uint32_t reconnect_period_ticks;  /* reconnect_interval_ms / quantum, rounded up (0 = off) */
 } swim_derived;
 
 /* one row of an observer's member list: serf.Member / memberlist.Node reduced to integers
@@ -217,6 +225,7 @@ typedef struct swim_event {
   uint32_t node;                    /* member id, or user-event id                          */
   uint32_t ltime;                   /* user events: Lamport time                            */
   uint32_t incarnation;
+  uint32_t observer;                /* whose EventCh this is: cfg.watch_node or a node added with swim_watch_events */
 } swim_event;
 
 /* one entry of a node's TransmitLimitedQueue */
@@ -280,6 +289,8 @@ typedef struct swim_stats_t {
   uint64_t fold_freed;              /* explicit view entries freed by folding                                   */
   uint64_t coord_updates;           /* coordinate.Client.Update calls (one per direct probe ack, SWIM_F_COORDINATES) */
   uint64_t coord_resets;            /* ... that left an invalid coordinate and reset it (Client.stats.Resets)     */
+  uint64_t reconnects;              /* serf reconnect(): attempts (a node that passed the failed/alive gate and picked a member) */
+  uint64_t reconnects_reached;      /* ... whose member was running and in reach: a state exchange went out        */
   uint64_t inbox_peak;              /* the largest number of messages one node received in one tick, counted from six on (five
                                        fit the node's inbox line; 0 = never more).  Sizes inbox_cap: a state exchange delivers
                                        a whole table at once                                                        */
@@ -412,6 +423,11 @@ int swim_watch(swim_sim* sim, uint32_t replica, uint32_t subject);
 /* serf.Config.EventCh drained by lanEventHandler (server_serf.go:270): events seen by
  * cfg.watch_node of every replica, oldest first */
 int swim_poll_events(swim_sim* sim, swim_event* out, size_t cap, size_t* n_out);
+/* One EventCh per agent (agent/consul/server.go:112-114, client.go:51-59): from now on the serf events of `node` are recorded
+ * too, tick-exact like cfg.watch_node's (swim_event.observer says whose).  At most SWIM_EVENT_WATCHERS per replica
+ * (SWIM_EOVERFLOW beyond); the node must live on this shard (SWIM_ERANGE). */
+#define SWIM_EVENT_WATCHERS 64
+int swim_watch_events(swim_sim* sim, uint32_t replica, uint32_t node);
 int swim_node_info_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_node_info* out);
 int swim_census_get(swim_sim* sim, uint32_t replica, uint32_t subject, swim_census* out);
 /* BASELINE config #4's deliverable ("rounds until all survivors mark all victims dead"), for any mix of stopped and

@@ -70,36 +70,8 @@ inline Config DefaultLocalConfig() {
   return c;
 }
 
-struct Address { std::string Addr, Name; };
-struct Packet { std::vector<uint8_t> Buf; std::string From; Duration Timestamp{0}; };
-
-// memberlist.Transport / NodeAwareTransport (poll model instead of channels: no callbacks cross the ABI)
-struct Transport {
-  virtual ~Transport() = default;
-  virtual std::pair<std::string, int> FinalAdvertiseAddr(const std::string& ip, int port) = 0;
-  virtual Duration WriteTo(const std::vector<uint8_t>& b, const std::string& addr) = 0;
-  virtual bool PollPacket(Packet* out) = 0;                    // PacketCh()
-  virtual void Shutdown() = 0;
-};
-struct NodeAwareTransport : Transport {
-  virtual Duration WriteToAddress(const std::vector<uint8_t>& b, const Address& addr) = 0;
-};
-// memberlist.Delegate / EventDelegate
-struct Delegate {
-  virtual ~Delegate() = default;
-  virtual std::vector<uint8_t> NodeMeta(int limit) = 0;
-  virtual void NotifyMsg(const std::vector<uint8_t>& msg) = 0;
-  virtual std::vector<std::vector<uint8_t>> GetBroadcasts(int overhead, int limit) = 0;
-  virtual std::vector<uint8_t> LocalState(bool join) = 0;
-  virtual void MergeRemoteState(const std::vector<uint8_t>& buf, bool join) = 0;
-};
-struct Node { std::string Name, Addr; uint16_t Port = 0; uint32_t Incarnation = 0; int State = 0; };
-struct EventDelegate {
-  virtual ~EventDelegate() = default;
-  virtual void NotifyJoin(const Node&) = 0;
-  virtual void NotifyLeave(const Node&) = 0;
-  virtual void NotifyUpdate(const Node&) = 0;
-};
+// (memberlist.Transport / NodeAwareTransport at the byte level is include/swimsim_wire.hpp's BridgeTransport; memberlist's
+// Delegate / EventDelegate are what serf itself implements inside the simulator — the facade below is the serf side of them.)
 }  // namespace memberlist
 
 // =================================================================================================
@@ -156,6 +128,13 @@ struct Config {
   Duration LeavePropagateDelay{1000};
   int EventBuffer = 512, UserEventSizeLimit = 512, MaxQueueDepth = 4096, MinQueueDepth = 0;
   uint8_t ProtocolVersion = 4;
+  // serf.Config.Merge (MergeDelegate.NotifyMerge): called with the members a join / push-pull would merge; a non-empty string
+  // is the error that vetoes it.  Consul: lanMergeDelegate / wanMergeDelegate (agent/consul/merge.go:34-87, 111-131) refuse a
+  // member of another datacenter, a server id clash, a segment mismatch.
+  std::function<std::string(const std::vector<Member>&)> Merge;
+  // serf.Config.ReconnectTimeoutOverride.ReconnectTimeout(member, timeout): per-member reap timeout
+  // (internal/gossip/libserf/serf.go:68-85 reads the member's "rc_tm" tag)
+  std::function<Duration(const Member&, Duration)> ReconnectTimeoutOverride;
 };
 inline Config DefaultConfig() { return Config{}; }
 // internal/gossip/libserf/serf.go:19-36 + agent/consul/config.go:640-641
@@ -186,6 +165,11 @@ class Cluster {
     // probe ack.  The latency the probes measure is the simulator's model (swimsim.h, swim_config.rtt_*).
     bool Coordinates = false;
     uint32_t RttScaleUs = 40000, RttHeightUs = 2000, RttJitterUs = 0;
+    // serf.Config.ReconnectInterval of the members (serf default 30 s): what heals a partition older than GossipToTheDeadTime
+    uint32_t ReconnectIntervalMs = 0;
+    // The tags of a virtual member nobody holds a Serf handle for (every member carries tags in serf: Consul's consumers start
+    // with metadata.IsConsulServer(m) on m.Tags["role"], agent/metadata/server.go:77-80).  nullptr: {"role": "node"}.
+    std::function<std::map<std::string, std::string>(uint32_t)> DefaultTags;
   };
   Cluster(const memberlist::Config& mc, const Options& o) : opts_(o) {
     check(swim_config_preset(&cfg_, SWIM_PRESET_LAN), "swim_config_preset");
@@ -200,6 +184,7 @@ class Cluster {
     cfg_.event_buffer = (uint32_t)o.EventBuffer; cfg_.flags |= SWIM_F_SERF_EVENTS;
     cfg_.n_initial = o.Initial; cfg_.view_cap = o.ViewCap; cfg_.fold_interval_ms = o.FoldIntervalMs;
     cfg_.reap_interval_ms = o.ReapIntervalMs; cfg_.reconnect_timeout_ms = o.ReconnectTimeoutMs; cfg_.tombstone_timeout_ms = o.TombstoneTimeoutMs;
+    cfg_.reconnect_interval_ms = o.ReconnectIntervalMs;
     if (o.Coordinates) { cfg_.flags |= SWIM_F_COORDINATES; cfg_.rtt_scale_us = o.RttScaleUs; cfg_.rtt_height_us = o.RttHeightUs; cfg_.rtt_jitter_us = o.RttJitterUs; }
     check(swim_config_derive(&cfg_, &derived_), "swim_config_derive");
     check(swim_create(&cfg_, &sim_), "swim_create");
@@ -229,6 +214,36 @@ class Cluster {
   void Restore(const std::string& path) { check(swim_checkpoint_load(sim_, path.c_str()), "swim_checkpoint_load"); }
   void SetPacketLoss(double p) { check(swim_set_loss(sim_, (uint32_t)std::min(4294967295.0, p * 4294967296.0)), "swim_set_loss"); }
 
+  // ---- what the members of the pool share on the host: tags by member, the EventCh router, who holds a handle ----
+  static uint64_t key(uint32_t replica, uint32_t id) { return ((uint64_t)replica << 32) | id; }
+  void SetTags(uint32_t replica, uint32_t id, const std::map<std::string, std::string>& t) { tags_[key(replica, id)] = t; }
+  std::map<std::string, std::string> TagsOf(uint32_t replica, uint32_t id) const {
+    auto it = tags_.find(key(replica, id));
+    if (it != tags_.end()) return it->second;
+    if (opts_.DefaultTags) return opts_.DefaultTags(id);
+    return { { "role", "node" } };
+  }
+  // swim_poll_events hands out every observer's events in one stream: sort them into the handles' channels (nothing is dropped:
+  // an event for an observer without a handle waits in its queue)
+  void Route() {
+    swim_event buf[256]; size_t n = 0;
+    do {
+      check(swim_poll_events(sim_, buf, 256, &n), "swim_poll_events");
+      for (size_t i = 0; i < n; i++) inbox_[key(buf[i].replica, buf[i].observer)].push_back(buf[i]);
+    } while (n == 256);
+  }
+  bool NextEvent(uint32_t replica, uint32_t id, swim_event* out) {
+    auto it = inbox_.find(key(replica, id));
+    if (it == inbox_.end() || it->second.empty()) return false;
+    *out = it->second.front(); it->second.pop_front();
+    return true;
+  }
+  // does the device record this member's serf events tick by tick (cfg.watch_node, or registered with swim_watch_events)?
+  bool WatchEvents(uint32_t replica, uint32_t id) { return id == cfg_.watch_node || swim_watch_events(sim_, replica, id) == SWIM_OK; }
+  void Register(uint32_t replica, uint32_t id, void* serf) { handles_[key(replica, id)] = serf; }
+  void Unregister(uint32_t replica, uint32_t id, void* serf) { auto it = handles_.find(key(replica, id)); if (it != handles_.end() && it->second == serf) handles_.erase(it); }
+  void* HandleOf(uint32_t replica, uint32_t id) const { auto it = handles_.find(key(replica, id)); return it == handles_.end() ? nullptr : it->second; }
+
   swim_sim* handle() const { return sim_; }
   const swim_config& config() const { return cfg_; }
   const swim_derived& derived() const { return derived_; }
@@ -242,6 +257,9 @@ class Cluster {
   swim_config cfg_{};
   swim_derived derived_{};
   swim_sim* sim_ = nullptr;
+  std::map<uint64_t, std::map<std::string, std::string>> tags_;
+  std::map<uint64_t, std::deque<swim_event>> inbox_;
+  std::map<uint64_t, void*> handles_;
 };
 
 // One member's *serf.Serf.
@@ -249,6 +267,7 @@ class Serf {
  public:
   // serf.Create(conf): conf.NodeName must name a member of the pool ("node-<id>").  For an id that is not running (beyond
   // Cluster::Options::Initial, or shut down earlier) this is a new process of that name: it starts with its first Join.
+  ~Serf() { pool_->Unregister(replica_, id_, this); }
   static std::unique_ptr<Serf> Create(const Config& conf, std::shared_ptr<Cluster> pool, uint32_t id, uint32_t replica = 0) {
     if (!pool || id >= pool->config().n_nodes) throw Error("serf.Create: unknown member", SWIM_ERANGE);
     if (conf.UserEventSizeLimit > 9 * 1024) throw Error("serf.Create: user event size limit exceeds limit of 9216 bytes", SWIM_EINVAL);
@@ -273,6 +292,8 @@ class Serf {
       if (st == StatusNone) continue;
       if (!device_reaper && (st == StatusFailed || st == StatusLeft)) {   // the pool runs no reaper: this member's own timeouts
         int64_t limit = st == StatusFailed ? conf_.ReconnectTimeout.count() : conf_.TombstoneTimeout.count();
+        if (st == StatusFailed && conf_.ReconnectTimeoutOverride)           // serf.go reap(): the override sees the member (its rc_tm tag)
+          limit = conf_.ReconnectTimeoutOverride(makeMember(r.id, st, r.incarnation), conf_.ReconnectTimeout).count();
         int64_t checked = now / reap_q * reap_q;                     // the reaper only looks every ReapInterval
         if (checked - (int64_t)r.state_change_ms > limit) continue;
       }
@@ -284,7 +305,6 @@ class Serf {
     swim_member r;
     check(swim_view(pool_->handle(), replica_, id_, id_, &r), "swim_view");
     Member m = makeMember(id_, (MemberStatus)r.status, r.incarnation);
-    m.Tags = conf_.Tags;
     if (state_ == SerfLeaving) m.Status = StatusLeaving;
     if (state_ == SerfLeft) m.Status = StatusLeft;
     return m;
@@ -319,6 +339,21 @@ class Serf {
     swim_node_info me; check(swim_node_info_get(pool_->handle(), replica_, id_, &me), "swim_node_info_get");
     if (!me.alive) {                                    // a process that starts now
       if (via == SWIM_NONE) throw Error("Join: failed to join any of the " + std::to_string(existing.size()) + " addresses", SWIM_ESTATE);
+      // MergeDelegate.NotifyMerge on both ends of the join push-pull (agent/consul/merge.go:34-87): this member looks at what
+      // `via` would hand over, `via` (when somebody holds its handle) at this member; an error on either side vetoes the join
+      if (conf_.Merge) {
+        std::vector<swim_member> raw(pool_->config().n_nodes); size_t n = 0;
+        check(swim_members(pool_->handle(), replica_, via, raw.data(), raw.size(), &n), "swim_members");
+        std::vector<Member> theirs;
+        for (size_t i = 0; i < n; i++) if (raw[i].status != StatusNone) theirs.push_back(makeMember(raw[i].id, (MemberStatus)raw[i].status, raw[i].incarnation));
+        const std::string err = conf_.Merge(theirs);
+        if (!err.empty()) throw Error("Join: merge canceled: " + err, SWIM_ESTATE);
+      }
+      if (Serf* peer = static_cast<Serf*>(pool_->HandleOf(replica_, via)))
+        if (peer->conf_.Merge) {
+          const std::string err = peer->conf_.Merge({ makeMember(id_, StatusAlive, me.incarnation + 1) });
+          if (!err.empty()) throw Error("Join: merge canceled by " + Cluster::NodeName(via) + ": " + err, SWIM_ESTATE);
+        }
       check(swim_inject_join(pool_->handle(), replica_, &id_, 1, via), "swim_inject_join");
     }
     return contacted;
@@ -349,7 +384,7 @@ class Serf {
   }
   void SetTags(const std::map<std::string, std::string>& tags) {
     requireNotShutdown("SetTags");
-    conf_.Tags = tags;
+    conf_.Tags = tags; pool_->SetTags(replica_, id_, tags);
     check(swim_inject_update(pool_->handle(), replica_, &id_, 1), "swim_inject_update");   // memberlist.UpdateNode
   }
   // RemoveFailedNode / RemoveFailedNodePrune: a Lamport-clocked leave intent on behalf of `node`, gossiped to the pool
@@ -383,6 +418,9 @@ class Serf {
   struct Fired { std::string name; std::vector<uint8_t> payload; bool coalesce; };
   Serf(const Config& c, std::shared_ptr<Cluster> p, uint32_t id, uint32_t r) : conf_(c), pool_(std::move(p)), id_(id), replica_(r) {
     if (conf_.NodeName.empty()) conf_.NodeName = Cluster::NodeName(id);
+    if (!conf_.Tags.empty()) pool_->SetTags(replica_, id_, conf_.Tags);
+    pool_->Register(replica_, id_, this);
+    exact_ = pool_->WatchEvents(replica_, id_);        // an EventCh of its own on the device (up to SWIM_EVENT_WATCHERS per pool replica)
   }
   void forceLeave(const std::string& node, bool prune) {
     requireNotShutdown("RemoveFailedNode");
@@ -407,6 +445,7 @@ class Serf {
   }
   Member makeMember(uint32_t id, MemberStatus st, uint32_t inc) const {
     Member m; m.id = id; m.Name = Cluster::NodeName(id); m.Addr = Cluster::NodeAddr(id); m.Port = 8301; m.Status = st; m.Incarnation = inc;
+    m.Tags = pool_->TagsOf(replica_, id);              // every member carries its tags (a registry on the host, keyed by member)
     return m;
   }
   static uint32_t idOf(const std::string& name) {
@@ -448,33 +487,33 @@ class Serf {
     }
     seen_ = std::move(now); diff_primed_ = true;
   }
-  // swim_poll_events -> EventCh (only the pool's watch node has its events recorded on the device)
+  // swim_poll_events -> EventCh.  The device records the events of the pool's watch node and of every handle registered with
+  // swim_watch_events (the first SWIM_EVENT_WATCHERS per pool replica), tick-exact; the pool routes them by observer, so a handle
+  // never swallows another handle's (or another replica's) events.  A handle beyond that number derives its member events.
   void pump() {
-    if (id_ != pool_->config().watch_node) { pump_by_diff(); return; }
-    swim_event buf[256]; size_t n = 0;
-    do {
-      check(swim_poll_events(pool_->handle(), buf, 256, &n), "swim_poll_events");
-      for (size_t i = 0; i < n; i++) {
-        if (buf[i].replica != replica_) continue;
-        Event e; e.Type = (EventType)buf[i].type; e.At = Duration(buf[i].time_ms);
-        if (e.Type == EventUser) {
-          auto it = catalog().find(buf[i].node);
-          e.LTime = buf[i].ltime;
-          if (it != catalog().end()) { e.Name = it->second.name; e.Payload = it->second.payload; e.Coalesce = it->second.coalesce; }
-        } else {
-          MemberStatus st = e.Type == EventMemberFailed ? StatusFailed : e.Type == EventMemberLeave ? StatusLeft
-                          : e.Type == EventMemberReap ? StatusNone : StatusAlive;
-          e.Members.push_back(makeMember(buf[i].node, st, buf[i].incarnation));
-        }
-        ch_.push_back(std::move(e));
+    if (!exact_) { pump_by_diff(); return; }
+    pool_->Route();
+    swim_event ev;
+    while (pool_->NextEvent(replica_, id_, &ev)) {
+      Event e; e.Type = (EventType)ev.type; e.At = Duration(ev.time_ms);
+      if (e.Type == EventUser) {
+        auto it = catalog().find(ev.node);
+        e.LTime = ev.ltime;
+        if (it != catalog().end()) { e.Name = it->second.name; e.Payload = it->second.payload; e.Coalesce = it->second.coalesce; }
+      } else {
+        MemberStatus st = e.Type == EventMemberFailed ? StatusFailed : e.Type == EventMemberLeave ? StatusLeft
+                        : e.Type == EventMemberReap ? StatusNone : StatusAlive;
+        e.Members.push_back(makeMember(ev.node, st, ev.incarnation));
       }
-    } while (n == 256);
+      ch_.push_back(std::move(e));
+    }
   }
 
   Config conf_;
   std::shared_ptr<Cluster> pool_;
   uint32_t id_, replica_;
   SerfState state_ = SerfAlive;
+  bool exact_ = false;                       // the device records this member's events (else: derived from member-list snapshots)
   std::deque<Event> ch_;
   std::map<uint32_t, std::pair<MemberStatus, uint32_t>> seen_; bool diff_primed_ = false;   // pump_by_diff: the previous snapshot
 };

@@ -44,7 +44,7 @@
 /* RNG and hashing                                                                             */
 /* ------------------------------------------------------------------------------------------ */
 
-enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4, STREAM_PUSHPULL = 5, STREAM_TRUTH = 6, STREAM_RTT = 7, STREAM_COORD = 8 };
+enum { STREAM_GOSSIP = 1, STREAM_PERM = 2, STREAM_INDIRECT = 3, STREAM_LOSS = 4, STREAM_PUSHPULL = 5, STREAM_TRUTH = 6, STREAM_RTT = 7, STREAM_COORD = 8, STREAM_RECONNECT = 9 };
 
 /* Philox4x32-10 (Salmon et al., SC'11; Random123).  Pinned by kat vectors in the tests. */
 static void philox4x32(const uint32_t c[4], const uint32_t k[2], uint32_t o[4]) {
@@ -228,6 +228,7 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
   d->view_cap = c->view_cap ? c->view_cap : (c->n_nodes < 32 ? c->n_nodes : 32);
   d->fold_period_ticks = (c->fold_interval_ms + q - 1) / q;
   d->reap_period_ticks = (c->reap_interval_ms + q - 1) / q;
+  d->reconnect_period_ticks = (c->reconnect_interval_ms + q - 1) / q;
   return SWIM_OK;
 }
 
@@ -290,6 +291,7 @@ struct swim_sim {
   swim_config cfg; swim_derived d;
   uint32_t N, R, nloc, i0, tick; int in_tick;
   uint32_t ev_words;             /* words per event-buffer slot: ltime, n, ids */
+  uint32_t *ev_watch, *n_ev_watch, ev_observer;   /* swim_watch_events: [R][SWIM_EVENT_WATCHERS] observers with an EventCh of their own; whose event record_event writes next */
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
   uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
   uint8_t* alone;                /* [R*N] replicated: started by swim_inject_join, join push-pull not carried out (yet): it knows nobody */
@@ -310,7 +312,7 @@ struct swim_sim {
   edgevec in, last_edges;
   edgevec carry[2];              /* piggy-backed broadcasts picked in tick t travel with tick t+1's packets */
   edgevec pp_reply[2];           /* push-pull requests seen in tick t are answered in tick t+1: {dst=replier, subject=requester, incarnation=replica} */
-  swim_event* events; size_t n_events, cap_events;
+  swim_event* events; size_t n_events, cap_events, n_sorted;   /* n_sorted: the events a poll has already put in delivery order */
   swim_stats_t st;
   uint32_t loss_q32;
   /* swim_xchg_*: the other shards of the population (same process) and ticks one of them already ran on our behalf */
@@ -335,13 +337,21 @@ static inline int acts(const swim_sim* s, uint32_t r, uint32_t i) { size_t g = (
 static inline uint32_t gphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk) % s->d.gossip_period; }
 static inline uint32_t pphase_of(const swim_sim* s, uint32_t i) { return (i / s->d.phase_chunk / s->d.gossip_period) % s->d.probe_period; }
 
+static int watching(swim_sim* s, uint32_t r, uint32_t o);
 static void record_event(swim_sim* s, uint32_t r, uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
   if (s->n_events == s->cap_events) {
     s->cap_events = s->cap_events ? s->cap_events * 2 : 256;
     s->events = (swim_event*)realloc(s->events, s->cap_events * sizeof(swim_event));
   }
-  swim_event e = { now_ms(s), r, type, node, ltime, inc };
+  swim_event e = { now_ms(s), r, type, node, ltime, inc, s->ev_observer };
   s->events[s->n_events++] = e;
+}
+/* does observer o of replica r have an EventCh (cfg.watch_node, or added with swim_watch_events)?  Notes whose event comes next. */
+static int watching(swim_sim* s, uint32_t r, uint32_t o) {
+  s->ev_observer = o;
+  if (o == s->cfg.watch_node) return 1;
+  for (uint32_t j = 0; j < s->n_ev_watch[r]; j++) if (s->ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + j] == o) return 1;
+  return 0;
 }
 
 /* ---- an observer's explicit views --------------------------------------------------------------- */
@@ -608,7 +618,7 @@ static void alive_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
   broadcast(s, nd, x, SWIM_MSG_ALIVE, inc, upd);
   set_view(s, r, x, v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
   s->st.msgs_applied[SWIM_MSG_ALIVE]++;
-  if (o == s->cfg.watch_node) {
+  if (watching(s, r, o)) {
     if (old == SWIM_STATE_DEAD || old == SWIM_STATE_LEFT) record_event(s, r, SWIM_EVENT_MEMBER_JOIN, x, 0, inc);
     else if (upd) record_event(s, r, SWIM_EVENT_MEMBER_UPDATE, x, 0, inc);   /* NotifyUpdate: meta changed */
   }
@@ -653,7 +663,7 @@ static void dead_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t 
   v->leaving = 0;
   set_view(s, r, x, v, inc, st, 1);
   s->st.msgs_applied[SWIM_MSG_DEAD]++;
-  if (o == s->cfg.watch_node && x != o)
+  if (x != o && watching(s, r, o))
     record_event(s, r, st == SWIM_STATE_LEFT ? SWIM_EVENT_MEMBER_LEAVE : SWIM_EVENT_MEMBER_FAILED, x, 0, inc);
 }
 
@@ -679,11 +689,11 @@ static void leave_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32
   if (st == SWIM_STATE_DEAD) {
     set_view(s, r, x, v, KINC(key), SWIM_STATE_LEFT, 1);
     s->st.intents_applied++;
-    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_LEAVE, x, 0, KINC(key));
+    if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_MEMBER_LEAVE, x, 0, KINC(key));
   }
   if (prune) {
     v->reaped = 1; s->st.reaped++; touch_slot(s, r, x);
-    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_REAP, x, 0, KINC(key));
+    if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_MEMBER_REAP, x, 0, KINC(key));
   }
 }
 
@@ -703,7 +713,7 @@ static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
   if (id & SWIM_INTENT_LEAVE) leave_intent(s, r, o, nd, id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
   else {
     s->st.user_events_delivered++;
-    if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
+    if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
   }
   queue_push(s, nd->evq, &nd->evqlen, &nd->evqseq, s->cfg.event_queue_cap, 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
 }
@@ -1147,6 +1157,43 @@ static void phase_pushpull(swim_sim* s) {
     }
 }
 
+/* serf.go reconnect() (every ReconnectInterval, per node): n failed members, prob = n / alive members; with probability prob
+ * pick one failed member uniformly and memberlist.Join([its address]) — a state exchange (pushPullNode, join) that succeeds when
+ * the member runs and is in reach.  Here: a node is due in tick (id mod period), grouped to probe-interval boundaries like
+ * push-pull; "failed" = its explicit Dead views that serf has not erased (a death folded into the base row is settled for
+ * everybody and not retried); the gate compares a Philox word with n / alive in integers; the uniform pick is the member with
+ * the smallest keyed hash (no order of enumeration enters). */
+static void phase_reconnect(swim_sim* s) {
+  uint32_t per = s->d.reconnect_period_ticks, grp = s->d.probe_period;
+  if (!per || s->tick % grp) return;
+  for (uint32_t r = 0; r < s->R; r++)
+   for (uint32_t off = 0; off < grp && off < per; off++)
+    for (uint64_t i64 = (s->tick + off) % per; i64 < s->N; i64 += per) {
+      uint32_t o = (uint32_t)i64;
+      if (!is_local(s, o) || !acts(s, r, o)) continue;
+      node_t* nd = node_at(s, r, o);
+      uint32_t key[2], c[4] = { s->tick, o, 0, 0x5245434Eu }, w[4];
+      stream_key(seed_of(s, r), STREAM_RECONNECT, key); philox4x32(c, key, w);
+      uint32_t n_failed = 0, best = SWIM_NONE, best_h = 0;
+      for (uint32_t i = 0; i < nd->vt.slots; i++) {
+        const view_t* v = &nd->vt.e[i];
+        if (v->subj == V_EMPTY || v->subj == o || KST(v->key) != SWIM_STATE_DEAD || v->reaped) continue;
+        n_failed++;
+        uint32_t h = fmix32(v->subj ^ w[1]);
+        if (best == SWIM_NONE || h < best_h || (h == best_h && v->subj < best)) { best = v->subj; best_h = h; }
+      }
+      if (!n_failed) continue;
+      uint32_t members = est_n(s, r, nd), alive = members > n_failed ? members - n_failed : 1;
+      if ((uint64_t)w[0] * alive > ((uint64_t)n_failed << 32)) continue;          /* rand.Float32() > prob */
+      s->st.reconnects++;
+      size_t base = (size_t)r * s->N;
+      if (!s->gt_alive[base + best] || s->part[base + o] != s->part[base + best]) continue;   /* the dial fails */
+      s->st.reconnects_reached++;
+      send_state(s, r, o, best);
+      emit(s, r, best, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0);
+    }
+}
+
 /* gossip(): k random peers; per peer one getBroadcasts() = memberlist queue, then the serf
  * delegate's user events in the bytes that remain; stop at the first empty packet */
 static void phase_gossip(swim_sim* s) {
@@ -1215,7 +1262,7 @@ static void phase_reap(swim_sim* s) {
         uint32_t st = KST(v->key);
         if (st < SWIM_STATE_DEAD || !(now - v->since > (st == SWIM_STATE_DEAD ? s->cfg.reconnect_timeout_ms : s->cfg.tombstone_timeout_ms))) continue;
         v->reaped = 1; s->st.reaped++; touch_slot(s, r, v->subj);
-        if (o == s->cfg.watch_node) record_event(s, r, SWIM_EVENT_MEMBER_REAP, v->subj, 0, KINC(v->key));
+        if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_MEMBER_REAP, v->subj, 0, KINC(v->key));
       }
     }
 }
@@ -1412,6 +1459,7 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   s->ev_words = 4 * (((cfg->event_ids_per_ltime ? cfg->event_ids_per_ltime : 14) + 2 + 3) / 4);      /* 14 ids: a 64-byte slot */
   s->nloc = s->N / cfg->n_shards; s->i0 = cfg->shard_rank * s->nloc; s->loss_q32 = cfg->loss_q32;
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
+  s->ev_watch = (uint32_t*)calloc((size_t)s->R * SWIM_EVENT_WATCHERS, 4); s->n_ev_watch = (uint32_t*)calloc(s->R, 4);
   s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1); s->alone = (uint8_t*)calloc(NT, 1);
   s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
   s->base_key = (uint32_t*)malloc(NT * 4); s->subj_cnt = (uint32_t*)calloc(NT, 4);
@@ -1454,7 +1502,7 @@ int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
   if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].ring); free(s->nodes[g].vt.e); }
   free(s->base_key); free(s->subj_cnt); free(s->base_known); free(s->join_list); free(s->f_cnt); free(s->f_kmin); free(s->f_kmax); free(s->f_bad); free(s->f_touched);
-  free(s->inbox_slab);
+  free(s->inbox_slab); free(s->ev_watch); free(s->n_ev_watch);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
   free(s->attached); free(s->alone); free(s->captured.v); free(s->cap_src); free(s->xpeers);
@@ -1487,7 +1535,7 @@ int swim_tick_begin(swim_sim* s) {
   s->in.n = 0;
   fold_census(s);
   phase_reap(s);
-  phase_expire(s); phase_probe(s); phase_pushpull(s); phase_gossip(s);
+  phase_expire(s); phase_probe(s); phase_pushpull(s); phase_reconnect(s); phase_gossip(s);
   /* swim_debug_edges: what the roles emitted (orders excluded), then the carried broadcasts before the filter */
   s->last_edges.n = 0;
   for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++)
@@ -1707,12 +1755,31 @@ int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* out, size_t c
   for (uint32_t x = 0; x < s->N && x < cap; x++) swim_view(s, r, o, x, &out[x]);
   if (n_out) *n_out = s->N; return SWIM_OK;
 }
+int swim_watch_events(swim_sim* s, uint32_t r, uint32_t node) {
+  if (!s) return SWIM_EINVAL; if (r >= s->R || node >= s->N || !is_local(s, node)) return SWIM_ERANGE;
+  if (node == s->cfg.watch_node) return SWIM_OK;
+  for (uint32_t j = 0; j < s->n_ev_watch[r]; j++) if (s->ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + j] == node) return SWIM_OK;
+  if (s->n_ev_watch[r] >= SWIM_EVENT_WATCHERS) return SWIM_EOVERFLOW;
+  s->ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + s->n_ev_watch[r]++] = node;
+  return SWIM_OK;
+}
+/* events leave in (time, replica, observer) order, each observer's own events in the order they happened (stable) */
+static int event_before(const swim_event* a, const swim_event* b) {
+  if (a->time_ms != b->time_ms) return a->time_ms < b->time_ms;
+  if (a->replica != b->replica) return a->replica < b->replica;
+  return a->observer < b->observer;
+}
 int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
+  for (size_t i = s->n_sorted; i < s->n_events; i++) {            /* insertion sort of what came in since the last poll: nearly in order already */
+    swim_event e = s->events[i]; size_t j = i;
+    while (j > s->n_sorted && event_before(&e, &s->events[j - 1])) { s->events[j] = s->events[j - 1]; j--; }
+    s->events[j] = e;
+  }
   size_t n = s->n_events < cap ? s->n_events : cap;
   memcpy(out, s->events, n * sizeof(swim_event));
   memmove(s->events, s->events + n, (s->n_events - n) * sizeof(swim_event));
-  s->n_events -= n; *n_out = n; return SWIM_OK;
+  s->n_events -= n; s->n_sorted = s->n_events; *n_out = n; return SWIM_OK;
 }
 static int rumour_cmp(const void* a, const void* b) {
   const swim_rumour *x = (const swim_rumour*)a, *y = (const swim_rumour*)b;
@@ -1930,6 +1997,7 @@ int swim_checkpoint_save(swim_sim* s, const char* path) {
   ok = ok && ck_wr_vec(f, &s->in) && ck_wr_vec(f, &s->last_edges) && ck_wr_vec(f, &s->carry[0]) && ck_wr_vec(f, &s->carry[1]);
   ok = ok && ck_wr_vec(f, &s->pp_reply[0]) && ck_wr_vec(f, &s->pp_reply[1]) && ck_wr_vec(f, &s->captured) && ck_wr(f, s->cap_src, (size_t)s->captured.n * 4);
   ok = ok && ck_wr(f, s->events, (size_t)s->n_events * sizeof(swim_event));
+  ok = ok && ck_wr(f, s->ev_watch, (size_t)s->R * SWIM_EVENT_WATCHERS * 4) && ck_wr(f, s->n_ev_watch, (size_t)s->R * 4);
   if (s->cs) ok = ok && ck_wr(f, s->cs, NL * sizeof(coord_state));
   if (fclose(f) != 0) ok = 0;
   return ok ? SWIM_OK : SWIM_EIO;
@@ -1984,11 +2052,12 @@ int swim_checkpoint_load(swim_sim* s, const char* path) {
   ok = ok && ck_rd(f, s->cap_src, (size_t)s->captured.n * 4);
   if (ok && h.n_events > s->cap_events) { swim_event* v = (swim_event*)realloc(s->events, (size_t)h.n_events * sizeof(swim_event)); if (v) { s->events = v; s->cap_events = (size_t)h.n_events; } else ok = 0; }
   ok = ok && ck_rd(f, s->events, (size_t)h.n_events * sizeof(swim_event));
+  ok = ok && ck_rd(f, s->ev_watch, (size_t)s->R * SWIM_EVENT_WATCHERS * 4) && ck_rd(f, s->n_ev_watch, (size_t)s->R * 4);
   if (s->cs) ok = ok && ck_rd(f, s->cs, NL * sizeof(coord_state));
   fclose(f);
   if (!ok) { snprintf(s->err, sizeof s->err, "checkpoint truncated or out of memory: the handle's state is undefined"); return SWIM_EIO; }
   s->tick = h.tick; s->loss_q32 = h.loss_q32; s->n_join_pending = h.n_join_pending; s->f_ntouched = h.f_ntouched; s->xcredit = h.xcredit;
-  s->n_events = (size_t)h.n_events; s->st = h.st; s->c_n = 0; s->in_tick = 0;
+  s->n_events = (size_t)h.n_events; s->n_sorted = 0; s->st = h.st; s->c_n = 0; s->in_tick = 0;
   return SWIM_OK;
 }
 

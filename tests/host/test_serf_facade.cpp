@@ -249,10 +249,106 @@ static void testCheckpointRestore() {
   std::printf("ok CheckpointRestore\n");
 }
 
+// TestLeader_FailedMember (agent/consul/leader_registrator_v1_test.go:99-160): a client joins, is shut down, and the leader —
+// consuming its EventCh like lanEventHandler does (agent/consul/server_serf.go:270-297) — turns the member's serfHealth check
+// critical.  Every consumer starts with the member's TAGS (metadata.IsConsulServer: m.Tags["role"], agent/metadata/server.go:77-80),
+// so every member of Members() and of every event must carry them, not only the local one.
+static void testFailedMemberTurnsSerfHealthCritical() {
+  serf::Cluster::Options o{ 8, 1, 8, 32, 8, 0, 3, 0, 512 };
+  o.Initial = 3;
+  o.DefaultTags = [](uint32_t id) { return std::map<std::string, std::string>{ { "role", id < 3 ? "consul" : "node" }, { "dc", "dc1" }, { "id", "uuid-" + std::to_string(id) } }; };
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+  serf::Config sc = serf::ConsulDefaultConfig(); sc.Tags = { { "role", "consul" }, { "dc", "dc1" }, { "id", "uuid-0" }, { "vsn", "2" } };
+  auto leader = serf::Serf::Create(sc, pool, 0);
+  serf::Config cc = serf::ConsulDefaultConfig(); cc.Tags = { { "role", "node" }, { "dc", "dc1" }, { "id", "uuid-5" }, { "vsn", "2" } };
+  auto client = serf::Serf::Create(cc, pool, 5);
+  EXPECT(client->Join({ "node-0" }, true) == 1);
+  std::map<std::string, std::string> serfHealth;            // node -> "passing" / "critical" (the catalog's serfHealth check)
+  auto drain = [&]() {
+    serf::Event e;
+    while (leader->PollEvent(&e))
+      for (auto& m : e.Members) {
+        EXPECT(m.Tags.count("role") == 1);                     // metadata.IsConsulServer needs it on every member of every event
+        if (e.Type == serf::EventMemberJoin) serfHealth[m.Name] = "passing";
+        if (e.Type == serf::EventMemberFailed) serfHealth[m.Name] = "critical";
+        if (e.Type == serf::EventMemberLeave || e.Type == serf::EventMemberReap) serfHealth.erase(m.Name);
+      }
+  };
+  for (int i = 0; i < 20; i++) { pool->Advance(Duration(50)); drain(); }
+  EXPECT(serfHealth["node-5"] == "passing");
+  int servers = 0, clients = 0;
+  for (auto& m : leader->Members()) { servers += m.Tags.at("role") == "consul"; clients += m.Tags.at("role") == "node"; if (m.Name == "node-5") EXPECT(m.Tags.at("id") == "uuid-5" && m.Tags.at("vsn") == "2"); }
+  EXPECT(servers == 3 && clients == 1);                      // the tags of members nobody holds a handle for come from the pool
+  client->Shutdown();
+  for (int i = 0; i < 100 && serfHealth["node-5"] != "critical"; i++) { pool->Advance(Duration(50)); drain(); }
+  EXPECT(serfHealth["node-5"] == "critical");
+  std::printf("ok FailedMemberTurnsSerfHealthCritical\n");
+}
+
+// serf.Config.Merge (lanMergeDelegate.NotifyMerge, agent/consul/merge.go:34-87): a member of another datacenter is refused —
+// by the joiner looking at the pool, and by the pool's member looking at the joiner
+static void testMergeDelegateVetoesAForeignDatacenter() {
+  serf::Cluster::Options o{ 8, 1, 8, 32, 8, 0, 4, 0, 512 };
+  o.Initial = 3;
+  o.DefaultTags = [](uint32_t) { return std::map<std::string, std::string>{ { "role", "consul" }, { "dc", "dc1" } }; };
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+  auto refuse_other_dc = [](const std::string& mine) {
+    return [mine](const std::vector<serf::Member>& ms) { for (auto& m : ms) { auto it = m.Tags.find("dc"); if (it != m.Tags.end() && it->second != mine) return std::string("Member '" + m.Name + "' part of wrong datacenter '" + it->second + "'"); } return std::string(); };
+  };
+  serf::Config sc = serf::ConsulDefaultConfig(); sc.Tags = { { "role", "consul" }, { "dc", "dc1" } }; sc.Merge = refuse_other_dc("dc1");
+  auto s0 = serf::Serf::Create(sc, pool, 0);
+  serf::Config fc = serf::ConsulDefaultConfig(); fc.Tags = { { "role", "consul" }, { "dc", "dc2" } };
+  auto foreign = serf::Serf::Create(fc, pool, 6);
+  bool vetoed = false;
+  try { foreign->Join({ "node-0" }, true); } catch (const Error& e) { vetoed = std::string(e.what()).find("wrong datacenter 'dc2'") != std::string::npos; }
+  EXPECT(vetoed);                                            // node-0's delegate refused the joiner
+  fc.Merge = refuse_other_dc("dc2");
+  auto foreign2 = serf::Serf::Create(fc, pool, 7);
+  vetoed = false;
+  try { foreign2->Join({ "node-1" }, true); } catch (const Error& e) { vetoed = std::string(e.what()).find("wrong datacenter 'dc1'") != std::string::npos; }
+  EXPECT(vetoed);                                            // the joiner's own delegate refused the pool
+  pool->Advance(Duration(1000));
+  EXPECT(s0->Members().size() == 3);                         // nobody got in
+  serf::Config ok = serf::ConsulDefaultConfig(); ok.Tags = { { "role", "node" }, { "dc", "dc1" } }; ok.Merge = refuse_other_dc("dc1");
+  auto good = serf::Serf::Create(ok, pool, 4);
+  EXPECT(good->Join({ "node-0" }, true) == 1);
+  pool->Advance(Duration(1000));
+  EXPECT(s0->Members().size() == 4);
+  std::printf("ok MergeDelegateVetoesAForeignDatacenter\n");
+}
+
+// two pools in one handle (replicas), a member of each with a Serf handle: each EventCh carries its own pool's events only, and
+// polling one never loses the other's; ReconnectTimeoutOverride reads the member's rc_tm tag (libserf/serf.go:68-85)
+static void testHandlesOnTwoReplicasAndReconnectOverride() {
+  serf::Cluster::Options o{ 16, 2, 8, 32, 8, 0, 5, 0, 512 };
+  o.DefaultTags = [](uint32_t id) { return std::map<std::string, std::string>{ { "role", "node" }, { "rc_tm", id == 3 ? "100" : "" } }; };
+  auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+  serf::Config c = serf::ConsulDefaultConfig();
+  c.ReconnectTimeout = Duration(60000); c.ReapInterval = Duration(100);
+  c.ReconnectTimeoutOverride = [](const serf::Member& m, Duration t) { auto it = m.Tags.find("rc_tm"); return it != m.Tags.end() && !it->second.empty() ? Duration(std::stol(it->second)) : t; };
+  auto a = serf::Serf::Create(c, pool, 2, 0), b = serf::Serf::Create(c, pool, 2, 1);
+  pool->Advance(Duration(500));
+  pool->Kill({ 3, 4 }, 0); pool->Kill({ 9 }, 1);
+  int a3 = 0, a4 = 0, a9 = 0, b9 = 0, b3 = 0;
+  serf::Event e;
+  for (int i = 0; i < 60; i++) {
+    pool->Advance(Duration(50));
+    while (a->PollEvent(&e)) if (e.Type == serf::EventMemberFailed) { a3 += e.Members[0].Name == "node-3"; a4 += e.Members[0].Name == "node-4"; a9 += e.Members[0].Name == "node-9"; }
+  }
+  while (b->PollEvent(&e)) if (e.Type == serf::EventMemberFailed) { b9 += e.Members[0].Name == "node-9"; b3 += e.Members[0].Name == "node-3"; }
+  EXPECT(a3 == 1 && a4 == 1 && a9 == 0);
+  EXPECT(b9 == 1 && b3 == 0);                                // replica 1's events were not swallowed while replica 0's handle polled
+  auto ms = a->Members();
+  EXPECT(statusOf(ms, "node-3") == serf::StatusNone);        // rc_tm = 100 ms: reaped from this member's list already
+  EXPECT(statusOf(ms, "node-4") == serf::StatusFailed);      // the pool-wide 60 s: still listed as failed
+  std::printf("ok HandlesOnTwoReplicasAndReconnectOverride\n");
+}
+
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
     testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates(); testCheckpointRestore(); testEventsForEveryHandle();
+    testFailedMemberTurnsSerfHealthCritical(); testMergeDelegateVetoesAForeignDatacenter(); testHandlesOnTwoReplicasAndReconnectOverride();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;
