@@ -146,7 +146,10 @@ def test_mass_failure_sharded_in_process(hip, oracle, n_shards):
     n, nv = 8192, 400
     victims = np.random.default_rng(9).choice(n, size=nv, replace=False)
     kw = dict(n_nodes=n, seed=9, queue_cap=16, inbox_cap=2048, subject_cap=4, fold_interval_ms=20000)
-    for xchg in (LocalExchange, LibraryExchange):
+    # (the mailbox exchange with FOUR shards in one process depends on each shard's stream getting a hardware queue of its own —
+    # a wait kernel spins until its sources have signalled — which the runtime does not promise; the four-PROCESS case is
+    # tests/test_scale_gpu.py's, here the mailboxes run with two)
+    for xchg in ((LocalExchange, LibraryExchange) if n_shards == 2 else (LocalExchange,)):
         a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, mass_rows=nv + 8, view_cap=8, **kw)) for i in range(n_shards)], xchg())
         b = Sim(oracle, preset(oracle, abi.PRESET_LAN, view_cap=nv + 64, **kw))
         for s in (a, b):
