@@ -340,7 +340,7 @@ def run_config5(hip, args, device) -> dict:
     of serf user events (E per second from uniformly drawn live origins, Lamport-clocked, 512-slot event buffer).  Every node is
     a subject sooner or later: all views live in the dense pair store (mass_rows = N), nothing may be dropped."""
     n, secs, E = args.config5_nodes, args.config5_seconds, args.config5_events
-    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=32, event_ids_per_ltime=62, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=16, event_ids_per_ltime=62, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
               fold_interval_ms=5000, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=abi.NONE, device=device)
     s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
     G, q = s.derived.gossip_period, s.derived.quantum_ms

@@ -541,7 +541,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
                                                   (D.rc_period ? cdiv(D.N, D.rc_period) * std::min(D.P, D.rc_period) : 0)));   // pull requests of a boundary tick: push-pull + serf reconnect
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
-  s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1);
+  s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1, cfg->mass_rows != 0);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
@@ -714,7 +714,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_deliver, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(D.M ? k_deliver<true> : k_deliver<false>, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D,
@@ -725,7 +725,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_apply_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(k_resolve, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(D.M ? k_resolve<true> : k_resolve<false>, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));

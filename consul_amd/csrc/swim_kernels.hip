@@ -153,9 +153,12 @@ __device__ void vt_erase(DevRef D, size_t l, uint32_t i) {
 }
 // observer (r, local k) looking at node x whose word is `w`: the base row unless somebody here has news about x
 // AND this observer holds an explicit view
+// (MASS: the handle has a dense pair store — a compile-time switch, so that a handle without one runs the code it ran before
+// the store existed: the extra branches cost the tick kernels of the headline workload 5-8 %)
+template <bool MASS>
 __device__ __forceinline__ uint32_t view_of(DevRef D, uint32_t r, uint32_t k, uint32_t x, uint32_t w, uint32_t* since) {
   *since = 0;
-  if (w & NW_MASS) {
+  if (MASS && (w & NW_MASS)) {
     const size_t idx = m_idx(D, r, D.mrow[(size_t)r * D.N + x], k);
     const uint32_t a = D.mA[idx];
     if (a) { if (MA_STATE(a) == SWIM_STATE_DEAD) *since = MB_TICK(D.mB[idx]) * D.quantum_ms; return MA_KEY(a); }   // (callers look at `since` of Dead views only)
@@ -341,6 +344,7 @@ __device__ __forceinline__ uint32_t awareness_apply(DevRef D, uint32_t aw, int d
 // mode 0 = gossip() (skip Left, and Dead for longer than GossipToTheDeadTime);
 // mode 1 = probeNode's indirect helpers (skip the target and anything not Alive).
 // wout[] receives the picked nodes' words so the caller needs no second lookup.
+template <bool MASS>
 __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_local, uint32_t t,
                                    uint32_t stream, uint32_t want, int mode, uint32_t target,
                                    uint32_t* out, uint32_t* wout, const ExcList& X) {
@@ -365,7 +369,7 @@ __device__ uint32_t k_random_nodes(DevRef D, uint32_t r, uint32_t o, uint32_t k_
     if (i < 4) { x = i == 0 ? x4[0] : i == 1 ? x4[1] : i == 2 ? x4[2] : x4[3]; w = i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]; }
     else { x = mod_n(D, d.get((uint32_t)i)); w = X.usable() ? X.word(x) : nw[x]; }
     if (x == o) continue;
-    uint32_t since, key = view_of(D, r, k_local, x, w, &since), st = SW_KST(key);
+    uint32_t since, key = view_of<MASS>(D, r, k_local, x, w, &since), st = SW_KST(key);
     if (mode == 0) {
       if (key < 4u) continue;                        // incarnation 0: never heard of it, not in this node's member list
       if (st == SWIM_STATE_LEFT) continue;
@@ -435,7 +439,7 @@ __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
 // role: pending — ProbeTimeout after a failed direct ping: indirectPingReq to IndirectChecks random
 // alive peers; each relays the target's ack or (Lifeguard) answers nack one ProbeTimeout later.
 // =================================================================================================
-template <int KMAX>
+template <int KMAX, bool MASS>
 __device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats, uint32_t peer_active) {
   BlockStats S; S.init(lds_stats);
   uint32_t t = *D.tick;
@@ -452,7 +456,7 @@ __device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, 
       if (p_stage(h.y) != 1 || p0.w + D.TQ != t) continue;
       uint32_t x = p0.x, wx = nw[x], peers[KMAX], pw[KMAX];
       ExcList none; none.id = nullptr; none.w = nullptr; none.n = SW_EXC_MAX + 1;   // entries span replicas: read nw
-      uint32_t np = k_random_nodes(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, 1, x, peers, pw, none);
+      uint32_t np = k_random_nodes<MASS>(D, r, i, k, t, SW_STREAM_INDIRECT, D.k_indirect, 1, x, peers, pw, none);
       uint32_t expected = 0, nacks = 0; bool acked = false;
       bool nack_in_time = 2 * D.TQ < p0.z - p0.w;
       for (uint32_t q = 0; q < np; q++) {
@@ -491,7 +495,7 @@ __device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, 
 // role: probe — memberlist probe()/probeNode (state.go) for the nodes whose probe ticker fires now.
 // Hot path per lane: own word, 8 B of probe state, one Feistel evaluation, the target's word.
 // =================================================================================================
-template <bool MULTI>
+template <bool MULTI, bool MASS>
 __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc, uint32_t* s_cnt, uint32_t peer_active) {
   ExcList X; X.stage(D, r, lds_exc);
   if (threadIdx.x == 0) s_cnt[0] = 0;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void role_probe(DevRef D, uint32_t r, uint32_t pb, ui
       while (num_check < D.N) {
         if (cursor >= D.N) { epoch = (epoch + 1) & 0xFFFFu; cursor = 0; num_check++; continue; }   // resetNodes
         uint32_t c = sw_probe_perm(seed_of(D, r), D.N, i, epoch, cursor++);
-        wx = X.usable() ? X.word(c) : nw[c]; key = view_of(D, r, k, c, wx, &since);
+        wx = X.usable() ? X.word(c) : nw[c]; key = view_of<MASS>(D, r, k, c, wx, &since);
         if (c == i || SW_KST(key) == SWIM_STATE_DEAD || SW_KST(key) == SWIM_STATE_LEFT) { num_check++; continue; }
         x = c; break;
       }
@@ -648,9 +652,10 @@ __device__ __forceinline__ bool noop_given_view(DevRef D, uint32_t key, uint32_t
 }
 // the same question for receiver lane lr and a subject whose node word is ws; `first` = the home slot of the
 // subject in the receiver's table when the caller fetched it already (have_first)
+template <bool MASS>
 __device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr, uint32_t ws, uint4 e, bool have_first, uint4 first) {
   const size_t NL = (size_t)D.R * D.nloc;
-  if (ws & NW_MASS) {                              // the pair of the dense store: one 4-byte read decides all but suspect-on-suspect
+  if (MASS && (ws & NW_MASS)) {                              // the pair of the dense store: one 4-byte read decides all but suspect-on-suspect
     const size_t idx = m_idx(D, r, D.mrow[(size_t)r * D.N + e.x], (uint32_t)(lr - (size_t)r * D.nloc));
     const uint32_t a = have_first ? first.x : D.mA[idx];
     if (a) {
@@ -719,7 +724,7 @@ __device__ uint32_t get_broadcasts(DevRef D, QV sq, uint32_t n, uint32_t& live, 
 // A lane's work is a chain of dependent memory round trips, so independent loads are issued together:
 //   trip 1  own node word + header            trip 3  subject node words (slot of each queued rumour)
 //   trip 2  queue entries + 4 candidate peers  trip 4  the receivers' view records for the no-op filter
-template <int KMAX, bool SERF, bool MULTI>
+template <int KMAX, bool SERF, bool MULTI, bool MASS>
 __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, uint4* lds_q, uint32_t* lds_stats, uint32_t* s_cnt, uint32_t* s_base, uint32_t* lds_exc) {
   uint32_t t = *D.tick;
   uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
@@ -767,7 +772,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       // trip 2: the queue entries and the first four peer candidates' node words, all independent
       uint4 e0 = qlen > 0 ? D.q[l] : make_uint4(0, 0, 0, 0), e1 = qlen > 1 ? D.q[NL + l] : make_uint4(0, 0, 0, 0);
       uint32_t found;
-      found = k_random_nodes(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
+      found = k_random_nodes<MASS>(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
       if (qlen > 0) sq[0] = e0;
       if (qlen > 1) sq[SW_BLOCK] = e1;
       for (uint32_t j = 2; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
@@ -801,11 +806,11 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       // case — every lane gossips about the same subject — that is the entry itself); rumours beyond the first take
       // the one-at-a-time path.
       if (filter) {
-        uint4 va0[KMAX]; const bool m0 = (ws0 & NW_MASS) != 0;                 // rumour 0's subject owns a row of the dense store: 4 bytes per receiver
+        uint4 va0[KMAX]; const bool m0 = MASS && (ws0 & NW_MASS) != 0;                 // rumour 0's subject owns a row of the dense store: 4 bytes per receiver
         const uint32_t h0 = (ws0 & NW_SUBJECT) ? vt_home(D, e0.x) : 0, row0 = m0 ? D.mrow[(size_t)r * D.N + e0.x] : 0;
 #pragma unroll
         for (int p = 0; p < KMAX; p++) {
-          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && (ws0 & (NW_SUBJECT | NW_MASS));
+          bool need = (uint32_t)p < npk && ok[p] && (sent_m[p] & 1u) && (!MULTI || peers[p] / D.nloc == D.rank) && e0.x != peers[p] && (ws0 & (MASS ? (NW_SUBJECT | NW_MASS) : NW_SUBJECT));
           va0[p] = !need ? make_uint4(0, 0, 0, 0) : m0 ? make_uint4(D.mA[m_idx(D, r, row0, peers[p] - D.i0)], 0, 0, 0) : D.vt[(size_t)h0 * NL + (size_t)r * D.nloc + (peers[p] - D.i0)];
         }
 #pragma unroll
@@ -813,12 +818,12 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
           if ((uint32_t)p >= npk || !ok[p] || (MULTI && peers[p] / D.nloc != D.rank)) continue;
           uint32_t tm = sent_m[p];
           const size_t lr = (size_t)r * D.nloc + (peers[p] - D.i0);
-          if ((tm & 1u) && e0.x != peers[p] && noop_at_receiver(D, r, lr, ws0, e0, true, va0[p])) { tm &= ~1u; c_filt++; }
+          if ((tm & 1u) && e0.x != peers[p] && noop_at_receiver<MASS>(D, r, lr, ws0, e0, true, va0[p])) { tm &= ~1u; c_filt++; }
           for (uint32_t m = tm & ~1u; m; m &= m - 1) {
             uint32_t j = __ffs(m) - 1; uint4 e = sq[j * SW_BLOCK];
             if (e.x == peers[p]) continue;
             uint32_t ws = j == 1 ? ws1 : (X.usable() ? X.word(e.x) : nw[e.x]);
-            if (noop_at_receiver(D, r, lr, ws, e, false, e)) { tm &= ~(1u << j); c_filt++; }
+            if (noop_at_receiver<MASS>(D, r, lr, ws, e, false, e)) { tm &= ~(1u << j); c_filt++; }
           }
           sent_m[p] = tm;
         }
@@ -926,6 +931,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
 // =================================================================================================
 // Every lane of the wave calls this together (`on` = the lane takes part); the records of a wave are
 // appended with one atomic per destination shard, never one per record.
+template <bool MASS>
 __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
   // what the base row says merges to nothing: only the owner's explicit views travel.  The lanes of the wave walk
   // their tables slot by slot together (wave_append_* is a wave-wide operation).
@@ -949,7 +955,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
         else { type = SWIM_MSG_SUSPECT; from = dst; }
         want = true;
         if (filter && x != dst) {
-          if (noop_at_receiver(D, r, (size_t)r * D.nloc + (dst - D.i0), D.nw[(size_t)r * D.N + x], make_uint4(x, SW_KINC(a.y), from, type << 30), false, a)) { want = false; c_filt++; }
+          if (noop_at_receiver<MASS>(D, r, (size_t)r * D.nloc + (dst - D.i0), D.nw[(size_t)r * D.N + x], make_uint4(x, SW_KINC(a.y), from, type << 30), false, a)) { want = false; c_filt++; }
         }
         rec = mk_edge(D, r, dst, x, SW_KINC(a.y), type, from);
       }
@@ -959,7 +965,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
   }
   // ...and the owner's pairs of the dense store.  One exchange at a time, the whole wave on it: 64 rows per step (a lane
   // walking its 26 214 rows alone would hold the launch for tens of milliseconds)
-  if (D.M) {
+  if (MASS && D.M) {
     uint64_t todo = __ballot(on && D.mcnt[lo] != 0);
     const uint32_t lane = sw_lane();
     while (todo) {
@@ -981,7 +987,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
               if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
               else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
               else { type = SWIM_MSG_SUSPECT; from = dst_; }
-              if (filt_ && x != dst_ && noop_at_receiver(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
+              if (filt_ && x != dst_ && noop_at_receiver<true>(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
               rec = mk_edge(D, r_, dst_, x, MA_INC(a), type, from);
             }
           }
@@ -1021,6 +1027,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
     c_edges += want; c_remote += want && sh != D.rank;
   }
 }
+template <bool MASS>
 __device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
   uint32_t t = *D.tick;
   if (t % D.P) return;                              // exchanges start on probe-interval boundaries only
@@ -1035,12 +1042,12 @@ __device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, 
     o = (uint32_t)i64;
     if (o >= D.i0 && o < D.i0 + D.nloc) {
       uint32_t wo = nw[o], wp;
-      if (!(wo & NW_INERT) && k_random_nodes(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X))
+      if (!(wo & NW_INERT) && k_random_nodes<MASS>(D, r, o, o - D.i0, t, SW_STREAM_PUSHPULL, 1, 1, NONE, &p, &wp, X))
         go = !(wp & NW_DEAD) && NW_PART(wo) == NW_PART(wp);          // else the TCP dial fails
     }
   }
   uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
-  send_state(D, go, r, o, p, c_edges, c_remote, c_filt);
+  send_state<MASS>(D, go, r, o, p, c_edges, c_remote, c_filt);
   uint32_t sh = go ? p / D.nloc : 0;
   wave_append_sharded(D, go, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
   c_edges += go; c_remote += go && sh != D.rank;
@@ -1050,6 +1057,7 @@ __device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, 
 }
 // pull requests are filed in 64 sub-lists (k_resolve picks one by block) so that no counter is hot
 #define SW_PP_LISTS 64
+template <bool MASS>
 __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, uint32_t* lds_stats) {
   uint32_t t = *D.tick, li = t & 1u;
   if (t == 0) return;                               // (requests of scheduled exchanges exist the tick after a boundary; a join asks any time)
@@ -1064,7 +1072,7 @@ __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, 
         r = rq.x / D.nloc; p = D.i0 + rq.x % D.nloc; o = rq.y;
         on = !(D.nw[(size_t)r * D.N + p] & NW_INERT);
       }
-      send_state(D, on, r, p, o, c_edges, c_remote, c_filt);
+      send_state<MASS>(D, on, r, p, o, c_edges, c_remote, c_filt);
     }
   }
   S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
@@ -1073,6 +1081,7 @@ __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, 
 
 // role: join — swim_inject_join: the join push-pull (pushPullNode(join=true)) of the nodes started since the last tick:
 // their state to `via` and a pull request; via answers through the ordinary reply list one tick later
+template <bool MASS>
 __device__ __forceinline__ void role_join(DevRef D, uint32_t* lds_stats) {
   const uint32_t n = *D.join_cnt < D.join_cap ? *D.join_cnt : D.join_cap;
   if (!n) return;
@@ -1089,7 +1098,7 @@ __device__ __forceinline__ void role_join(DevRef D, uint32_t* lds_stats) {
         S.add(on ? ST_JOINS : ST_JOIN_FAIL);
       }
     }
-    send_state(D, on, r, o, p, c_edges, c_remote, c_filt);
+    send_state<MASS>(D, on, r, o, p, c_edges, c_remote, c_filt);
     const uint32_t sh = on ? p / D.nloc : 0;
     wave_append_sharded(D, on, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
     c_edges += on; c_remote += on && sh != D.rank;
@@ -1335,7 +1344,7 @@ __global__ void k_coord_init(const SwDev* __restrict__ Dp) {
 __device__ unsigned long long g_bclk[2][BCLK_ROWS][4];
 #define BCLK_OUT(k, t_in_, tag) do { if (threadIdx.x == 0) { unsigned long long* row_ = g_bclk[k][blockIdx.x % BCLK_ROWS]; row_[0] = (t_in_); row_[1] = wall_clock64(); row_[2] = (tag); row_[3] = blockIdx.x; } } while (0)
 #endif
-template <int KMAX, bool SERF, bool MULTI>
+template <int KMAX, bool SERF, bool MULTI, bool MASS>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_BEGIN_WAVES, 8))) k_begin(const SwDev* __restrict__ Dp, BeginPlan pl) {
   SW_DEV_BIND
   extern __shared__ uint4 lds_q[];
@@ -1355,33 +1364,37 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #endif
   if (b < pl.nb_expire) { if (pl.roles & 1u) role_expire(D, b, pl.nb_expire); ROLE_DONE(0); return; }
   b -= pl.nb_expire;
-  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX>(D, b, pl.nb_pend, lds_stats, MULTI ? *D.peer_act : 1u); ROLE_DONE(1); return; }
+  if (b < pl.nb_pend) { if (pl.roles & 2u) role_pending<KMAX, MASS>(D, b, pl.nb_pend, lds_stats, MULTI ? *D.peer_act : 1u); ROLE_DONE(1); return; }
   b -= pl.nb_pend;
   // (an XCD-aware block order — each XCD working on R/8 of the clusters, so that the gossip role's random reads of
   // receivers' views share an L2 — was measured: no faster once every cluster is busy, slower while only some are, because
   // the load then sits on a few XCDs; profiles/r02_ab_begin.txt)
-  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, MULTI ? *D.peer_act : 1u); ROLE_DONE(2); return; }
+  if (b < D.R * pl.nb_probe) { if (pl.roles & 4u) role_probe<MULTI, MASS>(D, b / pl.nb_probe, b % pl.nb_probe, (b % pl.nb_probe) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc, s_cnt, MULTI ? *D.peer_act : 1u); ROLE_DONE(2); return; }
   b -= D.R * pl.nb_probe;
-  if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
+  if (b < D.R * pl.nb_gossip) { if (pl.roles & 8u) role_gossip<KMAX, SERF, MULTI, MASS>(D, b / pl.nb_gossip, b % pl.nb_gossip, lds_q, lds_stats, s_cnt, s_base, lds_exc); ROLE_DONE(3); return; }
   b -= D.R * pl.nb_gossip;
-  if (b < pl.nb_ppreply) { if (pl.roles & 64u) role_ppreply(D, b, pl.nb_ppreply, lds_stats); ROLE_DONE(4); return; }
+  if (b < pl.nb_ppreply) { if (pl.roles & 64u) role_ppreply<MASS>(D, b, pl.nb_ppreply, lds_stats); ROLE_DONE(4); return; }
   b -= pl.nb_ppreply;
   if (MULTI) {
     if (b < pl.nb_carry) { if (pl.roles & 32u) role_carry(D, b, pl.nb_carry, lds_stats); ROLE_DONE(5); return; }
     b -= pl.nb_carry;
   }
-  if (b < pl.nb_join) { role_join(D, lds_stats); ROLE_DONE(7); return; }
+  if (b < pl.nb_join) { role_join<MASS>(D, lds_stats); ROLE_DONE(7); return; }
   b -= pl.nb_join;
-  if (pl.roles & 16u) role_pushpull(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
+  if (pl.roles & 16u) role_pushpull<MASS>(D, b / pl.nb_pp, (b % pl.nb_pp) * SW_BLOCK + threadIdx.x, lds_stats, lds_exc);
   ROLE_DONE(6);
 #undef ROLE_DONE
 }
 typedef void (*BeginKernel)(const SwDev*, BeginPlan);
 // pick the leanest instantiation the configuration allows
-static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi) {
+template <bool MASS>
+static BeginKernel select_begin_m(uint32_t fanout, bool serf, bool multi) {
   const bool k8 = fanout > 4;
-  if (k8) return serf ? (multi ? k_begin<8, true, true> : k_begin<8, true, false>) : (multi ? k_begin<8, false, true> : k_begin<8, false, false>);
-  return serf ? (multi ? k_begin<4, true, true> : k_begin<4, true, false>) : (multi ? k_begin<4, false, true> : k_begin<4, false, false>);
+  if (k8) return serf ? (multi ? k_begin<8, true, true, MASS> : k_begin<8, true, false, MASS>) : (multi ? k_begin<8, false, true, MASS> : k_begin<8, false, false, MASS>);
+  return serf ? (multi ? k_begin<4, true, true, MASS> : k_begin<4, true, false, MASS>) : (multi ? k_begin<4, false, true, MASS> : k_begin<4, false, false, MASS>);
+}
+static BeginKernel select_begin(uint32_t fanout, bool serf, bool multi, bool mass) {
+  return mass ? select_begin_m<true>(fanout, serf, multi) : select_begin_m<false>(fanout, serf, multi);
 }
 
 // =================================================================================================
@@ -1435,6 +1448,7 @@ __device__ __forceinline__ void deliver_span(DevRef D, const uint4* edges, uint3
 // The broadcasts piggy-backed on last tick's pings and acks (picked by k_resolve, one private area per block)
 // arrive with this tick's packets.  Same no-op filter as the gossip role applies at the sender: here the
 // receiver's view is read before the inbox is touched.
+template <bool MASS>
 __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_t& c_edges, uint32_t& c_filt) {
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
   for (uint32_t e = threadIdx.x; e < n; e += SW_BLOCK) {
@@ -1443,7 +1457,7 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
     uint32_t r = div_n(D, rec.x), x = mod_n(D, rec.x), type = rec.w >> 30;
     if (filter && type != SWIM_MSG_USER && rec.y != x) {
       uint32_t ws = D.nw[(size_t)r * D.N + rec.y];
-      if (noop_at_receiver(D, r, (size_t)r * D.nloc + (x - D.i0), ws, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30), false, rec)) { c_filt++; continue; }
+      if (noop_at_receiver<MASS>(D, r, (size_t)r * D.nloc + (x - D.i0), ws, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30), false, rec)) { c_filt++; continue; }
     }
     c_edges++;
     size_t l; uint32_t pos = inbox_reserve(D, rec, l);
@@ -1452,6 +1466,7 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
 }
 // grid = n_seg blocks + extra blocks over the shard's misc list.  Block b drains segment b and the carry areas
 // b, b + n_seg, ... (their counts are fetched together with the segment's: no extra trip in a quiet tick)
+template <bool MASS>
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint32_t b = blockIdx.x;
@@ -1495,12 +1510,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
     uint32_t c_edges = 0, c_filt = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (cn[j]) deliver_carried(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
+      if (cn[j]) deliver_carried<MASS>(D, D.carry + ((size_t)par * D.NB + b + j * D.n_seg) * D.carry_cap, cn[j] < D.carry_cap ? cn[j] : D.carry_cap, c_edges, c_filt);
     for (uint32_t a = b + 4 * D.n_seg; a < D.NB; a += D.n_seg) {      // only with very fine quanta (G > 4)
       uint2 cc = D.carry_cl[a]; uint32_t c = cc.x;
       __syncthreads();
       if (threadIdx.x == 0 && (cc.x | cc.y)) D.carry_cl[a] = make_uint2(0, c);
-      if (c) deliver_carried(D, D.carry + ((size_t)par * D.NB + a) * D.carry_cap, c < D.carry_cap ? c : D.carry_cap, c_edges, c_filt);
+      if (c) deliver_carried<MASS>(D, D.carry + ((size_t)par * D.NB + a) * D.carry_cap, c < D.carry_cap ? c : D.carry_cap, c_edges, c_filt);
     }
     if (__any((c_edges | c_filt) != 0)) {
       for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_filt += __shfl_down(c_filt, off); }
@@ -1635,7 +1650,7 @@ extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at 
 // and the entries that changed are written back once); otherwise it is edited in HBM (the stimulus kernels).
 // (Every method is __forceinline__: left to the inliner's threshold, one more statement in a method made it a call, the
 // context was passed by pointer and lived in scratch memory — 646 scratch instructions in k_resolve.)
-template <bool LQ>
+template <bool LQ, bool MASS>
 struct NodeCtxT {
   DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
@@ -1722,7 +1737,7 @@ struct NodeCtxT {
   // The inbox is applied in subject order, so consecutive messages mostly concern the same subject: its view is looked up
   // once, edited in registers across those messages and written back when the subject changes (or at store()).
   View cv; uint32_t cv_x = NONE; bool cv_dirty = false;
-  __device__ __forceinline__ static bool v_mass(const View& v) { return (v.free_slot & SW_MASS_SLOT) && v.free_slot != NONE; }
+  __device__ __forceinline__ static bool v_mass(const View& v) { return MASS && (v.free_slot & SW_MASS_SLOT) && v.free_slot != NONE; }
   __device__ __forceinline__ void put(const View& v) {
     if (v_mass(v)) m_store(D, m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k), v.e, v.c.x);
     else D.vt[(size_t)v.slot * NL + l] = v.e;
@@ -1737,9 +1752,10 @@ struct NodeCtxT {
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
   __device__ __forceinline__ View lookup(uint32_t x) {
     View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
-    const uint32_t row = D.M ? D.mrow[(size_t)r * D.N + x] : NONE;      // (fetched next to the node word: one round trip, not two)
+    uint32_t row = NONE;
+    if (MASS && D.M) row = D.mrow[(size_t)r * D.N + x];               // (fetched next to the node word: one round trip, not two)
     v.w = D.nw[(size_t)r * D.N + x];
-    if (v.w & NW_MASS) {                                   // the subject owns a row of the dense store: pair (row, this lane)
+    if (MASS && (v.w & NW_MASS)) {                                   // the subject owns a row of the dense store: pair (row, this lane)
       const size_t idx = m_idx(D, r, row, k);
       const uint32_t a = D.mA[idx], b = D.mB[idx], c = D.mC[idx];
       v.free_slot = SW_MASS_SLOT | row; v.c = make_uint4(0, 0, 0, 0); v.c_have = true;
@@ -2035,7 +2051,7 @@ struct NodeCtxT {
   }
 };
 #undef SQ
-typedef NodeCtxT<false> NodeCtx;       // the stimulus kernels edit the queue in HBM
+typedef NodeCtxT<false, true> NodeCtx;       // the stimulus kernels edit the queue in HBM
 
 // canonical order key of an inbox record: (user?, subject, type) then (incarnation, from)
 __device__ __forceinline__ void edge_key(uint4 e, uint64_t& hi, uint64_t& lo) {
@@ -2110,6 +2126,7 @@ __device__ unsigned long long g_wclk[WCLK_ROWS][6];
 #ifndef SW_RESOLVE_WAVES
 #define SW_RESOLVE_WAVES 4
 #endif
+template <bool MASS>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
@@ -2177,7 +2194,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-    NodeCtxT<true> n(D, S);
+    NodeCtxT<true, MASS> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
     RCLK_MARK(1);                                  // line + header + vmeta
@@ -3301,7 +3318,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict_
     }
   }
   uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
-  send_state(D, go, r, o, best, c_edges, c_remote, c_filt);
+  send_state<true>(D, go, r, o, best, c_edges, c_remote, c_filt);
   const uint32_t sh = go ? best / D.nloc : 0;
   wave_append_sharded(D, go, sh, mk_edge(D, r, best, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
   c_edges += go; c_remote += go && sh != D.rank;

@@ -154,7 +154,7 @@ def test_mass_failure_of_five_percent_65536_matches_golden(hip, n_shards):
         assert f"{digest:#018x}" == want["digest"], f"digest after {sec} s"
         assert det == want["detection"], (sec, det)
         for k in sc.MASS_STAT_KEYS:
-            if n_shards > 1 and k in ("msgs_filtered", "edges"):
+            if n_shards > 1 and k in ("msgs_filtered", "edges", "inbox_peak"):
                 continue                       # (a shard cannot see a remote receiver's view: remote rumours are not filtered)
             assert st[k] == want["stats"][k], (sec, k)
         assert st["view_drops"] == 0
