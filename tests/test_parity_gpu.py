@@ -374,3 +374,11 @@ def test_randomised_parity_cases(hip, oracle):
         res = fz.run_case(k, hip, oracle, 131, False)
         tally[res] = tally.get(res, 0) + 1
     assert tally == {"ok": len(cases)}, tally
+    # a second slice (seed 977), drawn after round 3 added serf's reconnect(), narrow event-buffer slots and — on the product
+    # side only — the dense pair store to the draw: same rule
+    cases = [1, 3, 6, 7, 8, 10, 11, 12, 14, 15, 16, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29]
+    tally = {}
+    for k in cases:
+        res = fz.run_case(k, hip, oracle, 977, False)
+        tally[res] = tally.get(res, 0) + 1
+    assert tally == {"ok": len(cases)}, tally

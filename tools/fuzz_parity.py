@@ -15,7 +15,7 @@ from consul_amd.dist import LocalExchange, ShardedSim
 KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent", "msgs_applied", "probes",
         "probe_acks", "probe_indirect_acks", "probe_tcp_acks", "probe_failures", "nacks_missed", "refutes", "suspicion_timeouts",
         "confirmations", "queue_drops", "event_drops", "user_events_delivered", "user_events_deduped", "user_events_stale",
-        "piggybacks", "msgs_piggybacked", "push_pulls", "view_drops", "view_evictions", "folds", "fold_freed"]
+        "piggybacks", "msgs_piggybacked", "push_pulls", "view_drops", "view_evictions", "folds", "fold_freed", "reconnects", "reconnects_reached"]
 
 
 def draw_case(rng):
@@ -49,7 +49,19 @@ def draw_case(rng):
     kw["fold_interval_ms"] = int(rng.choice([0, 0, 1000, 5000]))
     if rng.random() < 0.5:
         kw["gossip_to_dead_ms"] = int(rng.choice([500, 2000]))      # so that settled views fold / get evicted within a case
+    # round 3 (drawn after everything else, so that the cases above stay what they were): serf's reconnect(), a narrow
+    # event-buffer slot, and — the product library only — the dense pair store.  The store is a representation: with tables
+    # that never fill (tiny == 0) results must not depend on it, and the checker has none.
+    kw["reconnect_interval_ms"] = int(rng.choice([0, 0, 1000, 3000]))
+    kw["event_ids_per_ltime"] = int(rng.choice([0, 0, 2, 6]))
+    rows = int(rng.choice([0, 0, 2, 16, 256]))
+    HIP_ONLY.clear()
+    if rows and not tiny and kw["suspicion_mult"] <= 4:
+        HIP_ONLY["mass_rows"] = min(rows, n)
     return which, shards, kw
+
+
+HIP_ONLY = {}    # per case: configuration of the product library alone (the checker ignores / has no such field)
 
 
 BRIDGE = {}      # per case: replica -> the node a "real" member is attached as (unsharded cases only)
@@ -117,8 +129,8 @@ def diagnose(k, lib, ora, seed):
     rng = np.random.default_rng([seed, k])
     which, shards, kw = draw_case(rng)
     n, reps = kw["n_nodes"], kw["n_replicas"]
-    a = (ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw)) for i in range(shards)], LocalExchange())
-         if shards > 1 else Sim(lib, preset(lib, which, **kw)))
+    a = (ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
+         if shards > 1 else Sim(lib, preset(lib, which, **kw, **HIP_ONLY)))
     b = Sim(ora, preset(ora, which, **kw))
     dead = [[False] * n for _ in range(reps)]
     serf = bool(kw["flags"] & abi.F_SERF_EVENTS)
@@ -172,9 +184,9 @@ def run_case(k, lib, ora, seed, verbose):
     n, reps = kw["n_nodes"], kw["n_replicas"]
     try:
         if shards > 1:
-            a = ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw)) for i in range(shards)], LocalExchange())
+            a = ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
         else:
-            a = Sim(lib, preset(lib, which, **kw))
+            a = Sim(lib, preset(lib, which, **kw, **HIP_ONLY))
         b = Sim(ora, preset(ora, which, **kw))
     except SwimError as e:
         if verbose: print(f"case {k}: config refused ({e})")
@@ -205,7 +217,7 @@ def run_case(k, lib, ora, seed, verbose):
         return "overflow"
     finally:
         a.close(); b.close()
-    if verbose: print(f"case {k}: ok ({ticks} ticks, preset {which}, {shards} shard(s), n {n} x {reps})")
+    if verbose: print(f"case {k}: ok ({ticks} ticks, preset {which}, {shards} shard(s), n {n} x {reps}, rows {HIP_ONLY.get('mass_rows', 0)}, reconnect {kw['reconnect_interval_ms']})")
     return "ok"
 
 
