@@ -518,6 +518,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     D.rtt_scale_us = cfg->rtt_scale_us; D.rtt_height_us = cfg->rtt_height_us; D.rtt_jitter_us = cfg->rtt_jitter_us;
   }
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
+  DALLOC(s, D.cen_dl, NS * 8); HIPCK(s, hipMemsetAsync(D.cen_dl, 0, NS * 8 * 4, s->stream));
   if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
 
   // the fused first launch: block ranges per role (upper bounds of the stagger enumeration)

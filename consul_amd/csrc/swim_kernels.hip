@@ -1646,6 +1646,14 @@ __device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_
   for (uint32_t j = 0; j < n; j++) if (ent[j].x == x) atomicOr(&ent[j].y, now & ~old);
 }
 extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at file scope so that NodeCtxT's accesses stay LDS-typed, not generic)
+// k_resolve keeps the censuses of watched subjects up to date INCREMENTALLY: a view that changes state (or reaches the slot's
+// highest incarnation) adds its delta here — per workgroup in LDS, flushed with one global atomic per touched counter — and k_finish
+// adds the deltas to the cached census.  A recount of all observers (k_census) is left for what is not a view change of a running
+// observer: stimulus, folds, evictions, a new highest incarnation.  (Re-counting 65 536 observers per cluster in every tick of the
+// dissemination phase was 8 % of the driver window's kernel time.)
+#define SW_CEN_LDS 8                      /* watch slots per replica tallied in LDS; higher slot numbers go to global memory directly */
+__shared__ int g_s_cen[SW_CEN_LDS * 5];   // [slot][state 0..3, current]
+__shared__ uint32_t g_s_cen_r;            // the replica the workgroup's first node block belongs to
 // LQ = the memberlist queue of the lane is staged in LDS (k_resolve: every queue access of the merge is then an LDS access
 // and the entries that changed are written back once); otherwise it is edited in HBM (the stimulus kernels).
 // (Every method is __forceinline__: left to the inliner's threshold, one more statement in a method made it a call, the
@@ -1810,6 +1818,7 @@ struct NodeCtxT {
   }
   __device__ __forceinline__ void set_view(View& v, uint32_t inc, uint32_t st, bool touch_since) {
     const uint32_t old = v.fresh ? (uint32_t)SWIM_STATE_ALIVE : SW_KST(v.e.y);     // (a fresh view comes from the base row: never Suspect)
+    const uint32_t old_key = v.e.y;                         // (of a fresh view: what the base row says)
     v.fresh = false;
     v.e.y = SW_KEY(inc, st);
     if (touch_since) v.e.z = now_ms(D, t);
@@ -1821,8 +1830,20 @@ struct NodeCtxT {
     if (st >= SWIM_STATE_DEAD && !v_mass(v)) { need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
     if (NW_HAS_SLOT(v.w)) {
       const size_t sidx = (size_t)r * D.S + NW_SLOT(v.w);
-      if (inc > D.slot_maxinc[sidx]) atomicMax(&D.slot_maxinc[sidx], inc);
-      D.slot_dirty[sidx] = 1;
+      const uint32_t mx = D.slot_maxinc[sidx];
+      if (inc > mx) { atomicMax(&D.slot_maxinc[sidx], inc); D.slot_dirty[sidx] = 1; }      // what "current" is measured against moved: recount
+      else if constexpr (!LQ) D.slot_dirty[sidx] = 1;                                      // stimulus kernels: recount
+      else if (v.e.x != o) {                                                               // (a subject's view of itself is not part of its census)
+        const uint32_t os = SW_KST(old_key), slot = NW_SLOT(v.w);
+        const int dcur = (int)(inc == mx) - (int)(SW_KINC(old_key) == mx);
+        if (r == g_s_cen_r && slot < SW_CEN_LDS) {
+          if (os != st) { atomicAdd(&g_s_cen[slot * 5 + os], -1); atomicAdd(&g_s_cen[slot * 5 + st], 1); }
+          if (dcur) atomicAdd(&g_s_cen[slot * 5 + 4], dcur);
+        } else {
+          if (os != st) { atomicAdd(&D.cen_dl[sidx * 8 + os], (uint32_t)-1); atomicAdd(&D.cen_dl[sidx * 8 + st], 1u); }
+          if (dcur) atomicAdd(&D.cen_dl[sidx * 8 + 4], (uint32_t)dcur);
+        }
+      }
     }
   }
   __device__ __forceinline__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
@@ -1889,7 +1910,8 @@ struct NodeCtxT {
       if (nc <= 3) { if (!v_mass(v)) D.vc[ci] = b; v.c = b; }
       v.e.w = vw_pack(vw_conf0(v.e.w), nc, vw_leaving(v.e.w)); put_later(v);
       arm_deadline(v, b.w);
-      if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
+      // (a confirmation changes neither the state nor the incarnation: nothing a census or a trace row shows — re-counting the
+      // slot's 65 536 observers every tick of the confirmation phase was a twelfth of the driver window's kernel time)
       S.add(ST_CONFIRMS);
       broadcast(x, SWIM_MSG_SUSPECT, inc, from);
       return;
@@ -2148,6 +2170,8 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     if (!any) return;
   }
   if (threadIdx.x < SW_RTILE) { s_carry[threadIdx.x] = 0; s_dl[threadIdx.x] = NONE; }
+  if (threadIdx.x < SW_CEN_LDS * 5) g_s_cen[threadIdx.x] = 0;
+  if (threadIdx.x == 0) g_s_cen_r = div_nloc(D, (size_t)nb0 * SW_BLOCK);
   BlockStats S; S.init(lds_stats);
   const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)nb0 * SW_BLOCK;
   // ---- the tile's receivers, compacted in ascending node order
@@ -2272,7 +2296,9 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     S.wave_add(ST_PIGGY, c_pig); S.wave_add(ST_PIGGY_MSGS, s0 + s1 + s2 + s3);
     S.wave_add(ST_SENT0, s0); S.wave_add(ST_SENT1, s1); S.wave_add(ST_SENT2, s2); S.wave_add(ST_SENT3, s3);
   }
-  S.flush(D);                                      // (barrier inside: every lane's carry reservations and deadlines are in)
+  S.flush(D);                                      // (barrier inside: every lane's carry reservations, deadlines and census deltas are in)
+  if (threadIdx.x < SW_CEN_LDS * 5 && g_s_cen[threadIdx.x] && threadIdx.x / 5 < D.S)
+    atomicAdd(&D.cen_dl[((size_t)g_s_cen_r * D.S + threadIdx.x / 5) * 8 + threadIdx.x % 5], (uint32_t)g_s_cen[threadIdx.x]);
   if (threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) {
     const uint32_t sb = threadIdx.x;
     if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
@@ -2330,6 +2356,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ D
   if (threadIdx.x < 6) { if (acc[threadIdx.x]) atomicAdd(&D.cen_acc[(size_t)sidx * CEN_WORDS + threadIdx.x], acc[threadIdx.x]); }
 }
 
+// first-suspect / first-dead / all-dead / all-current stamps of a slot whose cached census just changed
+__device__ void census_stamps(DevRef D, uint32_t sidx, uint32_t now) {
+  swim_census* c = &D.census[sidx];
+  if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
+  if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
+  if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
+  if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+}
 // fold the accumulators of a dirty slot into its cached census and stamp the first-times
 __device__ void census_commit(DevRef D, uint32_t sidx, uint32_t now) {
   swim_census* c = &D.census[sidx];
@@ -2337,11 +2371,19 @@ __device__ void census_commit(DevRef D, uint32_t sidx, uint32_t now) {
   c->n_observers = a[CEN_OBS]; c->by_state[0] = a[CEN_ST0]; c->by_state[1] = a[CEN_ST1];
   c->by_state[2] = a[CEN_ST2]; c->by_state[3] = a[CEN_ST3]; c->n_current = a[CEN_CUR];
   for (int j = 0; j < CEN_WORDS; j++) a[j] = 0;
-  if (c->first_suspect_ms == NONE && c->by_state[1]) c->first_suspect_ms = now;
-  if (c->first_dead_ms == NONE && (c->by_state[2] || c->by_state[3])) c->first_dead_ms = now;
-  if (c->all_dead_ms == NONE && c->n_observers && c->by_state[2] + c->by_state[3] == c->n_observers) c->all_dead_ms = now;
-  if (c->all_current_ms == NONE && c->n_observers && D.slot_maxinc[sidx] > 1 && c->n_current == c->n_observers) c->all_current_ms = now;
+  for (int j = 0; j < 5; j++) D.cen_dl[(size_t)sidx * 8 + j] = 0;        // (a recount is of the state AFTER this tick's changes: their deltas are in it)
+  census_stamps(D, sidx, now);
   D.slot_dirty[sidx] = 0;
+}
+// this tick's view changes of running observers, tallied by k_resolve: add them to the cached census (no recount)
+__device__ void census_apply_deltas(DevRef D, uint32_t sidx, uint32_t now) {
+  uint32_t* d = &D.cen_dl[(size_t)sidx * 8];
+  if (!(d[0] | d[1] | d[2] | d[3] | d[4])) return;
+  swim_census* c = &D.census[sidx];
+  for (int j = 0; j < 4; j++) c->by_state[j] += d[j];
+  c->n_current += d[4];
+  for (int j = 0; j < 5; j++) d[j] = 0;
+  census_stamps(D, sidx, now);
 }
 
 // collect the ids of replica r whose node word is non-zero (whole block cooperates)
@@ -2376,7 +2418,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
   for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += SW_BLOCK) {
     uint32_t r = sidx / D.S, sl = sidx % D.S;
     if (sl >= D.n_slots[r]) continue;
-    if (D.slot_dirty[sidx]) census_commit(D, sidx, now);
+    if (D.slot_dirty[sidx]) census_commit(D, sidx, now); else census_apply_deltas(D, sidx, now);
     if (D.trace && t < D.trace_ticks) {
       const swim_census* c = &D.census[sidx];
       uint32_t* row = &D.trace[((size_t)sidx * D.trace_ticks + t) * 5];
