@@ -41,9 +41,11 @@ from consul_amd import abi  # noqa: E402
 from consul_amd.sim import Sim, preset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRAFFIC_NOTE = ("profiles/r02_pmc_driver.json (driver window, one handle, per launch): k_resolve 104 MB with FETCH_SIZE as counted / 159 MB with the "
-                "guide's x2 for FETCH_SIZE (calibrated for wide coalesced reads only; these kernels scatter 16-64 B, so quote 13-20x the "
-                "algorithmic 7.8 MB), k_begin 168 MB (2.2x), k_deliver 63 MB (4.3x)")
+TRAFFIC_NOTE = ("profiles/r03_pmc_driver.json (driver window, one handle, per launch; FETCH_SIZE / WRITE_SIZE in separate --pmc passes): k_resolve 103 MB as "
+                "counted (54 fetch + 49 write) / 157 MB with the guide's x2 on FETCH_SIZE — calibrated for wide coalesced reads only, these kernels "
+                "scatter 16-64 B, so quote 13-20x the algorithmic 7.8 MB; k_begin 94 / 168 MB (1.2-2.2x of 75.6), k_deliver 46 / 63 MB (3.2-4.3x of 14.6).  "
+                "L2 requests per second (profiles/r03_pmc_l2_all_ticks.txt) against the 56-60 G/s the scattered-access probe reaches out of HBM "
+                "(profiles/r03_scatter_l2_requests.txt): k_begin 32 G/s, k_deliver 34 G/s, k_resolve 27 G/s")
 
 
 def victims_for(seed: int, reps: int, n: int):

@@ -80,3 +80,35 @@ def test_user_events_hip_matches_oracle(hip, oracle):
         assert sa[k] == sb[k], k
     assert a.poll_events() == b.poll_events()
     assert a.node_info(0, 100).event_clock == b.node_info(0, 100).event_clock
+
+
+def test_a_user_event_id_is_never_read_as_an_intent(oracle):
+    """force-leave intents share the broadcast queue with user events and are told apart by bits 31-30 of the id
+    word.  An application id with those bits set used to vanish (no delivery) and to force-leave — even prune — whatever member its
+    low bits named.  Ids are 30 bits now: anything larger is refused, never reinterpreted."""
+    from consul_amd.sim import SwimError
+    s = cluster(oracle, n_nodes=64)
+    s.kill(0, [3]); s.step_ms(40000)                         # node 3 is Failed everywhere
+    assert s.view(0, 9, 3).status == abi.MEMBER_FAILED
+    for bad in (0x80000003, 0xC0000003, 0x92345678, 0x40000000):
+        with pytest.raises(SwimError) as e:
+            s.user_event(0, 10, bad)
+        assert e.value.rc == abi.ERANGE
+    s.step_ms(5000)
+    assert s.view(0, 9, 3).status == abi.MEMBER_FAILED and s.stats()["intents_applied"] == 0 and s.stats()["reaped"] == 0
+    lt = s.user_event(0, 10, 0x3FFFFFFF)                     # the largest id there is: an ordinary event
+    s.step_ms(5000)
+    assert lt != abi.NONE and s.stats()["user_events_delivered"] == 63 and s.view(0, 9, 3).status == abi.MEMBER_FAILED
+    s.force_leave(0, 10, 3)                                  # the real thing still works
+    s.step_ms(5000)
+    assert s.view(0, 9, 3).status == abi.MEMBER_LEFT
+
+
+@pytest.mark.gpu
+def test_event_id_range_on_hip(hip):
+    from consul_amd.sim import SwimError
+    s = cluster(hip, n_nodes=64)
+    with pytest.raises(SwimError) as e:
+        s.user_event(0, 10, 0x80000003)
+    assert e.value.rc == abi.ERANGE
+    assert s.user_event(0, 10, 0x3FFFFFFF) != abi.NONE
