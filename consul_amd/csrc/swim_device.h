@@ -179,6 +179,7 @@ struct SwDev {
   uint32_t* m_tile_dl;                   // [R][M][nbl] lower bound of the suspicion deadlines of a row's 256-observer tile (acting observers)
   uint32_t* m_row_dl;                    // [R*M] ... of the whole row
   uint32_t *m_due, *m_due_cnt;           // [R*M], [1] rows whose bound has passed this tick (k_expire_mass_due -> k_expire_mass)
+  uint4* xs_list; uint32_t* xs_cnt; uint32_t xs_cap;   // state exchanges of this tick whose dense-store part k_send_mass sends: {replica, owner, receiver, flags}
   uint32_t* mcnt;                        // [NL] pairs of the dense store this observer holds (present)
   uint32_t* peak;                        // [1] the largest inbox any node has had in one tick (swim_stats_t.inbox_peak)
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view

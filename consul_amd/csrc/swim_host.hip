@@ -542,6 +542,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
                                                   (D.rc_period ? cdiv(D.N, D.rc_period) * std::min(D.P, D.rc_period) : 0)));   // pull requests of a boundary tick: push-pull + serf reconnect
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
+  if (D.M) { D.xs_cap = 2 * D.pp_cap + D.join_cap; DALLOC(s, D.xs_list, D.xs_cap); DALLOC(s, D.xs_cnt, 1); HIPCK(s, hipMemsetAsync(D.xs_cnt, 0, 4, s->stream)); }
   s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1, cfg->mass_rows != 0);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
@@ -706,6 +707,7 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     ProfScope p(s, PK_BEGIN);
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
   }
+  if (D.M) hipLaunchKernelGGL(k_send_mass, dim3(1024), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's part of the state exchanges listed above
   if (D.coord) {      // serf's ping delegate: the probers k_begin listed update their coordinates (from everybody's as of the start of the tick)
     hipLaunchKernelGGL(k_coord_update, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_coord_commit, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);

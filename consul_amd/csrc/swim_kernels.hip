@@ -931,6 +931,37 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
 // =================================================================================================
 // Every lane of the wave calls this together (`on` = the lane takes part); the records of a wave are
 // appended with one atomic per destination shard, never one per record.
+// the two records of a state exchange that are not explicit views (called by every lane of the wave together):
+__device__ __forceinline__ void send_state_tail(DevRef D, bool on, uint32_t r, uint32_t owner, uint32_t dst, bool saw_dst, bool saw_self, uint32_t& c_edges, uint32_t& c_remote) {
+  const uint32_t sh = on ? dst / D.nloc : 0;
+  // the owner's view of ITSELF travels when the base row says something else about it (a node that has just
+  // joined: nobody has heard of it; a node that came back after it was folded as dead)
+  {
+    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
+    if (on && !saw_self) {
+      const uint32_t self = SW_KEY(D.hdr[(size_t)r * D.nloc + (owner - D.i0)].x, SWIM_STATE_ALIVE);
+      if (self != base_key_of(D, r, owner, D.nw[(size_t)r * D.N + owner])) { rec = mk_edge(D, r, dst, owner, SW_KINC(self), SWIM_MSG_ALIVE, 0); want = true; }
+    }
+    wave_append_sharded(D, want, sh, rec);
+    c_edges += want; c_remote += want && sh != D.rank;
+  }
+  // ...and, with one exception to "what the base row says merges to nothing": the receiver's view of ITSELF is its own (it may
+  // have been away while the base row moved on), so the owner's view of the receiver travels even when it is the base row's
+  // (and not the trivial alive@1)
+  {
+    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
+    if (on && !saw_dst) {
+      const uint32_t key = base_key_of(D, r, dst, D.nw[(size_t)r * D.N + dst]);
+      if (key != SW_BASE_KEY && key >= 4u) {
+        const uint32_t st = SW_KST(key), type = st == SWIM_STATE_ALIVE ? SWIM_MSG_ALIVE : st == SWIM_STATE_LEFT ? SWIM_MSG_DEAD : SWIM_MSG_SUSPECT;
+        rec = mk_edge(D, r, dst, dst, SW_KINC(key), type, dst);     // dead{From: node} / suspect{From: receiver}: both = dst here
+        want = true;
+      }
+    }
+    wave_append_sharded(D, want, sh, rec);
+    c_edges += want; c_remote += want && sh != D.rank;
+  }
+}
 template <bool MASS>
 __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32_t dst, uint32_t& c_edges, uint32_t& c_remote, uint32_t& c_filt) {
   // what the base row says merges to nothing: only the owner's explicit views travel.  The lanes of the wave walk
@@ -963,69 +994,27 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
     wave_append_sharded(D, want, sh, rec);
     c_edges += want; c_remote += want && sh != D.rank;
   }
-  // ...and the owner's pairs of the dense store.  One exchange at a time, the whole wave on it: 64 rows per step (a lane
-  // walking its 26 214 rows alone would hold the launch for tens of milliseconds)
+  // ...and the owner's pairs of the dense store: a walk over up to mass_rows rows per exchange.  Inside this launch a wave would
+  // take its (up to 64) exchanges one after the other — the due nodes of a state-exchange tick sit in consecutive lanes, and at
+  // 13 107 rows that was 26-49 ms per boundary tick on 18 busy waves, half of config #4's wall time — so the exchange is only
+  // LISTED here and k_send_mass, right after this launch, gives every listed exchange a wave of its own.  The two trailing
+  // records below depend on what the row walk finds, so they move there too.
   if (MASS && D.M) {
-    uint64_t todo = __ballot(on && D.mcnt[lo] != 0);
-    const uint32_t lane = sw_lane();
-    while (todo) {
-      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1; todo &= todo - 1;
-      const uint32_t r_ = __shfl(r, leader), own_ = __shfl(owner, leader), dst_ = __shfl(dst, leader), sh_ = __shfl(sh, leader);
-      uint32_t left_ = __shfl(on ? D.mcnt[lo] : 0u, leader);
-      const bool filt_ = (D.flags & SWIM_F_FILTER_NOOP) && sh_ == D.rank;
-      uint64_t hit_dst = 0, hit_self = 0;
-      for (uint32_t row0 = 0; row0 < D.M && left_; row0 += 64) {
-        const uint32_t row = row0 + lane;
-        bool present = false, want = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t x = NONE;
-        if (row < D.M) {
-          x = D.mrow_subj[(size_t)r_ * D.M + row];
-          if (x != NONE) {
-            const uint32_t a = D.mA[m_idx(D, r_, row, own_ - D.i0)];
-            if (a) {
-              present = true; want = true;
-              const uint32_t st = MA_STATE(a); uint32_t type, from = 0;
-              if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
-              else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
-              else { type = SWIM_MSG_SUSPECT; from = dst_; }
-              if (filt_ && x != dst_ && noop_at_receiver<true>(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
-              rec = mk_edge(D, r_, dst_, x, MA_INC(a), type, from);
-            }
-          }
-        }
-        left_ -= (uint32_t)__popcll(__ballot(present));
-        hit_dst |= __ballot(present && x == dst_); hit_self |= __ballot(present && x == own_);
-        wave_append(D, sh_, want, rec);
-        c_edges += want; c_remote += want && sh_ != D.rank;
-      }
-      if (lane == leader) { saw_dst |= hit_dst != 0; saw_self |= hit_self != 0; }
-    }
-  }
-  // ...and the owner's view of ITSELF travels when the base row says something else about it (a node that has just
-  // joined: nobody has heard of it; a node that came back after it was folded as dead)
-  {
-    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
-    if (on && !saw_self) {
-      const uint32_t self = SW_KEY(D.hdr[lo].x, SWIM_STATE_ALIVE);
-      if (self != base_key_of(D, r, owner, D.nw[(size_t)r * D.N + owner])) { rec = mk_edge(D, r, dst, owner, SW_KINC(self), SWIM_MSG_ALIVE, 0); want = true; }
-    }
-    wave_append_sharded(D, want, sh, rec);
-    c_edges += want; c_remote += want && sh != D.rank;
-  }
-  // ...with one exception: the receiver's view of ITSELF is its own (it may have been away while the base row moved
-  // on), so the owner's view of the receiver travels even when it is the base row's (and not the trivial alive@1)
-  {
-    bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
-    if (on && !saw_dst) {
-      const uint32_t key = base_key_of(D, r, dst, D.nw[(size_t)r * D.N + dst]);
-      if (key != SW_BASE_KEY && key >= 4u) {
-        const uint32_t st = SW_KST(key), type = st == SWIM_STATE_ALIVE ? SWIM_MSG_ALIVE : st == SWIM_STATE_LEFT ? SWIM_MSG_DEAD : SWIM_MSG_SUSPECT;
-        rec = mk_edge(D, r, dst, dst, SW_KINC(key), type, dst);     // dead{From: node} / suspect{From: receiver}: both = dst here
-        want = true;
+    const uint64_t mask = __ballot(on);
+    if (mask) {
+      const uint32_t lane = sw_lane(), leader = (uint32_t)__ffsll((long long)mask) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(D.xs_cnt, (uint32_t)__popcll(mask));
+      base = __shfl(base, leader);
+      if (on) {
+        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        if (pos < D.xs_cap) D.xs_list[pos] = make_uint4(r, owner, dst, (saw_dst ? 1u : 0u) | (saw_self ? 2u : 0u));
+        else atomicOr(D.err, SW_ERR_PEND_OVF);
       }
     }
-    wave_append_sharded(D, want, sh, rec);
-    c_edges += want; c_remote += want && sh != D.rank;
+    return;
   }
+  send_state_tail(D, on, r, owner, dst, saw_dst, saw_self, c_edges, c_remote);
 }
 template <bool MASS>
 __device__ __forceinline__ void role_pushpull(DevRef D, uint32_t r, uint32_t a, uint32_t* lds_stats, uint32_t* lds_exc) {
@@ -2459,6 +2448,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     if (D.join_cnt) *D.join_cnt = 0;           // the joins of this tick are under way
     if (D.c_cnt) *D.c_cnt = 0;                 // this tick's coordinate updates are committed
     if (D.m_due_cnt) *D.m_due_cnt = 0;         // the dense store's due rows were looked at
+    if (D.xs_cnt) *D.xs_cnt = 0;               // ... and its state exchanges sent
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
@@ -3367,4 +3357,56 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict_
   S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
   if (D.n_shards > 1 && __any(go) && lane == 0) *D.act = 1;
   S.flush(D);
+}
+
+// =================================================================================================
+// k_send_mass — the dense store's part of the state exchanges send_state listed during k_begin / k_reconnect (xs_list): one
+// exchange per wave, 64 rows per step — what mergeState would derive from the owner's pair with each row's subject (Alive ->
+// alive, Left -> dead{From: node}, Dead | Suspect -> suspect{From: receiver}), the no-op filter against the receiver's pair, a
+// wave-aggregated append — then the exchange's two trailing records.
+// =================================================================================================
+__global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t n = *D.xs_cnt < D.xs_cap ? *D.xs_cnt : D.xs_cap, lane = sw_lane();
+  uint32_t c_edges = 0, c_remote = 0, c_filt = 0;
+  for (uint32_t e = blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64; e < n; e += gridDim.x * (SW_BLOCK / 64)) {
+    const uint4 x4 = D.xs_list[e];
+    const uint32_t r_ = x4.x, own_ = x4.y, dst_ = x4.z, sh_ = dst_ / D.nloc;
+    uint32_t left_ = D.mcnt[(size_t)r_ * D.nloc + (own_ - D.i0)];
+    const bool filt_ = (D.flags & SWIM_F_FILTER_NOOP) && sh_ == D.rank;
+    uint64_t hit_dst = 0, hit_self = 0;
+    for (uint32_t row0 = 0; row0 < D.M && left_; row0 += 64) {
+      const uint32_t row = row0 + lane;
+      bool present = false, want = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t x = NONE;
+      if (row < D.M) {
+        x = D.mrow_subj[(size_t)r_ * D.M + row];
+        if (x != NONE) {
+          const uint32_t a = D.mA[m_idx(D, r_, row, own_ - D.i0)];
+          if (a) {
+            present = true; want = true;
+            const uint32_t st = MA_STATE(a); uint32_t type, from = 0;
+            if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
+            else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
+            else { type = SWIM_MSG_SUSPECT; from = dst_; }
+            if (filt_ && x != dst_ && noop_at_receiver<true>(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
+            rec = mk_edge(D, r_, dst_, x, MA_INC(a), type, from);
+          }
+        }
+      }
+      left_ -= (uint32_t)__popcll(__ballot(present));
+      hit_dst |= __ballot(present && x == dst_); hit_self |= __ballot(present && x == own_);
+      wave_append(D, sh_, want, rec);
+      c_edges += want; c_remote += want && sh_ != D.rank;
+    }
+    send_state_tail(D, lane == 0, r_, own_, dst_, (x4.w & 1u) || hit_dst, (x4.w & 2u) || hit_self, c_edges, c_remote);
+  }
+  if (__any((c_edges | c_filt) != 0)) {
+    for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_remote += __shfl_down(c_remote, off); c_filt += __shfl_down(c_filt, off); }
+    if (lane == 0) {
+      if (c_edges) atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c_edges);
+      if (c_remote) atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c_remote);
+      if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
+      if (D.n_shards > 1 && c_edges) *D.act = 1;
+    }
+  }
 }
