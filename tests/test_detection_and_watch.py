@@ -44,7 +44,7 @@ def test_detection_census_equals_its_definition_on_the_checker(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [0, 128])
+@pytest.mark.parametrize("rows", [0, 96])
 def test_detection_census_equals_its_definition_on_hip(hip, oracle, rows):
     n = 96
     a = Sim(hip, preset(hip, abi.PRESET_LAN, n_nodes=n, seed=6, view_cap=n, fold_interval_ms=20000, mass_rows=rows))
