@@ -3080,16 +3080,23 @@ __global__ void __launch_bounds__(SW_BLOCK) k_expire_mass(const SwDev* __restric
   const uint32_t n_due = *D.m_due_cnt;
   if (!n_due) return;
   const uint32_t now = now_ms(D, *D.tick), lane = sw_lane();
-  const uint64_t items = (uint64_t)n_due * D.nbl, stride = (uint64_t)gridDim.x * (SW_BLOCK / 64);
+  const uint64_t items = (uint64_t)n_due * D.nbl, stride = (uint64_t)gridDim.x * (SW_BLOCK / 64) * 64;
   uint32_t fired = 0;
-  for (uint64_t it = (uint64_t)blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64; it < items; it += stride) {
-    const uint32_t rr = D.m_due[it / D.nbl], tile = (uint32_t)(it % D.nbl), r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr];
-    uint32_t* tb = &D.m_tile_dl[(size_t)rr * D.nbl + tile];
-    uint32_t m = *tb;
-    if (now >= m) {
-      m = NONE;
+  // 64 (row, tile) items per wave step: every lane looks at one tile bound (in a mass event thousands of rows are due with a few
+  // due tiles each: one item per wave step was 5 ms per tick of dependent scalar loads), then the wave takes the due ones in turn
+  for (uint64_t base = ((uint64_t)blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64) * 64; base < items; base += stride) {
+    const uint64_t it = base + lane;
+    uint32_t rr = 0, tile = 0, tb = NONE;
+    if (it < items) { rr = D.m_due[it / D.nbl]; tile = (uint32_t)(it % D.nbl); tb = D.m_tile_dl[(size_t)rr * D.nbl + tile]; }
+    const bool due = it < items && now >= tb;
+    if (it < items && !due && tb < D.m_row_dl[rr]) atomicMin(&D.m_row_dl[rr], tb);       // (the row's bound is rebuilt from its tiles')
+    uint64_t todo = __ballot(due);
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1; todo &= todo - 1;
+      const uint32_t rr_ = __shfl(rr, leader), tile_ = __shfl(tile, leader), r = rr_ / D.M, row = rr_ % D.M, x = D.mrow_subj[rr_];
+      uint32_t m = NONE;
       for (uint32_t part = 0; part < SW_BLOCK / 64; part++) {
-        const uint32_t k = tile * SW_BLOCK + part * 64 + lane;
+        const uint32_t k = tile_ * SW_BLOCK + part * 64 + lane;
         if (k >= D.nloc) continue;
         const size_t idx = m_idx(D, r, row, k);
         const uint32_t a = D.mA[idx];
@@ -3105,9 +3112,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_expire_mass(const SwDev* __restric
         m = dl < m ? dl : m;           // a fired timer keeps the bound low until its verdict is merged
       }
       for (int off = 32; off; off >>= 1) { const uint32_t v = __shfl_xor(m, off); m = v < m ? v : m; }
-      if (lane == 0) *tb = m;
+      if (lane == 0) { D.m_tile_dl[(size_t)rr_ * D.nbl + tile_] = m; if (m < D.m_row_dl[rr_]) atomicMin(&D.m_row_dl[rr_], m); }
     }
-    if (lane == 0 && m < D.m_row_dl[rr]) atomicMin(&D.m_row_dl[rr], m);
   }
   if (__any(fired != 0)) {
     for (int off = 32; off; off >>= 1) fired += __shfl_down(fired, off);
