@@ -152,6 +152,7 @@ PROTOTYPES = {
     "swim_inject_join": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u32]),
     "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
     "swim_set_loss": (C.c_int, [SimP, u32]),
+    "swim_set_tcp_class": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u8]),
     "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
     "swim_watch": (C.c_int, [SimP, u32, u32]),
     "swim_members": (C.c_int, [SimP, u32, u32, P(Member), C.c_size_t, P(C.c_size_t)]),

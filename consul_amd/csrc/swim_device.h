@@ -65,7 +65,9 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 //              the simulator does not probe / gossip on its behalf; peers that hear of it treat it like anybody
 //   bit 19     mass: the subject owns a ROW of the dense pair store (mrow[]): every local observer's view of it lives at
 //              [row][observer] of three 4-byte planes (12 bytes per pair) instead of in the observers' hash tables
-//   bits 18-0  watch slot + 1 (census / trace), 0 = not watched
+//   bits 18-15 TCP class (swim_set_tcp_class: memberlist's DisableTcpPingsForNode as Consul sets it — the fallback ping of a
+//              failed probe only goes between nodes of the same class; ground truth like the partition group)
+//   bits 14-0  watch slot + 1 (census / trace), 0 = not watched
 #define NW_DEAD 0x80000000u
 #define NW_ATTACHED 0x00800000u
 #define NW_SUBJECT 0x00400000u
@@ -73,7 +75,9 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 #define NW_ALONE 0x00100000u
 #define NW_INERT (NW_DEAD | NW_ATTACHED | NW_ALONE) /* the simulator takes no action on behalf of this node */
 #define NW_MASS 0x00080000u
-#define NW_SLOT_MASK 0x7FFFFu
+#define NW_TCP_SHIFT 15
+#define NW_TCP_MASK 0x00078000u
+#define NW_SLOT_MASK 0x7FFFu
 #define NW_PART(w) (((w) >> 24) & 0x7Fu)
 #define NW_SLOT(w) (((w) & NW_SLOT_MASK) - 1u)     /* 0xFFFFFFFF when none */
 #define NW_HAS_SLOT(w) (((w) & NW_SLOT_MASK) != 0u)

@@ -1108,6 +1108,22 @@ extern "C" int swim_inject_partition(swim_sim* s, uint32_t r, const uint8_t* g) 
   HIPCK(s, hipStreamSynchronize(s->stream));
   return SWIM_OK;
 }
+extern "C" int swim_set_tcp_class(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint8_t cls) {
+  int rc = check_ids(s, r, ids, n);
+  if (!rc && cls > SWIM_TCP_CLASS_MAX) rc = SWIM_ERANGE;
+  if (rc || !n) return rc;
+  touched(s);
+  const size_t chunk = s->scratch_bytes / 4;
+  for (size_t off = 0; off < n; off += chunk) {
+    const uint32_t c = (uint32_t)std::min(chunk, n - off);
+    HIPCK(s, hipMemcpyAsync(s->d_scratch, ids + off, (size_t)c * 4, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_set_tcp_class, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c, (uint32_t)cls);
+    HIPCK(s, hipStreamSynchronize(s->stream));
+  }
+  hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);   // node words changed
+  HIPCK(s, hipStreamSynchronize(s->stream));
+  return SWIM_OK;
+}
 extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
   if (!s) return SWIM_EINVAL;
   if (q) s->pristine = false;

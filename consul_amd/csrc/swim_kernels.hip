@@ -479,8 +479,8 @@ __device__ __forceinline__ void role_pending(DevRef D, uint32_t b, uint32_t nb, 
       }
       uint32_t aw = p_aw(h.y);
       // probeNode's TCP fallback ping next to the indirect probes: TCP rides out packet loss, so it reaches every
-      // running node of the same partition
-      const bool tcp = !acked && (D.flags & SWIM_F_TCP_FALLBACK) && !(wx & NW_DEAD) && NW_PART(wi) == NW_PART(wx);
+      // running node of the same partition — and of the same TCP class (DisableTcpPingsForNode: not across datacenters)
+      const bool tcp = !acked && (D.flags & SWIM_F_TCP_FALLBACK) && !(wx & NW_DEAD) && !((wi ^ wx) & (0x7F000000u | NW_TCP_MASK));
       if (acked || tcp) {
         aw = awareness_apply(D, aw, -1); S.add(acked ? ST_IACKS : ST_TCPACKS);
         D.pr0[l].x = NONE; h.y = p_pack(p_epoch(h.y), aw, 0, 0);
@@ -2637,6 +2637,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
+}
+// swim_set_tcp_class
+__global__ void __launch_bounds__(SW_BLOCK) k_set_tcp_class(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n, uint32_t cls) {
+  SW_DEV_BIND
+  const uint32_t a = blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (a < n) { uint32_t* w = &D.nw[(size_t)r * D.N + ids[a]]; atomicAnd(w, ~NW_TCP_MASK); atomicOr(w, cls << NW_TCP_SHIFT); }
 }
 // swim_inject_join: serf.Create + serf.Join([via]) for nodes that are not running — a fresh process
 __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n, uint32_t via) {

@@ -218,7 +218,7 @@ class ShardedSim:
 
     def __getattr__(self, name):
         # stimulus is replicated on every shard (each applies what it owns)
-        if name in ("kill", "revive", "leave", "update", "partition", "set_loss", "sync", "watch", "join"):
+        if name in ("kill", "revive", "leave", "update", "partition", "set_loss", "set_tcp_class", "sync", "watch", "join"):
             def fan(*a, **k):
                 out = None
                 for s in self.sims:

@@ -209,6 +209,11 @@ class Sim:
     def set_loss(self, prob: float):
         self._ck("swim_set_loss", self._l.swim_set_loss(self._h, min(int(prob * 2**32), 2**32 - 1)))
 
+    def set_tcp_class(self, replica: int, ids: Iterable[int], tcp_class: int):
+        """memberlist's DisableTcpPingsForNode as Consul's WAN pool sets it: no TCP fallback ping between nodes of different classes."""
+        a, p, n = _ids(ids)
+        self._ck("swim_set_tcp_class", self._l.swim_set_tcp_class(self._h, replica, p, n, tcp_class))
+
     def user_event(self, replica: int, origin: int, event_id: int) -> int:
         lt = abi.u32()
         self._ck("swim_user_event",

@@ -130,7 +130,7 @@ typedef struct swim_config {
   uint32_t inbox_cap;               /* per-node per-tick inbox slots                        */
   uint32_t subject_cap;             /* per-replica WATCH slots: subjects whose census, first-suspect/first-dead
                                        stamps and per-tick trace are maintained (swim_watch; every node named in
-                                       an inject_* call is watched automatically while slots remain)          */
+                                       an inject_* call is watched automatically while slots remain); < 32 767 */
   uint32_t view_cap;                /* per-observer bound on explicit (non-base) views: what an observer knows
                                        that the replica's base row does not say.  A rumour that would need one
                                        more entry is ignored and counted in view_drops (never silent).  Sized
@@ -399,6 +399,13 @@ int swim_force_leave(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t 
 /* partition mask: nodes exchange packets only within the same group id (config #4) */
 int swim_inject_partition(swim_sim* sim, uint32_t replica, const uint8_t* group_of_node);
 int swim_set_loss(swim_sim* sim, uint32_t loss_q32);
+/* memberlist.Config.DisableTcpPingsForNode (hashicorp/memberlist config.go; set by agent/consul/server_serf.go:222-232 on the
+ * WAN pool under mesh-gateway federation: `return s.config.Datacenter != dc`): probeNode skips its TCP fallback ping when the
+ * predicate holds for the target.  Here every node carries a class (Consul: its datacenter; 0 at creation) and the fallback ping
+ * is skipped between nodes of DIFFERENT classes — all nodes in class 0 is memberlist's default, no predicate.  Global
+ * DisableTcpPings is the absence of SWIM_F_TCP_FALLBACK.  Classes 0..SWIM_TCP_CLASS_MAX; more is SWIM_ERANGE. */
+#define SWIM_TCP_CLASS_MAX 15u
+int swim_set_tcp_class(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_t n, uint8_t tcp_class);
 /* serf.UserEvent(name, payload, coalesce=false) (agent/consul/server_ce.go:125-131):
  * event_id stands for hash(name,payload); returns the Lamport time stamped on it */
 int swim_user_event(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t event_id,

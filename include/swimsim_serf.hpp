@@ -212,6 +212,11 @@ class Cluster {
   // node's member list, the simulator keeps everybody's)
   void Checkpoint(const std::string& path) { check(swim_checkpoint_save(sim_, path.c_str()), "swim_checkpoint_save"); }
   void Restore(const std::string& path) { check(swim_checkpoint_load(sim_, path.c_str()), "swim_checkpoint_load"); }
+  // memberlist.Config.DisableTcpPingsForNode the way Consul's WAN pool sets it (agent/consul/server_serf.go:222-232): members of
+  // different datacenters skip the TCP fallback ping of a failed probe
+  void SetDatacenter(uint32_t replica, const std::vector<uint32_t>& ids, uint8_t dc) {
+    check(swim_set_tcp_class(sim_, replica, ids.data(), ids.size(), dc), "swim_set_tcp_class");
+  }
   void SetPacketLoss(double p) { check(swim_set_loss(sim_, (uint32_t)std::min(4294967295.0, p * 4294967296.0)), "swim_set_loss"); }
 
   // ---- what the members of the pool share on the host: tags by member, the EventCh router, who holds a handle ----

@@ -293,6 +293,7 @@ struct swim_sim {
   uint32_t ev_words;             /* words per event-buffer slot: ltime, n, ids */
   uint32_t *ev_watch, *n_ev_watch, ev_observer;   /* swim_watch_events: [R][SWIM_EVENT_WATCHERS] observers with an EventCh of their own; whose event record_event writes next */
   uint8_t *gt_alive, *part;      /* [R*N] replicated ground truth */
+  uint8_t *tcp_cls;              /* [R*N] swim_set_tcp_class (DisableTcpPingsForNode) */
   uint8_t* attached;             /* [R*N] driven from outside through the transport bridge */
   uint8_t* alone;                /* [R*N] replicated: started by swim_inject_join, join push-pull not carried out (yet): it knows nobody */
   edgevec captured;              /* rumours sent to attached nodes: {dst = replica*N+attached, ..}, src kept in cap_src */
@@ -1032,7 +1033,8 @@ static void probe_indirect(swim_sim* s, uint32_t r, uint32_t o, node_t* nd) {
   int tcp = 0;
   if (!acked && (s->cfg.flags & SWIM_F_TCP_FALLBACK)) {
     size_t base = (size_t)r * s->N;
-    tcp = s->gt_alive[base + x] && s->part[base + o] == s->part[base + x];
+    tcp = s->gt_alive[base + x] && s->part[base + o] == s->part[base + x] &&
+          s->tcp_cls[base + o] == s->tcp_cls[base + x];                /* DisableTcpPingsForNode: other datacenter */
   }
   if (acked || tcp) {
     awareness_delta(s, nd, -1);
@@ -1461,6 +1463,7 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R;
   s->ev_watch = (uint32_t*)calloc((size_t)s->R * SWIM_EVENT_WATCHERS, 4); s->n_ev_watch = (uint32_t*)calloc(s->R, 4);
   s->gt_alive = (uint8_t*)malloc(NT); s->part = (uint8_t*)calloc(NT, 1); s->attached = (uint8_t*)calloc(NT, 1); s->alone = (uint8_t*)calloc(NT, 1);
+  s->tcp_cls = (uint8_t*)calloc(NT, 1);
   s->node_slot = (uint32_t*)malloc(NT * 4); s->nodes = (node_t*)calloc(NL, sizeof(node_t));
   s->base_key = (uint32_t*)malloc(NT * 4); s->subj_cnt = (uint32_t*)calloc(NT, 4);
   s->f_cnt = (uint32_t*)calloc(NT, 4); s->f_kmin = (uint32_t*)calloc(NT, 4); s->f_kmax = (uint32_t*)calloc(NT, 4); s->f_bad = (uint8_t*)calloc(NT, 1);
@@ -1505,7 +1508,7 @@ int swim_destroy(swim_sim* s) {
   free(s->inbox_slab); free(s->ev_watch); free(s->n_ev_watch);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
   if (s->out) for (uint32_t i = 0; i < s->cfg.n_shards; i++) free(s->out[i].v);
-  free(s->attached); free(s->alone); free(s->captured.v); free(s->cap_src); free(s->xpeers);
+  free(s->attached); free(s->alone); free(s->tcp_cls); free(s->captured.v); free(s->cap_src); free(s->xpeers);
   free(s->q_slab); free(s->evq_slab); free(s->cs); free(s->c_new); free(s->c_list);
   free(s->gt_alive); free(s->part); free(s->node_slot); free(s->nodes); free(s->slots); free(s->n_slots);
   free(s->out); free(s->in.v); free(s->last_edges.v); free(s->pp_reply[0].v); free(s->pp_reply[1].v); free(s->carry[0].v); free(s->carry[1].v); free(s->events); free(s);
@@ -1700,6 +1703,13 @@ int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uin
 int swim_watch(swim_sim* s, uint32_t r, uint32_t x) {
   if (!s) return SWIM_EINVAL; if (s->in_tick) return SWIM_ESTATE; if (r >= s->R || x >= s->N) return SWIM_ERANGE;
   return alloc_slot(s, r, x);
+}
+/* memberlist.Config.DisableTcpPingsForNode as Consul sets it (agent/consul/server_serf.go:222-232): no TCP fallback ping across classes */
+int swim_set_tcp_class(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint8_t cls) {
+  int rc = chk(s, r, ids, n); if (rc) return rc;
+  if (cls > SWIM_TCP_CLASS_MAX) return SWIM_ERANGE;
+  for (size_t a = 0; a < n; a++) s->tcp_cls[(size_t)r * s->N + ids[a]] = cls;
+  return SWIM_OK;
 }
 int swim_set_loss(swim_sim* s, uint32_t q) { if (!s) return SWIM_EINVAL; s->loss_q32 = q; return SWIM_OK; }
 
@@ -1979,7 +1989,7 @@ int swim_checkpoint_save(swim_sim* s, const char* path) {
   h.abi = SWIM_ABI_VERSION; h.tick = s->tick; h.loss_q32 = s->loss_q32; h.n_join_pending = s->n_join_pending; h.f_ntouched = s->f_ntouched; h.xcredit = s->xcredit;
   h.n_events = s->n_events; h.cfg = s->cfg; h.st = s->st;
   int ok = ck_wr(f, &h, sizeof h);
-  ok = ok && ck_wr(f, s->gt_alive, NT) && ck_wr(f, s->part, NT) && ck_wr(f, s->attached, NT) && ck_wr(f, s->alone, NT);
+  ok = ok && ck_wr(f, s->gt_alive, NT) && ck_wr(f, s->part, NT) && ck_wr(f, s->attached, NT) && ck_wr(f, s->alone, NT) && ck_wr(f, s->tcp_cls, NT);
   ok = ok && ck_wr(f, s->node_slot, NT * 4) && ck_wr(f, s->base_key, NT * 4) && ck_wr(f, s->subj_cnt, NT * 4);
   ok = ok && ck_wr(f, s->f_cnt, NT * 4) && ck_wr(f, s->f_kmin, NT * 4) && ck_wr(f, s->f_kmax, NT * 4) && ck_wr(f, s->f_bad, NT);
   ok = ok && ck_wr(f, s->f_touched, (size_t)s->f_ntouched * 4) && ck_wr(f, s->join_list, (size_t)s->n_join_pending * 8);
@@ -2013,7 +2023,7 @@ int swim_checkpoint_load(swim_sim* s, const char* path) {
     fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another library, ABI or configuration"); return SWIM_EINVAL;
   }
   int ok = 1;
-  ok = ok && ck_rd(f, s->gt_alive, NT) && ck_rd(f, s->part, NT) && ck_rd(f, s->attached, NT) && ck_rd(f, s->alone, NT);
+  ok = ok && ck_rd(f, s->gt_alive, NT) && ck_rd(f, s->part, NT) && ck_rd(f, s->attached, NT) && ck_rd(f, s->alone, NT) && ck_rd(f, s->tcp_cls, NT);
   ok = ok && ck_rd(f, s->node_slot, NT * 4) && ck_rd(f, s->base_key, NT * 4) && ck_rd(f, s->subj_cnt, NT * 4);
   ok = ok && ck_rd(f, s->f_cnt, NT * 4) && ck_rd(f, s->f_kmin, NT * 4) && ck_rd(f, s->f_kmax, NT * 4) && ck_rd(f, s->f_bad, NT);
   if (ok && h.f_ntouched > s->f_cap) { uint32_t* v = (uint32_t*)realloc(s->f_touched, (size_t)h.f_ntouched * 4); if (v) { s->f_touched = v; s->f_cap = h.f_ntouched; } else ok = 0; }

@@ -464,6 +464,29 @@ def test_tcp_fallback_ping_rides_out_packet_loss(oracle):
     assert u.stats()["probe_failures"] > 0 and u.stats()["probe_tcp_acks"] == 0
 
 
+def test_no_tcp_ping_across_datacenters(oracle):
+    """memberlist's DisableTcpPingsForNode the way Consul's WAN pool sets it under mesh-gateway federation
+    (agent/consul/server_serf.go:222-232: `return s.config.Datacenter != dc`): with 30 % UDP loss, probes of a member of the SAME
+    datacenter are still saved by the TCP ping, probes across datacenters are not — so only cross-datacenter pairs ever
+    raise a (false) suspicion, and with everybody in one class nothing changes."""
+    kw = dict(n_nodes=256, seed=6, loss_q32=int(0.30 * 2**32), subject_cap=256, view_cap=256, queue_cap=16, inbox_cap=128)
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    s.set_tcp_class(0, range(128, 256), 1)                       # dc2
+    s.step_ms(20000)
+    st = s.stats()
+    assert st["probe_tcp_acks"] > 0 and st["probe_failures"] > 0 and st["msgs_sent"][abi.MSG_SUSPECT] > 0
+    plain = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    plain.step_ms(20000)
+    assert plain.stats()["probe_failures"] == 0 and plain.stats()["probe_tcp_acks"] > st["probe_tcp_acks"]
+    # one class for everybody (whatever its number) is the default behaviour, tick for tick
+    same = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    same.set_tcp_class(0, range(256), 7)
+    same.step_ms(20000)
+    assert same.stats() == plain.stats()
+    with pytest.raises(Exception):
+        s.set_tcp_class(0, [256], 1)
+
+
 def test_golden_fixture_config1(oracle):
     """tests/golden/config1_kill17.json was generated by tools/make_golden.py from this oracle at the
     commit that introduced it; it guards the restatement against silent drift."""

@@ -338,6 +338,20 @@ def test_tcp_fallback_under_loss_parity(hip, oracle):
     assert st["probe_tcp_acks"] > 0 and a.stats()["probe_tcp_acks"] == st["probe_tcp_acks"] and st["probe_failures"] > 0
 
 
+def test_no_tcp_ping_across_datacenters_parity(hip, oracle):
+    """swim_set_tcp_class (DisableTcpPingsForNode, agent/consul/server_serf.go:222-232): three datacenters under 25 % loss and
+    a real failure — both libraries skip the same TCP pings, raise the same false suspicions and refute them alike."""
+    a, b = pair(hip, oracle, n_nodes=1536, seed=21, subject_cap=512, view_cap=256, queue_cap=16, inbox_cap=256, loss_q32=int(0.25 * 2**32))
+    for s in (a, b):
+        s.set_tcp_class(0, range(512, 1024), 1); s.set_tcp_class(0, range(1024, 1536), 2)
+        s.step_ms(6000)
+        s.kill(0, [700])
+        s.step_ms(20000)
+    assert_same(a, b, [(0, 700)])
+    st = b.stats()
+    assert st["probe_tcp_acks"] > 0 and st["probe_failures"] > 0 and st["refutes"] > 0 and a.stats()["probe_tcp_acks"] == st["probe_tcp_acks"]
+
+
 def test_revived_node_fires_overdue_suspicion_timers(hip, oracle):
     """A node that went down while it suspected somebody resumes its old views when it comes back, and the suspicion
     timer that ran out meanwhile fires in its first tick (found by tools/fuzz_parity.py: the expire role's gate only
