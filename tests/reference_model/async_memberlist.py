@@ -26,8 +26,9 @@ CTL_LEN = {"ping": 86, "indirect": 122, "ack": 108, "nack": 13}
 class Cluster:
     def __init__(self, n=128, seed=1, gossip_interval=0.2, gossip_nodes=3, probe_interval=1.0, probe_timeout=0.5, suspicion_mult=4,
                  suspicion_max_mult=6, retransmit_mult=4, indirect_checks=3, awareness_max=8, gossip_to_dead=30.0, udp=1400,
-                 latency=(0.0002, 0.002)):
-        self.n, self.rng = n, random.Random(seed)
+                 latency=(0.0002, 0.002), loss=0.0):
+        self.n, self.rng, self.loss = n, random.Random(seed), loss
+        self.probe_failures = self.refutes = self.timeouts = 0
         self.gi, self.k, self.pi, self.pt = gossip_interval, gossip_nodes, probe_interval, probe_timeout
         self.ic, self.aw_max, self.g2d, self.budget, self.lat = indirect_checks, awareness_max, gossip_to_dead, udp - 2, latency
         self.limit = retransmit_mult * math.ceil(math.log10(n + 1))
@@ -48,7 +49,7 @@ class Cluster:
         heapq.heappush(self.heap, (t, self.seq, fn, a))
 
     def send(self, src, dst, fn, *a):                            # a UDP packet: arrives after its own latency if dst runs
-        if self.up[src]:
+        if self.up[src] and not (self.loss and self.rng.random() < self.loss):
             self.at(self.now + self.rng.uniform(*self.lat), self._deliver, dst, fn, a)
 
     def _deliver(self, dst, fn, a):
@@ -69,7 +70,7 @@ class Node:
         self.c, self.i = c, i
         self.inc, self.awareness = 1, 0
         self.view = {j: [ALIVE, 1, 0.0] for j in range(c.n)}     # state, incarnation, state change
-        self.timers = {}                                         # subject -> dict(confirmers, k, start, deadline, gen)
+        self.timers, self.tgen = {}, 0                           # subject -> dict(confirmers, k, start, gen)
         self.queue, self.qid = [], 0                             # limitedBroadcast: dict(name, type, inc, frm, transmits, id)
         self.order, self.pidx = [], 0                            # the shuffled probe list and probeIndex
         self.busy_until = 0.0
@@ -129,7 +130,7 @@ class Node:
             n = len(t["conf"]) - 1
             frac = math.log(n + 1.0) / math.log(t["k"] + 1.0)
             timeout = max(math.floor(1000.0 * (self.c.s_max - frac * (self.c.s_max - self.c.s_min))) / 1000.0, self.c.s_min)
-            t["gen"] += 1
+            self.tgen += 1; t["gen"] = self.tgen                 # timer.Reset: the earlier expiry is void
             self.c.at(max(t["start"] + timeout, self.c.now), self.suspicion_fired, x, t["gen"])
             self.broadcast("suspect", x, inc, frm)
             return
@@ -141,15 +142,17 @@ class Node:
         self.broadcast("suspect", x, inc, frm)
         self.set_state(x, SUSPECT, inc)
         k = self.c.s_k
-        t = dict(conf={frm}, k=k, start=self.c.now, gen=0)
+        self.tgen += 1                                           # (unique per node: an expiry scheduled for an EARLIER suspicion of x is void)
+        t = dict(conf={frm}, k=k, start=self.c.now, gen=self.tgen)
         self.timers[x] = t
-        self.c.at(self.c.now + (self.c.s_min if k < 1 else self.c.s_max), self.suspicion_fired, x, 0)
+        self.c.at(self.c.now + (self.c.s_min if k < 1 else self.c.s_max), self.suspicion_fired, x, t["gen"])
 
     def suspicion_fired(self, x, gen):
         t = self.timers.get(x)
         if t is None or t["gen"] != gen or not self.c.up[self.i]:
             return
         if self.view[x][0] == SUSPECT:
+            self.c.timeouts += 1
             self.dead_node(x, self.view[x][1], self.i)
 
     def dead_node(self, x, inc, frm):
@@ -166,7 +169,9 @@ class Node:
         self.set_state(x, DEAD, inc)
 
     def refute(self, accused):
+        self.c.refutes += 1
         self.inc = max(self.inc + 1, accused + 1)
+        self.view[self.i][1] = self.inc                          # state.Incarnation of the own entry: older accusations are stale now
         self.awareness = min(self.awareness + 1, self.c.aw_max - 1)
         self.broadcast("alive", self.i, self.inc, 0)
 
@@ -216,9 +221,9 @@ class Node:
             return
         interval = c.pi * (self.awareness + 1)                   # awareness.ScaleTimeout(ProbeInterval)
         self.busy_until = c.now + interval
-        st = dict(acked=False, nacks=0, expected=0)
+        st = dict(acked=False, nacks=0, expected=0, inc=self.view[target][1])    # probe() hands probeNode a COPY of the nodeState
         piggy = self.get_broadcasts(2, c.budget - CTL_LEN["ping"])
-        extra = [("suspect", target, self.view[target][1], self.i)] if self.view[target][0] != ALIVE else []
+        extra = [("suspect", target, st["inc"], self.i)] if self.view[target][0] != ALIVE else []
         c.send(self.i, target, c.nodes[target].on_ping, self.i, extra + piggy, st, self)
         c.at(c.now + c.pt, self.probe_indirect, target, st)
         c.at(c.now + interval, self.probe_conclude, target, st)
@@ -266,8 +271,9 @@ class Node:
         if st["acked"] or not self.c.up[self.i]:
             return
         delta = (st["expected"] - st["nacks"]) if st["expected"] else 1
+        self.c.probe_failures += 1
         self.awareness = min(max(self.awareness + delta, 0), self.c.aw_max - 1)
-        self.suspect_node(target, self.view[target][1], self.i)
+        self.suspect_node(target, st["inc"], self.i)              # ... and accuses with that copy's incarnation
 
 
 def config1(seed, n=128, victim=17, kill_at=10.0, horizon=70.0):
@@ -299,3 +305,31 @@ def config1(seed, n=128, victim=17, kill_at=10.0, horizon=70.0):
             allk = c.now - kill_at
             break
     return first_s, first_d, allk
+
+
+def lossy(seed, n=128, loss=0.2, seconds=60.0):
+    """Nobody stops, every packet is lost with probability `loss`, no TCP fallback ping: probes fail now and then, the accused
+    refute.  -> (failed probes, refutations, suspicion timers that ran out, mean awareness score at the end)."""
+    c = Cluster(n=n, seed=seed, loss=loss)
+    c.run(seconds)
+    return c.probe_failures, c.refutes, c.timeouts, sum(nd.awareness for nd in c.nodes) / n
+
+
+def update(seed, n=128, who=5, at=5.0, horizon=20.0):
+    """memberlist.UpdateNode on `who` at `at`: it bumps its incarnation and queues alive{}; seconds until the last member holds
+    the new incarnation (the dissemination time of ONE rumour through gossip and piggy-backing)."""
+    c = Cluster(n=n, seed=seed)
+    c.run(at)
+    nd = c.nodes[who]
+    nd.inc += 1
+    nd.view[who][1] = nd.inc
+    nd.broadcast("alive", who, nd.inc, 0)
+    done = [None]
+
+    def everybody():
+        if all(m.view[who][1] == nd.inc for m in c.nodes):
+            done[0] = c.now - at
+            return True
+        return False
+    c.run(at + horizon, stop=everybody)
+    return done[0]
