@@ -35,6 +35,21 @@ def test_in_process_shards_match_unsharded(oracle, n_shards):
     assert a["edges_remote"] > 0 and b["edges_remote"] == 0
 
 
+def test_tcp_classes_are_ground_truth_on_every_shard(oracle):
+    """swim_set_tcp_class is replicated like a partition mask: a prober on one shard and its target on another compare their
+    classes exactly as an unsharded run does (two datacenters under 25 % loss, TCP fallback on)."""
+    kw = dict(n_nodes=1024, seed=8, subject_cap=256, view_cap=1024, queue_cap=16, inbox_cap=2048, loss_q32=int(0.25 * 2**32))
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.set_tcp_class(0, range(0, 1024, 2), 3)                     # classes interleaved: most probes cross a shard AND a class
+        s.step_ms(15000)
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    assert a["inbox_overflow"] == b["inbox_overflow"] == 0     # (a shard cannot filter what another shard sends it: room for all of it)
+    assert a["probe_tcp_acks"] == b["probe_tcp_acks"] > 0 and a["probe_failures"] == b["probe_failures"] > 0 and a["refutes"] == b["refutes"]
+
+
 @pytest.mark.parametrize("n_shards", [2, 4])
 def test_library_exchange_calls_on_the_oracle(oracle, n_shards):
     """swim_xchg_export / connect / step (the product library's device-driven exchange) as the oracle implements them for
