@@ -10,6 +10,8 @@
 
 #define SW_MAX_SHARDS 16
 #define SW_EXC_MAX 16               /* per-replica list of nodes whose node word is non-zero */
+#define SW_BIGSORT_MIN 128u        /* from this many messages on an inbox is sorted by a whole workgroup (k_inbox_sort), not by its lane */
+#define SW_BIGSORT_MAX 8192u       /* ... up to what 96 KB of LDS hold (12 bytes per message) */
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
 #define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
@@ -119,6 +121,7 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 
 struct SwDev {
   // dimensions
+  uint32_t bigsort_cap;  // inboxes of SW_BIGSORT_MIN .. bigsort_cap messages are sorted by k_inbox_sort (a workgroup, in LDS) before k_resolve; 0 = never
   uint32_t N, R, nloc, i0, S, Q, C, C2, EQ, EB, EW;   // EW = 16-byte words per event-buffer slot (4*EW - 2 ids per Lamport time)
   uint32_t n_shift, nloc_shift;   // log2 of N / nloc when that is a power of two (division and remainder by shift and mask), else 0xFFFFFFFF
   uint32_t G, P, TQ, CH, quantum_ms;

@@ -407,7 +407,9 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.n_shift = (D.N & (D.N - 1)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(D.N);
   D.nloc_shift = (D.nloc & (D.nloc - 1)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(D.nloc);
   if (cfg->n_shards > 1 && D.nloc % d.phase_chunk) { swim_destroy(s); return SWIM_EINVAL; }
-  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C : 0;   // the overflow row has room for ALL C messages: a big inbox is sorted in it (k_resolve)
+  D.S = cfg->subject_cap; D.Q = cfg->queue_cap; D.C = cfg->inbox_cap; D.C2 = D.C > SW_INBOX_FAST ? D.C : 0;   // the overflow row has room for ALL C messages: a big inbox is sorted in it
+  D.bigsort_cap = D.C >= SW_BIGSORT_MIN ? std::min<uint32_t>(D.C, SW_BIGSORT_MAX) : 0;                         // ... by k_inbox_sort from SW_BIGSORT_MIN messages on, by its lane in k_resolve below that
+  if (const char* e = getenv("SWIMSIM_BIGSORT")) if (!atoi(e)) D.bigsort_cap = 0;                             // (A/B: the lane's heapsort for every size)
   D.EQ = serf ? cfg->event_queue_cap : 0; D.EB = serf ? cfg->event_buffer : 0;
   D.EW = serf ? ((cfg->event_ids_per_ltime ? cfg->event_ids_per_ltime : 14) + 2 + 3) / 4 : 0;
   D.G = d.gossip_period; D.P = d.probe_period; D.TQ = d.probe_timeout_ticks; D.CH = d.phase_chunk;
@@ -727,6 +729,10 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_apply_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
+  if (D.bigsort_cap) {   // inboxes of thousands of messages (a state exchange during a mass event) are sorted by a workgroup each, in LDS
+    uint32_t P = SW_BIGSORT_MIN; while (P < D.bigsort_cap) P <<= 1;
+    hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
   }
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(D.M ? k_resolve<true> : k_resolve<false>, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that

@@ -2102,6 +2102,53 @@ __device__ __attribute__((noinline)) void inbox_heapsort(uint32_t* a, uint32_t n
 }
 #define SW_INBOX_SORT_MIN 12      /* from this many messages on the inbox is sorted rather than searched */
 
+// A state exchange in the middle of a mass event hands a node thousands of messages in one tick (config #4: 3 800 at 262 144
+// nodes, 7 600 at 524 288).  Heap-sorting them from ONE lane is tens of thousands of dependent round trips — 20 ms of a tick in
+// which the rest of the device waits.  So before k_resolve the workgroup that owns the node sorts such an inbox in LDS (bitonic,
+// the same canonical key; pads sort last) and leaves it in the overflow row, line messages included; k_resolve then walks it.
+__global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort(const SwDev* __restrict__ Dp, uint32_t cap) {
+  SW_DEV_BIND
+  uint32_t* const sy = (uint32_t*)g_lds_dyn; uint32_t* const sz = sy + cap; uint32_t* const sw = sz + cap;
+  __shared__ uint32_t s_big[SW_BLOCK], s_nbig;
+  const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)blockIdx.x * SW_BLOCK, l = l0 + threadIdx.x;
+  uint32_t c = l < NL ? D.in_cnt[l] : 0u;
+  if (c > D.C) c = D.C;
+  const bool big = c >= SW_BIGSORT_MIN && c <= D.bigsort_cap;
+  if (!__syncthreads_or(big)) return;
+  if (threadIdx.x == 0) s_nbig = 0;
+  __syncthreads();
+  if (big) s_big[atomicAdd(&s_nbig, 1u)] = (c << 8) | threadIdx.x;
+  __syncthreads();
+  const uint32_t nbig = s_nbig;
+  for (uint32_t b = 0; b < nbig; b++) {
+    const uint32_t ent = s_big[b], n = ent >> 8;
+    const size_t ll = l0 + (ent & 255u);
+    uint32_t* const row = D.inbox2 + ll * D.C2 * 3;
+    const uint32_t* const line = D.inbox1 + ll * 16;
+    uint32_t P = SW_BIGSORT_MIN; while (P < n) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += SW_BLOCK) {
+      uint32_t y = NONE, z = NONE, w = NONE;                      // a pad: the greatest key there is
+      if (i < SW_INBOX_FAST) { y = line[1 + 3 * i]; z = line[2 + 3 * i]; w = line[3 + 3 * i]; }
+      else if (i < n) { const uint32_t* m = row + (size_t)(i - SW_INBOX_FAST) * 3; y = m[0]; z = m[1]; w = m[2]; }
+      sy[i] = y; sz[i] = z; sw[i] = w;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j; j >>= 1) {
+        for (uint32_t p = threadIdx.x; p < P / 2; p += SW_BLOCK) {
+          const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
+          const uint4 a = make_uint4(0, sy[i], sz[i], sw[i]), bb = make_uint4(0, sy[q], sz[q], sw[q]);
+          uint64_t ah, al, bh, bl; edge_key(a, ah, al); edge_key(bb, bh, bl);
+          const bool gt = ah > bh || (ah == bh && al > bl);
+          if (gt == ((i & k) == 0)) { sy[i] = bb.y; sz[i] = bb.z; sw[i] = bb.w; sy[q] = a.y; sz[q] = a.z; sw[q] = a.w; }
+        }
+        __syncthreads();
+      }
+    for (uint32_t i = threadIdx.x; i < n; i += SW_BLOCK) { uint32_t* m = row + (size_t)i * 3; m[0] = sy[i]; m[1] = sz[i]; m[2] = sw[i]; }
+    __syncthreads();
+  }
+}
+
 // A tile of SW_RTILE node blocks per workgroup.  Who got something this tick is sparse (a fifth of the nodes while a
 // rumour saturates a cluster, far fewer otherwise) and a lane's work is a chain of dependent memory round trips: lanes
 // that map 1:1 to nodes leave most of every wave idle through the whole chain.  So the workgroup first compacts the
@@ -2215,6 +2262,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)
     n.stage_queue();
     const bool sorted = cnt >= SW_INBOX_SORT_MIN;
+    const bool presorted = cnt >= SW_BIGSORT_MIN && cnt <= D.bigsort_cap;   // k_inbox_sort has been here
     if (!sorted) {
       const uint32_t gx = IN_WORD(1), gty = IN_WORD(3) >> 30;
       if (gx < D.N && gty != SWIM_MSG_USER && gx != n.o) { n.cv = n.lookup(gx); n.cv_x = gx; }
@@ -2222,7 +2270,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     bool have_last = false; uint64_t lhi = 0, llo = 0;
     uint32_t next_j = 0;
     RCLK_MARK(2);                                  // queue staged, first view fetched
-    if (sorted) {                                  // the five messages of the line join the row (it has room for all C), then one sort
+    if (sorted && !presorted) {                    // the five messages of the line join the row (it has room for all C), then one sort
       uint32_t* row = D.inbox2 + l * D.C2 * 3;
       for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
       inbox_heapsort(row, cnt);
