@@ -24,6 +24,7 @@ BUDGET = {
     "7k_quietPK": (40, 0, 8),
     "14k_coord_updatePK": (128, 0, 4),
     "13k_expire_massPK": (64, 0, 8),
+    "12k_inbox_sortPK": (48, 0, 8),           # big inboxes, a workgroup each, in LDS
 }
 
 
