@@ -306,34 +306,76 @@ def run_config4(hip, args, device) -> dict:
 
 def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, barrier, allreduce_max) -> dict:
     """BASELINE configs[3] across the ranks: one population block-partitioned over the GPUs, 5 % stopped at once, the 30 s after
-    the failure (the phase in which every node learns of every victim: the exchange carries ~7/8 of all records).  Sized so that
-    the dense pair store fits: every rank holds (victims of the WHOLE population) x (its own observers) pairs of 12 bytes —
-    524 288 nodes on 2 ranks, 1 048 576 on 4 or 8 (the full 4 194 304 with 209 715 victims would need 1.3 TB per rank: DESIGN §4a)."""
+    the failure (the phase in which every node learns of every victim: the exchange carries ~(world-1)/world of all records).
+    262 144 nodes / 13 107 victims whatever the number of ranks: a state exchange that crosses a shard boundary arrives UNFILTERED
+    (a shard cannot read a remote receiver's view), i.e. with every explicit view of the sender — ~2 500 of them 30 s after the
+    failure, all 13 107 later — and the inbox has to hold it: 8 192 slots here, the most `k_inbox_sort` sorts in LDS.  (The full
+    4 194 304 with 209 715 victims needs 1.3 TB of pair store per rank and inboxes of 2 * 10^5: DESIGN §4a, §10.)
+    A failure of this leg (an overflowing bounded structure raises, never passes silently) is reported in the line, not fatal."""
     from consul_amd.dist import LibraryExchange, ShardedSim
-    n = int(os.environ.get("SWIMSIM_BENCH_C4S_NODES", 0)) or (524288 if world <= 2 else 1048576)      # (the override: tests on one device)
+    n = int(os.environ.get("SWIMSIM_BENCH_C4S_NODES", 0)) or 262144      # (the override: tests on one device)
     nv = n // 20
-    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=16, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=16, inbox_cap=8192, subject_cap=4, gossip_nodes=3,
               device=device, shard_rank=rank, n_shards=world)
     victims = np.random.default_rng(args.seed).choice(n, size=nv, replace=False)
-    s = ShardedSim(Sim(hip, preset(hip, abi.PRESET_LAN, **kw)), LibraryExchange(gather_handles))
-    G, q = s.sim.derived.gossip_period, s.sim.derived.quantum_ms
-    s.step_ms(1000); s.kill(0, victims.tolist()); s.sync(); barrier()
-    t0 = time.perf_counter()
-    s.step_ms(30000); s.sync(); barrier()
-    dt = allreduce_max(time.perf_counter() - t0)
-    got = [None] * world
-    dist.all_gather_object(got, (s.sim.stats(), s.sim.detection(0)))
+    what = (f"{n} nodes block-partitioned over {world} GPUs, {nv} stopped at once, LAN timers, k = 3: the 30 s after the failure; "
+            "dense pair store per rank, the library's mailbox exchange")
+    s, err, dt, mine = None, None, 0.0, None
+
+    def agree(payload=None):
+        """Every rank arrives here whether its part failed or not (one all-gather per phase: it is also the barrier); -> the payloads,
+        or None if some rank failed (then every rank gives up together)."""
+        got = [None] * world
+        dist.all_gather_object(got, (err, payload))
+        return None if any(g[0] for g in got) else [g[1] for g in got], next((g[0] for g in got if g[0]), None), sum(1 for g in got if g[0])
+
+    def give_up(first, n_failed):
+        try:
+            if s is not None:
+                s.close()
+        except Exception:                                   # noqa: BLE001 (already failing: report the first error)
+            pass
+        return {"workload": what, "n_nodes": n, "victims": nv, "error": first, "ranks_failed": n_failed}
+
+    try:                                                    # phase 1: allocate (the pair store and the inboxes are tens of GB)
+        s = ShardedSim(Sim(hip, preset(hip, abi.PRESET_LAN, **kw)), LibraryExchange(gather_handles))
+        G, q = s.sim.derived.gossip_period, s.sim.derived.quantum_ms
+    except Exception as e:                                  # noqa: BLE001
+        err = f"rank {rank} (create): {e}"[:300]
+    ok, first, n_failed = agree()
+    if ok is None:
+        return give_up(first, n_failed)
+    try:                                                    # phase 2: connect the mailboxes (first step), the failure
+        s.step_ms(1000); s.kill(0, victims.tolist()); s.sync()
+    except Exception as e:                                  # noqa: BLE001 (a rank that stops makes the others' exchange time out: they get here too)
+        err = f"rank {rank} (start): {e}"[:300]
+    ok, first, n_failed = agree()
+    if ok is None:
+        return give_up(first, n_failed)
+    try:                                                    # phase 3: the timed 30 s (agree() was the barrier); an overflow is raised at the END of the call, on the rank it happened on
+        t0 = time.perf_counter()
+        s.step_ms(30000); s.sync()
+        dt = time.perf_counter() - t0
+        mine = (s.sim.stats(), s.sim.detection(0))
+    except Exception as e:                                  # noqa: BLE001
+        err = f"rank {rank} (run): {e}"[:300]
+    ok, first, n_failed = agree((dt, mine))
+    if ok is None:
+        return give_up(first, n_failed)
     s.close()
+    got = [(None,) + g for g in ok]
+    dt = max(g[1] for g in got)
+    got = [g[2] for g in got]
     st = {k: sum(g[0][k] for g in got) for k in ("edges", "edges_remote", "view_drops", "queue_drops", "inbox_overflow")}
     pairs = sum(g[1][0] for g in got); dead = sum(g[1][1][2] + g[1][1][3] for g in got); susp = sum(g[1][1][1] for g in got)
     ticks = 31000 // q
-    return {"workload": f"{n} nodes block-partitioned over {world} GPUs, {nv} stopped at once, LAN timers, k = 3: the 30 s after the failure; "
-                        "dense pair store per rank, the library's mailbox exchange",
+    return {"workload": what,
             "n_nodes": n, "victims": nv, "wall_s": round(dt, 2), "rounds_per_sec": 30000 / q / G / dt, "value": n * (30000 / q / G) / dt, "unit": "node-rounds/s",
             "pairs": pairs, "suspect_fraction": susp / max(pairs, 1), "dead_fraction": dead / max(pairs, 1),
             "a2a_bytes_per_tick_all_ranks": 16.0 * st["edges_remote"] / ticks, "a2a_bytes_per_tick_per_rank": 16.0 * st["edges_remote"] / ticks / world,
             "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_overflow": st["inbox_overflow"],
-            "inbox_peak": max(g[0]["inbox_peak"] for g in got), "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
+            "inbox_peak": max(g[0]["inbox_peak"] for g in got), "inbox_cap": kw["inbox_cap"],
+            "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
 
 
 def run_config5(hip, args, device) -> dict:
@@ -624,7 +666,10 @@ def main():
                 line["exchange"]["other"] = {"error": str(e)[:200]}
         line["exchange"]["us_per_tick"] = 1000.0 * line["ms_per_step"] / G
     if world > 1 and not args.no_config4:
-        line["config4_sharded"] = run_config4_sharded(hip, args, rank, world, local_rank, dist, gather_handles, barrier, allreduce_max)
+        if use_library:
+            line["config4_sharded"] = run_config4_sharded(hip, args, rank, world, local_rank, dist, gather_handles, barrier, allreduce_max)
+        else:
+            line["config4_sharded"] = {"skipped": "the leg runs on the library's mailbox exchange, which is not in use in this run"}
     if sharded and not args.no_replica_leg:
         # The clusters of this workload are independent of each other, so the box can also simply run 32 whole clusters
         # per GPU with nothing on the wire (same scenario, captured-graph replay as at N=1): reported next to the

@@ -27,3 +27,34 @@ def test_clusters_spread_over_handles_are_the_clusters_of_one_handle(oracle):
         assert (a.first_suspect_ms, a.first_dead_ms, a.all_dead_ms, list(a.by_state)) == (b.first_suspect_ms, b.first_dead_ms, b.all_dead_ms, list(b.by_state))
         assert a.all_dead_ms != abi.NONE
     one.close(); two.close()
+
+
+class _OneRank:
+    """torch.distributed's part in bench.run_config4_sharded for a world of one (the leg's control flow on the checker)."""
+    @staticmethod
+    def all_gather_object(out, obj):
+        out[0] = obj
+
+
+def _leg(oracle, nodes, monkeypatch):
+    import types
+    import bench
+    monkeypatch.setenv("SWIMSIM_BENCH_C4S_NODES", str(nodes))
+    args = types.SimpleNamespace(seed=3)
+    return bench.run_config4_sharded(oracle, args, 0, 1, 0, _OneRank, lambda mine: [mine[0]], lambda: None, lambda x: x)
+
+
+def test_sharded_config4_leg_control_flow_on_the_checker(oracle, monkeypatch):
+    """The N > 1 config-#4 leg of bench.py, world of one, on the checker (which has no dense store: its tables of 8 do drop
+    views — what is checked here is the leg's bookkeeping: phases, the gathered payloads, the fields of its object)."""
+    c = _leg(oracle, 4096, monkeypatch)
+    assert "error" not in c, c
+    assert c["n_nodes"] == 4096 and c["victims"] == 204 and c["pairs"] == (4096 - 204) * 204 and c["inbox_cap"] == 8192
+    assert c["wall_s"] >= 0 and c["rounds_per_sec"] > 0 and c["inbox_overflow"] == 0 and 0 < c["suspect_fraction"] + c["dead_fraction"] <= 1
+
+
+def test_sharded_config4_leg_reports_a_failure_instead_of_raising(oracle, monkeypatch):
+    """A rank that cannot even create its shard (here: a population of one, which no configuration accepts) makes every rank give
+    the leg up together; the bench line carries the error, the headline number is not lost."""
+    c = _leg(oracle, 1, monkeypatch)
+    assert c["ranks_failed"] == 1 and "create" in c["error"] and "wall_s" not in c
