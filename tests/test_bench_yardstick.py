@@ -35,3 +35,17 @@ def test_the_split_by_kernel_adds_up(oracle):
     # a filtered rumour is charged where it is dropped, never to k_resolve
     assert algorithmic_bytes("k_resolve", st) == 8.0 * (msgs - st["msgs_filtered"]) + 24.0 * applied + 16.0 * st["msgs_piggybacked"]
     s.close()
+
+
+def test_roofline_traffic_quotes_the_committed_pmc_passes_only_for_their_workload(oracle):
+    """`roofline.traffic` is the HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (they cannot be
+    collected inside the bench process) — quoted when the bench runs the window they were taken over, null otherwise."""
+    from bench import roofline_of
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=2048, seed=5, subject_cap=4))
+    s.step(20); s.kill(0, [77]); s0 = s.stats(); s.step(100); st = diff_stats(s0, s.stats())
+    s.close()
+    prof = {"k_begin": (40, 3.1), "k_deliver": (40, 1.7), "k_resolve": (40, 3.2), "k_census": (40, 0.2), "k_finish": (40, 0.3)}
+    r = roofline_of(prof, st, 0.0075, virtual_nodes=4194304)
+    assert r["kernel"] == "k_resolve" and r["traffic"] > r["traffic_as_counted"] > 5e7
+    assert r["traffic_over_algorithmic"]["as_counted"] > 1.0
+    assert roofline_of(prof, st, 0.0075, virtual_nodes=2048)["traffic"] is None
