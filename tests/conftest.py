@@ -32,6 +32,8 @@ def pytest_collection_modifyitems(config, items):
 def oracle():
     """The plain-C checker (oracle/), built on demand."""
     src = os.path.join(ROOT, "oracle", "swim_oracle.c")
+    if os.environ.get("SWIMSIM_ORACLE_SO"):            # e.g. oracle/_build/libswim_oracle_asan.so (`make -C oracle asan`; LD_PRELOAD libasan)
+        return abi.bind(C.CDLL(os.environ["SWIMSIM_ORACLE_SO"]))
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     return abi.bind(C.CDLL(ORACLE_SO))
