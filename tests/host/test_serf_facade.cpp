@@ -344,11 +344,34 @@ static void testHandlesOnTwoReplicasAndReconnectOverride() {
   std::printf("ok HandlesOnTwoReplicasAndReconnectOverride\n");
 }
 
+// Consul's WAN pool under mesh-gateway federation (agent/consul/server_serf.go:222-232): DisableTcpPingsForNode answers "another
+// datacenter".  With a third of the packets lost, the TCP fallback ping saves every probe inside a datacenter; across datacenters
+// it is not sent, probes fail and members get suspected (and refute) — only there.
+static void testNoTcpPingAcrossDatacenters() {
+  auto run = [](bool split) {
+    serf::Cluster::Options o{ 64, 1, 16, 256, 64, 0, 9, 0, 512 };
+    o.ViewCap = 64;
+    auto pool = std::make_shared<serf::Cluster>(testTimers(), o);
+    pool->SetPacketLoss(0.33);
+    if (split) { std::vector<uint32_t> dc2; for (uint32_t i = 32; i < 64; i++) dc2.push_back(i); pool->SetDatacenter(0, dc2, 1); }
+    pool->Advance(Duration(20000));
+    swim_stats_t st; swim_stats(pool->handle(), &st);
+    return st;
+  };
+  swim_stats_t one = run(false), two = run(true);
+  EXPECT(one.probe_failures == 0 && one.probe_tcp_acks > 0 && one.refutes == 0);
+  EXPECT(two.probe_failures > 0 && two.probe_tcp_acks > 0 && two.probe_tcp_acks < one.probe_tcp_acks && two.refutes > 0);
+  bool refused = false;
+  try { serf::Cluster::Options o{ 16, 1, 8, 32, 8, 0, 5, 0, 512 }; serf::Cluster c(testTimers(), o); c.SetDatacenter(0, { 1 }, 200); } catch (const Error&) { refused = true; }
+  EXPECT(refused);                                           // classes 0..15
+  std::printf("ok NoTcpPingAcrossDatacenters\n");
+}
+
 int main() {
   try {
     std::printf("backend %s\n", swim_backend());
     testConfigPresets(); testLANReap(); testForceLeaveAndPrune(); testJoinGrowsTheCluster(); testGracefulLeave(); testUserEvent(); testCoordinates(); testCheckpointRestore(); testEventsForEveryHandle();
-    testFailedMemberTurnsSerfHealthCritical(); testMergeDelegateVetoesAForeignDatacenter(); testHandlesOnTwoReplicasAndReconnectOverride();
+    testFailedMemberTurnsSerfHealthCritical(); testMergeDelegateVetoesAForeignDatacenter(); testHandlesOnTwoReplicasAndReconnectOverride(); testNoTcpPingAcrossDatacenters();
   } catch (const std::exception& ex) { std::printf("FAIL exception: %s\n", ex.what()); return 2; }
   std::printf(failures ? "FAILED %d\n" : "ALL PASSED\n", failures);
   return failures ? 1 : 0;
