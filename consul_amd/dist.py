@@ -97,7 +97,7 @@ class TorchExchange:
                 return
             # every rank derives the same (clamped) sizes from the same matrix; a clamped segment has
             # already raised the sender's sticky overflow flag
-            rcap = self._caps[(self.rank + 1) % W]
+            rcap = min(c for sh, c in enumerate(self._caps) if sh != self.rank)     # (outbound_capacity is the same number on every rank: one configuration)
             send = [0 if sh == self.rank else min(m[self.rank][sh], rcap) for sh in range(W)]
             recv_n = [0 if src == self.rank else min(m[src][self.rank], rcap) for src in range(W)]
             total = sum(recv_n)
