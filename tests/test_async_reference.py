@@ -136,3 +136,25 @@ def test_one_rumour_spreads_at_the_same_pace(oracle):
     assert None not in a
     assert 0.4 <= st.median(a) <= st.median(lock) <= st.median(a) + 1.5 * GOSSIP_ROUND, (st.median(a), st.median(lock))
     assert max(lock) <= 2.0 and max(a) <= 2.0
+
+
+# ---- the same failure at 1 024 nodes: the logarithmic scaling laws -----------------------------------------------------------------
+def test_detection_at_1024_nodes_scales_alike(oracle):
+    """ceil(log10(N+1)) and max(1, log10 N) enter the retransmit limit and the suspicion timeout: at 1 024 nodes the minimum timer is
+    4 x 3.010 s = 12.04 s (8.43 s at 128).  16 seeds each: the timer runs for exactly that in the async model and to the next tick
+    in the lock-step one; first Dead verdict and everybody-knows agree within half a second (measured with 40 seeds: medians
+    1.93 / 1.70 s first suspicion, 13.97 / 13.80 s first Dead, 14.61 / 14.70 s everybody knows)."""
+    a = [am.config1(s, n=1024, horizon=90.0) for s in range(1, 17)]
+    lock = []
+    for s in range(1, 17):
+        sim = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=1024, seed=s))
+        sim.step_ms(10000); sim.kill(0, [17]); sim.step_ms(80000)
+        c = sim.census(0, 17)
+        lock.append(tuple((x - 10000) / 1000.0 for x in (c.first_suspect_ms, c.first_dead_ms, c.all_dead_ms)))
+        sim.close()
+    assert all(None not in r for r in a)
+    assert all(abs((r[1] - r[0]) - 12.041) < 0.005 for r in a) and all(abs((r[1] - r[0]) - 12.1) < 1e-9 for r in lock)
+    for leg, tol in ((0, 0.8), (1, 0.8), (2, 0.8)):             # (the first suspicion waits for the victim's turn in somebody's probe order: noisy at 16 seeds)
+        assert abs(st.median(r[leg] for r in a) - st.median(r[leg] for r in lock)) <= tol, leg
+    # everybody knows within a few gossip rounds of the first verdict, in both
+    assert st.median(r[2] - r[1] for r in a) <= 1.2 and st.median(r[2] - r[1] for r in lock) <= 1.2
