@@ -262,6 +262,42 @@ class ShardedSim:
             by = [x + y for x, y in zip(by, b)]
         return pairs, by
 
+    # ---- queries: what one shard holds is routed to its owner, what every shard holds a part of is merged -------------------
+    def _owner(self, node: int) -> Sim:
+        per = self.sim.cfg.n_nodes // self.sim.cfg.n_shards
+        for s in self.sims:
+            if s.cfg.shard_rank == node // per:
+                return s
+        raise LookupError(f"node {node} lives on shard {node // per}, which is not in this process")
+
+    def view(self, replica: int, observer: int, subject: int):
+        return self._owner(observer).view(replica, observer, subject)
+
+    def members(self, replica: int, observer: int):
+        return self._owner(observer).members(replica, observer)
+
+    def node_info(self, replica: int, node: int):
+        return self._owner(node).node_info(replica, node)
+
+    def census(self, replica: int, subject: int):
+        """swim_census_get over the shards of this process: every shard counts its own observers (and stamps the first / all
+        times for them), so counts add up, a FIRST time is the earliest shard's, an ALL time the latest one's — and unset while any
+        shard that has observers is not there yet.  (n_current counts the observers that hold the highest incarnation THEIR SHARD
+        has seen of the subject: while a new incarnation has not reached every shard the sum runs ahead of an unsharded run's.)"""
+        from . import abi
+        parts = [s.census(replica, subject) for s in self.sims]
+        out = abi.Census()
+        out.n_observers = sum(p.n_observers for p in parts)
+        for j in range(4):
+            out.by_state[j] = sum(p.by_state[j] for p in parts)
+        out.n_current = sum(p.n_current for p in parts)
+        out.first_suspect_ms = min(p.first_suspect_ms for p in parts)
+        out.first_dead_ms = min(p.first_dead_ms for p in parts)
+        seeing = [p for p in parts if p.n_observers]
+        out.all_dead_ms = max((p.all_dead_ms for p in seeing), default=abi.NONE)
+        out.all_current_ms = max((p.all_current_ms for p in seeing), default=abi.NONE)
+        return out
+
     def close(self):
         if hasattr(self.exchange, "close"):
             self.exchange.close()

@@ -35,6 +35,34 @@ def test_in_process_shards_match_unsharded(oracle, n_shards):
     assert a["edges_remote"] > 0 and b["edges_remote"] == 0
 
 
+def test_queries_on_a_sharded_population_answer_like_the_unsharded_one(oracle):
+    """ShardedSim.census merges the shards' censuses (counts add up, first = earliest, all = latest and only when every shard is
+    there); view / members / node_info go to the shard that owns the observer."""
+    kw = dict(n_nodes=2048, seed=14, subject_cap=16, view_cap=64, queue_cap=16, inbox_cap=256)
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=4, **kw)) for i in range(4)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    fields = ("n_observers", "first_suspect_ms", "first_dead_ms", "all_dead_ms", "all_current_ms")
+    for t in (3000, 12000, 14000, 30000):                    # before anything, suspected, verdicts spreading, settled
+        for s in (sh, ref):
+            s.step_ms(t - (0 if t == 3000 else {12000: 3000, 14000: 12000, 30000: 14000}[t]))
+            if t == 3000:
+                s.kill(0, [700]); s.update(0, [1500])
+        for x in (700, 1500):
+            a, b = sh.census(0, x), ref.census(0, x)
+            assert list(a.by_state) == list(b.by_state) and all(getattr(a, f) == getattr(b, f) for f in fields), (t, x)
+    assert ref.census(0, 700).all_dead_ms != abi.NONE and ref.census(0, 1500).all_current_ms != abi.NONE
+    assert sh.census(0, 1500).n_current == ref.census(0, 1500).n_current == 2046      # (comparable once the new incarnation has reached every shard)
+    for o in (3, 600, 1100, 2047):                          # one observer per shard
+        va, vb = sh.view(0, o, 700), ref.view(0, o, 700)
+        assert (va.state, va.incarnation, va.state_change_ms) == (vb.state, vb.incarnation, vb.state_change_ms) and va.state == abi.STATE_DEAD
+        assert (sh.members(0, o) == ref.members(0, o)).all()
+        ia, ib = sh.node_info(0, o), ref.node_info(0, o)
+        assert (ia.incarnation, ia.awareness, ia.queue_len, ia.probe_target) == (ib.incarnation, ib.awareness, ib.queue_len, ib.probe_target)
+    one = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=1, n_shards=4, **kw))], LocalExchange())
+    with pytest.raises(LookupError):
+        one.view(0, 3, 700)                                 # shard 0 is in another process
+
+
 def test_tcp_classes_are_ground_truth_on_every_shard(oracle):
     """swim_set_tcp_class is replicated like a partition mask: a prober on one shard and its target on another compare their
     classes exactly as an unsharded run does (two datacenters under 25 % loss, TCP fallback on)."""
