@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--diagnose", type=int, default=3, help="replay this many mismatching cases tick by tick")
     ap.add_argument("--only", default="", help="comma separated case numbers")
     args = ap.parse_args()
-    ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
+    ora = abi.bind(C.CDLL(os.environ.get("SWIMSIM_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))   # (the ASan build: tools/oracle_asan.sh)
     if args.backend == "hip":
         from consul_amd import lib as L
         lib = L.load()

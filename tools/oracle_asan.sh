@@ -10,3 +10,7 @@ LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.s
   tests/test_views_fold.py tests/test_checkpoint.py tests/test_state_table.py tests/test_transport_bridge.py tests/test_coordinates.py tests/test_dist_cpu.py \
   tests/test_bench_handles.py -x -q -s -m "not gpu" -p no:cacheprovider 2>&1 | tee /tmp/oracle_asan.log | tail -3
 ! grep -qi "runtime error\|AddressSanitizer" /tmp/oracle_asan.log
+# ... and random configurations / stimulus schedules, sharded against unsharded, on the same instrumented build
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" SWIMSIM_ORACLE_SO=oracle/_build/libswim_oracle_asan.so \
+  python tools/fuzz_parity.py --backend oracle --cases ${FUZZ_CASES:-40} --seed ${FUZZ_SEED:-31337} 2>&1 | tee /tmp/oracle_asan_fuzz.log | tail -2
+! grep -qi "runtime error\|AddressSanitizer\|mismatch" /tmp/oracle_asan_fuzz.log
