@@ -487,6 +487,25 @@ def test_no_tcp_ping_across_datacenters(oracle):
         s.set_tcp_class(0, [256], 1)
 
 
+@pytest.mark.parametrize("piggyback", [True, False])
+def test_a_leave_reaches_a_100k_cluster_within_consuls_leave_propagate_delay(oracle, piggyback):
+    """A number the REFERENCE states about this path (internal/gossip/libserf/serf.go:29-35): LeavePropagateDelay = 3 s "was chosen
+    to be reasonably short, but to allow a leave to get to over 99.99 % of the cluster with 100k nodes" (serf's own convergence
+    simulator, LAN defaults: 200 ms gossip interval, fan-out 3).  102 400 nodes here: the leave is everywhere after 2.0-2.5 s —
+    over 99.99 % at 2.5 s and 100 % at 3 s, with or without broadcasts riding on pings and acks; at 1.5 s it is not (97-99.5 %),
+    so the delay is not generous either."""
+    flags = abi.F_DEFAULT if piggyback else abi.F_DEFAULT & ~abi.F_PIGGYBACK
+    s = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=102400, seed=2, subject_cap=4, flags=flags))
+    s.step_ms(2000); s.leave(0, [4242])
+    s.step_ms(1500); c = s.census(0, 4242)
+    assert 0.95 < c.by_state[abi.STATE_LEFT] / c.n_observers < 0.9999
+    s.step_ms(1000); c = s.census(0, 4242)
+    assert c.by_state[abi.STATE_LEFT] / c.n_observers > 0.9999
+    s.step_ms(500); c = s.census(0, 4242)
+    assert c.by_state[abi.STATE_LEFT] == c.n_observers == 102399 and c.by_state[abi.STATE_DEAD] == 0      # Left, not Failed
+    s.close()
+
+
 def test_golden_fixture_config1(oracle):
     """tests/golden/config1_kill17.json was generated by tools/make_golden.py from this oracle at the
     commit that introduced it; it guards the restatement against silent drift."""
