@@ -233,6 +233,18 @@ struct SwDev {
   // edge lists.  Records for nodes of this shard produced by gossip block b go to the block's
   // private segment seg[b*seg_cap ..] (no global atomic); everything else (timers, probes, slot
   // requests, other shards) is appended to out[shard] with wave-aggregated atomics.
+  // TILE BUCKETS (tb_on): instead of judging a rumour at the sender — one random 16-byte read of the receiver's view per
+  // rumour, 6 M of them per tick while 64 clusters are saturated — the gossip role hands every rumour for a node of this shard to the
+  // bucket of the receiver's 1 024-node tile (the tile one k_resolve workgroup owns): LDS histogram per block, one global atomic per
+  // (block, tile), contiguous runs.  k_resolve's workgroup reads its bucket coalesced, sorts it by receiver in LDS, judges every rumour
+  // against the receiver's pre-tick view (the same question the sender asked: reads that now fall into the tile's own window, in node
+  // order) and files what survives in the tile's inboxes.  The probe role's piggy-back orders take the same way.
+  // A record is an edge record whose meta word carries a class in bits 29-28 (node ids < 2^28).
+  uint4* tb;             // [tb_T][tb_cap]
+  uint32_t* tb_cnt;      // [tb_T] records waiting (k_begin's roles add, k_resolve consumes and zeroes)
+  uint32_t* tb_last;     // [tb_T] what k_resolve consumed in the most recent tick (swim_debug_edges; kept only while *dbg_on)
+  uint32_t tb_on, tb_T, tb_cap, tb_carry;   // tb_carry: the broadcasts carried by pings / acks take the buckets too (k_begin's carry role)
+  uint32_t* dbg_on;      // [1] swim_debug_edges was called: k_resolve voids the rumours its filter drops, in place
   uint4* seg;
   uint32_t* seg_cnt;     // [n_seg] consumed and zeroed by k_deliver
   uint32_t* seg_last;    // [n_seg] what k_deliver consumed in the most recent tick (swim_debug_edges)
@@ -288,7 +300,16 @@ struct BeginPlan {
   uint32_t nb_join;          // blocks doing the join push-pull of freshly started nodes (0 or 1)
   uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry, bit6 push-pull replies
 };
-#define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard */
+#define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard; a bucket record the receiver's filter dropped */
+#define SW_TB_TILE 1024u          /* lanes per tile bucket = SW_RTILE node blocks = what one k_resolve workgroup owns */
+#define SW_TB_BINS 132u           /* tiles the lanes of one replica can span (tile buckets need nloc <= 131 072) */
+#define TB_CLASS_MASK 0x30000000u /* class of a bucket record, bits 29-28 of the meta word: 0 = deliver as it is (orders, user events, a rumour about the receiver) */
+#define TB_GOSSIP 0x10000000u     /* ... judged at the receiver: a no-op counts as filtered, anything else as an edge */
+#define TB_CARRIED 0x20000000u    /* ... a broadcast carried by a ping / ack: judged at the receiver like TB_GOSSIP (swim_debug_edges reports it from its carry area) */
+#define TB_CARRIED_PLAIN 0x30000000u /* ... carried, delivered whatever the receiver holds (a user event, a rumour about the receiver): an edge when it arrives */
+#define TB_FROM_MASK 0x0FFFFFFFu
+#define SW_CARRY_GROUP 16u        /* carry areas (node blocks) one workgroup of the tile-bucket carry role files */
+#define SW_TB_CHUNK 1024u         /* records of a bucket k_resolve sorts at a time (16 KB of LDS) */
 
 #define SW_KEY(inc, st) (((uint32_t)(inc) << 2) | (uint32_t)(st))
 #define SW_KINC(k) ((k) >> 2)

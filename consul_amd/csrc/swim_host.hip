@@ -545,7 +545,6 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.pp_cap = (D.pp_cap + SW_PP_LISTS - 1) / SW_PP_LISTS * SW_PP_LISTS * 4;   // 64 sub-lists, 4x slack for imbalance
   DALLOC(s, D.pp_list, (size_t)2 * D.pp_cap); DALLOC(s, D.pp_cnt, 2 * SW_PP_LISTS * 16);
   if (D.M) { D.xs_cap = 2 * D.pp_cap + D.join_cap; DALLOC(s, D.xs_list, D.xs_cap); DALLOC(s, D.xs_cnt, 1); HIPCK(s, hipMemsetAsync(D.xs_cnt, 0, 4, s->stream)); }
-  s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1, cfg->mass_rows != 0);
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
@@ -564,6 +563,23 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   uint64_t e_cap = (uint64_t)D.n_seg * D.seg_cap;
   if (e_cap > 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
   DALLOC(s, D.seg, e_cap); DALLOC(s, D.seg_cnt, D.n_seg); DALLOC(s, D.seg_last, D.n_seg);
+  {   // tile buckets (swim_device.h): for handles without a dense pair store whose replicas span few tiles (a gossip block keeps a
+      // histogram over them in LDS and pays one global atomic per tile it sends to: 64 tiles at 65 536 nodes per cluster — at a million
+      // nodes per cluster nearly every record would pay its own).  SWIMSIM_TILEBUCKETS=0: the sender-side filter and k_deliver's scatter.
+    D.tb_T = (uint32_t)cdiv(NB, SW_RTILE);
+    const uint64_t per_tile = (uint64_t)SW_TB_TILE * D.k_gossip * per_pkt / std::max(1u, D.G);      // expected records of a tile when every queue is full
+    const uint64_t cap = 2 * per_tile + 3 * SW_TB_TILE;                                            // ... twice that, plus the orders (<= 2 per node)
+    const char* e = getenv("SWIMSIM_TILEBUCKETS");
+    D.tb_on = (!D.M && cdiv(D.nloc, SW_TB_TILE) + 2 <= SW_TB_BINS && cap * D.tb_T * sizeof(uint4) <= ((uint64_t)8 << 30) && cap < 0x7FFFFFFFull && D.N < (1u << 28)
+               && !(e && !atoi(e))) ? 1u : 0u;
+    D.tb_cap = D.tb_on ? (uint32_t)cap : 1;
+    const char* ec = getenv("SWIMSIM_TB_CARRY");      // (A/B: 0 = the carried broadcasts stay with k_deliver)
+    D.tb_carry = (D.tb_on && piggy && !(ec && !atoi(ec))) ? 1u : 0u;
+    if (D.tb_carry) { pl.nb_carry = (uint32_t)cdiv(NB, SW_CARRY_GROUP); pl.roles |= 0x20; }      // k_begin's carry role files them in the buckets
+    DALLOC(s, D.tb, D.tb_on ? (size_t)D.tb_T * D.tb_cap : 1); DALLOC(s, D.tb_cnt, D.tb_T); DALLOC(s, D.tb_last, D.tb_T); DALLOC(s, D.dbg_on, 1);
+    HIPCK(s, hipMemsetAsync(D.tb_cnt, 0, (size_t)D.tb_T * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.tb_last, 0, (size_t)D.tb_T * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.dbg_on, 0, 4, s->stream));
+  }
+  s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1, cfg->mass_rows != 0, D.tb_on != 0);
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
     // own shard: probe verdicts, fold census records, push-pull; other shards: their share of the gossip records, the
     // acks' piggy-back orders, carried broadcasts, fold census records, and push-pull — whose every exchange sends one
@@ -644,7 +660,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   }
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
-  s->structural = { (void*)s->d_D, (void*)D.out_tab, (void*)D.mb_tab, (void*)s->d_scratch, (void*)s->mailbox, (void*)s->in_buf };
+  s->structural = { (void*)s->d_D, (void*)D.out_tab, (void*)D.mb_tab, (void*)s->d_scratch, (void*)s->mailbox, (void*)s->in_buf, (void*)D.tb };   // (the tile buckets are empty between ticks)
   HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
   const uint32_t n_initial = cfg->n_initial ? cfg->n_initial : D.N;
   hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
@@ -732,9 +748,11 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   }
   if (D.bigsort_cap) {   // inboxes of thousands of messages (a state exchange during a mass event) are sorted by a workgroup each, in LDS
     uint32_t P = SW_BIGSORT_MIN; while (P < D.bigsort_cap) P <<= 1;
+    hipLaunchKernelGGL(k_inbox_sort_med, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
   }
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(D.M ? k_resolve<true> : k_resolve<false>, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
+  void (*const resolve_kernel)(const SwDev*) = D.M ? k_resolve<true, false> : D.tb_on ? k_resolve<false, true> : k_resolve<false, false>;
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
@@ -1399,6 +1417,29 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
   if (rc) return rc;
   size_t total = 0, w = 0;
   std::vector<swim_edge> tmp;
+  if (s->D.tb_on) {
+    // tile buckets: what the roles handed to the tiles' buckets in the finished tick, minus what the receivers' filter dropped — k_resolve
+    // voids those in place, but only once this call has switched the recording on (the first call reports the rumours of the tick
+    // before it unfiltered; callers that compare tick by tick call once before they start)
+    uint32_t on = 0;
+    if ((rc = d2h(s, &on, (const uint32_t*)s->D.dbg_on, 1))) return rc;
+    if (!on) { on = 1; HIPCK(s, hipMemcpy(s->D.dbg_on, &on, 4, hipMemcpyHostToDevice)); }
+    else {
+      std::vector<uint32_t> last(s->D.tb_T);
+      if ((rc = d2h(s, last.data(), (const uint32_t*)s->D.tb_last, s->D.tb_T))) return rc;
+      for (uint32_t tl = 0; tl < s->D.tb_T; tl++) {
+        const uint32_t n = std::min(last[tl], s->D.tb_cap);
+        if (!n) continue;
+        tmp.resize(n);
+        if ((rc = d2h(s, tmp.data(), (const swim_edge*)s->D.tb + (size_t)tl * s->D.tb_cap, n))) return rc;
+        for (uint32_t i = 0; i < n; i++) {
+          if (tmp[i].dst == SW_DST_VOID || tmp[i].subject == SWIM_SUBJECT_PIGGY || (tmp[i].meta & TB_CLASS_MASK) >= TB_CARRIED) continue;   // (carried broadcasts: from their areas, below)
+          if (w < cap) { out[w] = tmp[i]; out[w].meta &= ~TB_CLASS_MASK; w++; }
+          total++;
+        }
+      }
+    }
+  }
   std::vector<uint32_t> segn(s->D.n_seg);
   if ((rc = d2h(s, segn.data(), (const uint32_t*)s->D.seg_last, s->D.n_seg))) return rc;
   for (uint32_t b = 0; b < s->D.n_seg; b++) {

@@ -13,18 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel (mangled-name fragment) -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
-    "k_beginILi4ELb0ELb0ELb0E": (96, 16, 5),   # the bench's instantiation: fan-out <= 4, no serf events, one shard, no dense pair store
-    "k_beginILi4ELb0ELb0ELb1E": (96, 16, 5),   # ... with the dense pair store (config #4 / #5 legs)
-    "k_beginILi8ELb1ELb1ELb1E": (96, 128, 5),  # the heaviest one (fan-out 8, serf events, sharded, dense store)
+    "k_beginILi4ELb0ELb0ELb0ELb1E": (96, 32, 5),   # the bench's instantiation: fan-out <= 4, no serf events, one shard, no dense pair store, tile buckets
+    "k_beginILi4ELb0ELb0ELb0ELb0E": (96, 16, 5),   # ... with the sender-side filter and segments (clusters too large for tile buckets: config #3)
+    "k_beginILi4ELb0ELb0ELb1ELb0E": (96, 32, 5),   # ... with the dense pair store (config #4 / #5 legs)
+    "k_beginILi8ELb1ELb1ELb1ELb0E": (96, 128, 5),  # the heaviest one (fan-out 8, serf events, sharded, dense store)
     "9k_deliverILb0EE": (64, 0, 7),
-    "9k_resolveILb0EE": (128, 64, 4),          # the call frame of the in-place heapsort of big inboxes (cold path)
-    "9k_resolveILb1EE": (128, 64, 4),
+    "9k_resolveILb0ELb1EE": (128, 64, 4),      # tile buckets; the scratch is the call frame of the in-place heapsort of big inboxes (cold path)
+    "9k_resolveILb0ELb0EE": (128, 64, 4),
+    "9k_resolveILb1ELb0EE": (128, 64, 4),
     "8k_censusPK": (32, 0, 8),
     "8k_finishPK": (64, 0, 8),
     "7k_quietPK": (40, 0, 8),
     "14k_coord_updatePK": (128, 0, 4),
     "13k_expire_massPK": (64, 0, 8),
     "12k_inbox_sortPK": (48, 0, 8),           # big inboxes, a workgroup each, in LDS
+    "16k_inbox_sort_medPK": (48, 0, 8),       # inboxes of 12-127 messages, a wave each, in LDS
 }
 
 

@@ -46,6 +46,7 @@ def test_single_failure_lockstep_small(hip, oracle):
     for s in (a, b):
         s.step_ms(10000)
         s.kill(0, [17])
+    a.edges()        # (tile buckets: the first call switches the recording of what the receivers' filter drops on)
     for t in range(150):
         a.step(1); b.step(1)
         ea, eb = a.edges(), b.edges()
