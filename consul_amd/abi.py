@@ -21,6 +21,7 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
 (EVENT_MEMBER_JOIN, EVENT_MEMBER_LEAVE, EVENT_MEMBER_FAILED, EVENT_MEMBER_UPDATE,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
+INFO_TILE_BUCKETS, INFO_MAILBOX_KIND, INFO_DEVICE_BYTES = 0, 1, 2      # swim_info keys
 F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK, F_COORDINATES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK | F_TCP_FALLBACK
 SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
@@ -168,6 +169,7 @@ PROTOTYPES = {
     "swim_coordinate_distance": (C.c_double, [P(Coordinate), P(Coordinate)]),
     "swim_rtt_truth": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
     "swim_debug_edges": (C.c_int, [SimP, P(Edge), C.c_size_t, P(C.c_size_t)]),
+    "swim_info": (C.c_int, [SimP, u32, P(C.c_uint64)]),
     "swim_state_digest": (C.c_int, [SimP, P(u64)]),
     "swim_checkpoint_save": (C.c_int, [SimP, C.c_char_p]),
     "swim_checkpoint_load": (C.c_int, [SimP, C.c_char_p]),

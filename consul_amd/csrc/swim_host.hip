@@ -30,6 +30,11 @@ enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
 static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" };
 #define SW_GRAPH_TICKS 16
 
+#ifdef SW_NODE_LINE
+#define SW_HDR_STRIDE 4
+#else
+#define SW_HDR_STRIDE 1
+#endif
 struct swim_sim {
   swim_config cfg;
   swim_derived d;
@@ -433,8 +438,14 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (want_role_clk) { D.role_clk_ticks = 1024; DALLOC(s, D.role_clk, (size_t)D.role_clk_ticks * 16 * 64); }
   DALLOC(s, D.nw, NT);
   DALLOC(s, D.exc_ent, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
+#ifdef SW_NODE_LINE   // one 64-byte record per node {header, queue slot 0, view metadata, queue slot 1}; queue slots from 2 on slot-major (swim_kernels.hip)
+  DALLOC(s, D.hdr, NL * 4); D.vmeta = D.hdr + 2; DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
+  DALLOC(s, D.q, NL * (D.Q > 2 ? D.Q - 2 : 1)); DALLOC(s, D.inbox1, NL * 16);
+#else
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
-  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16); DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
+  DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16);
+#endif
+  DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB * D.EW); DALLOC(s, D.evseq, NL); }
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
@@ -443,7 +454,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.rc_period = d.reconnect_period_ticks;
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
-  DALLOC(s, D.vmeta, NL); DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
+#ifndef SW_NODE_LINE
+  DALLOC(s, D.vmeta, NL);
+#endif
+  DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
   D.M = cfg->mass_rows; D.nbl = cdiv(D.nloc, SW_BLOCK);
   if (D.M) {   // the dense pair store (swim_device.h): 12 bytes per (row, observer)
     const size_t RM = (size_t)D.R * D.M, pairs = RM * D.nloc;
@@ -570,9 +584,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     const uint64_t per_tile = (uint64_t)SW_TB_TILE * D.k_gossip * per_pkt / std::max(1u, D.G);      // expected records of a tile when every queue is full
     const uint64_t cap = 2 * per_tile + 3 * SW_TB_TILE;                                            // ... twice that, plus the orders (<= 2 per node)
     const char* e = getenv("SWIMSIM_TILEBUCKETS");
-    D.tb_on = (!D.M && cdiv(D.nloc, SW_TB_TILE) + 2 <= SW_TB_BINS && cap * D.tb_T * sizeof(uint4) <= ((uint64_t)8 << 30) && cap < 0x7FFFFFFFull && D.N < (1u << 28)
-               && !(e && !atoi(e))) ? 1u : 0u;
-    D.tb_cap = D.tb_on ? (uint32_t)cap : 1;
+    // OFF unless asked for (SWIMSIM_TILEBUCKETS=1): bit-identical (the GPU suite runs with it too) and measured — k_begin -10 us per launch
+    // without its 6 M random view reads per saturated tick, but the per-tile drain (sort + barriers: a chain per tile) costs k_deliver more
+    // than its scattered deliveries did: 0.441 ms per round against 0.418 (profiles/r04_ab_experiments.txt).
+    D.tb_on = (e && atoi(e) && !D.M && cdiv(D.nloc, SW_TB_TILE) + 2 <= SW_TB_BINS && cap * D.tb_T * sizeof(uint4) <= ((uint64_t)8 << 30) && cap < 0x7FFFFFFFull && D.N < (1u << 28)) ? 1u : 0u;
+    D.tb_cap = D.tb_on ? (uint32_t)cap : 1; if (!D.tb_on) D.tb_T = 1;
     const char* ec = getenv("SWIMSIM_TB_CARRY");      // (A/B: 0 = the carried broadcasts stay with k_deliver)
     D.tb_carry = (D.tb_on && piggy && !(ec && !atoi(ec))) ? 1u : 0u;
     if (D.tb_carry) { pl.nb_carry = (uint32_t)cdiv(NB, SW_CARRY_GROUP); pl.roles |= 0x20; }      // k_begin's carry role files them in the buckets
@@ -623,7 +639,12 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
       void* mb = nullptr; hipError_t e = hipErrorUnknown;
       if (!mode || !strcmp(mode, "fine")) e = hipExtMallocWithFlags(&mb, s->mailbox_bytes, hipDeviceMallocFinegrained);
       else if (!strcmp(mode, "uncached")) e = hipExtMallocWithFlags(&mb, s->mailbox_bytes, hipDeviceMallocUncached);
-      if (e != hipSuccess) { (void)hipGetLastError(); mb = nullptr; HIPCK(s, hipMalloc(&mb, s->mailbox_bytes)); s->mailbox_kind = "coarse"; }
+      if (e != hipSuccess) {
+        (void)hipGetLastError(); mb = nullptr;
+        // coarse-grained memory is only coherent across devices at kernel boundaries: never silently — only when asked for
+        if (!mode || strcmp(mode, "coarse")) { snprintf(s->err, sizeof s->err, "swim_create: no fine-grained memory for the exchange mailbox (SWIMSIM_MAILBOX=coarse to run without)"); swim_destroy(s); return SWIM_ENOMEM; }
+        HIPCK(s, hipMalloc(&mb, s->mailbox_bytes)); s->mailbox_kind = "coarse";
+      }
       else s->mailbox_kind = (mode && !strcmp(mode, "uncached")) ? "uncached" : "fine";
       s->allocs.push_back(mb); s->alloc_bytes.push_back(s->mailbox_bytes); s->mailbox = (uint8_t*)mb;
     }
@@ -651,7 +672,11 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.cap_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
   HIPCK(s, hipMemsetAsync(D.err, 0, 4, st));
+#ifdef SW_NODE_LINE
+  HIPCK(s, hipMemsetAsync(D.hdr, 0, NL * 4 * sizeof(uint4), st)); HIPCK(s, hipMemsetAsync(D.q, 0, NL * (D.Q > 2 ? D.Q - 2 : 1) * sizeof(uint4), st));
+#else
   HIPCK(s, hipMemsetAsync(D.q, 0, NL * D.Q * sizeof(uint4), st));
+#endif
   HIPCK(s, hipMemsetAsync(D.vt, 0xFF, NL * D.VT * sizeof(uint4), st));      // every slot free (subject = VT_EMPTY)
   HIPCK(s, hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st)); HIPCK(s, hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st));
   if (serf) {
@@ -735,7 +760,11 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
   SwDev& D = s->D; hipStream_t st = s->stream;
   const size_t NL = (size_t)D.nloc * D.R;
-  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(D.M ? k_deliver<true> : k_deliver<false>, dim3(D.n_seg + 32), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
+  {
+    void (*const deliver_kernel)(const SwDev*) = D.M ? k_deliver<true, false> : D.tb_on ? k_deliver<false, true> : k_deliver<false, false>;
+    const uint32_t dgrid = (D.tb_on ? D.tb_T + (D.tb_carry ? 0u : D.n_seg) : D.n_seg) + 32;
+    ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(deliver_kernel, dim3(dgrid), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
   if (s->in_count) {
     ProfScope p(s, PK_DELIVER);
     hipLaunchKernelGGL(k_deliver_list, dim3(std::min<uint32_t>(cdiv(s->in_count, SW_BLOCK * 4), 2048)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D,
@@ -751,7 +780,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_inbox_sort_med, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
   }
-  void (*const resolve_kernel)(const SwDev*) = D.M ? k_resolve<true, false> : D.tb_on ? k_resolve<false, true> : k_resolve<false, false>;
+  void (*const resolve_kernel)(const SwDev*) = D.M ? k_resolve<true> : k_resolve<false>;
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
@@ -1217,7 +1246,7 @@ extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* ou
   std::vector<uint32_t> bk(n ? n : 1);
   int rc = n ? d2h(s, bk.data(), (const uint32_t*)D.bk + (size_t)r * D.N, n) : SWIM_OK;
   if (rc) return rc;
-  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)) * SW_HDR_STRIDE, 1))) return rc;
   // implicit views (a Failed / Left member of the base row was erased by every observer's reaper before it got there)
   for (size_t x = 0; x < n; x++) fill_member(&out[x], (uint32_t)x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk[x], 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
@@ -1233,7 +1262,7 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
   uint32_t bk = 0; int rc = d2h(s, &bk, (const uint32_t*)D.bk + (size_t)r * D.N + x, 1);
   if (rc) return rc;
-  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + (size_t)r * D.nloc + (o - D.i0), 1))) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)) * SW_HDR_STRIDE, 1))) return rc;
   fill_member(out, x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk, 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
   if ((rc = gather_views(s, r, o, ex))) return rc;
@@ -1410,6 +1439,15 @@ extern "C" int swim_rtt_truth(swim_sim* s, uint32_t replica, uint32_t a, uint32_
   *rtt_us = (uint32_t)std::sqrt(sum) + h;
   return SWIM_OK;
 }
+extern "C" int swim_info(swim_sim* s, uint32_t what, uint64_t* out) {
+  if (!s || !out) return SWIM_EINVAL;
+  switch (what) {
+    case SWIM_INFO_TILE_BUCKETS: *out = s->D.tb_on; return SWIM_OK;
+    case SWIM_INFO_MAILBOX_KIND: *out = !strcmp(s->mailbox_kind, "fine") ? 1u : !strcmp(s->mailbox_kind, "uncached") ? 2u : !strcmp(s->mailbox_kind, "coarse") ? 3u : 0u; return SWIM_OK;
+    case SWIM_INFO_DEVICE_BYTES: { uint64_t b = 0; for (size_t n : s->alloc_bytes) b += n; *out = b; return SWIM_OK; }
+    default: return SWIM_EINVAL;
+  }
+}
 extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
   if (s->in_tick) return SWIM_ESTATE;
@@ -1469,7 +1507,7 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
     if (n && (rc = d2h(s, tmp.data(), (const swim_edge*)s->D.out[sh], n))) return rc;
     for (uint32_t i = 0; i < n; i++) {
       if (tmp[i].dst == SWIM_NONE || tmp[i].subject == SWIM_SUBJECT_PIGGY) continue;
-      if (w < cap) out[w++] = tmp[i];
+      if (w < cap) { out[w] = tmp[i]; if (tmp[i].subject != SWIM_SUBJECT_PULL) out[w].meta &= ~SW_EDGE_JUDGE; w++; }
       total++;
     }
   }

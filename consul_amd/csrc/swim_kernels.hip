@@ -64,6 +64,21 @@ __device__ __forceinline__ uint32_t sel4v(uint32_t a0, uint32_t a1, uint32_t a2,
 __device__ __forceinline__ uint64_t seed_of(DevRef D, uint32_t r) { return D.seed + r; }
 __device__ __forceinline__ uint32_t now_ms(DevRef D, uint32_t t) { return t * D.quantum_ms; }
 
+
+// ---- where a node's header, view metadata and the first two slots of its memberlist queue live -------------------------------------
+// SW_NODE_LINE: one 64-byte record per node, {header, queue slot 0, view metadata, queue slot 1} — a receiver of k_resolve touches ONE line
+// for what were three gathers in three arrays (and the gossip role reads header + slot 0 from one line); queue slots from 2 on stay
+// slot-major.  D.hdr is the base of the records, D.vmeta = D.hdr + 2 (swim_host.hip).  Otherwise: three arrays, as before.
+#ifdef SW_NODE_LINE
+#define HDR(l) D.hdr[(size_t)(l) * 4]
+#define VMETA(l) D.vmeta[(size_t)(l) * 4]
+#define QENT(j, l) (*((j) < 2u ? &D.hdr[(size_t)(l) * 4 + 1 + 2 * (j)] : &D.q[(size_t)((j) - 2u) * NL + (l)]))
+#else
+#define HDR(l) D.hdr[l]
+#define VMETA(l) D.vmeta[l]
+#define QENT(j, l) D.q[(size_t)(j) * NL + (l)]
+#endif
+
 // ---- an observer's explicit views (layout: swim_device.h) ------------------------------------------
 __device__ __forceinline__ uint32_t vt_home(DevRef D, uint32_t x) { return (x * 0x9E3779B1u) >> D.vt_shift; }
 __device__ __forceinline__ uint32_t vw_nconf(uint32_t w) { return w & 7u; }
@@ -441,7 +456,7 @@ __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
     const size_t l = (size_t)nbk * SW_BLOCK + part * 64 + lane;
     if (l >= NL) continue;
     const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
-    const uint4 vm = D.vmeta[l];
+    const uint4 vm = VMETA(l);
     uint32_t d = vm.z;
     if (d == NONE) continue;
     if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;              // its timers rest; a revive lowers dl_blk again
@@ -459,7 +474,7 @@ __device__ __forceinline__ void role_expire(DevRef D, uint32_t b, uint32_t nb) {
         }
         next = dl < next ? dl : next;   // a fired timer keeps the bound low until its verdict is merged
       }
-      d = next; D.vmeta[l].z = d;
+      d = next; VMETA(l).z = d;
     }
     m = d < m ? d : m;
   }
@@ -820,7 +835,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
   uint32_t wi = NW_DEAD;
   if (i != NONE) {                                  // trip 1: node word and header together
     l = (size_t)r * D.nloc + (i - D.i0);
-    wi = nw[i]; h = D.hdr[l];
+    wi = nw[i]; h = HDR(l);
   }
 
   if (!(wi & NW_INERT)) {
@@ -831,12 +846,12 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       active = true;
       size_t NL = (size_t)D.R * D.nloc;
       // trip 2: the queue entries and the first four peer candidates' node words, all independent
-      uint4 e0 = qlen > 0 ? D.q[l] : make_uint4(0, 0, 0, 0), e1 = qlen > 1 ? D.q[NL + l] : make_uint4(0, 0, 0, 0);
+      uint4 e0 = qlen > 0 ? QENT(0u, l) : make_uint4(0, 0, 0, 0), e1 = qlen > 1 ? QENT(1u, l) : make_uint4(0, 0, 0, 0);
       uint32_t found;
       found = k_random_nodes<MASS>(D, r, i, k, t, SW_STREAM_GOSSIP, D.k_gossip < (uint32_t)KMAX ? D.k_gossip : (uint32_t)KMAX, 0, NONE, peers, pw, X);
       if (qlen > 0) sq[0] = e0;
       if (qlen > 1) sq[SW_BLOCK] = e1;
-      for (uint32_t j = 2; j < qlen; j++) sq[j * SW_BLOCK] = D.q[(size_t)j * NL + l];
+      for (uint32_t j = 2; j < qlen; j++) sq[j * SW_BLOCK] = QENT(j, l);
       if (serf) for (uint32_t j = 0; j < evqlen; j++) se[j * SW_BLOCK] = D.evq[(size_t)j * NL + l];
       // trip 3: where the subjects of the first two rumours keep their view columns
       uint32_t ws0 = (!TB && filter && qlen > 0) ? (X.usable() ? X.word(e0.x) : nw[e0.x]) : 0, ws1 = (!TB && filter && qlen > 1) ? (X.usable() ? X.word(e1.x) : nw[e1.x]) : 0;
@@ -958,8 +973,7 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
       if (c) {
         b = atomicAdd(&D.out_cnt[threadIdx.x], c);
         if (b + c > D.out_cap_tab[threadIdx.x]) { atomicOr(D.err, SW_ERR_EDGE_OVF); b = NONE; }
-        atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c);
-        atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);
+        atomicAdd(stat_ptr(D, ST_EDGES_REMOTE), (unsigned long long)c);      // (edges: counted below — or by the receiving shard, SW_EDGE_JUDGE)
       }
       s_base[threadIdx.x] = b;
     }
@@ -974,7 +988,8 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
     }
     __syncthreads();
   }
-  uint32_t c_e0 = 0;                                 // TB: records that are edges whatever the receiver holds (counted here, like a segment's)
+  uint32_t c_e0 = 0;                                 // TB: records that are edges whatever the receiver holds (counted here, like a segment's);
+                                                     // MULTI: the same of the records for other shards (the rest is judged and counted where it arrives)
   for (uint32_t p = 0; p < np; p++) {
     uint4* dst; bool bucket = false;
     if (PKT_SH(p) == D.rank) {
@@ -989,17 +1004,21 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
         const uint32_t cls = (filter && e.x != peers[p]) ? TB_GOSSIP : 0u;
         c_e0 += cls == 0;
         *dst++ = make_uint4(gdst, e.x, e.y, (m_type(e.w) << 30) | cls | (e.z & TB_FROM_MASK));
+      } else if (MULTI && PKT_SH(p) != D.rank) {     // another shard's node: its shard judges (a rumour about the receiver itself is always delivered)
+        const uint32_t jd = (filter && e.x != peers[p]) ? SW_EDGE_JUDGE : 0u;
+        c_e0 += jd == 0;
+        *dst++ = make_uint4(gdst, e.x, e.y, (m_type(e.w) << 30) | jd | (e.z & TB_FROM_MASK));
       } else
       *dst++ = make_uint4(gdst, e.x, e.y, (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu));
     }
     if (SERF)
       for (uint32_t m = sent_e[p]; m; m &= m - 1) {
         uint4 e = se[(__ffs(m) - 1) * SW_BLOCK];
-        c_e0 += TB && bucket;
+        c_e0 += (TB && bucket) || (MULTI && PKT_SH(p) != D.rank);
         *dst++ = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
       }
   }
-  if (TB) S.wave_add(ST_EDGES, c_e0);
+  if (TB || MULTI) S.wave_add(ST_EDGES, c_e0);
 #undef PKT_SH
 #undef PKT_N
 #undef PKT_BIN
@@ -1007,10 +1026,10 @@ __device__ __forceinline__ void role_gossip(DevRef D, uint32_t r, uint32_t bx, u
   // ---- write the queues back, compacted; untouched entries are not rewritten
   if (active) {
     size_t NL = (size_t)D.R * D.nloc;
-    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { D.q[(size_t)nq * NL + l] = sq[j * SW_BLOCK]; nq++; }
+    for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) { QENT(nq, l) = sq[j * SW_BLOCK]; nq++; }
     if (SERF) for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) { D.evq[(size_t)ne * NL + l] = se[j * SW_BLOCK]; ne++; }
     uint32_t hy = h_pack(h_leaving(h.y), nq, ne);
-    if (hy != h.y) { h.y = hy; D.hdr[l] = h; }
+    if (hy != h.y) { h.y = hy; HDR(l) = h; }
   }
   {
     const bool drained = active && !(nq | ne);
@@ -1045,7 +1064,7 @@ __device__ __forceinline__ void send_state_tail(DevRef D, bool on, uint32_t r, u
   {
     bool want = false; uint4 rec = make_uint4(0, 0, 0, 0);
     if (on && !saw_self) {
-      const uint32_t self = SW_KEY(D.hdr[(size_t)r * D.nloc + (owner - D.i0)].x, SWIM_STATE_ALIVE);
+      const uint32_t self = SW_KEY(HDR((size_t)r * D.nloc + (owner - D.i0)).x, SWIM_STATE_ALIVE);
       if (self != base_key_of(D, r, owner, D.nw[(size_t)r * D.N + owner])) { rec = mk_edge(D, r, dst, owner, SW_KINC(self), SWIM_MSG_ALIVE, 0); want = true; }
     }
     wave_append_sharded<MULTI>(D, want, sh, rec);
@@ -1073,7 +1092,7 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
   // what the base row says merges to nothing: only the owner's explicit views travel.  The lanes of the wave walk
   // their tables slot by slot together (wave_append_* is a wave-wide operation).
   const size_t NL = (size_t)D.R * D.nloc, lo = (size_t)r * D.nloc + (owner - D.i0);
-  uint32_t left = on ? D.vmeta[lo].x : 0;
+  uint32_t left = on ? VMETA(lo).x : 0;
   bool saw_dst = false;
   const uint32_t sh = on ? dst / D.nloc : 0;
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) && sh == D.rank;
@@ -1095,10 +1114,11 @@ __device__ void send_state(DevRef D, bool on, uint32_t r, uint32_t owner, uint32
           if (noop_at_receiver<MASS>(D, r, (size_t)r * D.nloc + (dst - D.i0), D.nw[(size_t)r * D.N + x], make_uint4(x, SW_KINC(a.y), from, type << 30), false, a)) { want = false; c_filt++; }
         }
         rec = mk_edge(D, r, dst, x, SW_KINC(a.y), type, from);
+        if (MULTI && sh != D.rank && (D.flags & SWIM_F_FILTER_NOOP) && x != dst) rec.w |= SW_EDGE_JUDGE;     // the receiver's shard judges
       }
     }
     wave_append_sharded<MULTI>(D, want, sh, rec);
-    c_edges += want; c_remote += want && sh != D.rank;
+    c_edges += want && !(rec.w & SW_EDGE_JUDGE); c_remote += want && sh != D.rank;
   }
   // ...and the owner's pairs of the dense store: a walk over up to mass_rows rows per exchange.  Inside this launch a wave would
   // take its (up to 64) exchanges one after the other — the due nodes of a state-exchange tick sit in consecutive lanes, and at
@@ -1212,18 +1232,21 @@ __device__ __forceinline__ void role_carry(DevRef D, uint32_t b, uint32_t nb, ui
   if (*D.carry_stamp != *D.tick) return;            // nothing was piggy-backed last tick
   BlockStats S; S.init(lds_stats);
   const uint32_t par = *D.tick & 1u;
-  uint32_t c_rem = 0;
+  uint32_t c_rem = 0, c_rem0 = 0;                    // records that left for other shards; those of them that are edges whatever the receiver holds
   for (uint32_t a = b; a < D.NB; a += nb) {
     uint32_t n = D.carry_cl[a].x; if (n > D.carry_cap) n = D.carry_cap;
     uint4* area = D.carry + ((size_t)par * D.NB + a) * D.carry_cap;
     for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
       uint32_t e = e0 + threadIdx.x; bool rem = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t sh = 0;
-      if (e < n) { rec = area[e]; sh = (rec.x % D.N) / D.nloc; rem = sh != D.rank; }
+      if (e < n) {
+        rec = area[e]; sh = (rec.x % D.N) / D.nloc; rem = sh != D.rank;
+        if (rem && (D.flags & SWIM_F_FILTER_NOOP) && (rec.w >> 30) != SWIM_MSG_USER && rec.y != rec.x % D.N) rec.w |= SW_EDGE_JUDGE;   // what deliver_carried would judge here
+      }
       wave_append_sharded(D, rem, sh, rec);
-      if (rem) { area[e].x = SW_DST_VOID; c_rem++; }
+      if (rem) { area[e].x = SW_DST_VOID; c_rem++; c_rem0 += !(rec.w & SW_EDGE_JUDGE); }
     }
   }
-  S.wave_add(ST_EDGES, c_rem); S.wave_add(ST_EDGES_REMOTE, c_rem);
+  S.wave_add(ST_EDGES, c_rem0); S.wave_add(ST_EDGES_REMOTE, c_rem);
   S.flush(D);
 }
 
@@ -1243,14 +1266,20 @@ __device__ __forceinline__ void role_carry_tb(DevRef D, uint32_t b, uint32_t* ld
   const uint32_t tl0 = (uint32_t)(((size_t)div_nloc(D, (size_t)a0 * SW_BLOCK) * D.nloc) / SW_TB_TILE);   // first tile of the replica the group starts in
   if (threadIdx.x < SW_TB_BINS) s_tb[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t c_rem = 0;
+  uint32_t c_rem = 0, c_rem0 = 0;
   for (uint32_t a = a0; a < a1; a++) {              // pass 1: count per tile; what leaves the shard leaves now
     uint32_t n = D.carry_cl[a].x; if (n > D.carry_cap) { if (threadIdx.x == 0) atomicOr(D.err, SW_ERR_CARRY_OVF); n = D.carry_cap; }
     uint4* area = D.carry + ((size_t)par * D.NB + a) * D.carry_cap;
     for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
       const uint32_t e = e0 + threadIdx.x; bool rem = false; uint4 rec = make_uint4(0, 0, 0, 0); uint32_t sh = 0;
-      if (e < n) { rec = area[e]; if (MULTI) { sh = mod_n(D, rec.x) / D.nloc; rem = sh != D.rank; } }
-      if (MULTI) { wave_append_sharded(D, rem, sh, rec); if (rem) { area[e].x = SW_DST_VOID; c_rem++; } }
+      if (e < n) {
+        rec = area[e];
+        if (MULTI) {
+          sh = mod_n(D, rec.x) / D.nloc; rem = sh != D.rank;
+          if (rem && filter && (rec.w >> 30) != SWIM_MSG_USER && rec.y != mod_n(D, rec.x)) rec.w |= SW_EDGE_JUDGE;
+        }
+      }
+      if (MULTI) { wave_append_sharded(D, rem, sh, rec); if (rem) { area[e].x = SW_DST_VOID; c_rem++; c_rem0 += !(rec.w & SW_EDGE_JUDGE); } }
       if (e < n && !rem) {
         const uint32_t bin = (uint32_t)(((size_t)div_n(D, rec.x) * D.nloc + (mod_n(D, rec.x) - D.i0)) / SW_TB_TILE) - tl0;
         if (bin < SW_TB_BINS) atomicAdd(&s_tb[bin], 1u);
@@ -1290,7 +1319,7 @@ __device__ __forceinline__ void role_carry_tb(DevRef D, uint32_t b, uint32_t* ld
     const uint2 c = D.carry_cl[a0 + threadIdx.x];
     if (c.x | c.y) D.carry_cl[a0 + threadIdx.x] = make_uint2(0, c.x < D.carry_cap ? c.x : D.carry_cap);
   }
-  if (MULTI) { S.wave_add(ST_EDGES, c_rem); S.wave_add(ST_EDGES_REMOTE, c_rem); }
+  if (MULTI) { S.wave_add(ST_EDGES, c_rem0); S.wave_add(ST_EDGES_REMOTE, c_rem); }
   S.flush(D);
 }
 
@@ -1606,15 +1635,36 @@ __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint3
 // (round 4: the same written in explicit phases over the four records — unpredicated clamped loads, all node words, all atomics, all
 // stores, which is what the ISA of this loop does not do (profiles/r03_isa_notes.txt item 2) — measured 45.3 us per launch against 42.9:
 // the kernel is bound by the rate of its scattered requests, not by their serialisation within a lane; profiles/r04_ab_experiments.txt)
+// JUDGE: the list came from other shards (mailbox, swim_inbound) — a rumour marked SW_EDGE_JUDGE is first put to the no-op filter here
+template <bool JUDGE = false>
 __device__ __forceinline__ void deliver_span(DevRef D, const uint4* edges, uint32_t n, uint32_t first, uint32_t stride, const ExcList* X = nullptr) {
+  uint32_t c_filt = 0, c_edges = 0;
   for (uint32_t e = first; e < n; e += 4 * stride) {
-    uint4 rec[4]; size_t l[4]; uint32_t pos[4];
+    uint4 rec[4]; size_t l[4]; uint32_t pos[4]; bool on[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (e + j * stride < n) rec[j] = edges[e + j * stride];
+    for (int j = 0; j < 4; j++) { on[j] = e + j * stride < n; if (on[j]) rec[j] = edges[e + j * stride]; }
+    if (JUDGE) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) pos[j] = e + j * stride < n ? inbox_reserve(D, rec[j], l[j], X) : NONE;
+      for (int j = 0; j < 4; j++) {
+        if (!on[j] || rec[j].x == NONE || !(rec[j].w & SW_EDGE_JUDGE) || rec[j].y == SWIM_SUBJECT_PIGGY || rec[j].y == SWIM_SUBJECT_PULL) continue;
+        rec[j].w &= ~SW_EDGE_JUDGE;
+        const uint32_t r = div_n(D, rec[j].x), x = mod_n(D, rec[j].x), type = rec[j].w >> 30;
+        if (x >= D.i0 && x < D.i0 + D.nloc &&
+            noop_at_receiver<true>(D, r, (size_t)r * D.nloc + (x - D.i0), D.nw[(size_t)r * D.N + rec[j].y], make_uint4(rec[j].y, rec[j].z, rec[j].w & 0x3FFFFFFFu, type << 30), false, rec[j])) { c_filt++; on[j] = false; }
+        else c_edges++;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) pos[j] = on[j] ? inbox_reserve(D, rec[j], l[j], X) : NONE;
 #pragma unroll
     for (int j = 0; j < 4; j++) inbox_place(D, rec[j], l[j], pos[j]);
+  }
+  if (JUDGE && __any((c_edges | c_filt) != 0)) {
+    for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_filt += __shfl_down(c_filt, off); }
+    if (sw_lane() == 0) {
+      if (c_edges) atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c_edges);
+      if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
+    }
   }
 }
 // The broadcasts piggy-backed on last tick's pings and acks (picked by k_resolve, one private area per block)
@@ -1636,12 +1686,123 @@ __device__ void deliver_carried(DevRef D, const uint4* area, uint32_t n, uint32_
     inbox_place(D, rec, l, pos);
   }
 }
-// grid = n_seg blocks + extra blocks over the shard's misc list.  Block b drains segment b and the carry areas
-// b, b + n_seg, ... (their counts are fetched together with the segment's: no extra trip in a quiet tick)
+// ---- tile buckets (swim_device.h): one workgroup of k_deliver per tile drains the tile's bucket ------------------------------------
+// SW_TB_CHUNK records at a time: (1) the records into LDS (one coalesced read) and a histogram over the tile's 1 024 nodes, (2) its
+// exclusive prefix, (3) an index sorted by receiver, (4) every record judged IN RECEIVER ORDER — the view reads of a wave fall into a few
+// consecutive lines of the tile's own window instead of 64 lines anywhere in the cluster's — and what is not a no-op filed in the
+// receiver's inbox (count words and message lines of the tile: this workgroup's alone in this launch, and still in this XCD's L2 when
+// k_resolve's workgroup for the tile — same workgroup index, same XCD — reads them).  The question asked is the sender's
+// (noop_at_receiver against the pre-tick view: nothing has been merged yet), so the same rumours are dropped, delivered and counted
+// as when the gossip role asked it.  Four records per lane are in flight together (their subjects' node words, then the receivers'
+// home slots): the chain of a chunk is as long as one record's.
 template <bool MASS>
+__device__ __forceinline__ void deliver_bucket(DevRef D, uint32_t tile, uint32_t n_tb, uint4* raw, uint16_t* ord, uint32_t* bins, uint32_t* s_wt, bool dbg) {
+  uint4* const bk = D.tb + (size_t)tile * D.tb_cap;
+  const size_t l0 = (size_t)tile * SW_TB_TILE, NL = (size_t)D.R * D.nloc;
+  uint32_t c_filt = 0, c_edges = 0;
+  for (uint32_t c0 = 0; c0 < n_tb; c0 += SW_TB_CHUNK) {
+    const uint32_t nc = n_tb - c0 < SW_TB_CHUNK ? n_tb - c0 : SW_TB_CHUNK;
+    for (uint32_t i = threadIdx.x; i < SW_TB_TILE; i += SW_BLOCK) bins[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < SW_TB_CHUNK / SW_BLOCK; j++) {
+      const uint32_t e = threadIdx.x + j * SW_BLOCK;
+      if (e < nc) {
+        const uint4 rec = ld_global_u4(bk + c0 + e);
+        raw[e] = rec;
+        const size_t l = (size_t)div_n(D, rec.x) * D.nloc + (mod_n(D, rec.x) - D.i0);
+        atomicAdd(&bins[(uint32_t)(l - l0) & (SW_TB_TILE - 1u)], 1u);
+      }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 1 024 bins: four per thread, a wave scan of the sums, the four waves' totals
+      const uint32_t a0 = bins[4 * threadIdx.x], a1 = bins[4 * threadIdx.x + 1], a2 = bins[4 * threadIdx.x + 2], a3 = bins[4 * threadIdx.x + 3], sum = a0 + a1 + a2 + a3;
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
+      if (sw_lane() == 63) s_wt[threadIdx.x / 64] = incl;
+      __syncthreads();
+      uint32_t base = 0;
+      for (uint32_t w = 0; w < threadIdx.x / 64; w++) base += s_wt[w];
+      const uint32_t ex = base + incl - sum;
+      bins[4 * threadIdx.x] = ex; bins[4 * threadIdx.x + 1] = ex + a0; bins[4 * threadIdx.x + 2] = ex + a0 + a1; bins[4 * threadIdx.x + 3] = ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < SW_TB_CHUNK / SW_BLOCK; j++) {
+      const uint32_t e = threadIdx.x + j * SW_BLOCK;
+      if (e < nc) {
+        const uint32_t gx = raw[e].x;
+        const size_t l = (size_t)div_n(D, gx) * D.nloc + (mod_n(D, gx) - D.i0);
+        ord[atomicAdd(&bins[(uint32_t)(l - l0) & (SW_TB_TILE - 1u)], 1u)] = (uint16_t)e;
+      }
+    }
+    __syncthreads();
+    {
+      constexpr uint32_t K = SW_TB_CHUNK / SW_BLOCK;
+      uint4 rec[K], first[K]; uint32_t e[K], cls[K], ws[K], r[K]; size_t lr[K]; bool on[K], ask[K];
+#pragma unroll
+      for (uint32_t j = 0; j < K; j++) {
+        const uint32_t i = threadIdx.x + j * SW_BLOCK;
+        on[j] = i < nc; e[j] = on[j] ? ord[i] : 0u; rec[j] = raw[e[j]];
+        cls[j] = rec[j].w & TB_CLASS_MASK; rec[j].w &= ~TB_CLASS_MASK;
+        ask[j] = on[j] && (cls[j] == TB_GOSSIP || cls[j] == TB_CARRIED);           // the receiver's view decides
+        r[j] = div_n(D, rec[j].x); lr[j] = (size_t)r[j] * D.nloc + (mod_n(D, rec[j].x) - D.i0);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < K; j++) ws[j] = ask[j] ? D.nw[(size_t)r[j] * D.N + rec[j].y] : 0u;      // the subjects' node words (mostly one word for the whole wave)
+#pragma unroll
+      for (uint32_t j = 0; j < K; j++)                                                                 // the receivers' home slots for the subjects
+        first[j] = (ask[j] && !(MASS && (ws[j] & NW_MASS)) && (ws[j] & NW_SUBJECT)) ? D.vt[(size_t)vt_home(D, rec[j].y) * NL + lr[j]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t j = 0; j < K; j++) {
+        if (!on[j]) continue;
+        if (ask[j]) {
+          const uint32_t type = rec[j].w >> 30;
+          if (noop_at_receiver<MASS>(D, r[j], lr[j], ws[j], make_uint4(rec[j].y, rec[j].z, rec[j].w & 0x3FFFFFFFu, type << 30), !(MASS && (ws[j] & NW_MASS)), first[j])) {
+            c_filt++;
+            if (dbg && cls[j] == TB_GOSSIP) ((uint32_t*)(bk + c0 + e[j]))[0] = SW_DST_VOID;      // swim_debug_edges reports the gossip role's rumours that were delivered
+            continue;
+          }
+          c_edges++;
+        } else if (cls[j] == TB_CARRIED_PLAIN) c_edges++;
+        size_t l; const uint32_t pos = inbox_reserve(D, rec[j], l);
+        inbox_place(D, rec[j], l, pos);
+      }
+    }
+    __syncthreads();                                 // (the next chunk reuses raw / ord / bins)
+  }
+  if (__any((c_edges | c_filt) != 0)) {
+    for (int off = 32; off; off >>= 1) { c_edges += __shfl_down(c_edges, off); c_filt += __shfl_down(c_filt, off); }
+    if (sw_lane() == 0) {
+      if (c_edges) atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c_edges);
+      if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
+    }
+  }
+}
+
+// grid = [tile buckets: one block per tile] + n_seg blocks + extra blocks over the shard's misc list.  Block b drains segment b and the carry areas
+// b, b + n_seg, ... (their counts are fetched together with the segment's: no extra trip in a quiet tick)
+template <bool MASS, bool TB>
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint32_t b = blockIdx.x;
+  if constexpr (TB) {
+    if (b < D.tb_T) {                              // the bucket of the tile k_resolve's workgroup of the same index will merge (same XCD)
+      __shared__ uint4 s_raw[SW_TB_CHUNK];
+      __shared__ uint16_t s_ord[SW_TB_CHUNK];
+      __shared__ uint32_t s_bins[SW_TB_TILE], s_wt[SW_BLOCK / 64];
+      const uint32_t tile = D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + b] : b;
+      uint32_t n_tb = D.tb_cnt[tile];
+      const bool dbg = *D.dbg_on != 0;
+      if (n_tb > D.tb_cap) n_tb = D.tb_cap;        // (the producer that overflowed it has raised SW_ERR_EDGE_OVF)
+      if (n_tb) deliver_bucket<MASS>(D, tile, n_tb, s_raw, s_ord, s_bins, s_wt, dbg);
+      if (threadIdx.x == 0) { if (n_tb) D.tb_cnt[tile] = 0; if (dbg) D.tb_last[tile] = n_tb; }
+      return;
+    }
+    b -= D.tb_T;
+    if (D.tb_carry) b += D.n_seg;                  // (no segments, and the carry areas went through the buckets: only the misc list is left)
+  }
 #ifdef SWIMSIM_WAVECLK
   const unsigned long long t_in = wall_clock64();
 #define DCLK(tag) BCLK_OUT(1, t_in, tag)
@@ -1700,7 +1861,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
     return;
   }
   b -= D.n_seg;
-  uint32_t nb = gridDim.x - D.n_seg, n = D.out_cnt[D.rank];
+  uint32_t nb = gridDim.x - (TB ? D.tb_T + (D.tb_carry ? 0u : D.n_seg) : D.n_seg), n = D.out_cnt[D.rank];
   if (n > D.out_cap_tab[D.rank]) n = D.out_cap_tab[D.rank];
   deliver_span(D, D.out_tab[D.rank], n, b * SW_BLOCK + threadIdx.x, nb * SW_BLOCK);
   DCLK(1u << 30);
@@ -1764,12 +1925,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver_mail(const SwDev* __restri
   SW_DEV_BIND
   const uint32_t src = blockIdx.y;
   if (src == D.rank) return;
-  deliver_span(D, mb_rec(D, D.mb_tab[D.rank], *D.tick & 1u, src), D.xin_cnt[src], blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
+  deliver_span<true>(D, mb_rec(D, D.mb_tab[D.rank], *D.tick & 1u, src), D.xin_cnt[src], blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 // records handed over by other shards (swim_inbound)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restrict__ Dp, const uint4* edges, uint32_t n) {
   SW_DEV_BIND
-  deliver_span(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
+  deliver_span<true>(D, edges, n, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 
 // swim_watch / inject_*: give subject x a watch slot (census, first-* stamps, trace).  Single-threaded (host-side
@@ -1838,35 +1999,35 @@ struct NodeCtxT {
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
   uint32_t dl_new = NONE;                             // earliest deadline this lane armed (the caller lowers dl_blk with it)
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
-  __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = D.vmeta[l]; vm_have = true; } }
+  __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = VMETA(l); vm_have = true; } }
   uint4 h0;
   uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * 256 + threadIdx.x]; entries to write back
 #define SQ(j) g_lds_dyn[(j) * SW_BLOCK + threadIdx.x]
   __device__ __forceinline__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
 
-  __device__ __forceinline__ void load() { load(D.hdr[l]); }
+  __device__ __forceinline__ void load() { load(HDR(l)); }
   __device__ __forceinline__ void load(uint4 h) {
     h0 = h;
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
   }
   // LQ: fetch the queue into the LDS column (independent loads, issued together)
   __device__ __forceinline__ void stage_queue() {
-    for (uint32_t j = 0; j < qlen; j++) SQ(j) = D.q[(size_t)j * NL + l];
+    for (uint32_t j = 0; j < qlen; j++) SQ(j) = QENT(j, l);
   }
-  __device__ __forceinline__ uint4 mq_get(uint32_t j) const { if constexpr (LQ) return SQ(j); else return D.q[(size_t)j * NL + l]; }
-  __device__ __forceinline__ uint32_t mq_x(uint32_t j) const { if constexpr (LQ) return SQ(j).x; else return D.q[(size_t)j * NL + l].x; }
-  __device__ __forceinline__ uint32_t mq_w(uint32_t j) const { if constexpr (LQ) return SQ(j).w; else return D.q[(size_t)j * NL + l].w; }
-  __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) { if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else D.q[(size_t)j * NL + l] = e; }
+  __device__ __forceinline__ uint4 mq_get(uint32_t j) const { if constexpr (LQ) return SQ(j); else return QENT(j, l); }
+  __device__ __forceinline__ uint32_t mq_x(uint32_t j) const { if constexpr (LQ) return SQ(j).x; else return QENT(j, l).x; }
+  __device__ __forceinline__ uint32_t mq_w(uint32_t j) const { if constexpr (LQ) return SQ(j).w; else return QENT(j, l).w; }
+  __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) { if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else QENT(j, l) = e; }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
   // did the node go from "nothing queued" to "something queued" (or back) since load()?
   __device__ __forceinline__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
   __device__ __forceinline__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
   __device__ __forceinline__ void store() {
     flush_view();
-    if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) { const uint32_t j = __ffs(m) - 1; D.q[(size_t)j * NL + l] = SQ(j); }
+    if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) { const uint32_t j = __ffs(m) - 1; QENT(j, l) = SQ(j); }
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
-    if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) D.hdr[l] = h;
-    if (vm_dirty) D.vmeta[l] = vm;
+    if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) HDR(l) = h;
+    if (vm_dirty) VMETA(l) = vm;
   }
 
   // QueueBroadcast: same-subject invalidation, Prune() on overflow.  EV = the serf user-event queue (always in HBM)
@@ -2376,72 +2537,6 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort_med(const SwDev* __rest
   }
 }
 
-// ---- tile buckets (swim_device.h): the workgroup that owns a tile drains the tile's bucket before it merges -------------------------
-// SW_TB_CHUNK records at a time: (1) the records into LDS (one coalesced read) and a histogram over the tile's 1 024 nodes, (2) its
-// exclusive prefix, (3) an index sorted by receiver, (4) every record judged IN RECEIVER ORDER — the view reads of a wave fall into a few
-// consecutive lines of the tile's own window instead of 64 lines anywhere in the cluster's — and what is not a no-op filed in the
-// receiver's inbox (the tile's own count words and message lines: nobody else touches them in this launch).  The question asked is the
-// sender's (noop_at_receiver against the pre-tick view: this workgroup has merged nothing yet, and no other workgroup writes these views),
-// so the same rumours are dropped, delivered and counted as when the gossip role asked it.
-// raw = 16 KB (the inbox-line columns of the merge, not in use yet), ord = 2 KB of the queue staging area, bins = the receiver list.
-template <bool MASS>
-__device__ __forceinline__ void resolve_bucket(DevRef D, BlockStats& S, uint32_t tile, uint32_t n_tb, size_t l0, uint4* raw, uint16_t* ord, uint32_t* bins, uint32_t* s_wt, bool dbg) {
-  uint4* const bk = D.tb + (size_t)tile * D.tb_cap;
-  uint32_t c_filt = 0, c_edges = 0;
-  for (uint32_t c0 = 0; c0 < n_tb; c0 += SW_TB_CHUNK) {
-    const uint32_t nc = n_tb - c0 < SW_TB_CHUNK ? n_tb - c0 : SW_TB_CHUNK;
-    for (uint32_t i = threadIdx.x; i < SW_TB_TILE; i += SW_BLOCK) bins[i] = 0;
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < nc; e += SW_BLOCK) {
-      const uint4 rec = ld_global_u4(bk + c0 + e);
-      raw[e] = rec;
-      const size_t l = (size_t)div_n(D, rec.x) * D.nloc + (mod_n(D, rec.x) - D.i0);
-      atomicAdd(&bins[(uint32_t)(l - l0) & (SW_TB_TILE - 1u)], 1u);
-    }
-    __syncthreads();
-    {   // exclusive prefix over the 1 024 bins: four per thread, a wave scan of the sums, the four waves' totals
-      const uint32_t a0 = bins[4 * threadIdx.x], a1 = bins[4 * threadIdx.x + 1], a2 = bins[4 * threadIdx.x + 2], a3 = bins[4 * threadIdx.x + 3], sum = a0 + a1 + a2 + a3;
-      uint32_t incl = sum;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (sw_lane() >= (uint32_t)off) incl += v; }
-      if (sw_lane() == 63) s_wt[threadIdx.x / 64] = incl;
-      __syncthreads();
-      uint32_t base = 0;
-      for (uint32_t w = 0; w < threadIdx.x / 64; w++) base += s_wt[w];
-      const uint32_t ex = base + incl - sum;
-      bins[4 * threadIdx.x] = ex; bins[4 * threadIdx.x + 1] = ex + a0; bins[4 * threadIdx.x + 2] = ex + a0 + a1; bins[4 * threadIdx.x + 3] = ex + a0 + a1 + a2;
-    }
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < nc; e += SW_BLOCK) {
-      const uint32_t gx = raw[e].x;
-      const size_t l = (size_t)div_n(D, gx) * D.nloc + (mod_n(D, gx) - D.i0);
-      ord[atomicAdd(&bins[(uint32_t)(l - l0) & (SW_TB_TILE - 1u)], 1u)] = (uint16_t)e;
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nc; i += SW_BLOCK) {
-      const uint32_t e = ord[i];
-      uint4 rec = raw[e];
-      const uint32_t cls = rec.w & TB_CLASS_MASK;
-      rec.w &= ~TB_CLASS_MASK;
-      if (cls == TB_CARRIED_PLAIN) c_edges++;
-      else if (cls) {                                // TB_GOSSIP / TB_CARRIED: the receiver's view decides
-        const uint32_t r = div_n(D, rec.x), x = mod_n(D, rec.x), type = rec.w >> 30;
-        const uint32_t ws = D.nw[(size_t)r * D.N + rec.y];
-        if (noop_at_receiver<MASS>(D, r, (size_t)r * D.nloc + (x - D.i0), ws, make_uint4(rec.y, rec.z, rec.w & 0x3FFFFFFFu, type << 30), false, rec)) {
-          c_filt++;
-          if (dbg && cls == TB_GOSSIP) ((uint32_t*)(bk + c0 + e))[0] = SW_DST_VOID;       // swim_debug_edges reports the gossip role's rumours that were delivered
-          continue;
-        }
-        c_edges++;
-      }
-      size_t l; const uint32_t pos = inbox_reserve(D, rec, l);
-      inbox_place(D, rec, l, pos);
-    }
-    __syncthreads();                                 // (the next chunk reuses raw / ord / bins)
-  }
-  S.wave_add(ST_FILTERED, c_filt); S.wave_add(ST_EDGES, c_edges);
-}
-
 // A tile of SW_RTILE node blocks per workgroup.  Who got something this tick is sparse (a fifth of the nodes while a
 // rumour saturates a cluster, far fewer otherwise) and a lane's work is a chain of dependent memory round trips: lanes
 // that map 1:1 to nodes leave most of every wave idle through the whole chain.  So the workgroup first compacts the
@@ -2477,7 +2572,8 @@ __device__ unsigned long long g_wclk[WCLK_ROWS][6];
 #ifndef SW_RESOLVE_WAVES
 #define SW_RESOLVE_WAVES 4
 #endif
-template <bool MASS, bool TB>
+#define SW_ORDER_MIN 16u          /* a tile with an inbox of this many messages has its receiver list ordered by size class */
+template <bool MASS>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
@@ -2492,34 +2588,23 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SWIMSIM_DIAG
   unsigned long long rclk_t = __builtin_amdgcn_s_memtime(); const unsigned long long rclk_t0 = rclk_t; uint32_t rclk_it = 0, rclk_acc[6] = { 0, 0, 0, 0, 0, 0 };
 #endif
-  uint32_t n_tb = TB ? D.tb_cnt[nb0 / SW_RTILE] : 0u;           // records in this tile's bucket
-  const bool dbg = TB && *D.dbg_on != 0;
   if (D.fast_blocks) {                     // nothing reached this tile: a few words and out
-    uint32_t any = n_tb;
+    uint32_t any = 0;
 #pragma unroll
     for (uint32_t sb = 0; sb < SW_RTILE; sb++) any |= nb0 + sb < D.NB ? D.in_any[nb0 + sb] : 0u;
-    if (!any) { if (dbg && threadIdx.x == 0) D.tb_last[nb0 / SW_RTILE] = 0; return; }
+    if (!any) return;
   }
   if (threadIdx.x < SW_RTILE) { s_carry[threadIdx.x] = 0; s_dl[threadIdx.x] = NONE; }
   if (threadIdx.x < SW_CEN_LDS * 5) g_s_cen[threadIdx.x] = 0;
   if (threadIdx.x == 0) g_s_cen_r = div_nloc(D, (size_t)nb0 * SW_BLOCK);
   BlockStats S; S.init(lds_stats);
   const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)nb0 * SW_BLOCK;
-  if constexpr (TB) {
-    if (n_tb > D.tb_cap) n_tb = D.tb_cap;          // (the producer that overflowed it has raised SW_ERR_EDGE_OVF)
-    if (n_tb) {
-      resolve_bucket<MASS>(D, S, nb0 / SW_RTILE, n_tb, l0, &s_in[0][0], (uint16_t*)g_lds_dyn, s_list, s_wcnt, dbg);
-      __threadfence_block();                       // the deliveries above are read below by other lanes of this workgroup
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { if (n_tb) D.tb_cnt[nb0 / SW_RTILE] = 0; if (dbg) D.tb_last[nb0 / SW_RTILE] = n_tb; }
-  }
   // ---- the tile's receivers, compacted in ascending node order
   uint32_t cnts[SW_RTILE];
 #pragma unroll
   for (uint32_t sb = 0; sb < SW_RTILE; sb++) {
     const size_t l = l0 + sb * SW_BLOCK + threadIdx.x;
-    cnts[sb] = (l < NL && (!D.fast_blocks || (TB && n_tb) || D.in_any[nb0 + sb])) ? D.in_cnt[l] : 0u;   // (TB: this workgroup has just delivered; the hint words need not be visible yet)
+    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[nb0 + sb])) ? D.in_cnt[l] : 0u;
     const uint64_t m = __ballot(cnts[sb] != 0);
     if (sw_lane() == 0) s_wcnt[sb * (SW_BLOCK / 64) + threadIdx.x / 64] = (uint32_t)__popcll(m);
   }
@@ -2536,6 +2621,30 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     }
   }
   if (D.fast_blocks && threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) D.in_any[nb0 + threadIdx.x] = 0;
+  // Mass events: inboxes of very different sizes in one wave leave its lanes idle while the longest one is merged (config #4's mass phase,
+  // profiles/r03_config4_resolve_phase_clock.txt: the busiest lane of a wave held 153 messages where the mean was 22 — every wave busy
+  // for 8 ms of an 11.8 ms tick).  So when the tile holds an inbox of SW_ORDER_MIN messages or more the list is reordered by size class
+  // (floor(log2(count)), largest first: the lanes of a wave then hold inboxes within a factor of two of each other) — a counting sort in
+  // place, every lane carrying its up to four entries through the barrier.  Which lane merges which node shows in no result.
+  {
+    bool big = false;
+#pragma unroll
+    for (uint32_t sb = 0; sb < SW_RTILE; sb++) big |= cnts[sb] >= SW_ORDER_MIN;
+    if (__syncthreads_or(big)) {                    // (the barrier: the list is complete)
+      uint32_t ent[SW_RTILE], pos[SW_RTILE];
+#pragma unroll
+      for (uint32_t j = 0; j < SW_RTILE; j++) { const uint32_t i = threadIdx.x + j * SW_BLOCK; ent[j] = i < n_act ? s_list[i] : 0u; }
+      if (threadIdx.x < 16) s_wcnt[threadIdx.x] = 0;             // (16 size classes: 2^15 messages and more share the first)
+      __syncthreads();
+#pragma unroll
+      for (uint32_t j = 0; j < SW_RTILE; j++) pos[j] = ent[j] ? atomicAdd(&s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))], 1u) : 0u;
+      __syncthreads();
+      if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t c = 0; c < 16; c++) { const uint32_t v = s_wcnt[c]; s_wcnt[c] = acc; acc += v; } }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t j = 0; j < SW_RTILE; j++) if (ent[j]) s_list[s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))] + pos[j]] = ent[j];
+    }
+  }
   __syncthreads();
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0, c_peak = 0;
   const uint32_t t_now = *D.tick;
@@ -2551,8 +2660,8 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     // stay cache resident instead of pulling in the node's 64-byte message line)
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-    const uint4 hdr0 = D.hdr[l];
-    const uint4 vm0 = D.vmeta[l];
+    const uint4 hdr0 = HDR(l);
+    const uint4 vm0 = VMETA(l);
     D.in_cnt[l] = 0;
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
     c_peak = cnt > c_peak ? cnt : c_peak;
@@ -2880,11 +2989,11 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
   SW_DEV_BIND
   size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= NL) return;
-  D.hdr[l] = make_uint4(1, 0, 0, (D.flags & SWIM_F_SERF_EVENTS) ? 1u : 0u);   // serf.Create: eventClock.Increment()
+  HDR(l) = make_uint4(1, 0, 0, (D.flags & SWIM_F_SERF_EVENTS) ? 1u : 0u);   // serf.Create: eventClock.Increment()
   if (D.vnk) D.vnk[l] = 0;
   D.ph[l] = make_uint2(0, 0);
   D.pr0[l] = make_uint4(NONE, 0, 0, 0);
-  D.in_cnt[l] = 0; D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
+  D.in_cnt[l] = 0; VMETA(l) = make_uint4(0, 0, NONE, NONE);
   if (D.mcnt) D.mcnt[l] = 0;
   if (D.evseq) D.evseq[l] = 0;
   if (l % SW_BLOCK == 0) {
@@ -2960,7 +3069,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
         D.pr0[l].x = NONE; D.ph[l].y = p_pack(p_epoch(h.y), p_aw(h.y), 0, 0); D.in_cnt[l] = 0;
         // a node that comes back resumes its old views, whose suspicion timers may be long overdue: its bound
         // counts again in the block's gate
-        const uint32_t d = D.vmeta[l].z;
+        const uint32_t d = VMETA(l).z;
         if (d != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], d);
         if (D.M && D.mcnt[l])                                  // ... and so do its suspicions in the dense store
           for (uint32_t row = 0; row < D.M; row++) {
@@ -3012,13 +3121,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         const size_t NL = (size_t)D.R * D.nloc, l = (size_t)r * D.nloc + (x - D.i0);
         // nothing queued, no views of its own (it holds the base row), clean probe state
         for (uint32_t sl = 0; sl < D.VT; sl++) if (D.vt[(size_t)sl * NL + l].x != VT_EMPTY) D.vt[(size_t)sl * NL + l].x = VT_EMPTY;
-        D.vmeta[l] = make_uint4(0, 0, NONE, NONE);
+        VMETA(l) = make_uint4(0, 0, NONE, NONE);
         if (D.M && D.mcnt[l]) { for (uint32_t row = 0; row < D.M; row++) { const size_t idx = m_idx(D, r, row, x - D.i0); if (D.mA[idx]) D.mA[idx] = 0; } D.mcnt[l] = 0; }
         const uint32_t bkey = base_key_of(D, r, x, old);
         if (D.vnk) D.vnk[l] = SW_KINC(bkey) == 0 ? 1u : 0u;  // it knows itself, whatever the base row says
-        uint4 h = D.hdr[l];
+        uint4 h = HDR(l);
         if (SW_KINC(bkey) != 0 || h.x > 1 || h.z) h.x++;     // a restart: past the incarnation others may remember
-        h.y = 0; D.hdr[l] = h;
+        h.y = 0; HDR(l) = h;
         const uint2 p = D.ph[l];
         D.ph[l].y = p_pack(p_epoch(p.y), 0, 0, 0); D.pr0[l].x = NONE; D.in_cnt[l] = 0;
         q_bit_lane(D, l, false, true);
@@ -3044,7 +3153,7 @@ __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
   bool local = x >= D.i0 && x < D.i0 + D.nloc;
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
-    uint4 h = D.hdr[l]; h.y = h_pack(h_leaving(h.y), 0, 0); D.hdr[l] = h; D.in_cnt[l] = 0;
+    uint4 h = HDR(l); h.y = h_pack(h_leaving(h.y), 0, 0); HDR(l) = h; D.in_cnt[l] = 0;
     if (!(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);          // no longer one of the nodes the simulator acts for
     q_bit_lane(D, l, false, true);
   }
@@ -3104,10 +3213,10 @@ __global__ void k_gather_node(const SwDev* __restrict__ Dp, uint32_t r, uint32_t
   SW_DEV_BIND
   if (threadIdx.x || blockIdx.x) return;
   size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
-  uint4 h = D.hdr[l], p0 = D.pr0[l]; uint2 p = D.ph[l]; uint32_t w = D.nw[(size_t)r * D.N + i];
+  uint4 h = HDR(l), p0 = D.pr0[l]; uint2 p = D.ph[l]; uint32_t w = D.nw[(size_t)r * D.N + i];
   out[0] = h.x; out[1] = h.y; out[2] = h.z; out[3] = h.w;
   out[4] = p0.x; out[5] = p0.y; out[6] = p0.z; out[7] = p0.w; out[8] = p.x; out[9] = p.y; out[10] = w;
-  for (uint32_t j = 0; j < h_qlen(h.y) && j < 32; j++) { uint4 e = D.q[(size_t)j * NL + l]; out[16 + 4 * j] = e.x; out[17 + 4 * j] = e.y; out[18 + 4 * j] = e.z; out[19 + 4 * j] = e.w; }
+  for (uint32_t j = 0; j < h_qlen(h.y) && j < 32; j++) { uint4 e = QENT(j, l); out[16 + 4 * j] = e.x; out[17 + 4 * j] = e.y; out[18 + 4 * j] = e.z; out[19 + 4 * j] = e.w; }
 }
 
 // order-independent digest (same item hashes as the oracle; see swim_state_digest there)
@@ -3121,13 +3230,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restri
   uint64_t d = 0;
   if (l < NL) {
     uint32_t r = (uint32_t)(l / D.nloc), i = D.i0 + (uint32_t)(l % D.nloc); uint64_t g = (uint64_t)r * D.N + i;
-    uint4 h = D.hdr[l], p0 = D.pr0[l]; uint2 p = D.ph[l];
+    uint4 h = HDR(l), p0 = D.pr0[l]; uint2 p = D.ph[l];
     d += sw_h3(1, g, ((uint64_t)h.x << 32) | ((uint64_t)p_aw(p.y) << 8) | h_leaving(h.y));
     d += sw_h3(2, g, ((uint64_t)p.x << 32) | p_epoch(p.y));
     if (p0.x != NONE)
       d += sw_h3(3, g, ((uint64_t)p0.x << 32) | p0.z) + sw_h3(4, g, ((uint64_t)p0.y << 32) | ((uint64_t)p_stage(p.y) << 8) | p_nackm(p.y));
     for (uint32_t j = 0; j < h_qlen(h.y); j++) {
-      uint4 e = D.q[(size_t)j * NL + l];
+      uint4 e = QENT(j, l);
       d += sw_h3(5, g, sw_h3(e.x, ((uint64_t)e.y << 32) | e.z, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8) | m_type(e.w)));
     }
     d += sw_h3(6, g, ((uint64_t)h.z << 32) | h.w);
@@ -3157,7 +3266,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
   uint64_t d = 0;
   if (l < NL) {
     const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
-    uint32_t left = D.vmeta[l].x;
+    uint32_t left = VMETA(l).x;
     for (uint32_t sl = 0; sl < D.VT && left; sl++) {          // explicit views
       const uint4 a = D.vt[(size_t)sl * NL + l];
       if (a.x == VT_EMPTY) continue;
@@ -3271,7 +3380,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reap(const SwDev* __restrict__ Dp)
   SW_DEV_BIND
   const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l >= NL) return;
-  uint32_t left = D.vmeta[l].x;
+  uint32_t left = VMETA(l).x;
   if (!left) return;
   const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc), t = *D.tick, now = now_ms(D, t);
   if (D.nw[(size_t)r * D.N + o] & NW_INERT) return;
@@ -3311,7 +3420,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
   uint32_t left = 0, r = 0;
   if (l < NL) {
     r = (uint32_t)(l / D.nloc);
-    if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = D.vmeta[l].x;
+    if (!(D.nw[(size_t)r * D.N + D.i0 + (uint32_t)(l % D.nloc)] & NW_INERT)) left = VMETA(l).x;
   }
   // round VT stands for the node's view of ITSELF when that is implicit (alive at its own incarnation) and not what
   // the base row says: it takes part in the census like an explicit view (there is nothing to free later)
@@ -3322,7 +3431,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
     uint4 a = make_uint4(VT_EMPTY, 0, 0, 0);
     if (sl < D.VT) { if (left) a = D.vt[(size_t)sl * NL + l]; }
     else if (acting && !saw_self) {
-      const uint32_t self = SW_KEY(D.hdr[l].x, SWIM_STATE_ALIVE);
+      const uint32_t self = SW_KEY(HDR(l).x, SWIM_STATE_ALIVE);
       const uint32_t wo = D.nw[(size_t)r * D.N + o];
       const bool in_store = (wo & NW_MASS) && D.mA[m_idx(D, r, D.mrow[(size_t)r * D.N + o], o - D.i0)] != 0;   // (k_fold_scan_mass counts that one)
       if (self != D.bk[(size_t)r * D.N + o] && !in_store) a = make_uint4(o, self, 0, 0);
@@ -3391,7 +3500,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
   SW_DEV_BIND
   const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
   if (l >= NL) return;
-  uint4 vm = D.vmeta[l];
+  uint4 vm = VMETA(l);
   if (!vm.x) return;
   const uint32_t r = (uint32_t)(l / D.nloc), o = D.i0 + (uint32_t)(l % D.nloc);
   uint32_t freed = 0, nk_less = 0;
@@ -3406,7 +3515,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply(const SwDev* __restrict
     vm.x--; freed++;
   }
   if (freed) {
-    D.vmeta[l] = vm;
+    VMETA(l) = vm;
     if (nk_less && D.dyn) D.vnk[l] -= nk_less;
     atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
   }
@@ -3519,7 +3628,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply_mass(const SwDev* __res
   uint32_t freed = 0;
   for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
     const size_t idx = m_idx(D, r, row, k);
-    if (D.mA[idx]) { D.mA[idx] = 0; D.mcnt[(size_t)r * D.nloc + k]--; freed++; }
+    if (D.mA[idx]) { D.mA[idx] = 0; atomicSub(&D.mcnt[(size_t)r * D.nloc + k], 1u); freed++; }   // (several rows fold in the same tick: one workgroup each, the same observers' counters)
   }
   for (uint32_t tl = threadIdx.x; tl < D.nbl; tl += SW_BLOCK) D.m_tile_dl[(size_t)rr * D.nbl + tl] = NONE;
   for (int off = 32; off; off >>= 1) freed += __shfl_down(freed, off);
@@ -3606,7 +3715,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_detect_tables(const SwDev* __restr
   if (k < D.nloc) {
     const size_t NL = (size_t)D.R * D.nloc, l = (size_t)r * D.nloc + k;
     const uint32_t o = D.i0 + k, wo = D.nw[(size_t)r * D.N + o];
-    uint32_t left = (wo & NW_INERT) ? 0u : D.vmeta[l].x;
+    uint32_t left = (wo & NW_INERT) ? 0u : VMETA(l).x;
     for (uint32_t sl = 0; sl < D.VT && left; sl++) {
       const uint4 e = D.vt[(size_t)sl * NL + l];
       if (e.x == VT_EMPTY) continue;
@@ -3659,7 +3768,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict_
   if (due) { const uint64_t sr = seed_of(D, r); sw_philox(t, o, 0, 0x5245434Eu, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_RECONNECT, w); }
   uint32_t n_failed = 0, best = NONE, best_h = 0;
   if (due) {                                         // the hash table, one lane per due node
-    uint32_t left = D.vmeta[l].x;
+    uint32_t left = VMETA(l).x;
     for (uint32_t sl = 0; sl < D.VT && left; sl++) {
       const uint4 e = D.vt[(size_t)sl * NL + l];
       if (e.x == VT_EMPTY) continue;
@@ -3752,15 +3861,17 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
             if (st == SWIM_STATE_ALIVE) type = SWIM_MSG_ALIVE;
             else if (st == SWIM_STATE_LEFT) { type = SWIM_MSG_DEAD; from = x; }
             else { type = SWIM_MSG_SUSPECT; from = dst_; }
-            if (filt_ && x != dst_ && noop_at_receiver<true>(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
+            // (the subject's real node word: when the receiver holds no pair the base row decides, and a row's subject may have a modified base row — fold, then revive / kill)
+            if (filt_ && x != dst_ && noop_at_receiver<true>(D, r_, (size_t)r_ * D.nloc + (dst_ - D.i0), D.nw[(size_t)r_ * D.N + x] | NW_MASS, make_uint4(x, MA_INC(a), from, type << 30), false, rec)) { want = false; c_filt++; }
             rec = mk_edge(D, r_, dst_, x, MA_INC(a), type, from);
+            if (sh_ != D.rank && (D.flags & SWIM_F_FILTER_NOOP) && x != dst_) rec.w |= SW_EDGE_JUDGE;       // the receiver's shard judges
           }
         }
       }
       left_ -= (uint32_t)__popcll(__ballot(present));
       hit_dst |= __ballot(present && x == dst_); hit_self |= __ballot(present && x == own_);
       wave_append(D, sh_, want, rec);
-      c_edges += want; c_remote += want && sh_ != D.rank;
+      c_edges += want && !(rec.w & SW_EDGE_JUDGE); c_remote += want && sh_ != D.rank;
     }
     send_state_tail(D, lane == 0, r_, own_, dst_, (x4.w & 1u) || hit_dst, (x4.w & 2u) || hit_self, c_edges, c_remote);
   }

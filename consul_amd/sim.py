@@ -284,6 +284,12 @@ class Sim:
         self._ck("swim_rtt_truth", self._l.swim_rtt_truth(self._h, replica, a, b, C.byref(o)))
         return int(o.value)
 
+    def info(self, what: int) -> int:
+        """swim_info: how the handle is laid out (abi.INFO_*)."""
+        o = C.c_uint64()
+        self._ck("swim_info", self._l.swim_info(self._h, what, C.byref(o)))
+        return int(o.value)
+
     def stats(self) -> dict:
         o = abi.Stats()
         self._ck("swim_stats", self._l.swim_stats(self._h, C.byref(o)))

@@ -463,8 +463,16 @@ int swim_coordinate_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_coo
 double swim_coordinate_distance(const swim_coordinate* a, const swim_coordinate* b);
 /* the latency model's round-trip time between two nodes without jitter, microseconds (to judge the coordinates against) */
 int swim_rtt_truth(swim_sim* sim, uint32_t replica, uint32_t a, uint32_t b, uint32_t* rtt_us);
-/* the edge list of the most recent tick (after emit, before delivery), for parity tests */
+/* the edge list of the most recent tick (after emit, before delivery), for parity tests.  HIP library, handles with tile buckets
+ * (SWIM_INFO_TILE_BUCKETS): the no-op filter runs at the receivers, and what it dropped is only marked once this call has been made —
+ * the first call switches the recording on and reports the rumours of the tick before it unfiltered; callers that compare tick by
+ * tick call once before they start. */
 int swim_debug_edges(swim_sim* sim, swim_edge* out, size_t cap, size_t* n_out);
+/* how this handle is laid out (what = SWIM_INFO_*; unknown keys: SWIM_EINVAL).  Nothing here shows in any result. */
+#define SWIM_INFO_TILE_BUCKETS 0u   /* 1: rumours travel through per-tile buckets and are judged by the no-op filter at the receivers (HIP library); 0: at the senders */
+#define SWIM_INFO_MAILBOX_KIND 1u   /* memory of the swim_xchg mailbox: 0 none (one shard), 1 fine-grained, 2 uncached, 3 coarse-grained (only on request: SWIMSIM_MAILBOX=coarse) */
+#define SWIM_INFO_DEVICE_BYTES 2u   /* device memory the handle holds */
+int swim_info(swim_sim* sim, uint32_t what, uint64_t* out);
 /* order-independent 64-bit digest over all integer node state (self state, queues, views,
  * suspicion timers, serf clocks) — "checksum of checksums" for full-size parity */
 int swim_state_digest(swim_sim* sim, uint64_t* out);

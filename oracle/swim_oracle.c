@@ -727,16 +727,26 @@ static swim_edge mk_edge(const swim_sim* s, uint32_t r, uint32_t dst, uint32_t s
   swim_edge e = { r * s->N + dst, subject, inc, (type << 30) | (from & 0x3FFFFFFFu) };
   return e;
 }
+/* A rumour for a node of ANOTHER shard: the sender cannot see the receiver's view, so the no-op question (noop_at_receiver) is asked by
+ * the receiving shard when the record arrives (swim_inbound) — against the same pre-tick view the sender of an unsharded run reads.
+ * The record says so in bit 29 of its meta word (node ids < 2^28 in sharded runs); it counts as crossing the wire here (edges_remote)
+ * and as an edge or as filtered where it arrives, so that the shards' counters add up to the unsharded run's.  Without this a state
+ * exchange that crosses a shard boundary arrives with EVERY explicit view of the sender and the receiver's inbox must hold them all. */
+#define EDGE_JUDGE 0x20000000u
+static int judged_remotely(swim_sim* s, uint32_t dst, uint32_t subject, uint32_t type) {
+  return (s->cfg.flags & SWIM_F_FILTER_NOOP) && !is_local(s, dst) && type != SWIM_MSG_USER && subject != dst;
+}
 static void emit_from(swim_sim* s, uint32_t src, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
   if (s->attached[(size_t)r * s->N + dst]) {            /* memberlist.Transport: hand the packet to the real node */
     if (s->captured.n == s->cap_src_cap) { s->cap_src_cap = s->cap_src_cap ? s->cap_src_cap * 2 : 1024; s->cap_src = (uint32_t*)realloc(s->cap_src, (size_t)s->cap_src_cap * 4); }
     s->cap_src[s->captured.n] = src;
-    ev_push(&s->captured, mk_edge(s, r, dst, subject, inc, type, from));
+    ev_push(&s->captured, mk_edge(s, r, dst, subject, inc, type, from & ~EDGE_JUDGE));
     return;
   }
   uint32_t sh = shard_of(s, dst);
   ev_push(&s->out[sh], mk_edge(s, r, dst, subject, inc, type, from));
-  s->st.edges++; if (sh != s->cfg.shard_rank) s->st.edges_remote++;
+  if (!(from & EDGE_JUDGE)) s->st.edges++;
+  if (sh != s->cfg.shard_rank) s->st.edges_remote++;
 }
 static void emit(swim_sim* s, uint32_t r, uint32_t dst, uint32_t subject, uint32_t inc, uint32_t type, uint32_t from) {
   emit_from(s, SWIM_NONE, r, dst, subject, inc, type, from);
@@ -1116,7 +1126,7 @@ static void send_state(swim_sim* s, uint32_t r, uint32_t owner, uint32_t dst) {
       default: m.type = SWIM_MSG_SUSPECT; m.from = dst; break;
     }
     if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, dst, &m)) { s->st.msgs_filtered++; continue; }
-    emit(s, r, dst, m.subject, m.inc, m.type, m.from);
+    emit(s, r, dst, m.subject, m.inc, m.type, m.from | (judged_remotely(s, dst, m.subject, m.type) ? EDGE_JUDGE : 0u));
   }
 }
 static void phase_pushpull(swim_sim* s) {
@@ -1219,7 +1229,7 @@ static void phase_gossip(swim_sim* s) {
         if (!reach(s, r, o, peers[p], o, p)) { s->st.packets_dropped++; continue; }
         for (uint32_t m = 0; m < n; m++) {
           if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, peers[p], &msgs[m])) { s->st.msgs_filtered++; continue; }
-          emit_from(s, o, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from);
+          emit_from(s, o, r, peers[p], msgs[m].subject, msgs[m].inc, msgs[m].type, msgs[m].from | (judged_remotely(s, peers[p], msgs[m].subject, msgs[m].type) ? EDGE_JUDGE : 0u));
         }
       }
     }
@@ -1526,6 +1536,7 @@ static void phase_carry(swim_sim* s) {
     qent m = { e.subject, e.incarnation, e.meta & 0x3FFFFFFFu, 0, (uint8_t)(e.meta >> 30), 0 };
     if ((s->cfg.flags & SWIM_F_FILTER_NOOP) && noop_at_receiver(s, r, x, &m)) { s->st.msgs_filtered++; continue; }
     uint32_t sh = shard_of(s, x);
+    if (judged_remotely(s, x, m.subject, m.type)) { e.meta |= EDGE_JUDGE; ev_push(&s->out[sh], e); s->st.edges_remote++; continue; }
     ev_push(&s->out[sh], e);
     s->st.edges++; if (sh != s->cfg.shard_rank) s->st.edges_remote++;
   }
@@ -1543,7 +1554,7 @@ int swim_tick_begin(swim_sim* s) {
   s->last_edges.n = 0;
   for (uint32_t sh = 0; sh < s->cfg.n_shards; sh++)
     for (uint32_t i = 0; i < s->out[sh].n; i++)
-      if (s->out[sh].v[i].dst != SWIM_NONE && s->out[sh].v[i].subject != SWIM_SUBJECT_PIGGY) ev_push(&s->last_edges, s->out[sh].v[i]);
+      if (s->out[sh].v[i].dst != SWIM_NONE && s->out[sh].v[i].subject != SWIM_SUBJECT_PIGGY) { swim_edge e = s->out[sh].v[i]; if (e.subject != SWIM_SUBJECT_PULL) e.meta &= ~EDGE_JUDGE; ev_push(&s->last_edges, e); }
   phase_carry(s);
   s->in_tick = 1;
   /* the local segment never crosses the wire */
@@ -1565,7 +1576,17 @@ int swim_activity(swim_sim* s, int* active) { if (!s || !active) return SWIM_EIN
 uint32_t swim_outbound_capacity(swim_sim* s, uint32_t shard) { return (s && shard < s->cfg.n_shards) ? 0x7FFFFFFFu : 0; }
 int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   if (!s || (!ptr && count)) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
-  for (uint32_t i = 0; i < count; i++) ev_push(&s->in, ptr[i]);
+  for (uint32_t i = 0; i < count; i++) {
+    swim_edge e = ptr[i];
+    if (e.dst != SWIM_NONE && e.subject != SWIM_SUBJECT_PIGGY && e.subject != SWIM_SUBJECT_PULL && (e.meta & EDGE_JUDGE)) {   /* a rumour its sender could not judge */
+      e.meta &= ~EDGE_JUDGE;
+      uint32_t r = e.dst / s->N, x = e.dst % s->N;
+      qent m = { e.subject, e.incarnation, e.meta & 0x3FFFFFFFu, 0, (uint8_t)(e.meta >> 30), 0 };
+      if (is_local(s, x) && noop_at_receiver(s, r, x, &m)) { s->st.msgs_filtered++; continue; }
+      s->st.edges++;
+    }
+    ev_push(&s->in, e);
+  }
   return SWIM_OK;
 }
 int swim_tick_end(swim_sim* s) {
@@ -1858,6 +1879,11 @@ int swim_trace_read(swim_sim* s, uint32_t r, uint32_t x, uint32_t first, uint32_
   return SWIM_OK;
 }
 int swim_stats(swim_sim* s, swim_stats_t* out) { if (!s || !out) return SWIM_EINVAL; *out = s->st; return SWIM_OK; }
+/* layout introspection: the checker has neither tile buckets nor a mailbox nor device memory */
+int swim_info(swim_sim* s, uint32_t what, uint64_t* out) {
+  if (!s || !out || what > SWIM_INFO_DEVICE_BYTES) return SWIM_EINVAL;
+  *out = 0; return SWIM_OK;
+}
 int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t* n_out) {
   if (!s || (!out && cap) || !n_out) return SWIM_EINVAL;
   size_t n = s->last_edges.n < cap ? s->last_edges.n : cap;

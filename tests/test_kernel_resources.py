@@ -13,14 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel (mangled-name fragment) -> (max VGPRs, max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
-    "k_beginILi4ELb0ELb0ELb0ELb1E": (96, 32, 5),   # the bench's instantiation: fan-out <= 4, no serf events, one shard, no dense pair store, tile buckets
-    "k_beginILi4ELb0ELb0ELb0ELb0E": (96, 16, 5),   # ... with the sender-side filter and segments (clusters too large for tile buckets: config #3)
+    "k_beginILi4ELb0ELb0ELb0ELb0E": (96, 16, 5),   # the bench's instantiation: fan-out <= 4, no serf events, one shard, no dense pair store, no tile buckets
+    "k_beginILi4ELb0ELb0ELb0ELb1E": (96, 48, 5),   # ... with tile buckets (SWIMSIM_TILEBUCKETS=1; its carry role walks the areas twice)
     "k_beginILi4ELb0ELb0ELb1ELb0E": (96, 32, 5),   # ... with the dense pair store (config #4 / #5 legs)
     "k_beginILi8ELb1ELb1ELb1ELb0E": (96, 128, 5),  # the heaviest one (fan-out 8, serf events, sharded, dense store)
-    "9k_deliverILb0EE": (64, 0, 7),
-    "9k_resolveILb0ELb1EE": (128, 64, 4),      # tile buckets; the scratch is the call frame of the in-place heapsort of big inboxes (cold path)
-    "9k_resolveILb0ELb0EE": (128, 64, 4),
-    "9k_resolveILb1ELb0EE": (128, 64, 4),
+    "9k_deliverILb0ELb0EE": (64, 0, 7),
+    "9k_deliverILb0ELb1EE": (96, 0, 5),        # tile buckets: the per-tile drain, four records per lane in flight
+    "9k_resolveILb0EE": (128, 64, 4),          # the call frame of the in-place heapsort of big inboxes (cold path)
+    "9k_resolveILb1EE": (128, 64, 4),
     "8k_censusPK": (32, 0, 8),
     "8k_finishPK": (64, 0, 8),
     "7k_quietPK": (40, 0, 8),

@@ -145,7 +145,7 @@ def test_sharded_population_matches_unsharded(hip, oracle, n_shards):
     assert sh.digest() == ref.digest()
     a, b = sh.stats(), ref.stats()
     for k in STAT_KEYS:
-        if k not in ("subject_overflow", "edges", "msgs_filtered"):   # a shard cannot filter what goes to another shard
+        if k != "subject_overflow":                 # (edges and msgs_filtered included: the receiving shard judges what crosses a boundary)
             assert a[k] == b[k], k
     assert a["edges_remote"] > 0
     sh.close()
