@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NONE = 0xFFFFFFFF
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE, EIO = 0, -22, -12, -19, -34, -75, -71, -5
@@ -65,7 +65,7 @@ class Member(C.Structure):
 
 
 class Event(C.Structure):
-    _fields_ = [(n, u32) for n in ("time_ms", "replica", "type", "node", "ltime", "incarnation", "observer")]
+    _fields_ = [(n, u32) for n in ("time_ms", "replica", "type", "node", "incarnation", "observer")] + [("ltime", C.c_uint64)]
 
 
 class Rumour(C.Structure):
@@ -76,8 +76,9 @@ class Rumour(C.Structure):
 class NodeInfo(C.Structure):
     _fields_ = [(n, u32) for n in (
         "incarnation", "probe_target", "probe_deadline_tick", "probe_cursor", "probe_epoch",
-        "queue_len", "event_queue_len", "event_clock")] + [
+        "queue_len", "event_queue_len")] + [
         ("alive", u8), ("leaving", u8), ("awareness", u8), ("partition", u8),
+        ("event_clock", C.c_uint64),
         ("queue", Rumour * 32)]
 
 
@@ -149,12 +150,12 @@ PROTOTYPES = {
     "swim_inject_revive": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_leave": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
     "swim_inject_update": (C.c_int, [SimP, u32, P(u32), C.c_size_t]),
-    "swim_force_leave": (C.c_int, [SimP, u32, u32, u32, C.c_int, P(u32)]),
+    "swim_force_leave": (C.c_int, [SimP, u32, u32, u32, C.c_int, P(C.c_uint64)]),
     "swim_inject_join": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u32]),
     "swim_inject_partition": (C.c_int, [SimP, u32, P(u8)]),
     "swim_set_loss": (C.c_int, [SimP, u32]),
     "swim_set_tcp_class": (C.c_int, [SimP, u32, P(u32), C.c_size_t, u8]),
-    "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(u32)]),
+    "swim_user_event": (C.c_int, [SimP, u32, u32, u32, P(C.c_uint64)]),
     "swim_watch": (C.c_int, [SimP, u32, u32]),
     "swim_members": (C.c_int, [SimP, u32, u32, P(Member), C.c_size_t, P(C.c_size_t)]),
     "swim_view": (C.c_int, [SimP, u32, u32, u32, P(Member)]),

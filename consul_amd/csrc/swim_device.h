@@ -169,6 +169,12 @@ struct SwDev {
   uint32_t rc_period;                                                  // serf's reconnect(): ticks between a node's attempts (0 = off)
   uint4* vt;             // [VT][NL]
   uint4* vc;             // [VT][NL]
+  // serf's member.statusLTime (SWIM_F_SERF_EVENTS only; null otherwise): the Lamport time of the last join / leave intent an observer applied
+  // to a member — per explicit view (vs, beside vt / vc; a base-row view reads 0), per pair of the dense store (mD, a fourth plane), and for
+  // the agent's own member entry (sslt: bit 31 = this agent has broadcast its own leave intent, serf.Leave: it no longer refutes one)
+  uint32_t* vs;          // [VT][NL]
+  uint32_t* mD;          // [R][M][nloc]
+  uint32_t* sslt;        // [NL]
   uint4* vmeta;          // [NL] {explicit views held, how many of them are Suspect,
                          //       earliest suspicion deadline among them (a lower bound; NONE = none),
                          //       earliest time a view becomes evictable (Dead/Left for longer than GossipToTheDeadTime;

@@ -454,6 +454,10 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.rc_period = d.reconnect_period_ticks;
   { uint32_t tb = 2; while ((1ull << tb) < 2ull * (D.view_cap + 1)) tb++; D.VT = 1u << tb; D.vt_shift = 32 - tb; }
   DALLOC(s, D.vt, NL * D.VT); DALLOC(s, D.vc, NL * D.VT);
+  if (serf) {   // serf's member.statusLTime per explicit view and for the agent's own entry (swim_device.h); the dense store's plane below
+    DALLOC(s, D.vs, NL * D.VT); DALLOC(s, D.sslt, NL);
+    HIPCK(s, hipMemsetAsync(D.vs, 0, NL * D.VT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.sslt, 0, NL * 4, s->stream));
+  }
 #ifndef SW_NODE_LINE
   DALLOC(s, D.vmeta, NL);
 #endif
@@ -464,6 +468,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     if (RM >= 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
     DALLOC(s, D.mrow, NT); DALLOC(s, D.mrow_subj, RM); DALLOC(s, D.m_free, RM); DALLOC(s, D.m_nfree, D.R);
     DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
+    if (serf) { DALLOC(s, D.mD, pairs); HIPCK(s, hipMemsetAsync(D.mD, 0, pairs * 4, s->stream)); }
     DALLOC(s, D.m_tile_dl, RM * D.nbl); DALLOC(s, D.m_row_dl, RM); DALLOC(s, D.mcnt, NL);
     DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
@@ -780,7 +785,8 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_inbox_sort_med, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
   }
-  void (*const resolve_kernel)(const SwDev*) = D.M ? k_resolve<true> : k_resolve<false>;
+  const bool serf_k = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+  void (*const resolve_kernel)(const SwDev*) = D.M ? (serf_k ? k_resolve<true, true> : k_resolve<true, false>) : (serf_k ? k_resolve<false, true> : k_resolve<false, false>);
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
@@ -1084,7 +1090,7 @@ extern "C" int swim_inject_kill(swim_sim* s, uint32_t r, const uint32_t* ids, si
 extern "C" int swim_inject_revive(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_REVIVE, r, ids, n); }
 extern "C" int swim_inject_leave(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_LEAVE, r, ids, n); }
 extern "C" int swim_inject_update(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n) { return inject(s, INJ_UPDATE, r, ids, n); }
-extern "C" int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint32_t* lt) {
+extern "C" int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint64_t* lt) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
   if (r >= s->D.R || origin >= s->D.N || node >= s->D.N) return SWIM_ERANGE;
@@ -1094,7 +1100,7 @@ extern "C" int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32
   uint32_t v = SWIM_NONE;
   HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
-  if (lt) *lt = v;
+  if (lt) *lt = v == SWIM_NONE ? UINT64_MAX : (uint64_t)v;     // (the device clock is 32 bits wide; nothing was stamped: all ones)
   return SWIM_OK;
 }
 extern "C" int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uint32_t via) {
@@ -1187,7 +1193,7 @@ extern "C" int swim_set_loss(swim_sim* s, uint32_t q) {
   }
   return SWIM_OK;
 }
-extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
+extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint64_t* lt) {
   if (!s) return SWIM_EINVAL;
   if (s->in_tick || !(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
   if (r >= s->D.R || origin >= s->D.N || id > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;   // bits 31-30 mark serf's intents, never a user event
@@ -1196,7 +1202,7 @@ extern "C" int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_
   uint32_t v = SWIM_NONE;
   HIPCK(s, hipMemcpyAsync(&v, s->d_scratch, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCK(s, hipStreamSynchronize(s->stream));
-  if (lt) *lt = v;
+  if (lt) *lt = v == SWIM_NONE ? UINT64_MAX : (uint64_t)v;     // (the device clock is 32 bits wide; nothing was stamped: all ones)
   return SWIM_OK;
 }
 

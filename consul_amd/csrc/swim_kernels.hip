@@ -124,9 +124,10 @@ __device__ __forceinline__ void m_store(DevRef D, size_t idx, uint4 e, uint32_t 
 // a suspicion timer of pair (row, lane k of replica r) was (re)armed: keep the row's and the tile's bounds (k_expire_mass)
 __device__ __forceinline__ void m_arm(DevRef D, uint32_t r, uint32_t row, uint32_t k, uint32_t dl) {
   uint32_t* t = &D.m_tile_dl[((size_t)r * D.M + row) * D.nbl + k / SW_BLOCK];
-  if (dl < *t) atomicMin(t, dl);
   uint32_t* rw = &D.m_row_dl[(size_t)r * D.M + row];
-  if (dl < *rw) atomicMin(rw, dl);
+  const uint32_t tv = *t, rv = *rw;                 // (one round trip for both bounds, not two in a row)
+  if (dl < tv) atomicMin(t, dl);
+  if (dl < rv) atomicMin(rw, dl);
 }
 // what the base row says about the node whose word is w
 __device__ __forceinline__ uint32_t base_key_of(DevRef D, uint32_t r, uint32_t x, uint32_t w) {
@@ -175,6 +176,7 @@ __device__ void vt_erase(DevRef D, size_t l, uint32_t i) {
     const uint32_t k = vt_home(D, ej.x);
     if (i <= j ? (i < k && k <= j) : (i < k || k <= j)) continue;
     D.vt[(size_t)i * NL + l] = ej; D.vc[(size_t)i * NL + l] = D.vc[(size_t)j * NL + l];
+    if (D.vs) D.vs[(size_t)i * NL + l] = D.vs[(size_t)j * NL + l];
     i = j;
   }
   D.vt[(size_t)i * NL + l].x = VT_EMPTY;
@@ -1991,13 +1993,17 @@ __shared__ uint32_t g_s_cen_r;            // the replica the workgroup's first n
 // and the entries that changed are written back once); otherwise it is edited in HBM (the stimulus kernels).
 // (Every method is __forceinline__: left to the inliner's threshold, one more statement in a method made it a call, the
 // context was passed by pointer and lived in scratch memory — 646 scratch instructions in k_resolve.)
-template <bool LQ, bool MASS>
+// SERF = the handle has serf's event layer (SWIM_F_SERF_EVENTS): without it the user-event / intent handlers are not compiled into the
+// kernel at all (k_resolve of the headline workload: their register pressure showed in its merge loop — 78 -> 92 us per launch when serf's
+// intent ordering came in as run-time code)
+template <bool LQ, bool MASS, bool SERF = true>
 struct NodeCtxT {
   DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
   uint32_t self_inc, leaving, qlen, evqlen, qseq, ev_clock;
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
   uint32_t dl_new = NONE;                             // earliest deadline this lane armed (the caller lowers dl_blk with it)
+  uint32_t mcnt_add = 0;                              // pairs of the dense store this lane created (D.mcnt[l] is bumped once, in store())
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = VMETA(l); vm_have = true; } }
   uint4 h0;
@@ -2028,6 +2034,7 @@ struct NodeCtxT {
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) HDR(l) = h;
     if (vm_dirty) VMETA(l) = vm;
+    if (MASS && mcnt_add) { D.mcnt[l] += mcnt_add; mcnt_add = 0; }
   }
 
   // QueueBroadcast: same-subject invalidation, Prune() on overflow.  EV = the serf user-event queue (always in HBM)
@@ -2059,7 +2066,7 @@ struct NodeCtxT {
   }
   __device__ __forceinline__ void record_event(uint32_t type, uint32_t node, uint32_t ltime, uint32_t inc) {
     uint32_t pos = atomicAdd(D.ev_cnt, 1u);
-    if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, ltime, inc, o }; D.events[pos] = ev; }
+    if (pos < D.ev_cap) { swim_event ev = { now_ms(D, t), r, type, node, inc, o, (uint64_t)ltime }; D.events[pos] = ev; }
     else atomicOr(D.err, SW_ERR_EVENT_OVF);
   }
   // does this observer have an EventCh: cfg.watch_node, or one added with swim_watch_events (rare: the list is only looked at
@@ -2112,7 +2119,7 @@ struct NodeCtxT {
   // (its view of itself always fits): the caller ignores the rumour, counted in view_drops.
   __device__ __forceinline__ bool make(View& v, uint32_t x) {
     if (v.slot != NONE) return true;
-    if (v_mass(v)) { v.slot = v.free_slot; v.fresh = true; D.mcnt[l]++; return true; }   // the dense store has room for every observer
+    if (v_mass(v)) { v.slot = v.free_slot; v.fresh = true; mcnt_add++; if (D.mD) D.mD[m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k)] = 0; return true; }     // the dense store has room for every observer (the count: once per receiver, in store())
     need_vm();
     if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
     if (vm.x >= D.view_cap + (x == o ? 1u : 0u)) {
@@ -2143,6 +2150,7 @@ struct NodeCtxT {
     vm.x++; vm_dirty = true;
     if (D.dyn && x != o && v.e.y < 4u) D.vnk[l]++;          // a node the base row has never heard of: this observer now has (itself it counts from the start)
     v.slot = v.free_slot; v.fresh = true;
+    if (D.vs) D.vs[(size_t)v.slot * NL + l] = 0;           // (serf: no intent applied to it yet)
     if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
       const uint32_t old = atomicOr(&D.nw[(size_t)r * D.N + x], NW_SUBJECT);
       if (!(old & NW_SUBJECT)) exc_note(D, r, x, old, old | NW_SUBJECT);
@@ -2296,11 +2304,11 @@ struct NodeCtxT {
     HbmQ qe{D.evq + l, NL};
     // the user-event queue stays in HBM; the pick walks it several times, so its meta words are fetched once into LDS
     MetaQ me{lds_emeta + threadIdx.x};
-    for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
+    if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
     const uint32_t rl = retransmit_limit_n(D, est_n(D, r, l));
     uint32_t tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl), te = 0;
     int avail = limit - used;
-    if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
+    if constexpr (SERF) if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
     if (!(tm | te)) return;
     const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
     c_pig++;
@@ -2315,7 +2323,7 @@ struct NodeCtxT {
         uint4 e = SQ(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
         if (att) capture(D, o, gdst, e.x, e.y, meta); else area[pos++] = make_uint4(gdst, e.x, e.y, meta);
       }
-      for (uint32_t m = te; m && pos != NONE; m &= m - 1) {
+      if constexpr (SERF) for (uint32_t m = te; m && pos != NONE; m &= m - 1) {
         uint4 e = qe.at(__ffs(m) - 1);
         if (att) capture(D, o, gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30); else area[pos++] = make_uint4(gdst, e.x, e.y, (uint32_t)SWIM_MSG_USER << 30);
       }
@@ -2327,40 +2335,63 @@ struct NodeCtxT {
       if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j;
       nq++;
     }
-    for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) {
+    if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) {
       if (ne != j) { uint4 e = qe.at(j); e.w = me.meta(j); qe.at(ne) = e; } else if ((te >> j) & 1u) qe.at(j).w = me.meta(j);
       ne++;
     }
-    qlen = nq; evqlen = ne;
+    qlen = nq; if constexpr (SERF) evqlen = ne;
   }
-  // serf handleNodeLeaveIntent for a force-leave (RemoveFailedNode): a member held Failed becomes Left (EventMemberLeave);
-  // with prune it is erased at once (EventMemberReap), also when it was Left already.  A member that is Alive or Suspect
-  // here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.
-  __device__ __forceinline__ void leave_intent(uint32_t x, bool prune) {
-    if (x >= D.N || x == o) return;
+  // serf's member.statusLTime of the cached view (0: a base-row view, or no intent applied yet) — read and written in place, not
+  // carried in the View (only intents look at it)
+  __device__ __forceinline__ uint32_t slt_of(const View& v) const {
+    if (!D.vs || v.slot == NONE) return 0u;
+    return v_mass(v) ? D.mD[m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k)] : D.vs[(size_t)v.slot * NL + l];
+  }
+  __device__ __forceinline__ void slt_set(const View& v, uint32_t lt) {      // (v is explicit: make() succeeded)
+    if (v_mass(v)) D.mD[m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k)] = lt; else D.vs[(size_t)v.slot * NL + l] = lt;
+  }
+  // serf handleNodeLeaveIntent.  Returns 1 when the intent is rebroadcast (serf's return value), 0 when not, 2 when it is about this
+  // agent itself and must be refuted (the caller broadcasts a join intent: "go s.broadcastJoin(s.clock.Time())").  Order as upstream:
+  // the member's statusLTime first (an intent stamped no later than the last one applied here is stale), then the refutation, then the
+  // transition by status: a member held Failed becomes Left (EventMemberLeave), with prune it is erased at once (EventMemberReap), also
+  // when it was Left already; a member that is Alive or Suspect here is marked Leaving — when memberlist declares it dead it becomes
+  // Left, not Failed.  Not modelled: serf's recentIntents (an intent about a member this node has never heard of is passed on only).
+  __device__ __forceinline__ int leave_intent(uint32_t x, bool prune, uint32_t ltime) {
+    if (x >= D.N) return 0;
+    if (x == o) {
+      const uint32_t ss = D.sslt[l];
+      if (ltime <= (ss & 0x7FFFFFFFu)) return 0;
+      if (!(ss >> 31)) return 2;
+      D.sslt[l] = 0x80000000u | ltime;                     // its own Leave(): StatusLeaving until memberlist's leave goes out
+      return 1;
+    }
     View v = take_view(x);
-    leave_intent_v(v, x, prune);
+    const int rc = leave_intent_v(v, x, prune, ltime);
     cv = v;
+    return rc;
   }
-  __device__ __forceinline__ void leave_intent_v(View& v, uint32_t x, bool prune) {
+  __device__ __forceinline__ int leave_intent_v(View& v, uint32_t x, bool prune, uint32_t ltime) {
     const uint32_t key = v.e.y, st = SW_KST(key);
-    if (SW_KINC(key) == 0) return;
+    if (SW_KINC(key) == 0) return 1;
+    if (ltime <= slt_of(v)) return 0;                      // "If the message is old, then it is irrelevant and we can skip it"
     if (st < SWIM_STATE_DEAD) {                            // alive (or suspected) here: StatusLeaving — its death will read as a leave
-      if (!make(v, x)) return;
+      if (!make(v, x)) return 1;
+      slt_set(v, ltime);
       const uint32_t bit = st == SWIM_STATE_SUSPECT ? 8u : 2u;
       if (v.fresh || !(v.e.w & bit)) {
         v.e.w |= bit; v.fresh = false; put_later(v);
         if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1;
       }
-      return;
+      return 1;
     }
     // erased already (serf no longer has the member; a Failed / Left member of the base row was erased before it got there)
-    if (v.slot != NONE ? (v.e.w & 1u) != 0 : D.reap_period != 0) return;
-    if (st == SWIM_STATE_LEFT && !prune) return;
-    if (!make(v, x)) return;
+    if (v.slot != NONE ? (v.e.w & 1u) != 0 : D.reap_period != 0) return 1;
+    if (st == SWIM_STATE_LEFT && !prune) return 1;
+    if (!make(v, x)) return 1;
     v.e.w = 0;
     if (st == SWIM_STATE_DEAD) {
       set_view(v, SW_KINC(key), SWIM_STATE_LEFT, true);
+      slt_set(v, ltime);
       S.add(ST_INTENTS);
       if (watching()) record_event(SWIM_EVENT_MEMBER_LEAVE, x, 0, SW_KINC(key));
     } else if (v_mass(v)) v.fresh = false;
@@ -2371,38 +2402,80 @@ struct NodeCtxT {
       if (watching()) record_event(SWIM_EVENT_MEMBER_REAP, x, 0, SW_KINC(key));
     }
     put_later(v);
+    return 1;
+  }
+  // serf handleNodeJoinIntent: a newer join intent moves the member's statusLTime and takes a Leaving mark back ("the leaving message must
+  // have been for an older time")
+  __device__ __forceinline__ int join_intent(uint32_t x, uint32_t ltime) {
+    if (x >= D.N) return 0;
+    if (x == o) {
+      const uint32_t ss = D.sslt[l];
+      if (ltime <= (ss & 0x7FFFFFFFu)) return 0;
+      D.sslt[l] = (ss & 0x80000000u) | ltime;
+      return 1;
+    }
+    View v = take_view(x);
+    const int rc = join_intent_v(v, x, ltime);
+    cv = v;
+    return rc;
+  }
+  __device__ __forceinline__ int join_intent_v(View& v, uint32_t x, uint32_t ltime) {
+    const uint32_t key = v.e.y, st = SW_KST(key);
+    if (SW_KINC(key) == 0) return 1;                       // not a member here: passed on
+    if (st >= SWIM_STATE_DEAD && (v.slot != NONE ? (v.e.w & 1u) != 0 : D.reap_period != 0)) return 1;     // erased: likewise
+    if (ltime <= slt_of(v)) return 0;
+    if (!make(v, x)) return 1;
+    slt_set(v, ltime);
+    if (st < SWIM_STATE_DEAD) {
+      const uint32_t bit = st == SWIM_STATE_SUSPECT ? 8u : 2u;
+      if (!v.fresh && (v.e.w & bit)) { v.e.w &= ~bit; if (NW_HAS_SLOT(v.w)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(v.w)] = 1; }
+    } else if (v.fresh && !v_mass(v)) { need_vm(); const uint32_t ev = v.e.z + D.gossip_to_dead_ms + 1; if (ev < vm.w) { vm.w = ev; vm_dirty = true; } }
+    v.fresh = false; put_later(v);
+    return 1;
   }
   // serf handleUserEvent + LamportClock.Witness.  An event-buffer slot (one per LTime mod EventBuffer) is EW 16-byte words,
   // slot-major: word 0 = {ltime, n, id0, id1}, then four ids per word — serf's slot is an unbounded list of the events
-  // stamped with that LTime; ours holds 4*EW - 2 (swim_config.event_ids_per_ltime; a flood stamps many events alike)
-  __device__ __forceinline__ void user_event(uint32_t id, uint32_t ltime) {
+  // stamped with that LTime; ours holds 4*EW - 2 (swim_config.event_ids_per_ltime; a flood stamps many events alike).
+  // An id with bit 31 set is one of serf's intents: rebroadcast as its handler says (the origin always sends).  A leave intent about this
+  // agent itself, while it is not leaving, is answered in a second pass with the agent's own join intent stamped clock.Time().
+  __device__ __forceinline__ void user_event(uint32_t id, uint32_t ltime, bool origin = false) {
+    if constexpr (!SERF) { (void)id; (void)ltime; (void)origin; return; } else {
     if (!(D.flags & SWIM_F_SERF_EVENTS)) return;
-    if (ltime >= ev_clock) ev_clock = ltime + 1;
-    if (ev_clock > D.EB && ltime < ev_clock - D.EB) { S.add(ST_UEV_STALE); return; }
-    uint4* const slot = D.ring + (size_t)(ltime % D.EB) * D.EW * NL + l;      // word j at slot[j * NL]
-    uint4 w0 = slot[0]; uint32_t n = w0.y;
-    if (n && w0.x == ltime) {
-      bool dup = w0.z == id || (n >= 2 && w0.w == id);
-      for (uint32_t j = 1; !dup && 4 * j - 2 < n; j++) {
-        const uint4 w = slot[(size_t)j * NL]; const uint32_t m = n - (4 * j - 2);
-        dup = w.x == id || (m >= 2 && w.y == id) || (m >= 3 && w.z == id) || (m >= 4 && w.w == id);
+    for (int pass = 0; pass < 2; pass++) {
+      if (ltime >= ev_clock) ev_clock = ltime + 1;
+      if (ev_clock > D.EB && ltime < ev_clock - D.EB) { S.add(ST_UEV_STALE); break; }
+      uint4* const slot = D.ring + (size_t)(ltime % D.EB) * D.EW * NL + l;      // word j at slot[j * NL]
+      uint4 w0 = slot[0]; uint32_t n = w0.y;
+      if (n && w0.x == ltime) {
+        bool dup = w0.z == id || (n >= 2 && w0.w == id);
+        for (uint32_t j = 1; !dup && 4 * j - 2 < n; j++) {
+          const uint4 w = slot[(size_t)j * NL]; const uint32_t m = n - (4 * j - 2);
+          dup = w.x == id || (m >= 2 && w.y == id) || (m >= 3 && w.z == id) || (m >= 4 && w.w == id);
+        }
+        if (dup) { S.add(ST_UEV_DEDUP); break; }
+      } else n = 0;
+      if (n == 4 * D.EW - 2) { S.add(ST_EVDROPS); break; }
+      if (n == 0) w0.z = id; else if (n == 1) w0.w = id;
+      else {
+        uint32_t* w = (uint32_t*)&slot[(size_t)((n + 2) / 4) * NL];
+        w[(n + 2) & 3u] = id;
       }
-      if (dup) { S.add(ST_UEV_DEDUP); return; }
-    } else n = 0;
-    if (n == 4 * D.EW - 2) { S.add(ST_EVDROPS); return; }
-    if (n == 0) w0.z = id; else if (n == 1) w0.w = id;
-    else {
-      uint32_t* w = (uint32_t*)&slot[(size_t)((n + 2) / 4) * NL];
-      w[(n + 2) & 3u] = id;
+      n++; w0.x = ltime; w0.y = n; slot[0] = w0;
+      int rc = 1;
+      if (id & SWIM_INTENT_LEAVE)
+        rc = (id & SWIM_INTENT_JOIN) == SWIM_INTENT_JOIN ? join_intent(id & 0x1FFFFFFFu, ltime) : leave_intent(id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0, ltime);
+      else {
+        S.add(ST_UEV_DELIVERED);
+        if (watching()) record_event(SWIM_EVENT_USER, id, ltime, 0);
+      }
+      if (rc == 1 || origin) {
+        uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
+        queue_push<true>(D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
+      }
+      if (rc != 2) break;
+      id = SWIM_INTENT_JOIN | o; ltime = ev_clock; origin = true;       // the refutation: broadcastJoin(s.clock.Time())
     }
-    n++; w0.x = ltime; w0.y = n; slot[0] = w0;
-    if (id & SWIM_INTENT_LEAVE) leave_intent(id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
-    else {
-      S.add(ST_UEV_DELIVERED);
-      if (watching()) record_event(SWIM_EVENT_USER, id, ltime, 0);
     }
-    uint32_t seq = D.evseq[l]; D.evseq[l] = seq + 1;
-    queue_push<true>(D.EQ, evqlen, seq, false, id, SWIM_MSG_USER, ltime, 0, ST_EVDROPS);
   }
 };
 #undef SQ
@@ -2573,7 +2646,7 @@ __device__ unsigned long long g_wclk[WCLK_ROWS][6];
 #define SW_RESOLVE_WAVES 4
 #endif
 #define SW_ORDER_MIN 16u          /* a tile with an inbox of this many messages has its receiver list ordered by size class */
-template <bool MASS>
+template <bool MASS, bool SERF>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
@@ -2667,7 +2740,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-    NodeCtxT<true, MASS> n(D, S);
+    NodeCtxT<true, MASS, SERF> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
     RCLK_MARK(1);                                  // line + header + vmeta
@@ -2715,9 +2788,17 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
         if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
         else atomicOr(D.err, SW_ERR_PEND_OVF);
       }
-      else if (type == SWIM_MSG_ALIVE) n.alive_node(best.y, best.z, from);
-      else if (type == SWIM_MSG_SUSPECT) n.suspect_node(best.y, best.z, from);
-      else if (type == SWIM_MSG_DEAD) n.dead_node(best.y, best.z, from);
+      else if (type != SWIM_MSG_USER) {
+        // a membership rumour: ONE view lookup whatever its type — as three calls the lanes of a wave that hold an alive, a suspect and a
+        // dead message ran three copies of the lookup (node word + row / home slot, then the pair / entry) one after the other; in config
+        // #4's mass phase, where the types mix, that was most of a message iteration's round trips
+        const uint32_t x = best.y, inc = best.z;
+        auto v = n.take_view(x);
+        if (type == SWIM_MSG_ALIVE) { if (x != n.o) n.alive_other(v, x, inc, from); else if (!n.leaving && inc > n.self_inc) n.refute(v, inc); }
+        else if (type == SWIM_MSG_SUSPECT) n.suspect_v(v, x, inc, from);
+        else n.dead_v(v, x, inc, from);
+        n.cv = v;
+      }
       else n.user_event(best.y, best.z);
       have_last = true; lhi = bhi; llo = blo;
 #ifdef SWIMSIM_DIAG
@@ -3136,6 +3217,18 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = NL;
         c.load();
         c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 0);       // memberlist setAlive
+        if (D.sslt) {
+          // serf.Join: memberlist.Join's state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)),
+          // THEN broadcastJoin(s.clock.Time()) — a rejoining member's intent is newer than any leave intent `via` has seen about it.  The
+          // exchange itself takes a tick here; the clock is witnessed now, when `via` lives on this shard (else the joiner catches up by
+          // gossip).  The intent goes out once the join push-pull is through (the node is alone until then).
+          D.sslt[l] = 0;
+          if (via != x && via >= D.i0 && via < D.i0 + D.nloc && !(D.nw[(size_t)r * D.N + via] & NW_DEAD)) {
+            const uint32_t vclk = HDR((size_t)r * D.nloc + (via - D.i0)).w;
+            if (vclk > c.ev_clock) c.ev_clock = vclk;
+          }
+          c.user_event(SWIM_INTENT_JOIN | x, c.ev_clock, true);
+        }
         c.store();
         q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
       }
@@ -3180,7 +3273,7 @@ __global__ void k_user_event(const SwDev* __restrict__ Dp, uint32_t r, uint32_t 
       c.load();
       uint32_t lt = c.ev_clock; c.ev_clock++;
       *ltime_out = lt;
-      c.user_event(id, lt);
+      c.user_event(id, lt, true);
       c.store();
       q_bit_lane(D, c.l, c.q_became_set(), c.q_became_clr());
     }
@@ -3201,7 +3294,8 @@ __global__ void k_force_leave(const SwDev* __restrict__ Dp, uint32_t r, uint32_t
       c.load();
       uint32_t lt = c.ev_clock; c.ev_clock++;
       *ltime_out = lt;
-      c.user_event(id, lt);
+      if ((id & 0x1FFFFFFFu) == origin && D.sslt) D.sslt[c.l] |= 0x80000000u;      // serf.Leave(): its own leave intent — from now on it does not refute one
+      c.user_event(id, lt, true);
       c.store();
       q_bit_lane(D, c.l, c.q_became_set(), c.q_became_clr());
     }
@@ -3240,6 +3334,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_nodes(const SwDev* __restri
       d += sw_h3(5, g, sw_h3(e.x, ((uint64_t)e.y << 32) | e.z, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8) | m_type(e.w)));
     }
     d += sw_h3(6, g, ((uint64_t)h.z << 32) | h.w);
+    if (D.sslt) { const uint32_t ss = D.sslt[l]; if (ss) d += sw_h3(19, g, ((uint64_t)(ss >> 31) << 32) | (ss & 0x7FFFFFFFu)); }
     for (uint32_t j = 0; j < h_evqlen(h.y); j++) {
       uint4 e = D.evq[(size_t)j * NL + l];
       d += sw_h3(7, g, sw_h3(e.x, e.y, ((uint64_t)m_seq(e.w) << 16) | ((uint64_t)m_tr(e.w) << 8)));
@@ -3275,6 +3370,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_views(const SwDev* __restri
       d += sw_h3(9, id, ((uint64_t)a.y << 32) | a.z);
       if (SW_KST(a.y) >= SWIM_STATE_DEAD && (a.w & 1u)) d += sw_h3(16, id, 1);
       if (SW_KST(a.y) == SWIM_STATE_SUSPECT ? vw_leaving(a.w) : (a.w >> 1) & 1u) d += sw_h3(17, id, 1);
+      if (D.vs) { const uint32_t lt = D.vs[(size_t)sl * NL + l]; if (lt) d += sw_h3(18, id, lt); }
       if (SW_KST(a.y) == SWIM_STATE_SUSPECT) {
         const uint32_t nc = vw_nconf(a.w); const uint4 cf = D.vc[(size_t)sl * NL + l];
         d += sw_h3(10, id, nc);
@@ -3309,6 +3405,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_mass(const SwDev* __restric
       d += sw_h3(9, id, ((uint64_t)e.y << 32) | e.z);
       if (SW_KST(e.y) >= SWIM_STATE_DEAD && (e.w & 1u)) d += sw_h3(16, id, 1);
       if (SW_KST(e.y) == SWIM_STATE_SUSPECT ? vw_leaving(e.w) : (e.w >> 1) & 1u) d += sw_h3(17, id, 1);
+      if (D.mD) { const uint32_t lt = D.mD[idx]; if (lt) d += sw_h3(18, id, lt); }
       if (SW_KST(e.y) == SWIM_STATE_SUSPECT) {
         const uint32_t nc = vw_nconf(e.w);
         d += sw_h3(10, id, nc);
@@ -3399,7 +3496,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reap(const SwDev* __restrict__ Dp)
     if (!ev_ch && D.ev_any) { const uint32_t nw_ = D.ev_watch[(size_t)D.R * SWIM_EVENT_WATCHERS + r]; for (uint32_t j = 0; j < nw_; j++) ev_ch |= D.ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + j] == o; }
     if (ev_ch) {
       uint32_t pos = atomicAdd(D.ev_cnt, 1u);
-      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, e.x, 0, SW_KINC(e.y), o }; D.events[pos] = ev; }
+      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, e.x, SW_KINC(e.y), o, 0 }; D.events[pos] = ev; }
       else atomicOr(D.err, SW_ERR_EVENT_OVF);
     }
   }
@@ -3442,7 +3539,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict_
     // (with the reaper on, a Failed / Left member stays an explicit view until serf has erased it here)
     const bool bad = st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - a.z > D.gossip_to_dead_ms)) ||
                      (D.reap_period && st >= SWIM_STATE_DEAD && sl < D.VT && !(a.w & 1u)) ||
-                     (st == SWIM_STATE_ALIVE && (a.w & 2u));       // (a Leaving mark is not something the base row can hold)
+                     (st == SWIM_STATE_ALIVE && (a.w & 2u)) ||     // (a Leaving mark is not something the base row can hold,
+                     (have && sl < D.VT && D.vs && st < SWIM_STATE_DEAD && D.vs[(size_t)sl * NL + l] != 0);   //  nor a live member's statusLTime: a stale leave intent must stay stale)
     // lanes of a wave mostly hold the same subject in the same slot (one failure per cluster): one atomic set per
     // distinct (subject, key, settled) triple present in the wave
     uint64_t todo = __ballot(have);
@@ -3603,7 +3701,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_mass(const SwDev* __rest
     if (!a || (D.nw[(size_t)r * D.N + D.i0 + k] & NW_INERT)) continue;
     const uint32_t st = MA_STATE(a), key = MA_KEY(a);
     bad |= st == SWIM_STATE_SUSPECT || (st == SWIM_STATE_DEAD && !(now - MB_TICK(D.mB[idx]) * D.quantum_ms > D.gossip_to_dead_ms)) ||
-           (D.reap_period && st >= SWIM_STATE_DEAD && !MA_ERASED(a)) || (st == SWIM_STATE_ALIVE && MA_LEAVING(a));
+           (D.reap_period && st >= SWIM_STATE_DEAD && !MA_ERASED(a)) || (st == SWIM_STATE_ALIVE && MA_LEAVING(a)) ||
+           (D.mD && st < SWIM_STATE_DEAD && D.mD[idx] != 0);        // (a live member's statusLTime stays with the pair)
     cnt++; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax;
   }
   for (int off = 32; off; off >>= 1) {

@@ -191,7 +191,7 @@ class Sim:
 
     def force_leave(self, replica: int, origin: int, node: int, prune: bool = False) -> int:
         """serf.RemoveFailedNode[Prune] called on `origin`; returns the intent's Lamport time."""
-        lt = abi.u32()
+        lt = C.c_uint64()
         self._ck("swim_force_leave", self._l.swim_force_leave(self._h, replica, origin, node, int(prune), C.byref(lt)))
         return lt.value
 
@@ -215,7 +215,7 @@ class Sim:
         self._ck("swim_set_tcp_class", self._l.swim_set_tcp_class(self._h, replica, p, n, tcp_class))
 
     def user_event(self, replica: int, origin: int, event_id: int) -> int:
-        lt = abi.u32()
+        lt = C.c_uint64()
         self._ck("swim_user_event",
                  self._l.swim_user_event(self._h, replica, origin, event_id, C.byref(lt)))
         return lt.value

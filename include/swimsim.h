@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWIM_ABI_VERSION 6u
+#define SWIM_ABI_VERSION 7u
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define SWIM_OK          0
@@ -223,9 +223,10 @@ typedef struct swim_event {
   uint32_t replica;
   uint32_t type;                    /* SWIM_EVENT_*                                         */
   uint32_t node;                    /* member id, or user-event id                          */
-  uint32_t ltime;                   /* user events: Lamport time                            */
   uint32_t incarnation;
   uint32_t observer;                /* whose EventCh this is: cfg.watch_node or a node added with swim_watch_events */
+  uint64_t ltime;                   /* user events: Lamport time (serf.LamportTime is 64 bits, and so is it here since ABI v7; the
+                                       simulated clocks themselves are 31 bits wide: one tick per event, 2^31 events per run)  */
 } swim_event;
 
 /* one entry of a node's TransmitLimitedQueue */
@@ -239,8 +240,9 @@ typedef struct swim_rumour {
 typedef struct swim_node_info {
   uint32_t incarnation;
   uint32_t probe_target, probe_deadline_tick, probe_cursor, probe_epoch;
-  uint32_t queue_len, event_queue_len, event_clock;
+  uint32_t queue_len, event_queue_len;
   uint8_t  alive, leaving, awareness, partition;
+  uint64_t event_clock;             /* serf's event LamportClock.Time() (64 bits in the ABI since v7)                        */
   swim_rumour queue[32];
 } swim_node_info;
 
@@ -393,9 +395,11 @@ int swim_inject_join(swim_sim* sim, uint32_t replica, const uint32_t* ids, size_
  * `node`; every member that holds `node` Failed turns it Left (EventMemberLeave), with prune also erases it at once
  * (EventMemberReap).  Needs SWIM_F_SERF_EVENTS (the intent rides serf's broadcast queue and event-buffer dedupe).
  * The Lamport time stamped on the intent is returned like swim_user_event's. */
-int swim_force_leave(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t node, int prune, uint32_t* ltime_out);
+int swim_force_leave(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t node, int prune, uint64_t* ltime_out);
 #define SWIM_INTENT_LEAVE 0x80000000u   /* event id of a leave intent: SWIM_INTENT_LEAVE | prune << 30 | node */
 #define SWIM_INTENT_PRUNE 0x40000000u
+#define SWIM_INTENT_JOIN 0xA0000000u    /* event id of a join intent (serf messageJoinType): SWIM_INTENT_JOIN | node — what serf.Join broadcasts after the
+                                           join push-pull, and what a member answers a leave intent about ITSELF with while it is not leaving (the refutation) */
 /* partition mask: nodes exchange packets only within the same group id (config #4) */
 int swim_inject_partition(swim_sim* sim, uint32_t replica, const uint8_t* group_of_node);
 int swim_set_loss(swim_sim* sim, uint32_t loss_q32);
@@ -409,7 +413,7 @@ int swim_set_tcp_class(swim_sim* sim, uint32_t replica, const uint32_t* ids, siz
 /* serf.UserEvent(name, payload, coalesce=false) (agent/consul/server_ce.go:125-131):
  * event_id stands for hash(name,payload); returns the Lamport time stamped on it */
 int swim_user_event(swim_sim* sim, uint32_t replica, uint32_t origin, uint32_t event_id,
-                    uint32_t* ltime_out);
+                    uint64_t* ltime_out);
 /* user-event ids are 30 bits: bits 31-30 of the id word distinguish serf's intent messages (messageLeaveType; SWIM_INTENT_*)
  * from user events on the shared broadcast queue.  A larger id is refused (SWIM_ERANGE) — never reinterpreted as an intent. */
 #define SWIM_EVENT_ID_MAX 0x3FFFFFFFu

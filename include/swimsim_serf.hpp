@@ -126,6 +126,7 @@ struct Config {
   memberlist::Config MemberlistConfig;
   Duration ReapInterval{15000}, ReconnectTimeout{24 * 3600 * 1000}, TombstoneTimeout{24 * 3600 * 1000};
   Duration LeavePropagateDelay{1000};
+  Duration BroadcastTimeout{5000};         // serf.DefaultConfig: how long Leave() waits for its intent to be sent out
   int EventBuffer = 512, UserEventSizeLimit = 512, MaxQueueDepth = 4096, MinQueueDepth = 0;
   uint8_t ProtocolVersion = 4;
   // serf.Config.Merge (MergeDelegate.NotifyMerge): called with the members a join / push-pull would merge; a non-empty string
@@ -363,12 +364,25 @@ class Serf {
     }
     return contacted;
   }
-  // Leave: broadcast the intent (memberlist dead{Node==From} => StatusLeft at every peer)
+  // Leave, as serf.Leave does it: (1) the member's own leave intent, stamped clock.Time() (every peer: StatusLeaving — and from now on
+  // this member does not refute a leave intent about itself), (2) wait until the intent has used up its transmissions, at most
+  // BroadcastTimeout, (3) memberlist's leave (dead{Node == From} => StatusLeft at every peer), (4) LeavePropagateDelay
+  // (internal/gossip/libserf/serf.go:29-35; consumer agent/consul/server_serf.go:270-297).
   void Leave() {
     if (state_ == SerfLeft) return;
     if (state_ == SerfLeaving) throw Error("Leave: Leave already in progress", SWIM_ESTATE);
     if (state_ == SerfShutdown) throw Error("Leave: Leave called after Shutdown", SWIM_ESTATE);
     state_ = SerfLeaving;
+    uint64_t lt = 0;
+    if (pool_->config().flags & SWIM_F_SERF_EVENTS) {
+      check(swim_force_leave(pool_->handle(), replica_, id_, id_, 0, &lt), "swim_force_leave");
+      const Duration step = roundUp(Duration(pool_->config().gossip_interval_ms));
+      for (Duration waited{0}; waited < conf_.BroadcastTimeout; waited += step) {        // notifyCh: the broadcast is finished
+        swim_node_info ni; check(swim_node_info_get(pool_->handle(), replica_, id_, &ni), "swim_node_info_get");
+        if (!ni.event_queue_len) break;
+        pool_->Advance(step);
+      }
+    }
     check(swim_inject_leave(pool_->handle(), replica_, &id_, 1), "swim_inject_leave");
     pool_->Advance(roundUp(conf_.LeavePropagateDelay));
     state_ = SerfLeft;
@@ -383,7 +397,7 @@ class Serf {
     requireNotShutdown("UserEvent");
     if ((int)(name.size() + payload.size()) > conf_.UserEventSizeLimit)
       throw Error("user event exceeds configured limit of " + std::to_string(conf_.UserEventSizeLimit) + " bytes before encoding", SWIM_EINVAL);
-    uint32_t id = eventId(name, payload), lt = 0;
+    uint32_t id = eventId(name, payload); uint64_t lt = 0;
     catalog()[id] = { name, payload, coalesce };
     check(swim_user_event(pool_->handle(), replica_, id_, id, &lt), "swim_user_event");
   }
@@ -429,7 +443,7 @@ class Serf {
   }
   void forceLeave(const std::string& node, bool prune) {
     requireNotShutdown("RemoveFailedNode");
-    uint32_t lt = 0;
+    uint64_t lt = 0;
     check(swim_force_leave(pool_->handle(), replica_, id_, idOf(node), prune ? 1 : 0, &lt), "swim_force_leave");
   }
   // "node-7", "10.0.0.7" or "10.0.0.7:8301" -> 7

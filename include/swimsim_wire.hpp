@@ -154,6 +154,8 @@ struct AckResp { uint32_t seq_no = 0; Bytes payload; };
 struct NackResp { uint32_t seq_no = 0; };
 // serf messages.go messageUserEvent
 struct UserEvent { uint64_t ltime = 0; std::string name; Bytes payload; bool cc = false; };
+// serf messages.go messageLeave {LTime, Node, Prune} / messageJoin {LTime, Node}: the intents (SWIM_INTENT_* event ids in the simulator)
+struct SerfIntent { bool join = false; uint64_t ltime = 0; std::string node; bool prune = false; };
 
 inline Bytes encode(const Alive& m) {
   Bytes b{kAlive}; Writer w{b};
@@ -194,6 +196,12 @@ inline Bytes encode(const AckResp& m) {
   return b;
 }
 inline Bytes encode(const NackResp& m) { Bytes b{kNackResp}; Writer w{b}; w.map(1); w.str("SeqNo"); w.uint(m.seq_no); return b; }
+inline Bytes encode(const SerfIntent& m) {
+  Bytes b{kUser, uint8_t(m.join ? kSerfJoin : kSerfLeave)}; Writer w{b};
+  if (m.join) { w.map(2); w.str("LTime"); w.uint(m.ltime); w.str("Node"); w.str(m.node); }
+  else { w.map(3); w.str("LTime"); w.uint(m.ltime); w.str("Node"); w.str(m.node); w.str("Prune"); w.boolean(m.prune); }
+  return b;
+}
 // a serf user event as memberlist carries it: userMsg, then serf's own type byte, then the msgpack struct
 inline Bytes encode(const UserEvent& m) {
   Bytes b{kUser, kSerfUserEvent}; Writer w{b};
@@ -548,7 +556,12 @@ inline Bytes to_wire(const swim_edge& e, const Naming& nm = Naming()) {
     case SWIM_MSG_ALIVE: { Alive a; a.incarnation = e.incarnation; a.node = nm.name_of(e.subject); a.addr = nm.addr_of(e.subject); a.port = nm.port; a.vsn = nm.vsn; return encode(a); }
     case SWIM_MSG_SUSPECT: return encode_suspect(Suspect{ e.incarnation, nm.name_of(e.subject), nm.name_of(from) });
     case SWIM_MSG_DEAD: return encode_dead(Dead{ e.incarnation, nm.name_of(e.subject), nm.name_of(from) });
-    default: { UserEvent u; u.ltime = e.incarnation; u.name = nm.event_name;
+    default: {
+      if (e.subject & SWIM_INTENT_LEAVE) {           // one of serf's intents: messageLeave / messageJoin, not a user event
+        SerfIntent it; it.join = (e.subject & SWIM_INTENT_JOIN) == SWIM_INTENT_JOIN; it.ltime = e.incarnation; it.node = nm.name_of(e.subject & 0x1FFFFFFFu);
+        it.prune = !it.join && (e.subject & SWIM_INTENT_PRUNE) != 0; return encode(it);
+      }
+      UserEvent u; u.ltime = e.incarnation; u.name = nm.event_name;
                u.payload = Bytes{ uint8_t(e.subject >> 24), uint8_t(e.subject >> 16), uint8_t(e.subject >> 8), uint8_t(e.subject) }; return encode(u); }
   }
 }
@@ -589,7 +602,17 @@ inline std::vector<swim_edge> from_packet(const Bytes& packet, const Naming& nm 
         out.push_back(swim_edge{ 0, id, s.incarnation, uint32_t(m[0] == kSuspect ? SWIM_MSG_SUSPECT : SWIM_MSG_DEAD) << 30 | (from & 0x3FFFFFFFu) }); break;
       }
       case kUser: {
-        if (n < 1 || body[0] != kSerfUserEvent) { n_control++; break; }       // serf joins/leaves/queries: not modelled
+        if (n >= 1 && (body[0] == kSerfLeave || body[0] == kSerfJoin)) {       // serf's intents: {LTime, Node[, Prune]}
+          SerfIntent it; it.join = body[0] == kSerfJoin;
+          decode_map(body + 1, n - 1, [&](const std::string& k, Reader& r) {
+            if (k == "LTime") it.ltime = r.uint(); else if (k == "Node") it.node = r.str(); else if (k == "Prune") it.prune = r.boolean(); else return false;
+            return true;
+          });
+          uint32_t id;
+          if (!nm.id_of(it.node, &id) || id > 0x0FFFFFFFu) { n_foreign++; break; }
+          out.push_back(swim_edge{ 0, (it.join ? SWIM_INTENT_JOIN : SWIM_INTENT_LEAVE | (it.prune ? SWIM_INTENT_PRUNE : 0u)) | id, uint32_t(it.ltime), uint32_t(SWIM_MSG_USER) << 30 }); break;
+        }
+        if (n < 1 || body[0] != kSerfUserEvent) { n_control++; break; }       // serf queries etc.: not modelled
         UserEvent u = decode_user_event(body + 1, n - 1);
         uint32_t id = 0; for (size_t i = 0; i < u.payload.size() && i < 4; i++) id = id << 8 | u.payload[i];
         id &= SWIM_EVENT_ID_MAX;                                                   // (bits 31-30 of an id word mark serf's intents)

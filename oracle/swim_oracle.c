@@ -242,7 +242,10 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
 
 /* one explicit view: what an observer knows about `subj` beyond the replica's base row */
-typedef struct { uint32_t subj, key, since, conf[CONF_MAX], n0; uint8_t nconf, reaped, leaving; } view_t;   /* n0 = estNumNodes() when the suspicion started; reaped = serf erased the member (handleReap / prune); leaving = a leave intent was seen while the member was alive here (serf StatusLeaving) */
+/* n0 = estNumNodes() when the suspicion started; reaped = serf erased the member (handleReap / prune); leaving = a leave intent was seen while
+ * the member was alive here (serf StatusLeaving); slt = serf's member.statusLTime: the Lamport time of the last join / leave intent applied
+ * to the member here (0: none) */
+typedef struct { uint32_t subj, key, since, conf[CONF_MAX], n0, slt; uint8_t nconf, reaped, leaving; } view_t;
 /* an observer's explicit views: open addressing (linear probing, backward-shift deletion), grown on demand, at most
  * cfg.view_cap entries (+1 for the node's view of itself).  Layout is private to this file: everything observable
  * (digest, census, members) is keyed by (observer, subject). */
@@ -259,6 +262,8 @@ typedef uint32_t evslot;      /* an event-buffer slot is `ev_words` words: ltime
 typedef struct {
   uint32_t self_inc;
   uint8_t awareness, leaving;
+  uint8_t serf_leaving;                        /* this agent has broadcast its own leave intent (serf.Leave: state SerfLeaving) — it no longer refutes one */
+  uint32_t self_slt;                           /* statusLTime of the agent's own member entry */
   uint32_t qlen, qseq; qent* q;                 /* [queue_cap] in one slab for all nodes */
   uint32_t pr_target, pr_inc, pr_t0, pr_deadline, pr_cursor, pr_epoch; uint8_t pr_stage, pr_nack_miss;
   /* serf */
@@ -344,7 +349,7 @@ static void record_event(swim_sim* s, uint32_t r, uint32_t type, uint32_t node, 
     s->cap_events = s->cap_events ? s->cap_events * 2 : 256;
     s->events = (swim_event*)realloc(s->events, s->cap_events * sizeof(swim_event));
   }
-  swim_event e = { now_ms(s), r, type, node, ltime, inc, s->ev_observer };
+  swim_event e = { now_ms(s), r, type, node, inc, s->ev_observer, ltime };
   s->events[s->n_events++] = e;
 }
 /* does observer o of replica r have an EventCh (cfg.watch_node, or added with swim_watch_events)?  Notes whose event comes next. */
@@ -672,23 +677,36 @@ static void dead_node(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t 
  * (EventMemberLeave); with prune it is erased at once (EventMemberReap), also when it was Left already.  A member that is
  * Alive or Suspect here is marked Leaving: when memberlist declares it dead it becomes Left, not Failed.  The Lamport
  * ordering of the intent against the member's status time is not modelled. */
-static void leave_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, int prune) {
-  (void)nd;
-  if (x >= s->N || x == o) return;
+static void user_event_from(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime, int origin);
+/* serf.go handleNodeLeaveIntent.  Returns whether the intent is rebroadcast (serf's return value).  Order: the member's statusLTime
+ * (a stale intent — one stamped no later than the last join / leave intent applied to the member here — is ignored), then the refutation
+ * (an intent about this agent itself while it is not leaving: broadcastJoin(clock.Time())), then the transition by status.
+ * Not modelled: serf's recentIntents buffer (an intent about a member this node has never heard of is passed on, not remembered). */
+static int leave_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, int prune, uint32_t ltime) {
+  if (x >= s->N) return 0;
+  if (x == o) {
+    if (ltime <= nd->self_slt) return 0;
+    if (!nd->serf_leaving) { user_event_from(s, r, o, nd, SWIM_INTENT_JOIN | o, nd->ev_clock, 1); return 0; }   /* refute: go s.broadcastJoin(s.clock.Time()) */
+    nd->self_slt = ltime;                                  /* its own Leave(): StatusLeaving until memberlist's leave goes out */
+    return 1;
+  }
   view_t* v = view_ptr(s, r, o, x);
   uint32_t key = v ? v->key : implicit_key(s, r, o, x), st = KST(key);
-  if (KINC(key) == 0) return;
+  if (KINC(key) == 0) return 1;                            /* never heard of it (serf: upsertIntent into recentIntents, rebroadcast) */
+  if (ltime <= (v ? v->slt : 0u)) return 0;                /* "If the message is old, then it is irrelevant and we can skip it" */
   if (st < SWIM_STATE_DEAD) {                              /* alive (or suspected) here: StatusLeaving — its death will read as a leave */
-    if (!v && !(v = view_make(s, r, o, x))) return;
+    if (!v && !(v = view_make(s, r, o, x))) return 1;
+    v->slt = ltime;
     if (!v->leaving) { v->leaving = 1; touch_slot(s, r, x); }
-    return;
+    return 1;
   }
   /* erased already (serf no longer has the member; a Failed / Left member of the base row was erased before it got there) */
-  if (v ? v->reaped : s->d.reap_period_ticks != 0) return;
-  if (st == SWIM_STATE_LEFT && !prune) return;
-  if (!v && !(v = view_make(s, r, o, x))) return;
+  if (v ? v->reaped : s->d.reap_period_ticks != 0) return 1;
+  if (st == SWIM_STATE_LEFT && !prune) return 1;           /* StatusLeaving, StatusLeft: nothing but the prune */
+  if (!v && !(v = view_make(s, r, o, x))) return 1;
   if (st == SWIM_STATE_DEAD) {
     set_view(s, r, x, v, KINC(key), SWIM_STATE_LEFT, 1);
+    v->slt = ltime;
     s->st.intents_applied++;
     if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_MEMBER_LEAVE, x, 0, KINC(key));
   }
@@ -696,11 +714,26 @@ static void leave_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32
     v->reaped = 1; s->st.reaped++; touch_slot(s, r, x);
     if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_MEMBER_REAP, x, 0, KINC(key));
   }
+  return 1;
+}
+/* serf.go handleNodeJoinIntent: a newer join intent moves the member's statusLTime and takes a Leaving mark back ("the leaving message
+ * must have been for an older time") */
+static int join_intent(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t x, uint32_t ltime) {
+  if (x >= s->N) return 0;
+  if (x == o) { if (ltime <= nd->self_slt) return 0; nd->self_slt = ltime; return 1; }
+  view_t* v = view_ptr(s, r, o, x);
+  uint32_t key = v ? v->key : implicit_key(s, r, o, x);
+  if (KINC(key) == 0 || (v ? v->reaped : (KST(key) >= SWIM_STATE_DEAD && s->d.reap_period_ticks != 0))) return 1;     /* not a member here: passed on */
+  if (ltime <= (v ? v->slt : 0u)) return 0;
+  if (!v && !(v = view_make(s, r, o, x))) return 1;
+  v->slt = ltime;
+  if (v->leaving && KST(key) < SWIM_STATE_DEAD) { v->leaving = 0; touch_slot(s, r, x); }
+  return 1;
 }
 
 /* serf.go handleUserEvent + lamport.go Witness (Consul fires via server_ce.go:125-131 and
  * consumes at server_serf.go:283, client_serf.go:98) */
-static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime) {
+static void user_event_from(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime, int origin) {
   if (!nd->ring) return;
   if (ltime >= nd->ev_clock) nd->ev_clock = ltime + 1;                 /* Witness */
   uint32_t cur = nd->ev_clock, bl = s->cfg.event_buffer;
@@ -711,13 +744,17 @@ static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t
   } else { sl[0] = ltime; sl[1] = 0; }
   if (sl[1] == s->ev_words - 2) { s->st.event_drops++; return; }
   sl[2 + sl[1]++] = id;
-  if (id & SWIM_INTENT_LEAVE) leave_intent(s, r, o, nd, id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0);
-  else {
+  if (id & SWIM_INTENT_LEAVE) {                            /* bit 31: one of serf's intents; rebroadcast as the handler says (the origin always sends) */
+    const int again = (id & SWIM_INTENT_JOIN) == SWIM_INTENT_JOIN ? join_intent(s, r, o, nd, id & 0x1FFFFFFFu, ltime)
+                                                                  : leave_intent(s, r, o, nd, id & 0x1FFFFFFFu, (id & SWIM_INTENT_PRUNE) != 0, ltime);
+    if (!again && !origin) return;
+  } else {
     s->st.user_events_delivered++;
     if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
   }
   queue_push(s, nd->evq, &nd->evqlen, &nd->evqseq, s->cfg.event_queue_cap, 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
 }
+static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime) { user_event_from(s, r, o, nd, id, ltime, 0); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* tick phases                                                                                 */
@@ -1307,6 +1344,7 @@ static void fold_census(swim_sim* s) {
          * EventMemberReap must not be lost); in the base row it reads as erased */
         if (s->d.reap_period_ticks && st >= SWIM_STATE_DEAD && unreaped) s->f_bad[g] = 1;
         if (i < t->slots && t->e[i].leaving) s->f_bad[g] = 1;     /* a Leaving mark is not something the base row can hold */
+        if (i < t->slots && t->e[i].slt && st < SWIM_STATE_DEAD) s->f_bad[g] = 1;   /* ... nor a live member's statusLTime (a stale leave intent must stay stale) */
       }
     }
   for (uint32_t i = 0; i < s->f_ntouched; i++) {
@@ -1718,6 +1756,14 @@ int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uin
     nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->pr_nack_miss = 0;
     if (KINC(s->base_key[g]) != 0 || nd->self_inc > 1 || nd->qseq) nd->self_inc++;   /* a restart: past the incarnation others may remember */
     broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 0);   /* memberlist setAlive */
+    nd->serf_leaving = 0; nd->self_slt = 0;
+    if (nd->ring) {
+      /* serf.Join: memberlist.Join's state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)),
+       * THEN broadcastJoin(s.clock.Time()) — so a rejoining member's intent is newer than any leave intent `via` has seen about it.  The
+       * exchange itself takes a tick here; the clock is witnessed now, when `via` lives on this shard (else the joiner catches up by gossip). */
+      if (is_local(s, via) && s->gt_alive[(size_t)r * s->N + via] && via != x) { const node_t* vn = node_at(s, r, via); if (vn->ev_clock > nd->ev_clock) nd->ev_clock = vn->ev_clock; }
+      user_event_from(s, r, x, nd, SWIM_INTENT_JOIN | x, nd->ev_clock, 1);     /* goes out once the join push-pull is through (the node is alone until then) */
+    }
   }
   dirty_all(s, r); return SWIM_OK;
 }
@@ -1735,11 +1781,11 @@ int swim_set_tcp_class(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, u
 int swim_set_loss(swim_sim* s, uint32_t q) { if (!s) return SWIM_EINVAL; s->loss_q32 = q; return SWIM_OK; }
 
 /* serf.UserEvent: stamp eventClock.Time(), Increment(), handleUserEvent locally, queue */
-int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint32_t* lt) {
+int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint64_t* lt) {
   int rc = chk(s, r, &origin, 1); if (rc) return rc;
   if (!(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
   if (id > SWIM_EVENT_ID_MAX) return SWIM_ERANGE;           /* bits 31-30 mark serf's intents (messageLeaveType), never a user event */
-  if (lt) *lt = SWIM_NONE;
+  if (lt) *lt = UINT64_MAX;
   if (!is_local(s, origin) || !s->gt_alive[(size_t)r * s->N + origin]) return SWIM_OK;
   node_t* nd = node_at(s, r, origin);
   uint32_t ltime = nd->ev_clock; nd->ev_clock++;
@@ -1750,16 +1796,17 @@ int swim_user_event(swim_sim* s, uint32_t r, uint32_t origin, uint32_t id, uint3
 
 /* serf.RemoveFailedNode[Prune]: broadcast a leave intent on behalf of `node` (stamped with the origin's clock like any
  * serf message, handled locally first, queued for gossip) */
-int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint32_t* lt) {
+int swim_force_leave(swim_sim* s, uint32_t r, uint32_t origin, uint32_t node, int prune, uint64_t* lt) {
   int rc = chk(s, r, &origin, 1); if (rc) return rc;
   if (node >= s->N) return SWIM_ERANGE;
   if (!(s->cfg.flags & SWIM_F_SERF_EVENTS)) return SWIM_ESTATE;
-  if (lt) *lt = SWIM_NONE;
+  if (lt) *lt = UINT64_MAX;
   if (!is_local(s, origin) || !s->gt_alive[(size_t)r * s->N + origin]) return SWIM_OK;
   node_t* nd = node_at(s, r, origin);
   uint32_t ltime = nd->ev_clock; nd->ev_clock++;
   if (lt) *lt = ltime;
-  user_event(s, r, origin, nd, SWIM_INTENT_LEAVE | (prune ? SWIM_INTENT_PRUNE : 0u) | node, ltime);
+  if (node == origin) nd->serf_leaving = 1;                /* serf.Leave(): its own leave intent — from now on it does not refute one */
+  user_event_from(s, r, origin, nd, SWIM_INTENT_LEAVE | (prune ? SWIM_INTENT_PRUNE : 0u) | node, ltime, 1);
   return SWIM_OK;
 }
 static uint8_t status_of(uint32_t st) {
@@ -1909,6 +1956,7 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
         d += h3(5, g, h3(e->subject, ((uint64_t)e->inc << 32) | e->from, ((uint64_t)e->seq << 16) | ((uint64_t)e->transmits << 8) | e->type));
       }
       d += h3(6, g, ((uint64_t)nd->qseq << 32) | nd->ev_clock);
+      if (nd->self_slt | nd->serf_leaving) d += h3(19, g, ((uint64_t)nd->serf_leaving << 32) | nd->self_slt);
       for (uint32_t q = 0; q < nd->evqlen; q++) {
         const qent* e = &nd->evq[q];
         d += h3(7, g, h3(e->subject, e->inc, ((uint64_t)e->seq << 16) | ((uint64_t)e->transmits << 8)));
@@ -1925,6 +1973,7 @@ int swim_state_digest(swim_sim* s, uint64_t* out) {
         d += h3(9, id, ((uint64_t)v->key << 32) | v->since);
         if (v->reaped) d += h3(16, id, 1);
         if (v->leaving) d += h3(17, id, 1);
+        if (v->slt) d += h3(18, id, v->slt);
         if (KST(v->key) == SWIM_STATE_SUSPECT) {
           d += h3(10, id, v->nconf);
           /* the accusers that can still matter: Confirm() returns early once k confirmations are in, so the name of the

@@ -49,6 +49,20 @@ int main() {
     Alive d = decode_alive(alive.data() + 1, alive.size() - 1);
     CHECK(d.incarnation == 300 && d.node == "node-5" && d.addr == a.addr && d.port == 8301 && d.meta.empty() && d.vsn == a.vsn); }
 
+  // ---- serf's intents ride memberlist's user message: [userMsg 8][serf type 0 = leave / 1 = join][msgpack struct] (serf messages.go)
+  //      messageLeave{LTime: 9, Node: "node-7", Prune: false}; messageJoin{LTime: 300, Node: "node-7"}
+  { SerfIntent lv; lv.ltime = 9; lv.node = "node-7";
+    CHECK(encode(lv) == hex("08 00 83 a5 4c 54 69 6d 65 09 a4 4e 6f 64 65 a6 6e 6f 64 65 2d 37 a5 50 72 75 6e 65 c2"));
+    SerfIntent jn; jn.join = true; jn.ltime = 300; jn.node = "node-7";
+    CHECK(encode(jn) == hex("08 01 82 a5 4c 54 69 6d 65 cd 01 2c a4 4e 6f 64 65 a6 6e 6f 64 65 2d 37"));
+    // ... and back: the simulator's event ids (SWIM_INTENT_*), never a user event
+    size_t control = 0, foreign = 0;
+    std::vector<swim_edge> a = from_packet(encode(lv), Naming(), &control, &foreign), b = from_packet(encode(jn), Naming(), &control, &foreign);
+    CHECK(a.size() == 1 && a[0].subject == (SWIM_INTENT_LEAVE | 7u) && a[0].incarnation == 9 && (a[0].meta >> 30) == SWIM_MSG_USER);
+    CHECK(b.size() == 1 && b[0].subject == (SWIM_INTENT_JOIN | 7u) && b[0].incarnation == 300);
+    lv.prune = true; a = from_packet(encode(lv)); CHECK(a.size() == 1 && a[0].subject == (SWIM_INTENT_LEAVE | SWIM_INTENT_PRUNE | 7u));
+    CHECK(to_wire(a[0]) == encode(lv) && to_wire(b[0]) == encode(jn)); }
+
   // ---- nackResp{SeqNo: 42}; ackResp{SeqNo: 70000, Payload: nil}; ping with the omitempty Source* fields absent / present
   CHECK(encode(NackResp{42}) == hex("0b 81 a5 53 65 71 4e 6f 2a"));
   CHECK(encode(AckResp{70000, {}}) == hex("02 82 a5 53 65 71 4e 6f ce 00 01 11 70 a7 50 61 79 6c 6f 61 64 c0"));

@@ -19,8 +19,10 @@ BUDGET = {
     "k_beginILi8ELb1ELb1ELb1ELb0E": (96, 128, 5),  # the heaviest one (fan-out 8, serf events, sharded, dense store)
     "9k_deliverILb0ELb0EE": (64, 0, 7),
     "9k_deliverILb0ELb1EE": (96, 0, 5),        # tile buckets: the per-tile drain, four records per lane in flight
-    "9k_resolveILb0EE": (128, 64, 4),          # the call frame of the in-place heapsort of big inboxes (cold path)
-    "9k_resolveILb1EE": (128, 64, 4),
+    "9k_resolveILb0ELb0EE": (128, 32, 4),      # the bench's instantiation: no dense store, no serf event layer (user-event / intent handlers not compiled in)
+    "9k_resolveILb1ELb0EE": (128, 32, 4),      # ... the dense pair store (config #4's leg)
+    "9k_resolveILb0ELb1EE": (128, 128, 4),     # ... serf's event layer: intents with their statusLTime ordering, the event buffer (cold paths that spill)
+    "9k_resolveILb1ELb1EE": (128, 128, 4),     # ... both (config #5's leg)
     "8k_censusPK": (32, 0, 8),
     "8k_finishPK": (64, 0, 8),
     "7k_quietPK": (40, 0, 8),
