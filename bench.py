@@ -11,8 +11,10 @@ dissemination -> quiescence).  A "step" is one gossip round = GossipInterval/qua
 whole pipeline (timers, probe, gossip select/emit, delivery, merge) for every node.
 
 At N>1 every replica's node population is block-partitioned over the N ranks (one process per
-GPU) and cross-shard gossip records ride a per-tick all-to-all over RCCL; the replica count grows
-with N so per-GPU work is fixed (weak scaling).
+GPU) and cross-shard gossip records cross once per tick — by default through the library's own
+exchange (peer-mapped mailboxes over xGMI, no host round trip: `--exchange library`), with the
+split tick + RCCL all-to-all (`--exchange rccl`) timed beside it as `exchange.other`; the replica
+count grows with N so per-GPU work is fixed (weak scaling).
 
 One JSON line on stdout (rank 0).  `roofline` is for the kernel that dominates the timed region,
 timed with HIP events on the simulator's stream in a second, instrumented pass of the same region
@@ -20,7 +22,9 @@ timed with HIP events on the simulator's stream in a second, instrumented pass o
 plain-C oracle on the host cores, one thread and all cores, on a bounded sample of the same scenario.
 Legs that do not depend on --steps/--warmup, so that every line carries them: `detection` (config #2's
 deliverable: kill at t = 5 s, run until every replica's survivors all know), `config4` (524 288 nodes on this
-GPU, 5 % cut off at once, bounded views) and `convergence` (config #3).
+GPU = one GPU's share of BASELINE configs[3], 5 % stopped at once, every (survivor, victim) view kept in the dense
+pair store, run to full detection), `config5` (churn + user-event flood) and `convergence` (config #3).
+Numbers that are quoted from committed profiles rather than measured by this run sit under keys named `quoted_from_profiles`.
 """
 from __future__ import annotations
 
@@ -41,11 +45,29 @@ from consul_amd import abi  # noqa: E402
 from consul_amd.sim import Sim, preset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRAFFIC_NOTE = ("profiles/r03_pmc_driver.json (driver window, one handle, per launch; FETCH_SIZE / WRITE_SIZE in separate --pmc passes): k_resolve 103 MB as "
-                "counted (54 fetch + 49 write) / 157 MB with the guide's x2 on FETCH_SIZE — calibrated for wide coalesced reads only, these kernels "
-                "scatter 16-64 B, so quote 13-20x the algorithmic 7.8 MB; k_begin 94 / 168 MB (1.2-2.2x of 75.6), k_deliver 46 / 63 MB (3.2-4.3x of 14.6).  "
-                "L2 requests per second (profiles/r03_pmc_l2_all_ticks.txt) against the 56-60 G/s the scattered-access probe reaches out of HBM "
-                "(profiles/r03_scatter_l2_requests.txt): k_begin 32 G/s, k_deliver 34 G/s, k_resolve 27 G/s")
+PMC_FILES = ("r04_pmc_driver.json", "r03_pmc_driver.json")     # HBM bytes per launch, newest first (tools/pmc_traffic_pass.sh over the driver's window)
+
+
+def _pmc():
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)) as f:
+                return name, json.load(f)
+        except (OSError, ValueError):
+            continue
+    return None, {}
+
+
+def traffic_note() -> str:
+    """What the committed --pmc passes say, per tick kernel — built from the file, so it cannot lag behind it."""
+    name, d = _pmc()
+    if not name:
+        return "no committed --pmc passes"
+    parts = [f"{k} {v['fetch_bytes_per_launch_raw'] / 1e6 + v['write_bytes_per_launch'] / 1e6:.0f} MB as counted "
+             f"({v['fetch_bytes_per_launch_raw'] / 1e6:.0f} fetch + {v['write_bytes_per_launch'] / 1e6:.0f} write) / {v['hbm_bytes_per_launch'] / 1e6:.0f} MB with the guide's x2 on FETCH_SIZE"
+             for k, v in d.items() if k in ("k_begin", "k_deliver", "k_resolve")]
+    return (f"profiles/{name} (driver window, one handle, per launch; FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, not measured by this run): "
+            + "; ".join(parts) + ".  The x2 is calibrated for wide coalesced reads; these kernels scatter 16-64 B, so both figures are quoted.")
 
 
 def victims_for(seed: int, reps: int, n: int):
@@ -186,11 +208,7 @@ def traffic_from_pmc(kernel: str, virtual_nodes: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of the
     same window, FETCH_SIZE doubled as the guide prescribes for gfx950; tools/pmc_traffic_pass.sh), if they were taken on this
     workload — counters cannot be collected inside this process, so the line quotes the file; None when there is none to quote."""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_driver.json")) as f:
-            k = json.load(f).get(kernel)
-    except (OSError, ValueError):
-        return None
+    k = _pmc()[1].get(kernel)
     if not k or k.get("workload_nodes") != virtual_nodes:
         return None
     return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "as_counted": k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch"]}
@@ -215,12 +233,12 @@ def roofline_of(prof: dict, st: dict, wall_s=None, virtual_nodes=0) -> dict:
            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
            "headline_rule": "lowest algorithmic fraction among kernels with >= 20 % of the region's kernel time",
            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE), not from this run:
-           "traffic_source": TRAFFIC_NOTE,
+           "traffic_source": traffic_note(),
            # what the chip delivers for the access pattern these kernels have (tools/scatter_roofline.hip, 8 GB working set,
            # 8 waves per SIMD): dependent 64-byte-line gathers 3.1 TB/s, 16-byte gathers 0.66 TB/s (41 G accesses/s), 16-byte
            # scattered stores 0.36 TB/s, returning 4-byte atomics 20-27 G/s
-           "scatter_ceiling": {"line_64B_GBps": 3112.0, "gather_16B_GBps": 661.0, "gather_16B_Gacc_per_s": 41.3, "store_16B_GBps": 357.0,
-                               "atomic_4B_Gacc_per_s": 19.7, "frac_of_64B_line_ceiling": achieved / 3112.0, "source": "profiles/r03_scatter_roofline.txt"},
+           "quoted_from_profiles": {"scatter_ceiling": {"line_64B_GBps": 3112.0, "gather_16B_GBps": 661.0, "gather_16B_Gacc_per_s": 41.3, "store_16B_GBps": 357.0,
+                                                        "atomic_4B_Gacc_per_s": 19.7, "source": "profiles/r03_scatter_roofline.txt (tools/scatter_roofline.hip; not re-measured by this run)"}},
            "avg_launch_us": 1e6 * avg_s, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
            "kernel_time_share": {k: round(v[1] / total_ms, 4) for k, v in prof.items()},
            "per_kernel": {k: {"avg_launch_us": 1e3 * v[1] / max(v[0], 1), "launches": v[0],
@@ -280,8 +298,13 @@ def run_detection(hip, cfg_kw, victims, G, quantum_ms) -> dict:
             "compared_with": {
                 "first_dead_minus_first_suspect_ms": {"min": gaps[0], "median": gaps[len(gaps) // 2], "max": gaps[-1]} if gaps else None,
                 "suspicion_timeout_min_ms": int(sim_derived_min_timeout(cfg_kw["n_nodes"])),
-                "async_model": "tests/test_async_reference.py — event-driven, continuous time, per-packet latency (tests/reference_model/): medians async / "
-                               "lock-step at 128 nodes first Dead 10.10 / 10.20 s, everybody knows 10.51 / 10.80 s; at 1 024 nodes 13.97 / 13.80 s, 14.61 / 14.70 s"}}
+                "quoted_from_profiles": {
+                    "async_model": "tests/test_async_reference.py — event-driven, continuous time, per-packet latency (tests/reference_model/): medians async / "
+                                   "lock-step at 128 nodes first Dead 10.10 / 10.20 s, everybody knows 10.51 / 10.80 s; at 1 024 nodes 13.97 / 13.80 s, 14.61 / 14.70 s",
+                    # north_star asks for +-1 round against memberlist; against the asynchronous model the lock-step determinisation is on time
+                    # for first suspicion and first Dead and LATE on the last leg (a verdict is merged at the end of its tick and broadcasts
+                    # on pings arrive a tick later): say so next to the numbers
+                    "all_know_dead_is_late_by_gossip_rounds": 1.45}}}
 
 
 def run_config4(hip, args, device) -> dict:
@@ -336,8 +359,8 @@ def run_config4(hip, args, device) -> dict:
            # what would cross xGMI if this population were one of 8 shards: 7/8 of the records, 16 bytes each
            "a2a_bytes_per_tick_if_one_of_8_shards": {"mean": 16.0 * 7 / 8 * st["edges"] / max(ticks, 1)},
            "pair_store_GB": round(12.0 * (nv + 8) * n / 1e9, 1),
-           "queue_cap_cost": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
-                              "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}},
+           "quoted_from_profiles": {"queue_cap_cost": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
+                                                       "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}}},
            "curve": curve[:12] + curve[12::4]}
     s.close()
     return out
@@ -346,10 +369,13 @@ def run_config4(hip, args, device) -> dict:
 def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, barrier, allreduce_max) -> dict:
     """BASELINE configs[3] across the ranks: one population block-partitioned over the GPUs, 5 % stopped at once, the 30 s after
     the failure (the phase in which every node learns of every victim: the exchange carries ~(world-1)/world of all records).
-    262 144 nodes / 13 107 victims whatever the number of ranks: a state exchange that crosses a shard boundary arrives UNFILTERED
-    (a shard cannot read a remote receiver's view), i.e. with every explicit view of the sender — ~2 500 of them 30 s after the
-    failure, all 13 107 later — and the inbox has to hold it: 8 192 slots here, the most `k_inbox_sort` sorts in LDS.  (The full
-    4 194 304 with 209 715 victims needs 1.3 TB of pair store per rank and inboxes of 2 * 10^5: DESIGN §4a, §10.)
+    262 144 nodes / 13 107 victims whatever the number of ranks (SWIMSIM_BENCH_C4S_NODES overrides).  Since round 4 a rumour that
+    crosses a shard boundary is judged by the no-op filter of the RECEIVING shard (SW_EDGE_JUDGE), so a remote state exchange delivers
+    what an unsharded one would and the shards' counters add up to the unsharded run's; before, such an exchange arrived with every
+    explicit view of its sender, which is what had bounded the population.  The size stays where it was all the same: the one attempt at
+    524 288 nodes on two ranks SHARING one device did not finish within 15 minutes (two processes time-slicing one GPU around the
+    exchange's spin-wait; profiles/r04_config4_sharded_524k.txt) and no larger population has run on more than one device.  (The full
+    4 194 304 with 209 715 victims needs 1.3 TB of pair store per rank: DESIGN §4a, §10.)
     A failure of this leg (an overflowing bounded structure raises, never passes silently) is reported in the line, not fatal."""
     from consul_amd.dist import LibraryExchange, ShardedSim
     n = int(os.environ.get("SWIMSIM_BENCH_C4S_NODES", 0)) or 262144      # (the override: tests on one device)
@@ -485,7 +511,7 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="only the timed region (profiling runs): no roofline pass, no extra legs, no CPU baseline")
     ap.add_argument("--no-detection", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
-    ap.add_argument("--config4-nodes", type=int, default=262144, help="config4 leg: nodes on this GPU (524288 = one GPU's share of BASELINE configs[3]: profiles/r03_config4_524k.json)")
+    ap.add_argument("--config4-nodes", type=int, default=524288, help="config4 leg: nodes on this GPU (524288 = one GPU's share of BASELINE configs[3]; ~115 s of wall time: profiles/r04_config4_524k_full.log)")
     ap.add_argument("--config4-queue-cap", type=int, default=32)
     ap.add_argument("--config4-budget-s", type=float, default=400.0, help="config4 leg: give up (detection_complete false) after this much wall time")
     ap.add_argument("--no-config5", action="store_true")

@@ -786,7 +786,9 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
   }
   const bool serf_k = (D.flags & SWIM_F_SERF_EVENTS) != 0;
-  void (*const resolve_kernel)(const SwDev*) = D.M ? (serf_k ? k_resolve<true, true> : k_resolve<true, false>) : (serf_k ? k_resolve<false, true> : k_resolve<false, false>);
+  void (*const resolve_kernel)(const SwDev*) =
+      D.dyn ? (D.M ? (serf_k ? k_resolve<true, true, true> : k_resolve<true, false, true>) : (serf_k ? k_resolve<false, true, true> : k_resolve<false, false, true>))
+            : (D.M ? (serf_k ? k_resolve<true, true, false> : k_resolve<true, false, false>) : (serf_k ? k_resolve<false, true, false> : k_resolve<false, false, false>));
   { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.

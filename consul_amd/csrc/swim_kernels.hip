@@ -1996,7 +1996,9 @@ __shared__ uint32_t g_s_cen_r;            // the replica the workgroup's first n
 // SERF = the handle has serf's event layer (SWIM_F_SERF_EVENTS): without it the user-event / intent handlers are not compiled into the
 // kernel at all (k_resolve of the headline workload: their register pressure showed in its merge loop — 78 -> 92 us per launch when serf's
 // intent ordering came in as run-time code)
-template <bool LQ, bool MASS, bool SERF = true>
+// DYN = the handle's membership changes (n_initial < n_nodes): without it estNumNodes() is N and the scaling laws are the host's tables
+// (no per-observer counts, no f64 suspicion formula in the kernel) — a compile-time switch for the same reason as SERF
+template <bool LQ, bool MASS, bool SERF = true, bool DYN = true>
 struct NodeCtxT {
   DevRef D; BlockStats& S;
   uint32_t r, o, k, t; size_t l, NL;
@@ -2006,6 +2008,7 @@ struct NodeCtxT {
   uint32_t mcnt_add = 0;                              // pairs of the dense store this lane created (D.mcnt[l] is bumped once, in store())
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = VMETA(l); vm_have = true; } }
+  __device__ __forceinline__ bool dyn() const { if constexpr (DYN) return D.dyn != 0; else return false; }
   uint4 h0;
   uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * 256 + threadIdx.x]; entries to write back
 #define SQ(j) g_lds_dyn[(j) * SW_BLOCK + threadIdx.x]
@@ -2142,13 +2145,13 @@ struct NodeCtxT {
       vm.w = ev2;                                                      // the victim had the earliest one
       const uint32_t wv = D.nw[(size_t)r * D.N + vsubj];
       if (NW_HAS_SLOT(wv)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wv)] = 1;
-      if (D.dyn && SW_KINC(base_key_of(D, r, vsubj, wv)) == 0) D.vnk[l]--;
+      if (dyn() && SW_KINC(base_key_of(D, r, vsubj, wv)) == 0) D.vnk[l]--;
       vt_erase(D, l, vs); vm.x--; S.add(ST_VIEW_EVICT);
       uint4 dummy; vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * NL + l], dummy, v.free_slot);   // the layout changed
       if (v.free_slot == NONE) { S.add(ST_VIEW_DROPS); return false; }
     }
     vm.x++; vm_dirty = true;
-    if (D.dyn && x != o && v.e.y < 4u) D.vnk[l]++;          // a node the base row has never heard of: this observer now has (itself it counts from the start)
+    if (dyn() && x != o && v.e.y < 4u) D.vnk[l]++;          // a node the base row has never heard of: this observer now has (itself it counts from the start)
     v.slot = v.free_slot; v.fresh = true;
     if (D.vs) D.vs[(size_t)v.slot * NL + l] = 0;           // (serf: no intent applied to it yet)
     if (!(v.w & NW_SUBJECT)) {                              // first explicit view of x on this shard
@@ -2188,7 +2191,7 @@ struct NodeCtxT {
     }
   }
   __device__ __forceinline__ void arm_deadline(const View& v, uint32_t n0) {   // a suspicion timer was (re)armed: keep the gates' bounds
-    const uint32_t dl = v.e.z + susp_timeout_n(D, n0, vw_nconf(v.e.w));
+    const uint32_t dl = v.e.z + (DYN ? susp_timeout_n(D, n0, vw_nconf(v.e.w)) : sel8(D.susp_timeout, vw_nconf(v.e.w) & 7u));
     if (v_mass(v)) { m_arm(D, r, v.free_slot & ~SW_MASS_SLOT, k, dl); return; }
     need_vm();
     if (dl < vm.z) { vm.z = dl; vm_dirty = true; }
@@ -2240,11 +2243,11 @@ struct NodeCtxT {
     if (inc < SW_KINC(key)) return;
     if (SW_KST(key) == SWIM_STATE_SUSPECT) {           // timer exists: suspicion.Confirm(from) (the base row is never Suspect)
       uint32_t nc = vw_nconf(v.e.w);
-      if ((!D.dyn && nc >= D.susp_k) || vw_conf0(v.e.w) == from) return;
+      if ((!dyn() && nc >= D.susp_k) || vw_conf0(v.e.w) == from) return;
       const size_t ci = (size_t)v.slot * NL + l;          // (a pair of the dense store carries its accusers along: c_have)
-      if (!v.c_have) { v.c = (nc || D.dyn) ? D.vc[ci] : make_uint4(0, 0, 0, 0); v.c_have = true; }   // (dynamic membership: the timer's n sits in c.w)
+      if (!v.c_have) { v.c = (nc || dyn()) ? D.vc[ci] : make_uint4(0, 0, 0, 0); v.c_have = true; }   // (dynamic membership: the timer's n sits in c.w)
       uint4 b = v.c;
-      if (D.dyn && nc >= susp_k_n(D, b.w)) return;
+      if (dyn() && nc >= susp_k_n(D, b.w)) return;
       if ((nc >= 1 && b.x == from) || (nc >= 2 && b.y == from) || (nc >= 3 && b.z == from)) return;
       nc++;
       if (nc == 1) b.x = from; else if (nc == 2) b.y = from; else if (nc == 3) b.z = from;
@@ -2265,7 +2268,7 @@ struct NodeCtxT {
     v.e.w = vw_pack(from, 0, (v.e.w >> 1) & 1u);           // newSuspicion(from, k, min, max); a Leaving mark stays
     put_later(v);
     uint32_t n0 = 0;
-    if (D.dyn && !v_mass(v)) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
+    if (dyn() && !v_mass(v)) { n0 = est_n(D, r, l); D.vc[(size_t)v.slot * NL + l] = make_uint4(0, 0, 0, n0); }   // k, min, max from estNumNodes() now
     v.c = make_uint4(0, 0, 0, n0); v.c_have = true;
     arm_deadline(v, n0);
     S.add(ST_APPL1);
@@ -2305,7 +2308,7 @@ struct NodeCtxT {
     // the user-event queue stays in HBM; the pick walks it several times, so its meta words are fetched once into LDS
     MetaQ me{lds_emeta + threadIdx.x};
     if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
-    const uint32_t rl = retransmit_limit_n(D, est_n(D, r, l));
+    const uint32_t rl = DYN ? retransmit_limit_n(D, est_n(D, r, l)) : D.retransmit_limit;
     uint32_t tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl), te = 0;
     int avail = limit - used;
     if constexpr (SERF) if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
@@ -2646,7 +2649,7 @@ __device__ unsigned long long g_wclk[WCLK_ROWS][6];
 #define SW_RESOLVE_WAVES 4
 #endif
 #define SW_ORDER_MIN 16u          /* a tile with an inbox of this many messages has its receiver list ordered by size class */
-template <bool MASS, bool SERF>
+template <bool MASS, bool SERF, bool DYN>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
@@ -2740,7 +2743,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-    NodeCtxT<true, MASS, SERF> n(D, S);
+    NodeCtxT<true, MASS, SERF, DYN> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
     RCLK_MARK(1);                                  // line + header + vmeta

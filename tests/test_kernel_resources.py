@@ -19,10 +19,11 @@ BUDGET = {
     "k_beginILi8ELb1ELb1ELb1ELb0E": (96, 128, 5),  # the heaviest one (fan-out 8, serf events, sharded, dense store)
     "9k_deliverILb0ELb0EE": (64, 0, 7),
     "9k_deliverILb0ELb1EE": (96, 0, 5),        # tile buckets: the per-tile drain, four records per lane in flight
-    "9k_resolveILb0ELb0EE": (128, 32, 4),      # the bench's instantiation: no dense store, no serf event layer (user-event / intent handlers not compiled in)
-    "9k_resolveILb1ELb0EE": (128, 32, 4),      # ... the dense pair store (config #4's leg)
-    "9k_resolveILb0ELb1EE": (128, 128, 4),     # ... serf's event layer: intents with their statusLTime ordering, the event buffer (cold paths that spill)
-    "9k_resolveILb1ELb1EE": (128, 128, 4),     # ... both (config #5's leg)
+    "9k_resolveILb0ELb0ELb0EE": (128, 16, 4),  # the bench's instantiation: no dense store, no serf event layer, fixed membership — nothing of those three compiled in
+    "9k_resolveILb1ELb0ELb0EE": (128, 32, 4),  # ... the dense pair store (config #4's leg)
+    "9k_resolveILb0ELb0ELb1EE": (128, 48, 4),  # ... membership that changes (per-observer estNumNodes, the f64 suspicion formula)
+    "9k_resolveILb0ELb1ELb0EE": (128, 128, 4), # ... serf's event layer: intents with their statusLTime ordering, the event buffer (cold paths that spill)
+    "9k_resolveILb1ELb1ELb1EE": (128, 144, 4), # ... all three (config #5's leg with joins)
     "8k_censusPK": (32, 0, 8),
     "8k_finishPK": (64, 0, 8),
     "7k_quietPK": (40, 0, 8),
