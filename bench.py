@@ -161,9 +161,11 @@ def run_cpu_baseline(args, ticks_per_round: int) -> dict:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    # every host thread by default, one cluster (65 536 nodes, ~150 MB of checker state) per thread; the thread
-    # count used is what `cores` reports.  The clusters are created by the pool's threads too (256 creations in a row take longer than the sample).
-    cores = max(1, min(ncpu, args.cpu_threads or ncpu))
+    # One cluster (65 536 nodes, ~150 MB of randomly accessed checker state) per thread.  More threads are not more throughput on this
+    # host: 2.45e8 node-rounds/s on 16 threads, 2.05e8 on 32, 1.44e8 on 64, 1.10e8 on 128, 5.6e7 on all 256 (profiles/r04_cpu_baseline_sweep.txt,
+    # r04_bench_driver.json) — so the leg sweeps 8 / 16 / 32 threads and reports the BEST as `value` (`cores` = the thread count that
+    # reached it); --cpu-threads pins one count.  The clusters are created by the pool's threads too.
+    sweep_counts = [max(1, min(ncpu, args.cpu_threads))] if args.cpu_threads else sorted({max(1, min(ncpu, c)) for c in (8, 16, 32)})
 
     def sample(threads):
         nonlocal per_thread
@@ -192,12 +194,14 @@ def run_cpu_baseline(args, ticks_per_round: int) -> dict:
     per_thread = 4
     v1, dt1, n1 = sample(1)
     per_thread = 1
-    try:
-        vn, dtn, repsn = sample(cores)
-    except (MemoryError, RuntimeError):              # a host too small for one cluster per thread: the round-3 sample
-        cores = min(cores, 32)
-        vn, dtn, repsn = sample(cores)
+    sweep = {}
+    for c in sweep_counts:
+        sweep[c] = sample(c)
+    cores = max(sweep, key=lambda c: sweep[c][0])
+    vn, dtn, repsn = sweep[cores]
     return {"value": vn, "unit": "node-rounds/s", "cores": cores, "kind": "port",
+            "thread_sweep": {str(c): {"value": v[0], "wall_s": round(v[1], 2)} for c, v in sweep.items()},
+            "quoted_from_profiles": {"more_threads": "profiles/r04_cpu_baseline_sweep.txt: 64 threads 1.44e8, 128 threads 1.10e8, all 256 threads 5.6e7 node-rounds/s on the same host"},
             "one_thread": {"value": v1, "cores": 1, "wall_s": round(dt1, 2)},
             "sample": f"{repsn} clusters x {args.nodes} nodes x {rounds} rounds after the failure (config #2's scenario, "
                       f"kill after {warm} rounds), {per_thread} per thread: {dtn:.1f} s wall on {cores} of {ncpu} host threads; "

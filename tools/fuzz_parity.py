@@ -15,7 +15,8 @@ from consul_amd.dist import LocalExchange, ShardedSim
 KEYS = ["node_rounds_active", "node_rounds_quiescent", "packets_sent", "packets_dropped", "msgs_sent", "msgs_applied", "probes",
         "probe_acks", "probe_indirect_acks", "probe_tcp_acks", "probe_failures", "nacks_missed", "refutes", "suspicion_timeouts",
         "confirmations", "queue_drops", "event_drops", "user_events_delivered", "user_events_deduped", "user_events_stale",
-        "piggybacks", "msgs_piggybacked", "push_pulls", "view_drops", "view_evictions", "folds", "fold_freed", "reconnects", "reconnects_reached"]
+        "piggybacks", "msgs_piggybacked", "push_pulls", "view_drops", "view_evictions", "folds", "fold_freed", "reconnects", "reconnects_reached",
+        "edges", "msgs_filtered"]      # (round 4: sharded runs too — what crosses a shard boundary is judged by the receiving shard)
 
 
 def draw_case(rng):

@@ -1,4 +1,5 @@
-# The GPU-box sessions of round 4 (each block was one gpurun call).
+# The GPU-box sessions of round 4, one after the other (each block was one gpurun call; kept as the record of how profiles/r04_* were taken).
+# Calls 3 ran twice (the first build had lost two allocations to a stray #endif: memory fault at create); call 8's two-rank run was killed by its time-out.
 
 # ---- r4_gpu1.sh
 # round 4, GPU call 1: A/B of the ISA fixes (base / +LDS-typed statistics / + deliver_span in phases + one-shard append path + medium-inbox wave sort),
@@ -53,8 +54,109 @@ d=json.loads(sys.stdin.read()); print('$name default window: value %.4e ms/round
 import json,sys
 d=json.loads(sys.stdin.read()); print('$name driver window, 3 handles: value %.4e ms/round %.4f' % (d['value'], d['ms_per_step']))" | tee -a $O/ab.txt
 }
+( time python tools/config4_run.py --nodes 262144 --seconds 1300 --every 100 ) > $O/config4_262k.log 2>&1; tail -3 $O/config4_262k.log
 run base _ab/lib_7tbd.so SWIMSIM_TILEBUCKETS=0
 run tb_nocarry _ab/lib_7tbd.so SWIMSIM_TB_CARRY=0
 run tb _ab/lib_7tbd.so X=1
 run nl_base _ab/lib_8nl.so SWIMSIM_TILEBUCKETS=0
 run nl_tb _ab/lib_8nl.so X=1
+
+# ---- r4_gpu4.sh
+# round 4, GPU call 4: the whole GPU suite on the current tree (tile buckets off by default + their own tests), config #4's leg at 524 288 nodes
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04d; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+( time python tools/config4_run.py --nodes 524288 --seconds 1600 --every 100 ) > $O/config4_524k.log 2>&1; tail -4 $O/config4_524k.log
+
+# ---- r4_gpu5.sh
+# round 4, GPU call 5: the GPU suite with the receiving-shard filter, where config #4's mass phase spends its time (per-kernel HIP events)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04e; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+( time python tools/config4_run.py --nodes 262144 --seconds 120 --every 20 --profile ) > $O/config4_262k_profile.log 2>&1; tail -4 $O/config4_262k_profile.log
+
+# ---- r4_gpu6.sh
+# round 4, GPU call 6: serf intent ordering on the device, one view lookup per membership rumour; suite, headline check, config-4 leg
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04f; mkdir -p $O
+( time timeout 600 python -m pytest tests/test_serf_intents_gpu.py -m gpu -x -q ) > $O/pytest_intents.log 2>&1; tail -25 $O/pytest_intents.log
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+bash tools/ab_kernels.sh _ab/lib_0base.so consul_amd/libswimsim.so > $O/ab.txt 2>&1; cat $O/ab.txt
+( time python tools/config4_run.py --nodes 262144 --seconds 1300 --every 100 --profile ) > $O/config4_262k.log 2>&1; tail -4 $O/config4_262k.log | cut -c1-300
+
+# ---- r4_gpu7.sh
+# round 4, GPU call 7: k_resolve compiled without serf's handlers for handles without an event layer: headline A/B (reference = the build before the
+# intent work), the intent scripts, the suite, config #4's leg
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04g; mkdir -p $O
+bash tools/ab_kernels.sh _ab/lib_0ref.so consul_amd/libswimsim.so > $O/ab.txt 2>&1; cat $O/ab.txt
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+( time python tools/config4_run.py --nodes 262144 --seconds 1300 --every 100 ) > $O/config4_262k.log 2>&1; tail -3 $O/config4_262k.log | cut -c1-200
+
+# ---- r4_gpu8.sh
+# round 4, GPU call 8: k_resolve's tile size (2 / 8 node blocks per workgroup against 4); the sharded config-4 leg at 524 288 nodes on two
+# ranks (both on this one device) beside the same population unsharded
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04h; mkdir -p $O
+bash tools/ab_kernels.sh _ab/lib_rtile2.so _ab/lib_rtile8.so > $O/ab_rtile.txt 2>&1; cat $O/ab_rtile.txt
+export HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1
+( time SWIMSIM_BENCH_C4S_NODES=524288 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 4 --warmup 2 --no-replica-leg --replicas 2 --dist-backend gloo --exchange library > $O/bench_gpus2.json 2> $O/bench_gpus2.err ); tail -3 $O/bench_gpus2.err
+python -c "
+import json; d=json.loads([l for l in open('$O/bench_gpus2.json') if l.startswith('{')][0]); print(json.dumps(d.get('config4_sharded'))); print('parity', d.get('parity'))"
+( time python tools/config4_sharded_check.py --nodes 524288 ) > $O/c4_unsharded_524k.json 2>&1; cat $O/c4_unsharded_524k.json
+
+# ---- r4_gpu9.sh
+# round 4, GPU call 9: k_resolve<MASS, SERF, DYN> against k_resolve<MASS, SERF>; the suite on it
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04i; mkdir -p $O
+bash tools/ab_kernels.sh _ab/lib_serf.so _ab/lib_dyn.so > $O/ab_dyn.txt 2>&1; cat $O/ab_dyn.txt
+cp _ab/lib_dyn.so consul_amd/libswimsim.so
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+
+# ---- r4_final.sh
+# round 4, the final GPU-box session: smoke, the GPU suite, the bench at the driver's arguments and at the defaults, the kernel trace and
+# tick breakdown of the timed region, HBM traffic (FETCH_SIZE / WRITE_SIZE passes), L2 / SQ counters, the kernel table of the driver's exact command
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04z; mkdir -p $O
+( time python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err ) 2>&1 | tail -4
+( time python bench.py --no-config4 --no-config5 --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err ) 2>&1 | tail -4
+wc -c $O/*.json
+SKIP=10 bash tools/trace_pass.sh $O/driver_trace --steps 20 --warmup 5 > $O/driver_trace.log 2>&1; tail -12 $O/driver_trace.log
+bash tools/pmc_traffic_pass.sh $O/pmc_driver --steps 20 --warmup 5 > $O/pmc_driver.log 2>&1; tail -3 $O/pmc_driver.log | cut -c1-300
+PMC_GROUPS="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum;GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" bash tools/pmc_pass.sh $O/pmc_l2 --steps 20 --warmup 5 > $O/pmc_l2.log 2>&1
+python tools/pmc_report.py $O/pmc_l2 8 > $O/pmc_l2_heavy_ticks.txt 2>&1
+python tools/pmc_report.py $O/pmc_l2 400 > $O/pmc_l2_all_ticks.txt 2>&1
+rm -rf $O/pmc_l2
+mkdir -p $O/fullcmd
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/fullcmd/trace -- python bench.py --gpus 1 --steps 20 --warmup 5 > $O/fullcmd/bench.json 2> $O/fullcmd/bench.err
+cp $(find $O/fullcmd/trace -name "*kernel_stats.csv" | head -1) $O/driver_fullcmd_kernel_stats.csv; rm -rf $O/fullcmd/trace
+ls -la $O
+
+# ---- cpu_baseline_sweep (one call)
+python tools/cpu_baseline_sweep.py 16 32 64 128
+
+# ---- r4_last.sh
+# round 4, last GPU call: how many library handles (HIP streams) the clusters are best spread over with this build, then the bench line at the
+# driver's arguments once more (cpu_baseline as a thread sweep, roofline.traffic from this round's --pmc passes)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04x; mkdir -p $O
+for h in 1 2 3 4 6; do
+  for w in "--steps 20 --warmup 5" ""; do
+    python bench.py --main-only --handles $h $w 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('handles $h window [$w]: value %.4e ms/round %.4f' % (d['value'], d['ms_per_step']))" | tee -a $O/handles.txt
+  done
+done
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err ) 2>&1 | tail -4
+python -c "
+import json; d=json.load(open('$O/bench_driver.json')); print(d['value'], d['single_handle'], d['cpu_baseline'], d['roofline']['frac'], d['roofline'].get('traffic_over_algorithmic'))"
