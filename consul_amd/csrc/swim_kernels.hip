@@ -1183,13 +1183,23 @@ __device__ __forceinline__ void role_ppreply(DevRef D, uint32_t b, uint32_t nb, 
   for (uint32_t sub = b; sub < SW_PP_LISTS; sub += nb) {
     uint32_t n = D.pp_cnt[(li * SW_PP_LISTS + sub) * 16]; if (n > sub_cap) n = sub_cap;
     for (uint32_t e0 = 0; e0 < n; e0 += SW_BLOCK) {
-      uint32_t e = e0 + threadIdx.x; bool on = e < n; uint32_t r = 0, p = 0, o = 0;
+      uint32_t e = e0 + threadIdx.x; bool on = e < n, jn = false; uint32_t r = 0, p = 0, o = 0, pclk = 0;
       if (on) {
         uint2 rq = D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + e];
-        r = rq.x / D.nloc; p = D.i0 + rq.x % D.nloc; o = rq.y;
+        r = rq.x / D.nloc; p = D.i0 + rq.x % D.nloc; o = rq.y & 0x7FFFFFFFu; jn = (rq.y >> 31) != 0;
         on = !(D.nw[(size_t)r * D.N + p] & NW_INERT);
+        if (on && jn && D.sslt) pclk = HDR(rq.x).w;
       }
       send_state<MASS, MULTI>(D, on, r, p, o, c_edges, c_remote, c_filt);
+      // serf.Join: the state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)), THEN the joiner
+      // calls broadcastJoin(s.clock.Time()) — its join intent is stamped with the clock of the member it joined through.  The reply to a
+      // JOIN's pull request therefore carries that intent, ready-stamped, to the joiner, which witnesses it, applies it to its own entry
+      // and broadcasts it (a message like any other: the same across shards).
+      if (D.sslt) {
+        const bool want = on && jn; const uint32_t sh = want ? o / D.nloc : 0;
+        wave_append_sharded<MULTI>(D, want, sh, make_uint4(r * D.N + o, SWIM_INTENT_JOIN | o, pclk, (uint32_t)SWIM_MSG_USER << 30));
+        c_edges += want; c_remote += want && sh != D.rank;
+      }
     }
   }
   S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
@@ -1217,7 +1227,7 @@ __device__ __forceinline__ void role_join(DevRef D, uint32_t* lds_stats) {
     }
     send_state<MASS, MULTI>(D, on, r, o, p, c_edges, c_remote, c_filt);
     const uint32_t sh = on ? p / D.nloc : 0;
-    wave_append_sharded<MULTI>(D, on, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0));
+    wave_append_sharded<MULTI>(D, on, sh, mk_edge(D, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 1));      // from = 1: a JOIN's pull request (serf.Join: the reply brings the join intent)
     c_edges += on; c_remote += on && sh != D.rank;
   }
   S.wave_add(ST_EDGES, c_edges); S.wave_add(ST_EDGES_REMOTE, c_remote); S.wave_add(ST_FILTERED, c_filt);
@@ -2788,7 +2798,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
       else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
         uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
         uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
-        if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z);
+        if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z | ((from & 1u) << 31));   // (bit 31: a join's request)
         else atomicOr(D.err, SW_ERR_PEND_OVF);
       }
       else if (type != SWIM_MSG_USER) {
@@ -3220,18 +3230,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         c.r = r; c.o = x; c.k = x - D.i0; c.t = *D.tick; c.l = l; c.NL = NL;
         c.load();
         c.broadcast(x, SWIM_MSG_ALIVE, c.self_inc, 0);       // memberlist setAlive
-        if (D.sslt) {
-          // serf.Join: memberlist.Join's state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)),
-          // THEN broadcastJoin(s.clock.Time()) — a rejoining member's intent is newer than any leave intent `via` has seen about it.  The
-          // exchange itself takes a tick here; the clock is witnessed now, when `via` lives on this shard (else the joiner catches up by
-          // gossip).  The intent goes out once the join push-pull is through (the node is alone until then).
-          D.sslt[l] = 0;
-          if (via != x && via >= D.i0 && via < D.i0 + D.nloc && !(D.nw[(size_t)r * D.N + via] & NW_DEAD)) {
-            const uint32_t vclk = HDR((size_t)r * D.nloc + (via - D.i0)).w;
-            if (vclk > c.ev_clock) c.ev_clock = vclk;
-          }
-          c.user_event(SWIM_INTENT_JOIN | x, c.ev_clock, true);
-        }
+        if (D.sslt) D.sslt[l] = 0;                           // (its join intent comes with the answer to its join push-pull: role_ppreply)
         c.store();
         q_bit_lane(D, l, c.q_became_set(), c.q_became_clr());
       }

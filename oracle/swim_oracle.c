@@ -1171,7 +1171,13 @@ static void phase_pushpull(swim_sim* s) {
   edgevec* rq = &s->pp_reply[s->tick & 1];
   for (uint32_t i = 0; i < rq->n; i++) {
     uint32_t r = rq->v[i].incarnation, p = rq->v[i].dst, o = rq->v[i].subject;
-    if (acts(s, r, p)) send_state(s, r, p, o);
+    if (!acts(s, r, p)) continue;
+    send_state(s, r, p, o);
+    /* serf.Join: the state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)), THEN the joiner
+     * calls broadcastJoin(s.clock.Time()) — i.e. its join intent is stamped with the clock of the member it joined through.  The reply to a
+     * JOIN's pull request therefore carries that intent, ready-stamped, to the joiner, which witnesses it, applies it to its own entry and
+     * broadcasts it (a message like any other: the same across shards). */
+    if ((rq->v[i].meta & 1u) && node_at(s, r, p)->ring) emit(s, r, o, SWIM_INTENT_JOIN | o, node_at(s, r, p)->ev_clock, SWIM_MSG_USER, 0);
   }
   rq->n = 0;
   /* swim_inject_join: the join push-pull (pushPullNode(join=true)) of the nodes started since the last tick */
@@ -1185,7 +1191,7 @@ static void phase_pushpull(swim_sim* s) {
     if (!ok) { s->st.join_failures++; continue; }
     s->st.joins++;
     send_state(s, r, o, p);
-    emit(s, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 0);
+    emit(s, r, p, SWIM_SUBJECT_PULL, o, SWIM_MSG_ALIVE, 1);          /* from = 1: a JOIN's pull request (serf.Join: the reply brings the join intent) */
   }
   /* stagger: node i is due in tick (i mod period), but exchanges start only on probe-interval boundaries
    * (everything due within the next ProbeInterval goes now) — memberlist's own stagger is a random point
@@ -1449,7 +1455,7 @@ static void phase_deliver_resolve(swim_sim* s) {
         uint32_t type = e.meta >> 30, from = e.meta & 0x3FFFFFFFu;
         if (e.subject == SWIM_SUBJECT_PIGGY) { piggyback(s, r, o, nd, e.incarnation, type); continue; }
         if (e.subject == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {      /* answer next tick */
-          swim_edge rq = { o, e.incarnation, r, 0 };
+          swim_edge rq = { o, e.incarnation, r, from & 1u };
           ev_push(&s->pp_reply[(s->tick + 1) & 1], rq);
           continue;
         }
@@ -1756,14 +1762,7 @@ int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uin
     nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->pr_nack_miss = 0;
     if (KINC(s->base_key[g]) != 0 || nd->self_inc > 1 || nd->qseq) nd->self_inc++;   /* a restart: past the incarnation others may remember */
     broadcast(s, nd, x, SWIM_MSG_ALIVE, nd->self_inc, 0);   /* memberlist setAlive */
-    nd->serf_leaving = 0; nd->self_slt = 0;
-    if (nd->ring) {
-      /* serf.Join: memberlist.Join's state exchange hands over serf's own push-pull message too (MergeRemoteState: clock.Witness(LTime - 1)),
-       * THEN broadcastJoin(s.clock.Time()) — so a rejoining member's intent is newer than any leave intent `via` has seen about it.  The
-       * exchange itself takes a tick here; the clock is witnessed now, when `via` lives on this shard (else the joiner catches up by gossip). */
-      if (is_local(s, via) && s->gt_alive[(size_t)r * s->N + via] && via != x) { const node_t* vn = node_at(s, r, via); if (vn->ev_clock > nd->ev_clock) nd->ev_clock = vn->ev_clock; }
-      user_event_from(s, r, x, nd, SWIM_INTENT_JOIN | x, nd->ev_clock, 1);     /* goes out once the join push-pull is through (the node is alone until then) */
-    }
+    nd->serf_leaving = 0; nd->self_slt = 0;                /* (its join intent comes with the answer to its join push-pull: phase_pushpull) */
   }
   dirty_all(s, r); return SWIM_OK;
 }

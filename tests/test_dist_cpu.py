@@ -133,3 +133,31 @@ def test_randomised_sharding_cases(oracle):
         res = fz.run_case(k, oracle, oracle, 7, False)
         tally[res] = tally.get(res, 0) + 1
     assert not tally.get("mismatch") and tally.get("ok", 0) >= 5, tally
+
+
+def test_join_intents_are_the_same_on_a_sharded_population(oracle):
+    """serf.Join's intent is handed to the joiner by the member it joined through, ready-stamped with that member's clock, in the answer to
+    the join push-pull — a message, so a joiner and its `via` on DIFFERENT shards behave like on one (a clock read at injection time would
+    not: round 4 had that for a few hours).  Force-leave a failed member, let it rejoin through a node of the other shard, then an
+    ordinary join of a member that starts late: digests, members and counters equal to the unsharded run's at every step."""
+    kw = dict(n_nodes=1024, n_initial=1000, seed=17, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=64, view_cap=256, queue_cap=16,
+              event_queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+
+    def both(f):
+        f(sh); f(ref)
+        assert sh.digest() == ref.digest()
+
+    both(lambda s: s.step_ms(2000))
+    both(lambda s: (s.kill(0, [700]), s.step_ms(30000)))                       # node 700 (shard 1) fails and is declared Failed
+    both(lambda s: (s.force_leave(0, 3, 700, False), s.step_ms(4000)))          # ... and force-left: Left everywhere
+    assert int(ref.view(0, 10, 700).status) == abi.MEMBER_LEFT
+    both(lambda s: (s.join(0, [700], via=5), s.step_ms(6000)))                  # it comes back through node 5 (shard 0)
+    assert int(ref.view(0, 10, 700).status) == abi.MEMBER_ALIVE and int(ref.view(0, 900, 700).status) == abi.MEMBER_ALIVE
+    both(lambda s: (s.join(0, [1010], via=600), s.step_ms(6000)))               # a member that starts late: shard 1, via a node of shard 1
+    both(lambda s: (s.join(0, [1011], via=2), s.step_ms(6000)))                 # ... and one via a node of shard 0
+    assert int(ref.view(0, 10, 1011).status) == abi.MEMBER_ALIVE
+    a, b = sh.stats(), ref.stats()
+    for k in ("msgs_sent", "msgs_applied", "packets_sent", "edges", "msgs_filtered", "user_events_deduped", "joins", "intents_applied"):
+        assert a[k] == b[k], k

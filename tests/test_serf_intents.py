@@ -110,3 +110,29 @@ def test_graceful_leave_broadcasts_its_intent_first(oracle):
     o = script_graceful_leave(Sim(oracle, preset(oracle, abi.PRESET_LAN, **KW)))
     assert set(o["leaving"]) == {abi.MEMBER_LEAVING}
     assert set(o["left"]) == {abi.MEMBER_LEFT}
+
+
+JOIN_KW = dict(n_nodes=1024, n_initial=1000, seed=17, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, subject_cap=64, view_cap=256, queue_cap=16,
+               event_queue_cap=16, inbox_cap=1024, push_pull_interval_ms=0)
+
+
+def script_joins(s):
+    """A failed member is force-left and comes back through a node of the OTHER half of the id space (another shard, when there are two);
+    then two members that start late, one via each half.  Returns (digest, a few statuses) after every step."""
+    out = []
+
+    def mark():
+        s.sync()
+        out.append((s.digest(), int(s.view(0, 10, 700).status), int(s.view(0, 900, 700).status), int(s.view(0, 10, 1011).status)))
+    s.step_ms(2000); mark()
+    s.kill(0, [700]); s.step_ms(30000); mark()
+    s.force_leave(0, 3, 700, False); s.step_ms(4000); mark()
+    s.join(0, [700], via=5); s.step_ms(6000); mark()
+    s.join(0, [1010], via=600); s.step_ms(6000); mark()
+    s.join(0, [1011], via=2); s.step_ms(6000); mark()
+    return out
+
+
+def test_joins_with_intents_on_the_checker(oracle):
+    o = script_joins(Sim(oracle, preset(oracle, abi.PRESET_LAN, **JOIN_KW)))
+    assert o[2][1] == abi.MEMBER_LEFT and o[3][1] == abi.MEMBER_ALIVE and o[3][2] == abi.MEMBER_ALIVE and o[5][3] == abi.MEMBER_ALIVE

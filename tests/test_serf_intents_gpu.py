@@ -24,3 +24,19 @@ def test_intent_scripts_on_hip_match_the_checker(hip, oracle, script, rows):
     for k in ("user_events_deduped", "user_events_stale", "event_drops", "msgs_applied", "refutes", "intents_applied", "reaped", "msgs_sent", "packets_sent"):
         assert sa[k] == sb[k], k
     assert a.poll_events() == b.poll_events()
+
+
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_joins_with_intents_on_hip(hip, oracle, n_shards):
+    """serf.Join's intent reaches the joiner in the answer to its join push-pull, stamped with the clock of the member it joined through —
+    a message, so one shard or two (joiner and `via` on different ones) give the unsharded checker's digests step by step."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    b = Sim(oracle, preset(oracle, abi.PRESET_LAN, **ti.JOIN_KW))
+    if n_shards == 1:
+        a = Sim(hip, preset(hip, abi.PRESET_LAN, **ti.JOIN_KW))
+    else:
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **ti.JOIN_KW)) for i in range(n_shards)], LocalExchange())
+    assert ti.script_joins(a) == ti.script_joins(b)
+    sa, sb = a.stats(), b.stats()
+    for k in ("msgs_sent", "msgs_applied", "packets_sent", "edges", "msgs_filtered", "user_events_deduped", "joins", "intents_applied"):
+        assert sa[k] == sb[k], k

@@ -205,7 +205,10 @@ def run_case(k, lib, ora, seed, verbose):
             a.sync()
             da, db = a.digest(), b.digest()
             sa, sb = a.stats(), b.stats()
-            bad = [key for key in KEYS if sa[key] != sb[key]]
+            # (`edges` is left out once a node is attached to the transport bridge: a record for an attached node that is not a gossip
+            #  rumour — a state exchange, a buddy suspect — is counted when it is sent by the product library and not at all by the
+            #  checker, which captures it before it counts; an accounting difference of a debug counter, no state behind it)
+            bad = [key for key in KEYS if sa[key] != sb[key] and not (key == "edges" and BRIDGE)]
             same, what = bridge_poll_equal((a, b)) if shards == 1 else (True, None)
             if not same:
                 bad.append(f"transport_poll {what}")

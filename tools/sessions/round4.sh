@@ -160,3 +160,21 @@ done
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err ) 2>&1 | tail -4
 python -c "
 import json; d=json.load(open('$O/bench_driver.json')); print(d['value'], d['single_handle'], d['cpu_baseline'], d['roofline']['frac'], d['roofline'].get('traffic_over_algorithmic'))"
+
+# ---- r4_gpu10.sh
+# round 4, GPU call 10: the join intent handed over by the answer to the join push-pull — the intent scripts, then the whole suite
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04j; mkdir -p $O
+( time timeout 600 python -m pytest tests/test_serf_intents_gpu.py tests/test_membership.py -m gpu -x -q ) > $O/pytest_intents.log 2>&1; tail -25 $O/pytest_intents.log
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; tail -8 $O/pytest_gpu.log
+python bench.py --main-only --handles 1 --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('driver window, one handle: value %.4e ms/round %.4f' % (d['value'], d['ms_per_step']))"
+
+# ---- r4_gpu11.sh
+# round 4, GPU call 11: the whole GPU suite on the final tree
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04k; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
