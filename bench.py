@@ -13,7 +13,8 @@ whole pipeline (timers, probe, gossip select/emit, delivery, merge) for every no
 At N>1 every replica's node population is block-partitioned over the N ranks (one process per
 GPU) and cross-shard gossip records cross once per tick — by default through the library's own
 exchange (peer-mapped mailboxes over xGMI, no host round trip: `--exchange library`), with the
-split tick + RCCL all-to-all (`--exchange rccl`) timed beside it as `exchange.other`; the replica
+split tick + ONE equal-split RCCL all_to_all_single of frames per tick, the counts in the frames' headers, nothing
+read back by the host (`--exchange rccl`) timed beside it as `exchange.other`; the replica
 count grows with N so per-GPU work is fixed (weak scaling).
 
 One JSON line on stdout (rank 0).  `roofline` is for the kernel that dominates the timed region,
@@ -447,6 +448,14 @@ def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, ba
             "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
 
 
+RCCL_KIND = "rccl: one equal-split all_to_all_single of frames per tick, the counts in the frames' headers (no host round trip)"
+
+
+def frame_note(ex) -> dict:
+    """What the framed exchange puts on the wire whatever the fill (consul_amd/dist.py TorchExchange)."""
+    return {"frame_records": ex._F, "frame_bytes_per_tick_per_rank": ex.frame_bytes_per_tick}
+
+
 def run_config5(hip, args, device) -> dict:
     """BASELINE configs[4]'s shape on one GPU: N nodes (default 65 536), LAN timers, Lifeguard on (the default flags), 10 % of the
     nodes flip alive <-> dead every second (kill / revive: a node that comes back refutes with a higher incarnation), and a flood
@@ -530,9 +539,13 @@ def main():
     ap.add_argument("--no-piggyback", action="store_true", help="ablation: SWIM_F_PIGGYBACK off (not memberlist's behaviour)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
+    ap.add_argument("--frame-records", type=int, default=0,
+                    help="--exchange rccl: records per frame of the equal-split all-to-all (header included).  0 = the library's bound "
+                         "(1 + the largest outbound capacity: can never overflow); a smaller frame moves fewer bytes per tick and raises "
+                         "the sticky edge-list overflow if a tick's segment does not fit")
     ap.add_argument("--exchange", choices=("auto", "library", "rccl"), default="auto",
                     help="N > 1: `library` = the library's own device-driven exchange (peer-mapped mailboxes over xGMI, no host round trip, "
-                         "no collective); `rccl` = split tick + RCCL all-gather / all-to-all from Python; `auto` = library, and rccl if the "
+                         "no collective); `rccl` = split tick + one equal-split RCCL all_to_all_single of frames per tick, issued from Python on the simulator's stream, no host round trip; `auto` = library, and rccl if the "
                          "mailboxes cannot be set up or a peer's flag does not arrive")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the control group (gloo: several ranks on ONE device, tests)")
     args = ap.parse_args()
@@ -611,7 +624,7 @@ def main():
             return ShardedSim(sim, LibraryExchange(gather_handles))
         if not on_dev and world > 1:
             raise SystemExit("--dist-backend gloo drives the control group only: use --exchange library for the records")
-        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank))
+        return ShardedSim(sim, TorchExchange(dist.group.WORLD, local_rank, args.frame_records or None))
 
     def allreduce_max(x: float) -> float:
         t = torch.tensor([x], device="cuda" if on_dev else "cpu", dtype=torch.float64)
@@ -623,7 +636,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    exchange_used = "library (peer-mapped mailboxes, device driven)" if use_library else "rccl all-gather + all-to-all per tick" if sharded else None
+    exchange_used = "library (peer-mapped mailboxes, device driven)" if use_library else RCCL_KIND if sharded else None
     sim = fresh()
     G = (sim.sim if sharded else sim).derived.gossip_period
     if use_library:
@@ -640,7 +653,7 @@ def main():
                 raise SystemExit("the library's device-driven exchange failed and --exchange library leaves no alternative")
             sim.close()
             use_library = False
-            exchange_used = "rccl all-gather + all-to-all per tick (the library's mailbox exchange could not be used: see stderr)"
+            exchange_used = RCCL_KIND + " (the library's mailbox exchange could not be used: see stderr)"
             sim = fresh()
             sim.step(G); sim.sync()
     else:
@@ -720,7 +733,7 @@ def main():
             other_lib = not use_library
             try:
                 o = Sim(hip, preset(hip, abi.PRESET_LAN, **cfg_kw))
-                o = ShardedSim(o, LibraryExchange(gather_handles) if other_lib else TorchExchange(dist.group.WORLD, local_rank))
+                o = ShardedSim(o, LibraryExchange(gather_handles) if other_lib else TorchExchange(dist.group.WORLD, local_rank, args.frame_records or None))
                 o.step(args.warmup * G)
                 for r, v in enumerate(victims):
                     o.kill(r, [v])
@@ -728,12 +741,17 @@ def main():
                 to = time.perf_counter()
                 o.step(args.steps * G); o.sync(); barrier()
                 dto = allreduce_max(time.perf_counter() - to)
+                line["exchange"]["other"] = {"kind": "library (peer-mapped mailboxes)" if other_lib else RCCL_KIND,
+                                             "value": reps * args.nodes * args.steps / dto, "ms_per_step": 1000.0 * dto / args.steps,
+                                             "us_per_tick": 1000.0 * 1000.0 * dto / args.steps / G}
+                if not other_lib:
+                    line["exchange"]["other"].update(frame_note(o.exchange))
                 o.close()
-                line["exchange"]["other"] = {"kind": "library (peer-mapped mailboxes)" if other_lib else "rccl all-gather + all-to-all per tick",
-                                             "value": reps * args.nodes * args.steps / dto, "ms_per_step": 1000.0 * dto / args.steps}
             except (SwimError, OSError, RuntimeError) as e:
                 line["exchange"]["other"] = {"error": str(e)[:200]}
         line["exchange"]["us_per_tick"] = 1000.0 * line["ms_per_step"] / G
+        if not use_library:
+            line["exchange"].update(frame_note(sim.exchange))
     if world > 1 and not args.no_config4:
         if use_library:
             line["config4_sharded"] = run_config4_sharded(hip, args, rank, world, local_rank, dist, gather_handles, barrier, allreduce_max)

@@ -10,6 +10,7 @@ import ctypes as C
 
 ABI_VERSION = 7
 NONE = 0xFFFFFFFF
+FRAME_MAGIC = 0x4D415246          # SWIM_FRAME_MAGIC: the header record of a frame of the framed exchange
 
 OK, EINVAL, ENOMEM, ENODEV, ERANGE, EOVERFLOW, ESTATE, EIO = 0, -22, -12, -19, -34, -75, -71, -5
 ERRNAMES = {EINVAL: "SWIM_EINVAL", ENOMEM: "SWIM_ENOMEM", ENODEV: "SWIM_ENODEV",
@@ -141,6 +142,9 @@ PROTOTYPES = {
     "swim_stream": (C.c_int, [SimP, P(C.c_void_p)]),
     "swim_outbound_raw": (C.c_int, [SimP, u32, P(C.c_void_p), P(C.c_void_p)]),
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
+    "swim_frame_records": (u32, [SimP]),
+    "swim_frame_pack": (C.c_int, [SimP, C.c_void_p, u32]),
+    "swim_frame_deliver": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_tick_end": (C.c_int, [SimP]),
     "swim_tick_end_begin": (C.c_int, [SimP]),
     "swim_xchg_export": (C.c_int, [SimP, P(XchgHandle)]),

@@ -811,7 +811,8 @@ static int check_device_errors(swim_sim* s) {
   HIPCK(s, hipStreamSynchronize(s->stream));
   HIPCK(s, hipGetLastError());
   if (e & SW_ERR_XCHG_TIMEOUT) {
-    snprintf(s->err, sizeof s->err, "swim_xchg_step: a source shard did not deliver within %u ms (is every shard stepping?)", s->D.xchg_timeout_ms);
+    snprintf(s->err, sizeof s->err, "a source shard did not deliver this tick's records (swim_xchg_step: no flag within %u ms; swim_frame_deliver: a frame "
+             "whose header is not this tick's) - is every shard stepping?", s->D.xchg_timeout_ms);
     return SWIM_ESTATE;
   }
   if (e) {
@@ -893,6 +894,34 @@ extern "C" int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   s->in_count += count;
   return SWIM_OK;
 }
+// ---- framed exchange (swimsim.h): one equal-split collective per tick, the counts stay on the device ----------------------
+extern "C" uint32_t swim_frame_records(swim_sim* s) {
+  if (!s) return 0;
+  uint32_t mc = 1;                                   // (a lone shard: a header and one record nobody fills)
+  for (uint32_t sh = 0; sh < s->D.n_shards; sh++) if (sh != s->D.rank) mc = std::max(mc, s->D.out_cap[sh]);
+  return mc + 1;
+}
+static int frame_args(swim_sim* s, const void* p, uint32_t F) {
+  if (!s || !p || F < 2) return SWIM_EINVAL;
+  if (!s->in_tick) return SWIM_ESTATE;
+  return SWIM_OK;
+}
+extern "C" int swim_frame_pack(swim_sim* s, swim_edge* send, uint32_t F) {
+  int rc = frame_args(s, send, F);
+  if (rc) return rc;
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(std::min(F - 1, swim_frame_records(s) - 1), SW_BLOCK * 8), 64));
+  hipLaunchKernelGGL(k_frame_pack, dim3(xb, s->D.n_shards), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (uint4*)send, F);
+  return SWIM_OK;
+}
+extern "C" int swim_frame_deliver(swim_sim* s, const swim_edge* recv, uint32_t F) {
+  int rc = frame_args(s, recv, F);
+  if (rc) return rc;
+  const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(std::min(F - 1, swim_frame_records(s) - 1), SW_BLOCK * 8), 64));
+  { ProfScope p(s, PK_DELIVER); hipLaunchKernelGGL(k_frame_deliver, dim3(xb, s->D.n_shards), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (const uint4*)recv, F); }
+  s->peer_act_host = 2;          // the device has set the hint itself: the host's copy of it is stale (touched() raises it again)
+  return SWIM_OK;
+}
+
 // sharded runs: end tick t and begin tick t+1 in one go.  When nothing came in from other shards (every quiet
 // tick) the six launches are replayed from one captured graph instead of being issued one by one — the host
 // sits on the critical path of a sharded tick (it must read the exchanged counts), so its launch time shows.
@@ -983,6 +1012,7 @@ extern "C" int swim_xchg_step(swim_sim* s, uint32_t n) {
     } else { launch_begin(s, s->tick); launch_xchg(s); launch_end(s, s->tick); }
     advance(s, 1);
   }
+  if (n) s->peer_act_host = 2;   // k_xchg_wait sets the hint on the device: the host's copy is stale (touched() raises the word again after a stimulus)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(s->err, sizeof s->err, "launch failed: %s", hipGetErrorString(e)); return SWIM_ENODEV; }
   return SWIM_OK;

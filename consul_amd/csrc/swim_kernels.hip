@@ -1939,6 +1939,45 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver_mail(const SwDev* __restri
   if (src == D.rank) return;
   deliver_span<true>(D, mb_rec(D, D.mb_tab[D.rank], *D.tick & 1u, src), D.xin_cnt[src], blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
+// ---- swim_frame_*: the exchange as ONE equal-split collective, sizes known to the host, counts known to the device only (swimsim.h) ----
+// frame for shard blockIdx.y at send + blockIdx.y * F: header {count, activity, tick + 1, magic}, then the segment's records
+__global__ void __launch_bounds__(SW_BLOCK) k_frame_pack(const SwDev* __restrict__ Dp, uint4* send, uint32_t F) {
+  SW_DEV_BIND
+  const uint32_t dst = blockIdx.y;
+  uint4* const fr = send + (size_t)dst * F;
+  uint32_t n = dst == D.rank ? 0u : D.out_cnt[dst];
+  const uint32_t room = D.out_cap_tab[dst] < F - 1 ? D.out_cap_tab[dst] : F - 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t any = *D.act;
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) any |= D.out_cnt[sh];
+    if (n > room) atomicOr(D.err, SW_ERR_EDGE_OVF);
+    fr[0] = make_uint4(n < room ? n : room, any != 0, *D.tick + 1, SWIM_FRAME_MAGIC);
+  }
+  if (n > room) n = room;
+  const uint4* src = D.out_tab[dst];
+  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) fr[1 + e] = src[e];
+}
+// frame from shard blockIdx.y at recv + blockIdx.y * F: its records into the inboxes (judged here where the sender could not: SW_EDGE_JUDGE);
+// workgroup (0, 0) folds the activity words into next tick's hint
+__global__ void __launch_bounds__(SW_BLOCK) k_frame_deliver(const SwDev* __restrict__ Dp, const uint4* recv, uint32_t F) {
+  SW_DEV_BIND
+  const uint32_t src = blockIdx.y;
+  if (blockIdx.x == 0 && src == 0 && threadIdx.x == 0) {
+    uint32_t any = *D.act;
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) any |= D.out_cnt[sh];
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) {
+      if (sh == D.rank) continue;
+      const uint4 h = recv[(size_t)sh * F];
+      if (h.w != SWIM_FRAME_MAGIC || h.z != *D.tick + 1) { atomicOr(D.err, SW_ERR_XCHG_TIMEOUT); any = 1; }
+      else any |= h.y;
+    }
+    *D.peer_act = any != 0;
+  }
+  if (src == D.rank) return;
+  const uint4 h = recv[(size_t)src * F];
+  if (h.w != SWIM_FRAME_MAGIC || h.z != *D.tick + 1) return;
+  deliver_span<true>(D, recv + (size_t)src * F + 1, h.x < F - 1 ? h.x : F - 1, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
+}
 // records handed over by other shards (swim_inbound)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restrict__ Dp, const uint4* edges, uint32_t n) {
   SW_DEV_BIND

@@ -5,50 +5,46 @@ swim_tick_end.
 Two exchanges implement the same contract — "after run(), every shard has been handed the records
 every other shard addressed to it":
 
-  TorchExchange   one process per GPU; an all-to-all over torch.distributed.  With the "nccl"
-                  backend that is RCCL over xGMI on the device buffers; with "gloo" the same code
-                  moves host buffers (how the CPU tests cover the N>1 path).
+  TorchExchange   one process per GPU; ONE equal-split all_to_all_single over torch.distributed per
+                  tick, of frames whose headers carry the device-side counts (no host round trip).
+                  With the "nccl" backend that is RCCL over xGMI on device buffers; with "gloo" the
+                  same code moves host buffers (how the CPU tests cover the N>1 path).
   LocalExchange   several shards inside one process (e.g. all on one GPU): pointer hand-over.
                   Used to test the sharded kernels where only one device is available.
 
-The records are swim_edge (16 bytes).  Counts are exchanged first (one small all-to-all), then the
-payload with an uneven all_to_all_single; uniform random peer choice spreads remote records evenly
-over the destination shards, which suits xGMI's point-to-point mesh.
+The records are swim_edge (16 bytes); uniform random peer choice spreads remote records evenly over
+the destination shards, which suits xGMI's point-to-point mesh.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import List, Sequence
-
-import numpy as np
 
 from .sim import Sim
 
 
-class _DevMem:
-    """Expose a raw device pointer through __cuda_array_interface__ so torch can alias it."""
-
-    def __init__(self, ptr: int, n_words: int):
-        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i4", "data": (ptr, False),
-                                         "version": 2, "strides": None}
-
-
 class TorchExchange:
-    """All-to-all of the per-destination record segments over torch.distributed.
+    """The per-tick exchange as ONE equal-split all_to_all_single over torch.distributed, no host round trip.
 
-    GPU (backend nccl = RCCL over xGMI), device driven: the collectives are issued on the simulator's
-    own HIP stream (torch.cuda.ExternalStream), so kernels and exchange are ordered without host
-    synchronisation.  Per tick: all-gather the device-resident record counters (no D2H/H2D bounce),
-    read the gathered matrix once (the only host sync), and — only if some rank has remote records —
-    a list-form all_to_all (grouped ncclSend/ncclRecv) from slices of the aliased outbound buffers
-    straight into a persistent receive buffer.
-    CPU (backend gloo, used by the tests): host counts + uneven all_to_all_single of the concatenated
-    segments (gloo has no list form).
+    An all-to-all wants its sizes on the host; the record counts of a tick live on the device.  Instead of reading them
+    back every tick (rounds 1-3 did: an all-gather of the counters, `.cpu()`, then a list-form all-to-all), every rank
+    sends every other rank a FRAME of `frame_records` 16-byte records whose first record is a header the device writes
+    {count, activity word, tick + 1, magic} (swimsim.h: swim_frame_pack / swim_frame_deliver — what the library's mailbox
+    header does for its own exchange).  Per tick: pack (one kernel) -> all_to_all_single(recv, send) -> deliver (one
+    kernel, reads the counts out of the headers, folds the activity words into next tick's hint).  On the GPU (backend
+    nccl = RCCL over xGMI) all three are issued on the simulator's own HIP stream (torch.cuda.ExternalStream made torch's
+    current stream): nothing waits for the host, nothing is read back.  With gloo the same code moves host buffers of
+    the checker, which is how the CPU tests cover the N > 1 path.
+
+    frame_records: None = the library's bound (1 + the largest outbound capacity: can never overflow; the checker's
+    lists are unbounded, 65 536 there).  A smaller frame moves fewer bytes per tick; a segment that does not fit raises
+    the sticky edge-list overflow (SWIM_EOVERFLOW at the next sync).  Bytes on the wire per tick and rank:
+    (world - 1) * frame_records * 16, whatever the fill — the price of sizes the host never has to learn.
     """
 
     MAX_SHARDS = 16
+    ORACLE_FRAME = 1 << 16
 
-    def __init__(self, group, device_index: int | None):
+    def __init__(self, group, device_index: int | None, frame_records: int | None = None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -56,92 +52,40 @@ class TorchExchange:
         self.rank = dist.get_rank(group)
         self.on_gpu = device_index is not None
         self.device = torch.device("cuda", device_index) if self.on_gpu else torch.device("cpu")
-        self._bound = None          # simulator the GPU aliases belong to
-        self._recv = None
-        self._empty = torch.empty((0, 4), dtype=torch.int32, device=self.device)
-        self.skipped = 0            # ticks in which no rank had anything to send
+        self.frame_records = frame_records
+        self._bound = None          # simulator the frames were sized for
+        self._send = self._recv = None
+        self._F = 0
 
-    # ---- GPU path -------------------------------------------------------------------------------
     def _bind(self, sim: Sim):
         torch = self.torch
-        self._stream = torch.cuda.ExternalStream(sim.stream_ptr(), device=self.device)
-        self._segs = []
-        cnt_ptr = 0
-        for sh in range(self.world):
-            seg, cnt_ptr = sim.outbound_raw(sh)
-            cap = sim.outbound_capacity(sh)
-            self._segs.append(torch.as_tensor(_DevMem(seg, cap * 4), device=self.device).view(cap, 4))
-        # the n_shards counters, then the shard's activity word (swim_peer_activity)
-        self._counts = torch.as_tensor(_DevMem(cnt_ptr, self.world + 1), device=self.device)
-        self._gathered = torch.empty((self.world, self.world + 1), dtype=torch.int32, device=self.device)
-        self._caps = [sim.outbound_capacity(sh) for sh in range(self.world)]
+        F = self.frame_records or sim.frame_records() or self.ORACLE_FRAME
+        if F < 2:
+            raise ValueError("a frame holds a header and at least one record")
+        self._F = F
+        # (zero-filled once: a frame's tail beyond its count is never read, but it does cross the wire)
+        self._send = torch.zeros((self.world * F, 4), dtype=torch.int32, device=self.device)
+        self._recv = torch.zeros((self.world * F, 4), dtype=torch.int32, device=self.device)
+        if self.on_gpu:
+            # everything this exchange issues goes to the simulator's stream: make it torch's current stream once
+            # (entering a stream context per tick costs ~9 us of host time that sits on the tick's critical path)
+            self._stream = torch.cuda.ExternalStream(sim.stream_ptr(), device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # the two fills above
+            torch.cuda.set_stream(self._stream)
         self._bound = sim
-        # everything this exchange issues goes to the simulator's stream: make it torch's current stream once
-        # (entering a stream context per tick costs ~9 us of host time that sits on the tick's critical path)
-        torch.cuda.set_stream(self._stream)
 
-    def _run_gpu(self, sim: Sim):
-        torch, dist = self.torch, self.dist
-        if self._bound is not sim:
-            self._bind(sim)
-        if True:
-            dist.all_gather_into_tensor(self._gathered, self._counts, group=self.group)
-            m = self._gathered.cpu().tolist()              # the tick's only host synchronisation; plain lists from here
-            # nobody emitted anything and nobody can hold a queued broadcast: next tick's probes need not file
-            # piggy-back orders for nodes of other shards, and the quiescent tick stays off the wire
-            W = self.world
-            sim.peer_activity(any(any(row) for row in m))
-            remote_total = sum(m[i][j] for i in range(W) for j in range(W) if i != j)
-            if remote_total == 0:
-                self.skipped += 1
-                return
-            # every rank derives the same (clamped) sizes from the same matrix; a clamped segment has
-            # already raised the sender's sticky overflow flag
-            rcap = min(c for sh, c in enumerate(self._caps) if sh != self.rank)     # (outbound_capacity is the same number on every rank: one configuration)
-            send = [0 if sh == self.rank else min(m[self.rank][sh], rcap) for sh in range(W)]
-            recv_n = [0 if src == self.rank else min(m[src][self.rank], rcap) for src in range(W)]
-            total = sum(recv_n)
-            if self._recv is None or self._recv.shape[0] < total:
-                self._recv = torch.empty((max(total, 1) * 2, 4), dtype=torch.int32, device=self.device)
-            outs, off = [], 0
-            for n in recv_n:
-                outs.append(self._recv[off:off + n]); off += n
-            ins = [self._segs[sh][: send[sh]] for sh in range(self.world)]
-            dist.all_to_all(outs, ins, group=self.group)
-            if total:
-                sim.inbound(self._recv.data_ptr(), total)  # asynchronous copy on the same stream
-
-    # ---- CPU path -------------------------------------------------------------------------------
-    def _run_cpu(self, sim: Sim):
-        torch, dist = self.torch, self.dist
-        segs, counts = [], []
-        for sh in range(self.world):
-            ptr, n = sim.outbound(sh)
-            if sh == self.rank:
-                n = 0                            # the local segment never crosses the wire
-            if n:
-                buf = (C.c_int32 * (n * 4)).from_address(ptr)
-                segs.append(torch.from_numpy(np.frombuffer(buf, dtype=np.int32).reshape(n, 4)))
-            else:
-                segs.append(self._empty)
-            counts.append(n)
-        send_counts = torch.tensor(counts, dtype=torch.int64)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        rc = [int(x) for x in recv_counts.tolist()]
-        total = sum(rc)
-        recv = torch.empty((total, 4), dtype=torch.int32)
-        send = torch.cat(segs, dim=0) if sum(counts) else self._empty
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=counts, group=self.group)
-        if total:
-            sim.inbound(recv.data_ptr(), total)  # the oracle copies synchronously
+    @property
+    def frame_bytes_per_tick(self) -> int:
+        """What one rank puts on the wire per tick (its own frame stays home)."""
+        return (self.world - 1) * self._F * 16
 
     def run(self, sims: Sequence[Sim]):
         (sim,) = sims
-        if self.on_gpu:
-            self._run_gpu(sim)
-        else:
-            self._run_cpu(sim)
+        if self._bound is not sim:
+            self._bind(sim)
+        sim.frame_pack(self._send.data_ptr(), self._F)
+        self.dist.all_to_all_single(self._recv, self._send, group=self.group)
+        sim.frame_deliver(self._recv.data_ptr(), self._F)
 
     def close(self):
         """Give torch its default stream back (the simulator's stream is about to be destroyed)."""
@@ -149,6 +93,39 @@ class TorchExchange:
             self.torch.cuda.current_stream(self.device).synchronize()
             self.torch.cuda.set_stream(self.torch.cuda.default_stream(self.device))
         self._bound = None
+
+
+class LocalFramedExchange:
+    """The framed exchange between shards that live in ONE process (tests; one device): every shard packs its frames, the
+    frames are transposed with plain copies (what the collective does between processes), every shard delivers.  `alloc(n)`
+    returns a buffer of n records and `ptr(buf)` its address — numpy on the checker, torch device tensors on the product
+    library; `copy(dst, d0, src, s0, n)` moves n records; `sync()` orders the phases (the shards run on different streams)."""
+
+    def __init__(self, alloc, ptr, copy, sync=lambda: None, frame_records: int | None = None):
+        self.alloc, self.ptr, self.copy, self.sync = alloc, ptr, copy, sync
+        self.frame_records = frame_records
+        self._F = 0
+
+    def run(self, sims: Sequence[Sim]):
+        W = len(sims)
+        if not self._F:
+            self._F = self.frame_records or sims[0].frame_records() or TorchExchange.ORACLE_FRAME
+            self._send = [self.alloc(W * self._F) for _ in sims]
+            self._recv = [self.alloc(W * self._F) for _ in sims]
+        F = self._F
+        for s, b in zip(sims, self._send):
+            s.frame_pack(self.ptr(b), F)
+        for s in sims:
+            s.sync()
+        for i in range(W):
+            for j in range(W):
+                if i != j:
+                    self.copy(self._recv[j], i * F, self._send[i], j * F, F)
+        self.sync()
+        for s, b in zip(sims, self._recv):
+            s.frame_deliver(self.ptr(b), F)
+        for s in sims:
+            s.sync()
 
 
 class LocalExchange:

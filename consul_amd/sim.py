@@ -145,6 +145,17 @@ class Sim:
         self._ck("swim_activity", self._l.swim_activity(self._h, C.byref(a)))
         return bool(a.value)
 
+    # -- framed exchange (one equal-split collective per tick, the counts stay on the device) --------
+    def frame_records(self) -> int:
+        """The smallest frame that can never overflow (0 on the checker: its lists are unbounded)."""
+        return int(self._l.swim_frame_records(self._h))
+
+    def frame_pack(self, send_ptr: int, frame_records: int):
+        self._ck("swim_frame_pack", self._l.swim_frame_pack(self._h, C.c_void_p(send_ptr), frame_records))
+
+    def frame_deliver(self, recv_ptr: int, frame_records: int):
+        self._ck("swim_frame_deliver", self._l.swim_frame_deliver(self._h, C.c_void_p(recv_ptr), frame_records))
+
     def tick_end(self):
         self._ck("swim_tick_end", self._l.swim_tick_end(self._h))
 

@@ -356,6 +356,26 @@ int swim_tick_end_begin(swim_sim* sim);
 int swim_peer_activity(swim_sim* sim, int active);
 int swim_activity(swim_sim* sim, int* active);
 
+/* ---- framed exchange: the split tick for a COLLECTIVE with host-known sizes and no host round trip -----------------------
+ * (north_star's "all-to-all over RCCL"; consul_amd/dist.py TorchExchange).  An all-to-all wants its sizes on the host, the
+ * record counts of a tick live on the device: instead of reading them back every tick, every shard sends every other shard a
+ * FRAME of `frame_records` 16-byte records — record 0 is a header {count, activity word, tick + 1, SWIM_FRAME_MAGIC} written
+ * by the device, records 1..count the segment for that shard — with one equal-split all_to_all_single, and the receiving
+ * device reads the counts out of the headers:
+ *   swim_tick_begin -> swim_frame_pack(send) -> all_to_all_single(recv, send) -> swim_frame_deliver(recv) -> swim_tick_end[_begin]
+ * send / recv: n_shards * frame_records records, frame j of `send` for shard j, frame i of `recv` from shard i (the own frame
+ * is empty and ignored); device memory on the product library (both calls are asynchronous on the simulator's stream: issue
+ * the collective on swim_stream), host memory on the oracle.  The activity word of swim_peer_activity travels in the headers
+ * and is applied by swim_frame_deliver.  A segment that does not fit frame_records - 1 records raises the sticky overflow
+ * error of the edge lists (SWIM_EOVERFLOW at the next swim_sync); a frame whose header is not this tick's, SWIM_ESTATE.
+ * swim_frame_records = the smallest frame that can never overflow (1 + the largest outbound capacity; every shard of a
+ * population answers the same number); 0 on the oracle, whose lists are unbounded — pick any size there.  A population of ONE
+ * shard may make the same calls (its only frame is its own, empty): the plumbing of a collective can be checked on one device. */
+#define SWIM_FRAME_MAGIC 0x4D415246u   /* "FRAM" */
+uint32_t swim_frame_records(swim_sim* sim);
+int swim_frame_pack(swim_sim* sim, swim_edge* send, uint32_t frame_records);
+int swim_frame_deliver(swim_sim* sim, const swim_edge* recv, uint32_t frame_records);
+
 /* ---- device-driven exchange between the shards of one population (peer-mapped mailboxes over xGMI) -------
  * The split tick above leaves the exchange to the caller (consul_amd/dist.py uses RCCL).  This is the library's own: every
  * shard owns a mailbox in its HBM (one area per source shard, double buffered by tick parity), exports it as an IPC handle,

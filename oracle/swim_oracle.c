@@ -1633,6 +1633,32 @@ int swim_inbound(swim_sim* s, const swim_edge* ptr, uint32_t count) {
   }
   return SWIM_OK;
 }
+/* the framed exchange (swimsim.h) on host memory: frame j of `send` = header {count, 1, tick + 1, magic} + this shard's list for shard j */
+uint32_t swim_frame_records(swim_sim* s) { (void)s; return 0; }      /* the lists are unbounded here: any frame size will do */
+int swim_frame_pack(swim_sim* s, swim_edge* send, uint32_t F) {
+  if (!s || !send || F < 2) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  for (uint32_t j = 0; j < s->cfg.n_shards; j++) {
+    swim_edge* fr = send + (size_t)j * F;
+    uint32_t n = j == s->cfg.shard_rank ? 0 : s->out[j].n;
+    if (n > F - 1) { snprintf(s->err, sizeof s->err, "bounded structure overflowed: edge-list (a frame of %u records, %u to send)", F, n); return SWIM_EOVERFLOW; }
+    fr[0].dst = n; fr[0].subject = 1; fr[0].incarnation = s->tick + 1; fr[0].meta = SWIM_FRAME_MAGIC;
+    if (n) memcpy(fr + 1, s->out[j].v, (size_t)n * sizeof(swim_edge));
+  }
+  return SWIM_OK;
+}
+int swim_frame_deliver(swim_sim* s, const swim_edge* recv, uint32_t F) {
+  if (!s || !recv || F < 2) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  for (uint32_t i = 0; i < s->cfg.n_shards; i++) {
+    if (i == s->cfg.shard_rank) continue;
+    const swim_edge* fr = recv + (size_t)i * F;
+    if (fr[0].meta != SWIM_FRAME_MAGIC || fr[0].incarnation != s->tick + 1 || fr[0].dst > F - 1) {
+      snprintf(s->err, sizeof s->err, "swim_frame_deliver: frame %u is not this tick's (is every shard stepping?)", i); return SWIM_ESTATE;
+    }
+    int rc = swim_inbound(s, fr + 1, fr[0].dst);
+    if (rc) return rc;
+  }
+  return SWIM_OK;
+}
 int swim_tick_end(swim_sim* s) {
   if (!s) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
   phase_deliver_resolve(s);

@@ -1,8 +1,9 @@
 """The N>1 path on CPU: every replica's population block-partitioned over shards.
 
  * in-process: 2 and 4 shards of the oracle, records handed over by pointer (LocalExchange);
- * two real processes over torch.distributed/gloo: counts + uneven all_to_all_single
-   (TorchExchange — the code path bench.py uses with the nccl backend on GPUs).
+ * in-process: the framed exchange (swim_frame_pack / swim_frame_deliver) with the frames transposed by plain copies;
+ * two real processes over torch.distributed/gloo: one equal-split all_to_all_single of frames per tick, the counts
+   in the frames' headers (TorchExchange — the code path bench.py uses with the nccl backend on GPUs: no host round trip).
 Both must reproduce the unsharded oracle bit for bit (digests add up; counters add up)."""
 import os
 import subprocess
@@ -11,7 +12,9 @@ import sys
 import pytest
 
 from consul_amd import abi
-from consul_amd.dist import LibraryExchange, LocalExchange, ShardedSim
+import numpy as np
+
+from consul_amd.dist import LibraryExchange, LocalExchange, LocalFramedExchange, ShardedSim
 from consul_amd.sim import Sim, preset
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,6 +81,56 @@ def test_tcp_classes_are_ground_truth_on_every_shard(oracle):
     a, b = sh.stats(), ref.stats()
     assert a["inbox_overflow"] == b["inbox_overflow"] == 0     # (a shard cannot filter what another shard sends it: room for all of it)
     assert a["probe_tcp_acks"] == b["probe_tcp_acks"] > 0 and a["probe_failures"] == b["probe_failures"] > 0 and a["refutes"] == b["refutes"]
+
+
+def numpy_frames(frame_records=None):
+    """LocalFramedExchange over host memory (the checker)."""
+    def copy(dst, d0, src, s0, n):
+        dst[d0:d0 + n] = src[s0:s0 + n]
+    return LocalFramedExchange(alloc=lambda n: np.zeros((n, 4), dtype=np.uint32), ptr=lambda b: b.ctypes.data, copy=copy, frame_records=frame_records)
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_framed_exchange_matches_unsharded(oracle, n_shards):
+    """swim_frame_pack / swim_frame_deliver: per-destination frames {header: count, activity, tick + 1, magic; records}, transposed
+    between the shards like an equal-split all-to-all does — same run as with the pointer hand-over, same as unsharded; fold ticks
+    and push-pull included."""
+    kw = dict(n_nodes=1024, n_replicas=2, seed=9, fold_interval_ms=3000, push_pull_interval_ms=2000, view_cap=64,
+              loss_q32=int(0.05 * 2**32))
+    mk = lambda ex: ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, **kw)) for i in range(n_shards)], ex)
+    fr, ptr, ref = mk(numpy_frames()), mk(LocalExchange()), Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (fr, ptr, ref):
+        s.step_ms(1000); s.kill(0, [5, 700]); s.update(1, [512]); s.step_ms(30000)
+    assert fr.digest() == ptr.digest() == ref.digest()
+    a, b, c = fr.stats(), ptr.stats(), ref.stats()
+    for k in ("msgs_sent", "refutes", "msgs_applied", "packets_sent", "edges", "msgs_filtered", "folds", "push_pulls"):
+        assert a[k] == b[k] == c[k], k
+    assert a["edges_remote"] == b["edges_remote"] > 0
+
+
+def test_framed_exchange_refuses_what_it_cannot_carry(oracle):
+    kw = dict(n_nodes=512, seed=3, push_pull_interval_ms=1000)
+    sims = [Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)]
+    assert sims[0].frame_records() == 0                 # the checker's lists are unbounded: the caller picks a frame size
+    sh = ShardedSim(sims, numpy_frames(frame_records=4))
+    with pytest.raises(Exception, match="overflow|EOVERFLOW|frame"):   # the probes' piggy-back orders alone are more than three records a tick
+        sh.step_ms(5000)
+    # frames of another tick (a shard that did not step) are refused
+    a, b = [Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)]
+    F = 64
+    sa, sb = np.zeros((2 * F, 4), dtype=np.uint32), np.zeros((2 * F, 4), dtype=np.uint32)
+    with pytest.raises(Exception):
+        a.frame_pack(sa.ctypes.data, F)                 # no tick open
+    a.tick_begin(); b.tick_begin()
+    a.frame_pack(sa.ctypes.data, F); b.frame_pack(sb.ctypes.data, F)
+    assert tuple(sa[F]) [2:] == (1, abi.FRAME_MAGIC) and sa[0][0] == 0      # header of the frame for shard 1: tick + 1, magic; the own frame is empty
+    ra = np.zeros((2 * F, 4), dtype=np.uint32); ra[F:] = sb[:F]
+    a.frame_deliver(ra.ctypes.data, F)
+    a.tick_end_begin()
+    with pytest.raises(Exception, match="tick"):
+        a.frame_deliver(ra.ctypes.data, F)              # last tick's frame
+    with pytest.raises(Exception):
+        a.frame_pack(sa.ctypes.data, 1)                 # a frame holds a header and at least one record
 
 
 @pytest.mark.parametrize("n_shards", [2, 4])

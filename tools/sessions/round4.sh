@@ -178,3 +178,20 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04k; mkdir -p $O
 ( time timeout 1200 python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+
+# ---- r4_gpu12.sh
+# round 4, GPU call 12: the framed exchange (swim_frame_pack / swim_frame_deliver, TorchExchange over RCCL with a world of one) — its tests,
+# then what the split tick + one collective per tick costs on one device beside the captured-graph replay
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04m; mkdir -p $O
+( time timeout 400 python -m pytest tests/test_framed_exchange_gpu.py -x -q ) > $O/pytest_framed.log 2>&1; tail -25 $O/pytest_framed.log
+timeout 200 python tools/exchange_cost.py > $O/exchange_cost.txt 2>&1; head -5 $O/exchange_cost.txt
+timeout 200 python bench.py --force-exchange --exchange rccl --main-only --handles 1 --steps 20 --warmup 5 > $O/bench_force_rccl.json 2> $O/bench_force_rccl.err; tail -3 $O/bench_force_rccl.err; cut -c1-400 $O/bench_force_rccl.json
+
+# ---- r4_gpu13.sh
+# round 4, GPU call 13: the framed-exchange tests again (the in-process ones now allocate through the library's own HIP runtime, not torch)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04n; mkdir -p $O
+( time timeout 400 python -m pytest tests/test_framed_exchange_gpu.py -q ) > $O/pytest_framed.log 2>&1; tail -30 $O/pytest_framed.log
