@@ -160,7 +160,7 @@ typedef struct swim_config {
                                        incarnation and state, not Suspect, Dead for longer than
                                        GossipToTheDeadTime) is folded into the base row and its entries are
                                        freed (SURVEY §7 hard part 1, App. D k_reap_fold); 0 = never            */
-  uint32_t event_queue_cap;         /* per-node serf user-event queue slots (<= 32)         */
+  uint32_t event_queue_cap;         /* per-node serf user-event queue slots (<= 32; the oracle holds up to 8192: serf's max(2N, 4096)) */
   uint32_t event_buffer;            /* serf EventBuffer ring size (default 512)             */
   uint32_t event_ids_per_ltime;     /* distinct user events (and intents) a node remembers per Lamport time: serf's slot is an
                                        unbounded list, and a flood stamps many events alike; one more with the same LTime is

@@ -35,6 +35,8 @@
 #define _GNU_SOURCE
 #include "../include/swimsim.h"
 
+#define EVQ_MAX 8192   /* serf sizes its event queue max(2N, 4096) (internal/gossip/libserf/serf.go:22-27); the checker can hold that for N <= 4096 */
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -173,7 +175,7 @@ static int validate(const swim_config* c) {
   if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
   if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
   if (c->flags & SWIM_F_SERF_EVENTS)
-    if (c->event_queue_cap < 1 || c->event_queue_cap > 32 || c->event_buffer < 1 || c->event_ids_per_ltime > 254) return SWIM_EINVAL;
+    if (c->event_queue_cap < 1 || c->event_queue_cap > EVQ_MAX || c->event_buffer < 1 || c->event_ids_per_ltime > 254) return SWIM_EINVAL;   /* (the product library: <= 32) */
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
   if (c->n_initial > c->n_nodes || c->n_initial == 1) return SWIM_EINVAL;
   if (c->phase_chunk & (c->phase_chunk - 1)) return SWIM_EINVAL;
@@ -529,24 +531,27 @@ static void queue_push(swim_sim* s, qent* q, uint32_t* qlen, uint32_t* qseq, uin
 }
 
 /* GetBroadcasts(overhead, limit): walk tiers by transmit count, inside a tier largest first then
- * newest, take what fits, bump transmits after the sweep, retire at retransmitLimit. */
+ * newest, take what fits, bump transmits after the sweep, retire at retransmitLimit.
+ * (`taken` is a byte per entry: the checker's event queue may be as deep as serf's — EVQ_MAX — where the product library's holds 32) */
 static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out, uint32_t retransmit_limit) {
-  uint32_t n = *qlen, taken = 0, cnt = 0; int32_t used = 0;
+  uint32_t n = *qlen, cnt = 0; int32_t used = 0;
+  static _Thread_local uint8_t taken[EVQ_MAX];
+  memset(taken, 0, n);
   for (;;) {
     int32_t free_b = limit - used - (int32_t)overhead;
     if (free_b <= 0) break;
     uint32_t best = SWIM_NONE;
     for (uint32_t i = 0; i < n; i++) {
-      if ((taken >> i) & 1u) continue;
+      if (taken[i]) continue;
       if ((int32_t)ent_len(s, &q[i]) > free_b) continue;
       if (best == SWIM_NONE || ent_before(s, &q[i], &q[best])) best = i;
     }
     if (best == SWIM_NONE) break;
-    taken |= 1u << best; used += (int32_t)(overhead + ent_len(s, &q[best])); out[cnt++] = q[best];
+    taken[best] = 1; used += (int32_t)(overhead + ent_len(s, &q[best])); out[cnt++] = q[best];
   }
   uint32_t m = 0;
   for (uint32_t i = 0; i < n; i++) {
-    if ((taken >> i) & 1u) {
+    if (taken[i]) {
       if ((uint32_t)q[i].transmits + 1 >= retransmit_limit) continue;   /* Finished() */
       q[i].transmits++;
     }

@@ -113,6 +113,39 @@ def run_mass_kill(sim, n, checkpoints, until_detected=True, limit_s=2000):
     return out
 
 
+# BASELINE config #4 AS WRITTEN and its recovery phase, nothing dropped: 5 % of 65 536 nodes are cut off (a partition mask, both
+# directions: the majority declares the minority dead AND the minority starts on the majority), the cut heals after 60 s — when the
+# majority holds ~98 % of the minority dead — and serf's reconnect() (agent/consul/config.go:640-641 ReconnectTimeout's companion,
+# serf.Config.ReconnectInterval 30 s), push-pull and refutation bring everybody back while folds hand the rows of the dense store back.
+# A row for EVERY node on the HIP library (both directions live in the store), hash tables for all of them on the checker.
+PARTITION_HEAL_64K = dict(n_nodes=65536, seed=13, queue_cap=32, inbox_cap=32768, subject_cap=4, fold_interval_ms=5000, reconnect_interval_ms=30000)
+PARTITION_HEAL_64K_ORACLE = dict(view_cap=65536)
+PARTITION_HEAL_64K_HIP = dict(view_cap=8, mass_rows=65536)
+HEAL_STAT_KEYS = MASS_STAT_KEYS + ("reconnects", "reconnects_reached", "msgs_filtered")
+
+
+def run_partition_heal_mass(sim, n, cut_s=60, checkpoints=(30, 60, 90, 120, 180, 240), sample=(0, 1, 2, 3)):
+    """1 s of quiet, the cut, `cut_s` seconds later the heal; {second: (digest, stats subset, detection, members not alive in the eyes
+    of a few observers of either side)} at the checkpoints."""
+    mask = partition_mask(n, rng_seed=4)
+    minority, majority = np.flatnonzero(mask), np.flatnonzero(mask == 0)
+    watchers = [int(majority[i]) for i in sample] + [int(minority[i]) for i in sample]
+    out = {}
+    sim.step_ms(1000)
+    sim.partition(0, mask)
+    for sec in range(2, max(checkpoints) + 1):
+        if sec == cut_s + 2:
+            sim.partition(0, np.zeros(n, dtype=np.uint8))
+        sim.step_ms(1000)
+        if sec in checkpoints:
+            sim.sync()
+            st = sim.stats()
+            pairs, by = sim.detection(0)
+            not_alive = [int(sum(1 for m in sim.members(0, w) if int(m["status"]) != abi.MEMBER_ALIVE)) for w in watchers]
+            out[sec] = (sim.digest(), {k: st[k] for k in HEAL_STAT_KEYS}, [pairs] + by, not_alive)
+    return out
+
+
 # BASELINE config #5's shape with nothing dropped: 10 %/s churn (kill / revive) AND a flood of serf user events, Lifeguard on.
 # Every node becomes a subject: the checker holds N views per observer in its hash tables, the HIP library a row per node.
 CHURN_EVENTS_8K = dict(n_nodes=8192, seed=12, queue_cap=16, event_queue_cap=16, event_ids_per_ltime=30, inbox_cap=8192, subject_cap=4, fold_interval_ms=5000,

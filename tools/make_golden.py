@@ -75,6 +75,16 @@ def config4_mass_kill():
     return out
 
 
+def config4_partition_heal():
+    """BASELINE config #4 as written (a partition, both directions) and its recovery phase, 65 536 nodes, nothing dropped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenarios as sc
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.PARTITION_HEAL_64K, **sc.PARTITION_HEAL_64K_ORACLE))
+    res = sc.run_partition_heal_mass(s, sc.PARTITION_HEAL_64K["n_nodes"])
+    return {"config": sc.PARTITION_HEAL_64K, "oracle_only": sc.PARTITION_HEAL_64K_ORACLE,
+            "checkpoints": {str(k): {"digest": f"{v[0]:#018x}", "stats": v[1], "detection": v[2], "not_alive_seen_by_watchers": v[3]} for k, v in res.items()}}
+
+
 def config5_churn_events():
     """BASELINE config #5's shape with nothing dropped, 8 192 nodes: 10 %/s churn and 20 serf user events/s for 40 s."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -97,7 +107,8 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small),
-                     ("config3_infection_1m", config3_full), ("config4_mass_kill_64k", config4_mass_kill), ("config5_churn_events_8k", config5_churn_events)):
+                     ("config3_infection_1m", config3_full), ("config4_mass_kill_64k", config4_mass_kill), ("config4_partition_heal_64k", config4_partition_heal),
+                     ("config5_churn_events_8k", config5_churn_events)):
         if only and name not in only:
             continue
         with open(os.path.join(ROOT, "tests", "golden", name + ".json"), "w") as f:
