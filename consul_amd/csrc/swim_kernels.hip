@@ -2705,7 +2705,14 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
   __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
+#ifdef SW_RESOLVE_LINE1
+  // (-DSW_RESOLVE_LINE1, an A/B build for round 5: only the first 16 bytes of a lane's inbox line — the count word's neighbours: message 0 —
+  //  are parked in LDS, 4 KB instead of 16; the words of messages 1..4 are read from the line itself when a lane gets that far (it sits in
+  //  the L2 — the same 128-byte line — since the first load).  LDS per workgroup 37 -> 25 KB: with -DSW_RESOLVE_WAVES=5 five workgroups per CU fit)
+  __shared__ uint4 s_in[1][SW_BLOCK];
+#else
   __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
+#endif
   const uint32_t nb0 = (D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + blockIdx.x] : blockIdx.x) * SW_RTILE;   // heavy tiles first
 #ifdef SWIMSIM_WAVECLK
   unsigned long long wclk[4]; WCLK(0);
@@ -2784,11 +2791,19 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
     // stay cache resident instead of pulling in the node's 64-byte message line)
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
+#ifdef SW_RESOLVE_LINE1
+    s_in[0][threadIdx.x] = row4[0];
+#else
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
+#endif
     const uint4 hdr0 = HDR(l);
     const uint4 vm0 = VMETA(l);
     D.in_cnt[l] = 0;
+#ifdef SW_RESOLVE_LINE1
+#define IN_WORD(w) ((w) < 4u ? ((const uint32_t*)&s_in[0][threadIdx.x])[(w) & 3u] : ((const uint32_t*)row4)[(w)])
+#else
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
+#endif
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;

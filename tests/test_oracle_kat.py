@@ -97,6 +97,18 @@ def test_remaining_suspicion_time(anylib, n, elapsed, want):
     assert anylib.swim_kat_remaining_suspicion_ms(n, 3, elapsed, 2000, 30000) == want
 
 
+@pytest.mark.parametrize("confirmations,want,fudge", [
+    (0, 2000, 0), (1, 1250, 0), (2, 810, 2), (3, 500, 0), (4, 500, 0)])
+def test_suspicion_timer_table_like_upstream(anylib, confirmations, want, fudge):
+    """memberlist suspicion_test.go TestSuspicion_Timer (recalled): k = 3, min 500 ms, max 2 s; the timer's length after 0, 1 (also when
+    the same confirmer repeats), 2, 3 and more independent confirmations: max, 1 250 ms, 810 ms, min, min.  Upstream compares within a
+    fudge of 25 ms; the formula gives 811 (floor(1000 * (2 - log 3 / log 4 * 1.5)) ms), within 2 of the table's figure."""
+    got = anylib.swim_kat_remaining_suspicion_ms(confirmations, 3, 0, 500, 2000)
+    assert abs(got - want) <= fudge, got
+    if confirmations == 2:
+        assert got == 811
+
+
 def test_suspicion_table_lan_fraction(anylib):
     """LAN k=2: n=1 -> max - log(2)/log(3) * (max - min), floor to ms."""
     d = derive(anylib, preset(anylib, abi.PRESET_LAN, n_nodes=65536))

@@ -120,3 +120,36 @@ def test_refutation_on_the_checker(oracle):
 @pytest.mark.gpu
 def test_refutation_on_hip(hip):
     refutation(hip)
+
+
+def merge_state(lib):
+    """After upstream's TestMemberList_MergeState (state_test.go): three members alive at incarnation 1, the first of them suspected;
+    a remote state list arrives that holds the first ALIVE at incarnation 2, the second SUSPECT at 1, the third DEAD at 1 and a fourth,
+    unknown member alive at 2.  mergeState turns the list into aliveNode / suspectNode calls — a remote Dead is never adopted: it
+    becomes a suspicion from the receiver itself — so afterwards the first is alive at 2 (the newer incarnation clears the
+    suspicion), the second and the third are suspect at 1, the fourth has joined at 2, and the receiver's EventCh has exactly one
+    NodeJoin, the fourth's.  The list comes in as ONE packet through the transport bridge, the way BridgeTransport::PushPull hands it over."""
+    t1, t2, t3, t4 = 5, 6, 7, N - 1
+    s = Sim(lib, preset(lib, abi.PRESET_LAN, n_nodes=N, n_initial=N - 1, seed=2, probe_interval_ms=100000, probe_timeout_ms=500, push_pull_interval_ms=0,
+                        view_cap=N, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=OBS))
+    mask = np.zeros(N, dtype=np.uint8); mask[OBS] = 1
+    s.partition(0, mask)
+    s.transport_write_to(0, REAL, OBS, [(t1, 1, abi.MSG_SUSPECT, ACCUSER)]); s.step(1)
+    assert (s.view(0, OBS, t1).state, s.view(0, OBS, t4).state) == (S, D)      # (a node nobody has heard of reads as the base row: Dead at incarnation 0)
+    s.poll_events()
+    s.transport_write_to(0, REAL, OBS, [(t1, 2, abi.MSG_ALIVE, 0), (t2, 1, abi.MSG_SUSPECT, OBS), (t3, 1, abi.MSG_SUSPECT, OBS), (t4, 2, abi.MSG_ALIVE, 0)])
+    s.step(1)
+    got = {x: (s.view(0, OBS, x).state, s.view(0, OBS, x).incarnation) for x in (t1, t2, t3, t4)}
+    assert got == {t1: (A, 2), t2: (S, 1), t3: (S, 1), t4: (A, 2)}, got
+    joins = [e for e in s.poll_events() if e[2] == abi.EVENT_MEMBER_JOIN]
+    assert [(e[3], e[6]) for e in joins] == [(t4, OBS)], joins
+    s.close()
+
+
+def test_merge_state_on_the_checker(oracle):
+    merge_state(oracle)
+
+
+@pytest.mark.gpu
+def test_merge_state_on_hip(hip):
+    merge_state(hip)
