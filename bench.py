@@ -310,7 +310,8 @@ def run_detection(hip, cfg_kw, victims, G, quantum_ms) -> dict:
                     # north_star asks for +-1 round against memberlist; against the asynchronous model the lock-step determinisation is on time
                     # for first suspicion and first Dead and LATE on the last leg (a verdict is merged at the end of its tick and broadcasts
                     # on pings arrive a tick later): say so next to the numbers
-                    "all_know_dead_is_late_by_gossip_rounds": 1.45}}}
+                    "all_know_dead_is_late_by_gossip_rounds": 1.45,
+                                                                      "with_a_50_ms_tick": "all three legs within one gossip round of the asynchronous model (swim_config.quantum_ms = 50; tests/test_async_reference.py)"}}}
 
 
 def run_config4(hip, args, device) -> dict:

@@ -52,6 +52,33 @@ def both(oracle):
     return a, lock
 
 
+@pytest.fixture(scope="module")
+def lock_half_quantum(oracle):
+    """The same 120 runs of the lock-step simulator with a 50 ms tick instead of the 100 ms the presets derive (swim_config.quantum_ms)."""
+    lock = []
+    for s in range(1, SEEDS + 1):
+        sim = Sim(oracle, preset(oracle, abi.PRESET_LAN, n_nodes=128, seed=s, quantum_ms=50))
+        sim.step_ms(10000); sim.kill(0, [17]); sim.step_ms(60000)
+        c = sim.census(0, 17)
+        lock.append(tuple((x - 10000) / 1000.0 for x in (c.first_suspect_ms, c.first_dead_ms, c.all_dead_ms)))
+        sim.close()
+    return lock
+
+
+def test_the_last_leg_is_a_discretisation_error_that_halves_with_the_tick(both, lock_half_quantum):
+    """north_star asks for +-1 gossip round.  "Everybody knows" is 1.45 rounds late at the default 100 ms tick (a verdict is merged at the
+    end of the tick it arrives in, a broadcast riding on a ping arrives a tick after its carrier): both are a tick's worth of delay per hop,
+    so with a 50 ms tick the lag must shrink accordingly — and all three legs then sit within ONE round of the asynchronous model.
+    (Finer still makes no sense at 128 nodes: the stagger has gossip_period x probe_period phases to fill, 320 at 25 ms.)"""
+    a, lock = both
+    for leg, name in ((0, "first suspicion"), (1, "first Dead verdict"), (2, "everybody knows")):
+        d100 = st.median([r[leg] for r in lock]) - st.median([r[leg] for r in a])
+        d50 = st.median([r[leg] for r in lock_half_quantum]) - st.median([r[leg] for r in a])
+        assert abs(d50) <= 1.0 * GOSSIP_ROUND, (name, d50)
+        if leg == 2:
+            assert d100 > 1.0 * GOSSIP_ROUND > d50 and d50 < d100 - 0.5 * GOSSIP_ROUND, (d100, d50)
+
+
 def test_everybody_detects_in_both_models(both):
     a, lock = both
     assert all(None not in r for r in a) and all(None not in r for r in lock)
