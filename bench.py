@@ -394,15 +394,26 @@ def run_config4_partition(hip, args, device) -> dict:
     s.step_ms(1000); s.partition(0, mask); s.sync()
     s0 = s.stats()
     t0 = time.perf_counter()
-    s.step_ms(1000 * cut_s); s.sync()
+    budget, gave_up = args.config4p_budget_s, False
+    for _ in range(cut_s // 10):                    # (10 s at a time: the wall-time budget is looked at in between)
+        s.step_ms(10000); s.sync()
+        if time.perf_counter() - t0 > budget:
+            gave_up = True
+            break
     t_cut = time.perf_counter() - t0
+    if gave_up:
+        out = {"n_nodes": n, "cut_off": nv, "gave_up": f"the cut alone passed the leg's wall-time budget ({budget:.0f} s; --config4p-budget-s)", "wall_s": round(t_cut, 2)}
+        s.close()
+        return out
     pairs, by = s.detection(0)
     at_heal = {"pairs_out_of_reach": pairs, "dead_fraction": (by[2] + by[3]) / max(pairs, 1), "suspect_fraction": by[1] / max(pairs, 1)}
     s.partition(0, np.zeros(n, dtype=np.uint8))
     curve, sec, recovered = [], cut_s, None
-    while sec < cut_s + 720:
-        s.step_ms(30000); sec += 30
-        s.sync()
+    while sec < cut_s + 720 and not gave_up:
+        for _ in range(3):
+            s.step_ms(10000); s.sync()
+            gave_up = gave_up or time.perf_counter() - t0 > budget
+        sec += 30
         left = [int(sum(1 for m in s.members(0, w) if int(m["status"]) != abi.MEMBER_ALIVE)) for w in watchers]
         st = diff_stats(s0, s.stats())
         curve.append({"t_s": sec, "wall_s": round(time.perf_counter() - t0, 2), "not_alive_seen_by_watchers": left, "refutes": st["refutes"],
@@ -412,7 +423,8 @@ def run_config4_partition(hip, args, device) -> dict:
             break
     dt = time.perf_counter() - t0
     st = diff_stats(s0, s.stats())
-    out = {"workload": f"BASELINE configs[3] as written, {n} nodes on one GPU: {nv} cut off (partition, both directions) at t = 1 s for {cut_s} s, then heal + "
+    out = {"gave_up_on_wall_time_budget_s": budget if gave_up and recovered is None else None,
+           "workload": f"BASELINE configs[3] as written, {n} nodes on one GPU: {nv} cut off (partition, both directions) at t = 1 s for {cut_s} s, then heal + "
                        "serf reconnect (30 s) + push-pull + folds; dense pair store with a row for every node, queue_cap 32",
            "n_nodes": n, "cut_off": nv, "cut_s": cut_s, "at_heal": at_heal, "watchers": "4 majority + 4 minority observers",
            "recovered_for_the_watchers_at_s": recovered, "simulated_s": sec, "wall_s": round(dt, 2), "wall_s_of_the_cut": round(t_cut, 2),
@@ -606,6 +618,7 @@ def main():
     ap.add_argument("--config4p-nodes", type=int, default=65536, help="config4_partition leg (the partition as written + heal + recovery): nodes; a row of the "
                                                                     "dense store for every node = N^2 x 12 bytes")
     ap.add_argument("--no-config4-partition", action="store_true")
+    ap.add_argument("--config4p-budget-s", type=float, default=90.0, help="config4_partition leg: stop (the curve so far is reported) after this much wall time")
     ap.add_argument("--config4-queue-cap", type=int, default=32)
     ap.add_argument("--config4-budget-s", type=float, default=400.0, help="config4 leg: give up (detection_complete false) after this much wall time")
     ap.add_argument("--no-config5", action="store_true")
@@ -918,7 +931,10 @@ def main():
         except SwimError as e:                      # (an overflowing bounded structure raises, never passes silently: reported, not fatal for the line)
             line["config4_partition"] = {"error": str(e)[:300]}
     if rank == 0 and not sharded and not args.no_config5:
-        line["config5"] = run_config5(hip, args, local_rank)
+        try:
+            line["config5"] = run_config5(hip, args, local_rank)
+        except SwimError as e:                      # (reported, not fatal for the line)
+            line["config5"] = {"error": str(e)[:300]}
     if rank == 0 and not sharded and not args.no_convergence:
         # second half of the metric: rounds to full convergence at N ~ 1e6 (BASELINE configs[2]:
         # 1 048 576 nodes, DefaultWANConfig timers, one update rumour at node 0, fan-out sweep)

@@ -119,8 +119,14 @@ def run_mass_kill(sim, n, checkpoints, until_detected=True, limit_s=2000):
 # serf.Config.ReconnectInterval 30 s), push-pull and refutation bring everybody back while folds hand the rows of the dense store back.
 # A row for EVERY node on the HIP library (both directions live in the store), hash tables for all of them on the checker.
 PARTITION_HEAL_64K = dict(n_nodes=65536, seed=13, queue_cap=32, inbox_cap=32768, subject_cap=4, fold_interval_ms=5000, reconnect_interval_ms=30000)
-PARTITION_HEAL_64K_ORACLE = dict(view_cap=65536)
 PARTITION_HEAL_64K_HIP = dict(view_cap=8, mass_rows=65536)
+# ... the checker's fixture is taken at HALF that size: after the heal 40 % of the nodes have refuted an accusation of the minority's and every
+# observer holds an explicit view of each of them until the folds catch up — at 65 536 nodes the checker's per-observer hash tables passed
+# 56 GB of the build container's 62 GB and the run was stopped; 32 768 nodes need a quarter.  The HIP library runs both sizes (a row for
+# every node: 12.9 GB / 51.5 GB): the fixture pins 32 768, size-independent properties the 65 536 run.
+PARTITION_HEAL_32K = dict(PARTITION_HEAL_64K, n_nodes=32768, inbox_cap=16384)
+PARTITION_HEAL_32K_ORACLE = dict(view_cap=32768)
+PARTITION_HEAL_32K_HIP = dict(view_cap=8, mass_rows=32768)
 HEAL_STAT_KEYS = MASS_STAT_KEYS + ("reconnects", "reconnects_reached", "msgs_filtered")
 
 

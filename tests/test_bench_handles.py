@@ -58,3 +58,19 @@ def test_sharded_config4_leg_reports_a_failure_instead_of_raising(oracle, monkey
     the leg up together; the bench line carries the error, the headline number is not lost."""
     c = _leg(oracle, 1, monkeypatch)
     assert c["ranks_failed"] == 1 and "create" in c["error"] and "wall_s" not in c
+
+
+def test_partition_leg_control_flow_and_wall_time_budget_on_the_checker(oracle):
+    """bench.run_config4_partition (config #4 as written + recovery) on the checker at 1 024 nodes (tables of 8: views are dropped —
+    what is checked is the leg's bookkeeping), once to the end and once with a wall-time budget of nothing: the leg gives up after the
+    first 10 s of the cut and says so instead of holding the bench line up."""
+    import types
+    import bench
+    args = types.SimpleNamespace(seed=5, config4p_nodes=1024, config4p_budget_s=600.0)
+    c = bench.run_config4_partition(oracle, args, 0)
+    assert c["n_nodes"] == 1024 and c["cut_off"] == 51 and c["at_heal"]["pairs_out_of_reach"] == 2 * 51 * (1024 - 51)
+    assert c["gave_up_on_wall_time_budget_s"] is None and c["curve"] and c["curve"][0]["t_s"] == 90 and c["refutes"] > 0
+    assert c["simulated_s"] == c["curve"][-1]["t_s"] and (c["recovered_for_the_watchers_at_s"] in (None, c["simulated_s"]))
+    args.config4p_budget_s = 0.0
+    g = bench.run_config4_partition(oracle, args, 0)
+    assert "gave_up" in g and "curve" not in g

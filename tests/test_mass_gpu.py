@@ -138,6 +138,25 @@ def test_partition_both_directions_in_rows(hip, oracle):
     assert da[0] == 2 * nv * (n - nv) and nv * (n - nv) <= da[1][2] + da[1][3] < da[0] and a.stats()["view_drops"] == 0
 
 
+def test_partition_heal_and_reconnect_with_both_directions_in_rows(hip, oracle):
+    """config #4 as written AND its recovery phase, small (tests/scenarios.py run_partition_heal_mass; the 65 536-node fixture of
+    test_scale_gpu.py is this scenario): 5 % cut off, both sides start declaring each other dead — a row for every node, so both
+    directions live in the dense store — the cut heals after 60 s, serf's reconnect(), push-pull and refutations bring everybody back,
+    folds hand the rows back.  Digest, counters, detection census and what a few observers of either side hold not-alive, beside
+    the checker every 10 s."""
+    import scenarios as sc
+    n = 2048
+    kw = dict(sc.PARTITION_HEAL_64K, n_nodes=n, inbox_cap=2 * n)
+    a, b = pair(hip, oracle, dict(mass_rows=n, view_cap=8), dict(view_cap=n), **kw)
+    cps = tuple(range(10, 201, 10))
+    ra, rb = sc.run_partition_heal_mass(a, n, checkpoints=cps), sc.run_partition_heal_mass(b, n, checkpoints=cps)
+    for sec in cps:
+        assert ra[sec] == rb[sec], (sec, ra[sec], rb[sec])
+    st = a.stats()
+    assert st["view_drops"] == 0 and st["inbox_overflow"] == 0 and st["reconnects_reached"] > 0 and st["refutes"] > n // 20 and st["fold_freed"] > 0
+    assert ra[60][2][0] == 2 * (n // 20) * (n - n // 20) and ra[200][2][0] == 0            # pairs out of reach: both directions, then none
+
+
 @pytest.mark.parametrize("n_shards", [2, 4])
 def test_mass_failure_sharded_in_process(hip, oracle, n_shards):
     """The dense store is per shard (its columns are the shard's observers): 2 and 4 shards on one device against the unsharded

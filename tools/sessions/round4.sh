@@ -195,3 +195,29 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04n; mkdir -p $O
 ( time timeout 400 python -m pytest tests/test_framed_exchange_gpu.py -q ) > $O/pytest_framed.log 2>&1; tail -30 $O/pytest_framed.log
+
+# ---- r4_gpu14.sh
+# round 4, GPU call 14 (the last of the round's minutes: 7.4): what has never run on the device — the MergeState / Suspicion_Timer KATs on the
+# HIP library, the partition-heal-reconnect scenario beside the live checker (2 048), against the checker's fixture (32 768) and as
+# size-independent properties (65 536), and the bench line's config4_partition leg (65 536) under its wall-time budget
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04p; mkdir -p $O
+( time timeout 150 python -m pytest tests/test_state_table.py tests/test_mass_gpu.py::test_partition_heal_and_reconnect_with_both_directions_in_rows \
+    tests/test_scale_gpu.py::test_partition_and_recovery_32768_matches_golden -m gpu -q --durations=6 ) > $O/pytest_new.log 2>&1; tail -25 $O/pytest_new.log
+( time timeout 150 python -m pytest tests/test_scale_gpu.py::test_partition_and_recovery_65536_properties -m gpu -q --durations=3 ) > $O/pytest_65k.log 2>&1; tail -25 $O/pytest_65k.log
+( time timeout 100 python - <<'PY'
+import json, types, bench
+from consul_amd import lib
+hip = lib.load()
+args = types.SimpleNamespace(seed=1, config4p_nodes=65536, config4p_budget_s=70.0)
+print(json.dumps(bench.run_config4_partition(hip, args, 0)))
+PY
+) > $O/config4_partition.json 2> $O/config4_partition.err; tail -c 3000 $O/config4_partition.json; tail -5 $O/config4_partition.err
+
+# ---- r4_gpu15.sh
+# round 4, GPU call 15 (3.1 minutes left): the 65 536-node partition / recovery properties as rewritten after call 14 (a minute after the heal, not three)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04q; mkdir -p $O
+( time timeout 120 python -m pytest tests/test_scale_gpu.py::test_partition_and_recovery_65536_properties -m gpu -q --durations=3 ) > $O/pytest_65k.log 2>&1; tail -25 $O/pytest_65k.log
