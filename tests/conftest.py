@@ -20,7 +20,7 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest` on a box without a GPU skips the gpu-marked tests instead of failing them with SWIM_ENODEV."""
-    if os.path.exists("/dev/kfd"):
+    if os.path.exists("/dev/kfd") or os.environ.get("SWIMSIM_EMU_SO"):
         return
     skip = pytest.mark.skip(reason="no AMD GPU here (/dev/kfd missing): run on the MI355X box")
     for item in items:
@@ -42,5 +42,7 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     """The product library; loading it needs no GPU, creating a sim does."""
+    if os.environ.get("SWIMSIM_EMU_SO"):      # tools/emu: the kernel source compiled for the host against a wave64 lock-step emulator, so that
+        return abi.bind(C.CDLL(os.environ["SWIMSIM_EMU_SO"]))   # the gpu-marked tests can be run (slowly) where there is no GPU; never the product path
     from consul_amd import lib
     return lib.load()
