@@ -3827,6 +3827,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_apply_mass(const SwDev* __res
   for (uint32_t tl = threadIdx.x; tl < D.nbl; tl += SW_BLOCK) D.m_tile_dl[(size_t)rr * D.nbl + tl] = NONE;
   for (int off = 32; off; off >>= 1) freed += __shfl_down(freed, off);
   if (sw_lane() == 0 && freed) atomicAdd(stat_ptr(D, ST_FOLD_FREED), (unsigned long long)freed);
+  // Every wave has read mrow_subj[rr] (above) before thread 0 clears it: without this barrier a wave that starts after wave 0 has finished
+  // finds NONE, leaves, and its quarter of the row stays set in a row that is back on the free stack (found by running the waves of a
+  // workgroup one after the other: tools/emu; the device starts them together, which is the only reason it never showed).  Both returns
+  // above are workgroup-uniform.
+  __syncthreads();
   if (threadIdx.x == 0) {
     D.m_row_dl[rr] = NONE; D.mrow[g] = NONE; D.mrow_subj[rr] = NONE;
     atomicAnd(&D.nw[g], ~NW_MASS);

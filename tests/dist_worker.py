@@ -1,4 +1,5 @@
-"""One rank of the world_size-2 CPU test: a shard of the oracle, exchanged over gloo."""
+"""One rank of the world_size-2 CPU test: a shard of the oracle — or, with SWIMSIM_DIST_LIB naming it, of the HIP kernels' source emulated on the
+host (tools/emu) — exchanged over gloo; the unsharded reference run is always the oracle's."""
 import ctypes as C
 import os
 import sys
@@ -17,9 +18,10 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     ora = abi.bind(C.CDLL(os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))
+    shard_lib = abi.bind(C.CDLL(os.environ["SWIMSIM_DIST_LIB"])) if os.environ.get("SWIMSIM_DIST_LIB") else ora
     kw = dict(n_nodes=2048, n_replicas=2, seed=5, subject_cap=128, view_cap=128, queue_cap=16, inbox_cap=128,
               loss_q32=int(0.05 * 2**32), flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
-    sh = ShardedSim(Sim(ora, preset(ora, abi.PRESET_LAN, shard_rank=rank, n_shards=world, **kw)),
+    sh = ShardedSim(Sim(shard_lib, preset(shard_lib, abi.PRESET_LAN, shard_rank=rank, n_shards=world, **kw)),
                     TorchExchange(dist.group.WORLD, None))
     sh.step_ms(3000)
     sh.kill(0, [100, 1500]); sh.kill(1, [7]); sh.update(1, [1024])

@@ -150,6 +150,19 @@ def test_serf_events_intents_and_membership(emu, oracle):
     assert st["user_events_delivered"] > 0 and st["user_events_deduped"] > 0
 
 
+def test_two_processes_over_gloo_with_the_emulated_kernels(emu):
+    """The N > 1 path with the kernels' own code on both ranks: two processes, one shard each of a 2 x 2 048-node population, the framed
+    exchange (swim_frame_pack -> ONE equal-split all_to_all_single over gloo -> swim_frame_deliver, what consul_amd/dist.py does over RCCL on
+    the GPUs) — digest and counters summed over the ranks against the UNSHARDED run of the checker (tests/dist_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, SWIMSIM_DIST_LIB=os.environ.get("SWIMSIM_EMU_SO") or EMU_SO)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(ROOT, "tests", "dist_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and "ok=True" in line[0], (line, out.stderr[-1000:])
+
+
 def test_collectives_only_in_wave_uniform_control_flow(emu):
     """A property of the kernels the emulator can see and the device cannot report: in everything the tests above ran, no wave ever had
     lanes parked at two different collectives, and no shuffle read a lane that was not there."""

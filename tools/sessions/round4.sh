@@ -221,3 +221,10 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04q; mkdir -p $O
 ( time timeout 120 python -m pytest tests/test_scale_gpu.py::test_partition_and_recovery_65536_properties -m gpu -q --durations=3 ) > $O/pytest_65k.log 2>&1; tail -25 $O/pytest_65k.log
+
+# ---- r4_gpu16.sh
+# round 4, GPU call 16: the fold / row-recycling tests on the device after the barrier in k_fold_apply_mass (a race found by tools/emu)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04r; mkdir -p $O
+( time timeout 75 python -m pytest tests/test_mass_gpu.py -m gpu -q -x --durations=5 -k "leave_update_revive_join_in_rows or partition_heal_with_rows_and_folds or checkpoint_with_rows or churn" ) > $O/pytest_fold.log 2>&1; tail -15 $O/pytest_fold.log
