@@ -761,6 +761,14 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_coord_commit, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
 }
+// k_resolve's dynamic LDS: the lanes' memberlist queues ([Q][256] entries) and the meta words of their user-event queues — without the
+// former under -DSW_MASS_HBMQ when the handle has the dense pair store (swim_kernels.hip, k_resolve)
+static size_t resolve_lds_bytes(const SwDev& D) {
+#ifdef SW_MASS_HBMQ
+  if (D.M) return (size_t)D.EQ * SW_BLOCK * 4;
+#endif
+  return (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4;
+}
 static void launch_end(swim_sim* s, uint32_t tick) {
   const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
   SwDev& D = s->D; hipStream_t st = s->stream;
@@ -789,7 +797,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   void (*const resolve_kernel)(const SwDev*) =
       D.dyn ? (D.M ? (serf_k ? k_resolve<true, true, true> : k_resolve<true, false, true>) : (serf_k ? k_resolve<false, true, true> : k_resolve<false, false, true>))
             : (D.M ? (serf_k ? k_resolve<true, true, false> : k_resolve<true, false, false>) : (serf_k ? k_resolve<false, true, false> : k_resolve<false, false, false>));
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4, st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), resolve_lds_bytes(D), st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));

@@ -761,6 +761,8 @@ __device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr
 // (k_resolve: entry j of lane l at q[j*NL + l])
 struct LdsQ { uint4* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK].w; } };
 struct HbmQ { uint4* p; size_t NL; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[(size_t)j * NL]; } };
+// -DSW_MASS_HBMQ (A/B option, off): the meta words of a lane's memberlist queue where they live, slot-major in HBM (a wave reads 1 KB per slot)
+struct HbmMetaQ { uint4* p; size_t NL; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[(size_t)j * NL].w; } };
 // k_resolve: only the meta words (type | transmits | seq) of the lane's queue, staged in LDS
 struct MetaQ { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK]; } };
 
@@ -2360,7 +2362,6 @@ struct NodeCtxT {
   // tick.  Runs before the tick's arrivals are merged; what is picked goes to the block's carry area and
   // reaches `receiver` with the next tick's packets (NONE = the carrier was lost: transmits still count).
   __device__ __forceinline__ void piggyback(uint32_t receiver, uint32_t kind, uint32_t* s_carry, uint4* area, uint32_t* lds_emeta) {
-    static_assert(LQ, "the piggy-back pick works on the staged queue");
     const int limit = (int)D.budget - (int)sel4(D.ctl_len, kind & 3u);
     uint32_t live_m = qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1, live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1;
     int used = 0, used2 = 0;
@@ -2369,13 +2370,15 @@ struct NodeCtxT {
     MetaQ me{lds_emeta + threadIdx.x};
     if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
     const uint32_t rl = DYN ? retransmit_limit_n(D, est_n(D, r, l)) : D.retransmit_limit;
-    uint32_t tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl), te = 0;
+    uint32_t tm, te = 0;
+    if constexpr (LQ) tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);
+    else tm = get_broadcasts(D, HbmMetaQ{D.q + l, NL}, qlen, live_m, 2, limit, used, rl);     // (SW_MASS_HBMQ: transmit counts bumped in place)
     int avail = limit - used;
     if constexpr (SERF) if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
     if (!(tm | te)) return;
     const uint32_t cnt = (uint32_t)(__popc(tm) + __popc(te));
     c_pig++;
-    for (uint32_t m = tm; m; m &= m - 1) { uint32_t ty = m_type(SQ(__ffs(m) - 1).w); if (ty < 2) c_sent01 += 1u << (16 * ty); else c_sent23 += 1u << (16 * (ty - 2)); }
+    for (uint32_t m = tm; m; m &= m - 1) { uint32_t ty = m_type(mq_w(__ffs(m) - 1)); if (ty < 2) c_sent01 += 1u << (16 * ty); else c_sent23 += 1u << (16 * (ty - 2)); }
     c_sent23 += (uint32_t)__popc(te) << 16;
     if (receiver != NONE) {
       const uint32_t gdst = r * D.N + receiver;
@@ -2383,7 +2386,7 @@ struct NodeCtxT {
       uint32_t pos = att ? 0 : atomicAdd(s_carry, cnt);
       if (!att && pos + cnt > D.carry_cap) { atomicOr(D.err, SW_ERR_CARRY_OVF); pos = NONE; }
       for (uint32_t m = tm; m && pos != NONE; m &= m - 1) {
-        uint4 e = SQ(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
+        uint4 e = mq_get(__ffs(m) - 1); uint32_t meta = (m_type(e.w) << 30) | (e.z & 0x3FFFFFFFu);
         if (att) capture(D, o, gdst, e.x, e.y, meta); else area[pos++] = make_uint4(gdst, e.x, e.y, meta);
       }
       if constexpr (SERF) for (uint32_t m = te; m && pos != NONE; m &= m - 1) {
@@ -2395,7 +2398,8 @@ struct NodeCtxT {
     // write-back)
     uint32_t nq = 0, ne = 0;
     for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) {
-      if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j;
+      if constexpr (LQ) { if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j; }
+      else if (nq != j) QENT(nq, l) = QENT(j, l);
       nq++;
     }
     if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) if ((live_e >> j) & 1u) {
@@ -2713,6 +2717,21 @@ template <bool MASS, bool SERF, bool DYN>
 __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
+  // -DSW_MASS_HBMQ (A/B option for round 5, off by default; bit-identical on the emulator, unmeasured): a handle with the dense pair store
+  // (config #4: queue_cap 32 = 128 KB of staged queues, ONE workgroup per CU) edits the memberlist queue where it lives instead —
+  // slot-major in HBM, a wave reads or writes 1 KB per slot — and keeps 37 KB of LDS: four workgroups per CU
+#if defined(SW_MASS_HBMQ) && defined(SW_RESOLVE_SPEC)
+#error "SW_MASS_HBMQ and SW_RESOLVE_SPEC both move the queue staging: one at a time"
+#endif
+#if defined(SW_MASS_HBMQ) && defined(SW_NODE_LINE)
+#error "SW_MASS_HBMQ walks D.q directly: not with the one-line node record"
+#endif
+#ifdef SW_MASS_HBMQ
+  constexpr bool RESOLVE_LQ = !MASS;
+#else
+  constexpr bool RESOLVE_LQ = true;
+#endif
+  const size_t lds_q_slots = RESOLVE_LQ ? (size_t)D.Q : 0;     // queue slots staged in front of the event queues' meta words
   __shared__ uint32_t lds_stats[ST_COUNT];
   __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
   __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
@@ -2838,7 +2857,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
-    NodeCtxT<true, MASS, SERF, DYN> n(D, S);
+    NodeCtxT<RESOLVE_LQ, MASS, SERF, DYN> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
     RCLK_MARK(1);                                  // line + header + vmeta
@@ -2847,7 +2866,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SW_RESOLVE_SPEC
     n.stage_queue(1u + spec_q1);
 #else
-    n.stage_queue();
+    if constexpr (RESOLVE_LQ) n.stage_queue();
 #endif
     const bool sorted = cnt >= SW_INBOX_SORT_MIN;
     const bool presorted = cnt >= SW_INBOX_SORT_MIN && cnt <= D.bigsort_cap;   // k_inbox_sort_med / k_inbox_sort have been here (bigsort_cap = 0: neither runs)
@@ -2887,7 +2906,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
       if (!have) break;
       uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
       if (best.y == SWIM_SUBJECT_PIGGY)
-        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + (size_t)D.Q * SW_BLOCK));
+        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + lds_q_slots * SW_BLOCK));
       else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
         uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
         uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);

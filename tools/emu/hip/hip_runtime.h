@@ -138,16 +138,24 @@ static inline std::common_type_t<A, B> min(A a, B b) { using T = std::common_typ
 template <class A, class B, class = std::enable_if_t<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value>>
 static inline std::common_type_t<A, B> max(A a, B b) { using T = std::common_type_t<A, B>; return (T)a > (T)b ? (T)a : (T)b; }
 
-// ---------------------------------------------------------------- atomics (one host thread: plain read-modify-write)
-template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
-template <class T, class U> static inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
-template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
-template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
-template <class T, class U> static inline T atomicXor(T* p, U v) { T o = *p; *p = (T)(o ^ (T)v); return o; }
-template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
-template <class T, class U, class V> static inline T atomicCAS(T* p, U c, V v) { T o = *p; if (o == (T)c) *p = (T)v; return o; }
+// ---------------------------------------------------------------- atomics (one host thread: plain read-modify-write; the race build marks them)
+#ifdef EMU_RACE
+namespace emu { void atomic_begin(); void atomic_end(); }
+#define EMU_AB emu::atomic_begin();
+#define EMU_AE emu::atomic_end();
+#else
+#define EMU_AB
+#define EMU_AE
+#endif
+template <class T, class U> static inline T atomicAdd(T* p, U v) { EMU_AB T o = *p; *p = (T)(o + (T)v); EMU_AE return o; }
+template <class T, class U> static inline T atomicSub(T* p, U v) { EMU_AB T o = *p; *p = (T)(o - (T)v); EMU_AE return o; }
+template <class T, class U> static inline T atomicOr(T* p, U v) { EMU_AB T o = *p; *p = (T)(o | (T)v); EMU_AE return o; }
+template <class T, class U> static inline T atomicAnd(T* p, U v) { EMU_AB T o = *p; *p = (T)(o & (T)v); EMU_AE return o; }
+template <class T, class U> static inline T atomicXor(T* p, U v) { EMU_AB T o = *p; *p = (T)(o ^ (T)v); EMU_AE return o; }
+template <class T, class U> static inline T atomicMin(T* p, U v) { EMU_AB T o = *p; if ((T)v < o) *p = (T)v; else *p = o; EMU_AE return o; }
+template <class T, class U> static inline T atomicMax(T* p, U v) { EMU_AB T o = *p; if ((T)v > o) *p = (T)v; else *p = o; EMU_AE return o; }
+template <class T, class U> static inline T atomicExch(T* p, U v) { EMU_AB T o = *p; *p = (T)v; EMU_AE return o; }
+template <class T, class U, class V> static inline T atomicCAS(T* p, U c, V v) { EMU_AB T o = *p; if (o == (T)c) *p = (T)v; else *p = o; EMU_AE return o; }
 
 // ---------------------------------------------------------------- runtime
 typedef int hipError_t;

@@ -2,7 +2,7 @@
 """Randomised lock-step parity: random configurations and stimulus schedules, product library (optionally sharded over
 several in-process shards) against the unsharded oracle; state digest and counters compared every few ticks.
 
-usage: tools/fuzz_parity.py [--cases N] [--seed S] [--backend hip|oracle]   (oracle = sharded oracle vs unsharded oracle: a CPU
+usage: tools/fuzz_parity.py [--cases N] [--seed S] [--backend hip|emu|oracle]   (oracle = sharded oracle vs unsharded oracle: a CPU
 self-check of the harness and of the oracle's own sharding)
 """
 import argparse, ctypes as C, os, sys, time
@@ -236,6 +236,8 @@ def main():
     if args.backend == "hip":
         from consul_amd import lib as L
         lib = L.load()
+    elif args.backend == "emu":                     # the kernels' source on the host (tools/emu/build.sh): the same cases where there is no GPU
+        lib = abi.bind(C.CDLL(os.environ.get("SWIMSIM_EMU_SO") or os.path.join(ROOT, "tools", "emu", "_build", "libswimsim_emu.so")))
     else:
         lib = ora
     t0 = time.time(); tally = {}; diagnosed = 0

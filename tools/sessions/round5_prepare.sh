@@ -8,11 +8,17 @@
 #   SW_RESOLVE_LINE1 + SW_RESOLVE_WAVES=5
 #                      16 instead of 64 bytes of the inbox line parked in LDS (37 -> 25 KB per workgroup) and five waves per SIMD
 #                      (96 VGPR / 128 B scratch): five workgroups per CU where LDS and registers both allowed four.
+#   SW_MASS_HBMQ       handles with the dense pair store (config #4) edit the memberlist queue in HBM (slot-major: a wave touches 1 KB per slot)
+#                      instead of staging queue_cap x 256 x 16 B in LDS: 21 KB of LDS per workgroup instead of 149 KB at queue_cap 32, FOUR
+#                      workgroups of k_resolve<MASS> per CU instead of ONE (128 VGPR, no scratch: the compiler's report).  Bit-identical to the
+#                      checker on the emulator (tools/emu: the dense-store tests, serf intents in rows).  The config-4 leg is the measure.
+# All four options have run the parity tests on the emulated kernels (tools/emu/README.md): the first GPU call measures, it does not debug.
 cd "$(dirname "$0")/../.."
 mkdir -p _ab
 bash tools/build_variant.sh _ab/lib_0ref.so &
 bash tools/build_variant.sh _ab/lib_spec.so -DSW_RESOLVE_SPEC &
 bash tools/build_variant.sh _ab/lib_line1_w5.so -DSW_RESOLVE_LINE1 -DSW_RESOLVE_WAVES=5 &
 bash tools/build_variant.sh _ab/lib_spec_line1_w5.so -DSW_RESOLVE_SPEC -DSW_RESOLVE_LINE1 -DSW_RESOLVE_WAVES=5 &
+bash tools/build_variant.sh _ab/lib_hbmq.so -DSW_MASS_HBMQ &
 wait
 ls -la _ab/
