@@ -228,3 +228,11 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04r; mkdir -p $O
 ( time timeout 75 python -m pytest tests/test_mass_gpu.py -m gpu -q -x --durations=5 -k "leave_update_revive_join_in_rows or partition_heal_with_rows_and_folds or checkpoint_with_rows or churn" ) > $O/pytest_fold.log 2>&1; tail -15 $O/pytest_fold.log
+
+# ---- r4_gpu17.sh
+# round 4, GPU call 17 (the last seconds): smoke() and three parity cases on the FINAL binary (the barrier in k_fold_apply_mass, piggyback() generalised for the SW_MASS_HBMQ option — off)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04s; mkdir -p $O
+( time timeout 40 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+( time timeout 30 python -m pytest tests/test_parity_gpu.py tests/test_mass_gpu.py -m gpu -q -x -k "lockstep_small or leave_and_revive or churn_recycles" ) > $O/pytest.log 2>&1; tail -4 $O/pytest.log
