@@ -13,6 +13,9 @@
 #                      workgroups of k_resolve<MASS> per CU instead of ONE (128 VGPR, no scratch: the compiler's report).  Bit-identical to the
 #                      checker on the emulator (tools/emu: the dense-store tests, serf intents in rows).  The config-4 leg is the measure.
 # All four options have run the parity tests on the emulated kernels (tools/emu/README.md): the first GPU call measures, it does not debug.
+# After ANY kernel change of round 5, before it costs a GPU minute:  tools/emu/build.sh && python -m pytest tests/test_emulated_kernels.py
+# (1.5 min; the change against the checker on the host), then  SWIMSIM_EMU_SO=tools/emu/_build/libswimsim_emu.so python -m pytest tests -m gpu -k <what it touches>
+# and, for anything that adds a barrier-free hand-over between waves or workgroups,  tools/emu/sweep.sh race.
 cd "$(dirname "$0")/../.."
 mkdir -p _ab
 bash tools/build_variant.sh _ab/lib_0ref.so &
