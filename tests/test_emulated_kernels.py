@@ -4,7 +4,7 @@ arrived, workgroups one after the other).  What this buys the CPU suite, which o
 the device code path itself — `k_begin` / `k_deliver` / `k_resolve` and friends, the LDS staging, the ballot / prefix-sum compaction,
 the dense pair store, the fold and reap passes — is executed and held against the checker, tick by tick, on every run of
 `pytest -m "not gpu"`; a logic slip in a kernel shows up here, before any GPU minute is spent.  What it is not: the product (the library
-reports backend "hip-kernels-emulated-on-host" and consul_amd/lib.py refuses it), a model of the memory system, or a substitute for the
+reports backend "hip-emulated" and consul_amd/lib.py refuses it), a model of the memory system, or a substitute for the
 `-m gpu` tests (those run the same source as gfx950 code through the same C-ABI).
 
 The whole `-m gpu` suite can be driven through it too: `SWIMSIM_EMU_SO=tools/emu/_build/libswimsim_emu.so python -m pytest tests -m gpu`
@@ -62,7 +62,7 @@ def assert_same(a, b, tag=""):
 
 def test_the_emulated_build_is_not_the_product(emu, monkeypatch):
     from consul_amd import lib
-    assert emu.swim_backend() == b"hip-kernels-emulated-on-host"
+    assert emu.swim_backend() == b"hip-emulated"
     monkeypatch.setattr(lib, "LIB_PATH", os.environ.get("SWIMSIM_EMU_SO") or EMU_SO)
     monkeypatch.setattr(lib, "_cdll", None)
     with pytest.raises(ImportError):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/emu/build.sh [asan|race] — compile the UNMODIFIED kernel + host source of consul_amd/csrc for the build container's host cores against
 # the wave64 lock-step emulator (tools/emu/hip/hip_runtime.h): tools/emu/_build/libswimsim_emu.so (or _asan.so under -fsanitize=address,undefined).
-# TEST INFRASTRUCTURE: the library reports backend "hip-kernels-emulated-on-host", which consul_amd/lib.py refuses.
+# TEST INFRASTRUCTURE: the library reports backend "hip-emulated", which consul_amd/lib.py refuses.
 # The only textual changes, made on a scratch copy: `extern __shared__ T name[];` (dynamic LDS) becomes a pointer to the emulator's LDS
 # buffer, the amdgpu_waves_per_eu attribute (which the host target does not know) is dropped, and the backend string.
 set -e
@@ -10,7 +10,7 @@ B=$HERE/_build; S=$B/x.$$/csrc; mkdir -p "$S"; ln -sfn "$ROOT/include" "$B/inclu
 for f in swim_host.hip swim_kernels.hip swim_device.h; do
   sed -E -e 's/extern __shared__ ([A-Za-z0-9_]+) ([A-Za-z0-9_]+)\[\];/static \1* const \2 = (\1*)emu::dyn_lds;/' \
          -e 's/__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)//' \
-         -e 's/"hip-gfx950"/"hip-kernels-emulated-on-host"/' "${EMU_SRC:-$ROOT/consul_amd/csrc}/$f" > "$S/$f"
+         -e 's/"hip-gfx950"/"hip-emulated"/' "${EMU_SRC:-$ROOT/consul_amd/csrc}/$f" > "$S/$f"
 done
 printf '#include "swim_host.hip"\n#include "%s/emu_engine.inc"\n' "$HERE" > "$S/tu.cpp"
 OUT=${EMU_OUT:-$B/libswimsim_emu.so}; SAN=""
