@@ -169,3 +169,17 @@ def test_collectives_only_in_wave_uniform_control_flow(emu):
     c = counters(emu)
     assert c["launches"] > 1000 and c["workgroups"] > c["launches"]
     assert c["waves_parked_at_several_sites"] == 0 and c["shuffles_from_a_lane_not_there"] == 0, c
+
+
+def test_the_references_outcome_tests_on_the_emulated_kernels(emu, tmp_path):
+    """tests/host/test_serf_facade.cpp — the reference's own eventual-outcome tests re-staged against the C++ mirror of *serf.Serf
+    (TestServer_LANReap agent/consul/server_test.go:666-733, TestAgent_ForceLeave[Prune] agent/agent_endpoint_test.go:2524-2677,
+    TestServer_JoinLAN server_test.go:509, ...) — and the wire codec + Transport bridge end to end, linked against the emulated kernels
+    (the gpu-marked twins link the product library)."""
+    import test_host_facade as hf
+    libdir = os.path.dirname(os.environ.get("SWIMSIM_EMU_SO") or EMU_SO)
+    libname = os.path.basename(os.environ.get("SWIMSIM_EMU_SO") or EMU_SO)[3:-3]
+    out = hf.build_and_run(tmp_path, libdir, libname)
+    assert out.returncode == 0 and "ALL PASSED" in out.stdout and "backend hip-emulated" in out.stdout, out.stdout + out.stderr
+    out = hf.build_and_run(tmp_path, libdir, libname, hf.WIRE)
+    assert out.returncode == 0 and "ALL PASSED" in out.stdout and "backend hip-emulated" in out.stdout, out.stdout + out.stderr
