@@ -183,3 +183,17 @@ def test_the_references_outcome_tests_on_the_emulated_kernels(emu, tmp_path):
     assert out.returncode == 0 and "ALL PASSED" in out.stdout and "backend hip-emulated" in out.stdout, out.stdout + out.stderr
     out = hf.build_and_run(tmp_path, libdir, libname, hf.WIRE)
     assert out.returncode == 0 and "ALL PASSED" in out.stdout and "backend hip-emulated" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_legs_on_the_emulated_kernels(emu):
+    """bench.py's config-#4 and config-#5 legs, at toy sizes, on the emulated kernels — the legs' own code paths
+    (the dense pair store with a row per victim / per node, swim_detection_get, watch_events + poll_events, folds) end to end with the
+    kernels' code, where tests/test_bench_handles.py can only run them on the checker (which has no dense store)."""
+    import types
+    import bench
+    args = types.SimpleNamespace(seed=2, config4_nodes=1024, config4_queue_cap=16, config4_budget_s=300.0,
+                                 config5_nodes=512, config5_seconds=3, config5_events=5)
+    c4 = bench.run_config4(emu, args, 0)
+    assert c4["detection_complete"] and c4["view_drops"] == 0 and c4["pairs"] == (1024 - 51) * 51 and c4["rounds_to_full_detection"] > 0
+    c5 = bench.run_config5(emu, args, 0)
+    assert "error" not in c5 and c5.get("view_drops", 0) == 0
