@@ -21,6 +21,6 @@ if [ "$1" = race ]; then    # the kernels' loads and stores instrumented (-fsani
 fi
 if [ "$1" = asan ]; then OUT=${EMU_OUT:-$B/libswimsim_emu_asan.so}; SAN="-fsanitize=address,undefined -fno-sanitize=pointer-overflow,function -fno-sanitize-recover=undefined -fno-omit-frame-pointer"; fi
 ${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++} -std=c++17 -O1 -g -ffp-contract=off -fno-strict-aliasing -fwrapv -fPIC -shared $SAN $EMU_CXXFLAGS -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes \
-    -I "$HERE" -x c++ "$S/tu.cpp" -x none $EXTRA -o "$OUT"
+    -I "$HERE" -x c++ "$S/tu.cpp" ${EXTRA:+-x none $EXTRA} -o "$OUT"
 echo "$OUT"
 rm -rf "$B/x.$$" "$B/emu_race.$$.o"
