@@ -7,8 +7,8 @@
 //   * two waves of one workgroup touching the same granule between the same two barriers, at least one writing, not both atomic;
 //   * two workgroups of one launch touching the same global granule, at least one writing, not both atomic
 //     (nothing orders the workgroups of a launch; LDS is private to a workgroup and exempt).
-// Lanes of one wave are not checked against each other (they run in lock step on the device; the kernels separate such exchanges
-// with wave collectives, which the emulator already enforces).  One legal schedule is observed, but a conflict is reported whichever of
+// Lanes of one wave are checked against each other only with EMU_RACE_LANES=1 (same wave, same barrier epoch, no wave collective passed by
+// either since: an exchange that relies on the wave's lock step alone — legal on the device, but nothing the compiler promises).  One legal schedule is observed, but a conflict is reported whichever of
 // the two accesses came first in it — unlike a digest mismatch it does not need the unlucky schedule to happen.
 #include <cstdint>
 #include <cstdio>
@@ -28,11 +28,12 @@ extern uint64_t race_launch, race_block;                          // set by the 
 extern uint32_t race_epoch;
 extern int in_atomic;
 uintptr_t cur_stack();
+uint32_t cur_cep();
 extern const size_t stack_bytes;
 }  // namespace emu
 
 namespace {
-struct Acc { uint64_t launch; uint64_t block; const void* pc; uint32_t epoch; uint16_t wave; uint8_t atomic, valid; };
+struct Acc { uint64_t launch; uint64_t block; const void* pc; uint32_t epoch, cep; uint16_t wave; uint8_t lane, atomic, valid; };
 struct Cell { uintptr_t key; Acc w, r; };
 constexpr size_t kCells = size_t(1) << 23;                        // 8 M granules of the current launch (stale launches are overwritten)
 Cell* g_tab = nullptr;
@@ -41,6 +42,7 @@ uint64_t g_overflow = 0, g_checked = 0;
 struct Rep { uint64_t n; uintptr_t addr; uint64_t b1, b2; uint32_t w1, w2; const char* kind; };
 std::map<std::pair<const void*, const void*>, Rep>* g_reports = nullptr;
 uintptr_t g_base = 0;
+bool g_lanes_too = false;
 
 int phdr_cb(struct dl_phdr_info* info, size_t, void* self) {
   Dl_info di;
@@ -61,6 +63,7 @@ void init() {
   g_tab = (Cell*)calloc(kCells, sizeof(Cell));
   g_reports = new std::map<std::pair<const void*, const void*>, Rep>;
   dl_iterate_phdr(phdr_cb, (void*)&init);
+  g_lanes_too = getenv("EMU_RACE_LANES") != nullptr;
 }
 void report(const Acc& old, const void* pc, uintptr_t addr, uint64_t block, uint32_t wave, const char* kind) {
   auto key = std::make_pair(old.pc, pc);
@@ -68,10 +71,13 @@ void report(const Acc& old, const void* pc, uintptr_t addr, uint64_t block, uint
   if (it == g_reports->end()) (*g_reports)[key] = Rep{1, addr, old.block, block, old.wave, wave, kind};
   else it->second.n++;
 }
-inline bool conflicts(const Acc& a, uint64_t launch, uint64_t block, uint32_t wave, uint32_t epoch, bool lds) {
-  if (!a.valid || a.launch != launch) return false;
-  if (a.block != block) return !lds;                               // another workgroup of the same launch
-  return a.wave != wave && a.epoch == epoch;                       // another wave, no barrier in between
+// 0 = none, 1 = two workgroups, 2 = two waves, 3 = two lanes of a wave (EMU_RACE_LANES=1 only)
+inline int conflicts(const Acc& a, uint64_t launch, uint64_t block, uint32_t wave, uint32_t lane, uint32_t epoch, uint32_t cep, bool lds) {
+  if (!a.valid || a.launch != launch) return 0;
+  if (a.block != block) return lds ? 0 : 1;                        // another workgroup of the same launch
+  if (a.epoch != epoch) return 0;                                  // a workgroup barrier in between
+  if (a.wave != wave) return 2;                                    // another wave, no barrier in between
+  return g_lanes_too && a.lane != lane && a.cep == cep ? 3 : 0;    // another lane of the wave, no collective in between: relies on lock step
 }
 void access(uintptr_t addr, size_t size, bool write, const void* pc) {
   emu::LaneView* l = emu::cur_view ? emu::cur_view() : nullptr;
@@ -79,7 +85,7 @@ void access(uintptr_t addr, size_t size, bool write, const void* pc) {
   { const uintptr_t st = emu::cur_stack(); if (addr - st < emu::stack_bytes) return; }   // the lane's own fiber stack (locals): private by construction
   init();
   const uint64_t launch = emu::race_launch, block = emu::race_block;
-  const uint32_t wave = (l->tid.x + 0u) / 64u + 16u * l->tid.y, epoch = emu::race_epoch;   // (every kernel of this library is 1-D: tid.x / 64)
+  const uint32_t wave = (l->tid.x + 0u) / 64u + 16u * l->tid.y, lane = l->tid.x & 63u, epoch = emu::race_epoch, cep = emu::cur_cep();   // (every kernel of this library is 1-D: tid.x / 64)
   const bool atomic = emu::in_atomic != 0;
   for (uintptr_t g = addr >> 2; g <= (addr + size - 1) >> 2; g++) {
     const bool lds = (g << 2) >= g_img_lo && (g << 2) < g_img_hi;
@@ -93,11 +99,12 @@ void access(uintptr_t addr, size_t size, bool write, const void* pc) {
     }
     if (!c) { g_overflow++; continue; }
     g_checked++;
-    if (c->w.valid && conflicts(c->w, launch, block, wave, epoch, lds) && !(atomic && c->w.atomic))
-      report(c->w, pc, g << 2, block, wave, write ? (c->w.block != block ? "write/write, two workgroups" : "write/write, two waves") : (c->w.block != block ? "write/read, two workgroups" : "write/read, two waves"));
-    if (write && c->r.valid && conflicts(c->r, launch, block, wave, epoch, lds) && !(atomic && c->r.atomic))
-      report(c->r, pc, g << 2, block, wave, c->r.block != block ? "read/write, two workgroups" : "read/write, two waves");
-    Acc a{launch, block, pc, epoch, (uint16_t)wave, (uint8_t)atomic, 1};
+    static const char* const kind_w[2][4] = {{"", "write/read, two workgroups", "write/read, two waves", "write/read, two lanes of a wave"},
+                                             {"", "write/write, two workgroups", "write/write, two waves", "write/write, two lanes of a wave"}};
+    if (!(atomic && c->w.atomic)) if (int k = conflicts(c->w, launch, block, wave, lane, epoch, cep, lds)) report(c->w, pc, g << 2, block, wave, kind_w[write][k]);
+    if (write && !(atomic && c->r.atomic)) if (int k = conflicts(c->r, launch, block, wave, lane, epoch, cep, lds))
+      report(c->r, pc, g << 2, block, wave, k == 1 ? "read/write, two workgroups" : k == 2 ? "read/write, two waves" : "read/write, two lanes of a wave");
+    Acc a{launch, block, pc, epoch, cep, (uint16_t)wave, (uint8_t)lane, (uint8_t)atomic, 1};
     if (write) c->w = a; else c->r = a;
   }
 }

@@ -62,6 +62,7 @@ struct Lane {
   uint64_t val; int arg;    // deposited operand
   uint64_t res;             // result handed back
   unsigned char* stack;
+  uint32_t cep;             // wave collectives this lane has been released from (the race detector's lane-level epoch)
 };
 extern Lane* cur;
 extern dim3 g_blockIdx, g_blockDim, g_gridDim;
