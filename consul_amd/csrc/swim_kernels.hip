@@ -2841,10 +2841,20 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SW_RESOLVE_LINE1
     s_in[0][threadIdx.x] = row4[0];
 #else
+#ifdef SW_RESOLVE_LINECOND
+    // (A/B, round 5) only the 16-byte words of the line the receiver's messages occupy: nine receivers in ten hold one message
+    s_in[0][threadIdx.x] = row4[0];
+    if (cnt > 1) s_in[1][threadIdx.x] = row4[1];
+    if (cnt > 2) s_in[2][threadIdx.x] = row4[2];
+    if (cnt > 3) s_in[3][threadIdx.x] = row4[3];
+#else
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
 #endif
+#endif
     const uint4 hdr0 = HDR(l);
+#ifndef SW_RESOLVE_LAZYVM
     const uint4 vm0 = VMETA(l);
+#endif
 #ifdef SW_RESOLVE_SPEC
     lds_q[threadIdx.x] = sp_q0; lds_q[spec_q1 * SW_BLOCK + threadIdx.x] = sp_q1;       // (Q = 1: both are entry 0)
 #endif
@@ -2859,7 +2869,11 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
     NodeCtxT<RESOLVE_LQ, MASS, SERF, DYN> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
+#ifdef SW_RESOLVE_LAZYVM
+    n.load(hdr0);                                  // (A/B, round 5) the view metadata only when a handler asks for it: an order never does
+#else
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
+#endif
     RCLK_MARK(1);                                  // line + header + vmeta
     // second round trip: the queue (into LDS) and, in the same breath, the view of the subject the first message of the line
     // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)

@@ -561,6 +561,10 @@ static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhea
   return cnt;
 }
 
+/* where a packet's picks are collected: queue_get takes at most *qlen entries, so both queues whole always fit (a stack array of
+ * 2 * QMAX entries was only safe while the event queue was as shallow as the product library's: ADVICE r4) */
+static qent* pick_buf(void) { static _Thread_local qent buf[QMAX + EVQ_MAX]; return buf; }
+
 /* encodeAndBroadcast (broadcast.go) */
 static void broadcast(swim_sim* s, node_t* nd, uint32_t subject, uint8_t type, uint32_t inc, uint32_t from) {
   queue_push(s, nd->q, &nd->qlen, &nd->qseq, s->cfg.queue_cap, 1, subject, type, inc, from, &s->st.queue_drops);
@@ -1266,7 +1270,7 @@ static void phase_gossip(swim_sim* s) {
       s->st.node_rounds_active++;
       uint32_t peers[8], np = k_random_nodes(s, r, o, STREAM_GOSSIP, s->cfg.gossip_nodes, excl_gossip, NULL, peers);
       for (uint32_t p = 0; p < np; p++) {
-        qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
+        qent* const msgs = pick_buf(); int32_t used = 0, used2 = 0;     /* room for both queues whole, however deep serf's is */
         const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
         uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, (int32_t)s->d.packet_budget, msgs, &used, rl);
         int32_t avail = (int32_t)s->d.packet_budget - used;
@@ -1415,7 +1419,7 @@ static void fold_apply(swim_sim* s) {
 /* sendMsg: extra := getBroadcasts(compoundOverhead, UDPBufferSize - len(msg) - compoundHeaderOverhead) — the
  * memberlist queue, then the serf delegate's user events; what is picked travels with the next tick */
 static void piggyback(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t receiver, uint32_t kind) {
-  qent msgs[2 * QMAX]; int32_t used = 0, used2 = 0;
+  qent* const msgs = pick_buf(); int32_t used = 0, used2 = 0;
   int32_t limit = (int32_t)s->d.packet_budget - (int32_t)s->cfg.ctl_len[kind & 3];
   const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
   uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, limit, msgs, &used, rl);
