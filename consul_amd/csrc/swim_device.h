@@ -225,6 +225,7 @@ struct SwDev {
   uint2* c_list; uint32_t* c_cnt; uint32_t c_cap; swim_coordinate* c_new;
   uint32_t rtt_scale_us, rtt_height_us, rtt_jitter_us;
   uint32_t* cen_acc;     // [R*S][CEN_WORDS] accumulators
+  uint32_t* cf_ticket;   // k_census_finish: arrivals of the tick's participating blocks (back to 0 when the last one leaves)
   uint32_t* cen_dl;      // [R*S][8] this tick's census deltas (state 0..3, current) tallied by k_resolve, applied by k_finish
   swim_census* census;   // [R*S] cached
   uint32_t* trace;       // [R*S][trace_ticks][5]

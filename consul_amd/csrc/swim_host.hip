@@ -27,7 +27,7 @@
   } while (0)
 
 enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
-static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" };
+static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" }   /* (k_finish: k_census_finish since round 5 — the recount and the epilogue in one launch; k_census then has no launches of its own) */;
 #define SW_GRAPH_TICKS 16
 
 #ifdef SW_NODE_LINE
@@ -539,6 +539,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     D.rtt_scale_us = cfg->rtt_scale_us; D.rtt_height_us = cfg->rtt_height_us; D.rtt_jitter_us = cfg->rtt_jitter_us;
   }
   DALLOC(s, D.cen_acc, NS * CEN_WORDS); DALLOC(s, D.census, NS);
+  DALLOC(s, D.cf_ticket, 1); HIPCK(s, hipMemsetAsync(D.cf_ticket, 0, 4, s->stream));
   DALLOC(s, D.cen_dl, NS * 8); HIPCK(s, hipMemsetAsync(D.cen_dl, 0, NS * 8 * 4, s->stream));
   if (D.trace_ticks) DALLOC(s, D.trace, NS * D.trace_ticks * 5);
 
@@ -801,8 +802,12 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
+#ifdef SW_SPLIT_FINISH     /* (A/B: the two launches of rounds 1-4) */
   { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
+#else
+  { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_census_finish, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
+#endif
   if (fold) hipLaunchKernelGGL(k_exc_rebuild_folded, dim3(D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   s->in_count = 0;
 }

@@ -2841,20 +2841,10 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #ifdef SW_RESOLVE_LINE1
     s_in[0][threadIdx.x] = row4[0];
 #else
-#ifdef SW_RESOLVE_LINECOND
-    // (A/B, round 5) only the 16-byte words of the line the receiver's messages occupy: nine receivers in ten hold one message
-    s_in[0][threadIdx.x] = row4[0];
-    if (cnt > 1) s_in[1][threadIdx.x] = row4[1];
-    if (cnt > 2) s_in[2][threadIdx.x] = row4[2];
-    if (cnt > 3) s_in[3][threadIdx.x] = row4[3];
-#else
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
 #endif
-#endif
     const uint4 hdr0 = HDR(l);
-#ifndef SW_RESOLVE_LAZYVM
     const uint4 vm0 = VMETA(l);
-#endif
 #ifdef SW_RESOLVE_SPEC
     lds_q[threadIdx.x] = sp_q0; lds_q[spec_q1 * SW_BLOCK + threadIdx.x] = sp_q1;       // (Q = 1: both are entry 0)
 #endif
@@ -2869,11 +2859,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
     NodeCtxT<RESOLVE_LQ, MASS, SERF, DYN> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
-#ifdef SW_RESOLVE_LAZYVM
-    n.load(hdr0);                                  // (A/B, round 5) the view metadata only when a handler asks for it: an order never does
-#else
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
-#endif
     RCLK_MARK(1);                                  // line + header + vmeta
     // second round trip: the queue (into LDS) and, in the same breath, the view of the subject the first message of the line
     // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)
@@ -2994,11 +2980,9 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 // =================================================================================================
 // k_census / k_finish — observation: how the live observers of a replica see each dirty subject
 // =================================================================================================
-__global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ Dp) {
-  SW_DEV_BIND
-  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
-  if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) return;
-  __shared__ uint32_t acc[CEN_WORDS];
+// one block's share of the recount of dirty slot sidx (the caller has checked that it is one)
+__device__ __forceinline__ void census_recount(DevRef D, uint32_t sidx, uint32_t* acc) {
+  const uint32_t r = sidx / D.S;
   if (threadIdx.x < CEN_WORDS) acc[threadIdx.x] = 0;
   __syncthreads();
   uint32_t x = D.subj_node[sidx], maxinc = D.slot_maxinc[sidx];
@@ -3024,6 +3008,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ D
   }
   __syncthreads();
   if (threadIdx.x < 6) { if (acc[threadIdx.x]) atomicAdd(&D.cen_acc[(size_t)sidx * CEN_WORDS + threadIdx.x], acc[threadIdx.x]); }
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_census(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
+  if (sl >= D.n_slots[r] || !D.slot_dirty[sidx]) return;
+  __shared__ uint32_t acc[CEN_WORDS];
+  census_recount(D, sidx, acc);
 }
 
 // first-suspect / first-dead / all-dead / all-current stamps of a slot whose cached census just changed
@@ -3082,8 +3073,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_exc_rebuild_folded(const SwDev* __
   rebuild_exceptions(D, blockIdx.x, &s_n);
 }
 
-__global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ Dp, uint32_t* last_cnt) {
-  SW_DEV_BIND
+__device__ __forceinline__ void finish_tick(DevRef D, uint32_t* last_cnt) {
   uint32_t t = *D.tick, now = now_ms(D, t);
   for (uint32_t sidx = threadIdx.x; sidx < D.R * D.S; sidx += SW_BLOCK) {
     uint32_t r = sidx / D.S, sl = sidx % D.S;
@@ -3132,6 +3122,44 @@ __global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ D
     if (D.xs_cnt) *D.xs_cnt = 0;               // ... and its state exchanges sent
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_finish(const SwDev* __restrict__ Dp, uint32_t* last_cnt) {
+  SW_DEV_BIND
+  finish_tick(D, last_cnt);
+}
+// k_census and k_finish in ONE launch (round 5: a quiet tick is five launches of ~5 us each, and nothing in the last two depends on a grid).
+// Same grid as k_census.  The blocks of dirty slots recount; whoever of them arrives last at the ticket — or block (0, 0) alone when no
+// slot is dirty, every tick but a handful — runs the tick's epilogue.  Every participant derives the number of arrivals from the same
+// words (slot_dirty is only cleared by the epilogue itself), so no block waits for another: the last one in simply stays.
+__global__ void __launch_bounds__(SW_BLOCK) k_census_finish(const SwDev* __restrict__ Dp, uint32_t* last_cnt) {
+  SW_DEV_BIND
+  const uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
+  const bool dirty = sl < D.n_slots[r] && D.slot_dirty[sidx] != 0;
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  if (!dirty && !first) return;
+  __shared__ uint32_t acc[CEN_WORDS];
+  __shared__ uint32_t s_last;
+  __shared__ uint32_t s_dirty;
+  if (threadIdx.x == 0) s_dirty = 0;
+  __syncthreads();
+  {
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < D.R * D.S; i += SW_BLOCK) c += (i % D.S < D.n_slots[i / D.S] && D.slot_dirty[i]) ? 1u : 0u;
+    if (c) atomicAdd(&s_dirty, c);
+  }
+  __syncthreads();
+  const bool first_dirty = 0 < D.n_slots[0] && D.slot_dirty[0] != 0;                 // (block (0, 0) is one of a dirty slot's blocks then)
+  const uint32_t arrivals = s_dirty * gridDim.x + (first_dirty ? 0u : 1u);
+  if (dirty) census_recount(D, sidx, acc);                                           // (ends behind a barrier: the block's atomics are issued)
+  if (threadIdx.x == 0) {
+    __threadfence();                                                                 // the recount's sums before the ticket
+    s_last = atomicAdd(D.cf_ticket, 1u) + 1u == arrivals ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();                                                                   // ... and every other block's, after it
+  if (threadIdx.x == 0) *D.cf_ticket = 0;
+  finish_tick(D, last_cnt);
 }
 __global__ void k_census_commit(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND

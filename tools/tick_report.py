@@ -9,6 +9,7 @@ for r in rows:
     m = re.search(r'\b(k_[a-z_]+)', r['Kernel_Name'])
     if not m: continue
     n = m.group(1)
+    if n == 'k_census_finish': n = 'k_finish'      # round 5: census and epilogue in one launch
     if 'init' in n or 'inject' in n or 'commit' in n or n == 'k_deliver_list': continue
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if n == 'k_pending' or (n == 'k_begin' and (cur is None or 'k_deliver' in cur)): cur = {'start': int(r['Start_Timestamp'])}

@@ -8,6 +8,7 @@ for r in rows:
     m = re.search(r'\b(k_[a-z_]+)', r['Kernel_Name'])
     if not m: continue
     n = m.group(1)
+    if n == 'k_census_finish': n = 'k_finish'      # round 5: census and epilogue in one launch
     if n not in ('k_begin', 'k_deliver', 'k_resolve', 'k_census', 'k_finish', 'k_pending'): continue
     cur[n] = cur.get(n, 0) + (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if n == 'k_finish':
