@@ -513,12 +513,14 @@ def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, ba
             "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
 
 
-RCCL_KIND = "rccl: one equal-split all_to_all_single of frames per tick, the counts in the frames' headers (no host round trip)"
+RCCL_KIND = "rccl: one equal-split all_to_all_single of frames per tick, the counts in the frames' headers; frames sized from the load (one 64-byte-per-peer host look per tick, a tick that does not fit exchanged twice)"
 
 
 def frame_note(ex) -> dict:
     """What the framed exchange puts on the wire whatever the fill (consul_amd/dist.py TorchExchange)."""
-    return {"frame_records": ex._F, "frame_bytes_per_tick_per_rank": ex.frame_bytes_per_tick}
+    return {"frames": "fixed" if ex.frame_records else "sized from the load (swim_frame_pack_fill: twice the largest segment of the last 8 ticks, >= 64 records; "
+                                                       "a tick that does not fit is packed and exchanged again before it is delivered)",
+            "frame_records": ex._F, "frame_bytes_per_tick_per_rank": ex.frame_bytes_per_tick, "ticks": ex.ticks, "ticks_exchanged_twice": ex.retries}
 
 
 def run_config5(hip, args, device) -> dict:
@@ -634,12 +636,12 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="drive the split tick + torch.distributed all-to-all even at world_size 1 (plumbing check)")
     ap.add_argument("--frame-records", type=int, default=0,
-                    help="--exchange rccl: records per frame of the equal-split all-to-all (header included).  0 = the library's bound "
-                         "(1 + the largest outbound capacity: can never overflow); a smaller frame moves fewer bytes per tick and raises "
-                         "the sticky edge-list overflow if a tick's segment does not fit")
+                    help="--exchange rccl: records per frame of the equal-split all-to-all (header included).  0 = frames sized from the load "
+                         "(twice the largest segment of the last 8 ticks; a tick that does not fit is exchanged again with frames that hold it: lossless, "
+                         "one 64-byte-per-peer host look per tick); a number = fixed frames, no host look, the sticky edge-list overflow if a segment does not fit")
     ap.add_argument("--exchange", choices=("auto", "library", "rccl"), default="auto",
                     help="N > 1: `library` = the library's own device-driven exchange (peer-mapped mailboxes over xGMI, no host round trip, "
-                         "no collective); `rccl` = split tick + one equal-split RCCL all_to_all_single of frames per tick, issued from Python on the simulator's stream, no host round trip; `auto` = library, and rccl if the "
+                         "no collective); `rccl` = split tick + one equal-split RCCL all_to_all_single of frames per tick, issued from Python on the simulator's stream, frames sized from the load (one small host look per tick); `auto` = library, and rccl if the "
                          "mailboxes cannot be set up or a peer's flag does not arrive")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the control group (gloo: several ranks on ONE device, tests)")
     args = ap.parse_args()

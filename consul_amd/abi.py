@@ -144,6 +144,7 @@ PROTOTYPES = {
     "swim_inbound": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_frame_records": (u32, [SimP]),
     "swim_frame_pack": (C.c_int, [SimP, C.c_void_p, u32]),
+    "swim_frame_pack_fill": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_frame_deliver": (C.c_int, [SimP, C.c_void_p, u32]),
     "swim_tick_end": (C.c_int, [SimP]),
     "swim_tick_end_begin": (C.c_int, [SimP]),

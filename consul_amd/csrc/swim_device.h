@@ -308,7 +308,7 @@ struct BeginPlan {
   uint32_t roles;            // bit0 expire, bit1 pending, bit2 probe, bit3 gossip, bit4 push-pull, bit5 carry, bit6 push-pull replies
 };
 #define SW_DST_VOID 0xFFFFFFFEu   /* a carried record that already left for another shard; a bucket record the receiver's filter dropped */
-#define SW_TB_TILE 1024u          /* lanes per tile bucket = SW_RTILE node blocks = what one k_resolve workgroup owns */
+#define SW_TB_TILE 1024u          /* lanes per tile bucket (four node blocks: what one k_resolve workgroup owned in rounds 2-4) */
 #define SW_TB_BINS 132u           /* tiles the lanes of one replica can span (tile buckets need nloc <= 131 072) */
 #define TB_CLASS_MASK 0x30000000u /* class of a bucket record, bits 29-28 of the meta word: 0 = deliver as it is (orders, user events, a rumour about the receiver) */
 #define TB_GOSSIP 0x10000000u     /* ... judged at the receiver: a no-op counts as filtered, anything else as an edge */

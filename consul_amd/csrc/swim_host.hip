@@ -586,7 +586,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   {   // tile buckets (swim_device.h): for handles without a dense pair store whose replicas span few tiles (a gossip block keeps a
       // histogram over them in LDS and pays one global atomic per tile it sends to: 64 tiles at 65 536 nodes per cluster — at a million
       // nodes per cluster nearly every record would pay its own).  SWIMSIM_TILEBUCKETS=0: the sender-side filter and k_deliver's scatter.
-    D.tb_T = (uint32_t)cdiv(NB, SW_RTILE);
+    D.tb_T = (uint32_t)cdiv(NL, SW_TB_TILE);     // (1 024 lanes per bucket, whatever k_resolve's own tile is)
     const uint64_t per_tile = (uint64_t)SW_TB_TILE * D.k_gossip * per_pkt / std::max(1u, D.G);      // expected records of a tile when every queue is full
     const uint64_t cap = 2 * per_tile + 3 * SW_TB_TILE;                                            // ... twice that, plus the orders (<= 2 per node)
     const char* e = getenv("SWIMSIM_TILEBUCKETS");
@@ -766,9 +766,9 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
 // former under -DSW_MASS_HBMQ when the handle has the dense pair store (swim_kernels.hip, k_resolve)
 static size_t resolve_lds_bytes(const SwDev& D) {
 #ifdef SW_MASS_HBMQ
-  if (D.M) return (size_t)D.EQ * SW_BLOCK * 4;
+  if (D.M) return (size_t)D.EQ * SW_RES_THREADS * 4;
 #endif
-  return (size_t)D.Q * SW_BLOCK * sizeof(uint4) + (size_t)D.EQ * SW_BLOCK * 4;
+  return (size_t)D.Q * SW_RES_THREADS * sizeof(uint4) + (size_t)D.EQ * SW_RES_THREADS * 4;
 }
 static void launch_end(swim_sim* s, uint32_t tick) {
   const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
@@ -798,7 +798,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   void (*const resolve_kernel)(const SwDev*) =
       D.dyn ? (D.M ? (serf_k ? k_resolve<true, true, true> : k_resolve<true, false, true>) : (serf_k ? k_resolve<false, true, true> : k_resolve<false, false, true>))
             : (D.M ? (serf_k ? k_resolve<true, true, false> : k_resolve<true, false, false>) : (serf_k ? k_resolve<false, true, false> : k_resolve<false, false, false>));
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_BLOCK), resolve_lds_bytes(D), st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_RES_THREADS), resolve_lds_bytes(D), st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
@@ -919,13 +919,15 @@ static int frame_args(swim_sim* s, const void* p, uint32_t F) {
   if (!s->in_tick) return SWIM_ESTATE;
   return SWIM_OK;
 }
-extern "C" int swim_frame_pack(swim_sim* s, swim_edge* send, uint32_t F) {
+static int frame_pack(swim_sim* s, swim_edge* send, uint32_t F, uint32_t fill) {
   int rc = frame_args(s, send, F);
   if (rc) return rc;
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(std::min(F - 1, swim_frame_records(s) - 1), SW_BLOCK * 8), 64));
-  hipLaunchKernelGGL(k_frame_pack, dim3(xb, s->D.n_shards), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (uint4*)send, F);
+  hipLaunchKernelGGL(k_frame_pack, dim3(xb, s->D.n_shards), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, (uint4*)send, F, fill);
   return SWIM_OK;
 }
+extern "C" int swim_frame_pack(swim_sim* s, swim_edge* send, uint32_t F) { return frame_pack(s, send, F, 0u); }
+extern "C" int swim_frame_pack_fill(swim_sim* s, swim_edge* send, uint32_t F) { return frame_pack(s, send, F, 1u); }
 extern "C" int swim_frame_deliver(swim_sim* s, const swim_edge* recv, uint32_t F) {
   int rc = frame_args(s, recv, F);
   if (rc) return rc;

@@ -759,12 +759,13 @@ __device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr
 
 // where a node's queue lives: staged in LDS (gossip role: entry j of this lane at sq[j*256]) or in HBM
 // (k_resolve: entry j of lane l at q[j*NL + l])
-struct LdsQ { uint4* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK].w; } };
+template <uint32_t STRIDE> struct LdsQT { uint4* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * STRIDE].w; } };
+typedef LdsQT<SW_BLOCK> LdsQ;                  // (the gossip role: 256 lanes, entry j of a lane at sq[j * 256])
 struct HbmQ { uint4* p; size_t NL; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[(size_t)j * NL]; } };
 // -DSW_MASS_HBMQ (A/B option, off): the meta words of a lane's memberlist queue where they live, slot-major in HBM (a wave reads 1 KB per slot)
 struct HbmMetaQ { uint4* p; size_t NL; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[(size_t)j * NL].w; } };
 // k_resolve: only the meta words (type | transmits | seq) of the lane's queue, staged in LDS
-struct MetaQ { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * SW_BLOCK]; } };
+template <uint32_t STRIDE> struct MetaQT { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * STRIDE]; } };
 
 // one GetBroadcasts(overhead, limit) over a queue.  `live` = entries still queued;
 // returns the bitmask sent; bumps transmits / retires at the retransmit limit.
@@ -1943,17 +1944,21 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver_mail(const SwDev* __restri
 }
 // ---- swim_frame_*: the exchange as ONE equal-split collective, sizes known to the host, counts known to the device only (swimsim.h) ----
 // frame for shard blockIdx.y at send + blockIdx.y * F: header {count, activity, tick + 1, magic}, then the segment's records
-__global__ void __launch_bounds__(SW_BLOCK) k_frame_pack(const SwDev* __restrict__ Dp, uint4* send, uint32_t F) {
+// (fill: swim_frame_pack_fill — a segment that does not fit the frame is not an error: the header carries the segment's true count and, above
+//  the activity bit, the largest count this shard holds for any destination; the caller repeats the tick's exchange with larger frames)
+__global__ void __launch_bounds__(SW_BLOCK) k_frame_pack(const SwDev* __restrict__ Dp, uint4* send, uint32_t F, uint32_t fill) {
   SW_DEV_BIND
   const uint32_t dst = blockIdx.y;
   uint4* const fr = send + (size_t)dst * F;
   uint32_t n = dst == D.rank ? 0u : D.out_cnt[dst];
+  if (n > D.out_cap_tab[dst]) n = D.out_cap_tab[dst];          // (the list itself overflowed: the roles raised SW_ERR_EDGE_OVF when they appended)
   const uint32_t room = D.out_cap_tab[dst] < F - 1 ? D.out_cap_tab[dst] : F - 1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    uint32_t any = *D.act;
-    for (uint32_t sh = 0; sh < D.n_shards; sh++) any |= D.out_cnt[sh];
-    if (n > room) atomicOr(D.err, SW_ERR_EDGE_OVF);
-    fr[0] = make_uint4(n < room ? n : room, any != 0, *D.tick + 1, SWIM_FRAME_MAGIC);
+    uint32_t any = *D.act, need = 0;
+    for (uint32_t sh = 0; sh < D.n_shards; sh++) { const uint32_t c = D.out_cnt[sh] < D.out_cap_tab[sh] ? D.out_cnt[sh] : D.out_cap_tab[sh]; any |= c; if (sh != D.rank && c > need) need = c; }
+    if (n > room && !fill) atomicOr(D.err, SW_ERR_EDGE_OVF);
+    fr[0] = fill ? make_uint4(n, (any != 0 ? 1u : 0u) | (need << 1), *D.tick + 1, SWIM_FRAME_MAGIC)
+                 : make_uint4(n < room ? n : room, any != 0, *D.tick + 1, SWIM_FRAME_MAGIC);
   }
   if (n > room) n = room;
   const uint4* src = D.out_tab[dst];
@@ -1971,13 +1976,14 @@ __global__ void __launch_bounds__(SW_BLOCK) k_frame_deliver(const SwDev* __restr
       if (sh == D.rank) continue;
       const uint4 h = recv[(size_t)sh * F];
       if (h.w != SWIM_FRAME_MAGIC || h.z != *D.tick + 1) { atomicOr(D.err, SW_ERR_XCHG_TIMEOUT); any = 1; }
-      else any |= h.y;
+      else any |= h.y & 1u;                      // (above bit 0: what the sender's largest segment needs — swim_frame_pack_fill)
     }
     *D.peer_act = any != 0;
   }
   if (src == D.rank) return;
   const uint4 h = recv[(size_t)src * F];
   if (h.w != SWIM_FRAME_MAGIC || h.z != *D.tick + 1) return;
+  if (h.x > F - 1 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(D.err, SW_ERR_EDGE_OVF);       // a truncated frame must be re-sent, not delivered: loud
   deliver_span<true>(D, recv + (size_t)src * F + 1, h.x < F - 1 ? h.x : F - 1, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 // records handed over by other shards (swim_inbound)
@@ -2031,6 +2037,19 @@ __device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_
   uint32_t n = D.exc_cnt[r]; if (n > SW_EXC_MAX) return;               // unusable anyway
   for (uint32_t j = 0; j < n; j++) if (ent[j].x == x) atomicOr(&ent[j].y, now & ~old);
 }
+// k_resolve's geometry (round 5): a workgroup of SW_RES_THREADS threads owns a tile of SW_RTILE node blocks.  Rounds 2-4 ran 256 threads on
+// four node blocks; the phase clock of round 5 (profiles/r05_resolve_phase_clock_driver_window.txt) showed 59 % of a wave's life going to the
+// WORKGROUP's bookkeeping — barriers around the receiver list, three waves waiting at the flush for the fourth — so a workgroup is now ONE
+// wave on ONE node block: its barriers cost nothing, nobody waits for a sibling, and a wave that is done frees its slot at once.
+// (-DSW_RES_THREADS=256 -DSW_RTILE=4 builds the old geometry.)
+#ifndef SW_RES_THREADS
+#define SW_RES_THREADS 64
+#endif
+#ifndef SW_RTILE
+#define SW_RTILE 1
+#endif
+#define SW_RES_WAVES (SW_RES_THREADS / 64)
+#define SW_RES_SUBS (SW_RTILE * SW_BLOCK / SW_RES_THREADS)        /* passes of the workgroup over its tile's count words */
 extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at file scope so that NodeCtxT's accesses stay LDS-typed, not generic)
 // k_resolve keeps the censuses of watched subjects up to date INCREMENTALLY: a view that changes state (or reaches the slot's
 // highest incarnation) adds its delta here — per workgroup in LDS, flushed with one global atomic per touched counter — and k_finish
@@ -2061,8 +2080,8 @@ struct NodeCtxT {
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = VMETA(l); vm_have = true; } }
   __device__ __forceinline__ bool dyn() const { if constexpr (DYN) return D.dyn != 0; else return false; }
   uint4 h0;
-  uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * 256 + threadIdx.x]; entries to write back
-#define SQ(j) g_lds_dyn[(j) * SW_BLOCK + threadIdx.x]
+  uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * SW_RES_THREADS + threadIdx.x]; entries to write back
+#define SQ(j) g_lds_dyn[(j) * SW_RES_THREADS + threadIdx.x]   /* (LQ contexts live in k_resolve only) */
   __device__ __forceinline__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
 
   __device__ __forceinline__ void load() { load(HDR(l)); }
@@ -2152,17 +2171,6 @@ struct NodeCtxT {
     return lookup(x);
   }
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
-#ifdef SW_RESOLVE_SPEC
-  // (-DSW_RESOLVE_SPEC, an A/B build for round 5) the same for a subject whose node word and home-slot entry the caller fetched ahead of
-  // time — in the same round trip as the receiver's inbox line, on the guess that the line is about the replica's hot subject
-  __device__ __forceinline__ View lookup_with(uint32_t x, uint32_t w, uint4 first) {
-    View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
-    v.w = w;
-    v.slot = vt_probe(D, l, x, first, v.e, v.free_slot);
-    if (v.slot == NONE) v.e = make_uint4(x, x == o ? SW_KEY(self_inc, SWIM_STATE_ALIVE) : base_key_of(D, r, x, v.w), 0, 0);
-    return v;
-  }
-#endif
   __device__ __forceinline__ View lookup(uint32_t x) {
     View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
     uint32_t row = NONE;
@@ -2367,11 +2375,11 @@ struct NodeCtxT {
     int used = 0, used2 = 0;
     HbmQ qe{D.evq + l, NL};
     // the user-event queue stays in HBM; the pick walks it several times, so its meta words are fetched once into LDS
-    MetaQ me{lds_emeta + threadIdx.x};
+    MetaQT<SW_RES_THREADS> me{lds_emeta + threadIdx.x};
     if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
     const uint32_t rl = DYN ? retransmit_limit_n(D, est_n(D, r, l)) : D.retransmit_limit;
     uint32_t tm, te = 0;
-    if constexpr (LQ) tm = get_broadcasts(D, LdsQ{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);
+    if constexpr (LQ) tm = get_broadcasts(D, LdsQT<SW_RES_THREADS>{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);
     else tm = get_broadcasts(D, HbmMetaQ{D.q + l, NL}, qlen, live_m, 2, limit, used, rl);     // (SW_MASS_HBMQ: transmit counts bumped in place)
     int avail = limit - used;
     if constexpr (SERF) if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
@@ -2706,23 +2714,17 @@ __device__ unsigned long long g_wclk[WCLK_ROWS][6];
 #else
 #define WCLK(i) do { } while (0)
 #endif
-#ifndef SW_RTILE
-#define SW_RTILE 4
-#endif
 #ifndef SW_RESOLVE_WAVES
 #define SW_RESOLVE_WAVES 4
 #endif
 #define SW_ORDER_MIN 16u          /* a tile with an inbox of this many messages has its receiver list ordered by size class */
 template <bool MASS, bool SERF, bool DYN>
-__global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
+__global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
-  uint4* const lds_q = g_lds_dyn;                // [Q][256] the lanes' memberlist queues, then [EQ][256] words: meta words of their event queues
+  uint4* const lds_q = g_lds_dyn;                // [Q][threads] the lanes' memberlist queues, then [EQ][threads] words: meta words of their event queues
   // -DSW_MASS_HBMQ (A/B option for round 5, off by default; bit-identical on the emulator, unmeasured): a handle with the dense pair store
   // (config #4: queue_cap 32 = 128 KB of staged queues, ONE workgroup per CU) edits the memberlist queue where it lives instead —
   // slot-major in HBM, a wave reads or writes 1 KB per slot — and keeps 37 KB of LDS: four workgroups per CU
-#if defined(SW_MASS_HBMQ) && defined(SW_RESOLVE_SPEC)
-#error "SW_MASS_HBMQ and SW_RESOLVE_SPEC both move the queue staging: one at a time"
-#endif
 #if defined(SW_MASS_HBMQ) && defined(SW_NODE_LINE)
 #error "SW_MASS_HBMQ walks D.q directly: not with the one-line node record"
 #endif
@@ -2733,16 +2735,11 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
 #endif
   const size_t lds_q_slots = RESOLVE_LQ ? (size_t)D.Q : 0;     // queue slots staged in front of the event queues' meta words
   __shared__ uint32_t lds_stats[ST_COUNT];
-  __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SW_RTILE * (SW_BLOCK / 64)];
+  constexpr uint32_t RT = SW_RES_THREADS, SUBS = SW_RES_SUBS, WPB = SW_RES_WAVES;
+  static_assert(SW_RTILE * SW_BLOCK <= 1024 && SW_RTILE * SW_BLOCK % SW_RES_THREADS == 0 && SW_RES_THREADS % 64 == 0, "k_resolve's tile");
+  __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SUBS * WPB > 16 ? SUBS * WPB : 16];
   __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
-#ifdef SW_RESOLVE_LINE1
-  // (-DSW_RESOLVE_LINE1, an A/B build for round 5: only the first 16 bytes of a lane's inbox line — the count word's neighbours: message 0 —
-  //  are parked in LDS, 4 KB instead of 16; the words of messages 1..4 are read from the line itself when a lane gets that far (it sits in
-  //  the L2 — the same 128-byte line — since the first load).  LDS per workgroup 37 -> 25 KB: with -DSW_RESOLVE_WAVES=5 five workgroups per CU fit)
-  __shared__ uint4 s_in[1][SW_BLOCK];
-#else
-  __shared__ uint4 s_in[4][SW_BLOCK];            // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
-#endif
+  __shared__ uint4 s_in[4][RT];                  // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
   const uint32_t nb0 = (D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + blockIdx.x] : blockIdx.x) * SW_RTILE;   // heavy tiles first
 #ifdef SWIMSIM_WAVECLK
   unsigned long long wclk[4]; WCLK(0);
@@ -2762,24 +2759,24 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   BlockStats S; S.init(lds_stats);
   const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)nb0 * SW_BLOCK;
   // ---- the tile's receivers, compacted in ascending node order
-  uint32_t cnts[SW_RTILE];
+  uint32_t cnts[SUBS];                             // (sub-pass sb covers the RT nodes from offset sb * RT of the tile)
 #pragma unroll
-  for (uint32_t sb = 0; sb < SW_RTILE; sb++) {
-    const size_t l = l0 + sb * SW_BLOCK + threadIdx.x;
-    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[nb0 + sb])) ? D.in_cnt[l] : 0u;
+  for (uint32_t sb = 0; sb < SUBS; sb++) {
+    const size_t l = l0 + sb * RT + threadIdx.x;
+    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[nb0 + (sb * RT) / SW_BLOCK])) ? D.in_cnt[l] : 0u;
     const uint64_t m = __ballot(cnts[sb] != 0);
-    if (sw_lane() == 0) s_wcnt[sb * (SW_BLOCK / 64) + threadIdx.x / 64] = (uint32_t)__popcll(m);
+    if (sw_lane() == 0) s_wcnt[sb * WPB + threadIdx.x / 64] = (uint32_t)__popcll(m);
   }
   __syncthreads();
   uint32_t n_act = 0;
 #pragma unroll
-  for (uint32_t sb = 0; sb < SW_RTILE; sb++) {
+  for (uint32_t sb = 0; sb < SUBS; sb++) {
     uint32_t base = 0;
-    for (uint32_t j = 0; j < SW_RTILE * (SW_BLOCK / 64); j++) { const uint32_t c = s_wcnt[j]; n_act += sb == 0 ? c : 0; base += j < sb * (SW_BLOCK / 64) + threadIdx.x / 64 ? c : 0; }
+    for (uint32_t j = 0; j < SUBS * WPB; j++) { const uint32_t c = s_wcnt[j]; n_act += sb == 0 ? c : 0; base += j < sb * WPB + threadIdx.x / 64 ? c : 0; }
     const uint64_t m = __ballot(cnts[sb] != 0);
     if (cnts[sb]) {
       const uint32_t c = cnts[sb] > 0x3FFFFFu ? 0x3FFFFFu : cnts[sb];
-      s_list[base + (uint32_t)__popcll(m & ((1ull << sw_lane()) - 1))] = (c << 10) | (sb * SW_BLOCK + threadIdx.x);
+      s_list[base + (uint32_t)__popcll(m & ((1ull << sw_lane()) - 1))] = (c << 10) | (sb * RT + threadIdx.x);
     }
   }
   if (D.fast_blocks && threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) D.in_any[nb0 + threadIdx.x] = 0;
@@ -2791,69 +2788,41 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   {
     bool big = false;
 #pragma unroll
-    for (uint32_t sb = 0; sb < SW_RTILE; sb++) big |= cnts[sb] >= SW_ORDER_MIN;
+    for (uint32_t sb = 0; sb < SUBS; sb++) big |= cnts[sb] >= SW_ORDER_MIN;
     if (__syncthreads_or(big)) {                    // (the barrier: the list is complete)
-      uint32_t ent[SW_RTILE], pos[SW_RTILE];
+      uint32_t ent[SUBS], pos[SUBS];
 #pragma unroll
-      for (uint32_t j = 0; j < SW_RTILE; j++) { const uint32_t i = threadIdx.x + j * SW_BLOCK; ent[j] = i < n_act ? s_list[i] : 0u; }
+      for (uint32_t j = 0; j < SUBS; j++) { const uint32_t i = threadIdx.x + j * RT; ent[j] = i < n_act ? s_list[i] : 0u; }
       if (threadIdx.x < 16) s_wcnt[threadIdx.x] = 0;             // (16 size classes: 2^15 messages and more share the first)
       __syncthreads();
 #pragma unroll
-      for (uint32_t j = 0; j < SW_RTILE; j++) pos[j] = ent[j] ? atomicAdd(&s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))], 1u) : 0u;
+      for (uint32_t j = 0; j < SUBS; j++) pos[j] = ent[j] ? atomicAdd(&s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))], 1u) : 0u;
       __syncthreads();
       if (threadIdx.x == 0) { uint32_t acc = 0; for (uint32_t c = 0; c < 16; c++) { const uint32_t v = s_wcnt[c]; s_wcnt[c] = acc; acc += v; } }
       __syncthreads();
 #pragma unroll
-      for (uint32_t j = 0; j < SW_RTILE; j++) if (ent[j]) s_list[s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))] + pos[j]] = ent[j];
+      for (uint32_t j = 0; j < SUBS; j++) if (ent[j]) s_list[s_wcnt[15u - min(15u, 31u - (uint32_t)__clz(ent[j] >> 10))] + pos[j]] = ent[j];
     }
   }
   __syncthreads();
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0, c_peak = 0;
   const uint32_t t_now = *D.tick;
-#ifdef SW_RESOLVE_SPEC
-  // the replica's hot subject: the one in watch slot 0 (the victim of config #2's clusters; NONE while the replica has no slot).  A guess:
-  // a receiver whose first message is about somebody else looks that subject up as before — results cannot depend on it
-  const uint32_t r_tile = div_nloc(D, l0 < NL ? l0 : NL - 1);
-  const uint32_t spec = (!MASS && D.n_slots[r_tile]) ? D.subj_node[(size_t)r_tile * D.S] : NONE;
-  const uint32_t spec_x = spec < D.N ? spec : 0u, spec_home = vt_home(D, spec_x);
-  const uint32_t spec_q1 = D.Q > 1 ? 1u : 0u;
-#endif
   RCLK_MARK(0);                                    // compaction
   WCLK(1);
-  for (uint32_t a0 = 0; a0 < n_act; a0 += SW_BLOCK) {
+  for (uint32_t a0 = 0; a0 < n_act; a0 += RT) {
     if (a0 + threadIdx.x >= n_act) continue;
-    const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;
+    const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;      // (sb: the node block within the tile)
     uint32_t cnt = ent >> 10;
     const size_t l = l0 + (ent & 1023u);
     // the whole 64-byte line (first five messages) in one go, parked in the lane's LDS column
     // (the count lives in its own dense array: the scatter's returning atomic then works on 4 bytes per node that
     // stay cache resident instead of pulling in the node's 64-byte message line)
-#ifdef SW_RESOLVE_SPEC
-    // in the SAME round trip as the inbox line, what the second one used to fetch: the hot subject's node word, this receiver's home-slot
-    // entry for it and the first two entries of the receiver's queue — unconditional loads from clamped addresses, issued BEFORE the
-    // line's (a branch here, or their place after the line's first use, would put them behind the wait for the line)
-    const uint32_t sp_w = D.nw[(size_t)r_tile * D.N + spec_x];
-    const uint4 sp_e = D.vt[(size_t)spec_home * NL + l];
-    const uint4 sp_q0 = QENT(0u, l), sp_q1 = QENT(spec_q1, l);
-    const bool sp = spec < D.N && div_nloc(D, l) == r_tile;
-#endif
     const uint4* row4 = (const uint4*)(D.inbox1 + l * 16);
-#ifdef SW_RESOLVE_LINE1
-    s_in[0][threadIdx.x] = row4[0];
-#else
     s_in[0][threadIdx.x] = row4[0]; s_in[1][threadIdx.x] = row4[1]; s_in[2][threadIdx.x] = row4[2]; s_in[3][threadIdx.x] = row4[3];
-#endif
     const uint4 hdr0 = HDR(l);
     const uint4 vm0 = VMETA(l);
-#ifdef SW_RESOLVE_SPEC
-    lds_q[threadIdx.x] = sp_q0; lds_q[spec_q1 * SW_BLOCK + threadIdx.x] = sp_q1;       // (Q = 1: both are entry 0)
-#endif
     D.in_cnt[l] = 0;
-#ifdef SW_RESOLVE_LINE1
-#define IN_WORD(w) ((w) < 4u ? ((const uint32_t*)&s_in[0][threadIdx.x])[(w) & 3u] : ((const uint32_t*)row4)[(w)])
-#else
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
-#endif
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
     const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
@@ -2863,20 +2832,12 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
     RCLK_MARK(1);                                  // line + header + vmeta
     // second round trip: the queue (into LDS) and, in the same breath, the view of the subject the first message of the line
     // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)
-#ifdef SW_RESOLVE_SPEC
-    n.stage_queue(1u + spec_q1);
-#else
     if constexpr (RESOLVE_LQ) n.stage_queue();
-#endif
     const bool sorted = cnt >= SW_INBOX_SORT_MIN;
     const bool presorted = cnt >= SW_INBOX_SORT_MIN && cnt <= D.bigsort_cap;   // k_inbox_sort_med / k_inbox_sort have been here (bigsort_cap = 0: neither runs)
     if (!sorted) {
       const uint32_t gx = IN_WORD(1), gty = IN_WORD(3) >> 30;
-#ifdef SW_RESOLVE_SPEC
-      if (gx < D.N && gty != SWIM_MSG_USER && gx != n.o) { n.cv = (sp && gx == spec) ? n.lookup_with(gx, sp_w, sp_e) : n.lookup(gx); n.cv_x = gx; }
-#else
       if (gx < D.N && gty != SWIM_MSG_USER && gx != n.o) { n.cv = n.lookup(gx); n.cv_x = gx; }
-#endif
     }
     bool have_last = false; uint64_t lhi = 0, llo = 0;
     uint32_t next_j = 0;
@@ -2906,7 +2867,7 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
       if (!have) break;
       uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
       if (best.y == SWIM_SUBJECT_PIGGY)
-        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + lds_q_slots * SW_BLOCK));
+        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + lds_q_slots * RT));
       else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
         uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
         uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
@@ -2958,21 +2919,21 @@ __global__ void __launch_bounds__(SW_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   if (threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) {
     const uint32_t sb = threadIdx.x;
     if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
-    if (s_dl[sb] != NONE && s_dl[sb] < D.dl_blk[nb0 + sb]) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);
+    if (s_dl[sb] != NONE) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);       // (no look first: a load the workgroup would have to wait for on its way out)
   }
 #ifdef SWIMSIM_WAVECLK
   WCLK(3);
   if (sw_lane() == 0) {
-    unsigned long long* row = g_wclk[(blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64) % WCLK_ROWS];
+    unsigned long long* row = g_wclk[(blockIdx.x * WPB + threadIdx.x / 64) % WCLK_ROWS];
     row[0] = wclk[0]; row[1] = wclk[1]; row[2] = wclk[2]; row[3] = wclk[3]; row[4] = n_act; row[5] = blockIdx.x;
   }
 #endif
 #ifdef SWIMSIM_DIAG
   RCLK_MARK(5);                                    // tallies, flush
   if (sw_lane() == 0) {
-    uint32_t* row = g_rclk[(blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64) % RCLK_ROWS];
+    uint32_t* row = g_rclk[(blockIdx.x * WPB + threadIdx.x / 64) % RCLK_ROWS];
     for (int p = 0; p < 6; p++) row[p] = rclk_acc[p];
-    row[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - rclk_t0); row[7] = ((n_act + SW_BLOCK - 1) / SW_BLOCK) << 16 | (rclk_it & 0xFFFFu);
+    row[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - rclk_t0); row[7] = ((n_act + RT - 1) / RT) << 16 | (rclk_it & 0xFFFFu);
   }
 #endif
 }

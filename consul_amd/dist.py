@@ -6,7 +6,8 @@ Two exchanges implement the same contract — "after run(), every shard has been
 every other shard addressed to it":
 
   TorchExchange   one process per GPU; ONE equal-split all_to_all_single over torch.distributed per
-                  tick, of frames whose headers carry the device-side counts (no host round trip).
+                  tick, of frames whose headers carry the device-side counts; the frames follow the load (one 64-byte-per-peer
+                  host look per tick; a tick that does not fit is exchanged again before it is delivered).
                   With the "nccl" backend that is RCCL over xGMI on device buffers; with "gloo" the
                   same code moves host buffers (how the CPU tests cover the N>1 path).
   LocalExchange   several shards inside one process (e.g. all on one GPU): pointer hand-over.
@@ -23,26 +24,28 @@ from .sim import Sim
 
 
 class TorchExchange:
-    """The per-tick exchange as ONE equal-split all_to_all_single over torch.distributed, no host round trip.
+    """The per-tick exchange as ONE equal-split all_to_all_single over torch.distributed, with frames sized from the load.
 
-    An all-to-all wants its sizes on the host; the record counts of a tick live on the device.  Instead of reading them
-    back every tick (rounds 1-3 did: an all-gather of the counters, `.cpu()`, then a list-form all-to-all), every rank
-    sends every other rank a FRAME of `frame_records` 16-byte records whose first record is a header the device writes
-    {count, activity word, tick + 1, magic} (swimsim.h: swim_frame_pack / swim_frame_deliver — what the library's mailbox
-    header does for its own exchange).  Per tick: pack (one kernel) -> all_to_all_single(recv, send) -> deliver (one
-    kernel, reads the counts out of the headers, folds the activity words into next tick's hint).  On the GPU (backend
-    nccl = RCCL over xGMI) all three are issued on the simulator's own HIP stream (torch.cuda.ExternalStream made torch's
-    current stream): nothing waits for the host, nothing is read back.  With gloo the same code moves host buffers of
-    the checker, which is how the CPU tests cover the N > 1 path.
+    An all-to-all wants its sizes on the host; the record counts of a tick live on the device.  Every rank sends every other
+    rank a FRAME of F 16-byte records whose first record is a header the device writes (swimsim.h: swim_frame_pack_fill —
+    {records the segment has, activity | need << 1, tick + 1, magic}, `need` = the sender's largest segment of the tick).
+    Per tick: pack (one kernel) -> all_to_all_single(recv, send) -> read the W headers back (64 bytes per peer: the one host
+    look of the tick) -> deliver (one kernel).  F follows the load: twice the largest `need` any rank reported over the last
+    WINDOW ticks, a power of two, at least MIN_FRAME records — a quiet tick moves 1 KB per peer.  When a tick's largest segment
+    does not fit (every rank sees every sender's `need`, so all decide alike) the tick is packed and exchanged AGAIN with frames
+    that hold it, before anything is delivered: nothing is lost, nothing overflows.  (Round 4 shipped the library's bound —
+    1 + the largest outbound capacity, tens of millions of records at bench scale — whatever the fill: ADVICE r4.)
+    On the GPU (backend nccl = RCCL over xGMI) everything is issued on the simulator's own HIP stream
+    (torch.cuda.ExternalStream made torch's current stream); with gloo the same code moves host buffers of the checker,
+    which is how the CPU tests cover the N > 1 path.
 
-    frame_records: None = the library's bound (1 + the largest outbound capacity: can never overflow; the checker's
-    lists are unbounded, 65 536 there).  A smaller frame moves fewer bytes per tick; a segment that does not fit raises
-    the sticky edge-list overflow (SWIM_EOVERFLOW at the next sync).  Bytes on the wire per tick and rank:
-    (world - 1) * frame_records * 16, whatever the fill — the price of sizes the host never has to learn.
+    frame_records: None = adaptive (above).  A number = fixed frames of that size through swim_frame_pack: no host look at
+    all, and a segment that does not fit raises the sticky edge-list overflow (SWIM_EOVERFLOW at the next sync).
     """
 
     MAX_SHARDS = 16
-    ORACLE_FRAME = 1 << 16
+    MIN_FRAME = 64
+    WINDOW = 8
 
     def __init__(self, group, device_index: int | None, frame_records: int | None = None):
         import torch
@@ -56,36 +59,71 @@ class TorchExchange:
         self._bound = None          # simulator the frames were sized for
         self._send = self._recv = None
         self._F = 0
+        self._cap = 0               # records per frame the buffers can hold
+        self._recent = []           # the population's largest segment in each of the last WINDOW ticks
+        self.ticks = self.retries = 0
+        self.records_on_wire = 0    # frame records this rank put on the wire (x 16 bytes)
 
-    def _bind(self, sim: Sim):
+    def _alloc(self, F: int):
         torch = self.torch
-        F = self.frame_records or sim.frame_records() or self.ORACLE_FRAME
-        if F < 2:
-            raise ValueError("a frame holds a header and at least one record")
-        self._F = F
         # (zero-filled once: a frame's tail beyond its count is never read, but it does cross the wire)
         self._send = torch.zeros((self.world * F, 4), dtype=torch.int32, device=self.device)
         self._recv = torch.zeros((self.world * F, 4), dtype=torch.int32, device=self.device)
+        self._cap = F
+
+    def _bind(self, sim: Sim):
+        torch = self.torch
+        F = self.frame_records or self.MIN_FRAME
+        if F < 2:
+            raise ValueError("a frame holds a header and at least one record")
+        self._F = F
         if self.on_gpu:
             # everything this exchange issues goes to the simulator's stream: make it torch's current stream once
             # (entering a stream context per tick costs ~9 us of host time that sits on the tick's critical path)
             self._stream = torch.cuda.ExternalStream(sim.stream_ptr(), device=self.device)
-            torch.cuda.current_stream(self.device).synchronize()      # the two fills above
             torch.cuda.set_stream(self._stream)
+        self._alloc(max(F, 1024))
+        if self.on_gpu:
+            self._stream.synchronize()
         self._bound = sim
 
     @property
     def frame_bytes_per_tick(self) -> int:
-        """What one rank puts on the wire per tick (its own frame stays home)."""
-        return (self.world - 1) * self._F * 16
+        """What one rank put on the wire per tick on average so far (its own frame stays home)."""
+        return 16 * self.records_on_wire // max(self.ticks, 1) if self.ticks else (self.world - 1) * self._F * 16
+
+    def _exchange(self, sim: Sim, F: int, fill: bool):
+        W = self.world
+        if F > self._cap:                                        # (what is in the buffers is dead: every tick packs afresh)
+            if self.on_gpu:
+                self._stream.synchronize()
+            self._alloc(1 << (F - 1).bit_length())
+        send, recv = self._send[:W * F], self._recv[:W * F]
+        (sim.frame_pack_fill if fill else sim.frame_pack)(send.data_ptr(), F)
+        self.dist.all_to_all_single(recv, send, group=self.group)
+        self.records_on_wire += (W - 1) * F
+        return send, recv
 
     def run(self, sims: Sequence[Sim]):
         (sim,) = sims
         if self._bound is not sim:
             self._bind(sim)
-        sim.frame_pack(self._send.data_ptr(), self._F)
-        self.dist.all_to_all_single(self._recv, self._send, group=self.group)
-        sim.frame_deliver(self._recv.data_ptr(), self._F)
+        W, F = self.world, self._F
+        self.ticks += 1
+        if self.frame_records:                                   # fixed frames: no host look, overflow is loud
+            _, recv = self._exchange(sim, F, fill=False)
+            sim.frame_deliver(recv.data_ptr(), F)
+            return
+        send, recv = self._exchange(sim, F, fill=True)
+        # the one host look of the tick: `need` of every sender (the own frame's header carries this rank's)
+        need = max(int(recv.view(W, F, 4)[:, 0, 1].max().item()) >> 1 if W > 1 else 0, int(send[self.rank * F, 1].item()) >> 1)
+        if need > F - 1:                                         # (every rank computes the same maximum: all repeat together)
+            self.retries += 1
+            F = 1 << need.bit_length()                           # > need
+            send, recv = self._exchange(sim, F, fill=True)
+        sim.frame_deliver(recv.data_ptr(), F)
+        self._recent = (self._recent + [need])[-self.WINDOW:]
+        self._F = max(self.MIN_FRAME, 1 << (2 * max(self._recent)).bit_length())
 
     def close(self):
         """Give torch its default stream back (the simulator's stream is about to be destroyed)."""
@@ -98,23 +136,30 @@ class TorchExchange:
 class LocalFramedExchange:
     """The framed exchange between shards that live in ONE process (tests; one device): every shard packs its frames, the
     frames are transposed with plain copies (what the collective does between processes), every shard delivers.  `alloc(n)`
-    returns a buffer of n records and `ptr(buf)` its address — numpy on the checker, torch device tensors on the product
-    library; `copy(dst, d0, src, s0, n)` moves n records; `sync()` orders the phases (the shards run on different streams)."""
+    returns a buffer of n records and `ptr(buf)` its address — numpy on the checker, device memory on the product
+    library; `copy(dst, d0, src, s0, n)` moves n records; `sync()` orders the phases (the shards run on different streams).
+    `read(buf, i)` (optional) returns record i of a buffer as four words: with it and no fixed frame_records the frames are
+    sized from the load exactly like TorchExchange's — swim_frame_pack_fill, the headers read back, a tick whose largest
+    segment does not fit packed and moved again before anything is delivered."""
 
-    def __init__(self, alloc, ptr, copy, sync=lambda: None, frame_records: int | None = None):
-        self.alloc, self.ptr, self.copy, self.sync = alloc, ptr, copy, sync
+    ORACLE_FRAME = 1 << 16          # (the checker's lists are unbounded: swim_frame_records answers 0 there)
+
+    def __init__(self, alloc, ptr, copy, sync=lambda: None, frame_records: int | None = None, read=None):
+        self.alloc, self.ptr, self.copy, self.sync, self.read = alloc, ptr, copy, sync, read
         self.frame_records = frame_records
-        self._F = 0
+        self.adaptive = read is not None and not frame_records
+        self._F = self._cap = 0
+        self._recent = []
+        self.retries = 0
 
-    def run(self, sims: Sequence[Sim]):
+    def _move(self, sims, F, fill):
         W = len(sims)
-        if not self._F:
-            self._F = self.frame_records or sims[0].frame_records() or TorchExchange.ORACLE_FRAME
-            self._send = [self.alloc(W * self._F) for _ in sims]
-            self._recv = [self.alloc(W * self._F) for _ in sims]
-        F = self._F
+        if F > self._cap:
+            self._cap = F
+            self._send = [self.alloc(W * F) for _ in sims]
+            self._recv = [self.alloc(W * F) for _ in sims]
         for s, b in zip(sims, self._send):
-            s.frame_pack(self.ptr(b), F)
+            (s.frame_pack_fill if fill else s.frame_pack)(self.ptr(b), F)
         for s in sims:
             s.sync()
         for i in range(W):
@@ -122,6 +167,21 @@ class LocalFramedExchange:
                 if i != j:
                     self.copy(self._recv[j], i * F, self._send[i], j * F, F)
         self.sync()
+
+    def run(self, sims: Sequence[Sim]):
+        W = len(sims)
+        if not self._F:
+            self._F = TorchExchange.MIN_FRAME if self.adaptive else self.frame_records or sims[0].frame_records() or self.ORACLE_FRAME
+        F = self._F
+        self._move(sims, F, self.adaptive)
+        if self.adaptive:
+            need = max(self.read(b, i * F)[1] >> 1 for i, b in enumerate(self._send))     # every shard's own header carries its need
+            if need > F - 1:
+                self.retries += 1
+                F = 1 << need.bit_length()
+                self._move(sims, F, True)
+            self._recent = (self._recent + [need])[-TorchExchange.WINDOW:]
+            self._F = max(TorchExchange.MIN_FRAME, 1 << (2 * max(self._recent)).bit_length())
         for s, b in zip(sims, self._recv):
             s.frame_deliver(self.ptr(b), F)
         for s in sims:

@@ -153,6 +153,10 @@ class Sim:
     def frame_pack(self, send_ptr: int, frame_records: int):
         self._ck("swim_frame_pack", self._l.swim_frame_pack(self._h, C.c_void_p(send_ptr), frame_records))
 
+    def frame_pack_fill(self, send_ptr: int, frame_records: int):
+        """Frames sized from the load: what does not fit is not an error — the headers say what there is (swimsim.h)."""
+        self._ck("swim_frame_pack_fill", self._l.swim_frame_pack_fill(self._h, C.c_void_p(send_ptr), frame_records))
+
     def frame_deliver(self, recv_ptr: int, frame_records: int):
         self._ck("swim_frame_deliver", self._l.swim_frame_deliver(self._h, C.c_void_p(recv_ptr), frame_records))
 

@@ -375,6 +375,16 @@ int swim_activity(swim_sim* sim, int* active);
 uint32_t swim_frame_records(swim_sim* sim);
 int swim_frame_pack(swim_sim* sim, swim_edge* send, uint32_t frame_records);
 int swim_frame_deliver(swim_sim* sim, const swim_edge* recv, uint32_t frame_records);
+/* Frames sized from the LOAD, not from the bound (round 5; consul_amd/dist.py TorchExchange): swim_frame_pack_fill packs like
+ * swim_frame_pack, but a segment that does not fit is not an error — the frame carries what fits and its header says what there is:
+ *   {count = records the segment HAS, activity | need << 1, tick + 1, SWIM_FRAME_MAGIC},  need = the largest count this shard holds for
+ *   ANY destination this tick.
+ * The caller looks at the headers it received (and its own): when the largest `need` of the population exceeds frame_records - 1 —
+ * every shard sees every sender's, so all take the same decision — it packs again into frames of at least need + 1 records (packing
+ * is repeatable until swim_tick_end) and repeats the collective, BEFORE swim_frame_deliver: nothing is ever lost, and a quiet tick
+ * moves a frame of a few records instead of the bound's megabytes.  swim_frame_deliver refuses a frame whose count exceeds
+ * frame_records - 1 (the sticky edge-list overflow on the product library, SWIM_ESTATE on the oracle). */
+int swim_frame_pack_fill(swim_sim* sim, swim_edge* send, uint32_t frame_records);
 
 /* ---- device-driven exchange between the shards of one population (peer-mapped mailboxes over xGMI) -------
  * The split tick above leaves the exchange to the caller (consul_amd/dist.py uses RCCL).  This is the library's own: every

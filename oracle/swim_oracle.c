@@ -1655,6 +1655,19 @@ int swim_frame_pack(swim_sim* s, swim_edge* send, uint32_t F) {
   }
   return SWIM_OK;
 }
+/* ... frames sized from the load: what does not fit is not an error, the header says what there is and what the largest segment needs */
+int swim_frame_pack_fill(swim_sim* s, swim_edge* send, uint32_t F) {
+  if (!s || !send || F < 2) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
+  uint32_t need = 0;
+  for (uint32_t j = 0; j < s->cfg.n_shards; j++) if (j != s->cfg.shard_rank && s->out[j].n > need) need = (uint32_t)s->out[j].n;
+  for (uint32_t j = 0; j < s->cfg.n_shards; j++) {
+    swim_edge* fr = send + (size_t)j * F;
+    uint32_t n = j == s->cfg.shard_rank ? 0 : (uint32_t)s->out[j].n, fit = n < F - 1 ? n : F - 1;
+    fr[0].dst = n; fr[0].subject = 1u | (need << 1); fr[0].incarnation = s->tick + 1; fr[0].meta = SWIM_FRAME_MAGIC;
+    if (fit) memcpy(fr + 1, s->out[j].v, (size_t)fit * sizeof(swim_edge));
+  }
+  return SWIM_OK;
+}
 int swim_frame_deliver(swim_sim* s, const swim_edge* recv, uint32_t F) {
   if (!s || !recv || F < 2) return SWIM_EINVAL; if (!s->in_tick) return SWIM_ESTATE;
   for (uint32_t i = 0; i < s->cfg.n_shards; i++) {

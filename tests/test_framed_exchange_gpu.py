@@ -54,8 +54,8 @@ class HipRuntime:
         self.bufs = []
 
 
-def device_frames(rt, frame_records=None):
-    return LocalFramedExchange(alloc=rt.alloc, ptr=lambda b: b, copy=rt.copy, sync=rt.sync, frame_records=frame_records)
+def device_frames(rt, frame_records=None, adaptive=False):
+    return LocalFramedExchange(alloc=rt.alloc, ptr=lambda b: b, copy=rt.copy, sync=rt.sync, frame_records=frame_records, read=rt.record if adaptive else None)
 
 
 @pytest.mark.parametrize("n_shards", [2, 4])
@@ -78,6 +78,31 @@ def test_framed_exchange_on_hip_matches_the_unsharded_checker(hip, oracle, n_sha
     for k in STAT_KEYS:
         assert a[k] == b[k], k
     assert a["edges_remote"] > 0 and a["folds"] >= 1
+    sh.close(); rt.free()
+
+
+def test_frames_sized_from_the_load_on_hip(hip, oracle):
+    """swim_frame_pack_fill on the device: frames of 64 records that follow the load, a tick that does not fit packed and moved again before it
+    is delivered — the unsharded checker's digest and counters, with retries on the way and no overflow."""
+    kw = dict(n_nodes=4096, n_replicas=2, seed=5, subject_cap=256, view_cap=256, queue_cap=16, inbox_cap=1024,
+              loss_q32=int(0.05 * 2**32), fold_interval_ms=5000, flags=abi.F_DEFAULT & ~abi.F_TCP_FALLBACK)
+    sims = [Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)]
+    rt = HipRuntime()
+    ex = device_frames(rt, adaptive=True)
+    sh = ShardedSim(sims, ex)
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    sizes = set()
+    for s in (sh, ref):
+        s.step_ms(3000)
+        s.kill(0, [100, 3000]); s.kill(1, [7]); s.update(1, [2048])
+    for _ in range(30):
+        sh.step_ms(1000); ref.step_ms(1000); sizes.add(ex._F)
+    sh.sync()
+    assert sh.digest() == ref.digest()
+    a, b = sh.stats(), ref.stats()
+    for k in STAT_KEYS:
+        assert a[k] == b[k], k
+    assert ex.retries > 0 and min(sizes) < max(sizes) < sims[0].frame_records()
     sh.close(); rt.free()
 
 
