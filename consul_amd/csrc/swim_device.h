@@ -11,7 +11,9 @@
 #define SW_MAX_SHARDS 16
 #define SW_EXC_MAX 16               /* per-replica list of nodes whose node word is non-zero */
 #define SW_BIGSORT_MIN 128u        /* from this many messages on an inbox is sorted by a whole workgroup (k_inbox_sort), not by its lane */
-#define SW_BIGSORT_MAX 8192u       /* ... up to what 96 KB of LDS hold (12 bytes per message) */
+#ifndef SW_BIGSORT_MAX
+#define SW_BIGSORT_MAX 8192u       /* ... up to what 96 KB of LDS hold (12 bytes per message); beyond: k_inbox_sort_huge (a test build may lower it: a power of two >= SW_BIGSORT_MIN) */
+#endif
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
 #define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
@@ -191,6 +193,7 @@ struct SwDev {
   uint32_t *mA, *mB, *mC;                // [R][M][nloc]
   uint32_t* m_tile_dl;                   // [R][M][nbl] lower bound of the suspicion deadlines of a row's 256-observer tile (acting observers)
   uint32_t* m_row_dl;                    // [R*M] ... of the whole row
+  uint32_t* m_rev;                       // [nbl / 32] tiles that hold an observer revived by the stimulus call in progress (k_inject -> k_mass_rearm)
   uint32_t *m_due, *m_due_cnt;           // [R*M], [1] rows whose bound has passed this tick (k_expire_mass_due -> k_expire_mass)
   uint4* xs_list; uint32_t* xs_cnt; uint32_t xs_cap;   // state exchanges of this tick whose dense-store part k_send_mass sends: {replica, owner, receiver, flags}
   uint32_t* mcnt;                        // [NL] pairs of the dense store this observer holds (present)

@@ -470,6 +470,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
     if (serf) { DALLOC(s, D.mD, pairs); HIPCK(s, hipMemsetAsync(D.mD, 0, pairs * 4, s->stream)); }
     DALLOC(s, D.m_tile_dl, RM * D.nbl); DALLOC(s, D.m_row_dl, RM); DALLOC(s, D.mcnt, NL);
+    DALLOC(s, D.m_rev, cdiv(D.nbl, 32)); HIPCK(s, hipMemsetAsync(D.m_rev, 0, (size_t)cdiv(D.nbl, 32) * 4, s->stream));
     DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mB, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mC, 0, pairs * 4, s->stream));
@@ -793,6 +794,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     uint32_t P = SW_BIGSORT_MIN; while (P < D.bigsort_cap) P <<= 1;
     hipLaunchKernelGGL(k_inbox_sort_med, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_inbox_sort, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)P * 12, st, (const SwDev*)s->d_D, P);
+    if (D.C > D.bigsort_cap) hipLaunchKernelGGL(k_inbox_sort_huge, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)SW_BIGSORT_MAX * 12, st, (const SwDev*)s->d_D);   // (inbox_cap beyond what LDS sorts: config #4's recovery)
   }
   const bool serf_k = (D.flags & SWIM_F_SERF_EVENTS) != 0;
   void (*const resolve_kernel)(const SwDev*) =
@@ -1127,6 +1129,10 @@ static int inject(swim_sim* s, int op, uint32_t r, const uint32_t* ids, size_t n
     watch_ids(s, r, s->d_scratch, c);
     if (s->D.M) hipLaunchKernelGGL(k_mass_alloc, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r, (const uint32_t*)s->d_scratch, c);
     hipLaunchKernelGGL(k_inject, dim3(cdiv(c, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, op, r, (const uint32_t*)s->d_scratch, c);
+    if (s->D.M && op == INJ_REVIVE) {
+      hipLaunchKernelGGL(k_mass_rearm, dim3(cdiv(s->D.M, SW_BLOCK)), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);
+      HIPCK(s, hipMemsetAsync(s->D.m_rev, 0, (size_t)cdiv(s->D.nbl, 32) * 4, s->stream));
+    }
     HIPCK(s, hipStreamSynchronize(s->stream));          // ids is caller memory; the scratch buffer is reused
   }
   hipLaunchKernelGGL(k_exc_rebuild, dim3(1), dim3(SW_BLOCK), 0, s->stream, (const SwDev*)s->d_D, r);   // node words changed

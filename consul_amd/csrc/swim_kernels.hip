@@ -2641,6 +2641,84 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort(const SwDev* __restrict
   }
 }
 
+// ... and the inboxes beyond what LDS holds (round 5; config #4's RECOVERY: the first state exchange after a partition of 65 536 nodes heals
+// hands a node 62 000 messages — the lane's heapsort of that is two million dependent round trips, seconds of a tick).  A workgroup per
+// such inbox, a bitonic network in its "ascending only" form (the first step of a level compares mirrored positions, the others
+// positions j apart: the smaller key always goes to the lower index, so the pads — every position from n on, the greatest key there is,
+// never stored — stay where they are): the levels up to SW_BIGSORT_MAX and, of every higher level, the steps inside SW_BIGSORT_MAX-element
+// chunks run in LDS a chunk at a time; only the steps that cross chunks (six for 65 536 messages) work on the row in global memory.
+__device__ __forceinline__ bool rec_gt(uint32_t ay, uint32_t az, uint32_t aw, uint32_t by, uint32_t bz, uint32_t bw) {
+  uint64_t ah, al, bh, bl; edge_key(make_uint4(0, ay, az, aw), ah, al); edge_key(make_uint4(0, by, bz, bw), bh, bl);
+  return ah > bh || (ah == bh && al > bl);
+}
+__global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort_huge(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  constexpr uint32_t S = SW_BIGSORT_MAX;
+  uint32_t* const sy = (uint32_t*)g_lds_dyn; uint32_t* const sz = sy + S; uint32_t* const sw = sz + S;
+  __shared__ uint32_t s_big[SW_BLOCK], s_nbig;
+  const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)blockIdx.x * SW_BLOCK, l = l0 + threadIdx.x;
+  uint32_t c = l < NL ? D.in_cnt[l] : 0u;
+  if (c > D.C) c = D.C;
+  const bool big = c > D.bigsort_cap && D.bigsort_cap != 0;
+  if (!__syncthreads_or(big)) return;
+  if (threadIdx.x == 0) s_nbig = 0;
+  __syncthreads();
+  if (big) s_big[atomicAdd(&s_nbig, 1u)] = threadIdx.x;
+  __syncthreads();
+  const uint32_t nbig = s_nbig;
+  for (uint32_t b = 0; b < nbig; b++) {
+    const size_t ll = l0 + s_big[b];
+    uint32_t n = D.in_cnt[ll]; if (n > D.C) n = D.C;
+    uint32_t* const row = D.inbox2 + ll * D.C2 * 3;
+    const uint32_t* const line = D.inbox1 + ll * 16;
+    // the five messages of the line join the row (arrivals 6.. sit at 0.. : the row has room for all C)
+    if (threadIdx.x < SW_INBOX_FAST) { uint32_t* m = row + (size_t)(n - SW_INBOX_FAST + threadIdx.x) * 3; m[0] = line[1 + 3 * threadIdx.x]; m[1] = line[2 + 3 * threadIdx.x]; m[2] = line[3 + 3 * threadIdx.x]; }
+    __threadfence_block(); __syncthreads();
+    uint32_t P = S; while (P < n) P <<= 1;
+    // the steps of level k that stay inside a chunk of S positions (all of them for k <= S; j = S/2 .. 1 of a higher level), a chunk at a time in LDS
+    auto lds_pass = [&](uint32_t k_first, uint32_t k_last, bool tail_only) {
+      for (uint32_t c0 = 0; c0 < n; c0 += S) {
+        const uint32_t m = n - c0 < S ? n - c0 : S;                 // real elements of this chunk; beyond: pads
+        for (uint32_t i = threadIdx.x; i < S; i += SW_BLOCK) {
+          uint32_t y = NONE, z = NONE, w = NONE;
+          if (i < m) { const uint32_t* e = row + (size_t)(c0 + i) * 3; y = e[0]; z = e[1]; w = e[2]; }
+          sy[i] = y; sz[i] = z; sw[i] = w;
+        }
+        __syncthreads();
+        for (uint32_t k = k_first; k <= k_last; k <<= 1)
+          for (uint32_t j = tail_only ? S >> 1 : k >> 1; j; j >>= 1) {
+            const bool flip = !tail_only && j == k >> 1;
+            for (uint32_t p = threadIdx.x; p < S / 2; p += SW_BLOCK) {
+              const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = flip ? i ^ (k - 1) : i | j;
+              if (rec_gt(sy[i], sz[i], sw[i], sy[q], sz[q], sw[q])) {
+                const uint32_t ty = sy[i], tz = sz[i], tw = sw[i];
+                sy[i] = sy[q]; sz[i] = sz[q]; sw[i] = sw[q]; sy[q] = ty; sz[q] = tz; sw[q] = tw;
+              }
+            }
+            __syncthreads();
+          }
+        for (uint32_t i = threadIdx.x; i < m; i += SW_BLOCK) { uint32_t* e = row + (size_t)(c0 + i) * 3; e[0] = sy[i]; e[1] = sz[i]; e[2] = sw[i]; }
+        __threadfence_block(); __syncthreads();
+      }
+    };
+    lds_pass(2, S, false);
+    for (uint32_t k = S << 1; k <= P; k <<= 1) {
+      for (uint32_t j = k >> 1; j >= S; j >>= 1) {                  // the steps that cross chunks: on the row itself
+        const bool flip = j == k >> 1;
+        for (uint32_t p = threadIdx.x; p < P / 2; p += SW_BLOCK) {
+          const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = flip ? i ^ (k - 1) : i | j;
+          if (q >= n) continue;                                     // a pad: never smaller
+          uint32_t* a = row + (size_t)i * 3; uint32_t* e = row + (size_t)q * 3;
+          const uint32_t ay = a[0], az = a[1], aw = a[2], by = e[0], bz = e[1], bw = e[2];
+          if (rec_gt(ay, az, aw, by, bz, bw)) { a[0] = by; a[1] = bz; a[2] = bw; e[0] = ay; e[1] = az; e[2] = aw; }
+        }
+        __threadfence_block(); __syncthreads();
+      }
+      lds_pass(k, k, true);
+    }
+  }
+}
+
 // ... and the inboxes in between (SW_INBOX_SORT_MIN .. SW_BIGSORT_MIN - 1 messages: every node's, tick after tick, in the mass phase
 // of config #4 — profiles/r03_config4_resolve_phase_clock.txt: their heapsort by one lane in global memory was ~3.5 of the 8 ms a
 // wave of k_resolve spent on a tick) by one WAVE each, in the wave's own 1.5 KB strip of LDS: no workgroup barrier, 6 KB of LDS
@@ -2834,7 +2912,7 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
     // is about (nearly always the only subject in the inbox; a wrong guess costs one wasted lookup)
     if constexpr (RESOLVE_LQ) n.stage_queue();
     const bool sorted = cnt >= SW_INBOX_SORT_MIN;
-    const bool presorted = cnt >= SW_INBOX_SORT_MIN && cnt <= D.bigsort_cap;   // k_inbox_sort_med / k_inbox_sort have been here (bigsort_cap = 0: neither runs)
+    const bool presorted = cnt >= SW_INBOX_SORT_MIN && D.bigsort_cap != 0;      // k_inbox_sort_med / k_inbox_sort / k_inbox_sort_huge have been here (bigsort_cap = 0: none runs)
     if (!sorted) {
       const uint32_t gx = IN_WORD(1), gty = IN_WORD(3) >> 30;
       if (gx < D.N && gty != SWIM_MSG_USER && gx != n.o) { n.cv = n.lookup(gx); n.cv_x = gx; }
@@ -3280,13 +3358,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
         // counts again in the block's gate
         const uint32_t d = VMETA(l).z;
         if (d != NONE) atomicMin(&D.dl_blk[l / SW_BLOCK], d);
-        if (D.M && D.mcnt[l])                                  // ... and so do its suspicions in the dense store
-          for (uint32_t row = 0; row < D.M; row++) {
-            if (D.mrow_subj[(size_t)r * D.M + row] == NONE) continue;
-            const size_t idx = m_idx(D, r, row, x - D.i0);
-            const uint32_t a = D.mA[idx];
-            if (a && MA_STATE(a) == SWIM_STATE_SUSPECT) m_arm(D, r, row, x - D.i0, MB_TICK(D.mB[idx]) * D.quantum_ms + susp_timeout_n(D, 0, MA_NCONF(a)));
-          }
+        // ... and so do its suspicions in the dense store: its 256-observer tile is marked, and k_mass_rearm (right after this kernel) lowers
+        // that tile's bound in every row to "now" — the next k_expire_mass looks into those tiles and leaves exact bounds behind.  (Rounds 3-4
+        // walked the observer's column here, one lane through all M rows: 60 ms per call of config #5's leg, half its kernel time — profiles/r05_config5_kernel_stats.csv)
+        if (D.M && D.mcnt[l]) atomicOr(&D.m_rev[((x - D.i0) / SW_BLOCK) >> 5], 1u << (((x - D.i0) / SW_BLOCK) & 31u));
       }
     } else if (local && !(D.nw[g] & NW_DEAD)) {
       NodeCtx c(D, S);
@@ -3307,6 +3382,19 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject(const SwDev* __restrict__ D
   if ((op == INJ_KILL || op == INJ_REVIVE) && blockIdx.x == 0)
     for (uint32_t sl = threadIdx.x; sl < D.n_slots[r]; sl += SW_BLOCK) D.slot_dirty[(size_t)r * D.S + sl] = 1;
   S.flush(D);
+}
+// after k_inject(INJ_REVIVE) on a handle with the dense pair store: the tiles that hold a revived observer are due in every live row of replica r
+__global__ void __launch_bounds__(SW_BLOCK) k_mass_rearm(const SwDev* __restrict__ Dp, uint32_t r) {
+  SW_DEV_BIND
+  const uint32_t row = blockIdx.x * SW_BLOCK + threadIdx.x, now = now_ms(D, *D.tick);
+  if (row >= D.M || D.mrow_subj[(size_t)r * D.M + row] == NONE) return;
+  bool any = false;
+  for (uint32_t w = 0; w < (D.nbl + 31) / 32; w++)
+    for (uint32_t m = D.m_rev[w]; m; m &= m - 1) {
+      const uint32_t tile = w * 32 + (uint32_t)__ffs(m) - 1;
+      atomicMin(&D.m_tile_dl[((size_t)r * D.M + row) * D.nbl + tile], now); any = true;
+    }
+  if (any) atomicMin(&D.m_row_dl[(size_t)r * D.M + row], now);
 }
 // swim_set_tcp_class
 __global__ void __launch_bounds__(SW_BLOCK) k_set_tcp_class(const SwDev* __restrict__ Dp, uint32_t r, const uint32_t* ids, uint32_t n, uint32_t cls) {
