@@ -167,6 +167,7 @@ PROTOTYPES = {
     "swim_watch_events": (C.c_int, [SimP, u32, u32]),
     "swim_poll_events": (C.c_int, [SimP, P(Event), C.c_size_t, P(C.c_size_t)]),
     "swim_node_info_get": (C.c_int, [SimP, u32, u32, P(NodeInfo)]),
+    "swim_event_queued": (C.c_int, [SimP, u32, u32, u32, u64, C.POINTER(C.c_int)]),
     "swim_census_get": (C.c_int, [SimP, u32, u32, P(Census)]),
     "swim_detection_get": (C.c_int, [SimP, u32, P(Detection)]),
     "swim_trace_read": (C.c_int, [SimP, u32, u32, u32, u32, P(u32)]),

@@ -1369,6 +1369,15 @@ extern "C" int swim_poll_events(swim_sim* s, swim_event* out, size_t cap, size_t
   *n_out = k;
   return SWIM_OK;
 }
+extern "C" int swim_event_queued(swim_sim* s, uint32_t r, uint32_t i, uint32_t id, uint64_t ltime, int* queued) {
+  if (!s || !queued) return SWIM_EINVAL;
+  if (r >= s->D.R || i >= s->D.N || !is_local(s, i)) return SWIM_ERANGE;
+  hipLaunchKernelGGL(k_evq_find, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, i, id, (uint32_t)ltime, s->d_scratch);
+  uint32_t w = 0; int rc = d2h(s, &w, (const uint32_t*)s->d_scratch, 1);
+  if (rc) return rc;
+  *queued = w != 0;
+  return SWIM_OK;
+}
 extern "C" int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out) {
   if (!s || !out) return SWIM_EINVAL;
   const SwDev& D = s->D;

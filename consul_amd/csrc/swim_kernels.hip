@@ -3518,6 +3518,15 @@ __global__ void k_gather_node(const SwDev* __restrict__ Dp, uint32_t r, uint32_t
   for (uint32_t j = 0; j < h_qlen(h.y) && j < 32; j++) { uint4 e = QENT(j, l); out[16 + 4 * j] = e.x; out[17 + 4 * j] = e.y; out[18 + 4 * j] = e.z; out[19 + 4 * j] = e.w; }
 }
 
+// swim_event_queued: is {id, ltime} in the node's serf queue?
+__global__ void k_evq_find(const SwDev* __restrict__ Dp, uint32_t r, uint32_t i, uint32_t id, uint32_t ltime, uint32_t* out) {
+  SW_DEV_BIND
+  if (threadIdx.x || blockIdx.x) return;
+  const size_t l = (size_t)r * D.nloc + (i - D.i0), NL = (size_t)D.R * D.nloc;
+  uint32_t hit = 0;
+  if (D.EQ) for (uint32_t j = 0; j < h_evqlen(HDR(l).y); j++) { const uint4 e = D.evq[(size_t)j * NL + l]; hit |= e.x == id && e.y == ltime; }
+  out[0] = hit;
+}
 // order-independent digest (same item hashes as the oracle; see swim_state_digest there)
 __device__ __forceinline__ void digest_commit(uint64_t d, unsigned long long* out) {
   for (int off = 32; off; off >>= 1) d += __shfl_down(d, off);

@@ -470,6 +470,9 @@ int swim_poll_events(swim_sim* sim, swim_event* out, size_t cap, size_t* n_out);
 #define SWIM_EVENT_WATCHERS 64
 int swim_watch_events(swim_sim* sim, uint32_t replica, uint32_t node);
 int swim_node_info_get(swim_sim* sim, uint32_t replica, uint32_t node, swim_node_info* out);
+/* serf's notifyCh of a broadcast, as a question: is the serf broadcast {id, ltime} (a user event or an intent: swim_user_event / swim_force_leave
+ * return the ltime) still in `node`'s queue — not yet out of transmissions, not pruned?  What Serf.Leave() waits on (include/swimsim_serf.hpp). */
+int swim_event_queued(swim_sim* sim, uint32_t replica, uint32_t node, uint32_t id, uint64_t ltime, int* queued);
 int swim_census_get(swim_sim* sim, uint32_t replica, uint32_t subject, swim_census* out);
 /* BASELINE config #4's deliverable ("rounds until all survivors mark all victims dead"), for any mix of stopped and
  * partitioned nodes: over all ordered pairs (observer o, subject x != o) where o is a node of THIS shard the simulator acts

@@ -378,8 +378,8 @@ class Serf {
       check(swim_force_leave(pool_->handle(), replica_, id_, id_, 0, &lt), "swim_force_leave");
       const Duration step = roundUp(Duration(pool_->config().gossip_interval_ms));
       for (Duration waited{0}; waited < conf_.BroadcastTimeout; waited += step) {        // notifyCh: the broadcast is finished
-        swim_node_info ni; check(swim_node_info_get(pool_->handle(), replica_, id_, &ni), "swim_node_info_get");
-        if (!ni.event_queue_len) break;
+        int queued = 0; check(swim_event_queued(pool_->handle(), replica_, id_, SWIM_INTENT_LEAVE | id_, lt, &queued), "swim_event_queued");
+        if (!queued) break;                               // (the intent itself, not an empty queue: under steady user-event traffic that never comes — ADVICE r4)
         pool_->Advance(step);
       }
     }

@@ -35,6 +35,8 @@
 #define _GNU_SOURCE
 #include "../include/swimsim.h"
 
+#define QMAX 4096      /* memberlist's TransmitLimitedQueue is unbounded; the product library stages queue_cap <= 32 entries per node in LDS.  The checker may hold far
+                        * more, so that what the bound costs can be measured against (nearly) no bound at all: tools/queue_cap_sweep.py, profiles/r05_queue_cap_sweep.txt */
 #define EVQ_MAX 8192   /* serf sizes its event queue max(2N, 4096) (internal/gossip/libserf/serf.go:22-27); the checker can hold that for N <= 4096 */
 
 #include <math.h>
@@ -173,7 +175,7 @@ static int validate(const swim_config* c) {
   if (c->gossip_nodes < 1 || c->gossip_nodes > 8 || c->indirect_checks > 8) return SWIM_EINVAL;
   if (c->suspicion_mult < 1 || c->suspicion_mult > 6 || c->retransmit_mult < 1) return SWIM_EINVAL;
   if (c->awareness_max_mult < 1 || c->awareness_max_mult > 255) return SWIM_EINVAL;
-  if (c->queue_cap < 1 || c->queue_cap > 32 || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;
+  if (c->queue_cap < 1 || c->queue_cap > QMAX || c->inbox_cap < 1 || c->subject_cap < 1) return SWIM_EINVAL;   /* (the product library: <= 32) */
   if (c->flags & SWIM_F_SERF_EVENTS)
     if (c->event_queue_cap < 1 || c->event_queue_cap > EVQ_MAX || c->event_buffer < 1 || c->event_ids_per_ltime > 254) return SWIM_EINVAL;   /* (the product library: <= 32) */
   if (c->n_shards < 1 || c->shard_rank >= c->n_shards || c->n_nodes % c->n_shards) return SWIM_EINVAL;
@@ -238,7 +240,6 @@ int swim_config_derive(const swim_config* c, swim_derived* d) {
 /* State                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-#define QMAX 32
 #define CONF_MAX 4
 
 typedef struct { uint32_t subject, inc, from, seq; uint8_t type, transmits; } qent;
@@ -1919,11 +1920,19 @@ int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out)
   out->queue_len = nd->qlen; out->event_queue_len = nd->evqlen; out->event_clock = nd->ev_clock;
   out->alive = s->gt_alive[(size_t)r * s->N + i]; out->leaving = nd->leaving; out->awareness = nd->awareness;
   out->partition = s->part[(size_t)r * s->N + i];
-  for (uint32_t k = 0; k < nd->qlen; k++) {
+  const uint32_t nq = nd->qlen < 32 ? nd->qlen : 32;      /* (the struct holds 32; the checker's queue may be deeper: queue_len says how deep) */
+  for (uint32_t k = 0; k < nq; k++) {
     swim_rumour q = { nd->q[k].subject, nd->q[k].inc, nd->q[k].from, nd->q[k].type, nd->q[k].transmits, {0, 0}, nd->q[k].seq };
     out->queue[k] = q;
   }
-  qsort(out->queue, nd->qlen, sizeof(swim_rumour), rumour_cmp);
+  qsort(out->queue, nq, sizeof(swim_rumour), rumour_cmp);
+  return SWIM_OK;
+}
+/* serf's notifyCh of a broadcast, as a question: is {id, ltime} still in the node's serf queue? */
+int swim_event_queued(swim_sim* s, uint32_t r, uint32_t i, uint32_t id, uint64_t ltime, int* queued) {
+  if (!s || !queued) return SWIM_EINVAL; if (r >= s->R || i >= s->N || !is_local(s, i)) return SWIM_ERANGE;
+  node_t* nd = node_at(s, r, i); *queued = 0;
+  for (uint32_t k = 0; k < nd->evqlen; k++) if (nd->evq[k].subject == id && nd->evq[k].inc == (uint32_t)ltime) *queued = 1;
   return SWIM_OK;
 }
 int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {

@@ -155,7 +155,7 @@ def test_stagger_phases_cover_all_combinations(anylib):
 
 # ---- config validation -----------------------------------------------------------------------------
 @pytest.mark.parametrize("field,value", [("n_nodes", 1), ("gossip_nodes", 0), ("gossip_nodes", 9), ("suspicion_mult", 7),
-                                         ("queue_cap", 33), ("quantum_ms", 300), ("phase_chunk", 48),
+                                         ("queue_cap", 4097), ("quantum_ms", 300), ("phase_chunk", 48),
                                          ("n_shards", 3), ("abi_version", 99)])
 def test_bad_config_is_rejected(anylib, field, value):
     cfg = preset(anylib, abi.PRESET_LAN, n_nodes=128)
