@@ -193,6 +193,7 @@ struct SwDev {
   uint32_t *mA, *mB, *mC;                // [R][M][nloc]
   uint32_t* m_tile_dl;                   // [R][M][nbl] lower bound of the suspicion deadlines of a row's 256-observer tile (acting observers)
   uint32_t* m_row_dl;                    // [R*M] ... of the whole row
+  uint32_t* rc_cnt; unsigned long long* rc_best;   // [R][lanes of k_reconnect] serf's reconnect over the dense store: Failed members a due node holds, min (hash << 32 | id) of them (k_reconnect_scan)
   uint32_t* m_rev;                       // [nbl / 32] tiles that hold an observer revived by the stimulus call in progress (k_inject -> k_mass_rearm)
   uint32_t *m_due, *m_due_cnt;           // [R*M], [1] rows whose bound has passed this tick (k_expire_mass_due -> k_expire_mass)
   uint4* xs_list; uint32_t* xs_cnt; uint32_t xs_cap;   // state exchanges of this tick whose dense-store part k_send_mass sends: {replica, owner, receiver, flags}

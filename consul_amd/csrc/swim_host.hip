@@ -470,6 +470,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
     if (serf) { DALLOC(s, D.mD, pairs); HIPCK(s, hipMemsetAsync(D.mD, 0, pairs * 4, s->stream)); }
     DALLOC(s, D.m_tile_dl, RM * D.nbl); DALLOC(s, D.m_row_dl, RM); DALLOC(s, D.mcnt, NL);
+    if (D.rc_period) { const size_t rcl = (size_t)D.R * cdiv((uint64_t)cdiv(D.N, D.rc_period) * std::min(D.P, D.rc_period), SW_BLOCK) * SW_BLOCK; DALLOC(s, D.rc_cnt, rcl); DALLOC(s, D.rc_best, rcl); }
     DALLOC(s, D.m_rev, cdiv(D.nbl, 32)); HIPCK(s, hipMemsetAsync(D.m_rev, 0, (size_t)cdiv(D.nbl, 32) * 4, s->stream));
     DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
@@ -742,7 +743,13 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
   }
   if (tick != SW_PLAIN_TICK && reconnect_tick(s, tick)) {
     const uint32_t per = D.rc_period, grp = std::min(D.P, per);
-    hipLaunchKernelGGL(k_reconnect, dim3(cdiv((uint64_t)cdiv(D.N, per) * grp, SW_BLOCK), D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    const uint32_t rc_blocks = (uint32_t)cdiv((uint64_t)cdiv(D.N, per) * grp, SW_BLOCK), rc_lanes = rc_blocks * SW_BLOCK;
+    if (D.M) {      // the due nodes' columns of the dense store, a wave per (due node, chunk of rows)
+      (void)hipMemsetAsync(D.rc_cnt, 0, (size_t)D.R * rc_lanes * 4, st); (void)hipMemsetAsync(D.rc_best, 0xFF, (size_t)D.R * rc_lanes * 8, st);
+      const uint64_t waves = (uint64_t)rc_lanes * cdiv(D.M, SW_RC_CHUNK);
+      hipLaunchKernelGGL(k_reconnect_scan, dim3((uint32_t)cdiv(waves, SW_BLOCK / 64), D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, rc_lanes);
+    }
+    hipLaunchKernelGGL(k_reconnect, dim3(rc_blocks, D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   if (D.M) {   // the dense store's suspicion timers: list the due rows, then their due tiles over many waves
     hipLaunchKernelGGL(k_expire_mass_due, dim3(cdiv((size_t)D.R * D.M, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);

@@ -4070,6 +4070,51 @@ __global__ void __launch_bounds__(SW_BLOCK) k_detect_rows(const SwDev* __restric
 // runs and is in reach — exchange state with it like a join does (its answer comes one tick later through the reply list).
 // grid = (blocks over the due set, R).  The dense store's rows are walked by the whole wave, one due node at a time.
 // =================================================================================================
+// The dense store's part of serf's reconnect(): how many members a due node holds Failed and which of them its draw picks (the smallest
+// hash).  A due node's pairs are a COLUMN of the store — one line per row — so the column is cut into chunks of SW_RC_CHUNK rows and every
+// (due node, chunk) gets a wave of its own; the partial counts and minima meet in rc_cnt / rc_best (atomics), k_reconnect reads them.
+// (Rounds 3-4 walked the columns inside k_reconnect, a wave on one due node at a time: 2 184 columns of 65 536 rows on 35 waves — 64 ms per
+// call, a fifth of the partition leg's kernel time; profiles/r05_config4_partition_kernel_stats.csv.)
+#define SW_RC_CHUNK 2048u
+__global__ void __launch_bounds__(SW_BLOCK) k_reconnect_scan(const SwDev* __restrict__ Dp, uint32_t lanes) {
+  SW_DEV_BIND
+  const uint32_t t = *D.tick, r = blockIdx.y, per = D.rc_period, grp = D.P < per ? D.P : per, lane = sw_lane();
+  const uint32_t nchunk = (D.M + SW_RC_CHUNK - 1) / SW_RC_CHUNK;
+  const uint64_t wv = (uint64_t)blockIdx.x * (SW_BLOCK / 64) + threadIdx.x / 64;
+  const uint32_t a = (uint32_t)(wv / nchunk), chunk = (uint32_t)(wv % nchunk);
+  if (a >= lanes) return;
+  const uint64_t i64 = (uint64_t)((t + a % grp) % per) + (uint64_t)(a / grp) * per;
+  if (i64 >= D.N) return;
+  const uint32_t o_ = (uint32_t)i64;
+  if (o_ < D.i0 || o_ >= D.i0 + D.nloc || (D.nw[(size_t)r * D.N + o_] & NW_INERT)) return;
+  const size_t l = (size_t)r * D.nloc + (o_ - D.i0);
+  if (!D.mcnt[l]) return;
+  uint32_t w[4];
+  { const uint64_t sr = seed_of(D, r); sw_philox(t, o_, 0, 0x5245434Eu, (uint32_t)sr, (uint32_t)(sr >> 32) ^ SW_STREAM_RECONNECT, w); }
+  const uint32_t key_ = w[1];
+  uint32_t cnt = 0, b = NONE, bh = 0;
+  const uint32_t row_end = (chunk + 1) * SW_RC_CHUNK < D.M ? (chunk + 1) * SW_RC_CHUNK : D.M;
+  for (uint32_t row = chunk * SW_RC_CHUNK + lane; row < row_end; row += 64) {
+    const uint32_t x = D.mrow_subj[(size_t)r * D.M + row];
+    if (x == NONE) continue;
+    const uint32_t av = D.mA[m_idx(D, r, row, o_ - D.i0)];
+    if (av && x != o_ && MA_STATE(av) == SWIM_STATE_DEAD && !MA_ERASED(av)) {
+      cnt++;
+      const uint32_t h = sw_fmix32(x ^ key_);
+      if (b == NONE || h < bh || (h == bh && x < b)) { b = x; bh = h; }
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    cnt += __shfl_xor(cnt, off);
+    const uint32_t ob = __shfl_xor(b, off), obh = __shfl_xor(bh, off);
+    if (ob != NONE && (b == NONE || obh < bh || (obh == bh && ob < b))) { b = ob; bh = obh; }
+  }
+  if (lane == 0 && cnt) {
+    const size_t slot = (size_t)r * lanes + a;
+    atomicAdd(&D.rc_cnt[slot], cnt);
+    atomicMin(&D.rc_best[slot], ((unsigned long long)bh << 32) | b);
+  }
+}
 __global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   __shared__ uint32_t lds_stats[ST_COUNT];
@@ -4097,37 +4142,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reconnect(const SwDev* __restrict_
       if (best == NONE || h < best_h || (h == best_h && e.x < best)) { best = e.x; best_h = h; }
     }
   }
-  if (D.M) {                                         // the dense store, the wave on one due node at a time
-    uint64_t todo = __ballot(due && D.mcnt[l] != 0);
-    while (todo) {
-      const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1; todo &= todo - 1;
-      const uint32_t o_ = __shfl(o, leader), key_ = __shfl(w[1], leader);
-      uint32_t left_ = __shfl(due ? D.mcnt[l] : 0u, leader), cnt = 0, b = NONE, bh = 0;
-      for (uint32_t row0 = 0; row0 < D.M && left_; row0 += 64) {
-        const uint32_t row = row0 + lane; bool present = false;
-        if (row < D.M) {
-          const uint32_t x = D.mrow_subj[(size_t)r * D.M + row];
-          if (x != NONE) {
-            const uint32_t av = D.mA[m_idx(D, r, row, o_ - D.i0)];
-            present = av != 0;
-            if (av && x != o_ && MA_STATE(av) == SWIM_STATE_DEAD && !MA_ERASED(av)) {
-              cnt++;
-              const uint32_t h = sw_fmix32(x ^ key_);
-              if (b == NONE || h < bh || (h == bh && x < b)) { b = x; bh = h; }
-            }
-          }
-        }
-        left_ -= (uint32_t)__popcll(__ballot(present));
-      }
-      for (int off = 32; off; off >>= 1) {
-        cnt += __shfl_xor(cnt, off);
-        const uint32_t ob = __shfl_xor(b, off), obh = __shfl_xor(bh, off);
-        if (ob != NONE && (b == NONE || obh < bh || (obh == bh && ob < b))) { b = ob; bh = obh; }
-      }
-      if (lane == leader && cnt) {
-        n_failed += cnt;
-        if (best == NONE || bh < best_h || (bh == best_h && b < best)) { best = b; best_h = bh; }
-      }
+  if (D.M && due) {                                  // the dense store: k_reconnect_scan has been through the due nodes' columns
+    const size_t slot = (size_t)r * gridDim.x * SW_BLOCK + a;
+    const uint32_t cnt = D.rc_cnt[slot]; const unsigned long long key = D.rc_best[slot];
+    if (cnt) {
+      const uint32_t b = (uint32_t)key, bh = (uint32_t)(key >> 32);
+      n_failed += cnt;
+      if (best == NONE || bh < best_h || (bh == best_h && b < best)) { best = b; best_h = bh; }
     }
   }
   bool go = false;
