@@ -47,7 +47,7 @@ from consul_amd import abi  # noqa: E402
 from consul_amd.sim import Sim, preset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILES = ("r04_pmc_driver.json", "r03_pmc_driver.json")     # HBM bytes per launch, newest first (tools/pmc_traffic_pass.sh over the driver's window)
+PMC_FILES = ("r05_pmc_driver.json", "r04_pmc_driver.json", "r03_pmc_driver.json")     # HBM bytes per launch, newest first (tools/pmc_traffic_pass.sh over the driver's window)
 
 
 def _pmc():
@@ -366,8 +366,16 @@ def run_config4(hip, args, device) -> dict:
            # what would cross xGMI if this population were one of 8 shards: 7/8 of the records, 16 bytes each
            "a2a_bytes_per_tick_if_one_of_8_shards": {"mean": 16.0 * 7 / 8 * st["edges"] / max(ticks, 1)},
            "pair_store_GB": round(12.0 * (nv + 8) * n / 1e9, 1),
-           "quoted_from_profiles": {"queue_cap_cost": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
-                                                       "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}}},
+           "what_the_answer_is_a_property_of": "the 32-entry queue, NOT memberlist: memberlist's TransmitLimitedQueue is unbounded.  The checker (whose queue holds up to 4 096 "
+                                               "since round 5) reaches full detection of this shape at 8 192 nodes / 409 stopped after 396 / 361 / 336 / 266 / 306 / 51 / 31 s with "
+                                               "8 / 16 / 32 / 64 / 128 / 256 / 4 096 entries: with every victim's rumour queued at once detection is the suspicion timeout plus one "
+                                               "dissemination, with 32 entries the rumours take turns for ten times as long.  An unbounded queue per virtual node does not fit "
+                                               "(440 GB at this size): DESIGN.md 8 / 10",
+           "quoted_from_profiles": {"queue_cap_cost_on_the_device": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
+                                                                     "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}},
+                                    "queue_cap_sweep_on_the_checker": {"measured_at": "8192 nodes / 409 stopped (profiles/r05_queue_cap_sweep.txt)",
+                                                                       "simulated_s_to_full_detection": {"8": 396, "16": 361, "32": 336, "64": 266, "128": 306, "256": 51, "4096": 31},
+                                                                       "queue_drops_per_applied_message": {"32": 1.68, "256": 0.50, "4096": 0.0}}},
            "curve": curve[:12] + curve[12::4]}
     s.close()
     return out
@@ -380,7 +388,8 @@ def run_config4_partition(hip, args, device) -> dict:
     serf's reconnect() (one Failed member per node and 30 s, agent/consul/config.go:640-641), push-pull, refutations and folds bring
     everybody back.  tests/test_scale_gpu.py pins this very scenario (other seed) against the checker's fixture at 65 536 nodes.
     Reported: the detection census at the heal, then how many members eight observers (four of either side) still hold not-alive,
-    every 30 s until none is left or the push-pull period (30 s x pushPullScale = 360 s at this size) has passed twice."""
+    every 30 s until none is left (750 s of simulated time, 117 s of wall time at 65 536 nodes: profiles/r05_config4_partition_65k.json) or the
+    push-pull period (30 s x pushPullScale = 360 s at this size) has passed two and a half times."""
     n, cut_s = args.config4p_nodes, 60
     nv = n // 20
     rng = np.random.default_rng(args.seed + 4)
@@ -409,7 +418,7 @@ def run_config4_partition(hip, args, device) -> dict:
     at_heal = {"pairs_out_of_reach": pairs, "dead_fraction": (by[2] + by[3]) / max(pairs, 1), "suspect_fraction": by[1] / max(pairs, 1)}
     s.partition(0, np.zeros(n, dtype=np.uint8))
     curve, sec, recovered = [], cut_s, None
-    while sec < cut_s + 720 and not gave_up:
+    while sec < cut_s + 900 and not gave_up:
         for _ in range(3):
             s.step_ms(10000); s.sync()
             gave_up = gave_up or time.perf_counter() - t0 > budget
@@ -620,7 +629,7 @@ def main():
     ap.add_argument("--config4p-nodes", type=int, default=65536, help="config4_partition leg (the partition as written + heal + recovery): nodes; a row of the "
                                                                     "dense store for every node = N^2 x 12 bytes")
     ap.add_argument("--no-config4-partition", action="store_true")
-    ap.add_argument("--config4p-budget-s", type=float, default=90.0, help="config4_partition leg: stop (the curve so far is reported) after this much wall time")
+    ap.add_argument("--config4p-budget-s", type=float, default=150.0, help="config4_partition leg: stop (the curve so far is reported) after this much wall time")
     ap.add_argument("--config4-queue-cap", type=int, default=32)
     ap.add_argument("--config4-budget-s", type=float, default=400.0, help="config4 leg: give up (detection_complete false) after this much wall time")
     ap.add_argument("--no-config5", action="store_true")

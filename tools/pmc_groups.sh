@@ -6,6 +6,6 @@ mkdir -p "$out"
 i=0
 for c in "$@"; do
   d="$out/pass$i"; i=$((i+1))
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -- python bench.py --main-only --handles 1 > "$d.out" 2> "$d.err"
+  timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -- python bench.py --main-only --handles 1 > "$d.out" 2> "$d.err"
   tail -2 "$d.err"
 done

@@ -7,7 +7,7 @@ mkdir -p "$out"
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
   d="$out/pass$i"; i=$((i+1))
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -- python bench.py --main-only --handles 1 "$@" > "$d.out" 2> "$d.err"
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -- python bench.py --main-only --handles 1 "$@" > "$d.out" 2> "$d.err"
 done
 python tools/pmc_traffic.py "$out" 4194304 > "$out/pmc_traffic.json" 2> "$out/pmc_traffic.err"
 cat "$out/pmc_traffic.json"
