@@ -16,6 +16,19 @@
 #endif
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
 #define SW_BLOCK 256
+// k_resolve's geometry (round 5): a workgroup of SW_RES_THREADS threads owns a tile of SW_RTILE node blocks.  Rounds 2-4 ran 256 threads on
+// four node blocks; the phase clock of round 5 (profiles/r05_resolve_phase_clock_driver_window.txt) showed 59 % of a wave's life going to the
+// WORKGROUP's bookkeeping — barriers around the receiver list, three waves waiting at the flush for the fourth — so a workgroup is now ONE
+// wave on ONE node block: its barriers cost nothing, nobody waits for a sibling, and a wave that is done frees its slot at once.
+// (-DSW_RES_THREADS=256 -DSW_RTILE=4 builds the old geometry.)
+#ifndef SW_RES_THREADS
+#define SW_RES_THREADS 64
+#endif
+#ifndef SW_RTILE
+#define SW_RTILE 1
+#endif
+#define SW_RES_WAVES (SW_RES_THREADS / 64)
+#define SW_RES_SUBS (SW_RTILE * SW_BLOCK / SW_RES_THREADS)        /* passes of the workgroup over its tile's count words */
 #define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
 #define SW_COORD_FILTER 3        /* LatencyFilterSize */
 #define SW_COORD_PEERS 16        /* peers whose latency samples a node retains (serf's map is unbounded: DESIGN §8) */

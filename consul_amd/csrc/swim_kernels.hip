@@ -1807,7 +1807,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_deliver(const SwDev* __restrict__ 
       __shared__ uint4 s_raw[SW_TB_CHUNK];
       __shared__ uint16_t s_ord[SW_TB_CHUNK];
       __shared__ uint32_t s_bins[SW_TB_TILE], s_wt[SW_BLOCK / 64];
-      const uint32_t tile = D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + b] : b;
+      // (rs_order lists k_resolve's tiles — node blocks since round 5; it is the buckets' order too only when both tile alike)
+      const uint32_t tile = (SW_RTILE * SW_BLOCK == SW_TB_TILE && D.rs_order) ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + b] : b;
       uint32_t n_tb = D.tb_cnt[tile];
       const bool dbg = *D.dbg_on != 0;
       if (n_tb > D.tb_cap) n_tb = D.tb_cap;        // (the producer that overflowed it has raised SW_ERR_EDGE_OVF)
@@ -2037,19 +2038,6 @@ __device__ void exc_note(DevRef D, uint32_t r, uint32_t x, uint32_t old, uint32_
   uint32_t n = D.exc_cnt[r]; if (n > SW_EXC_MAX) return;               // unusable anyway
   for (uint32_t j = 0; j < n; j++) if (ent[j].x == x) atomicOr(&ent[j].y, now & ~old);
 }
-// k_resolve's geometry (round 5): a workgroup of SW_RES_THREADS threads owns a tile of SW_RTILE node blocks.  Rounds 2-4 ran 256 threads on
-// four node blocks; the phase clock of round 5 (profiles/r05_resolve_phase_clock_driver_window.txt) showed 59 % of a wave's life going to the
-// WORKGROUP's bookkeeping — barriers around the receiver list, three waves waiting at the flush for the fourth — so a workgroup is now ONE
-// wave on ONE node block: its barriers cost nothing, nobody waits for a sibling, and a wave that is done frees its slot at once.
-// (-DSW_RES_THREADS=256 -DSW_RTILE=4 builds the old geometry.)
-#ifndef SW_RES_THREADS
-#define SW_RES_THREADS 64
-#endif
-#ifndef SW_RTILE
-#define SW_RTILE 1
-#endif
-#define SW_RES_WAVES (SW_RES_THREADS / 64)
-#define SW_RES_SUBS (SW_RTILE * SW_BLOCK / SW_RES_THREADS)        /* passes of the workgroup over its tile's count words */
 extern __shared__ uint4 g_lds_dyn[];      // the kernel's dynamic LDS (named at file scope so that NodeCtxT's accesses stay LDS-typed, not generic)
 // k_resolve keeps the censuses of watched subjects up to date INCREMENTALLY: a view that changes state (or reaches the slot's
 // highest incarnation) adds its delta here — per workgroup in LDS, flushed with one global atomic per touched counter — and k_finish
