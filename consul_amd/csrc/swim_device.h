@@ -28,6 +28,12 @@
 #define SW_RTILE 1
 #endif
 #define SW_RES_WAVES (SW_RES_THREADS / 64)
+#define SW_RES_MASS_TILE 64u      /* nodes per workgroup of k_resolve on a handle with the dense pair store (one node block = SW_BLOCK otherwise) */
+#ifdef SW_NO_SPLITQ            /* (A/B: handles with the dense pair store stage whole queue entries, as rounds 3-4 did) */
+#define SW_SPLITQ 0
+#else
+#define SW_SPLITQ 1
+#endif
 #define SW_RES_SUBS (SW_RTILE * SW_BLOCK / SW_RES_THREADS)        /* passes of the workgroup over its tile's count words */
 #define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
 #define SW_COORD_FILTER 3        /* LatencyFilterSize */
@@ -175,7 +181,7 @@ struct SwDev {
   uint32_t* inbox2; // [NL][C2][3]
   // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
   uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue
-  uint32_t* in_any;   // [NL/256] some node of the block received something this tick
+  uint32_t* in_any;   // [NL/64] some node of the 64-node group received something this tick
   uint32_t* alive_cnt;// [NL/256] nodes of the block the simulator acts for (running, not attached)
   uint32_t* qbits;    // [NL/32] bit per lane: the node has something queued (exact; piggy-back orders are gated on it)
   // explicit views (see above) and what bounds them

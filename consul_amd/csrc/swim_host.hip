@@ -26,6 +26,8 @@
     }                                                                                               \
   } while (0)
 
+// nodes per workgroup of k_resolve (swim_kernels.hip): a node block; 64 nodes on a handle with the dense pair store
+static inline uint32_t resolve_tile(const SwDev& D) { return D.M ? SW_RES_MASS_TILE : SW_RTILE * SW_BLOCK; }
 enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
 static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" }   /* (k_finish: k_census_finish since round 5 — the recount and the epilogue in one launch; k_census then has no launches of its own) */;
 #define SW_GRAPH_TICKS 16
@@ -446,7 +448,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16);
 #endif
   DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
-  DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, NB); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
+  DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, cdiv(NL, 64)); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB * D.EW); DALLOC(s, D.evseq, NL); }
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
   D.view_cap = d.view_cap; D.fold_period = d.fold_period_ticks;
@@ -480,12 +482,12 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.peak, 1); HIPCK(s, hipMemsetAsync(D.peak, 0, 4, s->stream));
 #ifndef SW_RESOLVE_PLAIN_ORDER
   if (D.CH >= 64 && NB > 4 * SW_RTILE) {        // the longest-job-first order of k_resolve's tiles, per probe phase (swim_device.h)
-    const uint32_t T = (uint32_t)cdiv(NB, SW_RTILE);
+    const uint32_t TILE = resolve_tile(D), T = (uint32_t)cdiv(NL, TILE);
     std::vector<uint32_t> ord((size_t)D.P * T), due(T);
     for (uint32_t ph = 0; ph < D.P; ph++) {
       for (uint32_t tl = 0; tl < T; tl++) {
         uint32_t n = 0;
-        for (size_t l = (size_t)tl * SW_RTILE * SW_BLOCK; l < std::min<size_t>(NL, (size_t)(tl + 1) * SW_RTILE * SW_BLOCK); l += std::min<uint32_t>(D.CH, SW_BLOCK))
+        for (size_t l = (size_t)tl * TILE; l < std::min<size_t>(NL, (size_t)(tl + 1) * TILE); l += std::min<uint32_t>(D.CH, TILE))
           n += ((D.i0 + (uint32_t)(l % D.nloc)) / D.CH / D.G) % D.P == ph;
         due[tl] = n;
       }
@@ -770,13 +772,10 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_coord_commit, dim3(cdiv(D.c_cap, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
 }
-// k_resolve's dynamic LDS: the lanes' memberlist queues ([Q][256] entries) and the meta words of their user-event queues — without the
-// former under -DSW_MASS_HBMQ when the handle has the dense pair store (swim_kernels.hip, k_resolve)
+// k_resolve's dynamic LDS: the lanes' memberlist queues ([Q][threads] entries of 16 bytes; of 8 — {subject, meta} — on a handle with the
+// dense pair store) and the meta words of their user-event queues
 static size_t resolve_lds_bytes(const SwDev& D) {
-#ifdef SW_MASS_HBMQ
-  if (D.M) return (size_t)D.EQ * SW_RES_THREADS * 4;
-#endif
-  return (size_t)D.Q * SW_RES_THREADS * sizeof(uint4) + (size_t)D.EQ * SW_RES_THREADS * 4;
+  return (size_t)D.Q * SW_RES_THREADS * ((D.M && SW_SPLITQ) ? sizeof(uint2) : sizeof(uint4)) + (size_t)D.EQ * SW_RES_THREADS * 4;
 }
 static void launch_end(swim_sim* s, uint32_t tick) {
   const bool fold = tick != SW_PLAIN_TICK && fold_tick(s, tick);
@@ -807,7 +806,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   void (*const resolve_kernel)(const SwDev*) =
       D.dyn ? (D.M ? (serf_k ? k_resolve<true, true, true> : k_resolve<true, false, true>) : (serf_k ? k_resolve<false, true, true> : k_resolve<false, false, true>))
             : (D.M ? (serf_k ? k_resolve<true, true, false> : k_resolve<true, false, false>) : (serf_k ? k_resolve<false, true, false> : k_resolve<false, false, false>));
-  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3(cdiv(cdiv(NL, SW_BLOCK), SW_RTILE)), dim3(SW_RES_THREADS), resolve_lds_bytes(D), st, (const SwDev*)s->d_D); }
+  { ProfScope p(s, PK_RESOLVE); hipLaunchKernelGGL(resolve_kernel, dim3((uint32_t)cdiv(NL, resolve_tile(D))), dim3(SW_RES_THREADS), resolve_lds_bytes(D), st, (const SwDev*)s->d_D); }
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));

@@ -761,9 +761,9 @@ __device__ __forceinline__ bool noop_at_receiver(DevRef D, uint32_t r, size_t lr
 // (k_resolve: entry j of lane l at q[j*NL + l])
 template <uint32_t STRIDE> struct LdsQT { uint4* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * STRIDE].w; } };
 typedef LdsQT<SW_BLOCK> LdsQ;                  // (the gossip role: 256 lanes, entry j of a lane at sq[j * 256])
+// k_resolve on a handle with the dense pair store: only {subject, meta} of an entry are staged (8 bytes: NodeCtxT::SPLIT)
+template <uint32_t STRIDE> struct LdsQ2T { uint2* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * STRIDE].y; } };
 struct HbmQ { uint4* p; size_t NL; __device__ __forceinline__ uint4& at(uint32_t j) const { return p[(size_t)j * NL]; } };
-// -DSW_MASS_HBMQ (A/B option, off): the meta words of a lane's memberlist queue where they live, slot-major in HBM (a wave reads 1 KB per slot)
-struct HbmMetaQ { uint4* p; size_t NL; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[(size_t)j * NL].w; } };
 // k_resolve: only the meta words (type | transmits | seq) of the lane's queue, staged in LDS
 template <uint32_t STRIDE> struct MetaQT { uint32_t* p; __device__ __forceinline__ uint32_t& meta(uint32_t j) const { return p[j * STRIDE]; } };
 
@@ -1644,7 +1644,7 @@ __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint3
   if (pos < SW_INBOX_FAST) m = D.inbox1 + l * 16 + 1 + 3 * pos;
   else if (pos < D.C) m = D.inbox2 + (l * D.C2 + (pos - SW_INBOX_FAST)) * 3;
   if (m) { m[0] = rec.y; m[1] = rec.z; m[2] = rec.w; }
-  if (pos == 0 && D.fast_blocks) D.in_any[l / SW_BLOCK] = 1;
+  if (pos == 0 && D.fast_blocks) D.in_any[l / 64] = 1;                   // (a hint per 64 nodes: the unit k_resolve's workgroups own one or four of)
 }
 // four records per thread per trip: all four atomics are in flight before the first store
 // (round 4: the same written in explicit phases over the four records — unpredicated clamped loads, all node words, all atomics, all
@@ -2070,6 +2070,13 @@ struct NodeCtxT {
   uint4 h0;
   uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * SW_RES_THREADS + threadIdx.x]; entries to write back
 #define SQ(j) g_lds_dyn[(j) * SW_RES_THREADS + threadIdx.x]   /* (LQ contexts live in k_resolve only) */
+  // Round 5: a handle with the dense pair store runs queue_cap 16-32 (mass events), and 16 bytes x queue_cap x 64 lanes of staged queue left
+  // room for ONE wave per SIMD.  What the merge SCANS of an entry is its subject (QueueBroadcast's invalidation) and its meta word
+  // (GetBroadcasts' order, Prune's victim): only those 8 bytes are staged; incarnation and accuser stay in HBM, written when an entry is
+  // pushed and read when it is sent.  (Editing the whole queue in HBM — -DSW_MASS_HBMQ, round 4's idea — measured 30 % slower: every scan
+  // became a row of loads; profiles/r05_ab_experiments.txt item 1.)
+  static constexpr bool SPLIT = LQ && MASS && SW_SPLITQ;
+#define SQ2(j) ((uint2*)g_lds_dyn)[(j) * SW_RES_THREADS + threadIdx.x]
   __device__ __forceinline__ NodeCtxT(DevRef d, BlockStats& s) : D(d), S(s) {}
 
   __device__ __forceinline__ void load() { load(HDR(l)); }
@@ -2079,19 +2086,28 @@ struct NodeCtxT {
   }
   // LQ: fetch the queue into the LDS column (independent loads, issued together)
   __device__ __forceinline__ void stage_queue(uint32_t from = 0) {
-    for (uint32_t j = from; j < qlen; j++) SQ(j) = QENT(j, l);
+    for (uint32_t j = from; j < qlen; j++) { if constexpr (SPLIT) { const uint4 e = QENT(j, l); SQ2(j) = make_uint2(e.x, e.w); } else SQ(j) = QENT(j, l); }
   }
-  __device__ __forceinline__ uint4 mq_get(uint32_t j) const { if constexpr (LQ) return SQ(j); else return QENT(j, l); }
-  __device__ __forceinline__ uint32_t mq_x(uint32_t j) const { if constexpr (LQ) return SQ(j).x; else return QENT(j, l).x; }
-  __device__ __forceinline__ uint32_t mq_w(uint32_t j) const { if constexpr (LQ) return SQ(j).w; else return QENT(j, l).w; }
-  __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) { if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else QENT(j, l) = e; }
+  __device__ __forceinline__ uint4 mq_get(uint32_t j) const {
+    if constexpr (SPLIT) { uint4 e = QENT(j, l); const uint2 s2 = SQ2(j); e.x = s2.x; e.w = s2.y; return e; }
+    else if constexpr (LQ) return SQ(j); else return QENT(j, l);
+  }
+  __device__ __forceinline__ uint32_t mq_x(uint32_t j) const { if constexpr (SPLIT) return SQ2(j).x; else if constexpr (LQ) return SQ(j).x; else return QENT(j, l).x; }
+  __device__ __forceinline__ uint32_t mq_w(uint32_t j) const { if constexpr (SPLIT) return SQ2(j).y; else if constexpr (LQ) return SQ(j).w; else return QENT(j, l).w; }
+  __device__ __forceinline__ void mq_set(uint32_t j, uint4 e) {
+    if constexpr (SPLIT) { SQ2(j) = make_uint2(e.x, e.w); QENT(j, l) = e; qdirty &= ~(1u << j); }     // (HBM holds the whole entry from here on: not dirty)
+    else if constexpr (LQ) { SQ(j) = e; qdirty |= 1u << j; } else QENT(j, l) = e;
+  }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
   // did the node go from "nothing queued" to "something queued" (or back) since load()?
   __device__ __forceinline__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
   __device__ __forceinline__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
   __device__ __forceinline__ void store() {
     flush_view();
-    if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) { const uint32_t j = __ffs(m) - 1; QENT(j, l) = SQ(j); }
+    if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) {
+      const uint32_t j = __ffs(m) - 1;
+      if constexpr (SPLIT) QENT(j, l).w = SQ2(j).y; else QENT(j, l) = SQ(j);          // (SPLIT: only a transmit count can be newer than HBM's copy)
+    }
     uint4 h = make_uint4(self_inc, h_pack(leaving, qlen, evqlen), qseq, ev_clock);
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) HDR(l) = h;
     if (vm_dirty) VMETA(l) = vm;
@@ -2367,8 +2383,8 @@ struct NodeCtxT {
     if constexpr (SERF) for (uint32_t j = 0; j < evqlen; j++) me.meta(j) = qe.at(j).w;
     const uint32_t rl = DYN ? retransmit_limit_n(D, est_n(D, r, l)) : D.retransmit_limit;
     uint32_t tm, te = 0;
-    if constexpr (LQ) tm = get_broadcasts(D, LdsQT<SW_RES_THREADS>{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);
-    else tm = get_broadcasts(D, HbmMetaQ{D.q + l, NL}, qlen, live_m, 2, limit, used, rl);     // (SW_MASS_HBMQ: transmit counts bumped in place)
+    if constexpr (SPLIT) tm = get_broadcasts(D, LdsQ2T<SW_RES_THREADS>{(uint2*)g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);
+    else tm = get_broadcasts(D, LdsQT<SW_RES_THREADS>{g_lds_dyn + threadIdx.x}, qlen, live_m, 2, limit, used, rl);      // (piggyback() is k_resolve's: LQ)
     int avail = limit - used;
     if constexpr (SERF) if (D.EQ && avail > 2 + 1) te = get_broadcasts(D, me, evqlen, live_e, 3, avail, used2, rl);
     if (!(tm | te)) return;
@@ -2394,7 +2410,8 @@ struct NodeCtxT {
     // write-back)
     uint32_t nq = 0, ne = 0;
     for (uint32_t j = 0; j < qlen; j++) if ((live_m >> j) & 1u) {
-      if constexpr (LQ) { if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j; }
+      if constexpr (SPLIT) { if (nq != j) mq_set(nq, mq_get(j)); else if ((tm >> j) & 1u) qdirty |= 1u << j; }
+      else if constexpr (LQ) { if (nq != j) { SQ(nq) = SQ(j); qdirty |= 1u << nq; } else if ((tm >> j) & 1u) qdirty |= 1u << j; }
       else if (nq != j) QENT(nq, l) = QENT(j, l);
       nq++;
     }
@@ -2542,6 +2559,7 @@ struct NodeCtxT {
   }
 };
 #undef SQ
+#undef SQ2
 typedef NodeCtxT<false, true> NodeCtx;       // the stimulus kernels edit the queue in HBM
 
 // canonical order key of an inbox record: (user?, subject, type) then (incarnation, from)
@@ -2788,25 +2806,23 @@ template <bool MASS, bool SERF, bool DYN>
 __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_per_eu(SW_RESOLVE_WAVES, 8))) k_resolve(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   uint4* const lds_q = g_lds_dyn;                // [Q][threads] the lanes' memberlist queues, then [EQ][threads] words: meta words of their event queues
-  // -DSW_MASS_HBMQ (A/B option for round 5, off by default; bit-identical on the emulator, unmeasured): a handle with the dense pair store
-  // (config #4: queue_cap 32 = 128 KB of staged queues, ONE workgroup per CU) edits the memberlist queue where it lives instead —
-  // slot-major in HBM, a wave reads or writes 1 KB per slot — and keeps 37 KB of LDS: four workgroups per CU
-#if defined(SW_MASS_HBMQ) && defined(SW_NODE_LINE)
-#error "SW_MASS_HBMQ walks D.q directly: not with the one-line node record"
-#endif
-#ifdef SW_MASS_HBMQ
-  constexpr bool RESOLVE_LQ = !MASS;
-#else
   constexpr bool RESOLVE_LQ = true;
-#endif
-  const size_t lds_q_slots = RESOLVE_LQ ? (size_t)D.Q : 0;     // queue slots staged in front of the event queues' meta words
+  // the event queues' meta words sit behind the staged memberlist queue: [Q][threads] entries of 16 bytes — of 8 on a handle with the dense
+  // pair store, which stages {subject, meta} only (NodeCtxT::SPLIT)
+  uint32_t* const lds_emeta = (MASS && SW_SPLITQ) ? (uint32_t*)((uint2*)lds_q + (size_t)D.Q * SW_RES_THREADS) : (uint32_t*)(lds_q + (size_t)D.Q * SW_RES_THREADS);
   __shared__ uint32_t lds_stats[ST_COUNT];
-  constexpr uint32_t RT = SW_RES_THREADS, SUBS = SW_RES_SUBS, WPB = SW_RES_WAVES;
-  static_assert(SW_RTILE * SW_BLOCK <= 1024 && SW_RTILE * SW_BLOCK % SW_RES_THREADS == 0 && SW_RES_THREADS % 64 == 0, "k_resolve's tile");
-  __shared__ uint32_t s_carry[SW_RTILE], s_dl[SW_RTILE], s_wcnt[SUBS * WPB > 16 ? SUBS * WPB : 16];
-  __shared__ uint32_t s_list[SW_RTILE * SW_BLOCK];   // the tile's receivers: count << 10 | offset in the tile
+  // The tile: one node block (256 nodes) — but 64 nodes on a handle with the dense pair store: a mass event makes EVERY node a receiver of
+  // dozens of messages, config #4's share of one GPU is 1 024-2 048 node blocks, and one wave per block left three quarters of the
+  // device's wave slots empty while every wave walked its block's list in four passes (round 5, late).  Four tiles then share a node
+  // block's carry area (reserved with a global atomic instead of the LDS counter) and its deadline bound; in_any is kept per 64 nodes.
+  constexpr uint32_t RT = SW_RES_THREADS, TILE = MASS ? SW_RES_MASS_TILE : SW_RTILE * SW_BLOCK, SUBS = TILE / RT, WPB = SW_RES_WAVES;
+  static_assert(SW_RES_THREADS == 64 && SW_RTILE == 1 && TILE % RT == 0 && TILE <= SW_BLOCK && SW_BLOCK % TILE == 0, "k_resolve's tile");
+  __shared__ uint32_t s_carry[1], s_dl[1], s_wcnt[SUBS * WPB > 16 ? SUBS * WPB : 16];
+  __shared__ uint32_t s_list[TILE];              // the tile's receivers: count << 10 | offset in the tile
   __shared__ uint4 s_in[4][RT];                  // the lanes' 64-byte inbox lines (LDS, not registers: occupancy)
-  const uint32_t nb0 = (D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + blockIdx.x] : blockIdx.x) * SW_RTILE;   // heavy tiles first
+  const uint32_t tl = D.rs_order ? D.rs_order[(size_t)(*D.tick % D.P) * D.rs_T + blockIdx.x] : blockIdx.x;   // heavy tiles first
+  const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)tl * TILE;
+  const uint32_t nb0 = (uint32_t)(l0 / SW_BLOCK);                 // the node block the tile lies in
 #ifdef SWIMSIM_WAVECLK
   unsigned long long wclk[4]; WCLK(0);
 #endif
@@ -2816,20 +2832,19 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
   if (D.fast_blocks) {                     // nothing reached this tile: a few words and out
     uint32_t any = 0;
 #pragma unroll
-    for (uint32_t sb = 0; sb < SW_RTILE; sb++) any |= nb0 + sb < D.NB ? D.in_any[nb0 + sb] : 0u;
+    for (uint32_t sb = 0; sb < SUBS; sb++) any |= l0 + sb * RT < NL ? D.in_any[l0 / 64 + sb] : 0u;
     if (!any) return;
   }
-  if (threadIdx.x < SW_RTILE) { s_carry[threadIdx.x] = 0; s_dl[threadIdx.x] = NONE; }
+  if (threadIdx.x == 0) { s_carry[0] = 0; s_dl[0] = NONE; }
   if (threadIdx.x < SW_CEN_LDS * 5) g_s_cen[threadIdx.x] = 0;
-  if (threadIdx.x == 0) g_s_cen_r = div_nloc(D, (size_t)nb0 * SW_BLOCK);
+  if (threadIdx.x == 0) g_s_cen_r = div_nloc(D, l0 < NL ? l0 : NL - 1);
   BlockStats S; S.init(lds_stats);
-  const size_t NL = (size_t)D.R * D.nloc, l0 = (size_t)nb0 * SW_BLOCK;
   // ---- the tile's receivers, compacted in ascending node order
   uint32_t cnts[SUBS];                             // (sub-pass sb covers the RT nodes from offset sb * RT of the tile)
 #pragma unroll
   for (uint32_t sb = 0; sb < SUBS; sb++) {
     const size_t l = l0 + sb * RT + threadIdx.x;
-    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[nb0 + (sb * RT) / SW_BLOCK])) ? D.in_cnt[l] : 0u;
+    cnts[sb] = (l < NL && (!D.fast_blocks || D.in_any[l0 / 64 + sb])) ? D.in_cnt[l] : 0u;
     const uint64_t m = __ballot(cnts[sb] != 0);
     if (sw_lane() == 0) s_wcnt[sb * WPB + threadIdx.x / 64] = (uint32_t)__popcll(m);
   }
@@ -2845,7 +2860,7 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
       s_list[base + (uint32_t)__popcll(m & ((1ull << sw_lane()) - 1))] = (c << 10) | (sb * RT + threadIdx.x);
     }
   }
-  if (D.fast_blocks && threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) D.in_any[nb0 + threadIdx.x] = 0;
+  if (D.fast_blocks && threadIdx.x < SUBS && l0 + threadIdx.x * RT < NL) D.in_any[l0 / 64 + threadIdx.x] = 0;      // (this workgroup's own 64-node groups: nobody else reads them)
   // Mass events: inboxes of very different sizes in one wave leave its lanes idle while the longest one is merged (config #4's mass phase,
   // profiles/r03_config4_resolve_phase_clock.txt: the busiest lane of a wave held 153 messages where the mean was 22 — every wave busy
   // for 8 ms of an 11.8 ms tick).  So when the tile holds an inbox of SW_ORDER_MIN messages or more the list is reordered by size class
@@ -2877,7 +2892,7 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
   WCLK(1);
   for (uint32_t a0 = 0; a0 < n_act; a0 += RT) {
     if (a0 + threadIdx.x >= n_act) continue;
-    const uint32_t ent = s_list[a0 + threadIdx.x], sb = (ent & 1023u) / SW_BLOCK;      // (sb: the node block within the tile)
+    const uint32_t ent = s_list[a0 + threadIdx.x];
     uint32_t cnt = ent >> 10;
     const size_t l = l0 + (ent & 1023u);
     // the whole 64-byte line (first five messages) in one go, parked in the lane's LDS column
@@ -2933,9 +2948,9 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
       if (!have) break;
       uint32_t type = best.w >> 30, from = best.w & 0x3FFFFFFFu;
       if (best.y == SWIM_SUBJECT_PIGGY)
-        n.piggyback(best.z, type, &s_carry[sb], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0 + sb) * D.carry_cap, (uint32_t*)(lds_q + lds_q_slots * RT));
+        n.piggyback(best.z, type, MASS ? (uint32_t*)&D.carry_cl[nb0] : &s_carry[0], D.carry + ((size_t)((n.t + 1) & 1u) * D.NB + nb0) * D.carry_cap, lds_emeta);   // (MASS: four tiles share the block's area)
       else if (best.y == SWIM_SUBJECT_PULL && type == SWIM_MSG_ALIVE) {     // push-pull request: answer next tick
-        uint32_t li = (n.t + 1) & 1u, sub = (nb0 + sb) % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
+        uint32_t li = (n.t + 1) & 1u, sub = nb0 % SW_PP_LISTS, sub_cap = D.pp_cap / SW_PP_LISTS;
         uint32_t pos = atomicAdd(&D.pp_cnt[(li * SW_PP_LISTS + sub) * 16], 1u);
         if (pos < sub_cap) D.pp_list[((size_t)li * SW_PP_LISTS + sub) * sub_cap + pos] = make_uint2((uint32_t)l, best.z | ((from & 1u) << 31));   // (bit 31: a join's request)
         else atomicOr(D.err, SW_ERR_PEND_OVF);
@@ -2961,7 +2976,7 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
     n.store();
     // suspicion timers armed here: the block's deadline bound is lowered once per workgroup (every lane of a cluster arms
     // one within a few ticks of a failure)
-    if (n.dl_new != NONE) atomicMin(&s_dl[sb], n.dl_new);
+    if (n.dl_new != NONE) atomicMin(&s_dl[0], n.dl_new);
     c_pig += n.c_pig; c_sent01 += n.c_sent01; c_sent23 += n.c_sent23;
     q_bit_lane(D, l, n.q_became_set(), n.q_became_clr());
     RCLK_MARK(4);                                  // write-back
@@ -2982,11 +2997,9 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
   S.flush(D);                                      // (barrier inside: every lane's carry reservations, deadlines and census deltas are in)
   if (threadIdx.x < SW_CEN_LDS * 5 && g_s_cen[threadIdx.x] && threadIdx.x / 5 < D.S)
     atomicAdd(&D.cen_dl[((size_t)g_s_cen_r * D.S + threadIdx.x / 5) * 8 + threadIdx.x % 5], (uint32_t)g_s_cen[threadIdx.x]);
-  if (threadIdx.x < SW_RTILE && nb0 + threadIdx.x < D.NB) {
-    const uint32_t sb = threadIdx.x;
-    if (s_carry[sb]) { D.carry_cl[nb0 + sb].x = s_carry[sb]; *D.carry_stamp = t_now + 1; }
-    if (s_dl[sb] != NONE) atomicMin(&D.dl_blk[nb0 + sb], s_dl[sb]);       // (no look first: a load the workgroup would have to wait for on its way out)
-  }
+  if (MASS) { if (__any(c_pig != 0) && threadIdx.x == 0) *D.carry_stamp = t_now + 1; }        // (the block's count word was the reservation counter itself)
+  else if (threadIdx.x == 0 && s_carry[0]) { D.carry_cl[nb0].x = s_carry[0]; *D.carry_stamp = t_now + 1; }
+  if (threadIdx.x == 0 && s_dl[0] != NONE) atomicMin(&D.dl_blk[nb0], s_dl[0]);       // (no look first: a load the workgroup would have to wait for on its way out)
 #ifdef SWIMSIM_WAVECLK
   WCLK(3);
   if (sw_lane() == 0) {
@@ -3275,7 +3288,7 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
     size_t rem = NL - l;
     uint32_t in_blk = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK, started = 0;       // lanes of this block that run at t = 0
     for (uint32_t j = 0; j < in_blk; j++) started += D.i0 + (uint32_t)((l + j) % D.nloc) < n_initial;
-    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = started;
+    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / 64] = 0; D.alive_cnt[l / SW_BLOCK] = started;
     D.dl_blk[l / SW_BLOCK] = NONE;
   }
   if (l < D.R) { D.acting[l] = n_initial; D.base_known[l] = n_initial; }
