@@ -153,3 +153,34 @@ def test_merge_state_on_the_checker(oracle):
 @pytest.mark.gpu
 def test_merge_state_on_hip(hip):
     merge_state(hip)
+
+
+def queue_prune_and_invalidation(lib):
+    """TransmitLimitedQueue as upstream's queue_test.go pins it (recalled: TestTransmitLimited_Prune, TestTransmitLimited_QueueBroadcast), on the
+    queue of ONE node: with room for two broadcasts, four queued one after the other leave the two NEWEST ("Prune(2)": 'test' and 'foo' go,
+    'bar' and 'baz' stay); a broadcast about a node invalidates the older one about the same node and joins the queue at its end; what is
+    picked for a packet is what has been transmitted least, newest first.  The messages arrive in one packet through the transport bridge and
+    are applied in subject order, so the "newest" of a packet is the highest subject."""
+    s = Sim(lib, preset(lib, abi.PRESET_LAN, n_nodes=N, seed=2, probe_interval_ms=100000, probe_timeout_ms=500, push_pull_interval_ms=0, view_cap=N, queue_cap=2))
+    mask = np.zeros(N, dtype=np.uint8); mask[OBS] = 1
+    s.partition(0, mask)                                       # (nothing but the injected packets reaches the observer, nothing it gossips arrives anywhere)
+    queue = lambda: [(q.subject, q.incarnation, q.type) for q in list(s.node_info(0, OBS).queue)[:s.node_info(0, OBS).queue_len]]
+    s.transport_write_to(0, REAL, OBS, [(x, 6, abi.MSG_ALIVE, 0) for x in (5, 6, 7, 8)]); s.step(1)
+    assert queue() == [(7, 6, abi.MSG_ALIVE), (8, 6, abi.MSG_ALIVE)] and s.stats()["queue_drops"] == 2
+    s.close()
+    s = Sim(lib, preset(lib, abi.PRESET_LAN, n_nodes=N, seed=2, probe_interval_ms=100000, probe_timeout_ms=500, push_pull_interval_ms=0, view_cap=N, queue_cap=4))
+    s.partition(0, mask)
+    s.transport_write_to(0, REAL, OBS, [(5, 6, abi.MSG_ALIVE, 0), (6, 6, abi.MSG_ALIVE, 0)]); s.step(1)
+    assert queue() == [(5, 6, abi.MSG_ALIVE), (6, 6, abi.MSG_ALIVE)]
+    s.transport_write_to(0, REAL, OBS, [(5, 6, abi.MSG_SUSPECT, ACCUSER)]); s.step(1)       # about node 5 again: the alive about it is invalidated
+    assert queue() == [(6, 6, abi.MSG_ALIVE), (5, 6, abi.MSG_SUSPECT)] and s.stats()["queue_drops"] == 0
+    s.close()
+
+
+def test_queue_prune_and_invalidation_on_the_checker(oracle):
+    queue_prune_and_invalidation(oracle)
+
+
+@pytest.mark.gpu
+def test_queue_prune_and_invalidation_on_hip(hip):
+    queue_prune_and_invalidation(hip)
