@@ -815,6 +815,10 @@ def main():
                                    if handles > 1 else "1 GPU")},
         # what the TIMED window happened to see (it may end before any suspicion runs out): see `detection`
         "timed_window_detection_ms_after_failure": detect_after_kill,
+        "parity_vs_reference": "partial (oracle unpinned): the HIP library is bit-identical to oracle/swim_oracle.c — state digests, counters, per-tick edge lists, on every "
+                  "scenario of tests/ — and that checker restates memberlist v0.6.0 / serf v0.10.4 from recall: neither module is vendored in the reference "
+                  "and no Go toolchain is here; from outside it is pinned only by Philox vectors, the two scaling formulas of agent/config/runtime.go, librtt's "
+                  "distance table and libserf's leave-propagation claim.  The +-1 round against real memberlist is a distributional claim that could not be measured",
     }
 
     if world > 1:
