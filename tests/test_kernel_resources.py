@@ -1,5 +1,5 @@
 """Register, scratch and occupancy budget of the tick kernels, from the compiler's own report (hipcc cross-compiles gfx950
-without a GPU).  What the design rests on — k_begin at five waves per SIMD, k_resolve at four without a spilled context, the
+without a GPU).  What the design rests on — k_begin at five waves per SIMD, k_resolve (one wave per node block since round 5) at four without a spilled context, the
 others light — is easy to lose with one more statement in a handler (a context that fell out of registers made
 k_resolve twice as slow); this test says so on the CPU box, before anything is measured."""
 import os
@@ -26,6 +26,9 @@ BUDGET = {
     "9k_resolveILb1ELb1ELb1EE": (128, 144, 4), # ... all three (config #5's leg with joins)
     "8k_censusPK": (32, 0, 8),
     "8k_finishPK": (64, 0, 8),
+    "15k_census_finishPK": (48, 0, 8),       # round 5: the recount and the tick's epilogue in one launch
+    "17k_inbox_sort_hugePK": (48, 0, 8),     # inboxes beyond what LDS sorts (config #4's recovery)
+    "16k_reconnect_scanPK": (32, 0, 8),      # serf reconnect over the dense store: a wave per (due node, chunk of rows)
     "7k_quietPK": (40, 0, 8),
     "14k_coord_updatePK": (128, 0, 4),
     "13k_expire_massPK": (64, 0, 8),
