@@ -31,6 +31,7 @@ static inline uint32_t resolve_tile(const SwDev& D) { return D.M ? SW_RES_MASS_T
 enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
 static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" }   /* (k_finish: k_census_finish since round 5 — the recount and the epilogue in one launch; k_census then has no launches of its own) */;
 #define SW_GRAPH_TICKS 16
+#define SW_GRAPH_TICKS_MID 4      /* a middle tier (round 5): what is left of a call after the 16-tick graphs goes out four ticks at a time, not one */
 
 #ifdef SW_NODE_LINE
 #define SW_HDR_STRIDE 4
@@ -71,8 +72,8 @@ struct swim_sim {
   std::vector<uint64_t> attached;                      // (replica << 32 | node) driven through the transport bridge
   struct Captured { uint32_t gdst; swim_edge rec; };   // rec.dst = sender
   std::vector<Captured> captured;
-  // captured tick sequence: [0] one tick, [1] SW_GRAPH_TICKS ticks
-  hipGraphExec_t graph_exec[2] = { nullptr, nullptr };
+  // captured tick sequence: [0] one tick, [1] SW_GRAPH_TICKS ticks, [2] SW_GRAPH_TICKS_MID ticks
+  hipGraphExec_t graph_exec[3] = { nullptr, nullptr, nullptr };
   bool use_graphs = true;
   // optional per-launch HIP-event timing
   bool profiling = false;
@@ -265,7 +266,7 @@ uint64_t process_nonce() {
 }
 }
 static void drop_graphs(swim_sim* s) {
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (s->graph_exec[i]) { (void)hipGraphExecDestroy(s->graph_exec[i]); s->graph_exec[i] = nullptr; }
   if (s->graph_end_begin) { (void)hipGraphExecDestroy(s->graph_end_begin); s->graph_end_begin = nullptr; }
   if (s->graph_xchg) { (void)hipGraphExecDestroy(s->graph_xchg); s->graph_xchg = nullptr; }
@@ -1068,6 +1069,7 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
   if (use_graph && !s->graph_exec[0]) {
     int rc = build_graph(s, 0, 1);
     if (!rc) rc = build_graph(s, 1, SW_GRAPH_TICKS);
+    if (!rc) rc = build_graph(s, 2, SW_GRAPH_TICKS_MID);
     if (rc) return rc;
   }
   uint32_t i = 0;
@@ -1086,6 +1088,7 @@ extern "C" int swim_step(swim_sim* s, uint32_t n) {
     const uint32_t to_special = ticks_to_special(s);
     if (to_special == 0) { launch_begin(s, s->tick); launch_end(s, s->tick); }
     else if (use_graph && n - i >= SW_GRAPH_TICKS && to_special >= SW_GRAPH_TICKS) { HIPCK(s, hipGraphLaunch(s->graph_exec[1], s->stream)); adv = SW_GRAPH_TICKS; }
+    else if (use_graph && n - i >= SW_GRAPH_TICKS_MID && to_special >= SW_GRAPH_TICKS_MID) { HIPCK(s, hipGraphLaunch(s->graph_exec[2], s->stream)); adv = SW_GRAPH_TICKS_MID; }
     else if (use_graph) HIPCK(s, hipGraphLaunch(s->graph_exec[0], s->stream));
     else { launch_begin(s, SW_PLAIN_TICK); launch_end(s, SW_PLAIN_TICK); }
     advance(s, adv);
