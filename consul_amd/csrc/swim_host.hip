@@ -467,7 +467,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
   D.M = cfg->mass_rows; D.nbl = cdiv(D.nloc, SW_BLOCK);
   if (D.M) {   // the dense pair store (swim_device.h): 12 bytes per (row, observer)
-    const size_t RM = (size_t)D.R * D.M, pairs = RM * D.nloc;
+    const size_t RM = (size_t)D.R * D.M, pairs = RM * cdiv(D.nloc, 64) * 64;      // (m_idx: [replica][64 observers][row][64])
     if (RM >= 0x7FFFFFFFull) { swim_destroy(s); return SWIM_ERANGE; }
     DALLOC(s, D.mrow, NT); DALLOC(s, D.mrow_subj, RM); DALLOC(s, D.m_free, RM); DALLOC(s, D.m_nfree, D.R);
     DALLOC(s, D.mA, pairs); DALLOC(s, D.mB, pairs); DALLOC(s, D.mC, pairs);
@@ -1595,6 +1595,7 @@ extern "C" int swim_debug_edges(swim_sim* s, swim_edge* out, size_t cap, size_t*
 // Every device array was allocated through dalloc() in an order that depends on the configuration alone, so the state of a
 // population is the contents of those arrays in that order plus a handful of host words.  The descriptor, the pointer
 // tables and the scratch/staging buffers are this handle's own and are left alone.
+#define SW_STATE_LAYOUT 5      /* how the device arrays are laid out (round 5: the dense pair store by groups of 64 observers, in_any per 64 nodes): a checkpoint of another layout is refused */
 struct CkHeader {
   char magic[8], backend[16];
   uint32_t abi, tick, loss_q32, peer_act, n_arrays, n_events; uint8_t pristine, pad[3];
@@ -1617,6 +1618,7 @@ extern "C" int swim_checkpoint_save(swim_sim* s, const char* path) {
   if (!f) { snprintf(s->err, sizeof s->err, "cannot write %s", path); return SWIM_EIO; }
   CkHeader h; memset(&h, 0, sizeof h);
   memcpy(h.magic, "SWIMCKPT", 8); strncpy(h.backend, swim_backend(), sizeof h.backend - 1);
+  h.pad[0] = SW_STATE_LAYOUT;
   h.abi = SWIM_ABI_VERSION; h.tick = s->tick; h.loss_q32 = s->D.loss_q32; h.peer_act = s->peer_act_host; h.pristine = s->pristine;
   h.ticks_run = s->ticks_run; h.rounds_run = s->rounds_run; h.cfg = s->cfg; h.n_events = (uint32_t)s->pending_events.size();
   for (size_t i = 0; i < s->allocs.size(); i++) h.n_arrays += ck_is_state(s, i);
@@ -1648,7 +1650,7 @@ extern "C" int swim_checkpoint_load(swim_sim* s, const char* path) {
   CkHeader h;
   uint32_t n_arrays = 0;
   for (size_t i = 0; i < s->allocs.size(); i++) n_arrays += ck_is_state(s, i);
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SWIMCKPT", 8) || strncmp(h.backend, swim_backend(), sizeof h.backend) || h.abi != SWIM_ABI_VERSION ||
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "SWIMCKPT", 8) || strncmp(h.backend, swim_backend(), sizeof h.backend) || h.abi != SWIM_ABI_VERSION || h.pad[0] != SW_STATE_LAYOUT ||
       memcmp(&h.cfg, &s->cfg, sizeof h.cfg) || h.n_arrays != n_arrays) {
     fclose(f); snprintf(s->err, sizeof s->err, "checkpoint of another library, ABI or configuration"); return SWIM_EINVAL;
   }

@@ -104,7 +104,18 @@ __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint
   return vt_probe(D, l, x, D.vt[(size_t)vt_home(D, x) * ((size_t)D.R * D.nloc) + l], e, free_slot);
 }
 // ---- the dense pair store (swim_device.h): pair (row of the subject, observer) --------------------------------------------
-__device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) { return ((size_t)r * D.M + row) * D.nloc + k; }
+// Layout (round 5): [replica][group of 64 observers][row][64] — the pairs of 64 neighbouring observers with ALL rows are one contiguous region
+// (M x 256 bytes per plane: 3-7 MB at config #4's sizes).  k_resolve<MASS>'s wave is such a group, and its lanes look at 64 DIFFERENT rows at a
+// time: with rows outermost ([row][observer], rounds 3-4) those were 64 addresses a megabyte apart — 64 pages, 64 TLB misses per load, ~6 us a
+// round trip and 30 us per message iteration (profiles/r05_config4_mass_phase_clock.txt).  A row's 256-observer tile is four 256-byte runs now
+// (k_expire_mass, fold and census scans: a wave still reads one run), an observer's column 256-byte steps instead of megabyte steps.
+__device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
+#ifdef SW_MASS_ROWMAJOR
+  return ((size_t)r * D.M + row) * D.nloc + k;
+#else
+  return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.M + row) << 6) + (k & 63u);
+#endif
+}
 // a pair as a view-table entry {subject, inc<<2|state, state-change ms, w} (w as in vt) + the second accuser
 __device__ __forceinline__ uint4 m_unpack(DevRef D, uint32_t x, uint32_t a, uint32_t b, uint32_t c, uint32_t& conf1) {
   conf1 = M_CONF1(c);
