@@ -210,6 +210,12 @@ class Sim:
         self._ck("swim_force_leave", self._l.swim_force_leave(self._h, replica, origin, node, int(prune), C.byref(lt)))
         return lt.value
 
+    def event_queued(self, replica: int, node: int, event_id: int, ltime: int) -> bool:
+        """serf's notifyCh of a broadcast, as a question: is {event_id, ltime} still in `node`'s serf queue?"""
+        q = C.c_int()
+        self._ck("swim_event_queued", self._l.swim_event_queued(self._h, replica, node, event_id, ltime, C.byref(q)))
+        return bool(q.value)
+
     def partition(self, replica: int, group_of_node: Sequence[int]):
         g = np.ascontiguousarray(group_of_node, dtype=np.uint8)
         if g.size != self.cfg.n_nodes:

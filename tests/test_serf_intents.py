@@ -136,3 +136,32 @@ def script_joins(s):
 def test_joins_with_intents_on_the_checker(oracle):
     o = script_joins(Sim(oracle, preset(oracle, abi.PRESET_LAN, **JOIN_KW)))
     assert o[2][1] == abi.MEMBER_LEFT and o[3][1] == abi.MEMBER_ALIVE and o[3][2] == abi.MEMBER_ALIVE and o[5][3] == abi.MEMBER_ALIVE
+
+
+def event_queued_tracks_one_broadcast(lib):
+    """swim_event_queued (round 5): serf.Leave() waits on the notify channel of ITS intent — under steady user-event traffic the
+    queue never empties, the intent still retires once it has used up its transmissions."""
+    s = Sim(lib, preset(lib, abi.PRESET_LAN, n_nodes=64, seed=4, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, event_queue_cap=16))
+    s.step_ms(1000)
+    lt = s.force_leave(0, 9, 9)                                  # node 9's own leave intent (serf.Leave step 1)
+    intent = abi.INTENT_LEAVE | 9
+    assert s.event_queued(0, 9, intent, lt) and not s.event_queued(0, 9, intent, lt + 1) and not s.event_queued(0, 10, intent, lt)
+    retired_at, quiet_queue_seen = None, False
+    for tick in range(1, 120):
+        s.user_event(0, 9, 1000 + tick)                           # steady traffic from the same node: its queue never runs empty
+        s.step(1)
+        if not s.event_queued(0, 9, intent, lt):
+            retired_at = tick
+            break
+        quiet_queue_seen |= s.node_info(0, 9).event_queue_len == 0
+    assert retired_at is not None and not quiet_queue_seen and s.node_info(0, 9).event_queue_len > 0
+    s.close()
+
+
+def test_event_queued_tracks_one_broadcast_on_the_checker(oracle):
+    event_queued_tracks_one_broadcast(oracle)
+
+
+@pytest.mark.gpu
+def test_event_queued_tracks_one_broadcast_on_hip(hip):
+    event_queued_tracks_one_broadcast(hip)
