@@ -2131,18 +2131,24 @@ struct NodeCtxT {
                              uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, int drop_stat) {
     uint4* const eb = D.evq + l;
     uint32_t n = len;
-    if (named) {                                   // at most one entry per subject: no early exit, so that the loads overlap
-      uint32_t hit = NONE;
-      for (uint32_t j = 0; j < n; j++) hit = (EV ? eb[(size_t)j * NL].x : mq_x(j)) == subject ? j : hit;
-      if (hit != NONE) {
-        if (hit != n - 1) { if (EV) eb[(size_t)hit * NL] = eb[(size_t)(n - 1) * NL]; else mq_set(hit, mq_get(n - 1)); }
-        n--;
-      }
+    const uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq));
+    // ONE pass over the queue (round 5; two until then: the invalidation's, then Prune()'s): the entry about the same subject, and — only looked
+    // at when there is none and the queue is full — the entry that sorts last among the queue and the newcomer.  (A hit makes room, so the
+    // two never meet; no early exit, so that the loads overlap.)  Same comparisons in the same order as the two loops made.
+    const bool full = n == cap;
+    uint32_t hit = NONE, w = NONE, wmeta = e.w;
+    for (uint32_t j = 0; j < n; j++) {
+      uint32_t xj, mj;
+      if constexpr (EV) { const uint4 q = eb[(size_t)j * NL]; xj = q.x; mj = q.w; }
+      else if constexpr (SPLIT) { const uint2 q = SQ2(j); xj = q.x; mj = q.y; }
+      else { xj = mq_x(j); mj = mq_w(j); }
+      if (named && xj == subject) hit = j;
+      if (full && ent_before(D, wmeta, mj)) { wmeta = mj; w = j; }
     }
-    uint4 e = make_uint4(subject, inc, from, m_pack(type, 0, seq));
-    if (n == cap) {
-      uint32_t w = NONE, wmeta = e.w;
-      for (uint32_t j = 0; j < n; j++) { uint32_t mj = EV ? eb[(size_t)j * NL].w : mq_w(j); if (ent_before(D, wmeta, mj)) { wmeta = mj; w = j; } }
+    if (hit != NONE) {                             // at most one entry per subject: the older one goes, the new one joins at the end
+      if (hit != n - 1) { if (EV) eb[(size_t)hit * NL] = eb[(size_t)(n - 1) * NL]; else mq_set(hit, mq_get(n - 1)); }
+      if (EV) eb[(size_t)(n - 1) * NL] = e; else mq_set(n - 1, e);
+    } else if (full) {                             // Prune(): the last in order leaves — the newcomer itself if that is where it sorts
       S.add(drop_stat);
       if (w != NONE) { if (EV) eb[(size_t)w * NL] = e; else mq_set(w, e); }
     } else { if (EV) eb[(size_t)n * NL] = e; else mq_set(n, e); n++; }
