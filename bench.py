@@ -375,7 +375,8 @@ def run_config4(hip, args, device) -> dict:
                                                                      "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}},
                                     "queue_cap_sweep_on_the_checker": {"measured_at": "8192 nodes / 409 stopped (profiles/r05_queue_cap_sweep.txt)",
                                                                        "simulated_s_to_full_detection": {"8": 396, "16": 361, "32": 336, "64": 266, "128": 306, "256": 51, "4096": 31},
-                                                                       "queue_drops_per_applied_message": {"32": 1.68, "256": 0.50, "4096": 0.0}}},
+                                                                       "queue_drops_per_applied_message": {"32": 1.68, "256": 0.50, "4096": 0.0},
+                                                                       "and_at_16384_nodes_819_stopped": {"32": 406, "128": 406, "512": 56, "2048": 46, "4096": 46}}},
            "curve": curve[:12] + curve[12::4]}
     s.close()
     return out
