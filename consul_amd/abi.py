@@ -23,7 +23,7 @@ MEMBER_NONE, MEMBER_ALIVE, MEMBER_LEAVING, MEMBER_LEFT, MEMBER_FAILED = 0, 1, 2,
  EVENT_MEMBER_REAP, EVENT_USER, EVENT_QUERY) = range(7)
 PRESET_LAN, PRESET_WAN, PRESET_LOCAL = 0, 1, 2
 INFO_TILE_BUCKETS, INFO_MAILBOX_KIND, INFO_DEVICE_BYTES = 0, 1, 2      # swim_info keys
-F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK, F_COORDINATES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
+F_BUDDY_SUSPECT, F_NACK, F_SERF_EVENTS, F_FILTER_NOOP, F_PIGGYBACK, F_TCP_FALLBACK, F_COORDINATES, F_UNBOUNDED_QUEUE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80
 F_DEFAULT = F_BUDDY_SUSPECT | F_NACK | F_FILTER_NOOP | F_PIGGYBACK | F_TCP_FALLBACK
 SUBJECT_PULL, SUBJECT_PIGGY = 0xFFFFFFFE, 0xFFFFFFFD
 INTENT_LEAVE, INTENT_PRUNE = 0x80000000, 0x40000000

@@ -92,6 +92,18 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
  * NotifyPingComplete -> coordinate.Client.Update).  Round-trip times come from the latency model below (rtt_*).
  * Unsharded handles only (an ack from another shard would have to carry the coordinate).  Not in SWIM_F_DEFAULT. */
 #define SWIM_F_COORDINATES    0x40u
+/* memberlist's TransmitLimitedQueue as it is upstream: UNBOUNDED (queue.go never drops a broadcast before its retransmit limit; Consul
+ * sizes only serf's event queue, internal/gossip/libserf/serf.go:24-27).  Without the flag a node's queue holds queue_cap entries with
+ * Prune() semantics (counted in queue_drops) — which decides BASELINE config #4's answer.  With it:
+ *   - the checker's queues grow on demand;
+ *   - the product library keeps the rumour about a subject that owns a row of the dense pair store (mass_rows; every subject named in a
+ *     stimulus call) IN THE PAIR: 8 more bytes per (row, observer) hold {queued, transmits, type, sequence number, accuser, incarnation},
+ *     QueueBroadcast is a store into the pair, its invalidation is implied (one rumour per subject and node), and GetBroadcasts selects
+ *     over the node's column by (transmits asc, length desc, sequence desc) exactly as queue.go orders its btree.  A node's rumour about
+ *     ITSELF and rumours about subjects without a row stay in the queue_cap slots (Prune() there is still counted, never silent);
+ *   - both: a subject is not folded into the base row while a node of the shard still holds a queued rumour about it.
+ * Needs mass_rows > 0 and an unsharded handle on the product library.  Not in SWIM_F_DEFAULT. */
+#define SWIM_F_UNBOUNDED_QUEUE 0x80u
 #define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK | SWIM_F_TCP_FALLBACK)
 
 /* ---- configuration ---------------------------------------------------------------------- */

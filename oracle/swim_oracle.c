@@ -267,7 +267,7 @@ typedef struct {
   uint8_t awareness, leaving;
   uint8_t serf_leaving;                        /* this agent has broadcast its own leave intent (serf.Leave: state SerfLeaving) — it no longer refutes one */
   uint32_t self_slt;                           /* statusLTime of the agent's own member entry */
-  uint32_t qlen, qseq; qent* q;                 /* [queue_cap] in one slab for all nodes */
+  uint32_t qlen, qseq, qcap; qent* q;           /* [queue_cap] in one slab for all nodes; SWIM_F_UNBOUNDED_QUEUE: an array of its own that grows (qcap entries so far) */
   uint32_t pr_target, pr_inc, pr_t0, pr_deadline, pr_cursor, pr_epoch; uint8_t pr_stage, pr_nack_miss;
   /* serf */
   uint32_t ev_clock, evqlen, evqseq; qent* evq; evslot* ring;
@@ -314,7 +314,9 @@ struct swim_sim {
   uint32_t* join_list; uint32_t n_join_pending, join_cap;   /* {replica*N + node, via} of the nodes started since the last tick (every shard lists all of them) */
   uint32_t *f_cnt, *f_kmin, *f_kmax; uint8_t* f_bad; uint32_t* f_touched; uint32_t f_ntouched, f_cap;  /* fold accumulators [R*N] */
   node_t* nodes;                 /* [R*nloc] */
-  qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous */
+  qent *q_slab, *evq_slab;       /* the nodes' queues, contiguous (q_slab: NULL with SWIM_F_UNBOUNDED_QUEUE) */
+  int unbounded;                 /* SWIM_F_UNBOUNDED_QUEUE */
+  uint32_t* q_cnt;               /* [R*N] unbounded queues only: rumours about this subject queued at the shard's nodes (a subject is not folded while there is one) */
   swim_edge* inbox_slab;
   slot_t* slots; uint32_t* n_slots; /* [R*S], [R] */
   edgevec* out;                  /* [n_shards] */
@@ -511,64 +513,81 @@ static int ent_before(const swim_sim* s, const qent* a, const qent* b) {
   return a->seq > b->seq;
 }
 
+/* A queue is kept SORTED by that order (upstream keeps a btree): q[0] is what GetBroadcasts looks at first, q[n-1] what Prune() drops.
+ * Position of the first entry that does not sort before e. */
+static uint32_t queue_lower(const swim_sim* s, const qent* q, uint32_t n, const qent* e) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (ent_before(s, &q[mid], e)) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+/* a node's memberlist queue: its entries, how many, and — SWIM_F_UNBOUNDED_QUEUE — how many the array can hold before it grows */
+typedef struct { qent** q; uint32_t *len, *seq, *dyn_cap; uint32_t cap; uint32_t* subj_queued; } qref;
+
 /* QueueBroadcast: a memberlistBroadcast named by its node invalidates any queued rumour about
  * the same node (broadcast.go Invalidates); serf user events are UniqueBroadcasts.  The real
- * queue is unbounded; ours holds `cap` entries and, like Prune(), evicts the tail of the order. */
-static void queue_push(swim_sim* s, qent* q, uint32_t* qlen, uint32_t* qseq, uint32_t cap, int named,
-                       uint32_t subject, uint8_t type, uint32_t inc, uint32_t from, uint64_t* drops) {
-  uint32_t n = *qlen;
+ * queue is unbounded (so is ours with SWIM_F_UNBOUNDED_QUEUE: qr.dyn_cap); otherwise it holds `cap` entries and, like Prune(), evicts
+ * the tail of the order.  subj_queued (fold rule, unbounded queues only): queued rumours per subject over the shard's nodes. */
+static void queue_push(swim_sim* s, qref qr, int named, uint32_t subject, uint8_t type, uint32_t inc, uint32_t from, uint64_t* drops) {
+  qent* q = *qr.q; uint32_t n = *qr.len;
   if (named)
     for (uint32_t i = 0; i < n; i++)
-      if (q[i].subject == subject) { q[i] = q[n - 1]; n--; break; }
-  qent e = { subject, inc, from, (*qseq)++ & 0x3FFFFFu, type, 0 };
-  if (n == cap) {
-    uint32_t w = SWIM_NONE; const qent* worst = &e;      /* the new entry takes part in the prune */
-    for (uint32_t i = 0; i < n; i++) if (ent_before(s, worst, &q[i])) { worst = &q[i]; w = i; }
+      if (q[i].subject == subject) { memmove(q + i, q + i + 1, (size_t)(n - i - 1) * sizeof(qent)); n--; if (qr.subj_queued) qr.subj_queued[subject]--; break; }
+  qent e = { subject, inc, from, (*qr.seq)++ & 0x3FFFFFu, type, 0 };
+  uint32_t pos = queue_lower(s, q, n, &e);
+  if (qr.dyn_cap) {
+    if (n == *qr.dyn_cap) { *qr.dyn_cap = n ? n * 2 : 8; q = *qr.q = (qent*)realloc(q, (size_t)*qr.dyn_cap * sizeof(qent)); if (!q) abort(); }
+  } else if (n == qr.cap) {
     (*drops)++;
-    if (w == SWIM_NONE) { *qlen = n; return; }
-    q[w] = e;
-  } else q[n++] = e;
-  *qlen = n;
+    if (pos == n) { *qr.len = n; return; }                /* the new entry takes part in the prune: it sorts last itself */
+    n--; if (qr.subj_queued) qr.subj_queued[q[n].subject]--;
+  }
+  memmove(q + pos + 1, q + pos, (size_t)(n - pos) * sizeof(qent));
+  q[pos] = e; *qr.len = n + 1;
+  if (qr.subj_queued) qr.subj_queued[subject]++;
 }
 
 /* GetBroadcasts(overhead, limit): walk tiers by transmit count, inside a tier largest first then
- * newest, take what fits, bump transmits after the sweep, retire at retransmitLimit.
- * (`taken` is a byte per entry: the checker's event queue may be as deep as serf's — EVQ_MAX — where the product library's holds 32) */
-static uint32_t queue_get(swim_sim* s, qent* q, uint32_t* qlen, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out, uint32_t retransmit_limit) {
-  uint32_t n = *qlen, cnt = 0; int32_t used = 0;
-  static _Thread_local uint8_t taken[EVQ_MAX];
-  memset(taken, 0, n);
-  for (;;) {
+ * newest, take what fits (the space left only shrinks: one walk down the order), bump transmits after the sweep, retire at
+ * retransmitLimit.  `out` receives the picks in the order they were picked. */
+static uint32_t queue_get(swim_sim* s, qref qr, uint32_t overhead, int32_t limit, qent* out, int32_t* used_out, uint32_t retransmit_limit) {
+  qent* q = *qr.q; uint32_t n = *qr.len, cnt = 0; int32_t used = 0;
+  static _Thread_local uint32_t taken[2048];               /* a pick costs at least `overhead` (>= 2) of at most 65 535 bytes... of a 1 400-byte packet */
+  for (uint32_t i = 0; i < n && cnt < 2048; i++) {
     int32_t free_b = limit - used - (int32_t)overhead;
     if (free_b <= 0) break;
-    uint32_t best = SWIM_NONE;
-    for (uint32_t i = 0; i < n; i++) {
-      if (taken[i]) continue;
-      if ((int32_t)ent_len(s, &q[i]) > free_b) continue;
-      if (best == SWIM_NONE || ent_before(s, &q[i], &q[best])) best = i;
-    }
-    if (best == SWIM_NONE) break;
-    taken[best] = 1; used += (int32_t)(overhead + ent_len(s, &q[best])); out[cnt++] = q[best];
+    if ((int32_t)ent_len(s, &q[i]) > free_b) continue;
+    taken[cnt] = i; used += (int32_t)(overhead + ent_len(s, &q[i])); out[cnt++] = q[i];
   }
-  uint32_t m = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    if (taken[i]) {
-      if ((uint32_t)q[i].transmits + 1 >= retransmit_limit) continue;   /* Finished() */
-      q[i].transmits++;
-    }
-    q[m++] = q[i];
+  *used_out = used;
+  if (!cnt) return 0;
+  /* take the picks out (stable), then put each back where its new transmit count sorts — unless it is Finished() */
+  uint32_t m = taken[0], t = 0;
+  for (uint32_t i = taken[0]; i < n; i++) { if (t < cnt && taken[t] == i) { t++; continue; } q[m++] = q[i]; }
+  for (uint32_t j = 0; j < cnt; j++) {
+    qent e = out[j];
+    if ((uint32_t)e.transmits + 1 >= retransmit_limit) { if (qr.subj_queued) qr.subj_queued[e.subject]--; continue; }
+    e.transmits++;
+    uint32_t pos = queue_lower(s, q, m, &e);
+    memmove(q + pos + 1, q + pos, (size_t)(m - pos) * sizeof(qent));
+    q[pos] = e; m++;
   }
-  *qlen = m; *used_out = used;
+  *qr.len = m;
   return cnt;
 }
 
 /* where a packet's picks are collected: queue_get takes at most *qlen entries, so both queues whole always fit (a stack array of
  * 2 * QMAX entries was only safe while the event queue was as shallow as the product library's: ADVICE r4) */
-static qent* pick_buf(void) { static _Thread_local qent buf[QMAX + EVQ_MAX]; return buf; }
+static qent* pick_buf(void) { static _Thread_local qent buf[2 * 2048]; return buf; }   /* queue_get takes at most 2 048 entries per queue */
 
+static inline qref mlq(swim_sim* s, uint32_t r, node_t* nd) {
+  qref q = { &nd->q, &nd->qlen, &nd->qseq, s->unbounded ? &nd->qcap : NULL, s->cfg.queue_cap, s->q_cnt ? s->q_cnt + (size_t)r * s->N : NULL };
+  return q;
+}
+static inline qref evq_of(swim_sim* s, node_t* nd) { qref q = { &nd->evq, &nd->evqlen, &nd->evqseq, NULL, s->cfg.event_queue_cap, NULL }; return q; }
 /* encodeAndBroadcast (broadcast.go) */
 static void broadcast(swim_sim* s, node_t* nd, uint32_t subject, uint8_t type, uint32_t inc, uint32_t from) {
-  queue_push(s, nd->q, &nd->qlen, &nd->qseq, s->cfg.queue_cap, 1, subject, type, inc, from, &s->st.queue_drops);
+  const uint32_t r = (uint32_t)((size_t)(nd - s->nodes) / s->nloc);
+  queue_push(s, mlq(s, r, nd), 1, subject, type, inc, from, &s->st.queue_drops);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -762,7 +781,7 @@ static void user_event_from(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uin
     s->st.user_events_delivered++;
     if (watching(s, r, o)) record_event(s, r, SWIM_EVENT_USER, id, ltime, 0);
   }
-  queue_push(s, nd->evq, &nd->evqlen, &nd->evqseq, s->cfg.event_queue_cap, 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
+  queue_push(s, evq_of(s, nd), 0, id, SWIM_MSG_USER, ltime, 0, &s->st.event_drops);
 }
 static void user_event(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t id, uint32_t ltime) { user_event_from(s, r, o, nd, id, ltime, 0); }
 
@@ -1273,9 +1292,9 @@ static void phase_gossip(swim_sim* s) {
       for (uint32_t p = 0; p < np; p++) {
         qent* const msgs = pick_buf(); int32_t used = 0, used2 = 0;     /* room for both queues whole, however deep serf's is */
         const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
-        uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, (int32_t)s->d.packet_budget, msgs, &used, rl);
+        uint32_t n = queue_get(s, mlq(s, r, nd), 2, (int32_t)s->d.packet_budget, msgs, &used, rl);
         int32_t avail = (int32_t)s->d.packet_budget - used;
-        if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2, rl);
+        if (nd->ring && avail > 2 + 1) n += queue_get(s, evq_of(s, nd), 3, avail, msgs + n, &used2, rl);
         if (!n) break;
         s->st.packets_sent++;
         for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
@@ -1360,6 +1379,7 @@ static void fold_census(swim_sim* s) {
          * EventMemberReap must not be lost); in the base row it reads as erased */
         if (s->d.reap_period_ticks && st >= SWIM_STATE_DEAD && unreaped) s->f_bad[g] = 1;
         if (i < t->slots && t->e[i].leaving) s->f_bad[g] = 1;     /* a Leaving mark is not something the base row can hold */
+        if (s->q_cnt && s->q_cnt[g]) s->f_bad[g] = 1;             /* SWIM_F_UNBOUNDED_QUEUE: some node of the shard still has a rumour about it queued */
         if (i < t->slots && t->e[i].slt && st < SWIM_STATE_DEAD) s->f_bad[g] = 1;   /* ... nor a live member's statusLTime (a stale leave intent must stay stale) */
       }
     }
@@ -1423,9 +1443,9 @@ static void piggyback(swim_sim* s, uint32_t r, uint32_t o, node_t* nd, uint32_t 
   qent* const msgs = pick_buf(); int32_t used = 0, used2 = 0;
   int32_t limit = (int32_t)s->d.packet_budget - (int32_t)s->cfg.ctl_len[kind & 3];
   const uint32_t rl = retransmit_limit_n(s, est_n(s, r, nd));
-  uint32_t n = queue_get(s, nd->q, &nd->qlen, 2, limit, msgs, &used, rl);
+  uint32_t n = queue_get(s, mlq(s, r, nd), 2, limit, msgs, &used, rl);
   int32_t avail = limit - used;
-  if (nd->ring && avail > 2 + 1) n += queue_get(s, nd->evq, &nd->evqlen, 3, avail, msgs + n, &used2, rl);
+  if (nd->ring && avail > 2 + 1) n += queue_get(s, evq_of(s, nd), 3, avail, msgs + n, &used2, rl);
   if (!n) return;
   s->st.piggybacks++; s->st.msgs_piggybacked += n;
   for (uint32_t m = 0; m < n; m++) s->st.msgs_sent[msgs[m].type]++;
@@ -1544,10 +1564,12 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
       s->base_known[r] = ni;
       for (uint32_t x = ni; x < s->N; x++) { s->gt_alive[(size_t)r * s->N + x] = 0; s->base_key[(size_t)r * s->N + x] = KEY(0, SWIM_STATE_DEAD); }   /* not started, never heard of */
     } }
-  s->q_slab = (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
+  s->unbounded = (cfg->flags & SWIM_F_UNBOUNDED_QUEUE) != 0;
+  s->q_slab = s->unbounded ? NULL : (qent*)calloc(NL * cfg->queue_cap, sizeof(qent));
+  s->q_cnt = s->unbounded ? (uint32_t*)calloc(NT, 4) : NULL;
   s->evq_slab = (cfg->flags & SWIM_F_SERF_EVENTS) ? (qent*)calloc(NL * cfg->event_queue_cap, sizeof(qent)) : NULL;
   s->inbox_slab = (swim_edge*)malloc(NL * cfg->inbox_cap * sizeof(swim_edge));
-  if (!s->q_slab || !s->inbox_slab || ((cfg->flags & SWIM_F_SERF_EVENTS) && !s->evq_slab)) { swim_destroy(s); return SWIM_ENOMEM; }
+  if ((!s->unbounded && !s->q_slab) || (s->unbounded && !s->q_cnt) || !s->inbox_slab || ((cfg->flags & SWIM_F_SERF_EVENTS) && !s->evq_slab)) { swim_destroy(s); return SWIM_ENOMEM; }
   if (cfg->flags & SWIM_F_COORDINATES) {
     s->cs = (coord_state*)calloc(NL, sizeof(coord_state)); s->c_new = (swim_coordinate*)malloc(NL * sizeof(swim_coordinate)); s->c_list = (uint32_t*)malloc(NL * sizeof(uint32_t));
     if (!s->cs || !s->c_new || !s->c_list) { swim_destroy(s); return SWIM_ENOMEM; }
@@ -1555,7 +1577,7 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
   }
   for (size_t g = 0; g < NL; g++) {
     node_t* nd = &s->nodes[g];
-    nd->q = s->q_slab + g * cfg->queue_cap;
+    nd->q = s->unbounded ? NULL : s->q_slab + g * cfg->queue_cap;
     nd->evq = s->evq_slab ? s->evq_slab + g * cfg->event_queue_cap : NULL;
     nd->self_inc = 1; nd->pr_target = SWIM_NONE; nd->vdl = SWIM_NONE;
     nd->inbox = s->inbox_slab + g * cfg->inbox_cap;
@@ -1567,7 +1589,8 @@ int swim_create(const swim_config* cfg, swim_sim** out) {
 
 int swim_destroy(swim_sim* s) {
   if (!s) return SWIM_EINVAL;
-  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].ring); free(s->nodes[g].vt.e); }
+  if (s->nodes) for (size_t g = 0; g < (size_t)s->nloc * s->R; g++) { free(s->nodes[g].ring); free(s->nodes[g].vt.e); if (s->unbounded) free(s->nodes[g].q); }
+  free(s->q_cnt);
   free(s->base_key); free(s->subj_cnt); free(s->base_known); free(s->join_list); free(s->f_cnt); free(s->f_kmin); free(s->f_kmax); free(s->f_bad); free(s->f_touched);
   free(s->inbox_slab); free(s->ev_watch); free(s->n_ev_watch);
   if (s->slots) for (size_t i = 0; i < (size_t)s->R * s->cfg.subject_cap; i++) free(s->slots[i].trace);
@@ -1806,6 +1829,7 @@ int swim_inject_join(swim_sim* s, uint32_t r, const uint32_t* ids, size_t n, uin
     for (uint32_t j = 0; j < nd->vt.slots; j++) if (nd->vt.e[j].subj != V_EMPTY) { s->subj_cnt[(size_t)r * s->N + nd->vt.e[j].subj]--; touch_slot(s, r, nd->vt.e[j].subj); }
     free(nd->vt.e); memset(&nd->vt, 0, sizeof nd->vt); nd->vdl = SWIM_NONE;
     nd->nk = KINC(s->base_key[g]) == 0 ? 1u : 0u;          /* it knows itself, whatever the base row says */
+    if (s->q_cnt) for (uint32_t j = 0; j < nd->qlen; j++) s->q_cnt[(size_t)r * s->N + nd->q[j].subject]--;
     nd->qlen = 0; nd->evqlen = 0; nd->in_cnt = 0; nd->awareness = 0; nd->leaving = 0;
     if (s->cs) { coord_state* st = &s->cs[nd - s->nodes]; memset(st, 0, sizeof *st); coord_new(&st->c); }   /* a fresh process: a fresh coordinate client */
     nd->pr_target = SWIM_NONE; nd->pr_stage = 0; nd->pr_nack_miss = 0;
@@ -1920,12 +1944,15 @@ int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node_info* out)
   out->queue_len = nd->qlen; out->event_queue_len = nd->evqlen; out->event_clock = nd->ev_clock;
   out->alive = s->gt_alive[(size_t)r * s->N + i]; out->leaving = nd->leaving; out->awareness = nd->awareness;
   out->partition = s->part[(size_t)r * s->N + i];
-  const uint32_t nq = nd->qlen < 32 ? nd->qlen : 32;      /* (the struct holds 32; the checker's queue may be deeper: queue_len says how deep) */
-  for (uint32_t k = 0; k < nq; k++) {
+  /* the struct holds 32; a queue may be deeper (queue_len says how deep): the 32 oldest entries (lowest sequence numbers), oldest first */
+  const uint32_t nq = nd->qlen < 32 ? nd->qlen : 32;
+  swim_rumour* all = (swim_rumour*)malloc((size_t)(nd->qlen ? nd->qlen : 1) * sizeof(swim_rumour)); if (!all) return SWIM_ENOMEM;
+  for (uint32_t k = 0; k < nd->qlen; k++) {
     swim_rumour q = { nd->q[k].subject, nd->q[k].inc, nd->q[k].from, nd->q[k].type, nd->q[k].transmits, {0, 0}, nd->q[k].seq };
-    out->queue[k] = q;
+    all[k] = q;
   }
-  qsort(out->queue, nq, sizeof(swim_rumour), rumour_cmp);
+  qsort(all, nd->qlen, sizeof(swim_rumour), rumour_cmp);
+  memcpy(out->queue, all, (size_t)nq * sizeof(swim_rumour)); free(all);
   return SWIM_OK;
 }
 /* serf's notifyCh of a broadcast, as a question: is {id, ltime} still in the node's serf queue? */
@@ -2059,6 +2086,7 @@ static int attach(swim_sim* s, uint32_t r, uint32_t a) {
   size_t g = (size_t)r * s->N + a;
   if (!s->attached[g] && is_local(s, a)) {   /* from now on the node is driven from outside: what it had queued or received is void */
     node_t* nd = node_at(s, r, a);
+    if (s->q_cnt) for (uint32_t j = 0; j < nd->qlen; j++) s->q_cnt[(size_t)r * s->N + nd->q[j].subject]--;
     nd->qlen = 0; nd->evqlen = 0; nd->in_cnt = 0;
   }
   s->attached[g] = 1;
@@ -2113,6 +2141,7 @@ static int ck_rd_vec(FILE* f, edgevec* e) {
 int swim_checkpoint_save(swim_sim* s, const char* path) {
   if (!s || !path) return SWIM_EINVAL;
   if (s->in_tick || s->c_n) return SWIM_ESTATE;
+  if (s->unbounded) { snprintf(s->err, sizeof s->err, "the checker does not checkpoint unbounded queues"); return SWIM_ESTATE; }
   FILE* f = fopen(path, "wb"); if (!f) return SWIM_EIO;
   const size_t NT = (size_t)s->N * s->R, NL = (size_t)s->nloc * s->R, NS = (size_t)s->R * s->cfg.subject_cap;
   ck_header h; memset(&h, 0, sizeof h);
