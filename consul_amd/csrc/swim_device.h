@@ -70,6 +70,7 @@ enum {
 #define SW_ERR_XCHG_TIMEOUT 0x100u  /* swim_xchg_step: a source shard's flag did not arrive in time (reported as SWIM_ESTATE) */
 #define SW_ERR_VIEW_CORRUPT 0x80u   /* an observer's view table lost its free slot: cannot happen (load <= (view_cap+1)/VT <= 1/2) */
 #define SW_ERR_MASS_RANGE 0x200u    /* a pair of the dense store would need an incarnation >= 2^26 or a tick >= 2^20 */
+#define SW_ERR_ORDER_OVF 0x400u     /* SWIM_F_UNBOUNDED_QUEUE: more than ord_cap piggy-back orders for one node in one tick */
 
 // per-slot census accumulators (one row per replica*subject_cap slot)
 enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_WORDS = 8 };
@@ -137,6 +138,16 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 #define MA_INC(a) ((a) >> 6)
 #define MA_KEY(a) ((MA_INC(a) << 2) | MA_STATE(a))
 #define MB_TICK(b) ((b) & 0xFFFFFu)
+#define QE_QUEUED 0x80000000u
+#define QE_TR(e) (((e) >> 26) & 31u)
+#define QE_TYPE(e) (((e) >> 24) & 3u)
+#define QE_SEQ(e) ((e) & 0x3FFFFFu)
+#define QE_PACK(tr, type, seq) (QE_QUEUED | ((uint32_t)(tr) << 26) | ((uint32_t)(type) << 24) | ((seq) & 0x3FFFFFu))
+#define QF_FROM(f) ((f) & 0x3FFFFFu)
+#define QF_DELTA(f) ((f) >> 22)
+#define SW_IQ_POOL 512u           /* candidates a wave holds while it scans a node's column (LDS, 8 bytes each) */
+#define SW_IQ_PKT 64u             /* rumours one packet can take (the host refuses configurations that could take more) */
+#define SW_IQ_ORDERS 4u           /* piggy-back orders served per scan of a node's column */
 #define M_CONF0(b, c) (((b) >> 20) | (((c) & 0x3FFu) << 12))
 #define M_CONF1(c) ((c) >> 10)
 
@@ -217,6 +228,20 @@ struct SwDev {
   uint32_t *m_due, *m_due_cnt;           // [R*M], [1] rows whose bound has passed this tick (k_expire_mass_due -> k_expire_mass)
   uint4* xs_list; uint32_t* xs_cnt; uint32_t xs_cap;   // state exchanges of this tick whose dense-store part k_send_mass sends: {replica, owner, receiver, flags}
   uint32_t* mcnt;                        // [NL] pairs of the dense store this observer holds (present)
+  // SWIM_F_UNBOUNDED_QUEUE (iq != 0): memberlist's unbounded TransmitLimitedQueue, implied by the pair store.  The rumour node o has
+  // queued about a subject that owns a row (and is not o itself) lives in pair (row, o), 8 more bytes:
+  //   mE  bit 31 queued, 30-26 transmits, 25-24 type, 21-0 sequence number (the node's qseq when it was pushed) — everything
+  //       GetBroadcasts orders by, in ONE word, laid out [replica][64 observers][64 rows][observer][row]: an observer's 64 consecutive
+  //       rows are one 256-byte run, so a WAVE scans one node's column coalesced (k_gossip_iq, k_piggy_iq: a wave per node)
+  //   mF  bits 21-0 accuser (`from`), 31-22 message incarnation minus the view's (0 but for a confirmation that names a higher one);
+  //       same layout as mA/mB/mC; read only for the entries a packet takes
+  // iqn[l] = how many such rumours node l has queued (its "has something queued" bit and the scans' early exit).
+  // Piggy-back orders (SWIM_SUBJECT_PIGGY) do not enter the inboxes of such a handle: k_deliver files them in ord[l][..] and lists the node
+  // in ord_nodes; k_piggy_iq (between k_deliver and k_resolve) serves them with one scan of the node's column.
+  uint32_t iq, MB;                       // MB = 64-row blocks per replica
+  uint32_t *mE, *mF, *iqn;
+  uint2* ord; uint32_t *ord_cnt, *ord_nodes, *ord_n; uint32_t ord_cap;   // [NL][ord_cap] {receiver, kind << 30 | prober}, [NL], [NL], [1]
+  uint32_t len_rank[4], iq_keep[4];      // rank of a message type's length (0 = longest; equal lengths share a rank); candidates kept per rank and packet
   uint32_t* peak;                        // [1] the largest inbox any node has had in one tick (swim_stats_t.inbox_peak)
   uint32_t* bk;          // [R*N] replicated base row: inc<<2|state every observer holds unless it has an explicit view
   uint32_t* acting;      // [R] nodes of the whole population the simulator acts for (running, not attached)

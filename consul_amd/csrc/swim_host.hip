@@ -141,6 +141,11 @@ int validate(const swim_config* c) {
     if (c->suspicion_mult > 4 || (c->n_initial && c->n_initial != c->n_nodes) || c->reap_interval_ms) return SWIM_EINVAL;
     if (c->n_nodes > (1u << 22) || c->mass_rows > c->n_nodes) return SWIM_ERANGE;
   }
+  if (c->flags & SWIM_F_UNBOUNDED_QUEUE) {   // the queue implied by the pair store: a wave per node, fan-out <= 4, the column's queue word holds 5 bits of transmits
+    if (!c->mass_rows || c->n_shards != 1 || c->gossip_nodes > 4) return SWIM_EINVAL;
+    uint32_t min_len = std::min(std::min(c->msg_len[0], c->msg_len[1]), c->msg_len[2]);
+    if (c->udp_buffer_size / (2 + min_len) >= SW_IQ_PKT) return SWIM_ERANGE;      // rumours one packet can take
+  }
   return SWIM_OK;
 }
 uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -478,6 +483,23 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mB, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mC, 0, pairs * 4, s->stream));
+    D.iq = (cfg->flags & SWIM_F_UNBOUNDED_QUEUE) ? 1u : 0u; D.MB = cdiv(D.M, 64);
+    if (D.iq) {   // SWIM_F_UNBOUNDED_QUEUE (swim_device.h): 8 more bytes per pair, the queue word in its own column-major layout
+      const size_t epairs = (size_t)D.R * cdiv(D.nloc, 64) * D.MB * 4096;
+      DALLOC(s, D.mE, epairs); DALLOC(s, D.mF, pairs); DALLOC(s, D.iqn, NL);
+      HIPCK(s, hipMemsetAsync(D.mE, 0, epairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mF, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.iqn, 0, NL * 4, s->stream));
+      D.ord_cap = 16;
+      DALLOC(s, D.ord, NL * D.ord_cap); DALLOC(s, D.ord_cnt, NL); DALLOC(s, D.ord_nodes, NL); DALLOC(s, D.ord_n, 1);
+      HIPCK(s, hipMemsetAsync(D.ord_cnt, 0, NL * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.ord_n, 0, 4, s->stream));
+      // ranks of the three message lengths (0 = longest; equal lengths share a rank) and what one packet can take of each
+      uint32_t lens[3] = { cfg->msg_len[0], cfg->msg_len[1], cfg->msg_len[2] };
+      for (int t = 0; t < 3; t++) { uint32_t rk = 0; for (int u = 0; u < 3; u++) { bool seen = false; for (int v = 0; v < u; v++) seen |= lens[v] == lens[u]; if (!seen && lens[u] > lens[t]) rk++; } D.len_rank[t] = rk; }
+      D.len_rank[3] = 0;
+      for (int t = 0; t < 4; t++) D.iq_keep[t] = 0;
+      for (int t = 0; t < 3; t++) D.iq_keep[D.len_rank[t]] = d.packet_budget / (2 + lens[t]) + 1;
+      const uint32_t per_pkt_all = D.iq_keep[0] + D.iq_keep[1] + D.iq_keep[2];
+      if (d.retransmit_limit > 31 || per_pkt_all * std::max<uint32_t>(4u, SW_IQ_ORDERS) + 64 + 32 > SW_IQ_POOL) { swim_destroy(s); return SWIM_ERANGE; }
+    }
     HIPCK(s, hipMemsetAsync(D.m_tile_dl, 0xFF, RM * D.nbl * 4, s->stream));
   }
   DALLOC(s, D.peak, 1); HIPCK(s, hipMemsetAsync(D.peak, 0, 4, s->stream));
@@ -573,14 +595,16 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   D.pend_cap = pl.nb_probe * SW_BLOCK * D.R;
   DALLOC(s, D.pend, (size_t)D.pend_cap * (D.TQ + 1)); DALLOC(s, D.pend_cnt, D.TQ + 1);
   // worst-case records of one tick: a gossip block's private segment holds every packet it can emit
-  const uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
+  uint32_t per_pkt = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / 4));
+  if (D.iq) per_pkt = SW_IQ_PKT + D.EQ;               // an implied queue fills a packet to its byte budget
   D.nb_gossip = pl.nb_gossip; D.nb_probe = pl.nb_probe; D.n_seg = D.R * (pl.nb_gossip + pl.nb_probe);
   D.seg_cap = std::max<uint32_t>(SW_BLOCK * D.k_gossip * per_pkt, 2 * SW_BLOCK);   // a probe block files <= 2 orders per lane
   {   // carry areas: one per k_resolve block; a probe-due chunk is exactly one block, so all 256 nodes may answer
       // their own ping's order in the same tick, plus the acks and indirect legs they serve
     uint32_t min_len = std::min(std::min(cfg->msg_len[0], cfg->msg_len[1]), cfg->msg_len[2]) + 2;
     if (serf) min_len = std::min(min_len, cfg->msg_len[3] + 3);
-    const uint32_t fit = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / std::max(1u, min_len)));
+    uint32_t fit = std::min<uint32_t>(D.Q + D.EQ, std::max<uint32_t>(1, D.budget / std::max(1u, min_len)));
+    if (D.iq) fit = std::max<uint32_t>(1, D.budget / std::max(1u, min_len));
     D.NB = (uint32_t)NB; D.carry_cap = piggy ? 2 * SW_BLOCK * fit : 1;
     D.nb_carry = piggy ? 1 : 0;                      // (flag) k_deliver's segment blocks drain the carry areas too
     DALLOC(s, D.carry, piggy ? (size_t)2 * NB * D.carry_cap : 1); DALLOC(s, D.carry_cl, NB); DALLOC(s, D.att_any, 1); DALLOC(s, D.carry_stamp, 2);
@@ -606,6 +630,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.tb, D.tb_on ? (size_t)D.tb_T * D.tb_cap : 1); DALLOC(s, D.tb_cnt, D.tb_T); DALLOC(s, D.tb_last, D.tb_T); DALLOC(s, D.dbg_on, 1);
     HIPCK(s, hipMemsetAsync(D.tb_cnt, 0, (size_t)D.tb_T * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.tb_last, 0, (size_t)D.tb_T * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.dbg_on, 0, 4, s->stream));
   }
+  if (D.iq) pl.roles &= ~0x8u;                        // gossip() of a handle whose queue the pair store implies is k_gossip_iq's (launch_begin)
   s->begin_kernel = select_begin(std::max(D.k_gossip, D.k_indirect), serf, D.n_shards > 1, cfg->mass_rows != 0, D.tb_on != 0);
   for (uint32_t sh = 0; sh < D.n_shards; sh++) {
     // own shard: probe verdicts, fold census records, push-pull; other shards: their share of the gossip records, the
@@ -742,6 +767,7 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     (void)hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st); (void)hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st);
     hipLaunchKernelGGL(k_fold_scan, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_scan_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    if (D.iq) hipLaunchKernelGGL(k_fold_scan_iq, dim3(D.R * D.MB), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   if (tick != SW_PLAIN_TICK && reconnect_tick(s, tick)) {
@@ -766,6 +792,11 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
   } else {
     ProfScope p(s, PK_BEGIN);
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
+  }
+  if (D.iq) {    // gossip() over the queue the pair store implies: a wave per node with something queued (same blocks and segments as the gossip role)
+    ProfScope p(s, PK_BEGIN);
+    if (D.flags & SWIM_F_SERF_EVENTS) hipLaunchKernelGGL(k_gossip_iq<true>, dim3(D.R * pl.nb_gossip), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
+    else hipLaunchKernelGGL(k_gossip_iq<false>, dim3(D.R * pl.nb_gossip), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
   }
   if (D.M) hipLaunchKernelGGL(k_send_mass, dim3(1024), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's part of the state exchanges listed above
   if (D.coord) {      // serf's ping delegate: the probers k_begin listed update their coordinates (from everybody's as of the start of the tick)
@@ -804,6 +835,11 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     if (D.C > D.bigsort_cap) hipLaunchKernelGGL(k_inbox_sort_huge, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), (size_t)SW_BIGSORT_MAX * 12, st, (const SwDev*)s->d_D);   // (inbox_cap beyond what LDS sorts: config #4's recovery)
   }
   const bool serf_k = (D.flags & SWIM_F_SERF_EVENTS) != 0;
+  if (D.iq && (D.flags & SWIM_F_PIGGYBACK)) {   // the tick's piggy-back orders, served from the nodes' columns before anything is merged
+    ProfScope p(s, PK_RESOLVE);
+    if (serf_k) hipLaunchKernelGGL(k_piggy_iq<true>, dim3(2048), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    else hipLaunchKernelGGL(k_piggy_iq<false>, dim3(2048), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
   void (*const resolve_kernel)(const SwDev*) =
       D.dyn ? (D.M ? (serf_k ? k_resolve<true, true, true> : k_resolve<true, false, true>) : (serf_k ? k_resolve<false, true, true> : k_resolve<false, false, true>))
             : (D.M ? (serf_k ? k_resolve<true, true, false> : k_resolve<true, false, false>) : (serf_k ? k_resolve<false, true, false> : k_resolve<false, false, false>));
@@ -842,7 +878,7 @@ static int check_device_errors(swim_sim* s) {
              e & SW_ERR_EDGE_OVF ? " edge-list" : "", e & SW_ERR_INBOX_OVF ? " inbox" : "",
              e & SW_ERR_SUBJ_OVF ? " subject-slots" : "", e & SW_ERR_CTRL_OVF ? " slot-requests" : "",
              e & SW_ERR_EVENT_OVF ? " event-ring" : "", e & SW_ERR_PEND_OVF ? " pending-probes" : "",
-             e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : (e & SW_ERR_VIEW_CORRUPT ? " view-table(corrupt)" : (e & SW_ERR_MASS_RANGE ? " dense-store-field-range" : "")));
+             e & SW_ERR_CARRY_OVF ? " piggy-back-carry" : (e & SW_ERR_VIEW_CORRUPT ? " view-table(corrupt)" : (e & SW_ERR_MASS_RANGE ? " dense-store-field-range" : (e & SW_ERR_ORDER_OVF ? " piggy-back-orders" : ""))));
     return SWIM_EOVERFLOW;
   }
   return SWIM_OK;
@@ -1392,20 +1428,25 @@ extern "C" int swim_node_info_get(swim_sim* s, uint32_t r, uint32_t i, swim_node
   const SwDev& D = s->D;
   if (r >= D.R || i >= D.N || !is_local(s, i)) return SWIM_ERANGE;
   hipLaunchKernelGGL(k_gather_node, dim3(1), dim3(64), 0, s->stream, (const SwDev*)s->d_D, r, i, s->d_scratch);
-  uint32_t w[16 + 4 * 32]; int rc = d2h(s, w, (const uint32_t*)s->d_scratch, 16 + 4 * 32);
+  uint32_t w[16 + 4 * 64]; int rc = d2h(s, w, (const uint32_t*)s->d_scratch, 16 + 4 * 64);
   if (rc) return rc;
   memset(out, 0, sizeof *out);
   out->incarnation = w[0]; out->probe_target = w[4]; out->probe_deadline_tick = w[4] == SWIM_NONE ? 0 : w[6];
   out->probe_cursor = w[8]; out->probe_epoch = w[9] >> 16;
   out->queue_len = (w[1] >> 8) & 0xFF; out->event_queue_len = (w[1] >> 16) & 0xFF; out->event_clock = w[3];
   out->alive = !(w[10] & NW_DEAD); out->leaving = w[1] & 0xFF; out->awareness = (w[9] >> 8) & 0xFF; out->partition = NW_PART(w[10]);
-  uint32_t nq = std::min<uint32_t>(out->queue_len, 32);
-  for (uint32_t j = 0; j < nq; j++) {
-    const uint32_t* e = &w[16 + 4 * j];
+  // the struct holds 32; a queue may be deeper (SWIM_F_UNBOUNDED_QUEUE: queue_len = the slots' entries + what the pair store implies): the 32 oldest
+  // entries (lowest sequence numbers), oldest first — like the checker
+  const uint32_t n_slots = std::min<uint32_t>(out->queue_len, 32), n_imp = std::min<uint32_t>(w[12], 32);
+  swim_rumour all[64]; uint32_t na = 0;
+  for (uint32_t j = 0; j < n_slots + n_imp; j++) {
+    const uint32_t* e = j < n_slots ? &w[16 + 4 * j] : &w[16 + 4 * 32 + 4 * (j - n_slots)];
     swim_rumour q = { e[0], e[1], e[2], (uint8_t)(e[3] >> 30), (uint8_t)((e[3] >> 22) & 0xFF), { 0, 0 }, e[3] & 0x3FFFFFu };
-    out->queue[j] = q;
+    all[na++] = q;
   }
-  std::sort(out->queue, out->queue + nq, [](const swim_rumour& a, const swim_rumour& b) { return a.seq < b.seq; });
+  std::sort(all, all + na, [](const swim_rumour& a, const swim_rumour& b) { return a.seq < b.seq; });
+  out->queue_len += w[11];
+  memcpy(out->queue, all, std::min<uint32_t>(na, 32) * sizeof(swim_rumour));
   return SWIM_OK;
 }
 extern "C" int swim_census_get(swim_sim* s, uint32_t r, uint32_t x, swim_census* out) {

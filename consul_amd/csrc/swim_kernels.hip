@@ -116,6 +116,10 @@ __device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint
   return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.M + row) << 6) + (k & 63u);
 #endif
 }
+// the queue word of pair (row, lane k) — SWIM_F_UNBOUNDED_QUEUE, swim_device.h: [replica][64 observers][64 rows][observer][row]
+__device__ __forceinline__ size_t e_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
+  return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB + (row >> 6)) * 64u + (k & 63u)) * 64u + (row & 63u);
+}
 // a pair as a view-table entry {subject, inc<<2|state, state-change ms, w} (w as in vt) + the second accuser
 __device__ __forceinline__ uint4 m_unpack(DevRef D, uint32_t x, uint32_t a, uint32_t b, uint32_t c, uint32_t& conf1) {
   conf1 = M_CONF1(c);
@@ -1645,6 +1649,12 @@ __device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l
   l = (size_t)r * D.nloc + (x - D.i0);
   if (rec.y == SWIM_SUBJECT_PIGGY) {               // a piggy-back order for a node with nothing queued is a no-op
     if (!q_bit(D, l)) return NONE;                // (queues do not change between k_begin and k_resolve)
+    if (D.iq) {                                   // SWIM_F_UNBOUNDED_QUEUE: not a message of the inbox — k_piggy_iq serves the node's orders with one scan of its column
+      const uint32_t pos = atomicAdd(&D.ord_cnt[l], 1u);
+      if (pos < D.ord_cap) D.ord[l * D.ord_cap + pos] = make_uint2(rec.z, rec.w); else atomicOr(D.err, SW_ERR_ORDER_OVF);
+      if (pos == 0) D.ord_nodes[atomicAdd(D.ord_n, 1u)] = (uint32_t)l;
+      return NONE;
+    }
   }
   return atomicAdd(&D.in_cnt[l], 1u);
 }
@@ -2075,9 +2085,11 @@ struct NodeCtxT {
   uint32_t c_pig = 0, c_sent01 = 0, c_sent23 = 0;   // piggy-back tallies (orders are frequent: no LDS atomic each); two 16-bit halves
   uint32_t dl_new = NONE;                             // earliest deadline this lane armed (the caller lowers dl_blk with it)
   uint32_t mcnt_add = 0;                              // pairs of the dense store this lane created (D.mcnt[l] is bumped once, in store())
+  uint32_t iq0 = 0, iq_add = 0;                       // SWIM_F_UNBOUNDED_QUEUE: rumours implied by the pair store this node had queued at load(); pairs that became queued since
   uint4 vm; bool vm_have = false, vm_dirty = false;   // vmeta[l] {views, suspects, earliest deadline, earliest evictable}: fetched on first use
   __device__ __forceinline__ void need_vm() { if (!vm_have) { vm = VMETA(l); vm_have = true; } }
   __device__ __forceinline__ bool dyn() const { if constexpr (DYN) return D.dyn != 0; else return false; }
+  __device__ __forceinline__ bool iq() const { if constexpr (MASS) return D.iq != 0; else return false; }
   uint4 h0;
   uint32_t qdirty = 0;                                // LQ: entry j of the lane's queue sits at g_lds_dyn[j * SW_RES_THREADS + threadIdx.x]; entries to write back
 #define SQ(j) g_lds_dyn[(j) * SW_RES_THREADS + threadIdx.x]   /* (LQ contexts live in k_resolve only) */
@@ -2094,6 +2106,7 @@ struct NodeCtxT {
   __device__ __forceinline__ void load(uint4 h) {
     h0 = h;
     self_inc = h0.x; leaving = h_leaving(h0.y); qlen = h_qlen(h0.y); evqlen = h_evqlen(h0.y); qseq = h0.z; ev_clock = h0.w;
+    if (iq()) iq0 = D.iqn[l];
   }
   // LQ: fetch the queue into the LDS column (independent loads, issued together)
   __device__ __forceinline__ void stage_queue(uint32_t from = 0) {
@@ -2111,8 +2124,8 @@ struct NodeCtxT {
   }
   // most deliveries in a saturated cluster are old news: only write the header back when it changed
   // did the node go from "nothing queued" to "something queued" (or back) since load()?
-  __device__ __forceinline__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y)) && (qlen | evqlen); }
-  __device__ __forceinline__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y)) && !(qlen | evqlen); }
+  __device__ __forceinline__ bool q_became_set() const { return !(h_qlen(h0.y) | h_evqlen(h0.y) | iq0) && (qlen | evqlen | iq0 | iq_add); }
+  __device__ __forceinline__ bool q_became_clr() const { return (h_qlen(h0.y) | h_evqlen(h0.y) | iq0) && !(qlen | evqlen | iq0 | iq_add); }
   __device__ __forceinline__ void store() {
     flush_view();
     if constexpr (LQ) for (uint32_t m = qdirty & (qlen >= 32 ? 0xFFFFFFFFu : (1u << qlen) - 1); m; m &= m - 1) {
@@ -2123,6 +2136,7 @@ struct NodeCtxT {
     if (h.x != h0.x || h.y != h0.y || h.z != h0.z || h.w != h0.w) HDR(l) = h;
     if (vm_dirty) VMETA(l) = vm;
     if (MASS && mcnt_add) { D.mcnt[l] += mcnt_add; mcnt_add = 0; }
+    if (MASS && iq_add) D.iqn[l] = iq0 + iq_add;
   }
 
   // QueueBroadcast: same-subject invalidation, Prune() on overflow.  EV = the serf user-event queue (always in HBM)
@@ -2175,13 +2189,16 @@ struct NodeCtxT {
   }
   // ---- the observer's explicit view of a subject: looked up once per message (the home slot's entry and the
   // subject's node word are independent loads), edited in registers, written back once
-  struct View { uint32_t slot, free_slot, w; uint4 e; bool fresh; uint4 c; bool c_have; };   // c = the slot's confirmer record (vc), once fetched
+  struct View { uint32_t slot, free_slot, w; uint4 e; bool fresh; uint4 c; bool c_have; uint32_t qe, qf; bool q_dirty; };   // c = the slot's confirmer record (vc), once fetched; qe / qf = the pair's queue words (SWIM_F_UNBOUNDED_QUEUE)
   // The inbox is applied in subject order, so consecutive messages mostly concern the same subject: its view is looked up
   // once, edited in registers across those messages and written back when the subject changes (or at store()).
   View cv; uint32_t cv_x = NONE; bool cv_dirty = false;
   __device__ __forceinline__ static bool v_mass(const View& v) { return MASS && (v.free_slot & SW_MASS_SLOT) && v.free_slot != NONE; }
   __device__ __forceinline__ void put(const View& v) {
-    if (v_mass(v)) m_store(D, m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k), v.e, v.c.x);
+    if (v_mass(v)) {
+      m_store(D, m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k), v.e, v.c.x);
+      if (v.q_dirty) { D.mE[e_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k)] = v.qe; D.mF[m_idx(D, r, v.free_slot & ~SW_MASS_SLOT, k)] = v.qf; }
+    }
     else D.vt[(size_t)v.slot * NL + l] = v.e;
   }
   __device__ __forceinline__ void flush_view() { if (cv_dirty) { put(cv); cv_dirty = false; } }
@@ -2192,14 +2209,34 @@ struct NodeCtxT {
     return lookup(x);
   }
   __device__ __forceinline__ void put_later(View& v) { (void)v; cv_dirty = true; }     // the handler's wrapper copies v back into cv
+  // encodeAndBroadcast about the subject of view v.  SWIM_F_UNBOUNDED_QUEUE: a rumour about a subject that owns a row of the dense store (and is
+  // not this node itself) is stored IN THE PAIR — the invalidation of an older rumour about the same node is implied (one pair, one rumour),
+  // nothing is scanned, nothing can be pruned.  `delta` = the message's incarnation minus the view's once the handler is through (0 but for a
+  // confirmation that names a higher incarnation than the suspicion's).
+  __device__ __forceinline__ void broadcast_v(View& v, uint32_t subject, uint32_t type, uint32_t inc, uint32_t from, uint32_t delta) {
+    if (iq() && v_mass(v) && subject != o) {
+      if (!(v.qe & QE_QUEUED)) iq_add++;
+      if (from >= (1u << 22) || delta >= (1u << 10)) atomicOr(D.err, SW_ERR_MASS_RANGE);
+      v.qe = QE_PACK(0u, type, qseq); v.qf = (from & 0x3FFFFFu) | (delta << 22); v.q_dirty = true; qseq++;
+      if (qlen) {                                  // a rumour about it from before it owned a row may still sit in the slots: invalidated all the same
+        uint32_t hit = NONE;
+        for (uint32_t j = 0; j < qlen; j++) if (mq_x(j) == subject) hit = j;
+        if (hit != NONE) { if (hit != qlen - 1) mq_set(hit, mq_get(qlen - 1)); qlen--; }
+      }
+      if (D.fast_blocks) D.q_any[l / SW_BLOCK] = 1;
+      return;
+    }
+    (void)inc; broadcast(subject, type, inc, from);
+  }
   __device__ __forceinline__ View lookup(uint32_t x) {
-    View v; v.fresh = false; v.c_have = false; v.free_slot = 0;
+    View v; v.fresh = false; v.c_have = false; v.free_slot = 0; v.qe = 0; v.qf = 0; v.q_dirty = false;
     uint32_t row = NONE;
     if (MASS && D.M) row = D.mrow[(size_t)r * D.N + x];               // (fetched next to the node word: one round trip, not two)
     v.w = D.nw[(size_t)r * D.N + x];
     if (MASS && (v.w & NW_MASS)) {                                   // the subject owns a row of the dense store: pair (row, this lane)
       const size_t idx = m_idx(D, r, row, k);
       const uint32_t a = D.mA[idx], b = D.mB[idx], c = D.mC[idx];
+      if (iq()) v.qe = D.mE[e_idx(D, r, row, k)];
       v.free_slot = SW_MASS_SLOT | row; v.c = make_uint4(0, 0, 0, 0); v.c_have = true;
       if (a) { v.slot = v.free_slot; v.e = m_unpack(D, x, a, b, c, v.c.x); return v; }
       v.slot = NONE;
@@ -2315,7 +2352,7 @@ struct NodeCtxT {
     if (!make(v, x)) return;
     v.e.w = 0;                                             // delete(m.nodeTimers, a.Node)
     const uint32_t old = SW_KST(key);
-    broadcast(x, SWIM_MSG_ALIVE, inc, upd);
+    broadcast_v(v, x, SWIM_MSG_ALIVE, inc, upd, 0);
     set_view(v, inc, SWIM_STATE_ALIVE, old != SWIM_STATE_ALIVE);
     put_later(v);
     S.add(ST_APPL0);
@@ -2348,13 +2385,13 @@ struct NodeCtxT {
       // (a confirmation changes neither the state nor the incarnation: nothing a census or a trace row shows — re-counting the
       // slot's 65 536 observers every tick of the confirmation phase was a twelfth of the driver window's kernel time)
       S.add(ST_CONFIRMS);
-      broadcast(x, SWIM_MSG_SUSPECT, inc, from);
+      broadcast_v(v, x, SWIM_MSG_SUSPECT, inc, from, inc - SW_KINC(key));
       return;
     }
     if (SW_KST(key) != SWIM_STATE_ALIVE) return;
     if (x == o) { refute(v, inc); return; }
     if (!make(v, x)) return;
-    broadcast(x, SWIM_MSG_SUSPECT, inc, from);
+    broadcast_v(v, x, SWIM_MSG_SUSPECT, inc, from, 0);
     set_view(v, inc, SWIM_STATE_SUSPECT, true);
     v.e.w = vw_pack(from, 0, (v.e.w >> 1) & 1u);           // newSuspicion(from, k, min, max); a Leaving mark stays
     put_later(v);
@@ -2379,7 +2416,7 @@ struct NodeCtxT {
     // Left for a graceful leave (Node == From) and for a member a leave intent had marked Leaving here (serf handleNodeLeave)
     const bool was_leaving = old == SWIM_STATE_SUSPECT ? vw_leaving(v.e.w) != 0 : ((v.e.w >> 1) & 1u) != 0;
     v.e.w = 0;
-    broadcast(x, SWIM_MSG_DEAD, inc, from);
+    broadcast_v(v, x, SWIM_MSG_DEAD, inc, from, 0);
     const uint32_t st = (from == x || was_leaving) ? SWIM_STATE_LEFT : SWIM_STATE_DEAD;
     set_view(v, inc, st, true);
     put_later(v);
@@ -3438,6 +3475,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inject_join(const SwDev* __restric
         for (uint32_t sl = 0; sl < D.VT; sl++) if (D.vt[(size_t)sl * NL + l].x != VT_EMPTY) D.vt[(size_t)sl * NL + l].x = VT_EMPTY;
         VMETA(l) = make_uint4(0, 0, NONE, NONE);
         if (D.M && D.mcnt[l]) { for (uint32_t row = 0; row < D.M; row++) { const size_t idx = m_idx(D, r, row, x - D.i0); if (D.mA[idx]) D.mA[idx] = 0; } D.mcnt[l] = 0; }
+        if (D.iq && D.iqn[l]) { for (uint32_t row = 0; row < D.M; row++) { const size_t ei = e_idx(D, r, row, x - D.i0); if (D.mE[ei] & QE_QUEUED) D.mE[ei] = 0; } D.iqn[l] = 0; }
         const uint32_t bkey = base_key_of(D, r, x, old);
         if (D.vnk) D.vnk[l] = SW_KINC(bkey) == 0 ? 1u : 0u;  // it knows itself, whatever the base row says
         uint4 h = HDR(l);
@@ -3534,6 +3572,23 @@ __global__ void k_gather_node(const SwDev* __restrict__ Dp, uint32_t r, uint32_t
   out[0] = h.x; out[1] = h.y; out[2] = h.z; out[3] = h.w;
   out[4] = p0.x; out[5] = p0.y; out[6] = p0.z; out[7] = p0.w; out[8] = p.x; out[9] = p.y; out[10] = w;
   for (uint32_t j = 0; j < h_qlen(h.y) && j < 32; j++) { uint4 e = QENT(j, l); out[16 + 4 * j] = e.x; out[17 + 4 * j] = e.y; out[18 + 4 * j] = e.z; out[19 + 4 * j] = e.w; }
+  out[11] = 0; out[12] = 0;
+  if (D.iq) {     // SWIM_F_UNBOUNDED_QUEUE: what the pair store implies — how many, and the 32 oldest of them (lowest sequence numbers), as slot entries
+    uint32_t* imp = out + 16 + 4 * 32; uint32_t ni = 0, total = 0;
+    for (uint32_t row = 0; row < D.M; row++) {
+      const uint32_t qe = D.mE[e_idx(D, r, row, i - D.i0)];
+      if (!(qe & QE_QUEUED)) continue;
+      total++;
+      uint32_t at = ni;                            // insertion by sequence number, ascending; the 33rd falls off the end
+      while (at > 0 && (imp[4 * (at - 1) + 3] & 0x3FFFFFu) > QE_SEQ(qe)) at--;
+      if (at >= 32) continue;
+      for (uint32_t m = ni < 32 ? ni : 31; m > at; m--) for (int w2 = 0; w2 < 4; w2++) imp[4 * m + w2] = imp[4 * (m - 1) + w2];
+      const size_t mi = m_idx(D, r, row, i - D.i0); const uint32_t a = D.mA[mi], f = D.mF[mi];
+      imp[4 * at] = D.mrow_subj[(size_t)r * D.M + row]; imp[4 * at + 1] = MA_INC(a) + QF_DELTA(f); imp[4 * at + 2] = QF_FROM(f); imp[4 * at + 3] = m_pack(QE_TYPE(qe), QE_TR(qe), QE_SEQ(qe));
+      if (ni < 32) ni++;
+    }
+    out[11] = total; out[12] = ni;
+  }
 }
 
 // swim_event_queued: is {id, ltime} in the node's serf queue?
@@ -3643,6 +3698,13 @@ __global__ void __launch_bounds__(SW_BLOCK) k_digest_mass(const SwDev* __restric
         d += sw_h3(10, id, nc);
         d += sw_h3(11, id, vw_conf0(e.w));
         if (nc >= 1 && D.susp_k > 1) d += sw_h3(12, id, c1);
+      }
+      if (D.iq) {                                    // the rumour this observer has queued about the subject (what k_digest_nodes hashes of a slot's entry)
+        const uint32_t qe = D.mE[e_idx(D, r, row, k)];
+        if (qe & QE_QUEUED) {
+          const uint32_t f = D.mF[idx];
+          d += sw_h3(5, (uint64_t)r * D.N + D.i0 + k, sw_h3(x, ((uint64_t)(MA_INC(a) + QF_DELTA(f)) << 32) | QF_FROM(f), ((uint64_t)QE_SEQ(qe) << 16) | ((uint64_t)QE_TR(qe) << 8) | QE_TYPE(qe)));
+        }
       }
     }
   digest_commit(d, out);
@@ -4240,5 +4302,492 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
       if (c_filt) atomicAdd(stat_ptr(D, ST_FILTERED), (unsigned long long)c_filt);
       if (D.n_shards > 1 && c_edges) *D.act = 1;
     }
+  }
+}
+
+// =================================================================================================
+// SWIM_F_UNBOUNDED_QUEUE — memberlist's TransmitLimitedQueue, unbounded as it is upstream (queue.go; Consul sizes only serf's event
+// queue: internal/gossip/libserf/serf.go:24-27), IMPLIED by the dense pair store (swim_device.h: mE / mF / iqn).
+// QueueBroadcast is a store into the pair (NodeCtxT::broadcast_v).  GetBroadcasts is a SELECTION over the node's column: a WAVE per node
+// reads the column's queue words coalesced (64 rows per load), keeps per length rank the candidates that can possibly be taken this tick
+// (a packet takes at most budget / (2 + len) rumours of a length, so `packets x that many` per rank bound what the greedy walk can reach:
+// an entry beyond them is preceded, in queue.go's order, by more entries of its own length than all the packets together can take or
+// bump), sorts them by (transmits asc, length desc, sequence desc) with a bitonic network in LDS, and then walks that order exactly as the
+// checker walks its sorted queue: take what fits, bump transmits after the sweep, retire at the retransmit limit.  The node's rumour about
+// ITSELF and rumours about subjects without a row sit in the queue_cap slots as before and take part in the same order.
+// =================================================================================================
+#define IQ_DIRTY 0x80000000u
+#define IQ_EXPL 0x40000000u
+#define IQ_RETIRED 0xFFFFFFFFu
+struct IqWave { unsigned long long* pool; uint32_t* taken; uint32_t* evm; uint32_t* xq; uint32_t* scal; };   // one wave's strip of LDS
+__device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type, uint32_t seq) {
+  return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
+}
+__device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1ull; }
+// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave (each pair belongs to the lane that holds its lower index)
+__device__ void iq_sort(unsigned long long* pool, uint32_t P) {
+  const uint32_t lane = sw_lane();
+  for (uint32_t k = 2; k <= P; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t idx = lane; idx < P; idx += 64) {
+        const uint32_t ixj = idx ^ j;
+        if (ixj > idx) {
+          const unsigned long long a = pool[idx], b = pool[ixj];
+          if ((a > b) == ((idx & k) == 0)) { pool[idx] = b; pool[ixj] = a; }
+        }
+      }
+      wave_lds_sync();
+    }
+}
+__device__ void iq_resort(unsigned long long* pool, uint32_t n) {
+  uint32_t P = 64; while (P < n) P <<= 1;
+  for (uint32_t idx = n + sw_lane(); idx < P; idx += 64) pool[idx] = ~0ull;
+  wave_lds_sync();
+  iq_sort(pool, P);
+}
+// sort the pool and keep, per length rank, the keep[rank] x npk entries that sort first; thr[rank] = the key from which on nothing of that
+// rank needs to be looked at any more (0xFFFFFFFF while fewer are known)
+__device__ uint32_t iq_compact(DevRef D, unsigned long long* pool, uint32_t n, uint32_t npk, uint32_t& thr0, uint32_t& thr1, uint32_t& thr2) {
+  iq_resort(pool, n);
+  const uint64_t lt = iq_ltmask();
+  uint32_t base0 = 0, base1 = 0, base2 = 0, m = 0;
+  const uint32_t K0 = D.iq_keep[0] * npk, K1 = D.iq_keep[1] * npk, K2 = D.iq_keep[2] * npk;
+  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+    const uint32_t idx = c0 + sw_lane();
+    const bool valid = idx < n;
+    const unsigned long long e = valid ? pool[idx] : ~0ull;
+    const uint32_t key = (uint32_t)(e >> 32), rk = (key >> 22) & 3u;
+    const uint64_t m0 = __ballot(valid && rk == 0), m1 = __ballot(valid && rk == 1), m2 = __ballot(valid && rk >= 2);
+    const uint32_t pos = rk == 0 ? base0 + (uint32_t)__popcll(m0 & lt) : rk == 1 ? base1 + (uint32_t)__popcll(m1 & lt) : base2 + (uint32_t)__popcll(m2 & lt);
+    const uint32_t K = rk == 0 ? K0 : rk == 1 ? K1 : K2;
+    const bool keep = valid && pos < K;
+    const uint64_t ml = __ballot(valid && pos + 1 == K);           // the last one kept of a rank: the rank's threshold from now on
+    for (uint64_t q = ml; q; q &= q - 1) {
+      const uint32_t src = (uint32_t)__ffsll((long long)q) - 1, k2 = __shfl(key, src), r2 = (k2 >> 22) & 3u;
+      if (r2 == 0) thr0 = k2; else if (r2 == 1) thr1 = k2; else thr2 = k2;
+    }
+    const uint64_t mk = __ballot(keep);
+    if (keep) pool[m + (uint32_t)__popcll(mk & lt)] = e;          // (forward compaction: never past the lane's own index, and this chunk has been read)
+    m += (uint32_t)__popcll(mk);
+    base0 += (uint32_t)__popcll(m0); base1 += (uint32_t)__popcll(m1); base2 += (uint32_t)__popcll(m2);
+    wave_lds_sync();
+  }
+  if (m != n) iq_resort(pool, m);                                   // (pads behind the survivors; they are in order already)
+  return m;
+}
+// the candidates of node (r, local k, lane l): its slots' entries and what its column implies; sorted on return
+__device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
+  const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
+  uint32_t n = 0, thr0 = 0xFFFFFFFFu, thr1 = 0xFFFFFFFFu, thr2 = 0xFFFFFFFFu;
+  {
+    const bool have = lane < qlen;
+    const uint32_t w = have ? QENT(lane, l).w : 0u;
+    const uint64_t m = __ballot(have);
+    if (have) W.pool[(uint32_t)__popcll(m & lt)] = ((unsigned long long)iq_key(D, m_tr(w), m_type(w), m_seq(w)) << 32) | IQ_EXPL | (m_type(w) << 28) | lane;
+    n = (uint32_t)__popcll(m);
+  }
+  const uint32_t* col = D.mE + ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * 64u + lane;
+  uint32_t seen = 0;
+  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 4) {
+    uint32_t ew[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * 4096u] : 0u;     // four independent 256-byte runs in flight
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t e = ew[u];
+      const bool q = (e & QE_QUEUED) != 0;
+      const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
+      const bool qual = q && key < (rk == 0 ? thr0 : rk == 1 ? thr1 : thr2);
+      seen += (uint32_t)__popcll(__ballot(q));
+      const uint64_t mm = __ballot(qual);
+      if (mm) {
+        if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * 64u + lane);
+        n += (uint32_t)__popcll(mm);
+        if (n + 64u > SW_IQ_POOL) { wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); }
+      }
+    }
+  }
+  wave_lds_sync();
+  return iq_compact(D, W.pool, n, npk, thr0, thr1, thr2);
+}
+// one GetBroadcasts(2, limit) over the sorted candidates: lane 0 walks the order, everybody learns what it took (W.taken[0, returned))
+__device__ uint32_t iq_pick(DevRef D, const IqWave& W, uint32_t n, int limit, int& used_out) {
+  if (sw_lane() == 0) {
+    int used = 0; uint32_t nt = 0;
+    for (uint32_t q = 0; q < n && nt < SW_IQ_PKT; q++) {
+      const unsigned long long e = W.pool[q];
+      if ((uint32_t)(e >> 32) == IQ_RETIRED) break;
+      const int free_b = limit - used - 2;
+      if (free_b <= 0) break;
+      const int len = (int)sel4(D.msg_len, ((uint32_t)e >> 28) & 3u);
+      if (len > free_b) continue;
+      W.taken[nt++] = q; used += 2 + len;
+    }
+    W.scal[0] = nt; W.scal[1] = (uint32_t)used;
+  }
+  wave_lds_sync();
+  used_out = (int)W.scal[1];
+  return W.scal[0];
+}
+// the serf delegate's share of the same packet (the user-event queue: <= 32 entries, meta words staged in W.evm): lane 0 picks
+__device__ uint32_t iq_pick_events(DevRef D, const IqWave& W, uint32_t evqlen, uint32_t& live_e, int avail, uint32_t rl) {
+  if (sw_lane() == 0) {
+    int used2 = 0; uint32_t le = live_e;
+    const uint32_t te = get_broadcasts(D, MetaQT<1>{W.evm}, evqlen, le, 3, avail, used2, rl);
+    W.scal[2] = te; W.scal[3] = le;
+  }
+  wave_lds_sync();
+  live_e = W.scal[3];
+  return W.scal[2];
+}
+// candidate -> {subject, incarnation, from, type << 30}
+__device__ __forceinline__ uint4 iq_entry(DevRef D, unsigned long long pe, uint32_t r, uint32_t k, size_t l, size_t NL) {
+  const uint32_t src = (uint32_t)pe, type = (src >> 28) & 3u, idx = src & 0x0FFFFFFFu;
+  if (src & IQ_EXPL) { const uint4 e = QENT(idx, l); return make_uint4(e.x, e.y, e.z, type << 30); }
+  const size_t mi = m_idx(D, r, idx, k);
+  const uint32_t a = D.mA[mi], f = D.mF[mi];
+  return make_uint4(D.mrow_subj[(size_t)r * D.M + idx], MA_INC(a) + QF_DELTA(f), QF_FROM(f), type << 30);
+}
+// after the sweep: what was taken has one more transmit, or is Finished(); the order is restored for the next packet
+__device__ void iq_bump(const IqWave& W, uint32_t n, uint32_t nt, uint32_t rl, bool resort) {
+  const uint32_t lane = sw_lane();
+  if (lane < nt) {
+    const uint32_t q = W.taken[lane];
+    const unsigned long long e = W.pool[q];
+    uint32_t key = (uint32_t)(e >> 32);
+    key = (key >> 24) + 1u >= rl ? IQ_RETIRED : key + (1u << 24);
+    W.pool[q] = ((unsigned long long)key << 32) | (uint32_t)e | IQ_DIRTY;
+  }
+  wave_lds_sync();
+  if (resort && nt) iq_resort(W.pool, n);
+}
+// the transmit counts back where they live; returns how many implied rumours retired.  W.xq[slot] = the new meta word of a slot's entry
+// (0 = untouched, 0xFFFFFFFF = retired) for iq_store_slots
+__device__ uint32_t iq_writeback(DevRef D, const IqWave& W, uint32_t n, uint32_t r, uint32_t k) {
+  const uint32_t lane = sw_lane();
+  if (lane < 32) W.xq[lane] = 0;
+  wave_lds_sync();
+  uint32_t* col = D.mE + ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * 64u;
+  uint32_t retired = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+    const uint32_t idx = c0 + lane;
+    bool gone = false;
+    if (idx < n) {
+      const unsigned long long e = W.pool[idx];
+      const uint32_t src = (uint32_t)e, key = (uint32_t)(e >> 32), type = (src >> 28) & 3u, at = src & 0x0FFFFFFFu;
+      if (src & IQ_DIRTY) {
+        const uint32_t seq = 0x3FFFFFu - (key & 0x3FFFFFu);
+        if (src & IQ_EXPL) W.xq[at] = key == IQ_RETIRED ? 0xFFFFFFFFu : m_pack(type, key >> 24, seq);
+        else { gone = key == IQ_RETIRED; col[(size_t)(at >> 6) * 4096u + (at & 63u)] = gone ? 0u : QE_PACK(key >> 24, type, seq); }
+      }
+    }
+    retired += (uint32_t)__popcll(__ballot(gone));
+  }
+  wave_lds_sync();
+  return retired;
+}
+// the slots' entries (memberlist queue_cap slots, then serf's event queue) written back compacted, like the gossip role's write-back
+__device__ uint32_t iq_store_slots(DevRef D, const IqWave& W, size_t l, size_t NL, uint32_t qlen) {
+  const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
+  const bool have = lane < qlen;
+  uint4 e = have ? QENT(lane, l) : make_uint4(0, 0, 0, 0);
+  const uint32_t nm = have ? W.xq[lane] : 0u;
+  const bool live = have && nm != 0xFFFFFFFFu;
+  if (live && nm) e.w = nm;
+  const uint64_t mk = __ballot(live);
+  const uint32_t pos = (uint32_t)__popcll(mk & lt);
+  if (live && (pos != lane || nm)) QENT(pos, l) = e;
+  return (uint32_t)__popcll(mk);
+}
+__device__ uint32_t iq_store_events(DevRef D, const IqWave& W, size_t l, size_t NL, uint32_t evqlen, uint32_t live_e, uint32_t touched) {
+  const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
+  const bool have = lane < evqlen;
+  uint4 e = have ? D.evq[(size_t)lane * NL + l] : make_uint4(0, 0, 0, 0);
+  const bool live = have && ((live_e >> lane) & 1u);
+  if (have) e.w = W.evm[lane];
+  const uint64_t mk = __ballot(live);
+  const uint32_t pos = (uint32_t)__popcll(mk & lt);
+  if (live && (pos != lane || ((touched >> lane) & 1u))) D.evq[(size_t)pos * NL + l] = e;
+  return (uint32_t)__popcll(mk);
+}
+__device__ __forceinline__ uint32_t iq_nth_bit(uint32_t m, uint32_t n) { for (uint32_t i = 0; i < n; i++) m &= m - 1; return (uint32_t)__ffs((int)m) - 1u; }
+
+#define SW_IQ_STRIP_WORDS (SW_IQ_POOL * 2u + SW_IQ_PKT + 32u + 32u + 8u)
+__device__ __forceinline__ IqWave iq_strip(uint32_t* base) {
+  uint32_t* p = base + (threadIdx.x / 64u) * SW_IQ_STRIP_WORDS;
+  IqWave W; W.pool = (unsigned long long*)p; W.taken = p + SW_IQ_POOL * 2u; W.evm = W.taken + SW_IQ_PKT; W.xq = W.evm + 32u; W.scal = W.xq + 32u;
+  return W;
+}
+
+// memberlist gossip() for a handle whose queue is implied by the pair store: the block is the gossip role's stagger chunk (same block index,
+// same private edge segment, so k_deliver does not change); the peers are drawn lane per node, then every node with something queued gets
+// the whole wave for its GetBroadcasts.  Unsharded handles, fan-out <= 4.
+template <bool SERF>
+__global__ void __launch_bounds__(SW_BLOCK) k_gossip_iq(const SwDev* __restrict__ Dp, uint32_t nb_gossip) {
+  SW_DEV_BIND
+  __shared__ __attribute__((aligned(8))) uint32_t s_strips[(SW_BLOCK / 64) * SW_IQ_STRIP_WORDS];
+  __shared__ uint32_t lds_stats[ST_COUNT], lds_exc[2 * SW_EXC_MAX], s_cnt[1];
+  __shared__ uint32_t s_peer[SW_BLOCK * 4], s_pw[SW_BLOCK * 4];
+  const uint32_t r = blockIdx.x / nb_gossip, bx = blockIdx.x % nb_gossip, t = *D.tick, lane = sw_lane();
+  const size_t NL = (size_t)D.R * D.nloc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.ord_n = 0;            // this tick's list of nodes with piggy-back orders starts empty (k_deliver fills it)
+  const uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
+  uint32_t fb = NONE;
+  if (D.fast_blocks) {
+    const uint32_t i_first = map_gossip(D, t % D.G, bx * SW_BLOCK);
+    if (i_first == NONE) return;
+    fb = (uint32_t)(((size_t)r * D.nloc + (i_first - D.i0)) / SW_BLOCK);
+    if (!D.q_any[fb]) {
+      if (threadIdx.x == 0) { const uint32_t c = D.alive_cnt[fb]; if (c) atomicAdd(stat_ptr(D, ST_QUIESCENT), (unsigned long long)c); }
+      return;
+    }
+  }
+  ExcList X; X.stage(D, r, lds_exc);
+  BlockStats S; S.init(lds_stats);
+  if (threadIdx.x == 0) s_cnt[0] = 0;
+  __syncthreads();
+  const IqWave W = iq_strip(s_strips);
+  const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
+  // ---- lane per node: who has something queued, and whom it gossips to
+  size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0); uint32_t wi = NW_DEAD, iqn = 0;
+  if (i != NONE) { l = (size_t)r * D.nloc + (i - D.i0); wi = D.nw[(size_t)r * D.N + i]; h = HDR(l); iqn = D.iqn[l]; }
+  const bool something = (h_qlen(h.y) | h_evqlen(h.y) | iqn) != 0;
+  const bool acts = i != NONE && !(wi & NW_INERT), active = acts && something;
+  uint32_t found = 0, okm = 0;
+  if (active) {
+    uint32_t peers[4], pw[4];
+    found = k_random_nodes<true>(D, r, i, i - D.i0, t, SW_STREAM_GOSSIP, D.k_gossip < 4u ? D.k_gossip : 4u, 0, NONE, peers, pw, X);
+    for (uint32_t p = 0; p < found; p++) {
+      s_peer[threadIdx.x * 4 + p] = peers[p]; s_pw[threadIdx.x * 4 + p] = pw[p];
+      if (reach(D, r, t, wi, pw[p], i, p)) okm |= 1u << p;
+    }
+  }
+  S.count(ST_QUIESCENT, acts && !something); S.count(ST_ACTIVE, active);
+  wave_lds_sync();
+  uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0;      // (tallied on lane 0)
+  bool holds = i != NONE && (wi & NW_INERT) && something;        // a node that is not running keeps its (frozen) queue: the block's hint stays up
+  // ---- wave per node
+  for (uint64_t todo = __ballot(active); todo; todo &= todo - 1) {
+    const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1, tj = (threadIdx.x & ~63u) + j;
+    const uint32_t o = __shfl(i, j), k = o - D.i0, n_found = __shfl(found, j), ok_j = __shfl(okm, j), wi_j = __shfl(wi, j);
+    const size_t lj = (size_t)r * D.nloc + k;
+    const uint4 hj = make_uint4(__shfl(h.x, j), __shfl(h.y, j), __shfl(h.z, j), __shfl(h.w, j));
+    const uint32_t qlen = h_qlen(hj.y), evqlen = SERF ? h_evqlen(hj.y) : 0u; uint32_t iq_j = __shfl(iqn, j);
+    const uint32_t rl = D.retransmit_limit;
+    uint32_t live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1u, touched_e = 0;
+    if (SERF && lane < evqlen) W.evm[lane] = D.evq[(size_t)lane * NL + lj].w;
+    uint32_t n = iq_build(D, W, r, k, lj, NL, qlen, iq_j, n_found);
+    bool any_taken = false;
+    for (uint32_t p = 0; p < n_found; p++) {
+      int used = 0;
+      const uint32_t nt = iq_pick(D, W, n, (int)D.budget, used);
+      uint32_t te = 0;
+      const int avail = (int)D.budget - used;
+      if (SERF && avail > 2 + 1) te = iq_pick_events(D, W, evqlen, live_e, avail, rl);
+      if (!nt && !te) break;                         // "if len(msgs) == 0 { return }"
+      touched_e |= te; any_taken |= nt != 0;
+      uint4 e4 = make_uint4(0, 0, 0, 0);
+      if (lane < nt) e4 = iq_entry(D, W.pool[W.taken[lane]], r, k, lj, NL);
+      {
+        const uint32_t ty = e4.w >> 30;
+        const uint64_t b0 = __ballot(lane < nt && ty == SWIM_MSG_ALIVE), b1 = __ballot(lane < nt && ty == SWIM_MSG_SUSPECT), b2 = __ballot(lane < nt && ty == SWIM_MSG_DEAD);
+        c_pkt++; c_s0 += (uint32_t)__popcll(b0); c_s1 += (uint32_t)__popcll(b1); c_s2 += (uint32_t)__popcll(b2); c_s3 += (uint32_t)__popc(te);
+      }
+      const bool ok = (ok_j >> p) & 1u;
+      if (!ok) c_drop++;
+      else {
+        const uint32_t peer = s_peer[tj * 4 + p], pwp = s_pw[tj * 4 + p], gdst = r * D.N + peer;
+        const size_t lr = (size_t)r * D.nloc + (peer - D.i0);
+        bool keep = lane < nt;
+        if (keep && filter && e4.x != peer && noop_at_receiver<true>(D, r, lr, D.nw[(size_t)r * D.N + e4.x], e4, false, e4)) keep = false;
+        c_filt += (uint32_t)__popcll(__ballot(lane < nt && !keep));
+        uint4 ev = make_uint4(0, 0, 0, 0); const bool evl = SERF && lane < (uint32_t)__popc(te);
+        if (evl) ev = D.evq[(size_t)iq_nth_bit(te, lane) * NL + lj];
+        if (pwp & NW_ATTACHED) {                     // Transport.WriteTo towards the real node
+          if (keep) capture(D, o, gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | (e4.z & 0x3FFFFFFFu));
+          if (evl) capture(D, o, gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30);
+        } else {
+          const uint64_t mk = __ballot(keep);
+          const uint32_t nk = (uint32_t)__popcll(mk), total = nk + (uint32_t)__popc(te);
+          if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[0], total);
+            base = __shfl(base, 0);
+            uint4* seg = D.seg + (size_t)(r * D.nb_gossip + bx) * D.seg_cap;
+            if (base + total > D.seg_cap) { if (lane == 0) atomicOr(D.err, SW_ERR_EDGE_OVF); }
+            else {
+              if (keep) seg[base + (uint32_t)__popcll(mk & iq_ltmask())] = make_uint4(gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | (e4.z & 0x3FFFFFFFu));
+              if (evl) seg[base + nk + lane] = make_uint4(gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30);
+            }
+          }
+        }
+      }
+      iq_bump(W, n, nt, rl, p + 1 < n_found);
+    }
+    // ---- the queues back where they live
+    uint32_t nq = qlen, ne = evqlen;
+    if (any_taken) {
+      const uint32_t retired = iq_writeback(D, W, n, r, k);
+      iq_j -= retired;
+      nq = iq_store_slots(D, W, lj, NL, qlen);
+      if (lane == 0 && retired) D.iqn[lj] = iq_j;
+    }
+    if (SERF && touched_e) ne = iq_store_events(D, W, lj, NL, evqlen, live_e, touched_e);
+    if (lane == 0) {
+      const uint32_t hy = h_pack(h_leaving(hj.y), nq, SERF ? ne : h_evqlen(hj.y));
+      if (hy != hj.y) { uint4 hn = hj; hn.y = hy; HDR(lj) = hn; }
+      if (!(nq | ne | iq_j)) q_bit_lane(D, lj, false, true);
+    }
+    holds |= (nq | ne | iq_j) != 0;
+    wave_lds_sync();
+    (void)wi_j;
+  }
+  if (lane == 0) {
+    S.add(ST_PKT_SENT, c_pkt); S.add(ST_PKT_DROP, c_drop); S.add(ST_FILTERED, c_filt);
+    S.add(ST_SENT0, c_s0); S.add(ST_SENT1, c_s1); S.add(ST_SENT2, c_s2); S.add(ST_SENT3, c_s3);
+  }
+  const int any = __syncthreads_or(holds);
+  if (threadIdx.x == 0) {
+    if (fb != NONE && !any) D.q_any[fb] = 0;
+    const uint32_t c = s_cnt[0];
+    if (c) { D.seg_cnt[r * D.nb_gossip + bx] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); }
+  }
+  S.flush(D);
+}
+
+// sendMsg's getBroadcasts for the pings / indirect pings / acks / nacks of this tick, on a handle whose queue is implied by the pair store: the
+// orders k_deliver filed per node (canonical order: kind, receiver, prober; a duplicate once), SW_IQ_ORDERS of them per scan of the node's
+// column, a wave per node.  What is picked goes to the node block's carry area and arrives with the next tick's packets (k_deliver), exactly
+// like NodeCtxT::piggyback's picks.  Runs between k_deliver and k_resolve: the queue is as the gossip launch left it.
+template <bool SERF>
+__global__ void __launch_bounds__(SW_BLOCK) k_piggy_iq(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  __shared__ __attribute__((aligned(8))) uint32_t s_strips[(SW_BLOCK / 64) * SW_IQ_STRIP_WORDS];
+  __shared__ uint32_t lds_stats[ST_COUNT];
+  __shared__ uint2 s_ord[(SW_BLOCK / 64) * 64];
+  const uint32_t lane = sw_lane(), wv = threadIdx.x / 64, t = *D.tick;
+  const size_t NL = (size_t)D.R * D.nloc;
+  BlockStats S; S.init(lds_stats);
+  const IqWave W = iq_strip(s_strips);
+  uint2* const so = s_ord + wv * 64;
+  const uint32_t n_nodes = *D.ord_n;
+  uint32_t c_pig = 0, c_msgs = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0, c_peak = 0; bool stamped = false;
+  for (uint32_t a = blockIdx.x * (SW_BLOCK / 64) + wv; a < n_nodes; a += gridDim.x * (SW_BLOCK / 64)) {
+    const size_t l = D.ord_nodes[a];
+    const uint32_t r = div_nloc(D, l), k = mod_nloc(D, l), o = D.i0 + k, nb0 = (uint32_t)(l / SW_BLOCK);
+    uint32_t no = D.ord_cnt[l];
+    { const uint32_t pk = D.in_cnt[l] + no; c_peak = pk > c_peak ? pk : c_peak; }
+    if (no > D.ord_cap) no = D.ord_cap;
+    if (no > 64u) no = 64u;
+    // canonical order (edge_cmp among orders: kind, receiver, prober), by rank; duplicates once
+    const uint2 mine = lane < no ? D.ord[l * D.ord_cap + lane] : make_uint2(0, 0);
+    so[lane] = mine;
+    wave_lds_sync();
+    uint32_t rank = 0; bool dup = false;
+    if (lane < no)
+      for (uint32_t q = 0; q < no; q++) {
+        const uint2 b = so[q];
+        const bool less = (b.y >> 30) != (mine.y >> 30) ? (b.y >> 30) < (mine.y >> 30) : b.x != mine.x ? b.x < mine.x : b.y < mine.y;
+        const bool same = b.x == mine.x && b.y == mine.y;
+        rank += less || (same && q < lane); dup |= same && q < lane;
+      }
+    wave_lds_sync();
+    if (lane < no) so[rank] = dup ? make_uint2(NONE, NONE) : mine;      // (a duplicate sorts right behind its original and is skipped)
+    wave_lds_sync();
+    if (lane == 0) D.ord_cnt[l] = 0;
+    for (uint32_t o0 = 0; o0 < no; o0 += SW_IQ_ORDERS) {
+      const uint32_t nbatch = no - o0 < SW_IQ_ORDERS ? no - o0 : SW_IQ_ORDERS;
+      const uint4 hj = HDR(l);
+      const uint32_t qlen = h_qlen(hj.y), evqlen = SERF ? h_evqlen(hj.y) : 0u; uint32_t iq_j = D.iqn[l];
+      const uint32_t rl = D.retransmit_limit;
+      uint32_t live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1u, touched_e = 0;
+      if (SERF && lane < evqlen) W.evm[lane] = D.evq[(size_t)lane * NL + l].w;
+      const uint32_t n = iq_build(D, W, r, k, l, NL, qlen, iq_j, nbatch);
+      bool any_taken = false;
+      for (uint32_t p = 0; p < nbatch; p++) {
+        const uint2 od = so[o0 + p];
+        if (od.x == NONE && od.y == NONE) continue;                   // a duplicate
+        const uint32_t receiver = od.x, kind = od.y >> 30;
+        const int limit = (int)D.budget - (int)sel4(D.ctl_len, kind & 3u);
+        int used = 0;
+        const uint32_t nt = iq_pick(D, W, n, limit, used);
+        uint32_t te = 0;
+        const int avail = limit - used;
+        if (SERF && D.EQ && avail > 2 + 1) te = iq_pick_events(D, W, evqlen, live_e, avail, rl);
+        if (!(nt | te)) continue;
+        touched_e |= te; any_taken |= nt != 0;
+        uint4 e4 = make_uint4(0, 0, 0, 0);
+        if (lane < nt) e4 = iq_entry(D, W.pool[W.taken[lane]], r, k, l, NL);
+        {
+          const uint32_t ty = e4.w >> 30;
+          const uint64_t b0 = __ballot(lane < nt && ty == SWIM_MSG_ALIVE), b1 = __ballot(lane < nt && ty == SWIM_MSG_SUSPECT), b2 = __ballot(lane < nt && ty == SWIM_MSG_DEAD);
+          c_pig++; c_msgs += nt + (uint32_t)__popc(te);
+          c_s0 += (uint32_t)__popcll(b0); c_s1 += (uint32_t)__popcll(b1); c_s2 += (uint32_t)__popcll(b2); c_s3 += (uint32_t)__popc(te);
+        }
+        if (receiver != NONE) {
+          const uint32_t gdst = r * D.N + receiver, cnt = nt + (uint32_t)__popc(te);
+          const bool att = *D.att_any && (D.nw[gdst] & NW_ATTACHED);   // Transport.WriteTo towards the real node
+          uint4 ev = make_uint4(0, 0, 0, 0); const bool evl = SERF && lane < (uint32_t)__popc(te);
+          if (evl) ev = D.evq[(size_t)iq_nth_bit(te, lane) * NL + l];
+          if (att) {
+            if (lane < nt) capture(D, o, gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | (e4.z & 0x3FFFFFFFu));
+            if (evl) capture(D, o, gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30);
+          } else {
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd((uint32_t*)&D.carry_cl[nb0], cnt);
+            pos = __shfl(pos, 0);
+            uint4* area = D.carry + ((size_t)((t + 1) & 1u) * D.NB + nb0) * D.carry_cap;
+            if (pos + cnt > D.carry_cap) { if (lane == 0) atomicOr(D.err, SW_ERR_CARRY_OVF); }
+            else {
+              if (lane < nt) area[pos + lane] = make_uint4(gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | (e4.z & 0x3FFFFFFFu));
+              if (evl) area[pos + nt + lane] = make_uint4(gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30);
+            }
+            stamped = true;
+          }
+        }
+        iq_bump(W, n, nt, rl, p + 1 < nbatch);
+      }
+      uint32_t nq = qlen, ne = evqlen;
+      if (any_taken) {
+        const uint32_t retired = iq_writeback(D, W, n, r, k);
+        iq_j -= retired;
+        nq = iq_store_slots(D, W, l, NL, qlen);
+        if (lane == 0 && retired) D.iqn[l] = iq_j;
+      }
+      if (SERF && touched_e) ne = iq_store_events(D, W, l, NL, evqlen, live_e, touched_e);
+      if (lane == 0) {
+        const uint32_t hy = h_pack(h_leaving(hj.y), nq, SERF ? ne : h_evqlen(hj.y));
+        if (hy != hj.y) { uint4 hn = hj; hn.y = hy; HDR(l) = hn; }
+        if (!(nq | ne | iq_j)) q_bit_lane(D, l, false, true);
+      }
+      wave_lds_sync();
+      __threadfence();                               // (the next batch reads the header and the slots this one wrote)
+    }
+  }
+  if (lane == 0) {
+    if (c_peak > 5u && c_peak > *D.peak) atomicMax(D.peak, c_peak);
+    if (stamped) *D.carry_stamp = t + 1;
+    S.add(ST_PIGGY, c_pig); S.add(ST_PIGGY_MSGS, c_msgs);
+    S.add(ST_SENT0, c_s0); S.add(ST_SENT1, c_s1); S.add(ST_SENT2, c_s2); S.add(ST_SENT3, c_s3);
+  }
+  S.flush(D);
+}
+
+// fold ticks: a subject some node of the shard (running or not) still has a rumour queued about is not folded (the row would take the
+// rumour with it) — the same rule in the checker (q_cnt).  A workgroup per (replica, 64-row block) reads the block's queue words coalesced.
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_iq(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  __shared__ uint32_t s_busy[64];
+  const uint32_t r = blockIdx.x / D.MB, rb = blockIdx.x % D.MB, G = (D.nloc + 63u) >> 6;
+  if (threadIdx.x < 64) s_busy[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t g = 0; g < G; g++) {
+    const uint32_t* reg = D.mE + (((size_t)r * G + g) * D.MB + rb) * 4096u;
+    for (uint32_t w = threadIdx.x; w < 4096u; w += SW_BLOCK) if (reg[w] & QE_QUEUED) s_busy[w & 63u] = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_busy[threadIdx.x]) {
+    const uint32_t row = rb * 64u + threadIdx.x;
+    if (row < D.M) { const uint32_t x = D.mrow_subj[(size_t)r * D.M + row]; if (x != NONE) D.fl_bad[(size_t)r * D.N + x] = 1; }
   }
 }
