@@ -20,7 +20,7 @@
 // four node blocks; the phase clock of round 5 (profiles/r05_resolve_phase_clock_driver_window.txt) showed 59 % of a wave's life going to the
 // WORKGROUP's bookkeeping — barriers around the receiver list, three waves waiting at the flush for the fourth — so a workgroup is now ONE
 // wave on ONE node block: its barriers cost nothing, nobody waits for a sibling, and a wave that is done frees its slot at once.
-// (-DSW_RES_THREADS=256 -DSW_RTILE=4 builds the old geometry.)
+// (k_resolve is written for exactly this geometry — its static_assert says so; the two macros name the numbers, they are not knobs.)
 #ifndef SW_RES_THREADS
 #define SW_RES_THREADS 64
 #endif

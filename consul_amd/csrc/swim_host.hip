@@ -795,8 +795,8 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
   }
   if (D.iq) {    // gossip() over the queue the pair store implies: a wave per node with something queued (same blocks and segments as the gossip role)
     ProfScope p(s, PK_BEGIN);
-    if (D.flags & SWIM_F_SERF_EVENTS) hipLaunchKernelGGL(k_gossip_iq<true>, dim3(D.R * pl.nb_gossip), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
-    else hipLaunchKernelGGL(k_gossip_iq<false>, dim3(D.R * pl.nb_gossip), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
+    if (D.flags & SWIM_F_SERF_EVENTS) hipLaunchKernelGGL(k_gossip_iq<true>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
+    else hipLaunchKernelGGL(k_gossip_iq<false>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
   }
   if (D.M) hipLaunchKernelGGL(k_send_mass, dim3(1024), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's part of the state exchanges listed above
   if (D.coord) {      // serf's ping delegate: the probers k_begin listed update their coordinates (from everybody's as of the start of the tick)

@@ -2005,8 +2005,11 @@ __global__ void __launch_bounds__(SW_BLOCK) k_frame_deliver(const SwDev* __restr
   if (src == D.rank) return;
   const uint4 h = recv[(size_t)src * F];
   if (h.w != SWIM_FRAME_MAGIC || h.z != *D.tick + 1) return;
-  if (h.x > F - 1 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(D.err, SW_ERR_EDGE_OVF);       // a truncated frame must be re-sent, not delivered: loud
-  deliver_span<true>(D, recv + (size_t)src * F + 1, h.x < F - 1 ? h.x : F - 1, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
+  if (h.x > F - 1) {                             // a truncated frame must be re-sent, not delivered: loud, and nothing of it is filed (like the checker: ESTATE, no partial state)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(D.err, SW_ERR_EDGE_OVF);
+    return;
+  }
+  deliver_span<true>(D, recv + (size_t)src * F + 1, h.x, blockIdx.x * SW_BLOCK + threadIdx.x, gridDim.x * SW_BLOCK);
 }
 // records handed over by other shards (swim_inbound)
 __global__ void __launch_bounds__(SW_BLOCK) k_deliver_list(const SwDev* __restrict__ Dp, const uint4* edges, uint32_t n) {
@@ -3230,7 +3233,12 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census_finish(const SwDev* __restr
   const uint32_t sidx = blockIdx.y, r = sidx / D.S, sl = sidx % D.S;
   const bool dirty = sl < D.n_slots[r] && D.slot_dirty[sidx] != 0;
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-  if (!dirty && !first) return;
+  // A tick in which a join completes: the epilogue marks EVERY slot of the replica dirty (finish_tick), and a block of this launch that has
+  // not been scheduled yet would take the mark for this tick's — recount a second time, take a ticket the epilogue has already reset
+  // (ADVICE r5).  So in such a tick every block of the grid takes a ticket and the last one of ALL runs the epilogue: the marks are written
+  // after every block has read its flags.  join_cnt is the same for the whole launch (set between ticks, cleared by the epilogue alone).
+  const bool joins = D.join_cnt && *D.join_cnt != 0;
+  if (!dirty && !first && !joins) return;
   __shared__ uint32_t acc[CEN_WORDS];
   __shared__ uint32_t s_last;
   __shared__ uint32_t s_dirty;
@@ -3243,7 +3251,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_census_finish(const SwDev* __restr
   }
   __syncthreads();
   const bool first_dirty = 0 < D.n_slots[0] && D.slot_dirty[0] != 0;                 // (block (0, 0) is one of a dirty slot's blocks then)
-  const uint32_t arrivals = s_dirty * gridDim.x + (first_dirty ? 0u : 1u);
+  const uint32_t arrivals = joins ? gridDim.x * gridDim.y : s_dirty * gridDim.x + (first_dirty ? 0u : 1u);
   if (dirty) census_recount(D, sidx, acc);                                           // (ends behind a barrier: the block's atomics are issued)
   if (threadIdx.x == 0) {
     __threadfence();                                                                 // the recount's sums before the ticket
@@ -3338,11 +3346,12 @@ __global__ void k_init_nodes(const SwDev* __restrict__ Dp, uint32_t n_initial) {
   D.in_cnt[l] = 0; VMETA(l) = make_uint4(0, 0, NONE, NONE);
   if (D.mcnt) D.mcnt[l] = 0;
   if (D.evseq) D.evseq[l] = 0;
+  if (l % 64 == 0) D.in_any[l / 64] = 0;             // (a hint per 64 nodes: every group's, not every fourth — ADVICE r5)
   if (l % SW_BLOCK == 0) {
     size_t rem = NL - l;
     uint32_t in_blk = rem < SW_BLOCK ? (uint32_t)rem : SW_BLOCK, started = 0;       // lanes of this block that run at t = 0
     for (uint32_t j = 0; j < in_blk; j++) started += D.i0 + (uint32_t)((l + j) % D.nloc) < n_initial;
-    D.q_any[l / SW_BLOCK] = 0; D.in_any[l / 64] = 0; D.alive_cnt[l / SW_BLOCK] = started;
+    D.q_any[l / SW_BLOCK] = 0; D.alive_cnt[l / SW_BLOCK] = started;
     D.dl_blk[l / SW_BLOCK] = NONE;
   }
   if (l < D.R) { D.acting[l] = n_initial; D.base_known[l] = n_initial; }
@@ -4372,8 +4381,7 @@ __device__ uint32_t iq_compact(DevRef D, unsigned long long* pool, uint32_t n, u
     base0 += (uint32_t)__popcll(m0); base1 += (uint32_t)__popcll(m1); base2 += (uint32_t)__popcll(m2);
     wave_lds_sync();
   }
-  if (m != n) iq_resort(pool, m);                                   // (pads behind the survivors; they are in order already)
-  return m;
+  return m;                                                         // (the survivors are in order already: a stable compaction of a sorted pool)
 }
 // the candidates of node (r, local k, lane l): its slots' entries and what its column implies; sorted on return
 __device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
@@ -4410,24 +4418,45 @@ __device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, 
   wave_lds_sync();
   return iq_compact(D, W.pool, n, npk, thr0, thr1, thr2);
 }
-// one GetBroadcasts(2, limit) over the sorted candidates: lane 0 walks the order, everybody learns what it took (W.taken[0, returned))
+// one GetBroadcasts(2, limit) over the sorted candidates, W.taken[0, returned) = what it took, in the order it took them.  The walk is
+// queue.go's — down the order, take what fits, the space left only shrinks — done 64 candidates at a time: among the entries of a chunk that
+// still fit on their own, a prefix sum of their costs says how far the packet takes them in one go; the first one that no longer fits is
+// skipped for good (it cannot fit later either) and the walk resumes behind it, with fewer bytes, for the shorter ones.
 __device__ uint32_t iq_pick(DevRef D, const IqWave& W, uint32_t n, int limit, int& used_out) {
-  if (sw_lane() == 0) {
-    int used = 0; uint32_t nt = 0;
-    for (uint32_t q = 0; q < n && nt < SW_IQ_PKT; q++) {
-      const unsigned long long e = W.pool[q];
-      if ((uint32_t)(e >> 32) == IQ_RETIRED) break;
+  const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
+  int used = 0; uint32_t nt = 0; bool full = false;
+  for (uint32_t c0 = 0; c0 < n && !full; c0 += 64) {
+    const uint32_t idx = c0 + lane;
+    const unsigned long long e = idx < n ? W.pool[idx] : ~0ull;
+    const bool valid = idx < n && (uint32_t)(e >> 32) != IQ_RETIRED;
+    const int len = (int)sel4(D.msg_len, ((uint32_t)e >> 28) & 3u);
+    if (!__any(valid)) break;                                       // (retired entries and pads sort last)
+    uint32_t pos = 0;
+    for (;;) {
       const int free_b = limit - used - 2;
-      if (free_b <= 0) break;
-      const int len = (int)sel4(D.msg_len, ((uint32_t)e >> 28) & 3u);
-      if (len > free_b) continue;
-      W.taken[nt++] = q; used += 2 + len;
+      if (free_b <= 0 || nt >= SW_IQ_PKT) { full = true; break; }
+      const bool elig = valid && lane >= pos && len <= free_b;
+      const uint64_t me = __ballot(elig);
+      if (!me) break;
+      int cost = elig ? 2 + len : 0, incl = cost;                  // inclusive prefix sum of the eligible entries' costs
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= (uint32_t)off) incl += v; }
+      const bool fits = elig && used + incl <= limit;
+      const uint64_t mf = __ballot(fits), mbad = me & ~mf;
+      // the run ends at the first eligible entry that does not fit; eligible entries behind it are looked at again with what is left
+      const uint32_t stop = mbad ? (uint32_t)__ffsll((long long)mbad) - 1u : 64u;
+      const uint64_t mtake = stop >= 64u ? mf : (mf & ((1ull << stop) - 1ull));
+      uint32_t cnt = (uint32_t)__popcll(mtake);
+      if (nt + cnt > SW_IQ_PKT) cnt = SW_IQ_PKT - nt;              // (never binding: the host refuses configurations that could take more)
+      if (((mtake >> lane) & 1ull) && (uint32_t)__popcll(mtake & lt) < cnt) W.taken[nt + (uint32_t)__popcll(mtake & lt)] = idx;
+      if (cnt) { const uint32_t last = 63u - (uint32_t)__clzll((long long)mtake); used += __shfl(incl, last); nt += cnt; }
+      if (stop >= 64u) break;
+      pos = stop + 1u;
     }
-    W.scal[0] = nt; W.scal[1] = (uint32_t)used;
   }
   wave_lds_sync();
-  used_out = (int)W.scal[1];
-  return W.scal[0];
+  used_out = used;
+  return nt;
 }
 // the serf delegate's share of the same packet (the user-event queue: <= 32 entries, meta words staged in W.evm): lane 0 picks
 __device__ uint32_t iq_pick_events(DevRef D, const IqWave& W, uint32_t evqlen, uint32_t& live_e, int avail, uint32_t rl) {
@@ -4522,16 +4551,18 @@ __device__ __forceinline__ IqWave iq_strip(uint32_t* base) {
 // memberlist gossip() for a handle whose queue is implied by the pair store: the block is the gossip role's stagger chunk (same block index,
 // same private edge segment, so k_deliver does not change); the peers are drawn lane per node, then every node with something queued gets
 // the whole wave for its GetBroadcasts.  Unsharded handles, fan-out <= 4.
+#define SW_IQ_GTHREADS 1024u      /* k_gossip_iq: 16 waves per stagger chunk, 16 nodes each (a wave works on ONE node at a time: 4 waves left 3/4 of the device idle) */
 template <bool SERF>
-__global__ void __launch_bounds__(SW_BLOCK) k_gossip_iq(const SwDev* __restrict__ Dp, uint32_t nb_gossip) {
+__global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __restrict__ Dp, uint32_t nb_gossip) {
   SW_DEV_BIND
-  __shared__ __attribute__((aligned(8))) uint32_t s_strips[(SW_BLOCK / 64) * SW_IQ_STRIP_WORDS];
+  __shared__ __attribute__((aligned(8))) uint32_t s_strips[(SW_IQ_GTHREADS / 64) * SW_IQ_STRIP_WORDS];
   __shared__ uint32_t lds_stats[ST_COUNT], lds_exc[2 * SW_EXC_MAX], s_cnt[1];
   __shared__ uint32_t s_peer[SW_BLOCK * 4], s_pw[SW_BLOCK * 4];
+  __shared__ uint4 s_hdr[SW_BLOCK];
+  __shared__ uint32_t s_node[SW_BLOCK], s_iqn[SW_BLOCK], s_fo[SW_BLOCK];     // node id (NONE: not active), implied rumours queued, found | ok mask << 8
   const uint32_t r = blockIdx.x / nb_gossip, bx = blockIdx.x % nb_gossip, t = *D.tick, lane = sw_lane();
   const size_t NL = (size_t)D.R * D.nloc;
   if (blockIdx.x == 0 && threadIdx.x == 0) *D.ord_n = 0;            // this tick's list of nodes with piggy-back orders starts empty (k_deliver fills it)
-  const uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
   uint32_t fb = NONE;
   if (D.fast_blocks) {
     const uint32_t i_first = map_gossip(D, t % D.G, bx * SW_BLOCK);
@@ -4548,31 +4579,37 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip_iq(const SwDev* __restrict_
   __syncthreads();
   const IqWave W = iq_strip(s_strips);
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
-  // ---- lane per node: who has something queued, and whom it gossips to
-  size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0); uint32_t wi = NW_DEAD, iqn = 0;
-  if (i != NONE) { l = (size_t)r * D.nloc + (i - D.i0); wi = D.nw[(size_t)r * D.N + i]; h = HDR(l); iqn = D.iqn[l]; }
-  const bool something = (h_qlen(h.y) | h_evqlen(h.y) | iqn) != 0;
-  const bool acts = i != NONE && !(wi & NW_INERT), active = acts && something;
-  uint32_t found = 0, okm = 0;
-  if (active) {
-    uint32_t peers[4], pw[4];
-    found = k_random_nodes<true>(D, r, i, i - D.i0, t, SW_STREAM_GOSSIP, D.k_gossip < 4u ? D.k_gossip : 4u, 0, NONE, peers, pw, X);
-    for (uint32_t p = 0; p < found; p++) {
-      s_peer[threadIdx.x * 4 + p] = peers[p]; s_pw[threadIdx.x * 4 + p] = pw[p];
-      if (reach(D, r, t, wi, pw[p], i, p)) okm |= 1u << p;
+  bool holds = false;
+  // ---- lane per node (the chunk's 256 nodes on the first four waves): who has something queued, and whom it gossips to
+  if (threadIdx.x < SW_BLOCK) {
+    const uint32_t i = map_gossip(D, t % D.G, bx * SW_BLOCK + threadIdx.x);
+    size_t l = 0; uint4 h = make_uint4(0, 0, 0, 0); uint32_t wi = NW_DEAD, iqn = 0;
+    if (i != NONE) { l = (size_t)r * D.nloc + (i - D.i0); wi = D.nw[(size_t)r * D.N + i]; h = HDR(l); iqn = D.iqn[l]; }
+    const bool something = (h_qlen(h.y) | h_evqlen(h.y) | iqn) != 0;
+    const bool acts = i != NONE && !(wi & NW_INERT), active = acts && something;
+    uint32_t found = 0, okm = 0;
+    if (active) {
+      uint32_t peers[4], pw[4];
+      found = k_random_nodes<true>(D, r, i, i - D.i0, t, SW_STREAM_GOSSIP, D.k_gossip < 4u ? D.k_gossip : 4u, 0, NONE, peers, pw, X);
+      for (uint32_t p = 0; p < found; p++) {
+        s_peer[threadIdx.x * 4 + p] = peers[p]; s_pw[threadIdx.x * 4 + p] = pw[p];
+        if (reach(D, r, t, wi, pw[p], i, p)) okm |= 1u << p;
+      }
     }
+    s_node[threadIdx.x] = active ? i : NONE; s_hdr[threadIdx.x] = h; s_iqn[threadIdx.x] = iqn; s_fo[threadIdx.x] = found | (okm << 8);
+    S.count(ST_QUIESCENT, acts && !something); S.count(ST_ACTIVE, active);
+    holds = i != NONE && (wi & NW_INERT) && something;             // a node that is not running keeps its (frozen) queue: the block's hint stays up
   }
-  S.count(ST_QUIESCENT, acts && !something); S.count(ST_ACTIVE, active);
-  wave_lds_sync();
+  __syncthreads();
   uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0;      // (tallied on lane 0)
-  bool holds = i != NONE && (wi & NW_INERT) && something;        // a node that is not running keeps its (frozen) queue: the block's hint stays up
-  // ---- wave per node
-  for (uint64_t todo = __ballot(active); todo; todo &= todo - 1) {
-    const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1, tj = (threadIdx.x & ~63u) + j;
-    const uint32_t o = __shfl(i, j), k = o - D.i0, n_found = __shfl(found, j), ok_j = __shfl(okm, j), wi_j = __shfl(wi, j);
+  // ---- wave per node: wave w takes the chunk's nodes 16 w .. 16 w + 15
+  for (uint32_t tj = (threadIdx.x / 64u) * 16u; tj < (threadIdx.x / 64u) * 16u + 16u; tj++) {
+    const uint32_t o = s_node[tj];
+    if (o == NONE) continue;
+    const uint32_t k = o - D.i0, n_found = s_fo[tj] & 0xFFu, ok_j = s_fo[tj] >> 8;
     const size_t lj = (size_t)r * D.nloc + k;
-    const uint4 hj = make_uint4(__shfl(h.x, j), __shfl(h.y, j), __shfl(h.z, j), __shfl(h.w, j));
-    const uint32_t qlen = h_qlen(hj.y), evqlen = SERF ? h_evqlen(hj.y) : 0u; uint32_t iq_j = __shfl(iqn, j);
+    const uint4 hj = s_hdr[tj];
+    const uint32_t qlen = h_qlen(hj.y), evqlen = SERF ? h_evqlen(hj.y) : 0u; uint32_t iq_j = s_iqn[tj];
     const uint32_t rl = D.retransmit_limit;
     uint32_t live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1u, touched_e = 0;
     if (SERF && lane < evqlen) W.evm[lane] = D.evq[(size_t)lane * NL + lj].w;
@@ -4640,7 +4677,6 @@ __global__ void __launch_bounds__(SW_BLOCK) k_gossip_iq(const SwDev* __restrict_
     }
     holds |= (nq | ne | iq_j) != 0;
     wave_lds_sync();
-    (void)wi_j;
   }
   if (lane == 0) {
     S.add(ST_PKT_SENT, c_pkt); S.add(ST_PKT_DROP, c_drop); S.add(ST_FILTERED, c_filt);

@@ -379,6 +379,38 @@ def test_cluster_grows_by_joins_parity(hip, oracle):
     assert (ca.first_suspect_ms, ca.first_dead_ms, ca.all_dead_ms) == (cb.first_suspect_ms, cb.first_dead_ms, cb.all_dead_ms) and cb.all_dead_ms != abi.NONE
 
 
+def test_joins_in_many_replicas_with_watched_subjects(hip, oracle):
+    """A join completes in a tick's epilogue, which marks every watch slot of the replica for a recount (with many replicas the
+    census launch is large, and a block scheduled after the epilogue must not take those marks for its own tick's).  64 clusters x 8 watched
+    subjects, joins in a different cluster every other tick, a failure under way in each: digests and censuses tick by tick."""
+    n, R = 1024, 64
+    kw = dict(n_nodes=n, n_replicas=R, n_initial=n - 16, seed=17, view_cap=64, inbox_cap=256, subject_cap=8, trace_ticks=0, watch_node=abi.NONE)
+    a, b = pair(hip, oracle, **kw)
+    for s in (a, b):
+        s.step_ms(1000)
+        for r in range(R):
+            for x in (5 + r, 300 + r, 700):
+                s.watch(r, x)
+            s.kill(r, [300 + r])
+        s.step_ms(2000)
+    for t in range(48):
+        r = (7 * t) % R
+        if t % 2 == 0:
+            for s in (a, b):
+                s.join(r, [n - 16 + (t // 2) % 16], via=1 + t % 5)
+        a.step(1); b.step(1)
+        assert a.digest() == b.digest(), f"tick {a.now()[0]}"
+        for rr in (r, (r + 1) % R):
+            ca, cb = a.census(rr, 300 + rr), b.census(rr, 300 + rr)
+            assert list(ca.by_state) == list(cb.by_state) and ca.n_observers == cb.n_observers, (t, rr, list(ca.by_state), list(cb.by_state))
+    for s in (a, b):
+        s.step_ms(30000)
+    assert_same(a, b, "after the joins", keys=STAT_KEYS + ["joins", "join_failures"])
+    for r in (0, 13, 63):
+        ca, cb = a.census(r, 300 + r), b.census(r, 300 + r)
+        assert (list(ca.by_state), ca.first_dead_ms, ca.all_dead_ms) == (list(cb.by_state), cb.first_dead_ms, cb.all_dead_ms)
+
+
 def test_small_membership_in_a_large_id_space_parity(hip, oracle):
     """4 members of a 4 096-id space: suspicionTimeout and retransmitLimit follow the member count (4 s .. 24 s), a join
     through a dead member fails and leaves the node alone, a later join goes through."""

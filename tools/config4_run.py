@@ -23,6 +23,7 @@ ap.add_argument("--push-pull-ms", type=int, default=30000)
 ap.add_argument("--every", type=int, default=10)
 ap.add_argument("--seed", type=int, default=11)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--unbounded", action="store_true", help="SWIM_F_UNBOUNDED_QUEUE: memberlist's queue as it is upstream (the device: implied by the pair store)")
 a = ap.parse_args()
 n, nv = a.nodes, int(a.nodes * a.share)
 if a.oracle:
@@ -33,6 +34,8 @@ else:
     lib = L.load()
     rows = a.mass_rows if a.mass_rows >= 0 else (nv + 8 if a.mode == "kill" else n)
     kw = dict(view_cap=a.view_cap or 8, mass_rows=rows)
+if a.unbounded:
+    kw["flags"] = abi.F_DEFAULT | abi.F_UNBOUNDED_QUEUE
 cfg = dict(n_nodes=n, seed=a.seed, queue_cap=a.queue_cap, inbox_cap=a.inbox_cap or min(2 * nv + 256, 8192), subject_cap=8,
            push_pull_interval_ms=a.push_pull_ms, **kw)
 t0 = time.time()
