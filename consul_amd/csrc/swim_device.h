@@ -15,6 +15,10 @@
 #define SW_BIGSORT_MAX 8192u       /* ... up to what 96 KB of LDS hold (12 bytes per message); beyond: k_inbox_sort_huge (a test build may lower it: a power of two >= SW_BIGSORT_MIN) */
 #endif
 #define SW_INBOX_FAST 5            /* messages held in the first 64-byte inbox line */
+#define SW_INBOX_POOL_MIN 4096u    /* inbox_cap from which on the overflow rows are pooled (swim_device.h: inbox_big) */
+#define SW_INBOX_POOL_C1 1024u     /* ... and what a node's own row holds then */
+#define SW_BIGROW_CLAIM 0xFFFFFFFEu
+#define SW_BIGROW_NONE_LEFT 0xFFFFFFFDu
 #define SW_BLOCK 256
 // k_resolve's geometry (round 5): a workgroup of SW_RES_THREADS threads owns a tile of SW_RTILE node blocks.  Rounds 2-4 ran 256 threads on
 // four node blocks; the phase clock of round 5 (profiles/r05_resolve_phase_clock_driver_window.txt) showed 59 % of a wave's life going to the
@@ -189,7 +193,16 @@ struct SwDev {
   // overflow row for arrivals 6..C (a message = {subject, incarnation, type<<30|from})
   uint32_t* in_cnt; // [NL] arrivals this tick (dense: what the scatter's atomics work on)
   uint32_t* inbox1; // [NL][16] word 0 unused, then 5 x 12-byte messages
-  uint32_t* inbox2; // [NL][C2][3]
+  uint32_t* inbox2; // [NL][C1][3]: the node's own row.  C1 = C2 (= C: room for ALL C messages, a big inbox is sorted in its row) unless the rows are POOLED:
+  // inbox_cap beyond SW_INBOX_POOL_MIN would cost NL x C x 12 bytes (206 GB for 524 288 nodes x 32 768) for the few hundred nodes per tick that a
+  // state exchange hands a whole table — so the own row holds C1 = 1 024 and a node whose tick's arrivals pass that gets one of PB big rows of
+  // C2 slots for the tick: k_deliver files arrival C1.. in a deferred list, k_inbox_claim gives every such node a row (one CAS winner per node,
+  // nobody waits), k_inbox_file files the deferred records and copies the own row's part over; readers go through inbox_row().
+  uint32_t C1, PB;                       // PB = big rows (0: not pooled)
+  uint32_t* inbox_big;                   // [PB][C2][3]
+  uint32_t* big_row;                     // [NL] the node's big row this tick (NONE: none) — reset by k_resolve when it has read the inbox
+  uint32_t *big_list, *big_n;            // [PB] the nodes that own big rows this tick, [1]
+  uint4* defer_rec; uint32_t* defer_l; uint32_t* defer_n; uint32_t defer_cap;   // {subject, incarnation, meta, arrival index}, the node, [1]
   // per 256-lane block hints (only used when fast_blocks): skip quiescent gossip / empty-inbox work
   uint32_t* q_any;    // [NL/256] some node of the block may have a non-empty broadcast queue
   uint32_t* in_any;   // [NL/64] some node of the 64-node group received something this tick

@@ -453,7 +453,22 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16);
 #endif
-  DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C2 * 3);
+  // pooled overflow rows (swim_device.h): from inbox_cap 4 096 on a node's own row holds 1 024 messages and the rare node that receives more in a tick
+  // (a state exchange during a mass event) borrows one of PB big rows
+  D.C1 = D.C2; D.PB = 0;
+  { const char* e = getenv("SWIMSIM_INBOX_POOL");
+    if (D.C >= SW_INBOX_POOL_MIN && !(e && !atoi(e))) { D.C1 = SW_INBOX_POOL_C1; D.PB = (uint32_t)std::min<size_t>(std::max<size_t>(NL / 64, 256), 8192); } }
+  if (const char* e = getenv("SWIMSIM_INBOX_POOL_C1")) {   // (tests: pooled rows at any size, the node's own row as small as asked)
+    const uint32_t c1 = (uint32_t)atoi(e);
+    if (c1 >= 16 && D.C > c1) { D.C1 = c1; D.PB = (uint32_t)std::min<size_t>(std::max<size_t>(NL / 64, 256), 8192); }
+  }
+  DALLOC(s, D.in_cnt, NL); DALLOC(s, D.inbox2, NL * D.C1 * 3);
+  if (D.PB) {
+    DALLOC(s, D.inbox_big, (size_t)D.PB * D.C2 * 3); DALLOC(s, D.big_row, NL); DALLOC(s, D.big_list, D.PB); DALLOC(s, D.big_n, 1); DALLOC(s, D.defer_n, 1);
+    D.defer_cap = (uint32_t)std::min<size_t>((size_t)D.PB * D.C2 / 4, (size_t)1 << 26);
+    DALLOC(s, D.defer_rec, D.defer_cap); DALLOC(s, D.defer_l, D.defer_cap);
+    HIPCK(s, hipMemsetAsync(D.big_row, 0xFF, NL * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.big_n, 0, 4, s->stream)); HIPCK(s, hipMemsetAsync(D.defer_n, 0, 4, s->stream));
+  }
   DALLOC(s, D.q_any, NB); DALLOC(s, D.in_any, cdiv(NL, 64)); DALLOC(s, D.alive_cnt, NB); DALLOC(s, D.qbits, cdiv(NL, 32) + 2);
   if (serf) { DALLOC(s, D.evq, NL * D.EQ); DALLOC(s, D.ring, NL * D.EB * D.EW); DALLOC(s, D.evseq, NL); }
   // explicit views: VT slots per lane, a power of two >= 2*(view_cap+1) so that a probe always meets a free slot
@@ -721,7 +736,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   }
   if (D.trace) HIPCK(s, hipMemsetAsync(D.trace, 0, NS * D.trace_ticks * 5 * 4, st));
   DALLOC(s, s->d_D, 1);                             // every pointer is set by now: publish the descriptor
-  s->structural = { (void*)s->d_D, (void*)D.out_tab, (void*)D.mb_tab, (void*)s->d_scratch, (void*)s->mailbox, (void*)s->in_buf, (void*)D.tb };   // (the tile buckets are empty between ticks)
+  s->structural = { (void*)s->d_D, (void*)D.out_tab, (void*)D.mb_tab, (void*)s->d_scratch, (void*)s->mailbox, (void*)s->in_buf, (void*)D.tb, (void*)D.inbox_big, (void*)D.defer_rec, (void*)D.defer_l, (void*)D.big_list };   // (the tile buckets, the pooled inbox rows and their deferred records are empty between ticks)
   HIPCK(s, hipMemcpy(s->d_D, &D, sizeof D, hipMemcpyHostToDevice));
   const uint32_t n_initial = cfg->n_initial ? cfg->n_initial : D.N;
   hipLaunchKernelGGL(k_init_nodes, dim3(cdiv(NL, 256)), dim3(256), 0, st, (const SwDev*)s->d_D, n_initial);
@@ -827,6 +842,10 @@ static void launch_end(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_decide, dim3(cdiv((size_t)D.N * D.R, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_apply, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_apply_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+  }
+  if (D.PB) {   // pooled inbox rows: the nodes whose arrivals passed their own row get a big one, the deferred records are filed
+    hipLaunchKernelGGL(k_inbox_claim, dim3(512), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    hipLaunchKernelGGL(k_inbox_file, dim3(1024), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   if (D.bigsort_cap) {   // inboxes of thousands of messages (a state exchange during a mass event) are sorted by a workgroup each, in LDS
     uint32_t P = SW_BIGSORT_MIN; while (P < D.bigsort_cap) P <<= 1;

@@ -1658,12 +1658,23 @@ __device__ __forceinline__ uint32_t inbox_reserve(DevRef D, uint4 rec, size_t& l
   }
   return atomicAdd(&D.in_cnt[l], 1u);
 }
+// the overflow row of node l this tick: its own, or — pooled rows (swim_device.h) — the big row it was given
+__device__ __forceinline__ uint32_t* inbox_row(DevRef D, size_t l) {
+  if (D.PB) { const uint32_t br = D.big_row[l]; if (br < D.PB) return D.inbox_big + (size_t)br * D.C2 * 3; }
+  return D.inbox2 + l * D.C1 * 3;
+}
 // place: the message lands in the same line for the first SW_INBOX_FAST arrivals, else in the overflow row
 __device__ __forceinline__ void inbox_place(DevRef D, uint4 rec, size_t l, uint32_t pos) {
   if (pos == NONE) return;
   uint32_t* m = nullptr;
   if (pos < SW_INBOX_FAST) m = D.inbox1 + l * 16 + 1 + 3 * pos;
-  else if (pos < D.C) m = D.inbox2 + (l * D.C2 + (pos - SW_INBOX_FAST)) * 3;
+  else if (D.PB && pos >= D.C1) {                  // pooled rows: beyond the node's own row — deferred until the node has a big row (k_inbox_claim / k_inbox_file)
+    if (pos < D.C) {
+      const uint32_t at = atomicAdd(D.defer_n, 1u);
+      if (at < D.defer_cap) { D.defer_rec[at] = make_uint4(rec.y, rec.z, rec.w, pos); D.defer_l[at] = (uint32_t)l; } else atomicOr(D.err, SW_ERR_INBOX_OVF);
+    }
+  }
+  else if (pos < D.C) m = D.inbox2 + (l * D.C1 + (pos - SW_INBOX_FAST)) * 3;
   if (m) { m[0] = rec.y; m[1] = rec.z; m[2] = rec.w; }
   if (pos == 0 && D.fast_blocks) D.in_any[l / 64] = 1;                   // (a hint per 64 nodes: the unit k_resolve's workgroups own one or four of)
 }
@@ -2678,7 +2689,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort(const SwDev* __restrict
   for (uint32_t b = 0; b < nbig; b++) {
     const uint32_t ent = s_big[b], n = ent >> 8;
     const size_t ll = l0 + (ent & 255u);
-    uint32_t* const row = D.inbox2 + ll * D.C2 * 3;
+    uint32_t* const row = inbox_row(D, ll);
     const uint32_t* const line = D.inbox1 + ll * 16;
     uint32_t P = SW_BIGSORT_MIN; while (P < n) P <<= 1;
     for (uint32_t i = threadIdx.x; i < P; i += SW_BLOCK) {
@@ -2732,7 +2743,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort_huge(const SwDev* __res
   for (uint32_t b = 0; b < nbig; b++) {
     const size_t ll = l0 + s_big[b];
     uint32_t n = D.in_cnt[ll]; if (n > D.C) n = D.C;
-    uint32_t* const row = D.inbox2 + ll * D.C2 * 3;
+    uint32_t* const row = inbox_row(D, ll);
     const uint32_t* const line = D.inbox1 + ll * 16;
     // the five messages of the line join the row (arrivals 6.. sit at 0.. : the row has room for all C)
     if (threadIdx.x < SW_INBOX_FAST) { uint32_t* m = row + (size_t)(n - SW_INBOX_FAST + threadIdx.x) * 3; m[0] = line[1 + 3 * threadIdx.x]; m[1] = line[2 + 3 * threadIdx.x]; m[2] = line[3 + 3 * threadIdx.x]; }
@@ -2800,7 +2811,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_inbox_sort_med(const SwDev* __rest
   for (uint64_t mm = __ballot(c >= SW_INBOX_SORT_MIN && c < SW_BIGSORT_MIN); mm; mm &= mm - 1) {
     const uint32_t src = (uint32_t)__ffsll((long long)mm) - 1, n = __shfl(c, src);
     const size_t ll = l0 + wv * 64 + src;
-    uint32_t* const row = D.inbox2 + ll * D.C2 * 3;
+    uint32_t* const row = inbox_row(D, ll);
     const uint32_t* const line = D.inbox1 + ll * 16;
     uint32_t P = 16; while (P < n) P <<= 1;                        // 16 .. 128
     for (uint32_t i = ln; i < P; i += 64) {
@@ -2963,7 +2974,8 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
 #define IN_WORD(w) (((const uint32_t*)&s_in[(w) >> 2][threadIdx.x])[(w) & 3u])
     c_peak = cnt > c_peak ? cnt : c_peak;
     if (cnt > D.C) { S.add(ST_INBOX_OVF, cnt - D.C); atomicOr(D.err, SW_ERR_INBOX_OVF); cnt = D.C; }
-    const uint32_t* row2 = D.inbox2 + l * D.C2 * 3;
+    const uint32_t* row2 = inbox_row(D, l);
+    if (D.PB && cnt > D.C1) D.big_row[l] = NONE;      // (pooled rows: the big row is read below and free again next tick)
     NodeCtxT<RESOLVE_LQ, MASS, SERF, DYN> n(D, S);
     n.r = div_nloc(D, l); n.k = mod_nloc(D, l); n.o = D.i0 + n.k; n.t = t_now; n.l = l; n.NL = NL;
     n.load(hdr0); n.vm = vm0; n.vm_have = true;
@@ -2981,7 +2993,7 @@ __global__ void __launch_bounds__(SW_RES_THREADS) __attribute__((amdgpu_waves_pe
     uint32_t next_j = 0;
     RCLK_MARK(2);                                  // queue staged, first view fetched
     if (sorted && !presorted) {                    // the five messages of the line join the row (it has room for all C), then one sort
-      uint32_t* row = D.inbox2 + l * D.C2 * 3;
+      uint32_t* row = (uint32_t*)row2;
       for (uint32_t j = 0; j < SW_INBOX_FAST; j++) { uint32_t w = 1 + 3 * j, q = cnt - SW_INBOX_FAST + j; row[3 * q] = IN_WORD(w); row[3 * q + 1] = IN_WORD(w + 1); row[3 * q + 2] = IN_WORD(w + 2); }
       inbox_heapsort(row, cnt);
     }
@@ -3217,6 +3229,7 @@ __device__ __forceinline__ void finish_tick(DevRef D, uint32_t* last_cnt) {
     if (D.c_cnt) *D.c_cnt = 0;                 // this tick's coordinate updates are committed
     if (D.m_due_cnt) *D.m_due_cnt = 0;         // the dense store's due rows were looked at
     if (D.xs_cnt) *D.xs_cnt = 0;               // ... and its state exchanges sent
+    if (D.PB) { *D.big_n = 0; *D.defer_n = 0; }   // pooled inbox rows: all handed back (k_resolve cleared the nodes' row words)
   }
   if (threadIdx.x < SW_PP_LISTS) D.pp_cnt[((t & 1u) * SW_PP_LISTS + threadIdx.x) * 16] = 0;        // answered
 }
@@ -4825,5 +4838,37 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_iq(const SwDev* __restri
   if (threadIdx.x < 64 && s_busy[threadIdx.x]) {
     const uint32_t row = rb * 64u + threadIdx.x;
     if (row < D.M) { const uint32_t x = D.mrow_subj[(size_t)r * D.M + row]; if (x != NONE) D.fl_bad[(size_t)r * D.N + x] = 1; }
+  }
+}
+
+// pooled inbox rows (swim_device.h: inbox_big): every node with deferred arrivals gets a big row — one CAS winner per node allocates, the
+// others do nothing (no lane ever waits for another); the kernel boundary publishes the rows to k_inbox_file
+__global__ void __launch_bounds__(SW_BLOCK) k_inbox_claim(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t n = *D.defer_n < D.defer_cap ? *D.defer_n : D.defer_cap;
+  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) {
+    const uint32_t l = D.defer_l[e];
+    if (D.big_row[l] != NONE) continue;
+    if (atomicCAS(&D.big_row[l], NONE, SW_BIGROW_CLAIM) != NONE) continue;
+    const uint32_t idx = atomicAdd(D.big_n, 1u);
+    if (idx < D.PB) { D.big_list[idx] = l; D.big_row[l] = idx; }
+    else { D.big_row[l] = SW_BIGROW_NONE_LEFT; atomicOr(D.err, SW_ERR_INBOX_OVF); }
+  }
+}
+// ... the deferred records into the rows, and what the nodes' own rows already hold copied over (same positions)
+__global__ void __launch_bounds__(SW_BLOCK) k_inbox_file(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t n = *D.defer_n < D.defer_cap ? *D.defer_n : D.defer_cap;
+  if (!n) return;
+  for (uint32_t e = blockIdx.x * SW_BLOCK + threadIdx.x; e < n; e += gridDim.x * SW_BLOCK) {
+    const uint4 m = D.defer_rec[e]; const uint32_t br = D.big_row[D.defer_l[e]];
+    if (br >= D.PB) continue;
+    uint32_t* d = D.inbox_big + ((size_t)br * D.C2 + (m.w - SW_INBOX_FAST)) * 3;
+    d[0] = m.x; d[1] = m.y; d[2] = m.z;
+  }
+  const uint32_t nb = *D.big_n < D.PB ? *D.big_n : D.PB, words = (D.C1 - SW_INBOX_FAST) * 3;
+  for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const uint32_t* src = D.inbox2 + (size_t)D.big_list[b] * D.C1 * 3; uint32_t* dst = D.inbox_big + (size_t)b * D.C2 * 3;
+    for (uint32_t w = threadIdx.x; w < words; w += SW_BLOCK) dst[w] = src[w];
   }
 }
