@@ -33,11 +33,7 @@
 #endif
 #define SW_RES_WAVES (SW_RES_THREADS / 64)
 #define SW_RES_MASS_TILE 64u      /* nodes per workgroup of k_resolve on a handle with the dense pair store (one node block = SW_BLOCK otherwise) */
-#ifdef SW_NO_SPLITQ            /* (A/B: handles with the dense pair store stage whole queue entries, as rounds 3-4 did) */
-#define SW_SPLITQ 0
-#else
-#define SW_SPLITQ 1
-#endif
+#define SW_SPLITQ 1               /* handles with the dense pair store stage {subject, meta} of a queue entry only (NodeCtxT::SPLIT) */
 #define SW_RES_SUBS (SW_RTILE * SW_BLOCK / SW_RES_THREADS)        /* passes of the workgroup over its tile's count words */
 #define SW_COORD_WINDOW 20       /* coordinate.DefaultConfig().AdjustmentWindowSize */
 #define SW_COORD_FILTER 3        /* LatencyFilterSize */

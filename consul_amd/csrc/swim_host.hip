@@ -28,16 +28,11 @@
 
 // nodes per workgroup of k_resolve (swim_kernels.hip): a node block; 64 nodes on a handle with the dense pair store
 static inline uint32_t resolve_tile(const SwDev& D) { return D.M ? SW_RES_MASS_TILE : SW_RTILE * SW_BLOCK; }
-enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_COUNT };
-static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish" }   /* (k_finish: k_census_finish since round 5 — the recount and the epilogue in one launch; k_census then has no launches of its own) */;
+enum { PK_BEGIN = 0, PK_DELIVER, PK_RESOLVE, PK_CENSUS, PK_FINISH, PK_GOSSIP_IQ, PK_PIGGY_IQ, PK_COUNT };
+static const char* const kKernelNames[PK_COUNT] = { "k_begin", "k_deliver", "k_resolve", "k_census", "k_finish", "k_gossip_iq", "k_piggy_iq" }   /* (k_finish: k_census_finish since round 5 — the recount and the epilogue in one launch; k_census then has no launches of its own) */;
 #define SW_GRAPH_TICKS 16
 #define SW_GRAPH_TICKS_MID 4      /* a middle tier (round 5): what is left of a call after the 16-tick graphs goes out four ticks at a time, not one */
 
-#ifdef SW_NODE_LINE
-#define SW_HDR_STRIDE 4
-#else
-#define SW_HDR_STRIDE 1
-#endif
 struct swim_sim {
   swim_config cfg;
   swim_derived d;
@@ -446,13 +441,8 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   if (want_role_clk) { D.role_clk_ticks = 1024; DALLOC(s, D.role_clk, (size_t)D.role_clk_ticks * 16 * 64); }
   DALLOC(s, D.nw, NT);
   DALLOC(s, D.exc_ent, (size_t)D.R * SW_EXC_MAX); DALLOC(s, D.exc_cnt, D.R); DALLOC(s, D.exc_dirty, D.R);
-#ifdef SW_NODE_LINE   // one 64-byte record per node {header, queue slot 0, view metadata, queue slot 1}; queue slots from 2 on slot-major (swim_kernels.hip)
-  DALLOC(s, D.hdr, NL * 4); D.vmeta = D.hdr + 2; DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
-  DALLOC(s, D.q, NL * (D.Q > 2 ? D.Q - 2 : 1)); DALLOC(s, D.inbox1, NL * 16);
-#else
   DALLOC(s, D.hdr, NL); DALLOC(s, D.ph, NL); DALLOC(s, D.pr0, NL);
   DALLOC(s, D.q, NL * D.Q); DALLOC(s, D.inbox1, NL * 16);
-#endif
   // pooled overflow rows (swim_device.h): from inbox_cap 4 096 on a node's own row holds 1 024 messages and the rare node that receives more in a tick
   // (a state exchange during a mass event) borrows one of PB big rows
   D.C1 = D.C2; D.PB = 0;
@@ -481,9 +471,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.vs, NL * D.VT); DALLOC(s, D.sslt, NL);
     HIPCK(s, hipMemsetAsync(D.vs, 0, NL * D.VT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.sslt, 0, NL * 4, s->stream));
   }
-#ifndef SW_NODE_LINE
   DALLOC(s, D.vmeta, NL);
-#endif
   DALLOC(s, D.dl_blk, NB); DALLOC(s, D.bk, NT); DALLOC(s, D.acting, D.R);
   D.M = cfg->mass_rows; D.nbl = cdiv(D.nloc, SW_BLOCK);
   if (D.M) {   // the dense pair store (swim_device.h): 12 bytes per (row, observer)
@@ -723,11 +711,7 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
   HIPCK(s, hipMemsetAsync(D.cap_cnt, 0, 4, st));
   HIPCK(s, hipMemsetAsync(D.stats, 0, (size_t)SW_STAT_COPIES * SW_STAT_STRIDE * 8, st));
   HIPCK(s, hipMemsetAsync(D.err, 0, 4, st));
-#ifdef SW_NODE_LINE
-  HIPCK(s, hipMemsetAsync(D.hdr, 0, NL * 4 * sizeof(uint4), st)); HIPCK(s, hipMemsetAsync(D.q, 0, NL * (D.Q > 2 ? D.Q - 2 : 1) * sizeof(uint4), st));
-#else
   HIPCK(s, hipMemsetAsync(D.q, 0, NL * D.Q * sizeof(uint4), st));
-#endif
   HIPCK(s, hipMemsetAsync(D.vt, 0xFF, NL * D.VT * sizeof(uint4), st));      // every slot free (subject = VT_EMPTY)
   HIPCK(s, hipMemsetAsync(s->fold_zero, 0, s->fold_zero_bytes, st)); HIPCK(s, hipMemsetAsync(s->fold_ones, 0xFF, s->fold_ones_bytes, st));
   if (serf) {
@@ -809,7 +793,7 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(s->begin_kernel, dim3(grid), dim3(SW_BLOCK), lds, st, (const SwDev*)s->d_D, pl);
   }
   if (D.iq) {    // gossip() over the queue the pair store implies: a wave per node with something queued (same blocks and segments as the gossip role)
-    ProfScope p(s, PK_BEGIN);
+    ProfScope p(s, PK_GOSSIP_IQ);
     if (D.flags & SWIM_F_SERF_EVENTS) hipLaunchKernelGGL(k_gossip_iq<true>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
     else hipLaunchKernelGGL(k_gossip_iq<false>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
   }
@@ -855,7 +839,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   }
   const bool serf_k = (D.flags & SWIM_F_SERF_EVENTS) != 0;
   if (D.iq && (D.flags & SWIM_F_PIGGYBACK)) {   // the tick's piggy-back orders, served from the nodes' columns before anything is merged
-    ProfScope p(s, PK_RESOLVE);
+    ProfScope p(s, PK_PIGGY_IQ);
     if (serf_k) hipLaunchKernelGGL(k_piggy_iq<true>, dim3(2048), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     else hipLaunchKernelGGL(k_piggy_iq<false>, dim3(2048), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
@@ -866,12 +850,7 @@ static void launch_end(swim_sim* s, uint32_t tick) {
   // blocks per watch slot.  Measured (profiles/): a quiet tick costs the same with 1024 or 8192 blocks that
   // just leave, while a dirty slot is scanned markedly faster by 64 blocks than by 16 — so: many.
   const uint32_t xb = std::max(1u, std::min<uint32_t>(cdiv(D.nloc, SW_BLOCK * 4), 64));
-#ifdef SW_SPLIT_FINISH     /* (A/B: the two launches of rounds 1-4) */
-  { ProfScope p(s, PK_CENSUS); hipLaunchKernelGGL(k_census, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D); }
-  { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_finish, dim3(1), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
-#else
   { ProfScope p(s, PK_FINISH); hipLaunchKernelGGL(k_census_finish, dim3(xb, D.R * D.S), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D, s->d_last_cnt); }
-#endif
   if (fold) hipLaunchKernelGGL(k_exc_rebuild_folded, dim3(D.R), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   s->in_count = 0;
 }
@@ -1369,7 +1348,7 @@ extern "C" int swim_members(swim_sim* s, uint32_t r, uint32_t o, swim_member* ou
   std::vector<uint32_t> bk(n ? n : 1);
   int rc = n ? d2h(s, bk.data(), (const uint32_t*)D.bk + (size_t)r * D.N, n) : SWIM_OK;
   if (rc) return rc;
-  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)) * SW_HDR_STRIDE, 1))) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)), 1))) return rc;
   // implicit views (a Failed / Left member of the base row was erased by every observer's reaper before it got there)
   for (size_t x = 0; x < n; x++) fill_member(&out[x], (uint32_t)x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk[x], 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
@@ -1385,7 +1364,7 @@ extern "C" int swim_view(swim_sim* s, uint32_t r, uint32_t o, uint32_t x, swim_m
   if (r >= D.R || o >= D.N || x >= D.N || !is_local(s, o)) return SWIM_ERANGE;
   uint32_t bk = 0; int rc = d2h(s, &bk, (const uint32_t*)D.bk + (size_t)r * D.N + x, 1);
   if (rc) return rc;
-  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)) * SW_HDR_STRIDE, 1))) return rc;
+  uint4 h; if ((rc = d2h(s, &h, (const uint4*)D.hdr + ((size_t)r * D.nloc + (o - D.i0)), 1))) return rc;
   fill_member(out, x, x == o ? SW_KEY(h.x, SWIM_STATE_ALIVE) : bk, 0, 0, x != o && D.reap_period != 0);
   std::vector<std::pair<uint32_t, HostView>> ex;
   if ((rc = gather_views(s, r, o, ex))) return rc;

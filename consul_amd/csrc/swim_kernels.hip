@@ -65,19 +65,10 @@ __device__ __forceinline__ uint64_t seed_of(DevRef D, uint32_t r) { return D.see
 __device__ __forceinline__ uint32_t now_ms(DevRef D, uint32_t t) { return t * D.quantum_ms; }
 
 
-// ---- where a node's header, view metadata and the first two slots of its memberlist queue live -------------------------------------
-// SW_NODE_LINE: one 64-byte record per node, {header, queue slot 0, view metadata, queue slot 1} — a receiver of k_resolve touches ONE line
-// for what were three gathers in three arrays (and the gossip role reads header + slot 0 from one line); queue slots from 2 on stay
-// slot-major.  D.hdr is the base of the records, D.vmeta = D.hdr + 2 (swim_host.hip).  Otherwise: three arrays, as before.
-#ifdef SW_NODE_LINE
-#define HDR(l) D.hdr[(size_t)(l) * 4]
-#define VMETA(l) D.vmeta[(size_t)(l) * 4]
-#define QENT(j, l) (*((j) < 2u ? &D.hdr[(size_t)(l) * 4 + 1 + 2 * (j)] : &D.q[(size_t)((j) - 2u) * NL + (l)]))
-#else
+// ---- a node's header, its view metadata, slot j of its memberlist queue (three arrays; one 64-byte record per node was measured twice, rounds 4 and 5: nothing)
 #define HDR(l) D.hdr[l]
 #define VMETA(l) D.vmeta[l]
 #define QENT(j, l) D.q[(size_t)(j) * NL + (l)]
-#endif
 
 // ---- an observer's explicit views (layout: swim_device.h) ------------------------------------------
 __device__ __forceinline__ uint32_t vt_home(DevRef D, uint32_t x) { return (x * 0x9E3779B1u) >> D.vt_shift; }
@@ -110,11 +101,7 @@ __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint
 // round trip and 30 us per message iteration (profiles/r05_config4_mass_phase_clock.txt).  A row's 256-observer tile is four 256-byte runs now
 // (k_expire_mass, fold and census scans: a wave still reads one run), an observer's column 256-byte steps instead of megabyte steps.
 __device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
-#ifdef SW_MASS_ROWMAJOR
-  return ((size_t)r * D.M + row) * D.nloc + k;
-#else
   return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.M + row) << 6) + (k & 63u);
-#endif
 }
 // the queue word of pair (row, lane k) — SWIM_F_UNBOUNDED_QUEUE, swim_device.h: [replica][64 observers][64 rows][observer][row]
 __device__ __forceinline__ size_t e_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
@@ -4341,7 +4328,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
 #define IQ_DIRTY 0x80000000u
 #define IQ_EXPL 0x40000000u
 #define IQ_RETIRED 0xFFFFFFFFu
-struct IqWave { unsigned long long* pool; uint32_t* taken; uint32_t* evm; uint32_t* xq; uint32_t* scal; };   // one wave's strip of LDS
+struct IqWave { unsigned long long* pool; uint32_t* taken; uint32_t* evm; uint32_t* xq; uint32_t* scal; uint32_t* sent; };   // one wave's strip of LDS (sent: what each of up to four packets took)
 __device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type, uint32_t seq) {
   return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
 }
@@ -4409,12 +4396,15 @@ __device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, 
   }
   const uint32_t* col = D.mE + ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * 64u + lane;
   uint32_t seen = 0;
-  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 4) {
-    uint32_t ew[4];
+  // The scan is a chain of round trips (the next batch is only asked for when this one says there is more to see), so a batch is SIXTEEN
+  // independent 256-byte runs: with four, 410 row blocks were a hundred round trips per node — 200 us of a wave's life, most of the launch
+  // (profiles/r06_config4_524k_first.txt) — and 16 waves x 16 runs x 256 bytes per CU is also what 8 TB/s x 2 us of latency wants in flight.
+  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 16) {
+    uint32_t ew[16];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * 4096u] : 0u;     // four independent 256-byte runs in flight
+    for (uint32_t u = 0; u < 16; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * 4096u] : 0u;
 #pragma unroll
-    for (uint32_t u = 0; u < 4; u++) {
+    for (uint32_t u = 0; u < 16; u++) {
       const uint32_t e = ew[u];
       const bool q = (e & QE_QUEUED) != 0;
       const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
@@ -4554,16 +4544,34 @@ __device__ uint32_t iq_store_events(DevRef D, const IqWave& W, size_t l, size_t 
 }
 __device__ __forceinline__ uint32_t iq_nth_bit(uint32_t m, uint32_t n) { for (uint32_t i = 0; i < n; i++) m &= m - 1; return (uint32_t)__ffs((int)m) - 1u; }
 
-#define SW_IQ_STRIP_WORDS (SW_IQ_POOL * 2u + SW_IQ_PKT + 32u + 32u + 8u)
+#define SW_IQ_STRIP_WORDS (SW_IQ_POOL * 2u + SW_IQ_PKT + 32u + 32u + 8u + 4u * SW_IQ_PKT)
 __device__ __forceinline__ IqWave iq_strip(uint32_t* base) {
   uint32_t* p = base + (threadIdx.x / 64u) * SW_IQ_STRIP_WORDS;
-  IqWave W; W.pool = (unsigned long long*)p; W.taken = p + SW_IQ_POOL * 2u; W.evm = W.taken + SW_IQ_PKT; W.xq = W.evm + 32u; W.scal = W.xq + 32u;
+  IqWave W; W.pool = (unsigned long long*)p; W.taken = p + SW_IQ_POOL * 2u; W.evm = W.taken + SW_IQ_PKT; W.xq = W.evm + 32u; W.scal = W.xq + 32u; W.sent = W.scal + 8u;
   return W;
 }
 
 // memberlist gossip() for a handle whose queue is implied by the pair store: the block is the gossip role's stagger chunk (same block index,
 // same private edge segment, so k_deliver does not change); the peers are drawn lane per node, then every node with something queued gets
 // the whole wave for its GetBroadcasts.  Unsharded handles, fan-out <= 4.
+// the no-op question (noop_at_receiver) for a rumour whose subject owns row `row`, with the receiver's pair word `a` already fetched
+__device__ __forceinline__ bool iq_noop_pair(DevRef D, uint32_t r, uint32_t row, uint32_t kr, uint32_t a, uint4 e) {
+  if (a) {
+    const uint32_t type = m_type(e.w), vinc = MA_INC(a), st = MA_STATE(a);
+    if (type == SWIM_MSG_ALIVE) return e.y <= vinc;
+    if (e.y != vinc) return e.y < vinc;
+    if (st == SWIM_STATE_DEAD || st == SWIM_STATE_LEFT) return true;
+    if (type == SWIM_MSG_SUSPECT && st == SWIM_STATE_SUSPECT) {
+      const uint32_t nc = MA_NCONF(a);
+      if (nc >= D.susp_k) return true;
+      const size_t idx = m_idx(D, r, row, kr);
+      const uint32_t b = D.mB[idx], c = D.mC[idx];
+      return M_CONF0(b, c) == e.z || (nc >= 1 && M_CONF1(c) == e.z);
+    }
+    return false;
+  }
+  return noop_given_view(D, base_key_of(D, r, e.x, D.nw[(size_t)r * D.N + e.x]), 0, 0, e);
+}
 #define SW_IQ_GTHREADS 1024u      /* k_gossip_iq: 16 waves per stagger chunk, 16 nodes each (a wave works on ONE node at a time: 4 waves left 3/4 of the device idle) */
 template <bool SERF>
 __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __restrict__ Dp, uint32_t nb_gossip) {
@@ -4628,6 +4636,9 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
     if (SERF && lane < evqlen) W.evm[lane] = D.evq[(size_t)lane * NL + lj].w;
     uint32_t n = iq_build(D, W, r, k, lj, NL, qlen, iq_j, n_found);
     bool any_taken = false;
+    // every packet's GetBroadcasts first — nothing they decide waits for memory — then ONE round of loads for all they send (a packet at a
+    // time it was three dependent round trips per packet: the entry, the subject's words, the receiver's view)
+    uint32_t nt_p[4] = { 0, 0, 0, 0 }, te_p[4] = { 0, 0, 0, 0 }, npk = 0;
     for (uint32_t p = 0; p < n_found; p++) {
       int used = 0;
       const uint32_t nt = iq_pick(D, W, n, (int)D.budget, used);
@@ -4636,21 +4647,47 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
       if (SERF && avail > 2 + 1) te = iq_pick_events(D, W, evqlen, live_e, avail, rl);
       if (!nt && !te) break;                         // "if len(msgs) == 0 { return }"
       touched_e |= te; any_taken |= nt != 0;
-      uint4 e4 = make_uint4(0, 0, 0, 0);
-      if (lane < nt) e4 = iq_entry(D, W.pool[W.taken[lane]], r, k, lj, NL);
+      const uint32_t src = lane < nt ? (uint32_t)W.pool[W.taken[lane]] : 0u, ty = (src >> 28) & 3u;
+      if (lane < nt) W.sent[p * SW_IQ_PKT + lane] = src;
       {
-        const uint32_t ty = e4.w >> 30;
         const uint64_t b0 = __ballot(lane < nt && ty == SWIM_MSG_ALIVE), b1 = __ballot(lane < nt && ty == SWIM_MSG_SUSPECT), b2 = __ballot(lane < nt && ty == SWIM_MSG_DEAD);
         c_pkt++; c_s0 += (uint32_t)__popcll(b0); c_s1 += (uint32_t)__popcll(b1); c_s2 += (uint32_t)__popcll(b2); c_s3 += (uint32_t)__popc(te);
       }
-      const bool ok = (ok_j >> p) & 1u;
-      if (!ok) c_drop++;
-      else {
-        const uint32_t peer = s_peer[tj * 4 + p], pwp = s_pw[tj * 4 + p], gdst = r * D.N + peer;
-        const size_t lr = (size_t)r * D.nloc + (peer - D.i0);
-        bool keep = lane < nt;
-        if (keep && filter && e4.x != peer && noop_at_receiver<true>(D, r, lr, D.nw[(size_t)r * D.N + e4.x], e4, false, e4)) keep = false;
-        c_filt += (uint32_t)__popcll(__ballot(lane < nt && !keep));
+      if (!((ok_j >> p) & 1u)) c_drop++;
+      nt_p[p & 3u] = nt; te_p[p & 3u] = te; npk = p + 1;
+      iq_bump(W, n, nt, rl, p + 1 < n_found);
+    }
+    wave_lds_sync();
+    {
+      uint32_t x_[4], own_a[4], own_f[4], rcv_a[4], src_[4]; uint4 ex_[4]; bool on_[4];
+#pragma unroll
+      for (uint32_t p = 0; p < 4; p++) {             // the loads: all packets' entries and the receivers' pair words, independent of each other
+        on_[p] = p < npk && ((ok_j >> p) & 1u) && lane < nt_p[p];
+        src_[p] = on_[p] ? W.sent[p * SW_IQ_PKT + lane] : 0u;
+        x_[p] = 0; own_a[p] = 0; own_f[p] = 0; rcv_a[p] = 0; ex_[p] = make_uint4(0, 0, 0, 0);
+        if (on_[p]) {
+          const uint32_t at = src_[p] & 0x0FFFFFFFu;
+          if (src_[p] & IQ_EXPL) ex_[p] = QENT(at, lj);
+          else {
+            const size_t mi = m_idx(D, r, at, k);
+            x_[p] = D.mrow_subj[(size_t)r * D.M + at]; own_a[p] = D.mA[mi]; own_f[p] = D.mF[mi];
+            rcv_a[p] = D.mA[m_idx(D, r, at, s_peer[tj * 4 + p] - D.i0)];
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t p = 0; p < 4; p++) {
+        if (p >= npk || !((ok_j >> p) & 1u)) continue;
+        const uint32_t peer = s_peer[tj * 4 + p], pwp = s_pw[tj * 4 + p], gdst = r * D.N + peer, te = te_p[p];
+        const bool expl = (src_[p] & IQ_EXPL) != 0;
+        const uint4 e4 = expl ? make_uint4(ex_[p].x, ex_[p].y, ex_[p].z, ((src_[p] >> 28) & 3u) << 30)
+                              : make_uint4(x_[p], MA_INC(own_a[p]) + QF_DELTA(own_f[p]), QF_FROM(own_f[p]), ((src_[p] >> 28) & 3u) << 30);
+        bool keep = on_[p];
+        if (keep && filter && e4.x != peer) {
+          if (expl) keep = !noop_at_receiver<true>(D, r, (size_t)r * D.nloc + (peer - D.i0), D.nw[(size_t)r * D.N + e4.x], e4, false, e4);
+          else keep = !iq_noop_pair(D, r, src_[p] & 0x0FFFFFFFu, peer - D.i0, rcv_a[p], e4);
+        }
+        c_filt += (uint32_t)__popcll(__ballot(on_[p] && !keep));
         uint4 ev = make_uint4(0, 0, 0, 0); const bool evl = SERF && lane < (uint32_t)__popc(te);
         if (evl) ev = D.evq[(size_t)iq_nth_bit(te, lane) * NL + lj];
         if (pwp & NW_ATTACHED) {                     // Transport.WriteTo towards the real node
@@ -4672,7 +4709,6 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
           }
         }
       }
-      iq_bump(W, n, nt, rl, p + 1 < n_found);
     }
     // ---- the queues back where they live
     uint32_t nq = qlen, ne = evqlen;
