@@ -145,6 +145,7 @@ enum { CEN_OBS = 0, CEN_ST0, CEN_ST1, CEN_ST2, CEN_ST3, CEN_CUR, CEN_MINDL, CEN_
 #define QE_PACK(tr, type, seq) (QE_QUEUED | ((uint32_t)(tr) << 26) | ((uint32_t)(type) << 24) | ((seq) & 0x3FFFFFu))
 #define QF_FROM(f) ((f) & 0x3FFFFFu)
 #define QF_DELTA(f) ((f) >> 22)
+#define SW_IQ_RB 256u             /* rows per block of an observer's queue-word column: 1 KB contiguous, four rows per lane and load */
 #define SW_IQ_POOL 512u           /* candidates a wave holds while it scans a node's column (LDS, 8 bytes each) */
 #define SW_IQ_PKT 64u             /* rumours one packet can take (the host refuses configurations that could take more) */
 #define SW_IQ_ORDERS 4u           /* piggy-back orders served per scan of a node's column */
@@ -240,14 +241,14 @@ struct SwDev {
   // SWIM_F_UNBOUNDED_QUEUE (iq != 0): memberlist's unbounded TransmitLimitedQueue, implied by the pair store.  The rumour node o has
   // queued about a subject that owns a row (and is not o itself) lives in pair (row, o), 8 more bytes:
   //   mE  bit 31 queued, 30-26 transmits, 25-24 type, 21-0 sequence number (the node's qseq when it was pushed) — everything
-  //       GetBroadcasts orders by, in ONE word, laid out [replica][64 observers][64 rows][observer][row]: an observer's 64 consecutive
-  //       rows are one 256-byte run, so a WAVE scans one node's column coalesced (k_gossip_iq, k_piggy_iq: a wave per node)
+  //       GetBroadcasts orders by, in ONE word, laid out [replica][64 observers][256 rows][observer][row]: an observer's 256 consecutive
+  //       rows are one 1 KB run, so a WAVE scans one node's column coalesced, four rows per lane and load (k_gossip_iq, k_piggy_iq: a wave per node)
   //   mF  bits 21-0 accuser (`from`), 31-22 message incarnation minus the view's (0 but for a confirmation that names a higher one);
   //       same layout as mA/mB/mC; read only for the entries a packet takes
   // iqn[l] = how many such rumours node l has queued (its "has something queued" bit and the scans' early exit).
   // Piggy-back orders (SWIM_SUBJECT_PIGGY) do not enter the inboxes of such a handle: k_deliver files them in ord[l][..] and lists the node
   // in ord_nodes; k_piggy_iq (between k_deliver and k_resolve) serves them with one scan of the node's column.
-  uint32_t iq, MB;                       // MB = 64-row blocks per replica
+  uint32_t iq, MB;                       // MB = SW_IQ_RB-row blocks per replica
   uint32_t *mE, *mF, *iqn;
   uint2* ord; uint32_t *ord_cnt, *ord_nodes, *ord_n; uint32_t ord_cap;   // [NL][ord_cap] {receiver, kind << 30 | prober}, [NL], [NL], [1]
   uint32_t len_rank[4], iq_keep[4];      // rank of a message type's length (0 = longest; equal lengths share a rank); candidates kept per rank and packet

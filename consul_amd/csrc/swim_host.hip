@@ -341,6 +341,17 @@ extern "C" int swim_destroy(swim_sim* s) {
   }
 #endif
 #ifdef SWIMSIM_DIAG
+  if (s && s->D.iq && getenv("SWIMSIM_IQCLK")) {      // diagnostics: where the waves of k_gossip_iq spent their nodes
+    unsigned long long c[8];
+    if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_iqclk), sizeof c) == hipSuccess && c[5]) {
+      static const char* const nm[5] = { "column scan (with its compactions)", "  compactions alone", "picks + bumps + re-sorts", "loads, filter, records", "write-back" };
+      const double nn = (double)c[5], tot = (double)(c[0] + c[2] + c[3] + c[4]);
+      fprintf(stderr, "[iq clk] %llu nodes, %.2f compactions and %.1f row blocks per node; s_memtime ticks per node: %.0f\n", c[5], c[6] / nn, c[7] / nn, tot / nn);
+      for (int p = 0; p < 5; p++) fprintf(stderr, "[iq clk]   %-36s %9.0f  %5.1f %%\n", nm[p], c[p] / nn, 100.0 * c[p] / tot);
+    }
+  }
+#endif
+#ifdef SWIMSIM_DIAG
   if (s && getenv("SWIMSIM_RESOLVECLK")) {      // diagnostics: where the waves of k_resolve's LAST launches spent their lives
     std::vector<uint32_t> c((size_t)RCLK_ROWS * 8);
     if (hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_rclk), c.size() * 4) == hipSuccess) {
@@ -486,9 +497,9 @@ extern "C" int swim_create(const swim_config* cfg, swim_sim** out) {
     DALLOC(s, D.m_due, RM); DALLOC(s, D.m_due_cnt, 1); HIPCK(s, hipMemsetAsync(D.m_due_cnt, 0, 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mrow, 0xFF, NT * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mA, 0, pairs * 4, s->stream));
     HIPCK(s, hipMemsetAsync(D.mB, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mC, 0, pairs * 4, s->stream));
-    D.iq = (cfg->flags & SWIM_F_UNBOUNDED_QUEUE) ? 1u : 0u; D.MB = cdiv(D.M, 64);
+    D.iq = (cfg->flags & SWIM_F_UNBOUNDED_QUEUE) ? 1u : 0u; D.MB = cdiv(D.M, SW_IQ_RB);
     if (D.iq) {   // SWIM_F_UNBOUNDED_QUEUE (swim_device.h): 8 more bytes per pair, the queue word in its own column-major layout
-      const size_t epairs = (size_t)D.R * cdiv(D.nloc, 64) * D.MB * 4096;
+      const size_t epairs = (size_t)D.R * cdiv(D.nloc, 64) * D.MB * 64 * SW_IQ_RB;
       DALLOC(s, D.mE, epairs); DALLOC(s, D.mF, pairs); DALLOC(s, D.iqn, NL);
       HIPCK(s, hipMemsetAsync(D.mE, 0, epairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.mF, 0, pairs * 4, s->stream)); HIPCK(s, hipMemsetAsync(D.iqn, 0, NL * 4, s->stream));
       D.ord_cap = 16;

@@ -103,9 +103,13 @@ __device__ __forceinline__ uint32_t vt_find(DevRef D, size_t l, uint32_t x, uint
 __device__ __forceinline__ size_t m_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
   return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.M + row) << 6) + (k & 63u);
 }
-// the queue word of pair (row, lane k) — SWIM_F_UNBOUNDED_QUEUE, swim_device.h: [replica][64 observers][64 rows][observer][row]
+// the queue word of pair (row, lane k) — SWIM_F_UNBOUNDED_QUEUE, swim_device.h: [replica][64 observers][256 rows][observer][row]
 __device__ __forceinline__ size_t e_idx(DevRef D, uint32_t r, uint32_t row, uint32_t k) {
-  return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB + (row >> 6)) * 64u + (k & 63u)) * 64u + (row & 63u);
+  return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB + (row / SW_IQ_RB)) * 64u + (k & 63u)) * SW_IQ_RB + (row % SW_IQ_RB);
+}
+// ... and where lane k's column starts: row block rb of it is the SW_IQ_RB words at + rb * 64 * SW_IQ_RB
+__device__ __forceinline__ size_t e_col(DevRef D, uint32_t r, uint32_t k) {
+  return ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * SW_IQ_RB;
 }
 // a pair as a view-table entry {subject, inc<<2|state, state-change ms, w} (w as in vt) + the second accuser
 __device__ __forceinline__ uint4 m_unpack(DevRef D, uint32_t x, uint32_t a, uint32_t b, uint32_t c, uint32_t& conf1) {
@@ -4325,6 +4329,24 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
 // checker walks its sorted queue: take what fits, bump transmits after the sweep, retire at the retransmit limit.  The node's rumour about
 // ITSELF and rumours about subjects without a row sit in the queue_cap slots as before and take part in the same order.
 // =================================================================================================
+#ifdef SWIMSIM_DIAG
+// diagnostics (-DSWIMSIM_DIAG builds, SWIMSIM_IQCLK=1): where a wave of k_gossip_iq spends a node — s_memtime ticks summed over all nodes:
+// [0] the column scan with its compactions, [1] the compactions alone, [2] picks + bumps + re-sorts, [3] the packets' loads, filter and records,
+// [4] write-back, [5] nodes, [6] compactions, [7] row blocks read
+// (tallied per workgroup in LDS, one global atomic per counter and workgroup: the first version added to the global counters per batch of the
+// scan — 7 M same-address atomics a tick, 12 ns apiece, made the "scan" 95 % of a node and the kernel 4x slower: the clock measured itself)
+__device__ unsigned long long g_iqclk[8];
+__shared__ unsigned long long g_s_iqclk[8];
+#define IQCLK_T() __builtin_amdgcn_s_memtime()
+#define IQCLK_ADD(i, v) do { if (sw_lane() == 0) atomicAdd(&g_s_iqclk[i], (unsigned long long)(v)); } while (0)
+#define IQCLK_INIT() do { if (threadIdx.x < 8) g_s_iqclk[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define IQCLK_FLUSH() do { __syncthreads(); if (threadIdx.x < 8 && g_s_iqclk[threadIdx.x]) atomicAdd(&g_iqclk[threadIdx.x], g_s_iqclk[threadIdx.x]); } while (0)
+#else
+#define IQCLK_T() 0ull
+#define IQCLK_ADD(i, v) do { } while (0)
+#define IQCLK_INIT() do { } while (0)
+#define IQCLK_FLUSH() do { } while (0)
+#endif
 #define IQ_DIRTY 0x80000000u
 #define IQ_EXPL 0x40000000u
 #define IQ_RETIRED 0xFFFFFFFFu
@@ -4394,32 +4416,40 @@ __device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, 
     if (have) W.pool[(uint32_t)__popcll(m & lt)] = ((unsigned long long)iq_key(D, m_tr(w), m_type(w), m_seq(w)) << 32) | IQ_EXPL | (m_type(w) << 28) | lane;
     n = (uint32_t)__popcll(m);
   }
-  const uint32_t* col = D.mE + ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * 64u + lane;
+  const uint4* col = (const uint4*)(D.mE + e_col(D, r, k)) + lane;
   uint32_t seen = 0;
-  // The scan is a chain of round trips (the next batch is only asked for when this one says there is more to see), so a batch is SIXTEEN
-  // independent 256-byte runs: with four, 410 row blocks were a hundred round trips per node — 200 us of a wave's life, most of the launch
-  // (profiles/r06_config4_524k_first.txt) — and 16 waves x 16 runs x 256 bytes per CU is also what 8 TB/s x 2 us of latency wants in flight.
-  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 16) {
-    uint32_t ew[16];
+  // The scan is a chain of round trips (the next batch is only asked for when this one says there is more to see).  A lane reads FOUR
+  // consecutive rows per load — a kilobyte per wave and request — and a batch is eight independent requests.  (First version: a dword per lane,
+  // 256 bytes per request, four and then sixteen requests per batch: the phase clock — profiles/r06_iq_phase_clock.txt — showed a node spending
+  // 95 % of its 360 us in the scan, 13 us per batch, the whole device moving 1.2 TB/s: the requests in flight per CU, not the bytes, were the
+  // limit.)
+  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 8) {
+    uint4 ew[8];
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * 4096u] : 0u;
+    for (uint32_t u = 0; u < 8; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * (64u * SW_IQ_RB / 4u)] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (uint32_t u = 0; u < 16; u++) {
-      const uint32_t e = ew[u];
-      const bool q = (e & QE_QUEUED) != 0;
-      const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
-      const bool qual = q && key < (rk == 0 ? thr0 : rk == 1 ? thr1 : thr2);
-      seen += (uint32_t)__popcll(__ballot(q));
-      const uint64_t mm = __ballot(qual);
-      if (mm) {
-        if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * 64u + lane);
-        n += (uint32_t)__popcll(mm);
-        if (n + 64u > SW_IQ_POOL) { wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); }
+    for (uint32_t u = 0; u < 8; u++) {
+      if (!__any((ew[u].x | ew[u].y | ew[u].z | ew[u].w) & QE_QUEUED)) continue;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
+        const bool q = (e & QE_QUEUED) != 0;
+        const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
+        const bool qual = q && key < (rk == 0 ? thr0 : rk == 1 ? thr1 : thr2);
+        seen += (uint32_t)__popcll(__ballot(q));
+        const uint64_t mm = __ballot(qual);
+        if (mm) {
+          if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
+          n += (uint32_t)__popcll(mm);
+          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+        }
       }
     }
+    IQCLK_ADD(7, 8);
   }
   wave_lds_sync();
-  return iq_compact(D, W.pool, n, npk, thr0, thr1, thr2);
+  { const unsigned long long tc_ = IQCLK_T(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+  return n;
 }
 // one GetBroadcasts(2, limit) over the sorted candidates, W.taken[0, returned) = what it took, in the order it took them.  The walk is
 // queue.go's — down the order, take what fits, the space left only shrinks — done 64 candidates at a time: among the entries of a chunk that
@@ -4499,7 +4529,7 @@ __device__ uint32_t iq_writeback(DevRef D, const IqWave& W, uint32_t n, uint32_t
   const uint32_t lane = sw_lane();
   if (lane < 32) W.xq[lane] = 0;
   wave_lds_sync();
-  uint32_t* col = D.mE + ((((size_t)r * ((D.nloc + 63u) >> 6) + (k >> 6)) * D.MB) * 64u + (k & 63u)) * 64u;
+  uint32_t* col = D.mE + e_col(D, r, k);
   uint32_t retired = 0;
   for (uint32_t c0 = 0; c0 < n; c0 += 64) {
     const uint32_t idx = c0 + lane;
@@ -4510,7 +4540,7 @@ __device__ uint32_t iq_writeback(DevRef D, const IqWave& W, uint32_t n, uint32_t
       if (src & IQ_DIRTY) {
         const uint32_t seq = 0x3FFFFFu - (key & 0x3FFFFFu);
         if (src & IQ_EXPL) W.xq[at] = key == IQ_RETIRED ? 0xFFFFFFFFu : m_pack(type, key >> 24, seq);
-        else { gone = key == IQ_RETIRED; col[(size_t)(at >> 6) * 4096u + (at & 63u)] = gone ? 0u : QE_PACK(key >> 24, type, seq); }
+        else { gone = key == IQ_RETIRED; col[(size_t)(at / SW_IQ_RB) * (64u * SW_IQ_RB) + (at % SW_IQ_RB)] = gone ? 0u : QE_PACK(key >> 24, type, seq); }
       }
     }
     retired += (uint32_t)__popcll(__ballot(gone));
@@ -4598,6 +4628,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
   BlockStats S; S.init(lds_stats);
   if (threadIdx.x == 0) s_cnt[0] = 0;
   __syncthreads();
+  IQCLK_INIT();
   const IqWave W = iq_strip(s_strips);
   const bool filter = (D.flags & SWIM_F_FILTER_NOOP) != 0;
   bool holds = false;
@@ -4634,7 +4665,9 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
     const uint32_t rl = D.retransmit_limit;
     uint32_t live_e = evqlen >= 32 ? 0xFFFFFFFFu : (1u << evqlen) - 1u, touched_e = 0;
     if (SERF && lane < evqlen) W.evm[lane] = D.evq[(size_t)lane * NL + lj].w;
+    const unsigned long long tq0_ = IQCLK_T();
     uint32_t n = iq_build(D, W, r, k, lj, NL, qlen, iq_j, n_found);
+    const unsigned long long tq1_ = IQCLK_T();
     bool any_taken = false;
     // every packet's GetBroadcasts first — nothing they decide waits for memory — then ONE round of loads for all they send (a packet at a
     // time it was three dependent round trips per packet: the entry, the subject's words, the receiver's view)
@@ -4658,6 +4691,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
       iq_bump(W, n, nt, rl, p + 1 < n_found);
     }
     wave_lds_sync();
+    const unsigned long long tq2_ = IQCLK_T();
     {
       uint32_t x_[4], own_a[4], own_f[4], rcv_a[4], src_[4]; uint4 ex_[4]; bool on_[4];
 #pragma unroll
@@ -4711,6 +4745,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
       }
     }
     // ---- the queues back where they live
+    const unsigned long long tq3_ = IQCLK_T();
     uint32_t nq = qlen, ne = evqlen;
     if (any_taken) {
       const uint32_t retired = iq_writeback(D, W, n, r, k);
@@ -4726,6 +4761,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
     }
     holds |= (nq | ne | iq_j) != 0;
     wave_lds_sync();
+    IQCLK_ADD(0, tq1_ - tq0_); IQCLK_ADD(2, tq2_ - tq1_); IQCLK_ADD(3, tq3_ - tq2_); IQCLK_ADD(4, IQCLK_T() - tq3_); IQCLK_ADD(5, 1);
   }
   if (lane == 0) {
     S.add(ST_PKT_SENT, c_pkt); S.add(ST_PKT_DROP, c_drop); S.add(ST_FILTERED, c_filt);
@@ -4737,6 +4773,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
     const uint32_t c = s_cnt[0];
     if (c) { D.seg_cnt[r * D.nb_gossip + bx] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); }
   }
+  IQCLK_FLUSH();
   S.flush(D);
 }
 
@@ -4753,6 +4790,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_piggy_iq(const SwDev* __restrict__
   const uint32_t lane = sw_lane(), wv = threadIdx.x / 64, t = *D.tick;
   const size_t NL = (size_t)D.R * D.nloc;
   BlockStats S; S.init(lds_stats);
+  IQCLK_INIT();                                    // (its scans tally into the workgroup's words too; only k_gossip_iq's are reported)
   const IqWave W = iq_strip(s_strips);
   uint2* const so = s_ord + wv * 64;
   const uint32_t n_nodes = *D.ord_n;
@@ -4862,21 +4900,20 @@ __global__ void __launch_bounds__(SW_BLOCK) k_piggy_iq(const SwDev* __restrict__
 // rumour with it) — the same rule in the checker (q_cnt).  A workgroup per (replica, 64-row block) reads the block's queue words coalesced.
 __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_iq(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
-  __shared__ uint32_t s_busy[64];
+  __shared__ uint32_t s_busy[SW_IQ_RB];
   const uint32_t r = blockIdx.x / D.MB, rb = blockIdx.x % D.MB, G = (D.nloc + 63u) >> 6;
-  if (threadIdx.x < 64) s_busy[threadIdx.x] = 0;
+  for (uint32_t w = threadIdx.x; w < SW_IQ_RB; w += SW_BLOCK) s_busy[w] = 0;
   __syncthreads();
   for (uint32_t g = 0; g < G; g++) {
-    const uint32_t* reg = D.mE + (((size_t)r * G + g) * D.MB + rb) * 4096u;
-    for (uint32_t w = threadIdx.x; w < 4096u; w += SW_BLOCK) if (reg[w] & QE_QUEUED) s_busy[w & 63u] = 1;
+    const uint32_t* reg = D.mE + (((size_t)r * G + g) * D.MB + rb) * (64u * SW_IQ_RB);
+    for (uint32_t w = threadIdx.x; w < 64u * SW_IQ_RB; w += SW_BLOCK) if (reg[w] & QE_QUEUED) s_busy[w % SW_IQ_RB] = 1;
   }
   __syncthreads();
-  if (threadIdx.x < 64 && s_busy[threadIdx.x]) {
-    const uint32_t row = rb * 64u + threadIdx.x;
+  for (uint32_t w = threadIdx.x; w < SW_IQ_RB; w += SW_BLOCK) if (s_busy[w]) {
+    const uint32_t row = rb * SW_IQ_RB + w;
     if (row < D.M) { const uint32_t x = D.mrow_subj[(size_t)r * D.M + row]; if (x != NONE) D.fl_bad[(size_t)r * D.N + x] = 1; }
   }
 }
-
 // pooled inbox rows (swim_device.h: inbox_big): every node with deferred arrivals gets a big row — one CAS winner per node allocates, the
 // others do nothing (no lane ever waits for another); the kernel boundary publishes the rows to k_inbox_file
 __global__ void __launch_bounds__(SW_BLOCK) k_inbox_claim(const SwDev* __restrict__ Dp) {

@@ -63,3 +63,4 @@ for sec in range(1, a.seconds + 1):
 if a.profile:
     print({k: (v[0], round(v[1], 2)) for k, v in s.profile_read().items()})
 print("full detection after", done, "s of simulated time;", "wall %.1f s" % (time.time() - t0))
+s.close()
