@@ -346,7 +346,7 @@ extern "C" int swim_destroy(swim_sim* s) {
     if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_iqclk), sizeof c) == hipSuccess && c[5]) {
       static const char* const nm[5] = { "column scan (with its compactions)", "  compactions alone", "picks + bumps + re-sorts", "loads, filter, records", "write-back" };
       const double nn = (double)c[5], tot = (double)(c[0] + c[2] + c[3] + c[4]);
-      fprintf(stderr, "[iq clk] %llu nodes, %.2f compactions and %.1f row blocks per node; s_memtime ticks per node: %.0f\n", c[5], c[6] / nn, c[7] / nn, tot / nn);
+      fprintf(stderr, "[iq clk] %llu nodes, %.2f compactions per node; s_memtime ticks per node: %.0f; of the scan, waiting for the batches' loads: %.0f (the piggy-back kernel's scans add to this one)\n", c[5], c[6] / nn, tot / nn, c[7] / nn);
       for (int p = 0; p < 5; p++) fprintf(stderr, "[iq clk]   %-36s %9.0f  %5.1f %%\n", nm[p], c[p] / nn, 100.0 * c[p] / tot);
     }
   }

@@ -4332,7 +4332,7 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
 #ifdef SWIMSIM_DIAG
 // diagnostics (-DSWIMSIM_DIAG builds, SWIMSIM_IQCLK=1): where a wave of k_gossip_iq spends a node — s_memtime ticks summed over all nodes:
 // [0] the column scan with its compactions, [1] the compactions alone, [2] picks + bumps + re-sorts, [3] the packets' loads, filter and records,
-// [4] write-back, [5] nodes, [6] compactions, [7] row blocks read
+// [4] write-back, [5] nodes, [6] compactions, [7] of the scan: waiting for the batches' loads
 // (tallied per workgroup in LDS, one global atomic per counter and workgroup: the first version added to the global counters per batch of the
 // scan — 7 M same-address atomics a tick, 12 ns apiece, made the "scan" 95 % of a node and the kernel 4x slower: the clock measured itself)
 __device__ unsigned long long g_iqclk[8];
@@ -4350,13 +4350,19 @@ __shared__ unsigned long long g_s_iqclk[8];
 #define IQ_DIRTY 0x80000000u
 #define IQ_EXPL 0x40000000u
 #define IQ_RETIRED 0xFFFFFFFFu
-struct IqWave { unsigned long long* pool; uint32_t* taken; uint32_t* evm; uint32_t* xq; uint32_t* scal; uint32_t* sent; };   // one wave's strip of LDS (sent: what each of up to four packets took)
+// (LDS-typed pointers: handed around as plain pointers the strip's accesses became flat_load / flat_store with a full s_waitcnt each, and the
+// thresholds a reference parameter in scratch memory — 1 500 cycles per 64 candidates looked at, 95 % of the kernel: profiles/r06_iq_phase_clock_v2.txt)
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct IqWave { lds_u64* pool; lds_u32* taken; lds_u32* evm; lds_u32* xq; lds_u32* scal; lds_u32* sent; };   // one wave's strip of LDS (sent: what each of up to four packets took)
+struct IqThr { uint32_t t0, t1, t2; };
+struct LdsMetaQ { lds_u32* p; __device__ __forceinline__ lds_u32& meta(uint32_t j) const { return p[j]; } };
 __device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type, uint32_t seq) {
   return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
 }
 __device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1ull; }
 // bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave (each pair belongs to the lane that holds its lower index)
-__device__ void iq_sort(unsigned long long* pool, uint32_t P) {
+__device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
   const uint32_t lane = sw_lane();
   for (uint32_t k = 2; k <= P; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -4370,7 +4376,7 @@ __device__ void iq_sort(unsigned long long* pool, uint32_t P) {
       wave_lds_sync();
     }
 }
-__device__ void iq_resort(unsigned long long* pool, uint32_t n) {
+__device__ __forceinline__ void iq_resort(lds_u64* pool, uint32_t n) {
   uint32_t P = 64; while (P < n) P <<= 1;
   for (uint32_t idx = n + sw_lane(); idx < P; idx += 64) pool[idx] = ~0ull;
   wave_lds_sync();
@@ -4378,7 +4384,7 @@ __device__ void iq_resort(unsigned long long* pool, uint32_t n) {
 }
 // sort the pool and keep, per length rank, the keep[rank] x npk entries that sort first; thr[rank] = the key from which on nothing of that
 // rank needs to be looked at any more (0xFFFFFFFF while fewer are known)
-__device__ uint32_t iq_compact(DevRef D, unsigned long long* pool, uint32_t n, uint32_t npk, uint32_t& thr0, uint32_t& thr1, uint32_t& thr2) {
+__device__ __forceinline__ uint32_t iq_compact(DevRef D, lds_u64* pool, uint32_t n, uint32_t npk, IqThr& thr) {
   iq_resort(pool, n);
   const uint64_t lt = iq_ltmask();
   uint32_t base0 = 0, base1 = 0, base2 = 0, m = 0;
@@ -4395,7 +4401,7 @@ __device__ uint32_t iq_compact(DevRef D, unsigned long long* pool, uint32_t n, u
     const uint64_t ml = __ballot(valid && pos + 1 == K);           // the last one kept of a rank: the rank's threshold from now on
     for (uint64_t q = ml; q; q &= q - 1) {
       const uint32_t src = (uint32_t)__ffsll((long long)q) - 1, k2 = __shfl(key, src), r2 = (k2 >> 22) & 3u;
-      if (r2 == 0) thr0 = k2; else if (r2 == 1) thr1 = k2; else thr2 = k2;
+      if (r2 == 0) thr.t0 = k2; else if (r2 == 1) thr.t1 = k2; else thr.t2 = k2;
     }
     const uint64_t mk = __ballot(keep);
     if (keep) pool[m + (uint32_t)__popcll(mk & lt)] = e;          // (forward compaction: never past the lane's own index, and this chunk has been read)
@@ -4406,9 +4412,9 @@ __device__ uint32_t iq_compact(DevRef D, unsigned long long* pool, uint32_t n, u
   return m;                                                         // (the survivors are in order already: a stable compaction of a sorted pool)
 }
 // the candidates of node (r, local k, lane l): its slots' entries and what its column implies; sorted on return
-__device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
+__device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
-  uint32_t n = 0, thr0 = 0xFFFFFFFFu, thr1 = 0xFFFFFFFFu, thr2 = 0xFFFFFFFFu;
+  uint32_t n = 0; IqThr thr = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
   {
     const bool have = lane < qlen;
     const uint32_t w = have ? QENT(lane, l).w : 0u;
@@ -4426,36 +4432,42 @@ __device__ uint32_t iq_build(DevRef D, const IqWave& W, uint32_t r, uint32_t k, 
   for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 8) {
     uint4 ew[8];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) ew[u] = rb0 + u < D.MB ? col[(size_t)(rb0 + u) * (64u * SW_IQ_RB / 4u)] : make_uint4(0, 0, 0, 0);
+    for (uint32_t u = 0; u < 8; u++) ew[u] = ld_global_u4(col + (size_t)(rb0 + u < D.MB ? rb0 + u : D.MB - 1u) * (64u * SW_IQ_RB / 4u));     // (unconditional: a conditional load became a loop of single round trips)
+#ifdef SWIMSIM_DIAG
+    { const unsigned long long tw_ = IQCLK_T(); uint32_t any_ = 0;
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) any_ |= ew[u].x ^ ew[u].w;
+      if (__any(any_ == 0x12345u)) IQCLK_ADD(6, 1);               // (uses every load's result: the wait for the batch ends here)
+      IQCLK_ADD(7, IQCLK_T() - tw_); }
+#endif
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) {
-      if (!__any((ew[u].x | ew[u].y | ew[u].z | ew[u].w) & QE_QUEUED)) continue;
+      if (rb0 + u >= D.MB || !__any((ew[u].x | ew[u].y | ew[u].z | ew[u].w) & QE_QUEUED)) continue;
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
         const bool q = (e & QE_QUEUED) != 0;
         const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
-        const bool qual = q && key < (rk == 0 ? thr0 : rk == 1 ? thr1 : thr2);
+        const bool qual = q && key < (rk == 0 ? thr.t0 : rk == 1 ? thr.t1 : thr.t2);
         seen += (uint32_t)__popcll(__ballot(q));
         const uint64_t mm = __ballot(qual);
         if (mm) {
           if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
           n += (uint32_t)__popcll(mm);
-          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
         }
       }
     }
-    IQCLK_ADD(7, 8);
   }
   wave_lds_sync();
-  { const unsigned long long tc_ = IQCLK_T(); n = iq_compact(D, W.pool, n, npk, thr0, thr1, thr2); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+  { const unsigned long long tc_ = IQCLK_T(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
   return n;
 }
 // one GetBroadcasts(2, limit) over the sorted candidates, W.taken[0, returned) = what it took, in the order it took them.  The walk is
 // queue.go's — down the order, take what fits, the space left only shrinks — done 64 candidates at a time: among the entries of a chunk that
 // still fit on their own, a prefix sum of their costs says how far the packet takes them in one go; the first one that no longer fits is
 // skipped for good (it cannot fit later either) and the walk resumes behind it, with fewer bytes, for the shorter ones.
-__device__ uint32_t iq_pick(DevRef D, const IqWave& W, uint32_t n, int limit, int& used_out) {
+__device__ __forceinline__ uint32_t iq_pick(DevRef D, const IqWave W, uint32_t n, int limit, int& used_out) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
   int used = 0; uint32_t nt = 0; bool full = false;
   for (uint32_t c0 = 0; c0 < n && !full; c0 += 64) {
@@ -4492,10 +4504,10 @@ __device__ uint32_t iq_pick(DevRef D, const IqWave& W, uint32_t n, int limit, in
   return nt;
 }
 // the serf delegate's share of the same packet (the user-event queue: <= 32 entries, meta words staged in W.evm): lane 0 picks
-__device__ uint32_t iq_pick_events(DevRef D, const IqWave& W, uint32_t evqlen, uint32_t& live_e, int avail, uint32_t rl) {
+__device__ __forceinline__ uint32_t iq_pick_events(DevRef D, const IqWave W, uint32_t evqlen, uint32_t& live_e, int avail, uint32_t rl) {
   if (sw_lane() == 0) {
     int used2 = 0; uint32_t le = live_e;
-    const uint32_t te = get_broadcasts(D, MetaQT<1>{W.evm}, evqlen, le, 3, avail, used2, rl);
+    const uint32_t te = get_broadcasts(D, LdsMetaQ{W.evm}, evqlen, le, 3, avail, used2, rl);
     W.scal[2] = te; W.scal[3] = le;
   }
   wave_lds_sync();
@@ -4511,7 +4523,7 @@ __device__ __forceinline__ uint4 iq_entry(DevRef D, unsigned long long pe, uint3
   return make_uint4(D.mrow_subj[(size_t)r * D.M + idx], MA_INC(a) + QF_DELTA(f), QF_FROM(f), type << 30);
 }
 // after the sweep: what was taken has one more transmit, or is Finished(); the order is restored for the next packet
-__device__ void iq_bump(const IqWave& W, uint32_t n, uint32_t nt, uint32_t rl, bool resort) {
+__device__ __forceinline__ void iq_bump(const IqWave W, uint32_t n, uint32_t nt, uint32_t rl, bool resort) {
   const uint32_t lane = sw_lane();
   if (lane < nt) {
     const uint32_t q = W.taken[lane];
@@ -4525,7 +4537,7 @@ __device__ void iq_bump(const IqWave& W, uint32_t n, uint32_t nt, uint32_t rl, b
 }
 // the transmit counts back where they live; returns how many implied rumours retired.  W.xq[slot] = the new meta word of a slot's entry
 // (0 = untouched, 0xFFFFFFFF = retired) for iq_store_slots
-__device__ uint32_t iq_writeback(DevRef D, const IqWave& W, uint32_t n, uint32_t r, uint32_t k) {
+__device__ __forceinline__ uint32_t iq_writeback(DevRef D, const IqWave W, uint32_t n, uint32_t r, uint32_t k) {
   const uint32_t lane = sw_lane();
   if (lane < 32) W.xq[lane] = 0;
   wave_lds_sync();
@@ -4549,7 +4561,7 @@ __device__ uint32_t iq_writeback(DevRef D, const IqWave& W, uint32_t n, uint32_t
   return retired;
 }
 // the slots' entries (memberlist queue_cap slots, then serf's event queue) written back compacted, like the gossip role's write-back
-__device__ uint32_t iq_store_slots(DevRef D, const IqWave& W, size_t l, size_t NL, uint32_t qlen) {
+__device__ __forceinline__ uint32_t iq_store_slots(DevRef D, const IqWave W, size_t l, size_t NL, uint32_t qlen) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
   const bool have = lane < qlen;
   uint4 e = have ? QENT(lane, l) : make_uint4(0, 0, 0, 0);
@@ -4561,7 +4573,7 @@ __device__ uint32_t iq_store_slots(DevRef D, const IqWave& W, size_t l, size_t N
   if (live && (pos != lane || nm)) QENT(pos, l) = e;
   return (uint32_t)__popcll(mk);
 }
-__device__ uint32_t iq_store_events(DevRef D, const IqWave& W, size_t l, size_t NL, uint32_t evqlen, uint32_t live_e, uint32_t touched) {
+__device__ __forceinline__ uint32_t iq_store_events(DevRef D, const IqWave W, size_t l, size_t NL, uint32_t evqlen, uint32_t live_e, uint32_t touched) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
   const bool have = lane < evqlen;
   uint4 e = have ? D.evq[(size_t)lane * NL + l] : make_uint4(0, 0, 0, 0);
@@ -4576,8 +4588,8 @@ __device__ __forceinline__ uint32_t iq_nth_bit(uint32_t m, uint32_t n) { for (ui
 
 #define SW_IQ_STRIP_WORDS (SW_IQ_POOL * 2u + SW_IQ_PKT + 32u + 32u + 8u + 4u * SW_IQ_PKT)
 __device__ __forceinline__ IqWave iq_strip(uint32_t* base) {
-  uint32_t* p = base + (threadIdx.x / 64u) * SW_IQ_STRIP_WORDS;
-  IqWave W; W.pool = (unsigned long long*)p; W.taken = p + SW_IQ_POOL * 2u; W.evm = W.taken + SW_IQ_PKT; W.xq = W.evm + 32u; W.scal = W.xq + 32u; W.sent = W.scal + 8u;
+  lds_u32* p = (lds_u32*)base + (threadIdx.x / 64u) * SW_IQ_STRIP_WORDS;
+  IqWave W; W.pool = (lds_u64*)p; W.taken = p + SW_IQ_POOL * 2u; W.evm = W.taken + SW_IQ_PKT; W.xq = W.evm + 32u; W.scal = W.xq + 32u; W.sent = W.scal + 8u;
   return W;
 }
 
