@@ -320,12 +320,15 @@ def run_config4(hip, args, device) -> dict:
     (swim_detection_get).  The victims are STOPPED: for the survivors — whose detection the config measures — a minority that
     is cut off and one that is down are the same thing (no packet crosses either way), while the cut-off minority's own views
     of the majority would be another 13 G pairs beside the survivors' 13 G.  Every survivor's view of every victim
-    lives in the dense pair store (mass_rows): view_drops must be 0.  memberlist's queue is unbounded; ours holds queue_cap
-    entries with Prune() semantics — `queue_cap_cost` has what smaller caps cost in rounds (measured at 262 144 nodes)."""
+    lives in the dense pair store (mass_rows): view_drops must be 0.  memberlist's TransmitLimitedQueue is UNBOUNDED, and since round 6 so is
+    this leg's (SWIM_F_UNBOUNDED_QUEUE: the rumour a node has queued about a victim lives in the pair, GetBroadcasts selects over the node's
+    column — DESIGN 4b): queue_drops must be 0 too.  --bounded-queue runs the leg as rounds 3-5 did (queue_cap slots with Prune())."""
     n, share = args.config4_nodes, 0.05
     nv = int(n * share)
-    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=args.config4_queue_cap, inbox_cap=min(2 * nv + 256, 8192),
-              subject_cap=4, gossip_nodes=3, device=device)
+    uq = not getattr(args, "bounded_queue", False)
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=8 if uq else args.config4_queue_cap,
+              inbox_cap=(1 << (nv + 5000).bit_length()) if uq else min(2 * nv + 256, 8192),      # (a state exchange hands a node most of a table: pooled rows)
+              subject_cap=4, gossip_nodes=3, device=device, flags=abi.F_DEFAULT | (abi.F_UNBOUNDED_QUEUE if uq else 0))
     victims = np.random.default_rng(args.seed).choice(n, size=nv, replace=False)
     s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
     G, q = s.derived.gossip_period, s.derived.quantum_ms
@@ -336,7 +339,7 @@ def run_config4(hip, args, device) -> dict:
     budget = args.config4_budget_s
     sec = 0
     while sec < 4000:
-        step = 10 if sec < 100 else 50
+        step = 10 if sec < 100 else (20 if uq else 50)
         s.step_ms(1000 * step); sec += step
         s.sync()
         pairs, by = s.detection(0)
@@ -353,24 +356,26 @@ def run_config4(hip, args, device) -> dict:
     st = diff_stats(s0, s.stats())
     ticks = sec * 1000 // q
     out = {"workload": f"BASELINE configs[3], one GPU's share: {n} nodes, {nv} stopped at once at t = 1 s, LAN timers, k = 3; run to full detection "
-                       f"(every survivor holds every victim dead); dense pair store, queue_cap {kw['queue_cap']}",
+                       f"(every survivor holds every victim dead); dense pair store, " + ("memberlist's unbounded queue (implied by the pair store)" if uq else f"queue_cap {kw['queue_cap']}"),
            "n_nodes": n, "victims": nv, "pairs": int((n - nv)) * nv,
            "detection_complete": done is not None,
            "rounds_to_full_detection": done * 1000 // q // G if done else None, "simulated_s_to_full_detection": done,
            "simulated_s": sec, "wall_s": round(dt, 2), "rounds_per_sec": sec * 1000 / q / G / dt, "value": n * (sec * 1000 / q / G) / dt, "unit": "node-rounds/s",
            "first_60_s": {"wall_s": round(heavy, 2), "ms_per_round": 1000.0 * heavy / (60000 / q / G)} if heavy else None,
-           "view_drops": st["view_drops"], "view_evictions": st["view_evictions"], "queue_cap": kw["queue_cap"], "queue_drops": st["queue_drops"],
-           "queue_depth_peak": kw["queue_cap"] if st["queue_drops"] else None,
+           "view_drops": st["view_drops"], "view_evictions": st["view_evictions"], "queue": "unbounded (SWIM_F_UNBOUNDED_QUEUE)" if uq else f"{kw['queue_cap']} slots, Prune()",
+           "queue_drops": st["queue_drops"],
            "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"], "push_pulls": st["push_pulls"],
            "edges": st["edges"], "msgs_applied": sum(st["msgs_applied"]), "suspicion_timeouts": st["suspicion_timeouts"],
            # what would cross xGMI if this population were one of 8 shards: 7/8 of the records, 16 bytes each
            "a2a_bytes_per_tick_if_one_of_8_shards": {"mean": 16.0 * 7 / 8 * st["edges"] / max(ticks, 1)},
-           "pair_store_GB": round(12.0 * (nv + 8) * n / 1e9, 1),
-           "what_the_answer_is_a_property_of": "the 32-entry queue, NOT memberlist: memberlist's TransmitLimitedQueue is unbounded.  The checker (whose queue holds up to 4 096 "
-                                               "since round 5) reaches full detection of this shape at 8 192 nodes / 409 stopped after 396 / 361 / 336 / 266 / 306 / 51 / 31 s with "
-                                               "8 / 16 / 32 / 64 / 128 / 256 / 4 096 entries: with every victim's rumour queued at once detection is the suspicion timeout plus one "
-                                               "dissemination, with 32 entries the rumours take turns for ten times as long.  An unbounded queue per virtual node does not fit "
-                                               "(440 GB at this size): DESIGN.md 8 / 10",
+           "pair_store_GB": round((20.0 if uq else 12.0) * (nv + 8) * n / 1e9, 1),
+           "what_the_answer_is_a_property_of": ("memberlist's own queue: unbounded, nothing pruned (queue_drops 0).  What takes the time at this size is the PACKET: every node holds a rumour "
+                                                "about every one of the victims, each wants retransmitLimit = 24 transmissions, and a 1 398-byte packet takes 27 of them — 81 per gossip "
+                                                "round and node, three hundred rounds for one pass over the queue; detection ends when the last (survivor, victim) pair has either heard "
+                                                "the rumour or run out its own suspicion timer.  The same shape on the checker: 31 s at 8 192 nodes / 409 stopped, 46 s at 16 384 / 819 "
+                                                "(profiles/r05_queue_cap_sweep.txt); on the device 160 s at 65 536, 560 s at 262 144, 820 s at 524 288 (profiles/r06_*)") if uq else
+                                               ("the bounded queue, NOT memberlist (--bounded-queue): memberlist's TransmitLimitedQueue is unbounded; with 32 slots and Prune() the rumours take "
+                                                "turns for several times as long (checker, 8 192 nodes: 336 s against 31 s)"),
            "quoted_from_profiles": {"queue_cap_cost_on_the_device": {"measured_at": "262144 nodes / 13107 stopped (profiles/r03_config4_queue_cap.txt)",
                                                                      "simulated_s_to_full_detection": {"8": 1400, "16": 1200, "32": 1100}},
                                     "queue_cap_sweep_on_the_checker": {"measured_at": "8192 nodes / 409 stopped (profiles/r05_queue_cap_sweep.txt)",
@@ -397,8 +402,9 @@ def run_config4_partition(hip, args, device) -> dict:
     mask = np.zeros(n, dtype=np.uint8); mask[rng.choice(n, size=nv, replace=False)] = 1
     minority, majority = np.flatnonzero(mask), np.flatnonzero(mask == 0)
     watchers = [int(x) for x in majority[:4]] + [int(x) for x in minority[:4]]
-    kw = dict(n_nodes=n, seed=args.seed + 4, view_cap=8, mass_rows=n, queue_cap=32, inbox_cap=n // 2, subject_cap=4, gossip_nodes=3,
-              fold_interval_ms=5000, reconnect_interval_ms=30000, device=device)
+    uq = not getattr(args, "bounded_queue", False)
+    kw = dict(n_nodes=n, seed=args.seed + 4, view_cap=8, mass_rows=n, queue_cap=8 if uq else 32, inbox_cap=n // 2, subject_cap=4, gossip_nodes=3,
+              fold_interval_ms=5000, reconnect_interval_ms=30000, device=device, flags=abi.F_DEFAULT | (abi.F_UNBOUNDED_QUEUE if uq else 0))
     s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
     G, q = s.derived.gossip_period, s.derived.quantum_ms
     s.step_ms(1000); s.partition(0, mask); s.sync()
@@ -435,13 +441,13 @@ def run_config4_partition(hip, args, device) -> dict:
     st = diff_stats(s0, s.stats())
     out = {"gave_up_on_wall_time_budget_s": budget if gave_up and recovered is None else None,
            "workload": f"BASELINE configs[3] as written, {n} nodes on one GPU: {nv} cut off (partition, both directions) at t = 1 s for {cut_s} s, then heal + "
-                       "serf reconnect (30 s) + push-pull + folds; dense pair store with a row for every node, queue_cap 32",
+                       "serf reconnect (30 s) + push-pull + folds; dense pair store with a row for every node, " + ("memberlist's unbounded queue (implied by the pair store)" if uq else "queue_cap 32"),
            "n_nodes": n, "cut_off": nv, "cut_s": cut_s, "at_heal": at_heal, "watchers": "4 majority + 4 minority observers",
            "recovered_for_the_watchers_at_s": recovered, "simulated_s": sec, "wall_s": round(dt, 2), "wall_s_of_the_cut": round(t_cut, 2),
            "rounds_per_sec": sec * 1000 / q / G / dt, "value": n * (sec * 1000 / q / G) / dt, "unit": "node-rounds/s",
            "refutes": st["refutes"], "reconnects": st["reconnects"], "reconnects_reached": st["reconnects_reached"], "push_pulls": st["push_pulls"],
            "folds": st["folds"], "rows_freed_by_folds": st["fold_freed"], "view_drops": st["view_drops"], "queue_drops": st["queue_drops"],
-           "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"], "pair_store_GB": round(12.0 * n * n / 1e9, 1), "curve": curve}
+           "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"], "pair_store_GB": round((20.0 if uq else 12.0) * n * n / 1e9, 1), "curve": curve}
     s.close()
     return out
 
@@ -520,7 +526,10 @@ def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, ba
             "a2a_bytes_per_tick_all_ranks": 16.0 * st["edges_remote"] / ticks, "a2a_bytes_per_tick_per_rank": 16.0 * st["edges_remote"] / ticks / world,
             "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_overflow": st["inbox_overflow"],
             "inbox_peak": max(g[0]["inbox_peak"] for g in got), "inbox_cap": kw["inbox_cap"],
-            "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1)}
+            "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1),
+            "queue": "16 slots with Prune() — the bounded queue of rounds 3-5: memberlist's unbounded queue (the one-GPU legs' SWIM_F_UNBOUNDED_QUEUE) is not built for sharded "
+                     "handles yet, so what this leg says about DETECTION is a property of the bound (DESIGN 8); its subject is the exchange's volume",
+            "unmeasured_on_two_devices": True}
 
 
 RCCL_KIND = "rccl: one equal-split all_to_all_single of frames per tick, the counts in the frames' headers; frames sized from the load (one 64-byte-per-peer host look per tick, a tick that does not fit exchanged twice)"
@@ -539,8 +548,9 @@ def run_config5(hip, args, device) -> dict:
     of serf user events (E per second from uniformly drawn live origins, Lamport-clocked, 512-slot event buffer).  Every node is
     a subject sooner or later: all views live in the dense pair store (mass_rows = N), nothing may be dropped."""
     n, secs, E = args.config5_nodes, args.config5_seconds, args.config5_events
-    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=16, event_queue_cap=16, event_ids_per_ltime=62, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
-              fold_interval_ms=5000, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS, watch_node=abi.NONE, device=device)
+    uq = not getattr(args, "bounded_queue", False)
+    kw = dict(n_nodes=n, seed=args.seed + 5, view_cap=8, mass_rows=n, queue_cap=8 if uq else 16, event_queue_cap=16, event_ids_per_ltime=62, inbox_cap=4096, subject_cap=4, gossip_nodes=3,
+              fold_interval_ms=5000, flags=abi.F_DEFAULT | abi.F_SERF_EVENTS | (abi.F_UNBOUNDED_QUEUE if uq else 0), watch_node=abi.NONE, device=device)
     s = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
     G, q = s.derived.gossip_period, s.derived.quantum_ms
     rng = np.random.default_rng(args.seed + 5)
@@ -589,7 +599,7 @@ def run_config5(hip, args, device) -> dict:
     clocks = [s.node_info(0, int(i)).event_clock for i in rng.choice(live, size=min(256, len(live)), replace=False)]
     rounds = secs * 1000 / q / G
     out = {"workload": f"BASELINE configs[4]'s shape on one GPU: {n} nodes, LAN timers, Lifeguard on, 10 %/s churn (kill / revive), {E} serf user events/s; "
-                       f"{secs} s simulated; dense pair store for every node",
+                       f"{secs} s simulated; dense pair store for every node; memberlist's queue " + ("unbounded (implied by the pair store); serf's event queue holds 16 (serf: max(2N, 4096))" if uq else "16 slots"),
            "n_nodes": n, "simulated_s": secs, "wall_s": round(dt, 2), "rounds_per_sec": rounds / dt, "value": n * rounds / dt, "unit": "node-rounds/s",
            "events_fired": fired, "event_deliveries": st["user_events_delivered"], "event_deliveries_per_simulated_s": st["user_events_delivered"] / secs,
            "event_deliveries_per_wall_s": st["user_events_delivered"] / dt,
@@ -604,7 +614,7 @@ def run_config5(hip, args, device) -> dict:
            "lamport_clock_spread": {"sampled_live_nodes": len(clocks), "min": int(min(clocks)), "max": int(max(clocks))},
            "refutes": st["refutes"], "suspicion_timeouts": st["suspicion_timeouts"], "folds": st["folds"],
            "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"],
-           "pair_store_GB": round(12.0 * n * n / 1e9, 1)}
+           "pair_store_GB": round((20.0 if uq else 12.0) * n * n / 1e9, 1)}
     s.close()
     return out
 
@@ -631,7 +641,8 @@ def main():
                                                                     "dense store for every node = N^2 x 12 bytes")
     ap.add_argument("--no-config4-partition", action="store_true")
     ap.add_argument("--config4p-budget-s", type=float, default=150.0, help="config4_partition leg: stop (the curve so far is reported) after this much wall time")
-    ap.add_argument("--config4-queue-cap", type=int, default=32)
+    ap.add_argument("--config4-queue-cap", type=int, default=32, help="with --bounded-queue")
+    ap.add_argument("--bounded-queue", action="store_true", help="config4 / config4_partition / config5 legs with queue_cap slots and Prune() (rounds 3-5) instead of memberlist's unbounded queue")
     ap.add_argument("--config4-budget-s", type=float, default=400.0, help="config4 leg: give up (detection_complete false) after this much wall time")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--config5-nodes", type=int, default=65536)

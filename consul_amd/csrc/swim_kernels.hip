@@ -4366,12 +4366,10 @@ __device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
   const uint32_t lane = sw_lane();
   for (uint32_t k = 2; k <= P; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t idx = lane; idx < P; idx += 64) {
-        const uint32_t ixj = idx ^ j;
-        if (ixj > idx) {
-          const unsigned long long a = pool[idx], b = pool[ixj];
-          if ((a > b) == ((idx & k) == 0)) { pool[idx] = b; pool[ixj] = a; }
-        }
+      for (uint32_t p = lane; p < P / 2; p += 64) {               // pair p: every lane compares, none idles on the upper index of a pair
+        const uint32_t idx = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), ixj = idx | j;
+        const unsigned long long a = pool[idx], b = pool[ixj];
+        if ((a > b) == ((idx & k) == 0)) { pool[idx] = b; pool[ixj] = a; }
       }
       wave_lds_sync();
     }
@@ -4429,7 +4427,8 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
   // 256 bytes per request, four and then sixteen requests per batch: the phase clock — profiles/r06_iq_phase_clock.txt — showed a node spending
   // 95 % of its 360 us in the scan, 13 us per batch, the whole device moving 1.2 TB/s: the requests in flight per CU, not the bytes, were the
   // limit.)
-  for (uint32_t rb0 = 0; rb0 < D.MB && seen < iqn; rb0 += 8) {
+  const bool count_seen = iqn < 4096u;              // (the early exit is for short queues; a long one is scanned to the end without the bookkeeping)
+  for (uint32_t rb0 = 0; rb0 < D.MB && (!count_seen || seen < iqn); rb0 += 8) {
     uint4 ew[8];
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) ew[u] = ld_global_u4(col + (size_t)(rb0 + u < D.MB ? rb0 + u : D.MB - 1u) * (64u * SW_IQ_RB / 4u));     // (unconditional: a conditional load became a loop of single round trips)
@@ -4442,14 +4441,28 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
 #endif
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) {
-      if (rb0 + u >= D.MB || !__any((ew[u].x | ew[u].y | ew[u].z | ew[u].w) & QE_QUEUED)) continue;
+      if (rb0 + u >= D.MB) continue;
+      {
+        // a queued rumour in a tier above every rank's threshold cannot qualify: once the thresholds stand that is nearly all of a long queue,
+        // and the four rows of a load are judged with one ballot
+        const uint32_t tmax = ((thr.t0 > thr.t1 ? thr.t0 : thr.t1) > thr.t2 ? (thr.t0 > thr.t1 ? thr.t0 : thr.t1) : thr.t2) >> 24;
+        const uint32_t lim = QE_QUEUED | ((tmax < 31u ? tmax : 31u) << 26) | 0x03FFFFFFu;      // queued words above it: a higher tier
+        const bool maybe = ((ew[u].x & QE_QUEUED) && ew[u].x <= lim) || ((ew[u].y & QE_QUEUED) && ew[u].y <= lim) ||
+                           ((ew[u].z & QE_QUEUED) && ew[u].z <= lim) || ((ew[u].w & QE_QUEUED) && ew[u].w <= lim);
+        if (count_seen) {
+          const uint32_t c4 = ((ew[u].x >> 31) + (ew[u].y >> 31)) + ((ew[u].z >> 31) + (ew[u].w >> 31));
+          uint32_t cs = c4;
+          for (int off = 32; off; off >>= 1) cs += __shfl_xor(cs, off);
+          if (!__any(maybe)) { seen += cs; continue; }
+        } else if (!__any(maybe)) continue;
+      }
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
         const bool q = (e & QE_QUEUED) != 0;
         const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
         const bool qual = q && key < (rk == 0 ? thr.t0 : rk == 1 ? thr.t1 : thr.t2);
-        seen += (uint32_t)__popcll(__ballot(q));
+        if (count_seen) seen += (uint32_t)__popcll(__ballot(q));
         const uint64_t mm = __ballot(qual);
         if (mm) {
           if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
