@@ -116,7 +116,9 @@ class TorchExchange:
             return
         send, recv = self._exchange(sim, F, fill=True)
         # the one host look of the tick: `need` of every sender (the own frame's header carries this rank's)
-        need = max(int(recv.view(W, F, 4)[:, 0, 1].max().item()) >> 1 if W > 1 else 0, int(send[self.rank * F, 1].item()) >> 1)
+        # (ONE read-back — the maximum is taken on the device; rounds 4-5 read the two words back separately: two device-to-host syncs on the tick's critical path)
+        own = send[self.rank * F, 1]
+        need = int((self.torch.maximum(recv.view(W, F, 4)[:, 0, 1].max(), own) if W > 1 else own).item()) >> 1
         if need > F - 1:                                         # (every rank computes the same maximum: all repeat together)
             self.retries += 1
             F = 1 << need.bit_length()                           # > need
