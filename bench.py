@@ -334,6 +334,8 @@ def run_config4(hip, args, device) -> dict:
     G, q = s.derived.gossip_period, s.derived.quantum_ms
     s.step_ms(1000); s.kill(0, victims.tolist()); s.sync()
     s0 = s.stats()
+    if uq:
+        s.profile(True)                              # HIP events around every launch of the leg: what the implied queue's kernels cost and move
     t0 = time.perf_counter()
     curve, done, heavy = [], None, None
     budget = args.config4_budget_s
@@ -383,6 +385,18 @@ def run_config4(hip, args, device) -> dict:
                                                                        "queue_drops_per_applied_message": {"32": 1.68, "256": 0.50, "4096": 0.0},
                                                                        "and_at_16384_nodes_819_stopped": {"32": 406, "128": 406, "512": 56, "2048": 46, "4096": 46}}},
            "curve": curve[:12] + curve[12::4]}
+    if uq:
+        prof = s.profile_read()
+        rows_padded = -(-(nv + 8) // 256) * 256          # the queue words of an observer's column, in 1 KB runs (swim_device.h SW_IQ_RB)
+        g = prof.get("k_gossip_iq", (0, 0.0)); pg = prof.get("k_piggy_iq", (0, 0.0))
+        scan_bytes = 4.0 * rows_padded * (n - nv) / G    # per launch: every gossip-due survivor reads its whole column once
+        out["implied_queue_kernels"] = {
+            "kernel_ms_total": {k: round(v[1], 1) for k, v in prof.items() if v[0]}, "launches": int(g[0]),
+            "k_gossip_iq": {"avg_launch_ms": g[1] / max(g[0], 1), "column_bytes_scanned_per_launch": scan_bytes,
+                            "achieved_GBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6, "frac_of_8TBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6 / 8000.0,
+                            "bound": "hbm by design (4 bytes per pair and scan); measured: the wave's own instruction stream — the phase clock (profiles/r06_iq_phase_clock_v3.txt) has a "
+                                     "node at 88 % scan (a third of it the pool's bitonic compactions), 4 % waiting for the loads"},
+            "k_piggy_iq": {"avg_launch_ms": pg[1] / max(pg[0], 1)}}
     s.close()
     return out
 
@@ -610,6 +624,10 @@ def run_config5(hip, args, device) -> dict:
                                     "events at the end of the flood whether a node's event queue holds 16, 32, 64 or 4 096 entries (serf: max(2N, 4096)), and 1.0 with any "
                                     "depth once the churn is taken away: under 10 %/s churn memberlist's own broadcasts fill the packets first (getBroadcasts before the "
                                     "delegate's), not the queue depth, bound an event's reach; depth shows in the quiet tail only (0.83 / 0.89 / 0.92 after 20 s)"},
+           "why_the_coverage_is_what_it_is": ("memberlist's getBroadcasts fills a packet from its OWN queue first and hands the delegate (serf's user events) what is left; with the unbounded "
+                                              "queue every node has more membership rumours queued under 10 %/s churn than a packet holds, so an event waits for room that seldom "
+                                              "comes: mean coverage 0.07 where the 16-slot queue of rounds 3-5 (which pruned most membership rumours) left room for 0.35 — the faithful "
+                                              "number is the low one") if uq else "bounded queue (--bounded-queue): rounds 3-5's figure",
            "dedupe_hits": st["user_events_deduped"], "stale_events": st["user_events_stale"], "event_drops": st["event_drops"],
            "lamport_clock_spread": {"sampled_live_nodes": len(clocks), "min": int(min(clocks)), "max": int(max(clocks))},
            "refutes": st["refutes"], "suspicion_timeouts": st["suspicion_timeouts"], "folds": st["folds"],
@@ -637,8 +655,9 @@ def main():
     ap.add_argument("--no-detection", action="store_true")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--config4-nodes", type=int, default=524288, help="config4 leg: nodes on this GPU (524288 = one GPU's share of BASELINE configs[3]; ~115 s of wall time: profiles/r04_config4_524k_full.log)")
-    ap.add_argument("--config4p-nodes", type=int, default=65536, help="config4_partition leg (the partition as written + heal + recovery): nodes; a row of the "
-                                                                    "dense store for every node = N^2 x 12 bytes")
+    ap.add_argument("--config4p-nodes", type=int, default=32768, help="config4_partition leg (the partition as written + heal + recovery): nodes; a row of the "
+                                                                    "dense store for every node = N^2 x 20 bytes with the unbounded queue.  Default 32 768 since round 6 (the size of the "
+                                                                    "checker's fixture): at 65 536 the leg is 102 s of wall time (profiles/r06_bench_driver_call9.json), and config4 at its full size takes 230 s")
     ap.add_argument("--no-config4-partition", action="store_true")
     ap.add_argument("--config4p-budget-s", type=float, default=150.0, help="config4_partition leg: stop (the curve so far is reported) after this much wall time")
     ap.add_argument("--config4-queue-cap", type=int, default=32, help="with --bounded-queue")
