@@ -480,7 +480,9 @@ def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, ba
     from consul_amd.dist import LibraryExchange, ShardedSim
     n = int(os.environ.get("SWIMSIM_BENCH_C4S_NODES", 0)) or 262144      # (the override: tests on one device)
     nv = n // 20
-    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=16, inbox_cap=8192, subject_cap=4, gossip_nodes=3,
+    uq = not getattr(args, "bounded_queue", False)
+    kw = dict(n_nodes=n, seed=args.seed, view_cap=8, mass_rows=nv + 8, queue_cap=8 if uq else 16, inbox_cap=16384 if uq else 8192, subject_cap=4, gossip_nodes=3,
+              flags=abi.F_DEFAULT | (abi.F_UNBOUNDED_QUEUE if uq else 0),
               device=device, shard_rank=rank, n_shards=world)
     victims = np.random.default_rng(args.seed).choice(n, size=nv, replace=False)
     what = (f"{n} nodes block-partitioned over {world} GPUs, {nv} stopped at once, LAN timers, k = 3: the 30 s after the failure; "
@@ -540,9 +542,9 @@ def run_config4_sharded(hip, args, rank, world, device, dist, gather_handles, ba
             "a2a_bytes_per_tick_all_ranks": 16.0 * st["edges_remote"] / ticks, "a2a_bytes_per_tick_per_rank": 16.0 * st["edges_remote"] / ticks / world,
             "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_overflow": st["inbox_overflow"],
             "inbox_peak": max(g[0]["inbox_peak"] for g in got), "inbox_cap": kw["inbox_cap"],
-            "pair_store_GB_per_rank": round(12.0 * (nv + 8) * (n // world) / 1e9, 1),
-            "queue": "16 slots with Prune() — the bounded queue of rounds 3-5: memberlist's unbounded queue (the one-GPU legs' SWIM_F_UNBOUNDED_QUEUE) is not built for sharded "
-                     "handles yet, so what this leg says about DETECTION is a property of the bound (DESIGN 8); its subject is the exchange's volume",
+            "pair_store_GB_per_rank": round((20.0 if uq else 12.0) * (nv + 8) * (n // world) / 1e9, 1),
+            "queue": "memberlist's unbounded queue, implied by each shard's pair store (SWIM_F_UNBOUNDED_QUEUE; sharded since round 6, late: 2 / 4 shards on one device and on "
+                     "the emulated kernels == the unsharded checker)" if uq else "16 slots with Prune() (--bounded-queue)",
             "unmeasured_on_two_devices": True}
 
 

@@ -137,7 +137,7 @@ int validate(const swim_config* c) {
     if (c->n_nodes > (1u << 22) || c->mass_rows > c->n_nodes) return SWIM_ERANGE;
   }
   if (c->flags & SWIM_F_UNBOUNDED_QUEUE) {   // the queue implied by the pair store: a wave per node, fan-out <= 4, the column's queue word holds 5 bits of transmits
-    if (!c->mass_rows || c->n_shards != 1 || c->gossip_nodes > 4) return SWIM_EINVAL;
+    if (!c->mass_rows || c->gossip_nodes > 4) return SWIM_EINVAL;
     uint32_t min_len = std::min(std::min(c->msg_len[0], c->msg_len[1]), c->msg_len[2]);
     if (c->udp_buffer_size / (2 + min_len) >= SW_IQ_PKT) return SWIM_ERANGE;      // rumours one packet can take
   }
@@ -805,8 +805,9 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
   }
   if (D.iq) {    // gossip() over the queue the pair store implies: a wave per node with something queued (same blocks and segments as the gossip role)
     ProfScope p(s, PK_GOSSIP_IQ);
-    if (D.flags & SWIM_F_SERF_EVENTS) hipLaunchKernelGGL(k_gossip_iq<true>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
-    else hipLaunchKernelGGL(k_gossip_iq<false>, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
+    const bool sf = (D.flags & SWIM_F_SERF_EVENTS) != 0, mu = D.n_shards > 1;
+    void (*const gk)(const SwDev*, uint32_t) = sf ? (mu ? k_gossip_iq<true, true> : k_gossip_iq<true, false>) : (mu ? k_gossip_iq<false, true> : k_gossip_iq<false, false>);
+    hipLaunchKernelGGL(gk, dim3(D.R * pl.nb_gossip), dim3(SW_IQ_GTHREADS), 0, st, (const SwDev*)s->d_D, pl.nb_gossip);
   }
   if (D.M) hipLaunchKernelGGL(k_send_mass, dim3(1024), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);   // the dense store's part of the state exchanges listed above
   if (D.coord) {      // serf's ping delegate: the probers k_begin listed update their coordinates (from everybody's as of the start of the tick)

@@ -4608,7 +4608,8 @@ __device__ __forceinline__ IqWave iq_strip(uint32_t* base) {
 
 // memberlist gossip() for a handle whose queue is implied by the pair store: the block is the gossip role's stagger chunk (same block index,
 // same private edge segment, so k_deliver does not change); the peers are drawn lane per node, then every node with something queued gets
-// the whole wave for its GetBroadcasts.  Unsharded handles, fan-out <= 4.
+// the whole wave for its GetBroadcasts.  Fan-out <= 4.  MULTI: a packet for a node of another shard goes to that shard's list, unjudged — the receiving
+// shard asks the no-op question when the records arrive (SW_EDGE_JUDGE, like the gossip role).
 // the no-op question (noop_at_receiver) for a rumour whose subject owns row `row`, with the receiver's pair word `a` already fetched
 __device__ __forceinline__ bool iq_noop_pair(DevRef D, uint32_t r, uint32_t row, uint32_t kr, uint32_t a, uint4 e) {
   if (a) {
@@ -4628,7 +4629,7 @@ __device__ __forceinline__ bool iq_noop_pair(DevRef D, uint32_t r, uint32_t row,
   return noop_given_view(D, base_key_of(D, r, e.x, D.nw[(size_t)r * D.N + e.x]), 0, 0, e);
 }
 #define SW_IQ_GTHREADS 1024u      /* k_gossip_iq: 16 waves per stagger chunk, 16 nodes each (a wave works on ONE node at a time: 4 waves left 3/4 of the device idle) */
-template <bool SERF>
+template <bool SERF, bool MULTI>
 __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __restrict__ Dp, uint32_t nb_gossip) {
   SW_DEV_BIND
   __shared__ __attribute__((aligned(8))) uint32_t s_strips[(SW_IQ_GTHREADS / 64) * SW_IQ_STRIP_WORDS];
@@ -4678,7 +4679,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
     holds = i != NONE && (wi & NW_INERT) && something;             // a node that is not running keeps its (frozen) queue: the block's hint stays up
   }
   __syncthreads();
-  uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0;      // (tallied on lane 0)
+  uint32_t c_pkt = 0, c_drop = 0, c_filt = 0, c_s0 = 0, c_s1 = 0, c_s2 = 0, c_s3 = 0, c_remote = 0, c_e0 = 0;      // (tallied on lane 0)
   // ---- wave per node: wave w takes the chunk's nodes 16 w .. 16 w + 15
   for (uint32_t tj = (threadIdx.x / 64u) * 16u; tj < (threadIdx.x / 64u) * 16u + 16u; tj++) {
     const uint32_t o = s_node[tj];
@@ -4730,7 +4731,7 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
           else {
             const size_t mi = m_idx(D, r, at, k);
             x_[p] = D.mrow_subj[(size_t)r * D.M + at]; own_a[p] = D.mA[mi]; own_f[p] = D.mF[mi];
-            rcv_a[p] = D.mA[m_idx(D, r, at, s_peer[tj * 4 + p] - D.i0)];
+            if (!MULTI || s_peer[tj * 4 + p] / D.nloc == D.rank) rcv_a[p] = D.mA[m_idx(D, r, at, s_peer[tj * 4 + p] - D.i0)];
           }
         }
       }
@@ -4742,13 +4743,22 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
         const uint4 e4 = expl ? make_uint4(ex_[p].x, ex_[p].y, ex_[p].z, ((src_[p] >> 28) & 3u) << 30)
                               : make_uint4(x_[p], MA_INC(own_a[p]) + QF_DELTA(own_f[p]), QF_FROM(own_f[p]), ((src_[p] >> 28) & 3u) << 30);
         bool keep = on_[p];
+        const uint32_t psh = MULTI ? peer / D.nloc : D.rank;
+        uint4 ev = make_uint4(0, 0, 0, 0); const bool evl = SERF && lane < (uint32_t)__popc(te);
+        if (evl) ev = D.evq[(size_t)iq_nth_bit(te, lane) * NL + lj];
+        if (MULTI && psh != D.rank) {               // another shard's node: its shard judges (a rumour about the receiver itself is always delivered)
+          const uint32_t jd = (filter && e4.x != peer) ? SW_EDGE_JUDGE : 0u;
+          wave_append(D, psh, keep, make_uint4(gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | jd | (e4.z & TB_FROM_MASK)));
+          wave_append(D, psh, evl, make_uint4(gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30));
+          const uint32_t nrec = (uint32_t)__popcll(__ballot(keep)) + (uint32_t)__popc(te);
+          c_remote += nrec; c_e0 += (uint32_t)__popcll(__ballot(keep && !jd)) + (uint32_t)__popc(te);
+          continue;
+        }
         if (keep && filter && e4.x != peer) {
           if (expl) keep = !noop_at_receiver<true>(D, r, (size_t)r * D.nloc + (peer - D.i0), D.nw[(size_t)r * D.N + e4.x], e4, false, e4);
           else keep = !iq_noop_pair(D, r, src_[p] & 0x0FFFFFFFu, peer - D.i0, rcv_a[p], e4);
         }
         c_filt += (uint32_t)__popcll(__ballot(on_[p] && !keep));
-        uint4 ev = make_uint4(0, 0, 0, 0); const bool evl = SERF && lane < (uint32_t)__popc(te);
-        if (evl) ev = D.evq[(size_t)iq_nth_bit(te, lane) * NL + lj];
         if (pwp & NW_ATTACHED) {                     // Transport.WriteTo towards the real node
           if (keep) capture(D, o, gdst, e4.x, e4.y, (e4.w & 0xC0000000u) | (e4.z & 0x3FFFFFFFu));
           if (evl) capture(D, o, gdst, ev.x, ev.y, (uint32_t)SWIM_MSG_USER << 30);
@@ -4791,12 +4801,13 @@ __global__ void __launch_bounds__(SW_IQ_GTHREADS) k_gossip_iq(const SwDev* __res
   if (lane == 0) {
     S.add(ST_PKT_SENT, c_pkt); S.add(ST_PKT_DROP, c_drop); S.add(ST_FILTERED, c_filt);
     S.add(ST_SENT0, c_s0); S.add(ST_SENT1, c_s1); S.add(ST_SENT2, c_s2); S.add(ST_SENT3, c_s3);
+    if (MULTI) { S.add(ST_EDGES_REMOTE, c_remote); S.add(ST_EDGES, c_e0); if (c_remote) *D.act = 1; }
   }
   const int any = __syncthreads_or(holds);
   if (threadIdx.x == 0) {
     if (fb != NONE && !any) D.q_any[fb] = 0;
     const uint32_t c = s_cnt[0];
-    if (c) { D.seg_cnt[r * D.nb_gossip + bx] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); }
+    if (c) { D.seg_cnt[r * D.nb_gossip + bx] = c; atomicAdd(stat_ptr(D, ST_EDGES), (unsigned long long)c); if (MULTI) *D.act = 1; }
   }
   IQCLK_FLUSH();
   S.flush(D);

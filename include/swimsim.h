@@ -102,7 +102,7 @@ enum { SWIM_PRESET_LAN = 0, SWIM_PRESET_WAN = 1, SWIM_PRESET_LOCAL = 2 };
  *     over the node's column by (transmits asc, length desc, sequence desc) exactly as queue.go orders its btree.  A node's rumour about
  *     ITSELF and rumours about subjects without a row stay in the queue_cap slots (Prune() there is still counted, never silent);
  *   - both: a subject is not folded into the base row while a node of the shard still holds a queued rumour about it.
- * Needs mass_rows > 0 and an unsharded handle on the product library.  Not in SWIM_F_DEFAULT. */
+ * Needs mass_rows > 0 and gossip_nodes <= 4 on the product library.  Not in SWIM_F_DEFAULT. */
 #define SWIM_F_UNBOUNDED_QUEUE 0x80u
 #define SWIM_F_DEFAULT        (SWIM_F_BUDDY_SUSPECT | SWIM_F_NACK | SWIM_F_FILTER_NOOP | SWIM_F_PIGGYBACK | SWIM_F_TCP_FALLBACK)
 

@@ -61,3 +61,23 @@ def test_no_fold_while_a_rumour_is_queued(oracle):
         fa = fa or (sec if a.stats()["folds"] else None); fb = fb or (sec if b.stats()["folds"] else None)
     assert fa and fb and fb >= fa, (fa, fb)
     assert a.view(0, 5, 77).state == b.view(0, 5, 77).state == abi.STATE_DEAD
+
+
+def test_sharded_checker_with_unbounded_queues_and_folds(oracle):
+    """The fold rule across shards: a shard that still has a rumour about the subject queued poisons its census record, so all shards decide
+    alike — 2 shards of the checker with unbounded queues against the unsharded checker, folds every second, to the end of a mass event."""
+    from consul_amd.dist import LocalExchange, ShardedSim
+    n, nv = 1024, 60
+    victims = np.random.default_rng(2).choice(n, size=nv, replace=False).tolist()
+    kw = dict(n_nodes=n, seed=2, queue_cap=4, inbox_cap=2 * nv + 256, view_cap=nv + 64, subject_cap=4, fold_interval_ms=1000, gossip_to_dead_ms=3000, flags=UQ)
+    sh = ShardedSim([Sim(oracle, preset(oracle, abi.PRESET_LAN, shard_rank=i, n_shards=2, **kw)) for i in range(2)], LocalExchange())
+    ref = Sim(oracle, preset(oracle, abi.PRESET_LAN, **kw))
+    for s in (sh, ref):
+        s.step_ms(1000); s.kill(0, victims)
+    for sec in range(0, 60, 5):
+        sh.step_ms(5000); ref.step_ms(5000)
+        assert sh.digest() == ref.digest(), sec
+    a, b = sh.stats(), ref.stats()
+    for k in ("msgs_applied", "folds", "fold_freed", "queue_drops", "edges", "msgs_filtered"):
+        assert a[k] == b[k], k
+    assert b["folds"] == nv and b["queue_drops"] == 0
