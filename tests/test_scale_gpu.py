@@ -134,6 +134,28 @@ def test_partition_of_five_percent_32k_against_the_oracle(hip, oracle, n_shards)
     a.close()
 
 
+def test_mass_failure_65536_with_the_unbounded_queue_matches_golden(hip):
+    """The same failure with memberlist's queue as it is upstream — unbounded (SWIM_F_UNBOUNDED_QUEUE; the device: implied by the pair store) —
+    against the checker's fixture (tools/make_golden.py config4_mass_kill_64k_unbounded: digests, counters, detection census at 5 .. 120 s and
+    at full detection): every survivor holds every victim dead after 160 s of simulated time where the 32-slot queue needed 850 s."""
+    path = os.path.join(GOLDEN, "config4_mass_kill_64k_unbounded.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tools/make_golden.py config4_mass_kill_64k_unbounded: hours of checker time)")
+    g = json.load(open(path))
+    kw = dict(g["config"], **sc.MASS_KILL_64K_HIP); n = kw["n_nodes"]
+    a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    res = sc.run_mass_kill(a, n, tuple(int(k) for k in g["checkpoints"]))
+    for sec, (digest, st, det) in ((k, v) for k, v in res.items() if k != "done"):
+        want = g["checkpoints"][str(sec)]
+        assert f"{digest:#018x}" == want["digest"], f"digest after {sec} s"
+        assert det == want["detection"], (sec, det)
+        for k in sc.MASS_STAT_KEYS:
+            assert st[k] == want["stats"][k], (sec, k)
+    d = res["done"]
+    assert d[0] == g["done"]["second"] and f"{d[1]:#018x}" == g["done"]["digest"] and d[3] == g["done"]["detection"]
+    assert d[2]["queue_drops"] == 0 and d[2]["view_drops"] == 0 and d[0] <= 200
+
+
 @pytest.mark.parametrize("n_shards", [1, 2, 4])
 def test_mass_failure_of_five_percent_65536_matches_golden(hip, n_shards):
     """config #4's dynamics with NOTHING dropped (tests/scenarios.py MASS_KILL_64K): 3 276 of 65 536 nodes stop at once; the

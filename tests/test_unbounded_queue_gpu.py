@@ -162,24 +162,29 @@ def test_sharded_in_process(hip, oracle, n_shards):
     """The pair store — and with it the implied queue — is per shard (its columns are the shard's observers): 2 and 4 shards on one device
     against the UNSHARDED checker; what crosses a shard boundary is judged where it arrives, piggy-back orders for another
     shard's nodes travel with the tick's records, the carried broadcasts with the next tick's."""
-    from consul_amd.dist import LocalExchange, ShardedSim
+    import os
+    from consul_amd.dist import LibraryExchange, LocalExchange, ShardedSim
     n, nv = 2048, 120
     victims = np.random.default_rng(9).choice(n, size=nv, replace=False)
     kw = dict(n_nodes=n, seed=9, queue_cap=8, inbox_cap=2048, subject_cap=4, fold_interval_ms=20000, flags=UQ)
-    a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, mass_rows=nv + 8, view_cap=8, **kw)) for i in range(n_shards)], LocalExchange())
-    b = Sim(oracle, preset(oracle, abi.PRESET_LAN, view_cap=nv + 64, **kw))
-    for s in (a, b):
-        s.step_ms(1000); s.kill(0, victims.tolist())
-    for sec in range(0, 44, 4):
-        a.step_ms(4000); b.step_ms(4000); a.sync()
-        assert a.digest() == b.digest(), sec
-        assert a.detection(0) == b.detection(0)
-    sa, sb = a.stats(), b.stats()
-    for k in ("msgs_applied", "msgs_sent", "suspicion_timeouts", "confirmations", "probe_failures", "packets_sent", "push_pulls", "folds", "edges", "msgs_filtered", "piggybacks", "msgs_piggybacked", "queue_drops"):
-        assert sa[k] == sb[k], k
-    pairs, by = a.detection(0)
-    assert by[2] + by[3] == pairs == (n - nv) * nv and sa["view_drops"] == 0
-    a.close(); b.close()
+    # (the library's own mailbox exchange too, with two shards — as tests/test_mass_gpu.py: four shards in one process would need a hardware queue
+    # per stream; not on the emulated kernels, whose workgroups run one after the other)
+    exchanges = (LocalExchange, LibraryExchange) if n_shards == 2 and not os.environ.get("SWIMSIM_EMU_SO") else (LocalExchange,)
+    for xchg in exchanges:
+        a = ShardedSim([Sim(hip, preset(hip, abi.PRESET_LAN, shard_rank=i, n_shards=n_shards, mass_rows=nv + 8, view_cap=8, **kw)) for i in range(n_shards)], xchg())
+        b = Sim(oracle, preset(oracle, abi.PRESET_LAN, view_cap=nv + 64, **kw))
+        for s in (a, b):
+            s.step_ms(1000); s.kill(0, victims.tolist())
+        for sec in range(0, 44, 4):
+            a.step_ms(4000); b.step_ms(4000); a.sync()
+            assert a.digest() == b.digest(), (xchg.__name__, sec)
+            assert a.detection(0) == b.detection(0)
+        sa, sb = a.stats(), b.stats()
+        for k in ("msgs_applied", "msgs_sent", "suspicion_timeouts", "confirmations", "probe_failures", "packets_sent", "push_pulls", "folds", "edges", "msgs_filtered", "piggybacks", "msgs_piggybacked", "queue_drops"):
+            assert sa[k] == sb[k], (xchg.__name__, k)
+        pairs, by = a.detection(0)
+        assert by[2] + by[3] == pairs == (n - nv) * nv and sa["view_drops"] == 0
+        a.close(); b.close()
 
 
 def test_checkpoint_with_an_implied_queue(hip, tmp_path):

@@ -75,6 +75,21 @@ def config4_mass_kill():
     return out
 
 
+def config4_mass_kill_unbounded():
+    """... with memberlist's unbounded queue (SWIM_F_UNBOUNDED_QUEUE): nothing pruned, to full detection."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenarios as sc
+    s = Sim(ora, preset(ora, abi.PRESET_LAN, **sc.MASS_KILL_64K_UQ, **sc.MASS_KILL_64K_ORACLE))
+    res = sc.run_mass_kill(s, sc.MASS_KILL_64K_UQ["n_nodes"], (5, 15, 30, 60, 120))
+    out = {"config": sc.MASS_KILL_64K_UQ, "oracle_only": sc.MASS_KILL_64K_ORACLE, "checkpoints": {}}
+    for k, v in res.items():
+        if k == "done":
+            out["done"] = {"second": v[0], "digest": f"{v[1]:#018x}", "stats": v[2], "detection": v[3]}
+        else:
+            out["checkpoints"][str(k)] = {"digest": f"{v[0]:#018x}", "stats": v[1], "detection": v[2]}
+    return out
+
+
 def config4_partition_heal():
     """BASELINE config #4 as written (a partition, both directions) and its recovery phase, 32 768 nodes, nothing dropped (65 536 does
     not fit the build container's memory on the checker: tests/scenarios.py)."""
@@ -108,7 +123,7 @@ if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("config1_kill17", config1), ("config3_infection_32k", config3_small),
-                     ("config3_infection_1m", config3_full), ("config4_mass_kill_64k", config4_mass_kill), ("config4_partition_heal_32k", config4_partition_heal),
+                     ("config3_infection_1m", config3_full), ("config4_mass_kill_64k", config4_mass_kill), ("config4_mass_kill_64k_unbounded", config4_mass_kill_unbounded), ("config4_partition_heal_32k", config4_partition_heal),
                      ("config5_churn_events_8k", config5_churn_events)):
         if only and name not in only:
             continue

@@ -16,7 +16,7 @@ for p in sorted(glob.glob(f"{root}/pass*/*/*_counter_collection.csv")):
     for r in rows:
         if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"): continue
         m = re.search(r"\b(k_[a-z_]+)", r["Kernel_Name"])
-        if not m or m.group(1) not in ("k_begin", "k_deliver", "k_resolve", "k_census", "k_finish", "k_census_finish"): continue
+        if not m or m.group(1) not in ("k_begin", "k_deliver", "k_resolve", "k_census", "k_finish", "k_census_finish", "k_gossip_iq", "k_piggy_iq", "k_inbox_claim", "k_inbox_file"): continue
         k = m.group(1)
         idx = order[k].setdefault(r["Dispatch_Id"], len(order[k]))
         if first and idx >= first: continue
