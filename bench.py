@@ -396,7 +396,13 @@ def run_config4(hip, args, device) -> dict:
                             "achieved_GBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6, "frac_of_8TBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6 / 8000.0,
                             "bound": "hbm by design (4 bytes per pair and scan); measured: the wave's own instruction stream — the phase clock (profiles/r06_iq_phase_clock_v3.txt) has a "
                                      "node at 88 % scan (a third of it the pool's bitonic compactions), 4 % waiting for the loads"},
-            "k_piggy_iq": {"avg_launch_ms": pg[1] / max(pg[0], 1)}}
+            "k_piggy_iq": {"avg_launch_ms": pg[1] / max(pg[0], 1)},
+            "quoted_from_profiles": {"hbm_traffic": "profiles/r06_pmc_config4_262k.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; this shape at 262 144 nodes, the first 30 "
+                                                    "simulated seconds, per launch; not measured by this run): k_gossip_iq 5.33 GB fetched as counted (10.7 GB with the guide's x2 on FETCH_SIZE) + "
+                                                    "0.43 GB written against 6.6 GB of column scan — 0.8x / 1.6x the algorithmic bytes: nothing is re-read; k_piggy_iq 1.40 GB (2.8 GB) + 0.08 GB; "
+                                                    "k_resolve<MASS> 3.95 GB (7.9 GB) + 1.55 GB",
+                                     "kernel_trace": "profiles/r06_config4_262k_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command): k_resolve<MASS> 5.67 ms, k_gossip_iq 4.93 ms, "
+                                                     "k_piggy_iq 2.92 ms per launch in that phase"}}
     s.close()
     return out
 
@@ -588,6 +594,7 @@ def run_config5(hip, args, device) -> dict:
                 break
     s.step_ms(1000); s.sync()
     s0 = s.stats()
+    s.profile(True)                                  # (HIP events around the tick kernels: where the leg's time goes)
     t0 = time.perf_counter()
     fired = []
     for sec in range(secs):
@@ -634,7 +641,8 @@ def run_config5(hip, args, device) -> dict:
            "lamport_clock_spread": {"sampled_live_nodes": len(clocks), "min": int(min(clocks)), "max": int(max(clocks))},
            "refutes": st["refutes"], "suspicion_timeouts": st["suspicion_timeouts"], "folds": st["folds"],
            "view_drops": st["view_drops"], "queue_drops": st["queue_drops"], "inbox_peak": s.stats()["inbox_peak"], "inbox_overflow": st["inbox_overflow"],
-           "pair_store_GB": round((20.0 if uq else 12.0) * n * n / 1e9, 1)}
+           "pair_store_GB": round((20.0 if uq else 12.0) * n * n / 1e9, 1),
+           "kernel_ms_total": {k: round(v[1], 1) for k, v in s.profile_read().items() if v[0]}}
     s.close()
     return out
 
