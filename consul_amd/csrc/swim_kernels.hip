@@ -1,6 +1,6 @@
 // swim_kernels.hip — hand-written gfx950 kernels for the memberlist/serf SWIM hot path.
 //
-// One tick = five launches.  Everything is integer/byte work bounded by HBM bandwidth,
+// One tick = four launches.  Everything is integer/byte work bounded by HBM bandwidth,
 // random-access sector traffic and atomic throughput; there is no dense contraction, hence no MFMA.
 //
 //   k_begin    fused, role by block range:
@@ -11,8 +11,9 @@
 //                gossip   kRandomNodes + GetBroadcasts per peer   -> edge lists bucketed by shard
 //   k_deliver  edge list -> per-node inbox rows (one returning atomic + one 16 B store per record)
 //   k_resolve  per observer: canonical order, aliveNode/suspectNode/deadNode/handleUserEvent
-//   k_census   per dirty subject: how the live observers see it
-//   k_finish   first-suspect/first-dead/all-dead stamps, trace row, list recycling, tick++
+//   k_census_finish  per dirty subject: how the live observers see it; first-suspect/first-dead/all-dead stamps, trace row, list recycling, tick++
+// SWIM_F_UNBOUNDED_QUEUE (the queue implied by the dense pair store, at the end of this file): k_gossip_iq in the gossip role's place, k_piggy_iq between
+// k_deliver and k_resolve; pooled inbox rows: k_inbox_claim / k_inbox_file behind k_deliver.
 #include "swim_device.h"
 
 #define NONE 0xFFFFFFFFu

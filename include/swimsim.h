@@ -139,7 +139,8 @@ typedef struct swim_config {
   uint32_t quantum_ms;              /* tick length; 0 = gcd(gossip, probe, timeout)         */
   uint32_t phase_chunk;             /* nodes per stagger chunk (power of 2); 0 = auto       */
   uint32_t queue_cap;               /* per-node TransmitLimitedQueue slots (<= 32)          */
-  uint32_t inbox_cap;               /* per-node per-tick inbox slots                        */
+  uint32_t inbox_cap;               /* per-node per-tick inbox slots (from 4 096 on the product library pools the overflow rows: a node's own
+                                       row holds 1 024 messages, the few nodes a tick hands more borrow one of up to 8 192 rows of inbox_cap) */
   uint32_t subject_cap;             /* per-replica WATCH slots: subjects whose census, first-suspect/first-dead
                                        stamps and per-tick trace are maintained (swim_watch; every node named in
                                        an inject_* call is watched automatically while slots remain); < 32 767 */
@@ -153,7 +154,7 @@ typedef struct swim_config {
                                        leave, update, join, the minority sides of a partition) gets a row while rows remain, and
                                        every observer's view of it then costs 12 bytes in [row][observer] planes instead of a
                                        64-byte hash-table entry counted against view_cap: memory = 12 B x mass_rows x nodes on the
-                                       shard x replicas.  Representation only: no result depends on which subject has a row.
+                                       shard x replicas (20 B with SWIM_F_UNBOUNDED_QUEUE: the pair also holds the rumour queued about the subject).  Representation only: no result depends on which subject has a row.
                                        Needs SuspicionMult <= 4 (two accuser names per pair), a fixed population (n_initial = 0),
                                        n_nodes <= 2^22, the reaper off.  The checker ignores the field.  0 = off              */
   /* serf's reaper (handleReap): every ReapInterval a member that has been Failed for longer than ReconnectTimeout, or Left

@@ -83,6 +83,9 @@ MASS_KILL_64K = dict(n_nodes=65536, seed=11, queue_cap=32, inbox_cap=6808, subje
 MASS_KILL_64K_ORACLE = dict(view_cap=3276 + 64)
 MASS_KILL_64K_HIP = dict(view_cap=8, mass_rows=3276 + 8)
 # ... the same failure with memberlist's UNBOUNDED queue (SWIM_F_UNBOUNDED_QUEUE, round 6): full detection after 160 s instead of 850 s
+MASS_KILL_16K_UQ = dict(n_nodes=16384, seed=11, queue_cap=8, inbox_cap=2048, subject_cap=8, flags=abi.F_DEFAULT | abi.F_UNBOUNDED_QUEUE)   # (819 stop: VERDICT r5's parity size)
+MASS_KILL_16K_ORACLE = dict(view_cap=819 + 64)
+MASS_KILL_16K_HIP = dict(view_cap=8, mass_rows=819 + 8)
 MASS_KILL_64K_UQ = dict(n_nodes=65536, seed=11, queue_cap=8, inbox_cap=6808, subject_cap=8, flags=abi.F_DEFAULT | abi.F_UNBOUNDED_QUEUE)
 MASS_STAT_KEYS = STAT_KEYS + ("inbox_peak", "push_pulls", "edges")
 

@@ -134,6 +134,24 @@ def test_partition_of_five_percent_32k_against_the_oracle(hip, oracle, n_shards)
     a.close()
 
 
+def test_mass_failure_16384_with_the_unbounded_queue_matches_golden(hip):
+    """VERDICT r5's parity size: 819 of 16 384 nodes stop at once, memberlist's unbounded queue, to FULL detection with `queue_drops` 0 — against the
+    checker's fixture (digests, counters, detection census at 5 .. 40 s and at full detection, 50 s; the 32-slot queue needed 406 s)."""
+    g = json.load(open(os.path.join(GOLDEN, "config4_mass_kill_16k_unbounded.json")))
+    kw = dict(g["config"], **sc.MASS_KILL_16K_HIP); n = kw["n_nodes"]
+    a = Sim(hip, preset(hip, abi.PRESET_LAN, **kw))
+    res = sc.run_mass_kill(a, n, tuple(int(k) for k in g["checkpoints"]))
+    for sec, (digest, st, det) in ((k, v) for k, v in res.items() if k != "done"):
+        want = g["checkpoints"][str(sec)]
+        assert f"{digest:#018x}" == want["digest"], f"digest after {sec} s"
+        assert det == want["detection"], (sec, det)
+        for k in sc.MASS_STAT_KEYS:
+            assert st[k] == want["stats"][k], (sec, k)
+    d = res["done"]
+    assert d[0] == g["done"]["second"] == 50 and f"{d[1]:#018x}" == g["done"]["digest"] and d[3] == g["done"]["detection"]
+    assert d[2]["queue_drops"] == 0 and d[2]["view_drops"] == 0 and d[3][0] == (n - 819) * 819
+
+
 def test_mass_failure_65536_with_the_unbounded_queue_matches_golden(hip):
     """The same failure with memberlist's queue as it is upstream — unbounded (SWIM_F_UNBOUNDED_QUEUE; the device: implied by the pair store) —
     against the checker's fixture (tools/make_golden.py config4_mass_kill_64k_unbounded: digests, counters, detection census at 5 .. 120 s and
