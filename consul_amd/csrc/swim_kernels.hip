@@ -3522,6 +3522,7 @@ __global__ void k_attach(const SwDev* __restrict__ Dp, uint32_t r, uint32_t x) {
   if (local && !(old & NW_ATTACHED)) {                       // its frozen queue must not keep a gossip block busy
     size_t l = (size_t)r * D.nloc + (x - D.i0);
     uint4 h = HDR(l); h.y = h_pack(h_leaving(h.y), 0, 0); HDR(l) = h; D.in_cnt[l] = 0;
+    if (D.iq && D.iqn[l]) { for (uint32_t row = 0; row < D.M; row++) { const size_t ei = e_idx(D, r, row, x - D.i0); if (D.mE[ei] & QE_QUEUED) D.mE[ei] = 0; } D.iqn[l] = 0; }   // ... nor the rumours the pair store implies
     if (!(old & NW_DEAD)) atomicSub(&D.alive_cnt[l / SW_BLOCK], 1u);          // no longer one of the nodes the simulator acts for
     q_bit_lane(D, l, false, true);
   }

@@ -206,3 +206,28 @@ def test_refused_configurations(hip):
         cfg = preset(hip, abi.PRESET_LAN, n_nodes=256, flags=UQ, **bad)
         h = C.c_void_p()
         assert hip.swim_create(C.byref(cfg), C.byref(h)) == abi.EINVAL
+
+
+def test_transport_bridge_with_an_implied_queue(hip, oracle):
+    """memberlist.Transport at rumour granularity on a handle whose queue the pair store implies: a node is attached in the MIDDLE of a mass event
+    (what it had queued — in the pairs too — is void: peers keep seeing it alive, the simulator stops acting for it), the gossip and the piggy-backed
+    broadcasts addressed to it are captured with their senders by k_gossip_iq / k_piggy_iq, what it writes lands in the peers' inboxes."""
+    n = 1024
+    victims = list(range(3, 1000, 25))
+    kw = dict(n_nodes=n, seed=3, subject_cap=8, queue_cap=8, inbox_cap=512, flags=UQ)
+    a, b = pair(hip, oracle, dict(mass_rows=len(victims) + 8, view_cap=8), dict(view_cap=128), **kw)
+    out = []
+    for s in (a, b):
+        r = {}
+        s.step_ms(1000); s.kill(0, victims); s.step_ms(3000)
+        assert s.node_info(0, 7).queue_len > 0               # node 7 has rumours queued (implied by the pairs on the device)
+        assert s.transport_poll(0, 7) == []                  # first call attaches node 7
+        assert s.node_info(0, 7).queue_len == 0
+        s.step_ms(6000)
+        r["heard"] = sorted(s.transport_poll(0, 7))
+        s.transport_write_to(0, 7, 9, [(200, 1, abi.MSG_SUSPECT, 7)])
+        s.step_ms(4000)
+        r["after"] = sorted(s.transport_poll(0, 7))
+        r["digest"] = s.digest(); r["detection"] = s.detection(0); r["inc200"] = s.node_info(0, 200).incarnation
+        out.append(r)
+    assert out[0]["heard"] and out[0] == out[1]
