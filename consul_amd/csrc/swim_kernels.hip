@@ -3819,6 +3819,35 @@ __global__ void __launch_bounds__(SW_BLOCK) k_reap(const SwDev* __restrict__ Dp)
 // subject and shard into the tick's outbound lists; k_deliver accumulates every shard's records (fg_*);
 // k_fold_apply (between k_deliver and k_resolve) decides and frees.
 // =================================================================================================
+// ... and the members whose views live in the dense pair store: a workgroup per row (round 6: mass_rows no longer excludes the reaper)
+__global__ void __launch_bounds__(SW_BLOCK) k_reap_mass(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const uint32_t rr = blockIdx.x, r = rr / D.M, row = rr % D.M, x = D.mrow_subj[rr];
+  if (x == NONE) return;
+  const uint32_t t = *D.tick, now = now_ms(D, t);
+  uint32_t n = 0;
+  for (uint32_t k = threadIdx.x; k < D.nloc; k += SW_BLOCK) {
+    const size_t idx = m_idx(D, r, row, k);
+    const uint32_t a = D.mA[idx], st = MA_STATE(a), o = D.i0 + k;
+    if (!a || st < SWIM_STATE_DEAD || MA_ERASED(a) || x == o) continue;
+    if (D.nw[(size_t)r * D.N + o] & NW_INERT) continue;
+    if (!(now - MB_TICK(D.mB[idx]) * D.quantum_ms > (st == SWIM_STATE_DEAD ? D.reconnect_timeout_ms : D.tombstone_timeout_ms))) continue;
+    D.mA[idx] = a | (1u << 5); n++;
+    bool ev_ch = o == D.watch;
+    if (!ev_ch && D.ev_any) { const uint32_t nw_ = D.ev_watch[(size_t)D.R * SWIM_EVENT_WATCHERS + r]; for (uint32_t j = 0; j < nw_; j++) ev_ch |= D.ev_watch[(size_t)r * SWIM_EVENT_WATCHERS + j] == o; }
+    if (ev_ch) {
+      const uint32_t pos = atomicAdd(D.ev_cnt, 1u);
+      if (pos < D.ev_cap) { swim_event ev = { now, r, SWIM_EVENT_MEMBER_REAP, x, MA_INC(a), o, 0 }; D.events[pos] = ev; }
+      else atomicOr(D.err, SW_ERR_EVENT_OVF);
+    }
+  }
+  for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
+  if (sw_lane() == 0 && n) {
+    atomicAdd(stat_ptr(D, ST_REAPED), (unsigned long long)n);
+    const uint32_t wx = D.nw[(size_t)r * D.N + x];
+    if (NW_HAS_SLOT(wx)) D.slot_dirty[(size_t)r * D.S + NW_SLOT(wx)] = 1;
+  }
+}
 __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan(const SwDev* __restrict__ Dp) {
   SW_DEV_BIND
   const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;

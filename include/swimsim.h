@@ -156,7 +156,7 @@ typedef struct swim_config {
                                        64-byte hash-table entry counted against view_cap: memory = 12 B x mass_rows x nodes on the
                                        shard x replicas (20 B with SWIM_F_UNBOUNDED_QUEUE: the pair also holds the rumour queued about the subject).  Representation only: no result depends on which subject has a row.
                                        Needs SuspicionMult <= 4 (two accuser names per pair), a fixed population (n_initial = 0),
-                                       n_nodes <= 2^22, the reaper off.  The checker ignores the field.  0 = off              */
+                                       n_nodes <= 2^22.  The checker ignores the field.  0 = off              */
   /* serf's reaper (handleReap): every ReapInterval a member that has been Failed for longer than ReconnectTimeout, or Left
    * for longer than TombstoneTimeout, is erased from the observer's member list (status NONE) and EventMemberReap is
    * emitted (agent/consul/server_serf.go:279, timeouts agent/consul/config.go:640-641; the reference's tests run it at
