@@ -4480,23 +4480,31 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
         const uint32_t lim = QE_QUEUED | ((tmax < 31u ? tmax : 31u) << 26) | 0x03FFFFFFu;      // queued words above it: a higher tier
         const bool maybe = ((ew[u].x & QE_QUEUED) && ew[u].x <= lim) || ((ew[u].y & QE_QUEUED) && ew[u].y <= lim) ||
                            ((ew[u].z & QE_QUEUED) && ew[u].z <= lim) || ((ew[u].w & QE_QUEUED) && ew[u].w <= lim);
-        if (count_seen) {
-          const uint32_t c4 = ((ew[u].x >> 31) + (ew[u].y >> 31)) + ((ew[u].z >> 31) + (ew[u].w >> 31));
-          uint32_t cs = c4;
+        if (count_seen) {                            // (short queues: how many queued words this load held — one reduction, not a ballot per row)
+          uint32_t cs = ((ew[u].x >> 31) + (ew[u].y >> 31)) + ((ew[u].z >> 31) + (ew[u].w >> 31));
           for (int off = 32; off; off >>= 1) cs += __shfl_xor(cs, off);
-          if (!__any(maybe)) { seen += cs; continue; }
-        } else if (!__any(maybe)) continue;
+          seen += cs;
+        }
+        if (!__any(maybe)) continue;
       }
+      // the four rows' keys and verdicts first, without a ballot: in the heavy phase of a mass event every load passes the tier test above and
+      // nearly none holds a candidate once the thresholds stand — one ballot then dismisses the load (it was two per row)
+      uint32_t key4[4]; bool qual4[4]; bool anyq = false;
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
-        const bool q = (e & QE_QUEUED) != 0;
-        const uint32_t key = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)), rk = (key >> 22) & 3u;
-        const bool qual = q && key < (rk == 0 ? thr.t0 : rk == 1 ? thr.t1 : thr.t2);
-        if (count_seen) seen += (uint32_t)__popcll(__ballot(q));
-        const uint64_t mm = __ballot(qual);
+        key4[j] = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e));
+        const uint32_t rk = (key4[j] >> 22) & 3u;
+        qual4[j] = (e & QE_QUEUED) && key4[j] < (rk == 0 ? thr.t0 : rk == 1 ? thr.t1 : thr.t2);
+        anyq |= qual4[j];
+      }
+      if (!__any(anyq)) continue;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {               // (a compaction in between tightens the thresholds; the verdicts taken before it admit a superset)
+        const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
+        const uint64_t mm = __ballot(qual4[j]);
         if (mm) {
-          if (qual) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
+          if (qual4[j]) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key4[j] << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
           n += (uint32_t)__popcll(mm);
           if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
         }
