@@ -4392,20 +4392,34 @@ __device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type,
   return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
 }
 __device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1ull; }
-// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave (each pair belongs to the lane that holds its lower index)
-__device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
+// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave.  A stage's pairs are disjoint, so a lane reads ALL its pairs
+// (P / 128 of them) before it writes any: one LDS round trip per stage instead of one per pair (the loop form was latency bound: 53 k cycles per
+// sort of 512, a third of a node's time — profiles/r06_iq_phase_clock_v4.txt).
+template <uint32_t P>
+__device__ __forceinline__ void iq_sort_p(lds_u64* pool) {
   const uint32_t lane = sw_lane();
+  constexpr uint32_t Q = P >= 128 ? P / 128 : 1;
+#pragma unroll 1
   for (uint32_t k = 2; k <= P; k <<= 1)
+#pragma unroll 1
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t p = lane; p < P / 2; p += 64) {               // pair p: every lane compares, none idles on the upper index of a pair
-        const uint32_t idx = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)), ixj = idx | j;
-        const unsigned long long a = pool[idx], b = pool[ixj];
-        if ((a > b) == ((idx & k) == 0)) { pool[idx] = b; pool[ixj] = a; }
+      unsigned long long a[Q], b[Q]; uint32_t ia[Q], ib[Q];
+#pragma unroll
+      for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t p = lane + 64u * q;             // pair p (P = 64: the upper half of the wave has none)
+        ia[q] = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)); ib[q] = ia[q] | j;
+        if (p < P / 2) { a[q] = pool[ia[q]]; b[q] = pool[ib[q]]; }
       }
+#pragma unroll
+      for (uint32_t q = 0; q < Q; q++)
+        if (lane + 64u * q < P / 2 && (a[q] > b[q]) == ((ia[q] & k) == 0)) { pool[ia[q]] = b[q]; pool[ib[q]] = a[q]; }
       wave_lds_sync();
     }
 }
-__device__ __forceinline__ void iq_resort(lds_u64* pool, uint32_t n) {
+__device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
+  if (P <= 64) iq_sort_p<64>(pool); else if (P <= 128) iq_sort_p<128>(pool); else if (P <= 256) iq_sort_p<256>(pool); else iq_sort_p<512>(pool);
+}
+__device__ __attribute__((noinline)) void iq_resort(lds_u64* pool, uint32_t n) {
   uint32_t P = 64; while (P < n) P <<= 1;
   for (uint32_t idx = n + sw_lane(); idx < P; idx += 64) pool[idx] = ~0ull;
   wave_lds_sync();
