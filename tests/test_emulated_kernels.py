@@ -129,25 +129,25 @@ def test_unbounded_queue_implied_by_the_pair_store(emu, oracle, monkeypatch):
     (own rows of 256 messages, so that the state exchanges borrow big rows).  The GPU suite runs these and more: tests/test_unbounded_queue_gpu.py."""
     monkeypatch.setenv("SWIMSIM_INBOX_POOL_C1", "256")
     uq = abi.F_DEFAULT | abi.F_UNBOUNDED_QUEUE
-    n, nv = 1024, 120
+    n, nv = 512, 60
     victims = np.random.default_rng(8).choice(n, size=nv, replace=False).tolist()
     a, b = pair(emu, oracle, emu_kw=dict(view_cap=8, mass_rows=nv + 8), oracle_kw=dict(view_cap=nv + 64), n_nodes=n, seed=8, queue_cap=8,
                 inbox_cap=2 * nv + 300, subject_cap=4, flags=uq)
     for s in (a, b):
         s.step_ms(1000); s.kill(0, victims)
-    for sec in range(0, 34, 2):
-        a.step_ms(2000); b.step_ms(2000)
-        assert_same(a, b, f"t={sec + 3}s")
+    for sec in range(0, 28, 4):
+        a.step_ms(4000); b.step_ms(4000)
+        assert_same(a, b, f"t={sec + 5}s")
         assert a.detection(0) == b.detection(0)
     pairs, by = a.detection(0)
     assert pairs == (n - nv) * nv and by[2] + by[3] == pairs and a.stats()["queue_drops"] == 0
     qa, qb = a.node_info(0, 1), b.node_info(0, 1)
     assert qa.queue_len == qb.queue_len and [(e.subject, e.seq, e.transmits) for e in qa.queue] == [(e.subject, e.seq, e.transmits) for e in qb.queue]
-    n = 512
+    n = 256
     kw = dict(n_nodes=n, seed=13, queue_cap=8, event_queue_cap=16, event_ids_per_ltime=62, inbox_cap=2048, subject_cap=4, fold_interval_ms=5000,
               flags=uq | abi.F_SERF_EVENTS, watch_node=0)
     a, b = pair(emu, oracle, emu_kw=dict(mass_rows=n, view_cap=4), oracle_kw=dict(view_cap=n), **kw)
-    assert sc.run_churn_events(a, n, 12, events_per_s=6, checkpoints=(4, 8, 12)) == sc.run_churn_events(b, n, 12, events_per_s=6, checkpoints=(4, 8, 12))
+    assert sc.run_churn_events(a, n, 10, events_per_s=6, checkpoints=(5, 10)) == sc.run_churn_events(b, n, 10, events_per_s=6, checkpoints=(5, 10))
 
 
 def test_serf_events_intents_and_membership(emu, oracle):
