@@ -62,6 +62,7 @@ def draw_case(rng):
     return which, shards, kw
 
 
+UNBOUNDED = False
 HIP_ONLY = {}    # per case: configuration of the product library alone (the checker ignores / has no such field)
 
 
@@ -130,6 +131,11 @@ def diagnose(k, lib, ora, seed):
     rng = np.random.default_rng([seed, k])
     which, shards, kw = draw_case(rng)
     n, reps = kw["n_nodes"], kw["n_replicas"]
+    if UNBOUNDED:   # --unbounded (round 6): memberlist's unbounded queue — on the product library implied by the pair store, so every case gets rows
+        kw["flags"] |= abi.F_UNBOUNDED_QUEUE
+        kw["gossip_nodes"] = min(kw["gossip_nodes"], 4); kw["suspicion_mult"] = min(kw["suspicion_mult"], 4); kw["queue_cap"] = 32
+        kw["view_cap"] = min(n, 1024)                      # (tables that never fill)
+        HIP_ONLY["mass_rows"] = min(n, int(rng.choice([16, 256, 4096])))
     a = (ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
          if shards > 1 else Sim(lib, preset(lib, which, **kw, **HIP_ONLY)))
     b = Sim(ora, preset(ora, which, **kw))
@@ -183,6 +189,11 @@ def run_case(k, lib, ora, seed, verbose):
     rng = np.random.default_rng([seed, k])
     which, shards, kw = draw_case(rng)
     n, reps = kw["n_nodes"], kw["n_replicas"]
+    if UNBOUNDED:   # --unbounded (round 6): memberlist's unbounded queue — on the product library implied by the pair store, so every case gets rows
+        kw["flags"] |= abi.F_UNBOUNDED_QUEUE
+        kw["gossip_nodes"] = min(kw["gossip_nodes"], 4); kw["suspicion_mult"] = min(kw["suspicion_mult"], 4); kw["queue_cap"] = 32
+        kw["view_cap"] = min(n, 1024)                      # (tables that never fill)
+        HIP_ONLY["mass_rows"] = min(n, int(rng.choice([16, 256, 4096])))
     try:
         if shards > 1:
             a = ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
@@ -212,6 +223,10 @@ def run_case(k, lib, ora, seed, verbose):
             same, what = bridge_poll_equal((a, b)) if shards == 1 else (True, None)
             if not same:
                 bad.append(f"transport_poll {what}")
+            if UNBOUNDED and sa["queue_drops"] and not sb["queue_drops"]:
+                # the flag's documented limit on the device: rumours about subjects WITHOUT a row use the queue_cap slots and can be pruned there (counted)
+                if verbose: print(f"case {k}: the slots overflowed on the device ({sa['queue_drops']} drops, subjects without a row) after {ticks} ticks: not comparable from here")
+                return "slots"
             if da != db or bad:
                 print(f"case {k}: MISMATCH after {ticks} ticks: digest {'differs' if da != db else 'ok'}, stats {bad}\n   preset {which} shards {shards} {kw}")
                 return "mismatch"
@@ -231,7 +246,10 @@ def main():
     ap.add_argument("--backend", default="hip"); ap.add_argument("-v", action="store_true")
     ap.add_argument("--diagnose", type=int, default=3, help="replay this many mismatching cases tick by tick")
     ap.add_argument("--only", default="", help="comma separated case numbers")
+    ap.add_argument("--unbounded", action="store_true", help="every case with SWIM_F_UNBOUNDED_QUEUE (and rows of the pair store on the product library)")
     args = ap.parse_args()
+    global UNBOUNDED
+    UNBOUNDED = args.unbounded
     ora = abi.bind(C.CDLL(os.environ.get("SWIMSIM_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))   # (the ASan build: tools/oracle_asan.sh)
     if args.backend == "hip":
         from consul_amd import lib as L
