@@ -777,6 +777,7 @@ static void launch_begin(swim_sim* s, uint32_t tick) {
     hipLaunchKernelGGL(k_fold_scan, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.M) hipLaunchKernelGGL(k_fold_scan_mass, dim3(D.R * D.M), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     if (D.iq) hipLaunchKernelGGL(k_fold_scan_iq, dim3(D.R * D.MB), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
+    if (D.iq) hipLaunchKernelGGL(k_fold_scan_slots, dim3(cdiv(NL, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
     hipLaunchKernelGGL(k_fold_emit, dim3(cdiv(NT, SW_BLOCK)), dim3(SW_BLOCK), 0, st, (const SwDev*)s->d_D);
   }
   // serf's reaper AFTER the fold's census, like the checker (swim_tick_begin: fold_census, then phase_reap): a member whose last observer erases it in

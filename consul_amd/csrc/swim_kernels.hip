@@ -5003,6 +5003,16 @@ __global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_iq(const SwDev* __restri
     if (row < D.M) { const uint32_t x = D.mrow_subj[(size_t)r * D.M + row]; if (x != NONE) D.fl_bad[(size_t)r * D.N + x] = 1; }
   }
 }
+// ... and the rumours in the nodes' queue_cap slots (a node's rumour about itself, rumours about subjects without a row) hold their subjects back
+// the same way: the checker's q_cnt counts every queued rumour, wherever the device keeps it (found by tools/fuzz_parity.py --unbounded: 7 of 200
+// cases folded a subject whose own refutation was still queued in its slots)
+__global__ void __launch_bounds__(SW_BLOCK) k_fold_scan_slots(const SwDev* __restrict__ Dp) {
+  SW_DEV_BIND
+  const size_t NL = (size_t)D.R * D.nloc, l = (size_t)blockIdx.x * SW_BLOCK + threadIdx.x;
+  if (l >= NL) return;
+  const uint32_t n = h_qlen(HDR(l).y), r = div_nloc(D, l);
+  for (uint32_t j = 0; j < n; j++) { const uint32_t x = QENT(j, l).x; if (x < D.N) D.fl_bad[(size_t)r * D.N + x] = 1; }
+}
 // pooled inbox rows (swim_device.h: inbox_big): every node with deferred arrivals gets a big row — one CAS winner per node allocates, the
 // others do nothing (no lane ever waits for another); the kernel boundary publishes the rows to k_inbox_file
 __global__ void __launch_bounds__(SW_BLOCK) k_inbox_claim(const SwDev* __restrict__ Dp) {
