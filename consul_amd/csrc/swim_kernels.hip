@@ -4392,29 +4392,64 @@ __device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type,
   return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
 }
 __device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1ull; }
-// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave.  A stage's pairs are disjoint, so a lane reads ALL its pairs
-// (P / 128 of them) before it writes any: one LDS round trip per stage instead of one per pair (the loop form was latency bound: 53 k cycles per
-// sort of 512, a third of a node's time — profiles/r06_iq_phase_clock_v4.txt).
+// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave.  A lane holds EIGHT entries in registers — the group
+// {g + i * s, i < 8} that three consecutive stages of the network (strides 4s, 2s, s) keep to themselves — and runs up to three stages on them
+// between one round of LDS reads and one of writes: 16 passes for 512 entries instead of 45 stages.  (History, profiles/r06_iq_phase_clock_v4.txt:
+// a stage per LDS round trip with a loop over the lane's pairs was latency bound, 53 k cycles per sort of 512; all of a lane's pairs read before any
+// was written: a third of a node's time still; the compactions are what is left of a node once the scan judges rows on their raw words.)
+// The stages of a level k (strides k/2 ... 1) are cut into passes from the top, so a group never crosses the level's direction bit except in
+// the opening pass, which runs the levels 2, 4 and 8 on eight neighbours at once; the direction is taken per pair from its first element.
+template <int JJ>
+__device__ __forceinline__ void iq_stage8(unsigned long long (&e)[8], uint32_t g, uint32_t s, uint32_t k) {
+#pragma unroll
+  for (uint32_t i = 0; i < 8; i++) {
+    if (i & (1u << JJ)) continue;
+    const bool asc = ((g + i * s) & k) == 0;
+    unsigned long long& x = e[i]; unsigned long long& y = e[i | (1u << JJ)];
+    const bool sw = (x > y) == asc;
+    const unsigned long long lo = sw ? y : x, hi = sw ? x : y;
+    x = lo; y = hi;
+  }
+}
 template <uint32_t P>
 __device__ __forceinline__ void iq_sort_p(lds_u64* pool) {
-  const uint32_t lane = sw_lane();
-  constexpr uint32_t Q = P >= 128 ? P / 128 : 1;
-#pragma unroll 1
-  for (uint32_t k = 2; k <= P; k <<= 1)
-#pragma unroll 1
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      unsigned long long a[Q], b[Q]; uint32_t ia[Q], ib[Q];
+  const uint32_t t = sw_lane();
+  const bool on = P >= 512 || t < P / 8;
+  {   // levels 2, 4, 8: eight neighbours
+    const uint32_t g = t * 8u;
+    if (on) {
+      unsigned long long e[8];
 #pragma unroll
-      for (uint32_t q = 0; q < Q; q++) {
-        const uint32_t p = lane + 64u * q;             // pair p (P = 64: the upper half of the wave has none)
-        ia[q] = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)); ib[q] = ia[q] | j;
-        if (p < P / 2) { a[q] = pool[ia[q]]; b[q] = pool[ib[q]]; }
-      }
+      for (uint32_t i = 0; i < 8; i++) e[i] = pool[g + i];
+      iq_stage8<0>(e, g, 1, 2);
+      iq_stage8<1>(e, g, 1, 4); iq_stage8<0>(e, g, 1, 4);
+      iq_stage8<2>(e, g, 1, 8); iq_stage8<1>(e, g, 1, 8); iq_stage8<0>(e, g, 1, 8);
 #pragma unroll
-      for (uint32_t q = 0; q < Q; q++)
-        if (lane + 64u * q < P / 2 && (a[q] > b[q]) == ((ia[q] & k) == 0)) { pool[ia[q]] = b[q]; pool[ib[q]] = a[q]; }
-      wave_lds_sync();
+      for (uint32_t i = 0; i < 8; i++) pool[g + i] = e[i];
     }
+    wave_lds_sync();
+  }
+#pragma unroll 1
+  for (uint32_t lk = 4; (1u << lk) <= P; lk++) {
+    const uint32_t k = 1u << lk;
+#pragma unroll 1
+    for (uint32_t left = lk; left > 0; ) {                  // stages of this level still to run: strides 2^(left-1) ... 1
+      const uint32_t nst = left < 3 ? left : 3, ls = left - nst, s = 1u << ls;     // this pass: strides s << (nst-1) ... s
+      const uint32_t g = ((t >> ls) << (ls + 3)) | (t & (s - 1u));
+      if (on) {
+        unsigned long long e[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) e[i] = pool[g + i * s];
+        if (nst >= 3) iq_stage8<2>(e, g, s, k);
+        if (nst >= 2) iq_stage8<1>(e, g, s, k);
+        iq_stage8<0>(e, g, s, k);
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) pool[g + i * s] = e[i];
+      }
+      wave_lds_sync();
+      left = ls;
+    }
+  }
 }
 __device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
   if (P <= 64) iq_sort_p<64>(pool); else if (P <= 128) iq_sort_p<128>(pool); else if (P <= 256) iq_sort_p<256>(pool); else iq_sort_p<512>(pool);
@@ -4454,10 +4489,23 @@ __device__ __forceinline__ uint32_t iq_compact(DevRef D, lds_u64* pool, uint32_t
   }
   return m;                                                         // (the survivors are in order already: a stable compaction of a sorted pool)
 }
+// a rank's threshold (a key: transmits << 24 | rank << 22 | ~sequence; 0xFFFFFFFF while none stands) as a limit on the raw queue word with its
+// sequence flipped and its type masked (transmits << 26 | ~sequence): key < threshold <=> raw < limit for a word of that rank; 0x80000000 admits every
+// queued word
+__device__ __forceinline__ uint32_t iq_raw_limit(uint32_t thr) {
+  return thr == 0xFFFFFFFFu ? 0x80000000u : (((thr >> 24) & 31u) << 26) | (thr & 0x3FFFFFu);
+}
 // the candidates of node (r, local k, lane l): its slots' entries and what its column implies; sorted on return
 __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
   uint32_t n = 0; IqThr thr = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
+  const bool rl12 = sel4(D.len_rank, 1u) == sel4(D.len_rank, 2u);
+  uint32_t rl0 = 0x80000000u, rl1 = 0x80000000u, rl2 = 0x80000000u, rl3 = 0x80000000u;       // the types' raw limits (below); wave-uniform, renewed by a compaction
+#define IQ_RAW_LIMITS() do { \
+    rl0 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 0u) == 0 ? thr.t0 : sel4(D.len_rank, 0u) == 1 ? thr.t1 : thr.t2)); \
+    rl1 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 1u) == 0 ? thr.t0 : sel4(D.len_rank, 1u) == 1 ? thr.t1 : thr.t2)); \
+    rl2 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 2u) == 0 ? thr.t0 : sel4(D.len_rank, 2u) == 1 ? thr.t1 : thr.t2)); \
+    rl3 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 3u) == 0 ? thr.t0 : sel4(D.len_rank, 3u) == 1 ? thr.t1 : thr.t2)); } while (0)
   {
     const bool have = lane < qlen;
     const uint32_t w = have ? QENT(lane, l).w : 0u;
@@ -4487,32 +4535,40 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
 #pragma unroll
     for (uint32_t u = 0; u < 8; u++) {
       if (rb0 + u >= D.MB) continue;
-      {
-        // a queued rumour in a tier above every rank's threshold cannot qualify: once the thresholds stand that is nearly all of a long queue,
-        // and the four rows of a load are judged with one ballot
-        const uint32_t tmax = ((thr.t0 > thr.t1 ? thr.t0 : thr.t1) > thr.t2 ? (thr.t0 > thr.t1 ? thr.t0 : thr.t1) : thr.t2) >> 24;
-        const uint32_t lim = QE_QUEUED | ((tmax < 31u ? tmax : 31u) << 26) | 0x03FFFFFFu;      // queued words above it: a higher tier
-        const bool maybe = ((ew[u].x & QE_QUEUED) && ew[u].x <= lim) || ((ew[u].y & QE_QUEUED) && ew[u].y <= lim) ||
-                           ((ew[u].z & QE_QUEUED) && ew[u].z <= lim) || ((ew[u].w & QE_QUEUED) && ew[u].w <= lim);
-        if (count_seen) {                            // (short queues: how many queued words this load held — one reduction, not a ballot per row)
-          uint32_t cs = ((ew[u].x >> 31) + (ew[u].y >> 31)) + ((ew[u].z >> 31) + (ew[u].w >> 31));
-          for (int off = 32; off; off >>= 1) cs += __shfl_xor(cs, off);
-          seen += cs;
-        }
-        if (!__any(maybe)) continue;
+      if (count_seen) {                              // (short queues: how many queued words this load held — one reduction, not a ballot per row)
+        uint32_t cs = ((ew[u].x >> 31) + (ew[u].y >> 31)) + ((ew[u].z >> 31) + (ew[u].w >> 31));
+        for (int off = 32; off; off >>= 1) cs += __shfl_xor(cs, off);
+        seen += cs;
       }
-      // the four rows' keys and verdicts first, without a ballot: in the heavy phase of a mass event every load passes the tier test above and
-      // nearly none holds a candidate once the thresholds stand — one ballot then dismisses the load (it was two per row)
-      uint32_t key4[4]; bool qual4[4]; bool anyq = false;
+      // The four rows' verdicts on the RAW queue words, without building a key: within a type the order (transmits asc, sequence desc) is the order
+      // of (transmits << 26 | ~sequence) — the word with its sequence bits flipped and its type bits masked — and a type's length rank is fixed, so
+      // each type has one raw limit (wave-uniform, from its rank's threshold); flipping bit 31 as well puts every word that is not queued above any
+      // limit.  Three operations and a three-way select per row; the key (with its length-rank look-up) is built for the rare row that qualifies.
+      // In the heavy phase of a mass event nearly no load holds a candidate once the thresholds stand: one ballot dismisses the load.
+      bool qual4[4]; bool anyq = false;
+      if (rl12) {                                      // suspect and dead messages are equally long (every preset): one select per row.  (Type 3, a user
+#pragma unroll                                         //  event, never sits in a pair: serf's events have their own queue.)
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
+          qual4[j] = ((e ^ 0x803FFFFFu) & 0xFC3FFFFFu) < ((e & (3u << 24)) ? rl1 : rl0);
+          anyq |= qual4[j];
+        }
+      } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
+          const uint32_t lo = (e & (1u << 24)) ? rl1 : rl0, hi = (e & (1u << 24)) ? rl3 : rl2;      // (selects on the type's two bits: an equality chain became branches)
+          qual4[j] = ((e ^ 0x803FFFFFu) & 0xFC3FFFFFu) < ((e & (1u << 25)) ? hi : lo);
+          anyq |= qual4[j];
+        }
+      }
+      if (!__any(anyq)) continue;
+      uint32_t key4[4];
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
         key4[j] = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e));
-        const uint32_t rk = (key4[j] >> 22) & 3u;
-        qual4[j] = (e & QE_QUEUED) && key4[j] < (rk == 0 ? thr.t0 : rk == 1 ? thr.t1 : thr.t2);
-        anyq |= qual4[j];
       }
-      if (!__any(anyq)) continue;
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {               // (a compaction in between tightens the thresholds; the verdicts taken before it admit a superset)
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
@@ -4520,13 +4576,14 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
         if (mm) {
           if (qual4[j]) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key4[j] << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
           n += (uint32_t)__popcll(mm);
-          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr); IQ_RAW_LIMITS(); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
         }
       }
     }
   }
   wave_lds_sync();
   { const unsigned long long tc_ = IQCLK_T(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+#undef IQ_RAW_LIMITS
   return n;
 }
 // one GetBroadcasts(2, limit) over the sorted candidates, W.taken[0, returned) = what it took, in the order it took them.  The walk is

@@ -231,3 +231,22 @@ def test_transport_bridge_with_an_implied_queue(hip, oracle):
         r["digest"] = s.digest(); r["detection"] = s.detection(0); r["inc200"] = s.node_info(0, 200).incarnation
         out.append(r)
     assert out[0]["heard"] and out[0] == out[1]
+
+
+def test_randomised_cases_with_the_unbounded_queue(hip, oracle):
+    """A fixed slice of `tools/fuzz_parity.py --unbounded` (random configurations, every one with the flag and rows of the pair store on the product
+    library).  The seven of seed 606 are the cases that DIFFERED before `k_fold_scan_slots` (folds / fold_freed: the fold rule must also see the
+    rumours in the nodes' own slots, profiles/r06_fuzz_unbounded.txt); a case may end early as "slots" — a rumour about a subject without a row was
+    pruned from the device's queue_cap slots, counted, the flag's documented limit — but none may differ."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity_uq", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    fz.UNBOUNDED = True
+    tally = {}
+    for seed, cases in ((606, [25, 50, 51, 61, 88, 98, 191]), (2024, list(range(24)))):
+        for k in cases:
+            res = fz.run_case(k, hip, oracle, seed, False)
+            tally[res] = tally.get(res, 0) + 1
+    assert set(tally) <= {"ok", "slots", "refused"} and tally.get("ok", 0) >= 12, tally

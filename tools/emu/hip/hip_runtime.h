@@ -105,6 +105,7 @@ static inline void __builtin_amdgcn_wave_barrier_emu(EMU_HERE) { emu::park_colle
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 static inline unsigned long long __builtin_amdgcn_s_memtime_emu() { return (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count(); }
 #define __builtin_amdgcn_s_memtime() __builtin_amdgcn_s_memtime_emu()
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* (only ever applied to wave-uniform values: a hint that keeps them in scalar registers) */
 __attribute__((convergent)) static inline void __syncthreads() { emu::park_barrier(0); }
 __attribute__((convergent)) static inline int __syncthreads_or(int p) { return emu::park_barrier(p != 0); }
 static inline void __threadfence() {}
