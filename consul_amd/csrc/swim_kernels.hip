@@ -4399,6 +4399,29 @@ __device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1
 // was written: a third of a node's time still; the compactions are what is left of a node once the scan judges rows on their raw words.)
 // The stages of a level k (strides k/2 ... 1) are cut into passes from the top, so a group never crosses the level's direction bit except in
 // the opening pass, which runs the levels 2, 4 and 8 on eight neighbours at once; the direction is taken per pair from its first element.
+// (a) a stage per LDS round trip, all 64 lanes on a pair each: the pools of up to 256 entries — the re-sorts after a packet's bumps
+template <uint32_t P>
+__device__ __forceinline__ void iq_sort_s(lds_u64* pool) {
+  const uint32_t lane = sw_lane();
+  constexpr uint32_t Q = P >= 128 ? P / 128 : 1;
+#pragma unroll 1
+  for (uint32_t k = 2; k <= P; k <<= 1)
+#pragma unroll 1
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long a[Q], b[Q]; uint32_t ia[Q], ib[Q];
+#pragma unroll
+      for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t p = lane + 64u * q;             // pair p (P = 64: the upper half of the wave has none)
+        ia[q] = ((p & ~(j - 1u)) << 1) | (p & (j - 1u)); ib[q] = ia[q] | j;
+        if (p < P / 2) { a[q] = pool[ia[q]]; b[q] = pool[ib[q]]; }
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < Q; q++)
+        if (lane + 64u * q < P / 2 && (a[q] > b[q]) == ((ia[q] & k) == 0)) { pool[ia[q]] = b[q]; pool[ib[q]] = a[q]; }
+      wave_lds_sync();
+    }
+}
+// (b) eight entries per lane in registers: the full pool's compactions (with fewer entries most lanes would idle: measured slower there)
 template <int JJ>
 __device__ __forceinline__ void iq_stage8(unsigned long long (&e)[8], uint32_t g, uint32_t s, uint32_t k) {
 #pragma unroll
@@ -4452,7 +4475,7 @@ __device__ __forceinline__ void iq_sort_p(lds_u64* pool) {
   }
 }
 __device__ __forceinline__ void iq_sort(lds_u64* pool, uint32_t P) {
-  if (P <= 64) iq_sort_p<64>(pool); else if (P <= 128) iq_sort_p<128>(pool); else if (P <= 256) iq_sort_p<256>(pool); else iq_sort_p<512>(pool);
+  if (P <= 64) iq_sort_s<64>(pool); else if (P <= 128) iq_sort_s<128>(pool); else if (P <= 256) iq_sort_s<256>(pool); else iq_sort_p<512>(pool);
 }
 __device__ __attribute__((noinline)) void iq_resort(lds_u64* pool, uint32_t n) {
   uint32_t P = 64; while (P < n) P <<= 1;
@@ -4460,34 +4483,59 @@ __device__ __attribute__((noinline)) void iq_resort(lds_u64* pool, uint32_t n) {
   wave_lds_sync();
   iq_sort(pool, P);
 }
-// sort the pool and keep, per length rank, the keep[rank] x npk entries that sort first; thr[rank] = the key from which on nothing of that
-// rank needs to be looked at any more (0xFFFFFFFF while fewer are known)
-__device__ __forceinline__ uint32_t iq_compact(DevRef D, lds_u64* pool, uint32_t n, uint32_t npk, IqThr& thr) {
-  iq_resort(pool, n);
-  const uint64_t lt = iq_ltmask();
-  uint32_t base0 = 0, base1 = 0, base2 = 0, m = 0;
-  const uint32_t K0 = D.iq_keep[0] * npk, K1 = D.iq_keep[1] * npk, K2 = D.iq_keep[2] * npk;
-  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-    const uint32_t idx = c0 + sw_lane();
-    const bool valid = idx < n;
-    const unsigned long long e = valid ? pool[idx] : ~0ull;
-    const uint32_t key = (uint32_t)(e >> 32), rk = (key >> 22) & 3u;
-    const uint64_t m0 = __ballot(valid && rk == 0), m1 = __ballot(valid && rk == 1), m2 = __ballot(valid && rk >= 2);
-    const uint32_t pos = rk == 0 ? base0 + (uint32_t)__popcll(m0 & lt) : rk == 1 ? base1 + (uint32_t)__popcll(m1 & lt) : base2 + (uint32_t)__popcll(m2 & lt);
-    const uint32_t K = rk == 0 ? K0 : rk == 1 ? K1 : K2;
-    const bool keep = valid && pos < K;
-    const uint64_t ml = __ballot(valid && pos + 1 == K);           // the last one kept of a rank: the rank's threshold from now on
-    for (uint64_t q = ml; q; q &= q - 1) {
-      const uint32_t src = (uint32_t)__ffsll((long long)q) - 1, k2 = __shfl(key, src), r2 = (k2 >> 22) & 3u;
-      if (r2 == 0) thr.t0 = k2; else if (r2 == 1) thr.t1 = k2; else thr.t2 = k2;
-    }
-    const uint64_t mk = __ballot(keep);
-    if (keep) pool[m + (uint32_t)__popcll(mk & lt)] = e;          // (forward compaction: never past the lane's own index, and this chunk has been read)
-    m += (uint32_t)__popcll(mk);
-    base0 += (uint32_t)__popcll(m0); base1 += (uint32_t)__popcll(m1); base2 += (uint32_t)__popcll(m2);
-    wave_lds_sync();
+// Keep, per length rank, the keep[rank] x npk entries that sort first; thr[rank] = the key from which on nothing of that rank needs to be looked at
+// any more (0xFFFFFFFF while fewer are known).  A SELECTION, not a sort (until call 25 of round 6 every compaction sorted the pool: ~1 900 vector
+// instructions each, 40 % of what k_gossip_iq issues, and the kernel is issue bound — profiles/r06_iq_issue_bound.txt): a lane takes eight entries
+// into registers, and the K-th smallest key of a rank is found bit by bit from the top — "how many keys of the rank are <= this prefix, ones below"
+// is eight compares whose ballots the scalar unit counts — 29 steps, no LDS traffic.  The survivors go back unordered; only the LAST compaction of
+// a scan sorts what is left (<= keep x packets per rank: a sort of 128 or 256, not of 512).  Keys are unique within a node (the sequence number), so
+// "key <= K-th smallest" keeps exactly K.
+__device__ __forceinline__ uint32_t iq_compact(DevRef D, lds_u64* pool, uint32_t n, uint32_t npk, IqThr& thr, bool last) {
+  const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
+  unsigned long long e[8]; uint32_t key[8], rk[8];
+#pragma unroll
+  for (uint32_t i = 0; i < 8; i++) {
+    const uint32_t idx = lane + 64u * i;
+    e[i] = idx < n ? pool[idx] : ~0ull;
+    key[i] = (uint32_t)(e[i] >> 32);
+    rk[i] = idx < n ? ((key[i] >> 22) & 3u) : 4u;                 // (4: no entry)
+    if (rk[i] == 3u) rk[i] = 2u;
   }
-  return m;                                                         // (the survivors are in order already: a stable compaction of a sorted pool)
+  wave_lds_sync();                                                  // (every entry is in a register before any goes back)
+  uint32_t lim0 = 0, lim1 = 0, lim2 = 0; bool all0 = false, all1 = false, all2 = false, none0 = false, none1 = false, none2 = false;
+#pragma unroll 1
+  for (uint32_t r = 0; r < 3; r++) {
+    const uint32_t K = sel4(D.iq_keep, r) * npk;
+    uint32_t kr[8], cnt = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) { kr[i] = rk[i] == r ? key[i] : 0xFFFFFFFFu; cnt += (uint32_t)__popcll(__ballot(rk[i] == r)); }
+    bool all = false, none = false; uint32_t T = 0;
+    if (K == 0) none = true;
+    else if (cnt < K) all = true;
+    else {                                                          // the K-th smallest key of the rank (keys are below 2^29: five bits of transmits on top)
+#pragma unroll 1
+      for (int b = 28; b >= 0; b--) {
+        const uint32_t cand = T | ((1u << b) - 1u);
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) c += (uint32_t)__popcll(__ballot(kr[i] <= cand));
+        if (c < K) T |= 1u << b;
+      }
+      if (r == 0) thr.t0 = T; else if (r == 1) thr.t1 = T; else thr.t2 = T;
+    }
+    if (r == 0) { lim0 = T; all0 = all; none0 = none; } else if (r == 1) { lim1 = T; all1 = all; none1 = none; } else { lim2 = T; all2 = all; none2 = none; }
+  }
+  uint32_t m = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; i++) {
+    const bool keep = rk[i] == 0 ? (!none0 && (all0 || key[i] <= lim0)) : rk[i] == 1 ? (!none1 && (all1 || key[i] <= lim1)) : rk[i] == 2 ? (!none2 && (all2 || key[i] <= lim2)) : false;
+    const uint64_t mk = __ballot(keep);
+    if (keep) pool[m + (uint32_t)__popcll(mk & lt)] = e[i];
+    m += (uint32_t)__popcll(mk);
+  }
+  wave_lds_sync();
+  if (last) iq_resort(pool, m);
+  return m;
 }
 // a rank's threshold (a key: transmits << 24 | rank << 22 | ~sequence; 0xFFFFFFFF while none stands) as a limit on the raw queue word with its
 // sequence flipped and its type masked (transmits << 26 | ~sequence): key < threshold <=> raw < limit for a word of that rank; 0x80000000 admits every
@@ -4495,17 +4543,27 @@ __device__ __forceinline__ uint32_t iq_compact(DevRef D, lds_u64* pool, uint32_t
 __device__ __forceinline__ uint32_t iq_raw_limit(uint32_t thr) {
   return thr == 0xFFFFFFFFu ? 0x80000000u : (((thr >> 24) & 31u) << 26) | (thr & 0x3FFFFFu);
 }
+// iq_compact out of line, with the types' raw limits that follow from the new thresholds: iq_build calls it from 33 places (after any of a batch's
+// 32 row ballots), and inlined there the scan loop was 43 KB of code — more than the instruction cache two CUs share holds beside the rest of the kernel
+struct IqC { uint32_t n, t0, t1, t2, rl0, rl1, rl2, rl3; };
+__device__ __attribute__((noinline)) IqC iq_compact_nl(DevRef D, lds_u64* pool, uint32_t n, uint32_t npk, uint32_t t0, uint32_t t1, uint32_t t2, bool last) {
+  IqThr thr = { t0, t1, t2 };
+  IqC c; c.n = iq_compact(D, pool, n, npk, thr, last);
+  c.t0 = thr.t0; c.t1 = thr.t1; c.t2 = thr.t2;
+  c.rl0 = iq_raw_limit(sel4(D.len_rank, 0u) == 0 ? thr.t0 : sel4(D.len_rank, 0u) == 1 ? thr.t1 : thr.t2);
+  c.rl1 = iq_raw_limit(sel4(D.len_rank, 1u) == 0 ? thr.t0 : sel4(D.len_rank, 1u) == 1 ? thr.t1 : thr.t2);
+  c.rl2 = iq_raw_limit(sel4(D.len_rank, 2u) == 0 ? thr.t0 : sel4(D.len_rank, 2u) == 1 ? thr.t1 : thr.t2);
+  c.rl3 = iq_raw_limit(sel4(D.len_rank, 3u) == 0 ? thr.t0 : sel4(D.len_rank, 3u) == 1 ? thr.t1 : thr.t2);
+  return c;
+}
 // the candidates of node (r, local k, lane l): its slots' entries and what its column implies; sorted on return
 __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W, uint32_t r, uint32_t k, size_t l, size_t NL, uint32_t qlen, uint32_t iqn, uint32_t npk) {
   const uint32_t lane = sw_lane(); const uint64_t lt = iq_ltmask();
   uint32_t n = 0; IqThr thr = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
   const bool rl12 = sel4(D.len_rank, 1u) == sel4(D.len_rank, 2u);
   uint32_t rl0 = 0x80000000u, rl1 = 0x80000000u, rl2 = 0x80000000u, rl3 = 0x80000000u;       // the types' raw limits (below); wave-uniform, renewed by a compaction
-#define IQ_RAW_LIMITS() do { \
-    rl0 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 0u) == 0 ? thr.t0 : sel4(D.len_rank, 0u) == 1 ? thr.t1 : thr.t2)); \
-    rl1 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 1u) == 0 ? thr.t0 : sel4(D.len_rank, 1u) == 1 ? thr.t1 : thr.t2)); \
-    rl2 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 2u) == 0 ? thr.t0 : sel4(D.len_rank, 2u) == 1 ? thr.t1 : thr.t2)); \
-    rl3 = __builtin_amdgcn_readfirstlane(iq_raw_limit(sel4(D.len_rank, 3u) == 0 ? thr.t0 : sel4(D.len_rank, 3u) == 1 ? thr.t1 : thr.t2)); } while (0)
+#define IQ_COMPACT(last_) do { const IqC c_ = iq_compact_nl(D, W.pool, n, npk, thr.t0, thr.t1, thr.t2, last_); n = c_.n; thr.t0 = c_.t0; thr.t1 = c_.t1; thr.t2 = c_.t2; \
+    rl0 = __builtin_amdgcn_readfirstlane(c_.rl0); rl1 = __builtin_amdgcn_readfirstlane(c_.rl1); rl2 = __builtin_amdgcn_readfirstlane(c_.rl2); rl3 = __builtin_amdgcn_readfirstlane(c_.rl3); } while (0)
   {
     const bool have = lane < qlen;
     const uint32_t w = have ? QENT(lane, l).w : 0u;
@@ -4563,27 +4621,21 @@ __device__ __attribute__((noinline)) uint32_t iq_build(DevRef D, const IqWave W,
         }
       }
       if (!__any(anyq)) continue;
-      uint32_t key4[4];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
-        key4[j] = iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e));
-      }
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {               // (a compaction in between tightens the thresholds; the verdicts taken before it admit a superset)
         const uint32_t e = j == 0 ? ew[u].x : j == 1 ? ew[u].y : j == 2 ? ew[u].z : ew[u].w;
         const uint64_t mm = __ballot(qual4[j]);
         if (mm) {
-          if (qual4[j]) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)key4[j] << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
+          if (qual4[j]) W.pool[n + (uint32_t)__popcll(mm & lt)] = ((unsigned long long)iq_key(D, QE_TR(e), QE_TYPE(e), QE_SEQ(e)) << 32) | (QE_TYPE(e) << 28) | ((rb0 + u) * SW_IQ_RB + lane * 4u + j);
           n += (uint32_t)__popcll(mm);
-          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); n = iq_compact(D, W.pool, n, npk, thr); IQ_RAW_LIMITS(); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+          if (n + 64u > SW_IQ_POOL) { const unsigned long long tc_ = IQCLK_T(); wave_lds_sync(); IQ_COMPACT(false); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
         }
       }
     }
   }
   wave_lds_sync();
-  { const unsigned long long tc_ = IQCLK_T(); n = iq_compact(D, W.pool, n, npk, thr); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
-#undef IQ_RAW_LIMITS
+  { const unsigned long long tc_ = IQCLK_T(); IQ_COMPACT(true); IQCLK_ADD(1, IQCLK_T() - tc_); IQCLK_ADD(6, 1); }
+#undef IQ_COMPACT
   return n;
 }
 // one GetBroadcasts(2, limit) over the sorted candidates, W.taken[0, returned) = what it took, in the order it took them.  The walk is

@@ -20,7 +20,7 @@ for p in sorted(glob.glob(f"{root}/pass*/*/*_counter_collection.csv")):
         data[k][idx][r["Counter_Name"]] = data[k][idx].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         t = trace.get(did)
         if t: dur[k][idx] = (int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3
-for k in ("k_begin", "k_deliver", "k_resolve", "k_census"):
+for k in ("k_begin", "k_deliver", "k_resolve", "k_census", "k_gossip_iq", "k_piggy_iq"):
     if k not in data: continue
     idxs = sorted(data[k], key=lambda i: -dur[k].get(i, 0))[:top]
     print(f"== {k}: mean over the {len(idxs)} longest dispatches (profiled durations)")
