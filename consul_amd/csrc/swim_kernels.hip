@@ -5082,7 +5082,10 @@ __global__ void __launch_bounds__(SW_BLOCK) k_piggy_iq(const SwDev* __restrict__
         if (!(nq | ne | iq_j)) q_bit_lane(D, l, false, true);
       }
       wave_lds_sync();
-      __threadfence();                               // (the next batch reads the header and the slots this one wrote)
+      // the next batch of the SAME wave reads the header and the slots this one wrote — other lanes of it: a workgroup-scope fence, and only when there is
+      // a next batch (a node with more than four orders: rare).  (Until call 31 of round 6 a __threadfence() stood here, for every node: a device-scope
+      // release writes the L2's dirty lines back, and the kernel ran at the same 15 M nodes/s whatever its instruction count, occupancy or grid.)
+      if (o0 + SW_IQ_ORDERS < no) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
   }
   if (lane == 0) {
