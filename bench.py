@@ -47,7 +47,7 @@ from consul_amd import abi  # noqa: E402
 from consul_amd.sim import Sim, preset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILES = ("r05_pmc_driver.json", "r04_pmc_driver.json", "r03_pmc_driver.json")     # HBM bytes per launch, newest first (tools/pmc_traffic_pass.sh over the driver's window)
+PMC_FILES = ("r06_pmc_driver.json", "r05_pmc_driver.json", "r04_pmc_driver.json", "r03_pmc_driver.json")     # HBM bytes per launch, newest first (tools/pmc_traffic_pass.sh over the driver's window)
 
 
 def _pmc():
@@ -394,15 +394,17 @@ def run_config4(hip, args, device) -> dict:
             "kernel_ms_total": {k: round(v[1], 1) for k, v in prof.items() if v[0]}, "launches": int(g[0]),
             "k_gossip_iq": {"avg_launch_ms": g[1] / max(g[0], 1), "column_bytes_scanned_per_launch": scan_bytes,
                             "achieved_GBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6, "frac_of_8TBps": scan_bytes / max(g[1] / max(g[0], 1), 1e-9) / 1e6 / 8000.0,
-                            "bound": "hbm by design (4 bytes per pair and scan); measured: the wave's own instruction stream — the phase clock (profiles/r06_iq_phase_clock_v3.txt) has a "
-                                     "node at 88 % scan (a third of it the pool's bitonic compactions), 4 % waiting for the loads"},
+                            "bound": "hbm by design (4 bytes per pair and scan); measured: vector-ALU issue — SQ counters (profiles/r06_iq_issue_bound.txt, before the "
+                                     "selection): VALU instructions 62 % of the SIMDs' issue slots, all instruction types 113 %; since then the compactions are a selection "
+                                     "(not a sort) and a row is judged on its raw word in five instructions; the phase clock has a node at 60 % scan, 22 % compactions, 4 % "
+                                     "waiting for the loads"},
             "k_piggy_iq": {"avg_launch_ms": pg[1] / max(pg[0], 1)},
             "quoted_from_profiles": {"hbm_traffic": "profiles/r06_pmc_config4_262k.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; this shape at 262 144 nodes, the first 30 "
-                                                    "simulated seconds, per launch; not measured by this run): k_gossip_iq 5.33 GB fetched as counted (10.7 GB with the guide's x2 on FETCH_SIZE) + "
-                                                    "0.43 GB written against 6.6 GB of column scan — 0.8x / 1.6x the algorithmic bytes: nothing is re-read; k_piggy_iq 1.40 GB (2.8 GB) + 0.08 GB; "
-                                                    "k_resolve<MASS> 3.95 GB (7.9 GB) + 1.55 GB",
-                                     "kernel_trace": "profiles/r06_config4_262k_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command): k_resolve<MASS> 5.67 ms, k_gossip_iq 4.93 ms, "
-                                                     "k_piggy_iq 2.92 ms per launch in that phase"}}
+                                                    "simulated seconds, per launch; not measured by this run): k_gossip_iq 5.91 GB fetched as counted (11.8 GB with the guide's x2 on FETCH_SIZE) + "
+                                                    "1.60 GB written (1.2 GB of it the out-of-line selection's saved registers: scratch) against 6.6 GB of column scan — 0.9x / 1.8x the algorithmic "
+                                                    "bytes: nothing is re-read; k_piggy_iq 1.62 GB (3.2 GB) + 0.52 GB; k_resolve<MASS> 3.95 GB (7.9 GB) + 1.55 GB",
+                                     "kernel_trace": "profiles/r06_config4_262k_kernel_stats.csv (rocprofv3 --kernel-trace --stats, same command): k_resolve<MASS> 5.68 ms, k_gossip_iq 3.41 ms, "
+                                                     "k_piggy_iq 1.14 ms per launch in that phase (before the selection and without k_piggy_iq's device-scope fence: 4.93 and 2.92 ms)"}}
     s.close()
     return out
 
