@@ -4356,8 +4356,8 @@ __global__ void __launch_bounds__(SW_BLOCK) k_send_mass(const SwDev* __restrict_
 // reads the column's queue words coalesced (64 rows per load), keeps per length rank the candidates that can possibly be taken this tick
 // (a packet takes at most budget / (2 + len) rumours of a length, so `packets x that many` per rank bound what the greedy walk can reach:
 // an entry beyond them is preceded, in queue.go's order, by more entries of its own length than all the packets together can take or
-// bump), sorts them by (transmits asc, length desc, sequence desc) with a bitonic network in LDS, and then walks that order exactly as the
-// checker walks its sorted queue: take what fits, bump transmits after the sweep, retire at the retransmit limit.  The node's rumour about
+// bump: a selection of the K smallest keys per rank whenever the pool of candidates fills, iq_compact), sorts what is left at the end of the scan by
+// (transmits asc, length desc, sequence desc) with a bitonic network in LDS, and then walks that order exactly as the checker walks its sorted queue: take what fits, bump transmits after the sweep, retire at the retransmit limit.  The node's rumour about
 // ITSELF and rumours about subjects without a row sit in the queue_cap slots as before and take part in the same order.
 // =================================================================================================
 #ifdef SWIMSIM_DIAG
@@ -4392,14 +4392,16 @@ __device__ __forceinline__ uint32_t iq_key(DevRef D, uint32_t tr, uint32_t type,
   return (tr << 24) | (sel4(D.len_rank, type) << 22) | (0x3FFFFFu - (seq & 0x3FFFFFu));
 }
 __device__ __forceinline__ uint64_t iq_ltmask() { return (1ull << sw_lane()) - 1ull; }
-// bitonic sort of pool[0, P), P a power of two >= 64, ascending, by one wave.  A lane holds EIGHT entries in registers — the group
-// {g + i * s, i < 8} that three consecutive stages of the network (strides 4s, 2s, s) keep to themselves — and runs up to three stages on them
-// between one round of LDS reads and one of writes: 16 passes for 512 entries instead of 45 stages.  (History, profiles/r06_iq_phase_clock_v4.txt:
-// a stage per LDS round trip with a loop over the lane's pairs was latency bound, 53 k cycles per sort of 512; all of a lane's pairs read before any
-// was written: a third of a node's time still; the compactions are what is left of a node once the scan judges rows on their raw words.)
-// The stages of a level k (strides k/2 ... 1) are cut into passes from the top, so a group never crosses the level's direction bit except in
-// the opening pass, which runs the levels 2, 4 and 8 on eight neighbours at once; the direction is taken per pair from its first element.
-// (a) a stage per LDS round trip, all 64 lanes on a pair each: the pools of up to 256 entries — the re-sorts after a packet's bumps
+// Bitonic sorts of pool[0, P), P a power of two >= 64, ascending, by one wave — two forms:
+// (a) iq_sort_s: a stage per LDS round trip, all 64 lanes on a pair each (all of a lane's pairs read before any is written): the pools of up to 256
+//     entries — what a scan's last compaction leaves, the re-sorts after a packet's bumps;
+// (b) iq_sort_p: a lane holds EIGHT entries in registers — the group {g + i * s, i < 8} that three consecutive stages of the network (strides 4s, 2s, s)
+//     keep to themselves — and runs up to three stages on them between one round of LDS reads and one of writes: 16 passes for 512 entries instead of 45
+//     stages.  The stages of a level k (strides k/2 ... 1) are cut into passes from the top, so a group never crosses the level's direction bit except in
+//     the opening pass, which runs the levels 2, 4 and 8 on eight neighbours at once; the direction is taken per pair from its first element.  Only for a
+//     full pool: with fewer entries most lanes idle, and it was slower there (profiles/r06_iq_issue_bound.txt, v3 / v4).
+// (History, profiles/r06_iq_phase_clock_v4.txt: a stage per round trip with a loop over the lane's pairs was latency bound, 53 k cycles per sort of 512.
+//  Since call 26 of round 6 a full pool is no longer sorted at all — iq_compact selects.)
 template <uint32_t P>
 __device__ __forceinline__ void iq_sort_s(lds_u64* pool) {
   const uint32_t lane = sw_lane();
@@ -4421,7 +4423,6 @@ __device__ __forceinline__ void iq_sort_s(lds_u64* pool) {
       wave_lds_sync();
     }
 }
-// (b) eight entries per lane in registers: the full pool's compactions (with fewer entries most lanes would idle: measured slower there)
 template <int JJ>
 __device__ __forceinline__ void iq_stage8(unsigned long long (&e)[8], uint32_t g, uint32_t s, uint32_t k) {
 #pragma unroll
