@@ -250,3 +250,28 @@ def test_randomised_cases_with_the_unbounded_queue(hip, oracle):
             res = fz.run_case(k, hip, oracle, seed, False)
             tally[res] = tally.get(res, 0) + 1
     assert set(tally) <= {"ok", "slots", "refused"} and tally.get("ok", 0) >= 12, tally
+
+
+@pytest.mark.parametrize("lens,n,nv", [([100, 40, 24, 64], 1024, 200), ([48, 48, 48, 64], 1024, 200), ([40, 100, 100, 64], 1024, 200), ([30, 90, 60, 64], 1024, 200),
+                                       ([100, 40, 24, 64], 2048, 700), ([30, 90, 60, 64], 2048, 700)])
+def test_message_lengths_and_their_ranks(hip, oracle, lens, n, nv):
+    """queue.go orders a tier by message length (longer first): the device keeps a length RANK per type and per rank a keep count and a threshold.  The
+    presets have two ranks (alive longer than suspect = dead: the scan's one-select verdict); here three distinct lengths (three ranks, the per-type
+    verdict), one length for all (one rank), suspect = dead LONGER than alive, and dead between the two — a mass failure with refutations mixed in
+    (3 % loss), every queue compared with the checker's.  With 700 victims a node's queue outgrows the pool a wave holds while it scans: the selection
+    runs in mid-scan, with three thresholds standing."""
+    seed = 5
+    victims = np.random.default_rng(seed).choice(n, size=nv, replace=False)
+    a, b = pair(hip, oracle, dict(mass_rows=nv + 64, view_cap=64), dict(view_cap=nv + 128), n_nodes=n, seed=seed, queue_cap=32, inbox_cap=2 * nv + 512, subject_cap=8,
+                msg_len=lens, loss_q32=int(0.03 * 2**32), flags=UQ & ~abi.F_TCP_FALLBACK)
+    for s in (a, b):
+        s.step_ms(1000); s.kill(0, victims.tolist())
+    survivors = np.setdiff1d(np.arange(n), victims)
+    for sec in range(0, 30, 2):
+        a.step_ms(2000); b.step_ms(2000)
+        assert_same(a, b, [(0, int(victims[0])), (0, int(victims[1]))], tag=f"{lens} t={sec + 3}s")
+        o = int(survivors[(7 * sec) % len(survivors)])
+        qa, qb = queue_of(a, 0, o), queue_of(b, 0, o)
+        assert qa == qb, (lens, sec, o, qa, qb)
+    st = a.stats()
+    assert st["queue_drops"] == 0 and st["view_drops"] == 0 and st["msgs_sent"] == b.stats()["msgs_sent"]
