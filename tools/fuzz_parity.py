@@ -63,6 +63,7 @@ def draw_case(rng):
 
 
 UNBOUNDED = False
+LENS = False
 HIP_ONLY = {}    # per case: configuration of the product library alone (the checker ignores / has no such field)
 
 
@@ -136,6 +137,9 @@ def diagnose(k, lib, ora, seed):
         kw["gossip_nodes"] = min(kw["gossip_nodes"], 4); kw["suspicion_mult"] = min(kw["suspicion_mult"], 4); kw["queue_cap"] = 32
         kw["view_cap"] = min(n, 1024)                      # (tables that never fill)
         HIP_ONLY["mass_rows"] = min(n, int(rng.choice([16, 256, 4096])))
+    if LENS:        # --lens: message lengths drawn too (queue.go orders a tier by length: one, two or three ranks), from a stream of their own — the cases' other draws stay as pinned
+        lr = np.random.default_rng([seed, k, 7])
+        kw["msg_len"] = [int(x) for x in lr.choice([24, 32, 48, 64, 100, 128], size=3)] + [64]
     a = (ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
          if shards > 1 else Sim(lib, preset(lib, which, **kw, **HIP_ONLY)))
     b = Sim(ora, preset(ora, which, **kw))
@@ -194,6 +198,9 @@ def run_case(k, lib, ora, seed, verbose):
         kw["gossip_nodes"] = min(kw["gossip_nodes"], 4); kw["suspicion_mult"] = min(kw["suspicion_mult"], 4); kw["queue_cap"] = 32
         kw["view_cap"] = min(n, 1024)                      # (tables that never fill)
         HIP_ONLY["mass_rows"] = min(n, int(rng.choice([16, 256, 4096])))
+    if LENS:        # --lens: message lengths drawn too (queue.go orders a tier by length: one, two or three ranks), from a stream of their own — the cases' other draws stay as pinned
+        lr = np.random.default_rng([seed, k, 7])
+        kw["msg_len"] = [int(x) for x in lr.choice([24, 32, 48, 64, 100, 128], size=3)] + [64]
     try:
         if shards > 1:
             a = ShardedSim([Sim(lib, preset(lib, which, shard_rank=i, n_shards=shards, **kw, **HIP_ONLY)) for i in range(shards)], LocalExchange())
@@ -247,9 +254,10 @@ def main():
     ap.add_argument("--diagnose", type=int, default=3, help="replay this many mismatching cases tick by tick")
     ap.add_argument("--only", default="", help="comma separated case numbers")
     ap.add_argument("--unbounded", action="store_true", help="every case with SWIM_F_UNBOUNDED_QUEUE (and rows of the pair store on the product library)")
+    ap.add_argument("--lens", action="store_true", help="draw the three message lengths too (a stream of their own: the pinned cases keep their other draws)")
     args = ap.parse_args()
-    global UNBOUNDED
-    UNBOUNDED = args.unbounded
+    global UNBOUNDED, LENS
+    UNBOUNDED = args.unbounded; LENS = args.lens
     ora = abi.bind(C.CDLL(os.environ.get("SWIMSIM_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "libswim_oracle.so")))   # (the ASan build: tools/oracle_asan.sh)
     if args.backend == "hip":
         from consul_amd import lib as L
